@@ -1,0 +1,620 @@
+/*
+ * lsd_oracle.c -- CPU restatement of the LSD line detector as the reference reaches it.
+ * TEST INFRASTRUCTURE ONLY (same rules as orb_oracle.c).
+ *
+ * Reference entry: LineSegment::ExtractLineSegment, include/ExtractLineSegment.h:38 (body absent from
+ * /root/reference).  It calls cv::line_descriptor::LSDDetector::detect(img, lines,
+ * scale=int(1.2)=1, numOctaves=1), which runs cv::createLineSegmentDetector(LSD_REFINE_ADV)->detect
+ * on octave 0.  Neither OpenCV 3.3.x imgproc/lsd.cpp nor opencv_contrib line_descriptor is
+ * vendored, so this file restates their PUBLISHED algorithm (von Gioi et al., "LSD: a Line Segment
+ * Detector", IPOL 2012, as implemented in OpenCV 3.3) -- PARITY UNPINNED: no reference test, fixture
+ * or executable pins any number produced here.  Choices that differ between OpenCV versions are
+ * parameters with the 3.3 behaviour as default:
+ *   - the image is converted to double before the sigma=0.75 blur and the 0.8x INTER_LINEAR resize
+ *     (3.0-3.3: `img.convertTo(image, CV_64FC1)`), gradients in double;
+ *   - seeds are visited in RASTER order: 3.0-3.3 build the 1024-bin pseudo-ordering as a linked list
+ *     but iterate `list[i]` by index (seed_order=ORC_LSD_SEED_RASTER).  seed_order=ORC_LSD_SEED_BINNED
+ *     gives the published order (bins descending, raster inside a bin);
+ *   - `sumdx += cos(float(angle))` resolves to ::cos(double) under GCC 5.4 (no std::cos in scope).
+ * All arithmetic is double unless the upstream code says float; no FMA contraction (-ffp-contract=off).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+#define NOTDEF (-1024.0)
+#define NOTUSED 0
+#define USED 1
+#define M_3_2_PI (3 * 3.14159265358979323846 / 2)
+#define M_2__PI (2 * 3.14159265358979323846)
+#define CV_PI_ 3.1415926535897932384626433832795
+#define DEG_TO_RADS (CV_PI_ / 180)
+#define RELATIVE_ERROR_FACTOR 100.0
+
+typedef struct { int x, y; uint8_t *used; double angle, modgrad; } regpt;
+typedef struct { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; } rect_t;
+
+typedef struct {
+    int w, h;            /* scaled image size */
+    double *img;         /* scaled image */
+    double *angles, *modgrad;
+    uint8_t *used;
+    double LOG_NT;
+} lsd_t;
+
+static inline int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * (n - 1) - p; }
+    return p;
+}
+
+/* cv::getGaussianKernel(n, sigma, CV_64F) */
+void orc_gauss_kernel_f64(int n, double sigma, double *k)
+{
+    double scale2X = -0.5 / (sigma * sigma), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        k[i] = exp(scale2X * x * x);
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] *= sum;
+}
+
+/* GaussianBlur on CV_64F, separable, REFLECT_101: RowFilter then SymmColumnFilter (see header) */
+static void gaussian_blur_f64(const double *src, double *dst, int w, int h, const double *k, int ksize)
+{
+    const int r = ksize / 2;
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double s = k[0] * src[(size_t)y * w + reflect101(x - r, w)];
+            for (int t = 1; t < ksize; t++) s += k[t] * src[(size_t)y * w + reflect101(x - r + t, w)];
+            tmp[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double s = k[r] * tmp[(size_t)y * w + x] + 0.0;
+            for (int t = 1; t <= r; t++)
+                s += k[r + t] * (tmp[(size_t)reflect101(y + t, h) * w + x] + tmp[(size_t)reflect101(y - t, h) * w + x]);
+            dst[(size_t)y * w + x] = s;
+        }
+    free(tmp);
+}
+
+/* cv::resize(src64f, dst, Size(), fx, fy, INTER_LINEAR): float coefficients, double data */
+static void resize_linear_f64(const double *src, int sw, int sh, double *dst, int dw, int dh, double inv_scale_x,
+                              double inv_scale_y)
+{
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    int *xofs = (int *)malloc(sizeof(int) * dw);
+    float *alpha = (float *)malloc(sizeof(float) * 2 * dw);
+    double *r0 = (double *)malloc(sizeof(double) * dw), *r1 = (double *)malloc(sizeof(double) * dw);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) { if (dx < xmax) xmax = dx; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+        xofs[dx] = sx;
+        alpha[2 * dx] = 1.f - fx;
+        alpha[2 * dx + 1] = fx;
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        const double b0 = (double)(1.f - fy), b1 = (double)fy;
+        int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        const double *S0 = src + (size_t)y0 * sw, *S1 = src + (size_t)y1 * sw;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            if (dx < xmax) {
+                r0[dx] = S0[sx] * alpha[2 * dx] + S0[sx + 1] * alpha[2 * dx + 1];
+                r1[dx] = S1[sx] * alpha[2 * dx] + S1[sx + 1] * alpha[2 * dx + 1];
+            } else {
+                r0[dx] = S0[sx] * 1.0;
+                r1[dx] = S1[sx] * 1.0;
+            }
+        }
+        for (int dx = 0; dx < dw; dx++) dst[(size_t)dy * dw + dx] = r0[dx] * b0 + r1[dx] * b1;
+    }
+    free(xofs); free(alpha); free(r0); free(r1);
+}
+
+static inline double dist_(double x1, double y1, double x2, double y2) { return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
+static inline double distSq(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+
+static inline double angle_diff_signed(double a, double b)
+{
+    double diff = a - b;
+    while (diff <= -CV_PI_) diff += M_2__PI;
+    while (diff > CV_PI_) diff -= M_2__PI;
+    return diff;
+}
+static inline double angle_diff(double a, double b)
+{
+    double diff = angle_diff_signed(a, b);
+    if (diff < 0) diff = -diff;
+    return diff;
+}
+
+static inline int double_equal(double a, double b)
+{
+    if (a == b) return 1;
+    double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+    double abs_max = (aa > bb) ? aa : bb;
+    if (abs_max < DBL_MIN) abs_max = DBL_MIN;
+    return (abs_diff / abs_max) <= (RELATIVE_ERROR_FACTOR * DBL_EPSILON);
+}
+
+static inline int is_aligned(const lsd_t *L, int x, int y, double theta, double prec)
+{
+    if (x < 0 || y < 0 || x >= L->w || y >= L->h) return 0;
+    const double a = L->angles[(size_t)y * L->w + x];
+    if (a == NOTDEF) return 0;
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI) {
+        n_theta -= M_2__PI;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+static void region_grow(lsd_t *L, int sx, int sy, regpt *reg, int *reg_size, double *reg_angle, double prec)
+{
+    const int W = L->w, H = L->h;
+    int n = 1;
+    size_t addr = (size_t)sy * W + sx;
+    reg[0].x = sx; reg[0].y = sy; reg[0].used = L->used + addr;
+    *reg_angle = L->angles[addr];
+    reg[0].angle = *reg_angle;
+    reg[0].modgrad = L->modgrad[addr];
+    float sumdx = (float)cos(*reg_angle);
+    float sumdy = (float)sin(*reg_angle);
+    *reg[0].used = USED;
+    for (int i = 0; i < n; ++i) {
+        const int px = reg[i].x, py = reg[i].y;
+        int xx_min = px - 1 > 0 ? px - 1 : 0, xx_max = px + 1 < W - 1 ? px + 1 : W - 1;
+        int yy_min = py - 1 > 0 ? py - 1 : 0, yy_max = py + 1 < H - 1 ? py + 1 : H - 1;
+        for (int yy = yy_min; yy <= yy_max; ++yy) {
+            for (int xx = xx_min; xx <= xx_max; ++xx) {
+                size_t c = (size_t)yy * W + xx;
+                if (L->used[c] != USED && is_aligned(L, xx, yy, *reg_angle, prec)) {
+                    L->used[c] = USED;
+                    reg[n].x = xx; reg[n].y = yy; reg[n].used = L->used + c;
+                    reg[n].modgrad = L->modgrad[c];
+                    const double angle = L->angles[c];
+                    reg[n].angle = angle;
+                    ++n;
+                    /* `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulate */
+                    sumdx = (float)((double)sumdx + cos((double)(float)angle));
+                    sumdy = (float)((double)sumdy + sin((double)(float)angle));
+                    *reg_angle = (double)orc_fast_atan2(sumdy, sumdx) * DEG_TO_RADS;
+                }
+            }
+        }
+    }
+    *reg_size = n;
+}
+
+static double get_theta(const regpt *reg, int reg_size, double x, double y, double reg_angle, double prec)
+{
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    for (int i = 0; i < reg_size; ++i) {
+        const double regx = reg[i].x, regy = reg[i].y, weight = reg[i].modgrad;
+        double dx = regx - x, dy = regy - y;
+        Ixx += dy * dy * weight;
+        Iyy += dx * dx * weight;
+        Ixy -= dx * dy * weight;
+    }
+    double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)orc_fast_atan2((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)orc_fast_atan2((float)Ixy, (float)(lambda - Iyy));
+    theta *= DEG_TO_RADS;
+    if (angle_diff(theta, reg_angle) > prec) theta += CV_PI_;
+    return theta;
+}
+
+static void region2rect(const regpt *reg, int reg_size, double reg_angle, double prec, double p, rect_t *rec)
+{
+    double x = 0, y = 0, sum = 0;
+    for (int i = 0; i < reg_size; ++i) {
+        const double weight = reg[i].modgrad;
+        x += (double)reg[i].x * weight;
+        y += (double)reg[i].y * weight;
+        sum += weight;
+    }
+    x /= sum;
+    y /= sum;
+    double theta = get_theta(reg, reg_size, x, y, reg_angle, prec);
+    double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = 0; i < reg_size; ++i) {
+        double regdx = (double)reg[i].x - x, regdy = (double)reg[i].y - y;
+        double l = regdx * dx + regdy * dy;
+        double w = -regdx * dy + regdy * dx;
+        if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
+        if (w > w_max) w_max = w; else if (w < w_min) w_min = w;
+    }
+    rec->x1 = x + l_min * dx; rec->y1 = y + l_min * dy;
+    rec->x2 = x + l_max * dx; rec->y2 = y + l_max * dy;
+    rec->width = w_max - w_min;
+    rec->x = x; rec->y = y; rec->theta = theta; rec->dx = dx; rec->dy = dy; rec->prec = prec; rec->p = p;
+    if (rec->width < 1.0) rec->width = 1.0;
+}
+
+static int reduce_region_radius(lsd_t *L, regpt *reg, int *reg_size, double reg_angle, double prec, double p,
+                                rect_t *rec, double density, double density_th)
+{
+    double xc = (double)reg[0].x, yc = (double)reg[0].y;
+    double radSq1 = distSq(xc, yc, rec->x1, rec->y1), radSq2 = distSq(xc, yc, rec->x2, rec->y2);
+    double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+    (void)L;
+    while (density < density_th) {
+        radSq *= 0.75 * 0.75;
+        for (int i = 0; i < *reg_size; ++i) {
+            if (distSq(xc, yc, (double)reg[i].x, (double)reg[i].y) > radSq) {
+                *(reg[i].used) = NOTUSED;
+                regpt t = reg[i]; reg[i] = reg[*reg_size - 1]; reg[*reg_size - 1] = t;
+                --(*reg_size);
+                --i;
+            }
+        }
+        if (*reg_size < 2) return 0;
+        region2rect(reg, *reg_size, reg_angle, prec, p, rec);
+        density = (double)*reg_size / (dist_(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+    }
+    return 1;
+}
+
+static int refine(lsd_t *L, regpt *reg, int *reg_size, double reg_angle, double prec, double p, rect_t *rec,
+                  double density_th)
+{
+    double density = (double)*reg_size / (dist_(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+    if (density >= density_th) return 1;
+    double xc = (double)reg[0].x, yc = (double)reg[0].y;
+    const double ang_c = reg[0].angle;
+    double sum = 0, s_sum = 0;
+    int n = 0;
+    for (int i = 0; i < *reg_size; ++i) {
+        *(reg[i].used) = NOTUSED;
+        if (dist_(xc, yc, reg[i].x, reg[i].y) < rec->width) {
+            const double angle = reg[i].angle;
+            double ang_d = angle_diff_signed(angle, ang_c);
+            sum += ang_d;
+            s_sum += ang_d * ang_d;
+            ++n;
+        }
+    }
+    double mean_angle = sum / (double)n;
+    double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+    region_grow(L, reg[0].x, reg[0].y, reg, reg_size, &reg_angle, tau);
+    if (*reg_size < 2) return 0;
+    region2rect(reg, *reg_size, reg_angle, prec, p, rec);
+    density = (double)*reg_size / (dist_(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+    if (density < density_th) return reduce_region_radius(L, reg, reg_size, reg_angle, prec, p, rec, density, density_th);
+    return 1;
+}
+
+static inline double log_gamma_windschitl(double x)
+{
+    return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+}
+static inline double log_gamma_lanczos(double x)
+{
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+    double b = 0;
+    for (int n = 0; n < 7; ++n) {
+        a -= log(x + (double)n);
+        b += q[n] * pow(x, (double)n);
+    }
+    return a + log(b);
+}
+#define log_gamma(x) ((x) > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x))
+
+static double nfa(const lsd_t *L, int n, int k, double p)
+{
+    const double LOG_NT = L->LOG_NT;
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - (double)n * log10(p);
+    double p_term = p / (1 - p);
+    double log1term = log_gamma((double)n + 1) - log_gamma((double)k + 1) - log_gamma((double)(n - k) + 1) +
+                      (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    double term = exp(log1term);
+    if (double_equal(term, 0)) {
+        if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
+        else return -LOG_NT;
+    }
+    double bin_tail = term;
+    double tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+        double bin_term = (double)(n - i + 1) / (double)i;
+        double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            double err = term * ((1 - pow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - LOG_NT;
+}
+
+typedef struct { int x, y, taken; } edge_t;
+
+static double rect_nfa(const lsd_t *L, const rect_t *rec)
+{
+    int total_pts = 0, alg_pts = 0;
+    double half_width = rec->width / 2.0;
+    double dyhw = rec->dy * half_width, dxhw = rec->dx * half_width;
+    edge_t o[4];
+    o[0].x = (int)(rec->x1 - dyhw); o[0].y = (int)(rec->y1 + dxhw); o[0].taken = 0;
+    o[1].x = (int)(rec->x2 - dyhw); o[1].y = (int)(rec->y2 + dxhw); o[1].taken = 0;
+    o[2].x = (int)(rec->x2 + dyhw); o[2].y = (int)(rec->y2 - dxhw); o[2].taken = 0;
+    o[3].x = (int)(rec->x1 + dyhw); o[3].y = (int)(rec->y1 - dxhw); o[3].taken = 0;
+    /* std::sort(AsmallerB_XoverY) on 4 elements == insertion sort; equal elements are identical */
+    for (int i = 1; i < 4; i++) {
+        edge_t t = o[i];
+        int j = i - 1;
+        while (j >= 0 && (o[j].x > t.x || (o[j].x == t.x && o[j].y > t.y))) { o[j + 1] = o[j]; j--; }
+        o[j + 1] = t;
+    }
+    edge_t *min_y = &o[0], *max_y = &o[0];
+    for (int i = 1; i < 4; ++i) {
+        if (min_y->y > o[i].y) min_y = &o[i];
+        if (max_y->y < o[i].y) max_y = &o[i];
+    }
+    min_y->taken = 1;
+    edge_t *leftmost = 0;
+    for (int i = 0; i < 4; ++i)
+        if (!o[i].taken) { if (!leftmost) leftmost = &o[i]; else if (leftmost->x > o[i].x) leftmost = &o[i]; }
+    leftmost->taken = 1;
+    edge_t *rightmost = 0;
+    for (int i = 0; i < 4; ++i)
+        if (!o[i].taken) { if (!rightmost) rightmost = &o[i]; else if (rightmost->x < o[i].x) rightmost = &o[i]; }
+    rightmost->taken = 1;
+    edge_t *tailp = 0;
+    for (int i = 0; i < 4; ++i)
+        if (!o[i].taken) { if (!tailp) tailp = &o[i]; else if (tailp->x > o[i].x) tailp = &o[i]; }
+    tailp->taken = 1;
+    /* integer divisions and the `tailp->p.x` typo are upstream behaviour */
+    double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
+    double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
+    double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
+    double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
+    double lstep = flstep, rstep = frstep;
+    double left_x = min_y->x, right_x = min_y->x;
+    int min_iter = min_y->y, max_iter = max_y->y;
+    for (int y = min_iter; y <= max_iter; ++y) {
+        if (y >= 0 && y < L->h) {
+            for (int x = (int)left_x; x <= (int)right_x; ++x) {
+                if (x < 0 || x >= L->w) continue;
+                ++total_pts;
+                if (is_aligned(L, x, y, rec->theta, rec->prec)) ++alg_pts;
+            }
+        } else {
+            /* upstream `continue`s before the step update for out-of-image rows */
+            continue;
+        }
+        if (y >= leftmost->y) lstep = slstep;
+        if (y >= rightmost->y) rstep = srstep;
+        left_x += lstep;
+        right_x += rstep;
+    }
+    return nfa(L, total_pts, alg_pts, rec->p);
+}
+
+static double rect_improve(const lsd_t *L, rect_t *rec, double LOG_EPS)
+{
+    double delta = 0.5, delta_2 = delta / 2.0;
+    double log_nfa = rect_nfa(L, rec);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    rect_t r = *rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2;
+        r.prec = r.p * CV_PI_;
+        double v = rect_nfa(L, &r);
+        if (v > log_nfa) { log_nfa = v; *rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = *rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            double v = rect_nfa(L, &r);
+            if (v > log_nfa) { *rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = *rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+            r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            double v = rect_nfa(L, &r);
+            if (v > log_nfa) { *rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = *rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+            r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            double v = rect_nfa(L, &r);
+            if (v > log_nfa) { *rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = *rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2;
+            r.prec = r.p * CV_PI_;
+            double v = rect_nfa(L, &r);
+            if (v > log_nfa) { *rec = r; log_nfa = v; }
+        }
+    }
+    return log_nfa;
+}
+
+/* LineSegmentDetectorImpl::detect with LSD_REFINE_ADV and default parameters.
+ * lines: x1,y1,x2,y2 (float) per segment in detection order.  Returns the segment count. */
+int orc_lsd_detect(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int seed_order, float *lines, int cap,
+                   orc_lsd_debug *dbg)
+{
+    const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5, LOG_EPS = 0, DENSITY_TH = 0.7;
+    const int N_BINS = 1024;
+    if (!gray || w <= 0 || h <= 0) return 0;
+    lsd_t L;
+    const double prec = CV_PI_ * ANG_TH / 180, p = ANG_TH / 180;
+    const double rho = QUANT / sin(prec);
+    /* image -> double; blur; resize */
+    double *img = (double *)malloc(sizeof(double) * (size_t)w * h);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) img[(size_t)y * w + x] = (double)gray[(size_t)y * pitch + x];
+    const double sigma = SIGMA_SCALE / SCALE;
+    const double sprec = 3;
+    const unsigned hk = (unsigned)ceil(sigma * sqrt(2 * sprec * log(10.0)));
+    const int ksize = 1 + 2 * (int)hk;
+    double kern[64];
+    orc_gauss_kernel_f64(ksize, sigma, kern);
+    double *blur = (double *)malloc(sizeof(double) * (size_t)w * h);
+    gaussian_blur_f64(img, blur, w, h, kern, ksize);
+    L.w = (int)lrint(w * SCALE);
+    L.h = (int)lrint(h * SCALE);
+    L.img = (double *)malloc(sizeof(double) * (size_t)L.w * L.h);
+    resize_linear_f64(blur, w, h, L.img, L.w, L.h, SCALE, SCALE);
+    free(img); free(blur);
+    const int W = L.w, H = L.h;
+    const size_t NP = (size_t)W * H;
+    L.angles = (double *)malloc(sizeof(double) * NP);
+    L.modgrad = (double *)calloc(NP, sizeof(double)); /* cv::Mat_<double>(size) is uninitialised for the last row/col; never read */
+    L.used = (uint8_t *)calloc(NP, 1);
+    /* ll_angle */
+    for (int x = 0; x < W; x++) L.angles[(size_t)(H - 1) * W + x] = NOTDEF;
+    for (int y = 0; y < H; y++) L.angles[(size_t)y * W + (W - 1)] = NOTDEF;
+    double max_grad = -1;
+    for (int y = 0; y < H - 1; ++y) {
+        for (int x = 0; x < W - 1; ++x) {
+            size_t a = (size_t)y * W + x;
+            double DA = L.img[a + W + 1] - L.img[a];
+            double BC = L.img[a + 1] - L.img[a + W];
+            double gx = DA + BC, gy = DA - BC;
+            double norm = sqrt((gx * gx + gy * gy) / 4);
+            L.modgrad[a] = norm;
+            if (norm <= rho) L.angles[a] = NOTDEF;
+            else {
+                L.angles[a] = (double)orc_fast_atan2((float)gx, (float)-gy) * DEG_TO_RADS;
+                if (norm > max_grad) max_grad = norm;
+            }
+        }
+    }
+    /* seed list */
+    const size_t nseed_raster = (size_t)(W - 1) * (H - 1);
+    int *seeds = (int *)malloc(sizeof(int) * (NP + 1));
+    size_t nseeds = 0;
+    if (seed_order == ORC_LSD_SEED_BINNED) {
+        double bin_coef = (max_grad > 0) ? (double)(N_BINS - 1) / max_grad : 0;
+        int *cnt = (int *)calloc(N_BINS + 1, sizeof(int));
+        int *bin = (int *)malloc(sizeof(int) * nseed_raster);
+        size_t q = 0;
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x, ++q) {
+                int b = (int)(L.modgrad[(size_t)y * W + x] * bin_coef);
+                if (b > N_BINS - 1) b = N_BINS - 1;
+                bin[q] = b;
+                cnt[N_BINS - 1 - b + 1]++; /* descending bins */
+            }
+        for (int b = 0; b < N_BINS; b++) cnt[b + 1] += cnt[b];
+        q = 0;
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x, ++q) seeds[cnt[N_BINS - 1 - bin[q]]++] = y * W + x;
+        nseeds = nseed_raster;
+        free(cnt); free(bin);
+    } else {
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x) seeds[nseeds++] = y * W + x;
+        /* upstream also visits w*h - (w-1)(h-1) default-constructed entries at (0,0): no effect */
+    }
+    L.LOG_NT = 5 * (log10((double)W) + log10((double)H)) / 2 + log10(11.0);
+    const int min_reg_size = (int)(-L.LOG_NT / log10(p));
+    regpt *reg = (regpt *)malloc(sizeof(regpt) * NP);
+    int nlines = 0, nregions = 0;
+    for (size_t i = 0; i < nseeds; ++i) {
+        const int adx = seeds[i];
+        if (L.used[adx] == NOTUSED && L.angles[adx] != NOTDEF) {
+            int reg_size;
+            double reg_angle;
+            region_grow(&L, adx % W, adx / W, reg, &reg_size, &reg_angle, prec);
+            nregions++;
+            if (reg_size < min_reg_size) continue;
+            rect_t rec;
+            region2rect(reg, reg_size, reg_angle, prec, p, &rec);
+            if (!refine(&L, reg, &reg_size, reg_angle, prec, p, &rec, DENSITY_TH)) continue;
+            double log_nfa = rect_improve(&L, &rec, LOG_EPS);
+            if (log_nfa <= LOG_EPS) continue;
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            rec.x1 /= SCALE; rec.y1 /= SCALE; rec.x2 /= SCALE; rec.y2 /= SCALE; rec.width /= SCALE;
+            if (nlines < cap) {
+                lines[4 * nlines] = (float)rec.x1; lines[4 * nlines + 1] = (float)rec.y1;
+                lines[4 * nlines + 2] = (float)rec.x2; lines[4 * nlines + 3] = (float)rec.y2;
+            }
+            nlines++;
+        }
+    }
+    if (dbg) {
+        dbg->sw = W; dbg->sh = H; dbg->nregions = nregions; dbg->min_reg_size = min_reg_size; dbg->max_grad = max_grad;
+        if (dbg->want_maps) {
+            dbg->scaled = L.img; dbg->angles = L.angles; dbg->modgrad = L.modgrad; dbg->used = L.used;
+            L.img = NULL; L.angles = NULL; L.modgrad = NULL; L.used = NULL;
+        }
+    }
+    free(reg); free(seeds); free(L.img); free(L.angles); free(L.modgrad); free(L.used);
+    return nlines;
+}
+
+/* cv::line_descriptor::LSDDetector::detectImpl KeyLine fill (octave 0, octaveScale = 1) */
+int orc_keylines_from_segments(const float *lines, int n, int w, int h, orc_keyline *out)
+{
+    for (int k = 0; k < n; k++) {
+        float e0 = lines[4 * k], e1 = lines[4 * k + 1], e2 = lines[4 * k + 2], e3 = lines[4 * k + 3];
+        /* checkLineExtremes */
+        if (e0 < 0) e0 = 0;
+        if (e0 >= w) e0 = (float)w - 1.0f;
+        if (e2 < 0) e2 = 0;
+        if (e2 >= w) e2 = (float)w - 1.0f;
+        if (e1 < 0) e1 = 0;
+        if (e1 >= h) e1 = (float)h - 1.0f;
+        if (e3 < 0) e3 = 0;
+        if (e3 >= h) e3 = (float)h - 1.0f;
+        orc_keyline *kl = &out[k];
+        const float octaveScale = 1.0f; /* pow((float)scale, 0) */
+        kl->startPointX = e0 * octaveScale; kl->startPointY = e1 * octaveScale;
+        kl->endPointX = e2 * octaveScale; kl->endPointY = e3 * octaveScale;
+        kl->sPointInOctaveX = e0; kl->sPointInOctaveY = e1; kl->ePointInOctaveX = e2; kl->ePointInOctaveY = e3;
+        kl->lineLength = (float)sqrt((double)(e0 - e2) * (double)(e0 - e2) + (double)(e1 - e3) * (double)(e1 - e3));
+        /* LineIterator(img, Point(cvRound..), Point(cvRound..)), 8-connected: count = max(|dx|,|dy|)+1 */
+        int x0 = (int)lrintf(e0), y0 = (int)lrintf(e1), x1 = (int)lrintf(e2), y1 = (int)lrintf(e3);
+        int dx = abs(x1 - x0), dy = abs(y1 - y0);
+        kl->numOfPixels = (dx > dy ? dx : dy) + 1;
+        kl->angle = (float)atan2((double)(kl->endPointY - kl->startPointY), (double)(kl->endPointX - kl->startPointX));
+        kl->class_id = k;
+        kl->octave = 0;
+        kl->size = (kl->endPointX - kl->startPointX) * (kl->endPointY - kl->startPointY);
+        kl->response = kl->lineLength / (float)(w > h ? w : h);
+        kl->pt_x = (kl->endPointX + kl->startPointX) / 2;
+        kl->pt_y = (kl->endPointY + kl->startPointY) / 2;
+    }
+    return n;
+}

@@ -1,0 +1,400 @@
+/*
+ * match_oracle.c -- CPU restatement of the reference Hamming matchers.  TEST INFRASTRUCTURE ONLY
+ * (same rules as orb_oracle.c: only tests/, smoke() and bench.py's cpu_baseline may use it).
+ *
+ *   orc_hamming256                 ORBmatcher::DescriptorDistance  include/ORBmatcher.h:44, so@0x79d20,
+ *                                  source form Thirdparty/DBoW2/DBoW2/FORB.cpp:82-102; LSDmatcher.h:43   (8a-9)
+ *   orc_assign_grid / orc_features_in_area
+ *                                  Frame::AssignFeaturesToGrid so@0xf9120, Frame::GetFeaturesInArea
+ *                                  include/Frame.h:113, so@0xfbc60                                       (8a-11)
+ *   orc_search_by_projection_map   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)
+ *                                  include/ORBmatcher.h:61, so@0x79f10                                   (8a-10)
+ *   orc_search_by_projection_last  ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)
+ *                                  include/ORBmatcher.h:78, so@0x80d00                                   (8a-12)
+ *   orc_radius_by_viewing_cos      ORBmatcher::RadiusByViewingCos so@0x79b60
+ *   orc_three_maxima               ORBmatcher::ComputeThreeMaxima so@0x823eb
+ *   orc_knn2_hamming               cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) [UPSTREAM: OpenCV 3.3 batchDistance]
+ *   orc_line_mad / orc_match_lines_knn   Frame::lineDescriptorMAD include/Frame.h:75 + LSDmatcher::SearchByProjection
+ *                                  (Frame&, const Frame&) include/LSDmatcher.h:32 [UPSTREAM body, PL-SLAM family] (8a-13)
+ *   orc_lines_in_area / orc_search_by_projection_lines
+ *                                  Frame::GetLinesInArea include/Frame.h:116 + LSDmatcher::SearchByProjection
+ *                                  (Frame&, vector<MapLine*>&, th) include/LSDmatcher.h:40 [UPSTREAM body]   (8a-14)
+ *
+ * PINNED against the reference binary (tests/golden/ref_matcher.json): Hamming, RadiusByViewingCos,
+ * ComputeThreeMaxima, TH_LOW/TH_HIGH/HISTO_LENGTH.  The SearchByProjection bodies follow the full
+ * disassembly listing summarised in SURVEY.md 8a-10/12; the line matchers are "parity unpinned".
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define TH_HIGH 100
+#define TH_LOW 50
+#define HISTO_LENGTH 30
+
+int orc_hamming256(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+float orc_radius_by_viewing_cos(float viewCos) { return ((double)viewCos > 0.998) ? 2.5f : 4.0f; }
+
+/* ---------------------------------------------------------------- grid */
+typedef struct { int *start; int *idx; } grid_t; /* CSR over cell = ix*GRID_ROWS+iy */
+
+static void grid_build(const orc_frame *F, grid_t *g)
+{
+    const int ncell = GRID_COLS * GRID_ROWS;
+    int *cell = (int *)malloc(sizeof(int) * (F->n > 0 ? F->n : 1));
+    g->start = (int *)calloc(ncell + 1, sizeof(int));
+    g->idx = (int *)malloc(sizeof(int) * (F->n > 0 ? F->n : 1));
+    for (int i = 0; i < F->n; i++) {
+        int px = (int)roundf((F->ux[i] - F->minx) * F->grid_inv_w);
+        int py = (int)roundf((F->uy[i] - F->miny) * F->grid_inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) { cell[i] = -1; continue; }
+        cell[i] = px * GRID_ROWS + py;
+        g->start[cell[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) g->start[c + 1] += g->start[c];
+    int *fill = (int *)calloc(ncell, sizeof(int));
+    for (int i = 0; i < F->n; i++) /* insertion order inside a cell = keypoint order */
+        if (cell[i] >= 0) g->idx[g->start[cell[i]] + fill[cell[i]]++] = i;
+    free(fill); free(cell);
+}
+static void grid_free(grid_t *g) { free(g->start); free(g->idx); }
+
+/* exported CSR builder so tests can hand the same grid to the product */
+void orc_assign_grid(const orc_frame *F, int32_t *cell_start /*64*48+1*/, int32_t *cell_idx /*n*/)
+{
+    grid_t g; grid_build(F, &g);
+    memcpy(cell_start, g.start, sizeof(int) * (GRID_COLS * GRID_ROWS + 1));
+    memcpy(cell_idx, g.idx, sizeof(int) * (size_t)g.start[GRID_COLS * GRID_ROWS]);
+    grid_free(&g);
+}
+
+static int features_in_area(const orc_frame *F, const grid_t *g, float x, float y, float r, int minLevel,
+                            int maxLevel, int *out, int cap)
+{
+    int n = 0;
+    int nMinCellX = (int)floorf((x - F->minx - r) * F->grid_inv_w);
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - F->minx + r) * F->grid_inv_w);
+    if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - F->miny - r) * F->grid_inv_h);
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - F->miny + r) * F->grid_inv_h);
+    if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            int c = ix * GRID_ROWS + iy;
+            for (int j = g->start[c]; j < g->start[c + 1]; j++) {
+                int k = g->idx[j];
+                if (bCheckLevels) {
+                    if (F->octave[k] < minLevel) continue;
+                    if (maxLevel >= 0 && F->octave[k] > maxLevel) continue;
+                }
+                const float distx = F->ux[k] - x, disty = F->uy[k] - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) { if (n < cap) out[n] = k; n++; }
+            }
+        }
+    return n;
+}
+
+int orc_features_in_area(const orc_frame *F, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap)
+{
+    grid_t g; grid_build(F, &g);
+    int n = features_in_area(F, &g, x, y, r, minLevel, maxLevel, out, cap);
+    grid_free(&g);
+    return n;
+}
+
+/* ---------------------------------------------------------------- 8a-10 */
+/* match_of_kp[i] on entry: -1 = keypoint free (no MapPoint, or one with Observations()==0),
+ *                          -2 = keypoint holds a MapPoint with Observations()>0 (never overwritten).
+ * on exit: >= 0 = index of the map point written by this call.  MP->obs_positive[m] tells whether map
+ * point m has Observations()>0 (NULL = all do), which decides if a later point may overwrite it. */
+int orc_search_by_projection_map(const orc_frame *F, const orc_mappoints *MP, float th, float nnratio,
+                                 int32_t *match_of_kp)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0f;
+    grid_t g; grid_build(F, &g);
+    int *cand = (int *)malloc(sizeof(int) * (F->n > 0 ? F->n : 1));
+    for (int m = 0; m < MP->m; m++) {
+        if (!MP->in_view[m]) continue;
+        const int lvl = MP->level[m];
+        float r = orc_radius_by_viewing_cos(MP->view_cos[m]);
+        if (bFactor) r *= th;
+        const float rad = r * F->scale_factors[lvl];
+        int nc = features_in_area(F, &g, MP->proj_x[m], MP->proj_y[m], rad, lvl - 1, lvl, cand, F->n);
+        if (nc == 0) continue;
+        const uint8_t *d = MP->desc + (size_t)m * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int cur = match_of_kp[idx];
+            if (cur == -2) continue;
+            if (cur >= 0 && (!MP->obs_positive || MP->obs_positive[cur])) continue;
+            if (F->uright[idx] > 0) {
+                const float er = fabsf(MP->proj_xr[m] - F->uright[idx]);
+                if (er > rad) continue;
+            }
+            const int dist = orc_hamming256(d, F->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = F->octave[idx];
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F->octave[idx];
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            match_of_kp[bestIdx] = m;
+            nmatches++;
+        }
+    }
+    free(cand); grid_free(&g);
+    return nmatches;
+}
+
+/* ---------------------------------------------------------------- ComputeThreeMaxima */
+void orc_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    *ind1 = *ind2 = *ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* ---------------------------------------------------------------- 8a-12 */
+/* Last-frame tracking.  Rcw/tcw = current pose (row-major 3x3, 3), twc = -Rcw^T tcw is computed
+ * here; Rlw/tlw = last pose.  last_* arrays describe LastFrame: world position of its map points
+ * (has_mp[i] && !outlier[i] are projected), octave and angle of its keypoints.  fx..cy, bf, b.
+ * match_of_kp: same protocol as orc_search_by_projection_map (values >= 0 are LAST-FRAME indices). */
+int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Last, const float *Rcw,
+                                  const float *tcw, const float *Rlw, const float *tlw, float fx, float fy,
+                                  float cx, float cy, float bf, float b, float th, int bMono, int checkOri,
+                                  int32_t *match_of_kp)
+{
+    int nmatches = 0;
+    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (Cur->n > 0 ? Cur->n : 1));
+    int histN[HISTO_LENGTH];
+    memset(histN, 0, sizeof(histN));
+    /* twc = -Rcw^T * tcw ; tlc = Rlw*twc + tlw */
+    float twc[3], tlc[3];
+    /* cv::gemm: the transposed product goes through the generic double-accumulating kernel, the
+     * plain 3x3*3x1 products through the float small-matrix path [UPSTREAM OpenCV 3.3 matmul.cpp] */
+    for (int i = 0; i < 3; i++)
+        twc[i] = (float)(-((double)Rcw[0 * 3 + i] * tcw[0] + (double)Rcw[1 * 3 + i] * tcw[1] + (double)Rcw[2 * 3 + i] * tcw[2]));
+    for (int i = 0; i < 3; i++) tlc[i] = Rlw[i * 3 + 0] * twc[0] + Rlw[i * 3 + 1] * twc[1] + Rlw[i * 3 + 2] * twc[2] + tlw[i];
+    const int bForward = tlc[2] > b && !bMono;
+    const int bBackward = -tlc[2] > b && !bMono;
+    grid_t g; grid_build(Cur, &g);
+    int *cand = (int *)malloc(sizeof(int) * (Cur->n > 0 ? Cur->n : 1));
+    for (int i = 0; i < Last->n; i++) {
+        if (!Last->has_mp[i] || Last->outlier[i]) continue;
+        const float *xw = Last->xw + 3 * (size_t)i;
+        const float xc = Rcw[0] * xw[0] + Rcw[1] * xw[1] + Rcw[2] * xw[2] + tcw[0];
+        const float yc = Rcw[3] * xw[0] + Rcw[4] * xw[1] + Rcw[5] * xw[2] + tcw[1];
+        const float zc = Rcw[6] * xw[0] + Rcw[7] * xw[1] + Rcw[8] * xw[2] + tcw[2];
+        const float invzc = (float)(1.0 / (double)zc);
+        if (invzc < 0) continue;
+        const float u = fx * xc * invzc + cx;
+        const float v = fy * yc * invzc + cy;
+        if (u < Cur->minx || u > Cur->maxx) continue;
+        if (v < Cur->miny || v > Cur->maxy) continue;
+        const int nLastOctave = Last->octave[i];
+        const float radius = th * Cur->scale_factors[nLastOctave];
+        int nc;
+        if (bForward) nc = features_in_area(Cur, &g, u, v, radius, nLastOctave, -1, cand, Cur->n);
+        else if (bBackward) nc = features_in_area(Cur, &g, u, v, radius, 0, nLastOctave, cand, Cur->n);
+        else nc = features_in_area(Cur, &g, u, v, radius, nLastOctave - 1, nLastOctave + 1, cand, Cur->n);
+        if (nc == 0) continue;
+        const uint8_t *dMP = Last->mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int cur = match_of_kp[i2];
+            if (cur == -2 || cur >= 0) continue; /* map points of the last frame all have observations */
+            if (Cur->uright[i2] > 0) {
+                const float ur = u - bf * invzc;
+                const float er = fabsf(ur - Cur->uright[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_hamming256(dMP, Cur->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            match_of_kp[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                float rot = Last->angle[i] - Cur->angle[bestIdx2];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / 12.0f)); /* this binary: factor = HISTO_LENGTH/360 */
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin * Cur->n + histN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (checkOri) {
+        int i1, i2, i3;
+        orc_three_maxima(histN, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int bnum = 0; bnum < HISTO_LENGTH; bnum++) {
+            if (bnum == i1 || bnum == i2 || bnum == i3) continue;
+            for (int j = 0; j < histN[bnum]; j++) {
+                match_of_kp[rotHist[bnum * Cur->n + j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    free(cand); free(rotHist); grid_free(&g);
+    return nmatches;
+}
+
+/* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
+int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
+{
+    for (int i = 0; i < nq; i++) {
+        int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; j++) {
+            int d = orc_hamming256(q + 32 * (size_t)i, t + 32 * (size_t)j);
+            if (d < d1) {
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                else { d1 = d; i1 = j; }
+            }
+        }
+        idx[2 * i] = i0; idx[2 * i + 1] = i1;
+        dist[2 * i] = d0; dist[2 * i + 1] = d1;
+    }
+    return nq;
+}
+
+static int cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* Frame::lineDescriptorMAD: medians are order statistics, so sort tie order is irrelevant */
+void orc_line_mad(const int32_t *dist /*n x 2*/, int n, double *nn_mad, double *nn12_mad)
+{
+    *nn_mad = *nn12_mad = 0;
+    if (n <= 0) return;
+    float *v = (float *)malloc(sizeof(float) * n);
+    for (int i = 0; i < n; i++) v[i] = (float)dist[2 * i];
+    qsort(v, n, sizeof(float), cmp_float);
+    double med = v[n / 2];
+    for (int i = 0; i < n; i++) v[i] = fabsf((float)((double)(float)dist[2 * i] - med));
+    qsort(v, n, sizeof(float), cmp_float);
+    *nn_mad = 1.4826 * v[n / 2];
+    for (int i = 0; i < n; i++) v[i] = (float)dist[2 * i + 1] - (float)dist[2 * i];
+    qsort(v, n, sizeof(float), cmp_float);
+    med = v[n / 2];
+    for (int i = 0; i < n; i++) v[i] = fabsf((float)((double)((float)dist[2 * i + 1] - (float)dist[2 * i]) - med));
+    qsort(v, n, sizeof(float), cmp_float);
+    *nn12_mad = 1.4826 * v[n / 2];
+    free(v);
+}
+
+/* LSDmatcher::SearchByProjection(CurrentFrame, LastFrame): query = last-frame lines, train = current.
+ * last_has_mapline[q] says whether LastFrame.mvpMapLines[q] != NULL.  match_of_line[t] = q written. */
+int orc_match_lines_knn(const uint8_t *last_desc, int nlast, const uint8_t *cur_desc, int ncur,
+                        const uint8_t *last_has_mapline, int32_t *match_of_line)
+{
+    if (nlast <= 0 || ncur < 2) return 0;
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * 2 * nlast), *dist = (int32_t *)malloc(sizeof(int32_t) * 2 * nlast);
+    orc_knn2_hamming(last_desc, nlast, cur_desc, ncur, idx, dist);
+    double nn_mad, nn12_mad;
+    orc_line_mad(dist, nlast, &nn_mad, &nn12_mad);
+    const double th12 = nn12_mad * 0.5;
+    int n = 0;
+    for (int q = 0; q < nlast; q++) { /* sorted by queryIdx == natural order */
+        double d12 = (double)((float)dist[2 * q + 1] - (float)dist[2 * q]);
+        if (d12 > th12 && last_has_mapline[q]) { match_of_line[idx[2 * q]] = q; n++; }
+    }
+    free(idx); free(dist);
+    return n;
+}
+
+/* Frame::GetLinesInArea [UPSTREAM] */
+int orc_lines_in_area(const orc_lineframe *F, float x1, float y1, float x2, float y2, float r, int minLevel,
+                      int maxLevel, int *out, int cap)
+{
+    int n = 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel > 0);
+    for (int i = 0; i < F->n; i++) {
+        double dx = 0.5 * (x1 + x2) - F->pt_x[i], dy = 0.5 * (y1 + y2) - F->pt_y[i];
+        double distance = dx * dx + dy * dy;
+        if (distance > r * r) continue;
+        float slope = (y1 - y2) / (x1 - x2) - F->angle[i];
+        if (slope > r * 0.01) continue;
+        if (bCheckLevels) {
+            if (F->octave[i] < minLevel) continue;
+            if (maxLevel >= 0 && F->octave[i] > maxLevel) continue;
+        }
+        if (n < cap) out[n] = i;
+        n++;
+    }
+    return n;
+}
+
+int orc_search_by_projection_lines(const orc_lineframe *F, const orc_maplines *ML, float th, float nnratio,
+                                   int32_t *match_of_line)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0f;
+    int *cand = (int *)malloc(sizeof(int) * (F->n > 0 ? F->n : 1));
+    for (int m = 0; m < ML->m; m++) {
+        if (!ML->in_view[m]) continue;
+        const int lvl = ML->level[m];
+        float r = orc_radius_by_viewing_cos(ML->view_cos[m]);
+        if (bFactor) r *= th;
+        int nc = orc_lines_in_area(F, ML->x1[m], ML->y1[m], ML->x2[m], ML->y2[m], r * F->scale_factors[lvl], lvl - 1, lvl,
+                                   cand, F->n);
+        if (nc == 0) continue;
+        if (nc > F->n) nc = F->n;
+        const uint8_t *d = ML->desc + 32 * (size_t)m;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (match_of_line[idx] == -2 || match_of_line[idx] >= 0) continue;
+            const int dist = orc_hamming256(d, F->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->octave[idx]; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = F->octave[idx]; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            match_of_line[bestIdx] = m;
+            nmatches++;
+        }
+    }
+    free(cand);
+    return nmatches;
+}

@@ -1,0 +1,157 @@
+/* oracle.h -- declarations of the CPU oracle (TEST INFRASTRUCTURE ONLY; see orb_oracle.c header). */
+#ifndef PLF_ORACLE_H
+#define PLF_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bit-compatible with cv::KeyPoint (28 bytes) */
+typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint;
+
+/* field order of cv::line_descriptor::KeyLine (17 x 4 bytes) */
+typedef struct {
+    float angle; int class_id; int octave; float pt_x, pt_y; float response; float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength; int numOfPixels;
+} orc_keyline;
+
+typedef struct {
+    int want_planes;
+    int ncand[16], nsel[16], ncells[16], lw[16], lh[16];
+    uint8_t *pyr[16];  /* padded planes (malloc'd when want_planes) */
+    uint8_t *blur[16]; /* blurred interiors */
+    orc_keypoint *level_kps[16]; /* per-level keypoints, level coords, with angle (nsel[l] entries) */
+} orc_orb_debug;
+
+void orc_orb_tables(int nfeatures, float scaleFactor, int nlevels, float *scale, float *inv, float *sigma2,
+                    float *invsigma2, int *perLevel, int *umax);
+void orc_level_size(int w, int h, float inv, int *lw, int *lh);
+void orc_resize_linear_8u(const uint8_t *src, int sw, int sh, ptrdiff_t spitch, uint8_t *dst, int dw, int dh,
+                          ptrdiff_t dpitch);
+void orc_border_reflect101(uint8_t *plane, int w, int h, ptrdiff_t pitch, int b);
+int orc_compute_pyramid(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nlevels, const float *inv,
+                        uint8_t **planes, int *lw, int *lh);
+int orc_fast9_16(const uint8_t *img, int cols, int rows, ptrdiff_t pitch, int threshold, orc_keypoint *out, int cap);
+int orc_cell_rects(int cols, int rows, int *rects, int cap, int *wCell_out, int *hCell_out);
+int orc_fast_cells(const uint8_t *img, int cols, int rows, ptrdiff_t pitch, int iniTh, int minTh,
+                   orc_keypoint *out, int cap, int *ncells_out);
+int orc_distribute_octree(const orc_keypoint *kps, int nk, int minX, int maxX, int minY, int maxY, int N,
+                          orc_keypoint *out, int cap);
+float orc_fast_atan2(float y, float x);
+void orc_ic_moments(const uint8_t *img, ptrdiff_t pitch, int cx, int cy, const int *umax, int *m01, int *m10);
+float orc_ic_angle(const uint8_t *img, ptrdiff_t pitch, float x, float y, const int *umax);
+void orc_gauss_taps_8u(int ksize, double sigma, int *taps);
+void orc_gaussian_blur7_8u(const uint8_t *src, ptrdiff_t spitch, uint8_t *dst, ptrdiff_t dpitch, int w, int h);
+void orc_brief_descriptor(const uint8_t *blur, ptrdiff_t pitch, float x, float y, float angle_deg, uint8_t *desc);
+int orc_orb_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nfeatures, float scaleFactor,
+                    int nlevels, int iniTh, int minTh, orc_keypoint *kps, uint8_t *desc, int cap,
+                    orc_orb_debug *dbg);
+void orc_free(void *p);
+
+/* ---- matchers (match_oracle.c) */
+int orc_hamming256(const uint8_t *a, const uint8_t *b);
+
+typedef struct {
+    int n;                    /* keypoints */
+    const float *ux, *uy;     /* mvKeysUn[i].pt */
+    const int *octave;        /* mvKeysUn[i].octave */
+    const float *uright;      /* mvuRight (<=0: none) */
+    const uint8_t *desc;      /* n x 32 */
+    const float *angle;       /* mvKeys[i].angle (deg), used by the last-frame overload only */
+    float minx, miny, maxx, maxy; /* mnMinX.. image bounds */
+    float grid_inv_w, grid_inv_h; /* mfGridElementWidthInv / HeightInv */
+    const float *scale_factors;   /* mvScaleFactors */
+    int nlevels;
+} orc_frame;
+
+typedef struct {
+    int m;
+    const float *proj_x, *proj_y, *proj_xr; /* mTrackProjX/Y/XR */
+    const int *level;                       /* mnTrackScaleLevel */
+    const float *view_cos;                  /* mTrackViewCos */
+    const uint8_t *in_view;                 /* mbTrackInView && !isBad() */
+    const uint8_t *desc;                    /* m x 32 */
+    const uint8_t *obs_positive;            /* Observations()>0 per map point; NULL = all */
+} orc_mappoints;
+
+typedef struct { /* LastFrame view for the motion-model overload (8a-12) */
+    int n;
+    const uint8_t *has_mp, *outlier; /* mvpMapPoints[i]!=NULL, mvbOutlier[i] */
+    const float *xw;                 /* n x 3 world positions */
+    const int *octave;               /* mvKeys[i].octave */
+    const float *angle;              /* mvKeysUn[i].angle */
+    const uint8_t *mp_desc;          /* n x 32, pMP->GetDescriptor() */
+} orc_lastframe;
+
+typedef struct { /* current frame, lines */
+    int n;
+    const float *pt_x, *pt_y, *angle; /* mvKeylinesUn[i].pt / .angle */
+    const int *octave;
+    const uint8_t *desc;              /* n x 32 (mLdesc) */
+    const float *scale_factors;
+} orc_lineframe;
+
+typedef struct {
+    int m;
+    const float *x1, *y1, *x2, *y2; /* mTrackProjX1.. */
+    const int *level;
+    const float *view_cos;
+    const uint8_t *in_view;
+    const uint8_t *desc;
+} orc_maplines;
+
+int orc_features_in_area(const orc_frame *F, float x, float y, float r, int minLevel, int maxLevel,
+                         int *out, int cap);
+/* match_of_kp: in: >=0 where the keypoint already holds a map point with Observations()>0,
+ * -1 otherwise (use -2 for "holds a map point with 0 observations" if needed).  out: index of
+ * the matched map point (>= 0 new matches are written as map point index + 0). */
+int orc_search_by_projection_map(const orc_frame *F, const orc_mappoints *MP, float th, float nnratio,
+                                 int32_t *match_of_kp);
+void orc_assign_grid(const orc_frame *F, int32_t *cell_start, int32_t *cell_idx);
+float orc_radius_by_viewing_cos(float viewCos);
+void orc_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3);
+int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Last, const float *Rcw,
+                                  const float *tcw, const float *Rlw, const float *tlw, float fx, float fy,
+                                  float cx, float cy, float bf, float b, float th, int bMono, int checkOri,
+                                  int32_t *match_of_kp);
+void orc_line_mad(const int32_t *dist, int n, double *nn_mad, double *nn12_mad);
+int orc_match_lines_knn(const uint8_t *last_desc, int nlast, const uint8_t *cur_desc, int ncur,
+                        const uint8_t *last_has_mapline, int32_t *match_of_line);
+int orc_lines_in_area(const orc_lineframe *F, float x1, float y1, float x2, float y2, float r, int minLevel,
+                      int maxLevel, int *out, int cap);
+int orc_search_by_projection_lines(const orc_lineframe *F, const orc_maplines *ML, float th, float nnratio,
+                                   int32_t *match_of_line);
+int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq x 2*/,
+                     int32_t *dist /*nq x 2*/);
+
+/* ---- lines (lsd_oracle.c, lbd_oracle.c) */
+#define ORC_LSD_SEED_RASTER 0 /* OpenCV 3.0-3.3 behaviour (list[i] iterated by index) */
+#define ORC_LSD_SEED_BINNED 1 /* published LSD order: gradient bins descending */
+
+typedef struct {
+    int want_maps;
+    int sw, sh, nregions, min_reg_size;
+    double max_grad;
+    double *scaled, *angles, *modgrad; /* malloc'd sw*sh maps when want_maps */
+    uint8_t *used;
+} orc_lsd_debug;
+
+void orc_gauss_kernel_f64(int n, double sigma, double *k);
+int orc_lsd_detect(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int seed_order, float *lines, int cap,
+                   orc_lsd_debug *dbg);
+int orc_keylines_from_segments(const float *lines, int n, int w, int h, orc_keyline *out);
+void orc_sobel3_16s(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int16_t *dxImg, int16_t *dyImg);
+void orc_lbd_gauss_coefs(double *gaussCoefL, double *gaussCoefG);
+void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const orc_keyline *kl, int n, uint8_t *desc,
+                     float *fdesc);
+int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
+                     uint8_t *desc, double *lineeq, int cap, int *ndetected);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

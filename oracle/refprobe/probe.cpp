@@ -1,0 +1,425 @@
+// probe.cpp -- executes pure functions of the PREBUILT reference binary
+// (/root/reference/lib/libORB_SLAM2.so) to produce golden fixtures for tests/golden/.
+//
+// TEST TOOLING.  Runs only in the build container; nothing here ships or is imported by the
+// product.  No reference source is compiled (none exists for this path); the reference's own
+// machine code is called through look-alike declarations:
+//   tier A  (no OpenCV code involved): ORBextractor ctor tables, DistributeOctTree/DivideNode,
+//           computeOrientation integer moments (cv::fastAtan2 replaced by a recorder),
+//           ORBmatcher::DescriptorDistance, RadiusByViewingCos, ComputeThreeMaxima, constants.
+//   tier B  ("glue"): ORBextractor::ComputeKeyPointsOctTree driven on a hand-laid pyramid with
+//           cv::FAST / cv::fastAtan2 / cv::Mat(ROI) supplied by THIS repo's restated primitives
+//           (oracle/orb_oracle.c).  Pins cell tiling, retry rule, octree, border offsets, size
+//           truncation, orientation and output order against the reference's machine code; it does
+//           NOT pin the OpenCV primitives themselves (they are ours on both sides).
+//
+// A bump `operator new` makes node addresses monotonic so that DistributeOctTree's
+// pair<int,ExtractorNode*> tie-break equals creation order (Appendix B determinism rule).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <climits>
+#include <new>
+#include <string>
+#include <vector>
+#include <dlfcn.h>
+#include <link.h>
+
+#include "../oracle.h"
+
+// ---------------------------------------------------------------- bump allocator (interposes the .so's operator new)
+static char *g_arena = nullptr;
+static size_t g_arena_off = 0, g_arena_cap = 0;
+static void *bump(size_t n)
+{
+    if (!g_arena) { g_arena_cap = (size_t)3 << 30; g_arena = (char *)malloc(g_arena_cap); }
+    n = (n + 15) & ~(size_t)15;
+    if (g_arena_off + n > g_arena_cap) { fprintf(stderr, "arena exhausted\n"); abort(); }
+    void *p = g_arena + g_arena_off;
+    g_arena_off += n;
+    return p;
+}
+void *operator new(size_t n) { return bump(n); }
+void *operator new[](size_t n) { return bump(n); }
+void operator delete(void *) noexcept {}
+void operator delete[](void *) noexcept {}
+void operator delete(void *, size_t) noexcept {}
+void operator delete[](void *, size_t) noexcept {}
+static void arena_reset() { g_arena_off = 0; }
+
+// ---------------------------------------------------------------- look-alike OpenCV 3.3 PODs
+namespace cv {
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
+struct Range { int start, end; };
+struct Mat {  // OpenCV 3.3 layout, 96 bytes
+    int flags, dims, rows, cols;
+    unsigned char *data;
+    const unsigned char *datastart, *dataend, *datalimit;
+    void *allocator, *u;
+    int *size_p;
+    size_t *step_p;
+    size_t step_buf[2];
+    Mat() {}
+    Mat(const Mat &m, const Range &rowRange, const Range &colRange);
+    void deallocate();
+};
+struct _InputArray { int flags; void *obj; int sz_w, sz_h; };
+float fastAtan2(float y, float x);
+void fastFree(void *);
+void FAST(const _InputArray &, std::vector<KeyPoint> &, int, bool);
+}  // namespace cv
+static_assert(sizeof(cv::Mat) == 96, "cv::Mat 3.3 layout");
+static_assert(sizeof(cv::KeyPoint) == 28, "cv::KeyPoint layout");
+
+static void mat_init(cv::Mat *m, unsigned char *data, int rows, int cols, size_t pitch)
+{
+    memset(m, 0, sizeof(*m));
+    m->flags = 0x42FF0000;  // MAGIC_VAL | CV_8UC1 (continuity flag not set)
+    m->dims = 2; m->rows = rows; m->cols = cols; m->data = data;
+    m->datastart = data; m->dataend = m->datalimit = data + pitch * rows;
+    m->size_p = &m->rows; m->step_p = m->step_buf;
+    m->step_buf[0] = pitch; m->step_buf[1] = 1;
+}
+
+// ---- substitutes for the few OpenCV entry points the executed reference code reaches
+static int g_mode = 0;  // 0: record fastAtan2 args; 1: real polynomial
+static std::vector<float> g_atan_rec;
+struct FastCall { const unsigned char *p; int w, h, th, nonmax; };
+static std::vector<FastCall> g_fast_calls;
+static int g_fast_mode = 0;  // 0: record + synthetic (force empty at ini threshold optional), 1: real
+static int g_force_retry = 0;
+
+float cv::fastAtan2(float y, float x)
+{
+    if (g_mode == 0) { g_atan_rec.push_back(y); g_atan_rec.push_back(x); return 0.f; }
+    return orc_fast_atan2(y, x);
+}
+void cv::fastFree(void *) {}
+void cv::Mat::deallocate() {}
+cv::Mat::Mat(const Mat &m, const Range &rr, const Range &cr)
+{
+    memcpy((void *)this, &m, sizeof(Mat));
+    size_p = &rows; step_p = step_buf; u = nullptr;
+    if (!(rr.start == INT_MIN && rr.end == INT_MAX)) { data += step_buf[0] * rr.start; rows = rr.end - rr.start; }
+    if (!(cr.start == INT_MIN && cr.end == INT_MAX)) { data += (size_t)cr.start; cols = cr.end - cr.start; }
+}
+void cv::FAST(const _InputArray &arr, std::vector<KeyPoint> &kps, int th, bool nonmax)
+{
+    const Mat *m = (const Mat *)arr.obj;
+    FastCall c;
+    c.p = m->data;  // decoded to (level, x, y) by the caller, which knows the planes
+    c.w = m->cols; c.h = m->rows; c.th = th; c.nonmax = nonmax;
+    g_fast_calls.push_back(c);
+    kps.clear();
+    if (g_fast_mode == 0) {
+        if (g_force_retry && th > 10) return;  // pretend the ini-threshold call found nothing
+        KeyPoint k = {3.f, 3.f, 7.f, -1.f, 30.f, 0, -1};
+        kps.push_back(k);
+        return;
+    }
+    std::vector<orc_keypoint> tmp(4096);
+    int n = orc_fast9_16(m->data, m->cols, m->rows, (ptrdiff_t)m->step_buf[0], th, tmp.data(), 4096);
+    for (int i = 0; i < n && i < 4096; i++) {
+        KeyPoint k = {tmp[i].x, tmp[i].y, tmp[i].size, tmp[i].angle, tmp[i].response, tmp[i].octave, tmp[i].class_id};
+        kps.push_back(k);
+    }
+}
+
+// ---------------------------------------------------------------- look-alike reference classes
+namespace ORB_SLAM2 {
+class ORBextractor {
+public:
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    std::vector<cv::KeyPoint> DistributeOctTree(const std::vector<cv::KeyPoint> &, const int &, const int &,
+                                                const int &, const int &, const int &, const int &);
+    void ComputeKeyPointsOctTree(std::vector<std::vector<cv::KeyPoint>> &);
+    char storage[1024];
+};
+class ORBmatcher {
+public:
+    ORBmatcher(float nnratio, bool checkOri);
+    static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
+    float RadiusByViewingCos(const float &);
+    void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
+    static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
+    char storage[64];
+};
+}  // namespace ORB_SLAM2
+
+// ---------------------------------------------------------------- shared PRNG (same LCG in tests/refgen.py)
+static uint64_t g_rng = 1;
+static void rng_seed(uint64_t s) { g_rng = s; }
+static uint32_t rng_u32() { g_rng = g_rng * 6364136223846793005ULL + 1442695040888963407ULL; return (uint32_t)(g_rng >> 32); }
+static uint32_t rng_below(uint32_t n) { return (uint32_t)(((uint64_t)rng_u32() * n) >> 32); }
+
+template <class T> static std::vector<T> &vec_at(void *obj, size_t off) { return *(std::vector<T> *)((char *)obj + off); }
+
+static FILE *J;
+static void jarr_f(const char *name, const std::vector<float> &v, bool last = false)
+{
+    fprintf(J, "\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); i++) { uint32_t b; memcpy(&b, &v[i], 4); fprintf(J, "%s%u", i ? "," : "", b); }
+    fprintf(J, "]%s", last ? "" : ", ");
+}
+static void jarr_i(const char *name, const std::vector<int> &v, bool last = false)
+{
+    fprintf(J, "\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); i++) fprintf(J, "%s%d", i ? "," : "", v[i]);
+    fprintf(J, "]%s", last ? "" : ", ");
+}
+
+// synthetic image shared with tests (LCG blocks + noise) -- generator mirrored in tests/refgen.py
+static void synth_image(uint64_t seed, int w, int h, std::vector<unsigned char> &img)
+{
+    img.assign((size_t)w * h, 0);
+    rng_seed(seed);
+    unsigned base = 96 + rng_below(64);
+    for (size_t i = 0; i < img.size(); i++) img[i] = (unsigned char)base;
+    int nrect = 40 + (int)rng_below(40);
+    for (int r = 0; r < nrect; r++) {
+        int x0 = (int)rng_below(w), y0 = (int)rng_below(h);
+        int rw = 8 + (int)rng_below(w / 4), rh = 8 + (int)rng_below(h / 4);
+        unsigned char v = (unsigned char)rng_below(256);
+        for (int y = y0; y < y0 + rh && y < h; y++)
+            for (int x = x0; x < x0 + rw && x < w; x++) img[(size_t)y * w + x] = v;
+    }
+    for (size_t i = 0; i < img.size(); i++) {
+        int v = img[i] + (int)rng_below(9) - 4;
+        img[i] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const char *outdir = argc > 1 ? argv[1] : ".";
+    using namespace ORB_SLAM2;
+    std::string path;
+
+    // ------------------------------------------------------------ A1: ctor tables
+    path = std::string(outdir) + "/ref_orb_tables.json";
+    J = fopen(path.c_str(), "w");
+    fprintf(J, "{\"_doc\": \"ORBextractor ctor executed from the reference binary; floats as uint32 bit patterns\", \"cases\": [\n");
+    struct { int nf; float sf; int nl; } cfgs[] = {{1000, 1.2f, 8}, {2000, 1.2f, 8}, {4000, 1.2f, 8}, {500, 1.2f, 8},
+                                                    {1500, 1.5f, 5}, {1200, 1.1f, 12}, {300, 2.0f, 4}, {1000, 1.2f, 1}};
+    for (size_t c = 0; c < sizeof(cfgs) / sizeof(cfgs[0]); c++) {
+        ORBextractor *e = new ORBextractor(cfgs[c].nf, cfgs[c].sf, cfgs[c].nl, 20, 7);
+        fprintf(J, "{\"nfeatures\": %d, \"scaleFactor_bits\": %u, \"nlevels\": %d, ", cfgs[c].nf,
+                *(uint32_t *)&cfgs[c].sf, cfgs[c].nl);
+        jarr_i("perLevel", vec_at<int>(e, 0x50));
+        jarr_i("umax", vec_at<int>(e, 0x68));
+        jarr_f("scale", vec_at<float>(e, 0x80));
+        jarr_f("inv", vec_at<float>(e, 0x98));
+        jarr_f("sigma2", vec_at<float>(e, 0xb0));
+        jarr_f("invsigma2", vec_at<float>(e, 0xc8), true);
+        fprintf(J, "}%s\n", c + 1 < sizeof(cfgs) / sizeof(cfgs[0]) ? "," : "");
+        if (c == 0) {  // pattern copy inside the object must equal the .data table
+            std::vector<int> &pat = vec_at<int>(e, 0x18);  // vector<cv::Point> viewed as ints
+            FILE *pf = fopen((std::string(outdir) + "/ref_pattern_from_ctor.bin").c_str(), "wb");
+            fwrite(pat.data(), 4, 1024, pf);
+            fclose(pf);
+        }
+    }
+    fprintf(J, "]}\n");
+    fclose(J);
+
+    // ------------------------------------------------------------ A2: DistributeOctTree
+    path = std::string(outdir) + "/ref_octree_cases.json";
+    J = fopen(path.c_str(), "w");
+    fprintf(J, "{\"_doc\": \"DistributeOctTree executed from the reference binary under a monotonic allocator. "
+               "Inputs are regenerated from the LCG (tests/refgen.py: octree_case); out = class_id (input index) of each returned keypoint, in order\", \"cases\": [\n");
+    ORBextractor *ex = new ORBextractor(1000, 1.2f, 8, 20, 7);
+    const int NOCT = 48;
+    for (int c = 0; c < NOCT; c++) {
+        arena_reset();
+        ex = new ORBextractor(1000, 1.2f, 8, 20, 7);
+        rng_seed(1000 + c);
+        int W = 64 + (int)rng_below(1200), H = 48 + (int)rng_below(900);
+        if (W < H) { int t = W; W = H; H = t; }          // landscape (portrait > 2:1 divides by zero in the reference)
+        int nk = 1 + (int)rng_below(c % 4 == 0 ? 60 : 3500);
+        int N = 1 + (int)rng_below(450);
+        int resp_levels = (c % 3 == 0) ? 4 : 200;          // tie-heavy vs tie-light responses
+        int cluster = (c % 5 == 1);
+        std::vector<cv::KeyPoint> in(nk);
+        for (int i = 0; i < nk; i++) {
+            int x, y;
+            if (cluster) { x = (int)rng_below(W / 4 + 1) + (int)rng_below(2) * (W / 2); y = (int)rng_below(H / 3 + 1); }
+            else { x = (int)rng_below(W); y = (int)rng_below(H); }
+            if (x >= W) x = W - 1;
+            cv::KeyPoint k = {(float)x, (float)y, 7.f, -1.f, (float)(7 + rng_below(resp_levels)), 0, i};
+            in[i] = k;
+        }
+        int minX = 16, maxX = 16 + W, minY = 16, maxY = 16 + H, lvl = 0;
+        std::vector<cv::KeyPoint> out = ex->DistributeOctTree(in, minX, maxX, minY, maxY, N, lvl);
+        std::vector<int> ids(out.size());
+        for (size_t i = 0; i < out.size(); i++) ids[i] = out[i].class_id;
+        fprintf(J, "{\"seed\": %d, \"W\": %d, \"H\": %d, \"nk\": %d, \"N\": %d, \"resp_levels\": %d, \"cluster\": %d, ", 1000 + c, W, H, nk,
+                N, resp_levels, cluster);
+        jarr_i("out", ids, true);
+        fprintf(J, "}%s\n", c + 1 < NOCT ? "," : "");
+    }
+    fprintf(J, "]}\n");
+    fclose(J);
+
+    // ------------------------------------------------------------ A3: computeOrientation integer moments
+    {
+        struct link_map *lm = nullptr;
+        void *h = dlopen("libORB_SLAM2.so", RTLD_LAZY | RTLD_NOLOAD);
+        if (!h) h = dlopen("/root/reference/lib/libORB_SLAM2.so", RTLD_LAZY);
+        dlinfo(h, RTLD_DI_LINKMAP, &lm);
+        typedef void (*orient_fn)(const cv::Mat &, std::vector<cv::KeyPoint> &, const std::vector<int> &);
+        orient_fn computeOrientation = (orient_fn)((char *)lm->l_addr + 0x6fb10);
+        path = std::string(outdir) + "/ref_ic_moments.json";
+        J = fopen(path.c_str(), "w");
+        fprintf(J, "{\"_doc\": \"computeOrientation (so@0x6fb10) executed with a recording cv::fastAtan2: (m01,m10) per keypoint; images from tests/refgen.py: synth_image\", \"cases\": [\n");
+        std::vector<int> &umax = vec_at<int>(ex, 0x68);
+        for (int c = 0; c < 6; c++) {
+            int w = 96 + 16 * c, hh = 80 + 8 * c;
+            std::vector<unsigned char> img;
+            synth_image(7000 + c, w, hh, img);
+            cv::Mat m; mat_init(&m, img.data(), hh, w, w);
+            rng_seed(7100 + c);
+            std::vector<cv::KeyPoint> kps;
+            std::vector<int> xs, ys;
+            for (int i = 0; i < 40; i++) {
+                int x = 16 + (int)rng_below(w - 32), y = 16 + (int)rng_below(hh - 32);
+                cv::KeyPoint k = {(float)x, (float)y, 31.f, -1.f, 20.f, 0, i};
+                kps.push_back(k); xs.push_back(x); ys.push_back(y);
+            }
+            g_mode = 0; g_atan_rec.clear();
+            computeOrientation(m, kps, umax);
+            std::vector<int> m01, m10;
+            for (size_t i = 0; i + 1 < g_atan_rec.size(); i += 2) { m01.push_back((int)g_atan_rec[i]); m10.push_back((int)g_atan_rec[i + 1]); }
+            fprintf(J, "{\"seed\": %d, \"w\": %d, \"h\": %d, \"pt_seed\": %d, ", 7000 + c, w, hh, 7100 + c);
+            jarr_i("x", xs); jarr_i("y", ys); jarr_i("m01", m01); jarr_i("m10", m10, true);
+            fprintf(J, "}%s\n", c + 1 < 6 ? "," : "");
+        }
+        fprintf(J, "]}\n");
+        fclose(J);
+    }
+
+    // ------------------------------------------------------------ A4: matcher scalars
+    {
+        path = std::string(outdir) + "/ref_matcher.json";
+        J = fopen(path.c_str(), "w");
+        ORBmatcher *mt = new ORBmatcher(0.8f, true);
+        fprintf(J, "{\"_doc\": \"ORBmatcher constants and pure functions executed from the reference binary\",\n");
+        fprintf(J, "\"TH_LOW\": %d, \"TH_HIGH\": %d, \"HISTO_LENGTH\": %d,\n", ORBmatcher::TH_LOW, ORBmatcher::TH_HIGH, ORBmatcher::HISTO_LENGTH);
+        std::vector<float> cs = {1.0f, 0.9999f, 0.9981f, 0.998f, 0.99799f, 0.99f, 0.5f, 0.0f, -1.0f}, rs;
+        for (float c : cs) rs.push_back(mt->RadiusByViewingCos(c));
+        jarr_f("radius_cos", cs); jarr_f("radius", rs);
+        // Hamming
+        fprintf(J, "\n\"hamming\": [");
+        rng_seed(4242);
+        for (int c = 0; c < 64; c++) {
+            unsigned char a[32], b[32];
+            for (int i = 0; i < 32; i++) { a[i] = (unsigned char)rng_below(256); b[i] = (c % 4 == 0) ? (unsigned char)(a[i] ^ (1u << rng_below(8))) : (unsigned char)rng_below(256); }
+            if (c == 0) memcpy(b, a, 32);
+            if (c == 1) for (int i = 0; i < 32; i++) b[i] = (unsigned char)~a[i];
+            cv::Mat ma, mb; mat_init(&ma, a, 1, 32, 32); mat_init(&mb, b, 1, 32, 32);
+            int d = ORBmatcher::DescriptorDistance(ma, mb);
+            fprintf(J, "%s{\"a\": \"", c ? "," : "");
+            for (int i = 0; i < 32; i++) fprintf(J, "%02x", a[i]);
+            fprintf(J, "\", \"b\": \"");
+            for (int i = 0; i < 32; i++) fprintf(J, "%02x", b[i]);
+            fprintf(J, "\", \"d\": %d}", d);
+        }
+        fprintf(J, "],\n\"three_maxima\": [");
+        rng_seed(999);
+        for (int c = 0; c < 200; c++) {
+            std::vector<int> histo[30];
+            std::vector<int> sizes;
+            int mode = c % 4;
+            for (int b = 0; b < 30; b++) {
+                int n = mode == 0 ? (int)rng_below(50) : mode == 1 ? (int)rng_below(4) : mode == 2 ? ((int)rng_below(10) == 0 ? 100 + (int)rng_below(3) : (int)rng_below(8)) : (int)rng_below(200);
+                histo[b].assign(n, 0); sizes.push_back(n);
+            }
+            int i1 = -1, i2 = -1, i3 = -1;
+            mt->ComputeThreeMaxima(histo, 30, i1, i2, i3);
+            fprintf(J, "%s{", c ? "," : "");
+            jarr_i("sizes", sizes);
+            fprintf(J, "\"ind\": [%d,%d,%d]}", i1, i2, i3);
+        }
+        fprintf(J, "]}\n");
+        fclose(J);
+    }
+
+    // ------------------------------------------------------------ B: ComputeKeyPointsOctTree (glue)
+    {
+        path = std::string(outdir) + "/ref_cells.json";
+        FILE *JC = fopen(path.c_str(), "w");
+        fprintf(JC, "{\"_doc\": \"cv::FAST call rectangles issued by the reference ComputeKeyPointsOctTree (so@0x75fa0), interior coords, per level\", \"cases\": [\n");
+        path = std::string(outdir) + "/ref_glue_keypoints.json";
+        FILE *JG = fopen(path.c_str(), "w");
+        fprintf(JG, "{\"_doc\": \"ComputeKeyPointsOctTree from the reference binary on a pyramid built by oracle/orb_oracle.c from tests/refgen.py:synth_image, cv::FAST/fastAtan2 = this repo's restatement. per level: x,y,size,angle,response bit patterns\", \"cases\": [\n");
+        struct { int w, h, nf; uint64_t seed; } gc[] = {{640, 480, 1000, 9001}, {1280, 960, 4000, 9002}, {320, 240, 500, 9003}, {752, 480, 1200, 9004}};
+        const int NG = 4;
+        for (int c = 0; c < NG; c++) {
+            arena_reset();
+            ORBextractor *e = new ORBextractor(gc[c].nf, 1.2f, 8, 20, 7);
+            std::vector<unsigned char> img;
+            synth_image(gc[c].seed, gc[c].w, gc[c].h, img);
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(gc[c].nf, 1.2f, 8, scale, inv, s2, is2, per, um);
+            uint8_t *planes[16]; int lw[16], lh[16];
+            orc_compute_pyramid(img.data(), gc[c].w, gc[c].h, gc[c].w, 8, inv, planes, lw, lh);
+            cv::Mat *mats = (cv::Mat *)bump(sizeof(cv::Mat) * 8);
+            for (int l = 0; l < 8; l++) {
+                size_t pp = lw[l] + 38;
+                mat_init(&mats[l], planes[l] + 19 * pp + 19, lh[l], lw[l], pp);
+            }
+            void **vec = (void **)e;  // mvImagePyramid is the first member (offset 0 of the object)
+            vec[0] = mats; vec[1] = mats + 8; vec[2] = mats + 8;
+            for (int pass = 0; pass < 3; pass++) {
+                // pass 0: recorder (every call returns 1 kp), pass 1: recorder with forced retry, pass 2: real FAST
+                // The per-level base pointer is needed to decode the rectangles, so hook through a wrapper:
+                g_fast_calls.clear();
+                g_fast_mode = pass == 2 ? 1 : 0; g_force_retry = pass == 1; g_mode = 1;
+                std::vector<std::vector<cv::KeyPoint>> all;
+                e->ComputeKeyPointsOctTree(all);
+                if (pass < 2) {
+                    fprintf(JC, "{\"w\": %d, \"h\": %d, \"force_retry\": %d, \"levels\": [", gc[c].w, gc[c].h, pass);
+                    // re-decode rectangles per level
+                    std::vector<std::vector<int>> rects(8);
+                    for (const FastCall &fc : g_fast_calls) {
+                        const unsigned char *p = fc.p;
+                        for (int l = 0; l < 8; l++) {
+                            size_t pp = lw[l] + 38;
+                            const unsigned char *lo = planes[l], *hi = planes[l] + pp * (lh[l] + 38);
+                            if (p >= lo && p < hi) {
+                                ptrdiff_t off = p - (planes[l] + 19 * pp + 19);
+                                int yy = (int)floor((double)off / (double)pp); int xx = (int)(off - (ptrdiff_t)yy * (ptrdiff_t)pp);
+                                rects[l].push_back(xx); rects[l].push_back(yy); rects[l].push_back(fc.w); rects[l].push_back(fc.h);
+                                rects[l].push_back(fc.th); rects[l].push_back(fc.nonmax);
+                                break;
+                            }
+                        }
+                    }
+                    for (int l = 0; l < 8; l++) {
+                        fprintf(JC, "%s[", l ? "," : "");
+                        for (size_t i = 0; i < rects[l].size(); i++) fprintf(JC, "%s%d", i ? "," : "", rects[l][i]);
+                        fprintf(JC, "]");
+                    }
+                    fprintf(JC, "]}%s\n", (c + 1 < NG || pass < 1) ? "," : "");
+                } else {
+                    fprintf(JG, "{\"seed\": %llu, \"w\": %d, \"h\": %d, \"nfeatures\": %d, \"levels\": [", (unsigned long long)gc[c].seed, gc[c].w, gc[c].h, gc[c].nf);
+                    for (int l = 0; l < 8; l++) {
+                        std::vector<float> flat;
+                        for (const cv::KeyPoint &k : all[l]) { flat.push_back(k.x); flat.push_back(k.y); flat.push_back(k.size); flat.push_back(k.angle); flat.push_back(k.response); }
+                        fprintf(JG, "%s{", l ? "," : "");
+                        J = JG;
+                        jarr_f("kp", flat, true);
+                        fprintf(JG, "}");
+                    }
+                    fprintf(JG, "]}%s\n", c + 1 < NG ? "," : "");
+                }
+            }
+            for (int l = 0; l < 8; l++) free(planes[l]);
+        }
+        fprintf(JC, "]}\n"); fclose(JC);
+        fprintf(JG, "]}\n"); fclose(JG);
+    }
+    printf("refprobe: fixtures written to %s\n", outdir);
+    return 0;
+}

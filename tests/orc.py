@@ -1,0 +1,152 @@
+"""ctypes bindings of the CPU oracle (oracle/liborc.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
+                     ("response", "<f4"), ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"),
+                     ("endPointX", "<f4"), ("endPointY", "<f4"), ("sPointInOctaveX", "<f4"), ("sPointInOctaveY", "<f4"),
+                     ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"), ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+assert KP_DTYPE.itemsize == 28 and KL_DTYPE.itemsize == 68
+
+
+class OrbDebug(C.Structure):
+    _fields_ = [("want_planes", C.c_int), ("ncand", C.c_int * 16), ("nsel", C.c_int * 16), ("ncells", C.c_int * 16),
+                ("lw", C.c_int * 16), ("lh", C.c_int * 16), ("pyr", C.c_void_p * 16), ("blur", C.c_void_p * 16),
+                ("level_kps", C.c_void_p * 16)]
+
+
+class LsdDebug(C.Structure):
+    _fields_ = [("want_maps", C.c_int), ("sw", C.c_int), ("sh", C.c_int), ("nregions", C.c_int), ("min_reg_size", C.c_int),
+                ("max_grad", C.c_double), ("scaled", C.c_void_p), ("angles", C.c_void_p), ("modgrad", C.c_void_p),
+                ("used", C.c_void_p)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("n", C.c_int), ("ux", C.c_void_p), ("uy", C.c_void_p), ("octave", C.c_void_p), ("uright", C.c_void_p),
+                ("desc", C.c_void_p), ("angle", C.c_void_p), ("minx", C.c_float), ("miny", C.c_float), ("maxx", C.c_float),
+                ("maxy", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
+                ("nlevels", C.c_int)]
+
+
+class MapPoints(C.Structure):
+    _fields_ = [("m", C.c_int), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p),
+                ("level", C.c_void_p), ("view_cos", C.c_void_p), ("in_view", C.c_void_p), ("desc", C.c_void_p),
+                ("obs_positive", C.c_void_p)]
+
+
+class LastFrame(C.Structure):
+    _fields_ = [("n", C.c_int), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("xw", C.c_void_p), ("octave", C.c_void_p),
+                ("angle", C.c_void_p), ("mp_desc", C.c_void_p)]
+
+
+class LineFrame(C.Structure):
+    _fields_ = [("n", C.c_int), ("pt_x", C.c_void_p), ("pt_y", C.c_void_p), ("angle", C.c_void_p), ("octave", C.c_void_p),
+                ("desc", C.c_void_p), ("scale_factors", C.c_void_p)]
+
+
+class MapLines(C.Structure):
+    _fields_ = [("m", C.c_int), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
+                ("level", C.c_void_p), ("view_cos", C.c_void_p), ("in_view", C.c_void_p), ("desc", C.c_void_p)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
+        _lib.orc_fast_atan2.restype = C.c_float
+        _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.orc_radius_by_viewing_cos.restype = C.c_float
+        _lib.orc_radius_by_viewing_cos.argtypes = [C.c_float]
+        _lib.orc_ic_angle.restype = C.c_float
+        _lib.orc_free.argtypes = [C.c_void_p]
+    return _lib
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def orb_tables(nfeatures, scale_factor, nlevels):
+    L = lib()
+    sc = np.zeros(16, np.float32); inv = np.zeros(16, np.float32); s2 = np.zeros(16, np.float32); is2 = np.zeros(16, np.float32)
+    per = np.zeros(16, np.int32); umax = np.zeros(16, np.int32)
+    L.orc_orb_tables(C.c_int(nfeatures), C.c_float(scale_factor), C.c_int(nlevels), p(sc), p(inv), p(s2), p(is2), p(per), p(umax))
+    return dict(scale=sc[:nlevels], inv=inv[:nlevels], sigma2=s2[:nlevels], invsigma2=is2[:nlevels], perLevel=per[:nlevels], umax=umax)
+
+
+def distribute_octree(kps, minX, maxX, minY, maxY, N):
+    L = lib()
+    kin = np.zeros(len(kps), KP_DTYPE)
+    kin["x"] = kps[:, 0]; kin["y"] = kps[:, 1]; kin["response"] = kps[:, 2]; kin["size"] = 7; kin["angle"] = -1
+    kin["class_id"] = np.arange(len(kps))
+    out = np.zeros(len(kps) + 8, KP_DTYPE)
+    n = L.orc_distribute_octree(p(kin), C.c_int(len(kps)), C.c_int(minX), C.c_int(maxX), C.c_int(minY), C.c_int(maxY),
+                                C.c_int(N), p(out), C.c_int(len(out)))
+    return out[:n]
+
+
+def orb_extract(gray, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, debug=False):
+    L = lib()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    cap = nfeatures * 2 + 512
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    dbg = OrbDebug(); dbg.want_planes = 1 if debug else 0
+    n = L.orc_orb_extract(p(gray), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(nfeatures), C.c_float(scale_factor),
+                          C.c_int(nlevels), C.c_int(ini_th), C.c_int(min_th), p(kps), p(desc), C.c_int(cap), C.byref(dbg))
+    assert 0 <= n <= cap
+    res = dict(kps=kps[:n].copy(), desc=desc[:n].copy(), ncand=list(dbg.ncand[:nlevels]), nsel=list(dbg.nsel[:nlevels]),
+               ncells=list(dbg.ncells[:nlevels]), lw=list(dbg.lw[:nlevels]), lh=list(dbg.lh[:nlevels]))
+    if debug:
+        res["pyr"], res["blur"], res["level_kps"] = [], [], []
+        for l in range(nlevels):
+            lw, lh = dbg.lw[l], dbg.lh[l]
+            buf = (C.c_uint8 * ((lw + 38) * (lh + 38))).from_address(dbg.pyr[l])
+            res["pyr"].append(np.frombuffer(buf, np.uint8).reshape(lh + 38, lw + 38).copy())
+            buf = (C.c_uint8 * (lw * lh)).from_address(dbg.blur[l])
+            res["blur"].append(np.frombuffer(buf, np.uint8).reshape(lh, lw).copy())
+            ns = dbg.nsel[l]
+            if ns > 0:
+                buf = (C.c_uint8 * (28 * ns)).from_address(dbg.level_kps[l])
+                res["level_kps"].append(np.frombuffer(buf, KP_DTYPE).copy())
+            else:
+                res["level_kps"].append(np.zeros(0, KP_DTYPE))
+            L.orc_free(dbg.pyr[l]); L.orc_free(dbg.blur[l]); L.orc_free(dbg.level_kps[l])
+    return res
+
+
+def lsd_detect(gray, seed_order=0, maps=False):
+    L = lib()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    cap = 1 << 15
+    lines = np.zeros((cap, 4), np.float32)
+    dbg = LsdDebug(); dbg.want_maps = 1 if maps else 0
+    n = L.orc_lsd_detect(p(gray), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(seed_order), p(lines), C.c_int(cap), C.byref(dbg))
+    res = dict(lines=lines[:n].copy(), sw=dbg.sw, sh=dbg.sh, nregions=dbg.nregions, min_reg_size=dbg.min_reg_size, max_grad=dbg.max_grad)
+    if maps:
+        npx = dbg.sw * dbg.sh
+        for name, ct, dt in (("scaled", C.c_double, np.float64), ("angles", C.c_double, np.float64), ("modgrad", C.c_double, np.float64), ("used", C.c_uint8, np.uint8)):
+            addr = getattr(dbg, name)
+            res[name] = np.frombuffer((ct * npx).from_address(addr), dt).reshape(dbg.sh, dbg.sw).copy()
+            L.orc_free(addr)
+    return res
+
+
+def line_extract(gray, nkeep=100, seed_order=0):
+    L = lib()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    cap = nkeep
+    kl = np.zeros(cap, KL_DTYPE); desc = np.zeros((cap, 32), np.uint8); eq = np.zeros((cap, 3), np.float64)
+    nd = C.c_int(0)
+    n = L.orc_line_extract(p(gray), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(nkeep), C.c_int(seed_order), p(kl), p(desc),
+                           p(eq), C.c_int(cap), C.byref(nd))
+    return dict(kl=kl[:n].copy(), desc=desc[:n].copy(), eq=eq[:n].copy(), ndetected=nd.value)

@@ -1,0 +1,71 @@
+"""Deterministic input generators shared with oracle/refprobe/probe.cpp (same 64-bit LCG), so that
+the golden fixtures under tests/golden/ only need to store OUTPUTS of the reference binary."""
+import numpy as np
+
+_A = 6364136223846793005
+_C = 1442695040888963407
+_M = (1 << 64) - 1
+
+
+class LCG:
+    def __init__(self, seed):
+        self.s = seed & _M
+
+    def u32(self):
+        self.s = (self.s * _A + _C) & _M
+        return self.s >> 32
+
+    def below(self, n):
+        return (self.u32() * n) >> 32
+
+    def vec_u32(self, count):
+        """next `count` outputs, vectorised (uint64 wrap-around arithmetic)."""
+        if count == 0:
+            return np.zeros(0, np.uint64)
+        with np.errstate(over="ignore"):
+            a = np.full(count, _A, np.uint64)
+            A = np.multiply.accumulate(a)                      # a^(i+1)
+            Ash = np.concatenate(([np.uint64(1)], A[:-1]))     # a^i
+            S = np.add.accumulate(Ash)                         # 1 + a + ... + a^i
+            st = A * np.uint64(self.s) + S * np.uint64(_C)
+        self.s = int(st[-1])
+        return st >> np.uint64(32)
+
+    def vec_below(self, n, count):
+        return (self.vec_u32(count) * np.uint64(n)) >> np.uint64(32)
+
+
+def synth_image(seed, w, h):
+    """mirror of probe.cpp:synth_image"""
+    g = LCG(seed)
+    base = 96 + g.below(64)
+    img = np.full((h, w), base, np.int32)
+    nrect = 40 + g.below(40)
+    for _ in range(nrect):
+        x0 = g.below(w); y0 = g.below(h)
+        rw = 8 + g.below(w // 4); rh = 8 + g.below(h // 4)
+        v = g.below(256)
+        img[y0:min(y0 + rh, h), x0:min(x0 + rw, w)] = v
+    noise = g.vec_below(9, w * h).astype(np.int32).reshape(h, w) - 4
+    return np.clip(img + noise, 0, 255).astype(np.uint8)
+
+
+def octree_case(seed, cluster, resp_levels):
+    """mirror of the DistributeOctTree case generator in probe.cpp. Returns (W,H,N,kps[nk,3]=x,y,response)"""
+    g = LCG(seed)
+    W = 64 + g.below(1200); H = 48 + g.below(900)
+    if W < H:
+        W, H = H, W
+    c = seed - 1000
+    nk = 1 + g.below(60 if c % 4 == 0 else 3500)
+    N = 1 + g.below(450)
+    k = np.zeros((nk, 3), np.float32)
+    for i in range(nk):
+        if cluster:
+            x = g.below(W // 4 + 1) + g.below(2) * (W // 2); y = g.below(H // 3 + 1)
+        else:
+            x = g.below(W); y = g.below(H)
+        if x >= W:
+            x = W - 1
+        k[i] = (x, y, 7 + g.below(resp_levels))
+    return W, H, N, k
