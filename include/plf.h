@@ -1,0 +1,240 @@
+/*
+ * plf.h -- C ABI of the MI355X-native point+line feature front-end ("plf") for RGB-D PL-SLAM.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: the hot path sits
+ * behind C++ member calls, so every entry point below names the reference interface it replaces
+ * (file:line under /root/reference).  Plain pointers and sizes only; no OpenCV, torch or C++ types.
+ * INTEGRATION.md shows the adapter a maintainer adds on the reference side
+ * (ORB_SLAM2::ORBextractor::operator() etc. forwarding to these calls).
+ *
+ * Memory kinds: every image/feature pointer is either host memory (PLF_MEM_HOST) or device (HBM)
+ * memory of the handle's GPU (PLF_MEM_DEVICE).  `stream` arguments are hipStream_t passed as void*
+ * (NULL = the handle's own stream).  Calls with device-resident inputs AND outputs only enqueue work
+ * (asynchronous); calls touching host memory synchronise before returning.
+ *
+ * Error handling: 0 on success, negative plf_status otherwise; no exceptions cross this boundary
+ * (the reference asserts or returns silently: include/ORBextractor.h:58-61, so@0x76dda).
+ * Threading: a handle is confined to one thread at a time; different handles are independent
+ * (PL-SLAM forks run ORB and LSD extraction concurrently from two threads).
+ */
+#ifndef PLF_H
+#define PLF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PLF_OK = 0,
+    PLF_E_EMPTY = -1,    /* empty image: outputs untouched (reference: silent return) */
+    PLF_E_BADARG = -2,   /* unsupported size / parameter (reference: assert or UB) */
+    PLF_E_CAPACITY = -3, /* caller's output capacity too small; outputs truncated */
+    PLF_E_HIP = -4,      /* HIP runtime failure (no device, launch error, ...) */
+    PLF_E_NOMEM = -5
+} plf_status;
+
+enum { PLF_MEM_HOST = 0, PLF_MEM_DEVICE = 1 };
+
+/* bit-compatible with cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } plf_keypoint;
+
+/* field order of cv::line_descriptor::KeyLine (68 bytes) */
+typedef struct {
+    float angle; int32_t class_id; int32_t octave; float pt_x, pt_y; float response; float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength; int32_t numOfPixels;
+} plf_keyline;
+
+/* cv::DMatch */
+typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } plf_dmatch;
+
+const char *plf_version(void);
+const char *plf_status_string(int status);
+int plf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORB extractor -- replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:44-112)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct plf_orb plf_orb;
+
+typedef struct {
+    int32_t nfeatures;    /* ORBextractor.nFeatures   (Examples/RGB-D/TUM1.yaml:42) */
+    float scale_factor;   /* ORBextractor.scaleFactor (TUM1.yaml:45) */
+    int32_t nlevels;      /* ORBextractor.nLevels     (TUM1.yaml:48) */
+    int32_t ini_th_fast;  /* ORBextractor.iniThFAST   (TUM1.yaml:54) */
+    int32_t min_th_fast;  /* ORBextractor.minThFAST   (TUM1.yaml:55) */
+    int32_t device;       /* HIP device ordinal */
+    int32_t max_width, max_height; /* largest image the handle must accept */
+    int32_t max_batch;    /* frames in flight per call (>= 1) */
+} plf_orb_params;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  include/ORBextractor.h:51-52 */
+int plf_orb_create(const plf_orb_params *params, plf_orb **out);
+void plf_orb_destroy(plf_orb *h);
+
+/* GetLevels/GetScaleFactor(s)/GetInverseScaleFactors/GetScaleSigmaSquares/GetInverseScaleSigmaSquares
+ * include/ORBextractor.h:63-83; per_level = mnFeaturesPerLevel.  Arrays of nlevels entries; any may be NULL. */
+int plf_orb_get_tables(const plf_orb *h, int32_t *nlevels, float *scale, float *inv_scale, float *sigma2,
+                       float *inv_sigma2, int32_t *per_level);
+
+/* Required output capacity (keypoints per frame) for this handle: nfeatures + 4 * nlevels. */
+int plf_orb_capacity(const plf_orb *h);
+
+/* void ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>&, OutputArray descriptors)
+ * include/ORBextractor.h:59-61 -- single frame, host memory in and out (mask is ignored by the reference).
+ * gray: 8-bit single channel, `pitch` bytes per row.  kps/desc: capacity entries / capacity*32 bytes. */
+int plf_orb_extract(plf_orb *h, const uint8_t *gray, int32_t width, int32_t height, ptrdiff_t pitch,
+                    plf_keypoint *kps, uint8_t *desc, int32_t capacity, int32_t *n_out);
+
+/* Same operator over a batch of independent frames (BASELINE configs 3-4).  Frame f starts at
+ * gray + f*frame_stride; its outputs at kps + f*capacity, desc + f*capacity*32, n_out[f].
+ * in_mem / out_mem: PLF_MEM_HOST or PLF_MEM_DEVICE (n_out follows out_mem). */
+int plf_orb_extract_batch(plf_orb *h, const uint8_t *gray, int32_t in_mem, int32_t n_frames, int32_t width,
+                          int32_t height, ptrdiff_t pitch, ptrdiff_t frame_stride, plf_keypoint *kps, uint8_t *desc,
+                          int32_t *n_out, int32_t out_mem, int32_t capacity, void *stream);
+
+/* Public member mvImagePyramid (include/ORBextractor.h:85): copy level `level` of frame `frame` of the last
+ * call, INCLUDING its 19-pixel REFLECT_101 border, to host memory `dst` (pitch = level width + 38). */
+int plf_orb_get_pyramid_level(plf_orb *h, int32_t frame, int32_t level, uint8_t *dst, int32_t *level_w, int32_t *level_h);
+/* Test hook: the 7x7-blurred level image the descriptors were sampled from (pitch = level width). */
+int plf_orb_get_blurred_level(plf_orb *h, int32_t frame, int32_t level, uint8_t *dst);
+/* Test hook: FAST candidates (x, y relative to the 16-px border, response) handed to DistributeOctTree, reference order. */
+int plf_orb_get_candidates(plf_orb *h, int32_t frame, int32_t level, float *xyr, int32_t capacity, int32_t *n_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Line extractor -- replaces ORB_SLAM2::LineSegment::ExtractLineSegment (include/ExtractLineSegment.h:38)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct plf_line plf_line;
+
+typedef struct {
+    int32_t nlines;      /* lines kept after sorting by response (lsdNFeatures of the fork; BASELINE: 100/200/400) */
+    int32_t seed_order;  /* 0 = OpenCV 3.0-3.3 raster seed order (default), 1 = published bin order */
+    int32_t device;
+    int32_t max_width, max_height, max_batch;
+} plf_line_params;
+
+int plf_line_create(const plf_line_params *params, plf_line **out);
+void plf_line_destroy(plf_line *h);
+
+/* void LineSegment::ExtractLineSegment(const Mat& img, vector<KeyLine>&, Mat& ldesc, vector<Vector3d>& lineFunctions,
+ *                                      int scale = 1.2, int numOctaves = 1)      include/ExtractLineSegment.h:38
+ * single frame, host memory.  ldesc: capacity*32 bytes (CV_8U rows); line_eq: capacity*3 doubles. */
+int plf_line_extract(plf_line *h, const uint8_t *gray, int32_t width, int32_t height, ptrdiff_t pitch,
+                     plf_keyline *lines, uint8_t *ldesc, double *line_eq, int32_t capacity, int32_t *n_out);
+
+int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int32_t n_frames, int32_t width,
+                           int32_t height, ptrdiff_t pitch, ptrdiff_t frame_stride, plf_keyline *lines, uint8_t *ldesc,
+                           double *line_eq, int32_t *n_out, int32_t out_mem, int32_t capacity, void *stream);
+
+/* Test hook: all LSD segments (x1,y1,x2,y2) of frame `frame` in detection order, before the top-N cut. */
+int plf_line_get_segments(plf_line *h, int32_t frame, float *segs, int32_t capacity, int32_t *n_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matchers -- replace ORB_SLAM2::ORBmatcher / LSDmatcher tracking overloads
+ * ---------------------------------------------------------------------------------------------- */
+/* static int ORBmatcher::DescriptorDistance(const Mat&, const Mat&)  include/ORBmatcher.h:44 (= LSDmatcher.h:43,
+ * Thirdparty/DBoW2/DBoW2/FORB.cpp:82-102).  Host scalar utility: 256-bit Hamming distance. */
+int plf_hamming256(const uint8_t *a, const uint8_t *b);
+/* Batched on the GPU: dist[i*nb + j] = Hamming(a_i, b_j); pointers in `mem`. */
+int plf_hamming256_matrix(const uint8_t *a, int32_t na, const uint8_t *b, int32_t nb, int32_t *dist, int32_t mem,
+                          int32_t device, void *stream);
+
+/* View of the Frame members the matchers read (include/Frame.h): all pointers device memory. */
+typedef struct {
+    int32_t n;                 /* N */
+    const plf_keypoint *keys_un; /* mvKeysUn (pt, octave, angle are read) */
+    const float *uright;       /* mvuRight, NULL = monocular (-1 everywhere) */
+    const uint8_t *desc;       /* mDescriptors, n x 32 */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    const float *scale_factors;  /* mvScaleFactors (device, nlevels) */
+    int32_t nlevels;
+} plf_frame_view;
+
+/* MapPoint tracking fields (include/MapPoint.h:94-105) flattened; device memory */
+typedef struct {
+    int32_t m;
+    const float *proj_x, *proj_y, *proj_xr; /* mTrackProjX, mTrackProjY, mTrackProjXR */
+    const int32_t *level;                   /* mnTrackScaleLevel */
+    const float *view_cos;                  /* mTrackViewCos */
+    const uint8_t *in_view;                 /* mbTrackInView && !isBad() */
+    const uint8_t *desc;                    /* GetDescriptor(), m x 32 */
+    const uint8_t *obs_positive;            /* Observations() > 0, NULL = all */
+} plf_mappoint_view;
+
+typedef struct plf_matcher plf_matcher;
+int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t max_mappoints, int32_t max_lines,
+                       int32_t max_batch, plf_matcher **out);
+void plf_matcher_destroy(plf_matcher *h);
+
+/* int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+ * include/ORBmatcher.h:61 (so@0x79f10), with F.GetFeaturesInArea include/Frame.h:113 (so@0xfbc60) and
+ * AssignFeaturesToGrid (so@0xf9120) built on the device.  Batched over n_frames frames that each
+ * match the same map-point set (replicas).
+ * match_of_kp (device, n_frames x kp_stride int32), in/out: -1 = free, -2 = already holds a MapPoint with
+ * observations; on return >= 0 = index of the map point assigned by this call.
+ * nmatches (device, n_frames int32) = the reference's return value. nnratio = mfNNratio. */
+int plf_match_project_points(plf_matcher *h, const plf_frame_view *frames /*host array of views*/, int32_t n_frames,
+                             const plf_mappoint_view *mp, float th, float nnratio, int32_t *match_of_kp,
+                             int32_t kp_stride, int32_t *nmatches, void *stream);
+
+/* LastFrame members read by the motion-model overload; device memory */
+typedef struct {
+    int32_t n;
+    const uint8_t *has_mappoint; /* mvpMapPoints[i] != NULL */
+    const uint8_t *outlier;      /* mvbOutlier[i] */
+    const float *world_pos;      /* n x 3, pMP->GetWorldPos() */
+    const plf_keypoint *keys;    /* mvKeys / mvKeysUn (octave, angle) */
+    const uint8_t *mp_desc;      /* n x 32, pMP->GetDescriptor() */
+} plf_lastframe_view;
+
+typedef struct { float Rcw[9], tcw[3], Rlw[9], tlw[3]; float fx, fy, cx, cy, bf, b; } plf_pose_pair;
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+ * include/ORBmatcher.h:78 (so@0x80d00).  match_of_kp as above (values >= 0 are last-frame indices). */
+int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last,
+                                const plf_pose_pair *pose, float th, int32_t mono, int32_t check_orientation,
+                                int32_t *match_of_kp, int32_t *nmatches, void *stream);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as used by LSDmatcher (include/LSDmatcher.h:19-35).
+ * out: nq x 2 plf_dmatch in `mem`. */
+int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const uint8_t *train, int32_t nt,
+                        plf_dmatch *out, int32_t mem, void *stream);
+
+/* int LSDmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  include/LSDmatcher.h:32
+ * with Frame::lineDescriptorMAD include/Frame.h:75.  last_has_mapline[q] = LastFrame.mvpMapLines[q] != NULL.
+ * match_of_line (device, ncur int32, pre-set to -1): last-frame line index assigned to each current line. */
+int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_desc, int32_t nlast, const uint8_t *cur_desc,
+                              int32_t ncur, const uint8_t *last_has_mapline, int32_t *match_of_line, int32_t *nmatches,
+                              void *stream);
+
+/* Frame members read by the line projection search (include/Frame.h:201-214); device memory */
+typedef struct {
+    int32_t n;
+    const plf_keyline *lines_un; /* mvKeylinesUn (pt, angle, octave) */
+    const uint8_t *desc;         /* mLdesc */
+    const float *scale_factors;
+} plf_lineframe_view;
+
+/* MapLine tracking fields include/MapLine.h:113-129 */
+typedef struct {
+    int32_t m;
+    const float *x1, *y1, *x2, *y2; /* mTrackProjX1, Y1, X2, Y2 */
+    const int32_t *level;
+    const float *view_cos;
+    const uint8_t *in_view;
+    const uint8_t *desc;
+} plf_mapline_view;
+
+/* int LSDmatcher::SearchByProjection(Frame &F, const vector<MapLine*> &vpMapLines, const float th)
+ * include/LSDmatcher.h:40 with Frame::GetLinesInArea include/Frame.h:116. */
+int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view *frames, int32_t n_frames,
+                            const plf_mapline_view *ml, float th, float nnratio, int32_t *match_of_line,
+                            int32_t line_stride, int32_t *nmatches, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLF_H */

@@ -1,0 +1,44 @@
+// orb_geom.h -- per-handle geometry of the ORB pipeline shared by host code and kernels.
+#pragma once
+#include <stdint.h>
+
+#define PLF_MAX_LEVELS 12
+#define PLF_EDGE 19        // EDGE_THRESHOLD of the reference (so@0x7609c: 19 - 3 = 16)
+#define PLF_MINB 16        // minBorderX/Y
+#define PLF_HALF_PATCH 15
+#define PLF_PATCH 31
+
+struct OrbLevel {
+    int w, h;            // level image (interior) size
+    int ppitch;          // padded plane pitch = w + 38
+    uint32_t plane_off;  // byte offset of the padded plane inside one frame's pyramid block
+    int bpitch;          // pitch of the blurred / score planes (multiple of 64)
+    uint32_t blur_off;   // byte offset inside one frame's blur block (score block uses the same offsets)
+    int ncells;          // FAST cells of this level
+    int cell_base;       // index of the first cell in the cell table
+    int wCell, hCell;
+    int quota;           // mnFeaturesPerLevel[l]
+    float scale;         // mvScaleFactor[l]
+    int size_i;          // int(31 * scale), so@0x76996
+    uint32_t pool_off;   // candidate pool: first entry inside one frame's pool block
+    uint32_t pool_cap;   // entries
+    uint32_t sel_off;    // selected keypoints: first entry inside one frame's sel block
+    uint32_t sel_cap;    // quota + 8
+    uint32_t tabx_off, taby_off;  // resize coefficient tables (levels >= 1)
+    int tile_base;       // first 64x16 score/blur tile of this level in the flattened tile list
+    int tiles_x, tiles_y;
+};
+
+struct OrbGeom {
+    int nlevels;
+    int iniTh, minTh;
+    int in_w, in_h;
+    int cells_total;
+    int tiles_total;
+    int maxsel;            // max over levels of sel_cap
+    uint32_t pyr_stride;   // bytes per frame
+    uint32_t blur_stride;  // bytes per frame
+    uint32_t pool_stride;  // entries per frame
+    uint32_t sel_stride;   // entries per frame
+    OrbLevel lv[PLF_MAX_LEVELS];
+};

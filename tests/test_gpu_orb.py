@@ -1,0 +1,107 @@
+"""GPU parity: HIP ORB extractor (through the C ABI) vs the CPU oracle, bit-exact.
+Tolerances: NONE -- integer stages (pyramid, FAST scores/cells, octree, blur, BRIEF bits) must be equal;
+float fields (x, y, size, angle, response) are compared on their bit patterns."""
+import numpy as np
+import pytest
+
+import orc
+import refgen
+from conftest import gpu_available
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not gpu_available():
+        pytest.fail("no GPU visible: the -m gpu tests need a real MI355X")
+
+
+def _compare(img, nfeatures, stages=True, ext=None):
+    from rgbd_pl_slam_amd import ORBextractor
+    h, w = img.shape
+    own = ext is None
+    if own:
+        ext = ORBextractor(nfeatures=nfeatures, max_width=w, max_height=h)
+    kps, desc = ext(img)
+    ref = orc.orb_extract(img, nfeatures=nfeatures, debug=stages)
+    if stages:
+        for l in range(8):
+            assert np.array_equal(ext.pyramid_level(0, l), ref["pyr"][l]), "pyramid level %d" % l
+            assert np.array_equal(ext.blurred_level(0, l), ref["blur"][l]), "blur level %d" % l
+            cand = ext.candidates(0, l)
+            assert len(cand) == ref["ncand"][l], "candidate count level %d: %d vs %d" % (l, len(cand), ref["ncand"][l])
+    assert len(kps) == len(ref["kps"]), "keypoint count %d vs %d" % (len(kps), len(ref["kps"]))
+    for f in ("x", "y", "size", "angle", "response"):
+        assert np.array_equal(kps[f].view(np.uint32), ref["kps"][f].view(np.uint32)), f
+    assert np.array_equal(kps["octave"], ref["kps"]["octave"])
+    assert np.array_equal(desc, ref["desc"])
+    if own:
+        ext.close()
+    return kps, desc
+
+
+def test_orb_vga_synthetic_bit_exact():
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    for seed in (0, 1):
+        _compare(synth_frame(seed), 1000)
+
+
+def test_orb_reference_fixture_images():
+    _need_gpu()
+    _compare(refgen.synth_image(9001, 640, 480), 1000)
+    _compare(refgen.synth_image(9003, 320, 240), 500)
+
+
+def test_orb_2000_features_and_odd_size():
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    _compare(synth_frame(3), 2000)
+    _compare(synth_frame(4, 752, 480), 1200)
+
+
+def test_orb_1280x960_4000():
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    _compare(synth_frame(5, 1280, 960), 4000, stages=False)
+
+
+def test_orb_flat_and_noise_images():
+    """edge cases: no corners at all (empty output), and dense noise (retry threshold, many ties)"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor
+    flat = np.full((480, 640), 128, np.uint8)
+    ext = ORBextractor(max_width=640, max_height=480)
+    kps, desc = ext(flat)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    rng = np.random.default_rng(7)
+    noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    _compare(noise, 1000, ext=ext)
+    low = (128 + rng.integers(-6, 7, (480, 640))).astype(np.uint8)   # only the minTh retry can fire
+    _compare(low, 1000, ext=ext)
+    ext.close()
+
+
+def test_orb_batch_equals_single():
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor
+    from rgbd_pl_slam_amd.synth import synth_batch
+    imgs = synth_batch(10, 4)
+    ext = ORBextractor(max_width=640, max_height=480, max_batch=4)
+    res = ext.extract_batch(imgs)
+    for f in range(4):
+        ref = orc.orb_extract(imgs[f])
+        assert np.array_equal(res[f][1], ref["desc"])
+        assert np.array_equal(res[f][0]["angle"].view(np.uint32), ref["kps"]["angle"].view(np.uint32))
+    ext.close()
+
+
+def test_orb_errors():
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor, PlfError
+    ext = ORBextractor(max_width=640, max_height=480)
+    with pytest.raises(PlfError):
+        ext(np.zeros((960, 1280), np.uint8))        # larger than the handle was created for
+    with pytest.raises(PlfError):
+        ORBextractor(max_width=40, max_height=40)   # the reference divides by zero on such sizes
+    ext.close()
