@@ -50,6 +50,8 @@ void orc_brief_descriptor(const uint8_t *blur, ptrdiff_t pitch, float x, float y
 int orc_orb_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nfeatures, float scaleFactor,
                     int nlevels, int iniTh, int minTh, orc_keypoint *kps, uint8_t *desc, int cap,
                     orc_orb_debug *dbg);
+void orc_sincosf_glibc(float y, float *sinp, float *cosp);
+long orc_sincosf_selftest(long count);
 void orc_free(void *p);
 
 /* ---- matchers (match_oracle.c) */

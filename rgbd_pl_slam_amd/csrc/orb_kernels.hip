@@ -282,8 +282,8 @@ __global__ void __launch_bounds__(256) k_blur7(const uint8_t *__restrict__ pyr, 
 //             angle = cv::fastAtan2(float(m01), float(m10)).
 //   steered BRIEF on the blurred level: lane j evaluates comparisons 4j..4j+3; sample coordinates
 //             row = cvRound(fmaf(px, b, py*a)), col = cvRound(fmaf(px, a, -(py*b))) (the reference
-//             binary contracts exactly these two FMAs), a = cosf, b = sinf of angle * 0.01745329238f
-//             (computed in double and rounded to float).
+//             binary contracts exactly these two FMAs), (b, a) = glibc sincosf(angle * 0.01745329238f),
+//             re-evaluated operation by operation in double (plf_sincosf_glibc).
 // Output layout: level-major; the offset of level l is the sum of the counts of the levels below.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
@@ -330,7 +330,8 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
     const float angle = plf_fast_atan2((float)m01, (float)m10);
     // steered BRIEF
     const float arad = angle * 0.01745329238f;
-    const float a = (float)cos((double)arad), b = (float)sin((double)arad);
+    float a, b;
+    plf_sincosf_glibc(arad, &b, &a);  // a = cos, b = sin, as glibc's sincosf returns them (so@0x77803)
     const uint8_t *bc = blur + (size_t)f * g.blur_stride + L.blur_off + (size_t)y * L.bpitch + x;
     uint32_t bits = 0;
     const signed char *pat = c_pattern + lane * 16;
