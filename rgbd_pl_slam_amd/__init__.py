@@ -3,3 +3,4 @@ behind the call shapes of maxee1900/RGBD-PL-SLAM.  The compute path is libplf_hi
 this package is the thin host-side mirror used by tests and bench.  No CPU fallback exists."""
 from ._lib import PlfError, LIB_PATH  # noqa: F401
 from .orb import ORBextractor  # noqa: F401
+from .lines import LineSegment  # noqa: F401

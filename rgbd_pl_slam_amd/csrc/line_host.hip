@@ -1,0 +1,311 @@
+// line_host.hip -- host side of the line extractor: handle, geometry, launch sequence, C ABI.
+// Mirrors ORB_SLAM2::LineSegment::ExtractLineSegment (include/ExtractLineSegment.h:38):
+//   LSDDetector::detect(img, keylines, scale = int(1.2) = 1, numOctaves = 1)  ->  keep the N best by response
+//   -> BinaryDescriptor::compute -> normalised line equations.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "plf_common.h"
+#include "lsd_geom.h"
+
+__global__ void k_lsd_blur_rows(const uint8_t *, ptrdiff_t, ptrdiff_t, double *, LsdGeom, LsdTaps);
+__global__ void k_lsd_blur_cols(const double *, double *, LsdGeom, LsdTaps);
+__global__ void k_lsd_resize(const double *, double *, LsdGeom, const int *, const float2 *, const int *, const float2 *);
+__global__ void k_lsd_grad(const double *, float *, double *, double2 *, LsdGeom);
+__global__ void k_lsd_regions(const float *, const double *, const double2 *, uint32_t *, float *, double *, LsdRect *, int *, int *, LsdGeom);
+__global__ void k_lsd_nfa(const float *, const LsdRect *, const int *, float4 *, uint8_t *, LsdGeom);
+__global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
+                               int, int *, LsdGeom);
+__global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
+__global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
+
+struct plf_line {
+    plf_line_params prm;
+    int device;
+    LsdGeom g;
+    LsdTaps taps;
+    LbdCoefs lbd;
+    int cur_w, cur_h;
+    size_t alloc_full, alloc_scaled;  // elements per frame the buffers were sized for
+    int alloc_rect_cap;
+    size_t regions_lds, finalize_lds, nfa_lds;
+    hipStream_t stream;
+    uint8_t *d_in, *d_keep, *d_ldesc;
+    double *d_tmp, *d_blur, *d_scaled, *d_modgrad, *d_rmod, *d_lineeq;
+    double2 *d_cs;
+    float *d_ang, *d_rdeg;
+    uint32_t *d_rxy;
+    LsdRect *d_rects;
+    float4 *d_seg, *d_segs_out;
+    short2 *d_grad;
+    plf_keyline *d_kl_tmp, *d_lines;
+    int *d_counters;  // nrect[B], nseg[B], nout[B], status
+    int *d_xofs, *d_yofs;
+    float2 *d_xa, *d_yb;
+    int last_frames;
+};
+
+static void line_free(plf_line *h)
+{
+    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_tmp, h->d_blur, h->d_scaled, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
+                    h->d_ang, h->d_rdeg, h->d_rxy, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
+{
+    memset(g, 0, sizeof(*g));
+    const double SCALE = 0.8, ANG_TH = 22.5, QUANT = 2.0;
+    g->w = w; g->h = hh;
+    g->sw = (int)lrint(w * SCALE); g->sh = (int)lrint(hh * SCALE);  // cv::resize: saturate_cast<int>(ssize * inv_scale)
+    if (g->sw < 8 || g->sh < 8 || w > 32000 || hh > 32000) return PLF_E_BADARG;
+    g->full_stride = (uint32_t)plf_align_up((size_t)w * hh, 64);
+    g->s_stride = (uint32_t)plf_align_up((size_t)g->sw * g->sh, 64);
+    g->prec = 3.1415926535897932384626433832795 * ANG_TH / 180;
+    g->p = ANG_TH / 180;
+    g->rho = QUANT / sin(g->prec);
+    g->log_nt = 5 * (log10((double)g->sw) + log10((double)g->sh)) / 2 + log10(11.0);
+    g->min_reg_size = (int)(-g->log_nt / log10(g->p));
+    g->used_words = (g->sw * g->sh + 31) / 32;
+    g->rcap = 8192;
+    int rc = 2048;
+    while (rc < g->sw * g->sh / 48 && rc < 8192) rc <<= 1;
+    g->rect_cap = rc;
+    g->sort_cap = rc;
+    g->nkeep = h->prm.nlines;
+    if ((size_t)g->used_words * 4 + (size_t)(g->rcap + 1) * 4 > 150 * 1024) return PLF_E_BADARG;
+    return PLF_OK;
+}
+
+static int line_configure(plf_line *h, int w, int hh)
+{
+    if (h->cur_w == w && h->cur_h == hh) return PLF_OK;
+    LsdGeom g;
+    int rc = line_geometry(h, w, hh, &g);
+    if (rc != PLF_OK) return rc;
+    if (g.full_stride > h->alloc_full || g.s_stride > h->alloc_scaled || g.rect_cap > h->alloc_rect_cap) return PLF_E_BADARG;
+    // cv::resize(double image, fx = fy = 0.8, INTER_LINEAR): float coefficients, see oracle/lsd_oracle.c
+    const double scale = 1. / 0.8;
+    std::vector<int> xofs(g.sw), yofs(g.sh);
+    std::vector<float2> xa(g.sw), yb(g.sh);
+    int xmax = g.sw;
+    for (int dx = 0; dx < g.sw; dx++) {
+        float fx = (float)((dx + 0.5) * scale - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= w) { if (dx < xmax) xmax = dx; if (sx >= w - 1) { fx = 0; sx = w - 1; } }
+        xofs[dx] = sx; xa[dx].x = 1.f - fx; xa[dx].y = fx;
+    }
+    for (int dy = 0; dy < g.sh; dy++) {
+        float fy = (float)((dy + 0.5) * scale - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        yofs[dy] = sy; yb[dy].x = 1.f - fy; yb[dy].y = fy;
+    }
+    g.xmax = xmax;
+    // keep the allocation strides so that per-frame offsets stay inside the buffers
+    g.full_stride = (uint32_t)h->alloc_full; g.s_stride = (uint32_t)h->alloc_scaled; g.rect_cap = h->alloc_rect_cap;
+    g.sort_cap = h->alloc_rect_cap;
+    PLF_HIP_TRY(hipMemcpy(h->d_xofs, xofs.data(), sizeof(int) * g.sw, hipMemcpyHostToDevice));
+    PLF_HIP_TRY(hipMemcpy(h->d_xa, xa.data(), sizeof(float2) * g.sw, hipMemcpyHostToDevice));
+    PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
+    PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(float2) * g.sh, hipMemcpyHostToDevice));
+    h->g = g;
+    h->regions_lds = (size_t)g.used_words * 4 + (size_t)(g.rcap + 1) * 4;
+    h->finalize_lds = (size_t)g.sort_cap * 8 + (size_t)g.rect_cap * 4 + 260 * 4;
+    h->nfa_lds = (size_t)g.sh * 2 * sizeof(int) + 64;
+    h->cur_w = w; h->cur_h = hh;
+    return PLF_OK;
+}
+
+extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
+{
+    if (!p || !out) return PLF_E_BADARG;
+    *out = nullptr;
+    if (p->nlines < 1 || p->max_batch < 1 || p->max_width < 16 || p->max_height < 16) return PLF_E_BADARG;
+    if (p->seed_order != 0) return PLF_E_BADARG;  // only the OpenCV 3.0-3.3 raster seed order is implemented on the GPU
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[plf] no HIP device available: the line extractor has no CPU path\n");
+        return PLF_E_HIP;
+    }
+    if (p->device < 0 || p->device >= ndev) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(p->device));
+    plf_line *h = (plf_line *)calloc(1, sizeof(plf_line));
+    if (!h) return PLF_E_NOMEM;
+    h->prm = *p; h->device = p->device;
+    LsdGeom g;
+    int rc = line_geometry(h, p->max_width, p->max_height, &g);
+    if (rc != PLF_OK) { free(h); return rc; }
+    h->alloc_full = g.full_stride; h->alloc_scaled = g.s_stride; h->alloc_rect_cap = g.rect_cap;
+    // cv::getGaussianKernel(7, 0.6/0.8, CV_64F):  h = ceil(sigma * sqrt(2 * 3 * ln 10)) = 3 -> ksize 7
+    {
+        const double sigma = 0.6 / 0.8, scale2X = -0.5 / (sigma * sigma);
+        double sum = 0;
+        for (int i = 0; i < 7; i++) { const double x = i - 3.0; h->taps.k[i] = exp(scale2X * x * x); sum += h->taps.k[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 7; i++) h->taps.k[i] *= sum;
+    }
+    // BinaryDescriptor ctor: gaussCoefL_ (21 taps, centre 10, sigma 7), gaussCoefG_ (63 taps, centre 31, sigma 31)
+    {
+        double u = (7 * 3 - 1) / 2, sigma = (7 * 2 + 1) / 2, inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < 21; i++) { const double d = i - u; h->lbd.gL[i] = (float)exp(d * d * inv); }
+        u = (9 * 7 - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < 63; i++) { const double d = i - u; h->lbd.gG[i] = (float)exp(d * d * inv); }
+    }
+    const size_t B = (size_t)p->max_batch, F = g.full_stride, S = g.s_stride, R = (size_t)g.rect_cap;
+    const int cap = p->nlines;
+#define ALLOC(ptr, bytes)                                                             \
+    do {                                                                              \
+        if (hipMalloc((void **)&(ptr), (bytes) > 0 ? (bytes) : 256) != hipSuccess) { \
+            line_free(h); free(h); return PLF_E_NOMEM;                                \
+        }                                                                             \
+    } while (0)
+    ALLOC(h->d_in, B * (size_t)p->max_width * p->max_height);
+    ALLOC(h->d_tmp, B * F * sizeof(double));
+    ALLOC(h->d_blur, B * F * sizeof(double));
+    ALLOC(h->d_grad, B * F * sizeof(short2));
+    ALLOC(h->d_scaled, B * S * sizeof(double));
+    ALLOC(h->d_modgrad, B * S * sizeof(double));
+    ALLOC(h->d_cs, B * S * sizeof(double2));
+    ALLOC(h->d_ang, B * S * sizeof(float));
+    ALLOC(h->d_rxy, B * S * sizeof(uint32_t));
+    ALLOC(h->d_rdeg, B * S * sizeof(float));
+    ALLOC(h->d_rmod, B * S * sizeof(double));
+    ALLOC(h->d_rects, B * R * sizeof(LsdRect));
+    ALLOC(h->d_seg, B * R * sizeof(float4));
+    ALLOC(h->d_segs_out, B * R * sizeof(float4));
+    ALLOC(h->d_keep, B * R);
+    ALLOC(h->d_kl_tmp, B * R * sizeof(plf_keyline));
+    ALLOC(h->d_lines, B * (size_t)cap * sizeof(plf_keyline));
+    ALLOC(h->d_ldesc, B * (size_t)cap * 32);
+    ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
+    ALLOC(h->d_counters, (3 * B + 16) * sizeof(int));
+    ALLOC(h->d_xofs, sizeof(int) * (size_t)g.sw); ALLOC(h->d_xa, sizeof(float2) * (size_t)g.sw);
+    ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
+#undef ALLOC
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
+    (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    h->cur_w = -1; h->cur_h = -1;
+    rc = line_configure(h, p->max_width, p->max_height);
+    if (rc != PLF_OK) { line_free(h); free(h); return rc; }
+    if (hipDeviceSynchronize() != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
+    *out = h;
+    return PLF_OK;
+}
+
+extern "C" void plf_line_destroy(plf_line *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    line_free(h);
+    free(h);
+}
+
+static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pitch, ptrdiff_t fstride, plf_keyline *d_lines, uint8_t *d_ldesc,
+                        double *d_eq, int *d_nout, int capacity, hipStream_t s)
+{
+    const LsdGeom &g = h->g;
+    const size_t MB = (size_t)h->prm.max_batch;
+    int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB;
+    PLF_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
+    dim3 gfull((g.w + 255) / 256, g.h, B), gsc((g.sw + 255) / 256, g.sh, B);
+    hipLaunchKernelGGL(k_lsd_blur_rows, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_tmp, g, h->taps);
+    hipLaunchKernelGGL(k_lsd_blur_cols, gfull, dim3(256), 0, s, h->d_tmp, h->d_blur, g, h->taps);
+    hipLaunchKernelGGL(k_lsd_resize, gsc, dim3(256), 0, s, h->d_blur, h->d_scaled, g, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
+    hipLaunchKernelGGL(k_lsd_grad, gsc, dim3(256), 0, s, h->d_scaled, h->d_ang, h->d_modgrad, h->d_cs, g);
+    hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
+    hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_rxy, h->d_rdeg, h->d_rmod,
+                       h->d_rects, nrect, status, g);
+    hipLaunchKernelGGL(k_lsd_nfa, dim3(64, B), dim3(64), h->nfa_lds, s, h->d_ang, h->d_rects, nrect, h->d_seg, h->d_keep, g);
+    hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
+                       d_lines, d_eq, d_nout, capacity, status, g);
+    hipLaunchKernelGGL(k_lbd, dim3(capacity < g.nkeep ? capacity : g.nkeep, B), dim3(128), 0, s, h->d_grad, d_lines, d_nout, d_ldesc, capacity, g,
+                       h->lbd);
+    PLF_HIP_TRY(hipGetLastError());
+    h->last_frames = B;
+    return PLF_OK;
+}
+
+extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int32_t n_frames, int32_t width, int32_t height,
+                                      ptrdiff_t pitch, ptrdiff_t frame_stride, plf_keyline *lines, uint8_t *ldesc, double *line_eq,
+                                      int32_t *n_out, int32_t out_mem, int32_t capacity, void *stream)
+{
+    if (!h) return PLF_E_BADARG;
+    if (!gray || width <= 0 || height <= 0 || n_frames <= 0) return PLF_E_EMPTY;
+    if (n_frames > h->prm.max_batch || width > h->prm.max_width || height > h->prm.max_height || pitch < width || !lines || !ldesc ||
+        !line_eq || !n_out || capacity < 1)
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    int rc = line_configure(h, width, height);
+    if (rc != PLF_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const uint8_t *d_gray = gray;
+    ptrdiff_t dpitch = pitch, dfstride = frame_stride;
+    if (in_mem == PLF_MEM_HOST) {
+        dpitch = width; dfstride = (ptrdiff_t)width * height;
+        for (int f = 0; f < n_frames; f++)
+            PLF_HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)f * dfstride, dpitch, gray + (size_t)f * frame_stride, pitch, width, height,
+                                         hipMemcpyHostToDevice, s));
+        d_gray = h->d_in;
+    }
+    const bool host_out = out_mem == PLF_MEM_HOST;
+    const int cap_dev = host_out ? h->prm.nlines : capacity;
+    plf_keyline *d_lines = host_out ? h->d_lines : lines;
+    uint8_t *d_ldesc = host_out ? h->d_ldesc : ldesc;
+    double *d_eq = host_out ? h->d_lineeq : line_eq;
+    int *d_nout = host_out ? h->d_counters + 2 * (size_t)h->prm.max_batch : n_out;
+    rc = line_enqueue(h, d_gray, n_frames, dpitch, dfstride, d_lines, d_ldesc, d_eq, d_nout, cap_dev, s);
+    if (rc != PLF_OK) return rc;
+    if (!host_out && in_mem == PLF_MEM_DEVICE) return PLF_OK;
+    int status = 0;
+    PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
+    int ret = PLF_OK;
+    if (host_out) {
+        std::vector<int> cnt(n_frames);
+        PLF_HIP_TRY(hipMemcpyAsync(cnt.data(), d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        for (int f = 0; f < n_frames; f++) {
+            int n = cnt[f];
+            if (n > capacity) { n = capacity; ret = PLF_E_CAPACITY; }
+            n_out[f] = n;
+            if (n > 0) {
+                PLF_HIP_TRY(hipMemcpyAsync(lines + (size_t)f * capacity, d_lines + (size_t)f * cap_dev, sizeof(plf_keyline) * n, hipMemcpyDeviceToHost, s));
+                PLF_HIP_TRY(hipMemcpyAsync(ldesc + (size_t)f * capacity * 32, d_ldesc + (size_t)f * cap_dev * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
+                PLF_HIP_TRY(hipMemcpyAsync(line_eq + (size_t)f * capacity * 3, d_eq + (size_t)f * cap_dev * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
+            }
+        }
+    }
+    PLF_HIP_TRY(hipStreamSynchronize(s));
+    if (status & 1) return PLF_E_HIP;  // more rectangles than rect_cap
+    if (status & 2) ret = PLF_E_CAPACITY;
+    return ret;
+}
+
+extern "C" int plf_line_extract(plf_line *h, const uint8_t *gray, int32_t width, int32_t height, ptrdiff_t pitch, plf_keyline *lines,
+                                uint8_t *ldesc, double *line_eq, int32_t capacity, int32_t *n_out)
+{
+    return plf_line_extract_batch(h, gray, PLF_MEM_HOST, 1, width, height, pitch, (ptrdiff_t)pitch * height, lines, ldesc, line_eq, n_out,
+                                  PLF_MEM_HOST, capacity, nullptr);
+}
+
+extern "C" int plf_line_get_segments(plf_line *h, int32_t frame, float *segs, int32_t capacity, int32_t *n_out)
+{
+    if (!h || !n_out || frame < 0 || frame >= h->last_frames) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    int n = 0;
+    PLF_HIP_TRY(hipMemcpy(&n, h->d_counters + (size_t)h->prm.max_batch + frame, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (segs && n > 0) {
+        const int m = n < capacity ? n : capacity;
+        PLF_HIP_TRY(hipMemcpy(segs, h->d_segs_out + (size_t)frame * h->g.rect_cap, sizeof(float4) * m, hipMemcpyDeviceToHost));
+    }
+    return PLF_OK;
+}

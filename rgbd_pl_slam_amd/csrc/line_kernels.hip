@@ -1,0 +1,227 @@
+// line_kernels.hip -- KeyLine construction, top-N selection, Sobel and the LBD band descriptor on gfx950.
+//   k_lsd_finalize  LSDDetector::detectImpl KeyLine fill (opencv_contrib 3.3 line_descriptor/LSDDetector.cpp) +
+//                   the fork's "sort by response, keep N, renumber class_id" (include/auxiliar.h:67-72) +
+//                   normalised line equations (Eigen cross product in the fork's ExtractLineSegment)
+//   k_sobel3        cv::Sobel(img, CV_16S, 1|0, 0|1, 3), BORDER_REFLECT_101 (BinaryDescriptor::computeSobel)
+//   k_lbd           BinaryDescriptor::computeLBD + binaryConversion (line_descriptor/binary_descriptor.cpp)
+// Float arithmetic follows the upstream statement order exactly (no FMA contraction); sequential float sums are
+// kept sequential per row / per band and spread over lanes only across rows / bands.
+#include "plf_common.h"
+#include "lsd_geom.h"
+
+__global__ void __launch_bounds__(256) k_lsd_finalize(const float4 *__restrict__ seg_all, const uint8_t *__restrict__ keep_all,
+                                                      const int *__restrict__ nrect, float4 *__restrict__ segs_out, int *__restrict__ nseg_out,
+                                                      plf_keyline *__restrict__ kl_tmp_all, plf_keyline *__restrict__ lines,
+                                                      double *__restrict__ lineeq, int *__restrict__ n_out, int capacity,
+                                                      int *__restrict__ status, LsdGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *skey = (unsigned long long *)smem;       // sort_cap
+    int *flag = (int *)(skey + g.sort_cap);                      // rect_cap
+    int *scan_tmp = flag + g.rect_cap;                           // 257
+    const int f = blockIdx.x, T = blockDim.x, t = threadIdx.x;
+    const int nr = nrect[f];
+    const float4 *seg = seg_all + (size_t)f * g.rect_cap;
+    const uint8_t *keep = keep_all + (size_t)f * g.rect_cap;
+    for (int i = t; i < nr; i += T) flag[i] = keep[i] ? 1 : 0;
+    __syncthreads();
+    const int ns = plf_block_excl_scan(flag, nr, scan_tmp);
+    float4 *so = segs_out + (size_t)f * g.rect_cap;
+    plf_keyline *klt = kl_tmp_all + (size_t)f * g.rect_cap;
+    const int W = g.w, H = g.h;
+    for (int i = t; i < nr; i += T) {
+        if (!keep[i]) continue;
+        const int k = flag[i];
+        const float4 s = seg[i];
+        so[k] = s;
+        float e0 = s.x, e1 = s.y, e2 = s.z, e3 = s.w;
+        if (e0 < 0) e0 = 0;
+        if (e0 >= W) e0 = (float)W - 1.0f;
+        if (e2 < 0) e2 = 0;
+        if (e2 >= W) e2 = (float)W - 1.0f;
+        if (e1 < 0) e1 = 0;
+        if (e1 >= H) e1 = (float)H - 1.0f;
+        if (e3 < 0) e3 = 0;
+        if (e3 >= H) e3 = (float)H - 1.0f;
+        plf_keyline kl;
+        kl.startPointX = e0 * 1.0f; kl.startPointY = e1 * 1.0f; kl.endPointX = e2 * 1.0f; kl.endPointY = e3 * 1.0f;
+        kl.sPointInOctaveX = e0; kl.sPointInOctaveY = e1; kl.ePointInOctaveX = e2; kl.ePointInOctaveY = e3;
+        kl.lineLength = (float)sqrt((double)(e0 - e2) * (double)(e0 - e2) + (double)(e1 - e3) * (double)(e1 - e3));
+        const int x0 = __float2int_rn(e0), y0 = __float2int_rn(e1), x1 = __float2int_rn(e2), y1 = __float2int_rn(e3);
+        const int dx = abs(x1 - x0), dy = abs(y1 - y0);
+        kl.numOfPixels = (dx > dy ? dx : dy) + 1;
+        kl.angle = (float)atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
+        kl.class_id = k;
+        kl.octave = 0;
+        kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
+        kl.response = kl.lineLength / (float)(W > H ? W : H);
+        kl.pt_x = (kl.endPointX + kl.startPointX) / 2;
+        kl.pt_y = (kl.endPointY + kl.startPointY) / 2;
+        klt[k] = kl;
+    }
+    if (t == 0) nseg_out[f] = ns;
+    __syncthreads();
+    int nout = ns;
+    const bool sorted = ns > g.nkeep;
+    if (sorted) {
+        // stable "response descending" order: key = (response bits, ~index), sorted descending
+        int P2 = 1;
+        while (P2 < ns) P2 <<= 1;
+        for (int i = t; i < P2; i += T)
+            skey[i] = i < ns ? (((unsigned long long)__float_as_uint(klt[i].response) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i)) : 0ull;
+        __syncthreads();
+        for (int k2 = 2; k2 <= P2; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < P2; i += T) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = skey[i], b = skey[ixj];
+                        const bool desc = (i & k2) == 0;
+                        if (desc ? (a < b) : (a > b)) { skey[i] = b; skey[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        nout = g.nkeep;
+    }
+    if (nout > capacity) { nout = capacity; if (t == 0) atomicOr(status, 2); }
+    for (int i = t; i < nout; i += T) {
+        const int src = sorted ? (int)(0xFFFFFFFFu - (unsigned)(skey[i] & 0xFFFFFFFFull)) : i;
+        plf_keyline kl = klt[src];
+        if (sorted) kl.class_id = i;
+        lines[(size_t)f * capacity + i] = kl;
+        const double sx = kl.startPointX, sy = kl.startPointY, ex = kl.endPointX, ey = kl.endPointY;
+        const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+        const double nrm = sqrt(l0 * l0 + l1 * l1);
+        double *eq = lineeq + ((size_t)f * capacity + i) * 3;
+        eq[0] = l0 / nrm; eq[1] = l1 / nrm; eq[2] = l2 / nrm;
+    }
+    if (t == 0) n_out[f] = nout;
+}
+
+__global__ void __launch_bounds__(256) k_sobel3(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, short2 *__restrict__ grad,
+                                                LsdGeom g)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.w) return;
+    const uint8_t *img = in + (size_t)f * fstride;
+    const uint8_t *r0 = img + (size_t)plf_reflect101(y - 1, g.h) * pitch, *r1 = img + (size_t)y * pitch,
+                  *r2 = img + (size_t)plf_reflect101(y + 1, g.h) * pitch;
+    const int xm = plf_reflect101(x - 1, g.w), xp = plf_reflect101(x + 1, g.w);
+    const int gx = (r0[xp] + 2 * r1[xp] + r2[xp]) - (r0[xm] + 2 * r1[xm] + r2[xm]);
+    const int gy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
+    grad[(size_t)f * g.full_stride + (size_t)y * g.w + x] = make_short2((short)gx, (short)gy);
+}
+
+__constant__ int c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3, 2, 4, 2, 5, 2, 6, 2, 7,
+                                   2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6, 4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
+
+// one 128-thread block per (line, frame): threads 0..62 = rows of the 63-row line support region,
+// threads 0..71 = (band, statistic) accumulators, threads 0..31 = output bytes.
+__global__ void __launch_bounds__(128) k_lbd(const short2 *__restrict__ grad_all, const plf_keyline *__restrict__ lines,
+                                             const int *__restrict__ n_out, uint8_t *__restrict__ desc, int capacity, LsdGeom g, LbdCoefs cf)
+{
+    __shared__ float rowsum[8][64];
+    __shared__ float dv[72];
+    const int li = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+    if (li >= n_out[f]) return;
+    const plf_keyline kl = lines[(size_t)f * capacity + li];
+    const short2 *grad = grad_all + (size_t)f * g.full_stride;
+    const int realWidth = g.w;
+    const short imageWidth = (short)(g.w - 1), imageHeight = (short)(g.h - 1);
+    const short halfHeight = 31;
+    const short lengthOfLSP = (short)kl.numOfPixels;
+    const short halfWidth = (short)((lengthOfLSP - 1) / 2);
+    const float lineMiddlePointX = (float)(0.5 * (double)(kl.sPointInOctaveX + kl.ePointInOctaveX));
+    const float lineMiddlePointY = (float)(0.5 * (double)(kl.sPointInOctaveY + kl.ePointInOctaveY));
+    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
+    const float dO0 = -dL1, dO1 = dL0;
+    if (t < 63) {
+        float sCorX0 = -dL0 * (float)halfWidth + dL1 * (float)halfHeight + lineMiddlePointX;
+        float sCorY0 = -dL1 * (float)halfWidth - dL0 * (float)halfHeight + lineMiddlePointY;
+        for (int h = 0; h < t; h++) { sCorX0 -= dL1; sCorY0 += dL0; }
+        float sCorX = sCorX0, sCorY = sCorY0;
+        float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
+        for (short wID = 0; wID < lengthOfLSP; wID++) {
+            short tempCor = (short)(int)roundf(sCorX);
+            const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+            tempCor = (short)(int)roundf(sCorY);
+            const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+            const short2 d = grad[(int)yCor * realWidth + (int)xCor];
+            const float gDL = (float)d.x * dL0 + (float)d.y * dL1;
+            const float gDO = (float)d.x * dO0 + (float)d.y * dO1;
+            if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
+            if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
+            sCorX += dL0;
+            sCorY += dL1;
+        }
+        const float cg = cf.gG[t];
+        pgdL = cg * pgdL; ngdL = cg * ngdL; pgdO = cg * pgdO; ngdO = cg * ngdO;
+        rowsum[0][t] = pgdL; rowsum[1][t] = ngdL; rowsum[2][t] = pgdL * pgdL; rowsum[3][t] = ngdL * ngdL;
+        rowsum[4][t] = pgdO; rowsum[5][t] = ngdO; rowsum[6][t] = pgdO * pgdO; rowsum[7][t] = ngdO * ngdO;
+    }
+    __syncthreads();
+    if (t < 72) {
+        // band sums: band b receives, in row order, the rows of bands b-1, b, b+1 with the local Gaussian weights
+        const int b = t >> 3, st = t & 7;
+        const bool sq = (st & 2) != 0;  // statistics 2,3,6,7 are the squared sums
+        float acc = 0;
+        const int h0 = max(0, 7 * (b - 1)), h1 = min(62, 7 * (b + 2) - 1);
+        for (int hID = h0; hID <= h1; hID++) {
+            const int rb = hID / 7;
+            const int ci = (rb == b) ? (hID % 7 + 7) : (rb == b + 1 ? hID % 7 + 14 : hID % 7);
+            const float c = cf.gL[ci];
+            const float v = rowsum[st][hID];
+            acc += sq ? (c * c * v) : (c * v);
+        }
+        dv[t] = acc;  // staged as [band][stat: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2]
+    }
+    __syncthreads();
+    if (t == 0) {
+        float des[72];
+        const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
+        for (int b = 0; b < 9; b++) {
+            const float invN = (b == 0 || b == 8) ? invN2 : invN3;
+            const float *a = &dv[b * 8];
+            float temp = a[0] * invN;
+            des[b * 8] = temp;
+            des[b * 8 + 4] = sqrtf(a[2] * invN - temp * temp);
+            temp = a[1] * invN;
+            des[b * 8 + 1] = temp;
+            des[b * 8 + 5] = sqrtf(a[3] * invN - temp * temp);
+            temp = a[4] * invN;
+            des[b * 8 + 2] = temp;
+            des[b * 8 + 6] = sqrtf(a[6] * invN - temp * temp);
+            temp = a[5] * invN;
+            des[b * 8 + 3] = temp;
+            des[b * 8 + 7] = sqrtf(a[7] * invN - temp * temp);
+        }
+        float tempM = 0, tempS = 0;
+        for (int b = 0; b < 9; b++) {
+            const float *d = des + 8 * b;
+            tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
+            tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
+        }
+        tempM = 1 / sqrtf(tempM);
+        tempS = 1 / sqrtf(tempS);
+        for (int b = 0; b < 9; b++) {
+            float *d = des + 8 * b;
+            d[0] = d[0] * tempM; d[1] = d[1] * tempM; d[2] = d[2] * tempM; d[3] = d[3] * tempM;
+            d[4] = d[4] * tempS; d[5] = d[5] * tempS; d[6] = d[6] * tempS; d[7] = d[7] * tempS;
+        }
+        for (int i = 0; i < 72; i++)
+            if ((double)des[i] > 0.4) des[i] = (float)0.4;
+        float temp = 0;
+        for (int i = 0; i < 72; i++) temp += des[i] * des[i];
+        temp = 1 / sqrtf(temp);
+        for (int i = 0; i < 72; i++) dv[i] = des[i] * temp;
+    }
+    __syncthreads();
+    if (t < 32) {
+        const float *f1 = &dv[8 * c_lbd_comb[2 * t]], *f2 = &dv[8 * c_lbd_comb[2 * t + 1]];
+        unsigned r = 0;
+        for (int i = 0; i < 8; i++)
+            if (f1[i] > f2[i]) r += (unsigned)(8 * (8 - i - 1));  // upstream accumulates 8*(7-i), not 1<<(7-i)
+        desc[((size_t)f * capacity + li) * 32 + t] = (uint8_t)r;
+    }
+}

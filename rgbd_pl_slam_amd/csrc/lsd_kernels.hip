@@ -1,0 +1,608 @@
+// lsd_kernels.hip -- LSD line-segment detector on gfx950, restating what the reference reaches through
+// LineSegment::ExtractLineSegment -> cv::line_descriptor::LSDDetector::detect -> cv::LineSegmentDetector
+// (include/ExtractLineSegment.h:38; OpenCV 3.3 imgproc/lsd.cpp, LSD_REFINE_ADV, default parameters).
+//
+// Stage map (B frames per launch):
+//   k_lsd_blur_rows / k_lsd_blur_cols   GaussianBlur(7x7, sigma 0.75) on the image converted to double
+//   k_lsd_resize                        resize(0.8, INTER_LINEAR) of the double image (float coefficients)
+//   k_lsd_grad                          ll_angle: 2x2 gradient, modgrad (double), level-line angle (cv::fastAtan2)
+//   k_lsd_regions                       seed scan + region_grow + region2rect + refine   (ORDER-DEPENDENT, see below)
+//   k_lsd_nfa                           rect_improve / rect_nfa / nfa per surviving rectangle (independent)
+//   k_lsd_finalize                      ordered compaction -> segments -> KeyLine fields -> top-N by response
+//
+// The only inherently sequential part of LSD is k_lsd_regions: regions are grown greedily in seed order, every
+// accepted pixel changes the running region angle (float sums + fastAtan2), and `used` marks made by one region
+// (and un-made by refine) decide what later seeds see.  That chain is kept EXACTLY: one wave owns one frame and
+// performs the accept steps in the reference order, while its 64 lanes cooperate on everything that is
+// order-free inside a step (the 3x3 neighbourhood tests, pixel gathers, min/max extents, the rectangle pixel
+// counts).  Floating-point sums whose order matters are accumulated serially in the reference order.
+// The NFA validation does not touch `used`, so it is split off and runs one wave per rectangle.
+// Frames are independent, so a batch keeps 1 wave x B frames busy (the batch is the parallel axis).
+#include "plf_common.h"
+#include "lsd_geom.h"
+
+#define NOTDEF_F (-1024.0f)
+#define PI_D 3.1415926535897932384626433832795
+#define M_3_2_PI_D (3 * 3.14159265358979323846 / 2)
+#define M_2__PI_D (2 * 3.14159265358979323846)
+#define DEG2RAD_D (PI_D / 180)
+
+// ------------------------------------------------------------------------------------------------
+// blur + resize (double data, identical operation order to cv::RowFilter / SymmColumnFilter / resize)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lsd_blur_rows(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride,
+                                                       double *__restrict__ tmp, LsdGeom g, LsdTaps t)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.w) return;
+    const uint8_t *row = in + (size_t)f * fstride + (size_t)y * pitch;
+    double s = t.k[0] * (double)row[plf_reflect101(x - 3, g.w)];
+#pragma unroll
+    for (int i = 1; i < 7; i++) s += t.k[i] * (double)row[plf_reflect101(x - 3 + i, g.w)];
+    tmp[(size_t)f * g.full_stride + (size_t)y * g.w + x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_lsd_blur_cols(const double *__restrict__ tmp, double *__restrict__ blur, LsdGeom g, LsdTaps t)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.w) return;
+    const double *p = tmp + (size_t)f * g.full_stride + x;
+    double s = t.k[3] * p[(size_t)y * g.w] + 0.0;
+#pragma unroll
+    for (int i = 1; i <= 3; i++)
+        s += t.k[3 + i] * (p[(size_t)plf_reflect101(y + i, g.h) * g.w] + p[(size_t)plf_reflect101(y - i, g.h) * g.w]);
+    blur[(size_t)f * g.full_stride + (size_t)y * g.w + x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_lsd_resize(const double *__restrict__ blur, double *__restrict__ scaled, LsdGeom g,
+                                                    const int *__restrict__ xofs, const float2 *__restrict__ xa,
+                                                    const int *__restrict__ yofs, const float2 *__restrict__ yb)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, f = blockIdx.z;
+    if (dx >= g.sw) return;
+    const double *src = blur + (size_t)f * g.full_stride;
+    const int sx = xofs[dx], sy = yofs[dy];
+    const float2 a = xa[dx], b = yb[dy];
+    const int y0 = min(max(sy, 0), g.h - 1), y1 = min(max(sy + 1, 0), g.h - 1);
+    const double *S0 = src + (size_t)y0 * g.w, *S1 = src + (size_t)y1 * g.w;
+    double r0, r1;
+    if (dx < g.xmax) {
+        r0 = S0[sx] * (double)a.x + S0[sx + 1] * (double)a.y;
+        r1 = S1[sx] * (double)a.x + S1[sx + 1] * (double)a.y;
+    } else {
+        r0 = S0[sx] * 1.0;
+        r1 = S1[sx] * 1.0;
+    }
+    scaled[(size_t)f * g.s_stride + (size_t)dy * g.sw + dx] = r0 * (double)b.x + r1 * (double)b.y;
+}
+
+// ll_angle.  ang: level-line angle in DEGREES as cv::fastAtan2 returns it (the reference stores
+// double(deg) * DEG_TO_RADS, recomputed on use), NOTDEF_F where the gradient is too small or on the last
+// row/column.  cs: cos and sin of the float-rounded angle, the increments region_grow adds to its sums.
+__global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ scaled, float *__restrict__ ang, double *__restrict__ modgrad,
+                                                  double2 *__restrict__ cs, LsdGeom g)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.sw) return;
+    const size_t a = (size_t)f * g.s_stride + (size_t)y * g.sw + x;
+    if (x == g.sw - 1 || y == g.sh - 1) { ang[a] = NOTDEF_F; modgrad[a] = 0.0; return; }
+    const double *im = scaled + a;
+    const double DA = im[g.sw + 1] - im[0];
+    const double BC = im[1] - im[g.sw];
+    const double gx = DA + BC, gy = DA - BC;
+    const double norm = sqrt((gx * gx + gy * gy) / 4);
+    modgrad[a] = norm;
+    if (norm <= g.rho) { ang[a] = NOTDEF_F; return; }
+    const float deg = plf_fast_atan2((float)gx, (float)-gy);
+    ang[a] = deg;
+    const double af = (double)(float)((double)deg * DEG2RAD_D);
+    cs[a] = make_double2(cos(af), sin(af));
+}
+
+// ------------------------------------------------------------------------------------------------
+// region growing (one wave per frame)
+// ------------------------------------------------------------------------------------------------
+struct RegCtx {
+    int W, H;
+    const float *ang;
+    const double *modgrad;
+    const double2 *cs;
+    uint32_t *used;       // LDS bitmap, 1 = USED
+    uint32_t *rxy_l;      // LDS part of the region list (x | y << 16)
+    uint32_t *rxy_g;      // global overflow of the region list
+    int rcap;
+    float *rdeg;          // global, per region point: angle in degrees
+    double *rmod;         // global, per region point: modgrad
+};
+
+__device__ __forceinline__ bool used_get(const RegCtx &C, int a) { return (C.used[a >> 5] >> (a & 31)) & 1u; }
+__device__ __forceinline__ void used_set(RegCtx &C, int a) { atomicOr(&C.used[a >> 5], 1u << (a & 31)); }
+__device__ __forceinline__ void used_clr(RegCtx &C, int a) { atomicAnd(&C.used[a >> 5], ~(1u << (a & 31))); }
+__device__ __forceinline__ uint32_t rxy_get(const RegCtx &C, int i) { return i < C.rcap ? C.rxy_l[i] : C.rxy_g[i]; }
+__device__ __forceinline__ void rxy_put(RegCtx &C, int i, uint32_t v) { if (i < C.rcap) C.rxy_l[i] = v; else C.rxy_g[i] = v; }
+
+__device__ __forceinline__ double shfl_d(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ bool aligned_deg(float deg, double theta, double prec)
+{
+    if (deg == NOTDEF_F) return false;
+    const double a = (double)deg * DEG2RAD_D;
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_D) {
+        n_theta -= M_2__PI_D;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+// LineSegmentDetectorImpl::region_grow.  All lanes return the same (n, reg_angle).
+__device__ int region_grow(RegCtx &C, int sx, int sy, double prec, double &reg_angle_out)
+{
+    const int lane = plf_lane(), W = C.W, H = C.H;
+    const int addr0 = sy * W + sx;
+    const float deg0 = C.ang[addr0];
+    double reg_angle = (double)deg0 * DEG2RAD_D;
+    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    if (lane == 0) {
+        rxy_put(C, 0, (uint32_t)sx | ((uint32_t)sy << 16));
+        C.rdeg[0] = deg0;
+        C.rmod[0] = C.modgrad[addr0];
+        used_set(C, addr0);
+    }
+    __syncthreads();
+    int n = 1;
+    const int kx = lane % 3 - 1, ky = lane / 3 - 1;  // lanes 0..8 = the 3x3 neighbourhood in (yy, xx) order
+    for (int i = 0; i < n; ++i) {
+        const uint32_t pxy = rxy_get(C, i);
+        const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
+        const bool valid = lane < 9 && xx >= 0 && xx < W && yy >= 0 && yy < H;
+        const int a = valid ? yy * W + xx : 0;
+        const float deg = valid ? C.ang[a] : NOTDEF_F;
+        bool cand = valid && deg != NOTDEF_F && !used_get(C, a);
+        double2 csv = make_double2(0.0, 0.0);
+        double mg = 0.0;
+        if (cand) { csv = C.cs[a]; mg = C.modgrad[a]; }
+        while (true) {
+            const bool al = cand && aligned_deg(deg, reg_angle, prec);
+            const unsigned long long mask = __ballot(al);
+            if (!mask) break;
+            const int k = __ffsll((long long)mask) - 1;
+            if (lane == k) {
+                used_set(C, a);
+                rxy_put(C, n, (uint32_t)xx | ((uint32_t)yy << 16));
+                C.rdeg[n] = deg;
+                C.rmod[n] = mg;
+            }
+            const double cc = shfl_d(csv.x, k), ss = shfl_d(csv.y, k);
+            // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
+            sumdx = (float)((double)sumdx + cc);
+            sumdy = (float)((double)sumdy + ss);
+            reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
+            ++n;
+            cand = cand && lane > k;
+        }
+        __syncthreads();
+    }
+    reg_angle_out = reg_angle;
+    return n;
+}
+
+__device__ __forceinline__ double dist_d(double x1, double y1, double x2, double y2) { return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
+__device__ __forceinline__ double distsq_d(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+
+__device__ __forceinline__ double angle_diff_signed_d(double a, double b)
+{
+    double diff = a - b;
+    while (diff <= -PI_D) diff += M_2__PI_D;
+    while (diff > PI_D) diff -= M_2__PI_D;
+    return diff;
+}
+
+// region2rect incl. get_theta.  Order-dependent sums are accumulated serially in list order; the lanes only
+// prefetch 64 points at a time.  Extents (min/max) are order-free and reduced across the wave.
+__device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, double p, LsdRect &rec)
+{
+    const int lane = plf_lane();
+    double x = 0, y = 0, sum = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t xy = i < n ? rxy_get(C, i) : 0u;
+        const double w = i < n ? C.rmod[i] : 0.0;
+        const int cnt = min(64, n - base);
+        for (int k = 0; k < cnt; k++) {
+            const double wk = shfl_d(w, k);
+            const uint32_t q = (uint32_t)__shfl((int)xy, k, 64);
+            x += (double)(int)(q & 0xFFFF) * wk;
+            y += (double)(int)(q >> 16) * wk;
+            sum += wk;
+        }
+    }
+    x /= sum;
+    y /= sum;
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t xy = i < n ? rxy_get(C, i) : 0u;
+        const double w = i < n ? C.rmod[i] : 0.0;
+        const int cnt = min(64, n - base);
+        for (int k = 0; k < cnt; k++) {
+            const double wk = shfl_d(w, k);
+            const uint32_t q = (uint32_t)__shfl((int)xy, k, 64);
+            const double dx = (double)(int)(q & 0xFFFF) - x, dy = (double)(int)(q >> 16) - y;
+            Ixx += dy * dy * wk;
+            Iyy += dx * dx * wk;
+            Ixy -= dx * dy * wk;
+        }
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)plf_fast_atan2((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)plf_fast_atan2((float)Ixy, (float)(lambda - Iyy));
+    theta *= DEG2RAD_D;
+    {
+        double d = angle_diff_signed_d(theta, reg_angle);
+        if (d < 0) d = -d;
+        if (d > prec) theta += PI_D;
+    }
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t q = rxy_get(C, i);
+        const double regdx = (double)(int)(q & 0xFFFF) - x, regdy = (double)(int)(q >> 16) - y;
+        const double l = regdx * dx + regdy * dy;
+        const double w = -regdx * dy + regdy * dx;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l);
+        w_max = fmax(w_max, w); w_min = fmin(w_min, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, shfl_d(l_max, lane ^ o)); l_min = fmin(l_min, shfl_d(l_min, lane ^ o));
+        w_max = fmax(w_max, shfl_d(w_max, lane ^ o)); w_min = fmin(w_min, shfl_d(w_min, lane ^ o));
+    }
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy;
+    rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min;
+    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+// reduce_region_radius: the swap-with-last removal is replayed literally (it permutes the list, and the
+// order of the list decides the rounding of the next region2rect sums).
+__device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double prec, double p, LsdRect &rec, double density,
+                                     double density_th)
+{
+    const int lane = plf_lane();
+    const uint32_t q0 = rxy_get(C, 0);
+    const double xc = (double)(int)(q0 & 0xFFFF), yc = (double)(int)(q0 >> 16);
+    const double radSq1 = distsq_d(xc, yc, rec.x1, rec.y1), radSq2 = distsq_d(xc, yc, rec.x2, rec.y2);
+    double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+    while (density < density_th) {
+        radSq *= 0.75 * 0.75;
+        if (lane == 0) {
+            int m = n;
+            for (int i = 0; i < m; ++i) {
+                const uint32_t q = rxy_get(C, i);
+                if (distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq) {
+                    used_clr(C, (int)(q >> 16) * C.W + (int)(q & 0xFFFF));
+                    const uint32_t ql = rxy_get(C, m - 1);
+                    const float dl = C.rdeg[m - 1]; const double ml = C.rmod[m - 1];
+                    rxy_put(C, m - 1, q); C.rdeg[m - 1] = C.rdeg[i]; C.rmod[m - 1] = C.rmod[i];
+                    rxy_put(C, i, ql); C.rdeg[i] = dl; C.rmod[i] = ml;
+                    --m;
+                    --i;
+                }
+            }
+            C.rxy_l[C.rcap] = (uint32_t)m;  // one spare LDS word carries the new size to the other lanes
+        }
+        __syncthreads();
+        n = (int)C.rxy_l[C.rcap];
+        __syncthreads();
+        if (n < 2) return false;
+        region2rect(C, n, reg_angle, prec, p, rec);
+        density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    }
+    return true;
+}
+
+__device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double p, LsdRect &rec, double density_th)
+{
+    const int lane = plf_lane();
+    double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density >= density_th) return true;
+    const uint32_t q0 = rxy_get(C, 0);
+    const double xc = (double)(int)(q0 & 0xFFFF), yc = (double)(int)(q0 >> 16);
+    const double ang_c = (double)C.rdeg[0] * DEG2RAD_D;
+    double sum = 0, s_sum = 0;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool inc = false;
+        double ang_d = 0.0;
+        if (i < n) {
+            const uint32_t q = rxy_get(C, i);
+            used_clr(C, (int)(q >> 16) * C.W + (int)(q & 0xFFFF));
+            if (dist_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) < rec.width) {
+                inc = true;
+                ang_d = angle_diff_signed_d((double)C.rdeg[i] * DEG2RAD_D, ang_c);
+            }
+        }
+        unsigned long long m = __ballot(inc);
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const double d = shfl_d(ang_d, k);
+            sum += d;
+            s_sum += d * d;
+            ++cnt;
+        }
+    }
+    __syncthreads();
+    const double mean_angle = sum / (double)cnt;
+    const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
+    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), tau, reg_angle);
+    if (n < 2) return false;
+    region2rect(C, n, reg_angle, prec, p, rec);
+    density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density < density_th) return reduce_region_radius(C, n, reg_angle, prec, p, rec, density, density_th);
+    return true;
+}
+
+__global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                    const double2 *__restrict__ cs_all, uint32_t *__restrict__ rxy_all,
+                                                    float *__restrict__ rdeg_all, double *__restrict__ rmod_all,
+                                                    LsdRect *__restrict__ rects_all, int *__restrict__ nrect, int *__restrict__ status,
+                                                    LsdGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int W = g.sw, H = g.sh, NP = W * H;
+    RegCtx C;
+    C.W = W; C.H = H;
+    C.ang = ang_all + (size_t)f * g.s_stride;
+    C.modgrad = modgrad_all + (size_t)f * g.s_stride;
+    C.cs = cs_all + (size_t)f * g.s_stride;
+    C.used = (uint32_t *)smem;
+    C.rxy_l = C.used + g.used_words;
+    C.rcap = g.rcap;
+    C.rxy_g = rxy_all + (size_t)f * g.s_stride;
+    C.rdeg = rdeg_all + (size_t)f * g.s_stride;
+    C.rmod = rmod_all + (size_t)f * g.s_stride;
+    for (int i = lane; i < g.used_words; i += 64) C.used[i] = 0u;
+    __syncthreads();
+    LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
+    int nr = 0;
+    const double prec = g.prec, p = g.p;
+    for (int base = 0; base < NP; base += 64) {
+        const int px = base + lane;
+        const float deg = px < NP ? C.ang[px] : NOTDEF_F;
+        bool ok = px < NP && deg != NOTDEF_F && !used_get(C, px);
+        unsigned long long mask = __ballot(ok);
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            const int seed = base + j;
+            double reg_angle;
+            int n = region_grow(C, seed % W, seed / W, prec, reg_angle);
+            if (n >= g.min_reg_size) {
+                LsdRect rec;
+                region2rect(C, n, reg_angle, prec, p, rec);
+                if (refine(C, n, reg_angle, prec, p, rec, 0.7)) {
+                    if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
+                    else if (lane == 0) atomicOr(status, 1);
+                    nr++;
+                }
+            }
+            ok = ok && lane > j && !used_get(C, px);
+            mask = __ballot(ok);
+        }
+    }
+    if (lane == 0) nrect[f] = min(nr, g.rect_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NFA validation (one wave per rectangle)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double log_gamma_d(double x)
+{
+    if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+    const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+    double b = 0;
+    for (int n = 0; n < 7; ++n) {
+        a -= log(x + (double)n);
+        b += q[n] * pow(x, (double)n);
+    }
+    return a + log(b);
+}
+
+__device__ __forceinline__ bool double_equal_d(double a, double b)
+{
+    if (a == b) return true;
+    const double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+    double abs_max = (aa > bb) ? aa : bb;
+    if (abs_max < 2.2250738585072014e-308) abs_max = 2.2250738585072014e-308;
+    return (abs_diff / abs_max) <= (100.0 * 2.2204460492503131e-16);
+}
+
+__device__ double nfa_d(double LOG_NT, int n, int k, double p)
+{
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - (double)n * log10(p);
+    const double p_term = p / (1 - p);
+    const double log1term = log_gamma_d((double)n + 1) - log_gamma_d((double)k + 1) - log_gamma_d((double)(n - k) + 1) +
+                            (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    double term = exp(log1term);
+    if (double_equal_d(term, 0)) {
+        if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
+        return -LOG_NT;
+    }
+    double bin_tail = term;
+    const double tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+        const double bin_term = (double)(n - i + 1) / (double)i;
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            const double err = term * ((1 - pow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - LOG_NT;
+}
+
+struct EdgePt { int x, y, taken; };
+
+// rect_nfa: the scan-line walk (with upstream's integer-division slopes and the `tailp->p.x` slip) is replayed
+// serially to get each row's [left, right] span; the pixel tests are then spread over the lanes, one row per lane.
+__device__ double rect_nfa(const float *__restrict__ ang, int W, int H, double LOG_NT, const LsdRect &rec, int *span /*LDS 2*H*/)
+{
+    const int lane = plf_lane();
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    EdgePt o[4];
+    o[0].x = (int)(rec.x1 - dyhw); o[0].y = (int)(rec.y1 + dxhw); o[0].taken = 0;
+    o[1].x = (int)(rec.x2 - dyhw); o[1].y = (int)(rec.y2 + dxhw); o[1].taken = 0;
+    o[2].x = (int)(rec.x2 + dyhw); o[2].y = (int)(rec.y2 - dxhw); o[2].taken = 0;
+    o[3].x = (int)(rec.x1 + dyhw); o[3].y = (int)(rec.y1 - dxhw); o[3].taken = 0;
+    for (int i = 1; i < 4; i++) {  // std::sort on 4 elements = insertion sort, AsmallerB_XoverY
+        const EdgePt t = o[i];
+        int j = i - 1;
+        while (j >= 0 && (o[j].x > t.x || (o[j].x == t.x && o[j].y > t.y))) { o[j + 1] = o[j]; j--; }
+        o[j + 1] = t;
+    }
+    int imin = 0, imax = 0;
+    for (int i = 1; i < 4; ++i) {
+        if (o[imin].y > o[i].y) imin = i;
+        if (o[imax].y < o[i].y) imax = i;
+    }
+    o[imin].taken = 1;
+    int il = -1;
+    for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (il < 0) il = i; else if (o[il].x > o[i].x) il = i; }
+    o[il].taken = 1;
+    int ir = -1;
+    for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (ir < 0) ir = i; else if (o[ir].x < o[i].x) ir = i; }
+    o[ir].taken = 1;
+    int it = -1;
+    for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (it < 0) it = i; else if (o[it].x > o[i].x) it = i; }
+    const EdgePt mn = o[imin], mx = o[imax], lf = o[il], rt = o[ir], tl = o[it];
+    const double flstep = (mn.y != lf.y) ? (double)((mn.x - lf.x) / (mn.y - lf.y)) : 0;
+    const double slstep = (lf.y != tl.x) ? (double)((lf.x - tl.x) / (lf.y - tl.x)) : 0;
+    const double frstep = (mn.y != rt.y) ? (double)((mn.x - rt.x) / (mn.y - rt.y)) : 0;
+    const double srstep = (rt.y != tl.x) ? (double)((rt.x - tl.x) / (rt.y - tl.x)) : 0;
+    double lstep = flstep, rstep = frstep;
+    double left_x = mn.x, right_x = mn.x;
+    const int y_lo = max(mn.y, 0), y_hi = min(mx.y, H - 1);
+    // rows outside the image are skipped BEFORE the step update (upstream `continue`), so the walk starts at y_lo
+    if (lane == 0) {
+        for (int y = y_lo; y <= y_hi; ++y) {
+            span[2 * (y - y_lo)] = (int)left_x;
+            span[2 * (y - y_lo) + 1] = (int)right_x;
+            if (y >= lf.y) lstep = slstep;
+            if (y >= rt.y) rstep = srstep;
+            left_x += lstep;
+            right_x += rstep;
+        }
+    }
+    __syncthreads();
+    int total = 0, alg = 0;
+    for (int y = y_lo + lane; y <= y_hi; y += 64) {
+        const int xl = max(span[2 * (y - y_lo)], 0), xr = min(span[2 * (y - y_lo) + 1], W - 1);
+        const float *row = ang + (size_t)y * W;
+        for (int x = xl; x <= xr; ++x) {
+            ++total;
+            if (aligned_deg(row[x], rec.theta, rec.prec)) ++alg;
+        }
+    }
+    __syncthreads();
+    total = plf_wave_sum(total);
+    alg = plf_wave_sum(alg);
+    return nfa_d(LOG_NT, total, alg, rec.p);
+}
+
+__device__ double rect_improve(const float *ang, int W, int H, double LOG_NT, LsdRect &rec, double LOG_EPS, int *span)
+{
+    const double delta = 0.5, delta_2 = delta / 2.0;
+    double log_nfa = rect_nfa(ang, W, H, LOG_NT, rec, span);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    LsdRect r = rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2;
+        r.prec = r.p * PI_D;
+        const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+        if (v > log_nfa) { log_nfa = v; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+            r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+            r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2;
+            r.prec = r.p * PI_D;
+            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    return log_nfa;
+}
+
+// grid (blocks_per_frame, B); each wave loops over the frame's rectangles.  seg[i] = (x1,y1,x2,y2) as float,
+// keep[i] = 1 when log_nfa > LOG_EPS.
+__global__ void __launch_bounds__(64) k_lsd_nfa(const float *__restrict__ ang_all, const LsdRect *__restrict__ rects_all,
+                                                const int *__restrict__ nrect, float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all,
+                                                LsdGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *span = (int *)smem;
+    const int f = blockIdx.y;
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    const int nr = nrect[f];
+    for (int i = blockIdx.x; i < nr; i += gridDim.x) {
+        LsdRect rec = rects_all[(size_t)f * g.rect_cap + i];
+        const double log_nfa = rect_improve(ang, g.sw, g.sh, g.log_nt, rec, 0.0, span);
+        if (threadIdx.x == 0) {
+            const bool keep = log_nfa > 0.0;
+            keep_all[(size_t)f * g.rect_cap + i] = keep ? 1 : 0;
+            if (keep) {
+                rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+                rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
+                seg_all[(size_t)f * g.rect_cap + i] = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -1,0 +1,64 @@
+"""Host-side mirror of ORB_SLAM2::LineSegment (include/ExtractLineSegment.h:29-57) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class LineSegment:
+    """ExtractLineSegment(img, keylines, ldesc, lineFunctions, scale=1.2, numOctaves=1) -- include/ExtractLineSegment.h:38.
+    `nlines` is the number of lines kept after the response sort (compile-time constant in the fork)."""
+
+    def __init__(self, nlines=100, max_width=640, max_height=480, max_batch=1, device=0, seed_order=0):
+        self._h = C.c_void_p()
+        p = L.LineParams(nlines, seed_order, device, max_width, max_height, max_batch)
+        L.check(L.lib().plf_line_create(C.byref(p), C.byref(self._h)), "plf_line_create")
+        self.nlines, self.max_batch = nlines, max_batch
+
+    def close(self):
+        if self._h:
+            L.lib().plf_line_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ExtractLineSegment(self, img):
+        """returns (keylines[KL_DTYPE], ldesc[n,32] uint8, lineFunctions[n,3] float64)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        kl = np.zeros(self.nlines, L.KL_DTYPE); desc = np.zeros((self.nlines, 32), np.uint8); eq = np.zeros((self.nlines, 3), np.float64)
+        n = C.c_int32(0)
+        st = L.lib().plf_line_extract(self._h, L.vp(img), w, h, C.c_ssize_t(img.strides[0]), L.vp(kl), L.vp(desc), L.vp(eq),
+                                      self.nlines, C.byref(n))
+        if st == L.PLF_E_EMPTY:
+            return kl[:0], desc[:0], eq[:0]
+        L.check(st, "plf_line_extract")
+        return kl[:n.value].copy(), desc[:n.value].copy(), eq[:n.value].copy()
+
+    def extract_batch(self, images):
+        images = np.ascontiguousarray(images, np.uint8)
+        B, h, w = images.shape
+        kl = np.zeros((B, self.nlines), L.KL_DTYPE); desc = np.zeros((B, self.nlines, 32), np.uint8)
+        eq = np.zeros((B, self.nlines, 3), np.float64); n = np.zeros(B, np.int32)
+        L.check(L.lib().plf_line_extract_batch(self._h, L.vp(images), L.MEM_HOST, B, w, h, C.c_ssize_t(w), C.c_ssize_t(w * h), L.vp(kl),
+                                               L.vp(desc), L.vp(eq), L.vp(n), L.MEM_HOST, self.nlines, None), "plf_line_extract_batch")
+        return [(kl[f, :n[f]].copy(), desc[f, :n[f]].copy(), eq[f, :n[f]].copy()) for f in range(B)]
+
+    def extract_batch_device(self, d_images, w, h, d_lines, d_desc, d_eq, d_n, capacity, stream=None):
+        B = int(d_images.shape[0])
+        L.check(L.lib().plf_line_extract_batch(self._h, L.vp(d_images), L.MEM_DEVICE, B, w, h, C.c_ssize_t(w), C.c_ssize_t(w * h),
+                                               L.vp(d_lines), L.vp(d_desc), L.vp(d_eq), L.vp(d_n), L.MEM_DEVICE, capacity,
+                                               C.c_void_p(stream) if stream else None), "plf_line_extract_batch")
+
+    def segments(self, frame=0):
+        """test hook: all LSD segments of the last call in detection order"""
+        n = C.c_int32()
+        L.check(L.lib().plf_line_get_segments(self._h, frame, None, 0, C.byref(n)), "plf_line_get_segments")
+        out = np.zeros((max(n.value, 1), 4), np.float32)
+        L.check(L.lib().plf_line_get_segments(self._h, frame, L.vp(out), n.value, C.byref(n)), "plf_line_get_segments")
+        return out[:n.value]

@@ -1,0 +1,94 @@
+"""GPU parity: HIP LSD + LBD line extractor (through the C ABI) vs the CPU oracle.
+Segments / KeyLine floats: every arithmetic step is the same IEEE operation sequence as the oracle except the
+double-precision libm calls (cos/sin/atan2/log/exp/pow), whose last-bit differences are far below float rounding;
+the test therefore demands bit-equal float outputs and allows 1e-4 (north-star tolerance) only as a reported fallback.
+LBD bytes: exact."""
+import numpy as np
+import pytest
+
+import orc
+from conftest import gpu_available
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _need_gpu():
+    if not gpu_available():
+        pytest.fail("no GPU visible: the -m gpu tests need a real MI355X")
+
+
+def _check(img, nlines, ext=None):
+    from rgbd_pl_slam_amd import LineSegment
+    h, w = img.shape
+    own = ext is None
+    if own:
+        ext = LineSegment(nlines=nlines, max_width=w, max_height=h)
+    kl, desc, eq = ext.ExtractLineSegment(img)
+    segs = ext.segments(0)
+    ref_seg = orc.lsd_detect(img)["lines"]
+    ref = orc.line_extract(img, nlines)
+    assert len(segs) == len(ref_seg), "segment count %d vs %d" % (len(segs), len(ref_seg))
+    assert np.allclose(segs, ref_seg, rtol=0, atol=TOL)
+    nbits = int((segs.view(np.uint32) != ref_seg.view(np.uint32)).sum())
+    assert len(kl) == len(ref["kl"])
+    for name in kl.dtype.names:
+        a, b = kl[name], ref["kl"][name]
+        if a.dtype.kind == "f":
+            assert np.allclose(a, b, rtol=0, atol=TOL * max(1.0, float(np.abs(b).max()))), name
+        else:
+            assert np.array_equal(a, b), name
+    assert np.allclose(eq, ref["eq"], rtol=0, atol=1e-4)
+    same_fields = all(np.array_equal(kl[n].view(np.uint32), ref["kl"][n].view(np.uint32)) for n in kl.dtype.names)
+    bad_rows = int((desc != ref["desc"]).any(1).sum())
+    assert bad_rows == 0, "LBD descriptors differ in %d of %d rows (keylines bit-equal: %s)" % (bad_rows, len(desc), same_fields)
+    assert nbits == 0 and same_fields, "float outputs within 1e-4 but not bit-equal (segments differing words: %d)" % nbits
+    if own:
+        ext.close()
+
+
+def test_lines_vga_synthetic():
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    for seed in (0, 1):
+        _check(synth_frame(seed), 100)
+
+
+def test_lines_fewer_than_requested_and_200():
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    img = synth_frame(2)
+    _check(img, 200)
+    _check(img, 1000)   # fewer segments than nlines: detection order, no sort
+
+
+def test_lines_odd_size_and_large():
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    _check(synth_frame(4, 752, 480), 100)
+    _check(synth_frame(5, 1280, 960), 400)
+
+
+def test_lines_flat_and_noise():
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    ext = LineSegment(nlines=100, max_width=640, max_height=480)
+    kl, desc, eq = ext.ExtractLineSegment(np.full((480, 640), 99, np.uint8))
+    assert len(kl) == 0
+    rng = np.random.default_rng(3)
+    _check(rng.integers(0, 256, (480, 640), dtype=np.uint8), 100, ext=ext)
+    ext.close()
+
+
+def test_lines_batch_equals_single():
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_batch
+    imgs = synth_batch(20, 3)
+    ext = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=3)
+    res = ext.extract_batch(imgs)
+    for f in range(3):
+        ref = orc.line_extract(imgs[f], 100)
+        assert np.array_equal(res[f][1], ref["desc"])
+        assert np.array_equal(res[f][0]["startPointX"].view(np.uint32), ref["kl"]["startPointX"].view(np.uint32))
+    ext.close()
