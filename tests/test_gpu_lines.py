@@ -35,7 +35,7 @@ def _check(img, nlines, ext=None):
     for name in kl.dtype.names:
         a, b = kl[name], ref["kl"][name]
         if a.dtype.kind == "f":
-            assert np.allclose(a, b, rtol=0, atol=TOL * max(1.0, float(np.abs(b).max()))), name
+            assert np.allclose(a, b, rtol=0, atol=TOL * max(1.0, float(np.abs(b).max()) if len(b) else 1.0)), name
         else:
             assert np.array_equal(a, b), name
     assert np.allclose(eq, ref["eq"], rtol=0, atol=1e-4)
