@@ -144,7 +144,8 @@ int plf_hamming256_matrix(const uint8_t *a, int32_t na, const uint8_t *b, int32_
 
 /* View of the Frame members the matchers read (include/Frame.h): all pointers device memory. */
 typedef struct {
-    int32_t n;                 /* N */
+    int32_t n;                 /* N (upper bound when n_device is given) */
+    const int32_t *n_device;   /* optional: N lives in device memory (output of plf_orb_extract_batch); NULL = use n */
     const plf_keypoint *keys_un; /* mvKeysUn (pt, octave, angle are read) */
     const float *uright;       /* mvuRight, NULL = monocular (-1 everywhere) */
     const uint8_t *desc;       /* mDescriptors, n x 32 */
@@ -212,7 +213,8 @@ int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_desc, int32_t 
 
 /* Frame members read by the line projection search (include/Frame.h:201-214); device memory */
 typedef struct {
-    int32_t n;
+    int32_t n;                   /* number of lines (upper bound when n_device is given) */
+    const int32_t *n_device;     /* optional: count in device memory (output of plf_line_extract_batch) */
     const plf_keyline *lines_un; /* mvKeylinesUn (pt, angle, octave) */
     const uint8_t *desc;         /* mLdesc */
     const float *scale_factors;

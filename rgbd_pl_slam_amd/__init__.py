@@ -4,3 +4,4 @@ this package is the thin host-side mirror used by tests and bench.  No CPU fallb
 from ._lib import PlfError, LIB_PATH  # noqa: F401
 from .orb import ORBextractor  # noqa: F401
 from .lines import LineSegment  # noqa: F401
+from .matcher import Matcher, DescriptorDistance  # noqa: F401

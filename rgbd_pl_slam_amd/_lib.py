@@ -32,7 +32,7 @@ class LineParams(C.Structure):
 
 
 class FrameView(C.Structure):
-    _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("uright", C.c_void_p), ("desc", C.c_void_p),
+    _fields_ = [("n", C.c_int32), ("n_device", C.c_void_p), ("keys_un", C.c_void_p), ("uright", C.c_void_p), ("desc", C.c_void_p),
                 ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
                 ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
 
@@ -54,7 +54,7 @@ class PosePair(C.Structure):
 
 
 class LineFrameView(C.Structure):
-    _fields_ = [("n", C.c_int32), ("lines_un", C.c_void_p), ("desc", C.c_void_p), ("scale_factors", C.c_void_p)]
+    _fields_ = [("n", C.c_int32), ("n_device", C.c_void_p), ("lines_un", C.c_void_p), ("desc", C.c_void_p), ("scale_factors", C.c_void_p)]
 
 
 class MapLineView(C.Structure):

@@ -14,7 +14,9 @@ __global__ void k_lsd_blur_cols(const double *, double *, LsdGeom, LsdTaps);
 __global__ void k_lsd_resize(const double *, double *, LsdGeom, const int *, const float2 *, const int *, const float2 *);
 __global__ void k_lsd_grad(const double *, float *, double *, double2 *, LsdGeom);
 __global__ void k_lsd_regions(const float *, const double *, const double2 *, uint32_t *, float *, double *, LsdRect *, int *, int *, LsdGeom);
-__global__ void k_lsd_nfa(const float *, const LsdRect *, const int *, float4 *, uint8_t *, LsdGeom);
+__global__ void k_lsd_lgamma_table(double *);
+__global__ void k_lsd_nfa_first(const float *, const double *, const LsdRect *, const int *, float4 *, uint8_t *, int *, int2 *, LsdGeom);
+__global__ void k_lsd_nfa_improve(const float *, const double *, const LsdRect *, const int *, const int2 *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
                                int, int *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
@@ -32,7 +34,8 @@ struct plf_line {
     size_t regions_lds, finalize_lds, nfa_lds;
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
-    double *d_tmp, *d_blur, *d_scaled, *d_modgrad, *d_rmod, *d_lineeq;
+    double *d_tmp, *d_blur, *d_scaled, *d_modgrad, *d_rmod, *d_lineeq, *d_lgam;
+    int2 *d_fail;
     double2 *d_cs;
     float *d_ang, *d_rdeg;
     uint32_t *d_rxy;
@@ -50,7 +53,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_tmp, h->d_blur, h->d_scaled, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rdeg, h->d_rxy, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_fail};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -184,13 +187,16 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lines, B * (size_t)cap * sizeof(plf_keyline));
     ALLOC(h->d_ldesc, B * (size_t)cap * 32);
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
-    ALLOC(h->d_counters, (3 * B + 16) * sizeof(int));
+    ALLOC(h->d_counters, (4 * B + 16) * sizeof(int));
+    ALLOC(h->d_lgam, 65536 * sizeof(double));
+    ALLOC(h->d_fail, B * R * 2 * sizeof(int2));
     ALLOC(h->d_xofs, sizeof(int) * (size_t)g.sw); ALLOC(h->d_xa, sizeof(float2) * (size_t)g.sw);
     ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
     (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
     h->cur_w = -1; h->cur_h = -1;
     rc = line_configure(h, p->max_width, p->max_height);
     if (rc != PLF_OK) { line_free(h); free(h); return rc; }
@@ -213,8 +219,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
 {
     const LsdGeom &g = h->g;
     const size_t MB = (size_t)h->prm.max_batch;
-    int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB;
-    PLF_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
+    int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail = h->d_counters + 3 * MB + 16;
+    PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
     dim3 gfull((g.w + 255) / 256, g.h, B), gsc((g.sw + 255) / 256, g.sh, B);
     hipLaunchKernelGGL(k_lsd_blur_rows, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_tmp, g, h->taps);
     hipLaunchKernelGGL(k_lsd_blur_cols, gfull, dim3(256), 0, s, h->d_tmp, h->d_blur, g, h->taps);
@@ -223,7 +229,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
     hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_rxy, h->d_rdeg, h->d_rmod,
                        h->d_rects, nrect, status, g);
-    hipLaunchKernelGGL(k_lsd_nfa, dim3(64, B), dim3(64), h->nfa_lds, s, h->d_ang, h->d_rects, nrect, h->d_seg, h->d_keep, g);
+    hipLaunchKernelGGL(k_lsd_nfa_first, dim3((g.rect_cap + 63) / 64, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_seg,
+                       h->d_keep, nfail, h->d_fail, g);
+    hipLaunchKernelGGL(k_lsd_nfa_improve, dim3((g.rect_cap + 63) / 64, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nfail, h->d_fail,
+                       h->d_seg, h->d_keep, g);
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
                        d_lines, d_eq, d_nout, capacity, status, g);
     hipLaunchKernelGGL(k_lbd, dim3(capacity < g.nkeep ? capacity : g.nkeep, B), dim3(128), 0, s, h->d_grad, d_lines, d_nout, d_ldesc, capacity, g,

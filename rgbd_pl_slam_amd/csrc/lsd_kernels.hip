@@ -16,7 +16,7 @@
 // performs the accept steps in the reference order, while its 64 lanes cooperate on everything that is
 // order-free inside a step (the 3x3 neighbourhood tests, pixel gathers, min/max extents, the rectangle pixel
 // counts).  Floating-point sums whose order matters are accumulated serially in the reference order.
-// The NFA validation does not touch `used`, so it is split off and runs one wave per rectangle.
+// The NFA validation does not touch `used`, so it is split off and runs one lane per rectangle.
 // Frames are independent, so a batch keeps 1 wave x B frames busy (the batch is the parallel axis).
 #include "plf_common.h"
 #include "lsd_geom.h"
@@ -142,52 +142,73 @@ __device__ __forceinline__ bool aligned_deg(float deg, double theta, double prec
 }
 
 // LineSegmentDetectorImpl::region_grow.  All lanes return the same (n, reg_angle).
-__device__ int region_grow(RegCtx &C, int sx, int sy, double prec, double &reg_angle_out)
+// The accept steps happen strictly in the reference order (centre by centre, neighbours in (yy, xx) order, the
+// region angle updated after every accepted pixel).  What is batched is only the DATA FETCH: the 3x3
+// neighbourhoods of up to 7 already-queued centres are gathered with one round trip (lanes 9s..9s+8 serve
+// centre i+s); `used` is read from LDS at the moment a centre is processed, so it is always current.
+// wsum (optional): the modgrad-weighted coordinate sums of region2rect, accumulated in list order as points
+// are appended (same additions in the same order as the reference's first region2rect loop).
+struct RegSums { double x, y, sum; };
+
+__device__ int region_grow(RegCtx &C, int sx, int sy, double prec, double &reg_angle_out, RegSums &ws)
 {
     const int lane = plf_lane(), W = C.W, H = C.H;
     const int addr0 = sy * W + sx;
     const float deg0 = C.ang[addr0];
+    const double mg0 = C.modgrad[addr0];
     double reg_angle = (double)deg0 * DEG2RAD_D;
     float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
     if (lane == 0) {
         rxy_put(C, 0, (uint32_t)sx | ((uint32_t)sy << 16));
         C.rdeg[0] = deg0;
-        C.rmod[0] = C.modgrad[addr0];
+        C.rmod[0] = mg0;
         used_set(C, addr0);
     }
+    ws.x = 0.0; ws.y = 0.0; ws.sum = 0.0;
+    ws.x += (double)sx * mg0; ws.y += (double)sy * mg0; ws.sum += mg0;
     __syncthreads();
     int n = 1;
-    const int kx = lane % 3 - 1, ky = lane / 3 - 1;  // lanes 0..8 = the 3x3 neighbourhood in (yy, xx) order
-    for (int i = 0; i < n; ++i) {
-        const uint32_t pxy = rxy_get(C, i);
+    const int slot = lane / 9, k9 = lane - slot * 9;
+    const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;  // 3x3 neighbourhood in (yy, xx) order
+    int i = 0;
+    while (i < n) {
+        const int gcount = min(7, n - i);
+        const bool active = lane < 63 && slot < gcount;
+        const uint32_t pxy = active ? rxy_get(C, i + slot) : 0u;
         const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
-        const bool valid = lane < 9 && xx >= 0 && xx < W && yy >= 0 && yy < H;
+        const bool valid = active && xx >= 0 && xx < W && yy >= 0 && yy < H;
         const int a = valid ? yy * W + xx : 0;
-        const float deg = valid ? C.ang[a] : NOTDEF_F;
-        bool cand = valid && deg != NOTDEF_F && !used_get(C, a);
+        float deg = NOTDEF_F;
         double2 csv = make_double2(0.0, 0.0);
         double mg = 0.0;
-        if (cand) { csv = C.cs[a]; mg = C.modgrad[a]; }
-        while (true) {
-            const bool al = cand && aligned_deg(deg, reg_angle, prec);
-            const unsigned long long mask = __ballot(al);
-            if (!mask) break;
-            const int k = __ffsll((long long)mask) - 1;
-            if (lane == k) {
-                used_set(C, a);
-                rxy_put(C, n, (uint32_t)xx | ((uint32_t)yy << 16));
-                C.rdeg[n] = deg;
-                C.rmod[n] = mg;
+        if (valid) { deg = C.ang[a]; csv = C.cs[a]; mg = C.modgrad[a]; }
+        const bool defined = valid && deg != NOTDEF_F;
+        for (int s = 0; s < gcount; s++) {
+            bool cand = defined && slot == s && !used_get(C, a);
+            while (true) {
+                const bool al = cand && aligned_deg(deg, reg_angle, prec);
+                const unsigned long long mask = __ballot(al);
+                if (!mask) break;
+                const int k = __ffsll((long long)mask) - 1;
+                if (lane == k) {
+                    used_set(C, a);
+                    rxy_put(C, n, (uint32_t)xx | ((uint32_t)yy << 16));
+                    C.rdeg[n] = deg;
+                    C.rmod[n] = mg;
+                }
+                const double cc = shfl_d(csv.x, k), ss = shfl_d(csv.y, k), mk = shfl_d(mg, k);
+                const int qx = __shfl(xx, k, 64), qy = __shfl(yy, k, 64);
+                // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
+                sumdx = (float)((double)sumdx + cc);
+                sumdy = (float)((double)sumdy + ss);
+                reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
+                ws.x += (double)qx * mk; ws.y += (double)qy * mk; ws.sum += mk;
+                ++n;
+                cand = cand && lane > k;
             }
-            const double cc = shfl_d(csv.x, k), ss = shfl_d(csv.y, k);
-            // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
-            sumdx = (float)((double)sumdx + cc);
-            sumdy = (float)((double)sumdy + ss);
-            reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
-            ++n;
-            cand = cand && lane > k;
+            __syncthreads();
         }
-        __syncthreads();
+        i += gcount;
     }
     reg_angle_out = reg_angle;
     return n;
@@ -206,21 +227,25 @@ __device__ __forceinline__ double angle_diff_signed_d(double a, double b)
 
 // region2rect incl. get_theta.  Order-dependent sums are accumulated serially in list order; the lanes only
 // prefetch 64 points at a time.  Extents (min/max) are order-free and reduced across the wave.
-__device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, double p, LsdRect &rec)
+__device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, double p, LsdRect &rec, const RegSums *pre)
 {
     const int lane = plf_lane();
     double x = 0, y = 0, sum = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const uint32_t xy = i < n ? rxy_get(C, i) : 0u;
-        const double w = i < n ? C.rmod[i] : 0.0;
-        const int cnt = min(64, n - base);
-        for (int k = 0; k < cnt; k++) {
-            const double wk = shfl_d(w, k);
-            const uint32_t q = (uint32_t)__shfl((int)xy, k, 64);
-            x += (double)(int)(q & 0xFFFF) * wk;
-            y += (double)(int)(q >> 16) * wk;
-            sum += wk;
+    if (pre) {  // sums already accumulated in list order while the region was grown
+        x = pre->x; y = pre->y; sum = pre->sum;
+    } else {
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const uint32_t xy = i < n ? rxy_get(C, i) : 0u;
+            const double w = i < n ? C.rmod[i] : 0.0;
+            const int cnt = min(64, n - base);
+            for (int k = 0; k < cnt; k++) {
+                const double wk = shfl_d(w, k);
+                const uint32_t q = (uint32_t)__shfl((int)xy, k, 64);
+                x += (double)(int)(q & 0xFFFF) * wk;
+                y += (double)(int)(q >> 16) * wk;
+                sum += wk;
+            }
         }
     }
     x /= sum;
@@ -228,16 +253,21 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
     double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        const uint32_t xy = i < n ? rxy_get(C, i) : 0u;
-        const double w = i < n ? C.rmod[i] : 0.0;
+        // the per-point products are order-free and computed by all lanes; only the running sums are serial
+        double txx = 0.0, tyy = 0.0, txy = 0.0;
+        if (i < n) {
+            const uint32_t q = rxy_get(C, i);
+            const double w = C.rmod[i];
+            const double dx = (double)(int)(q & 0xFFFF) - x, dy = (double)(int)(q >> 16) - y;
+            txx = dy * dy * w;
+            tyy = dx * dx * w;
+            txy = dx * dy * w;
+        }
         const int cnt = min(64, n - base);
         for (int k = 0; k < cnt; k++) {
-            const double wk = shfl_d(w, k);
-            const uint32_t q = (uint32_t)__shfl((int)xy, k, 64);
-            const double dx = (double)(int)(q & 0xFFFF) - x, dy = (double)(int)(q >> 16) - y;
-            Ixx += dy * dy * wk;
-            Iyy += dx * dx * wk;
-            Ixy -= dx * dy * wk;
+            Ixx += shfl_d(txx, k);
+            Iyy += shfl_d(tyy, k);
+            Ixy -= shfl_d(txy, k);
         }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -303,7 +333,7 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
         n = (int)C.rxy_l[C.rcap];
         __syncthreads();
         if (n < 2) return false;
-        region2rect(C, n, reg_angle, prec, p, rec);
+        region2rect(C, n, reg_angle, prec, p, rec, nullptr);
         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     }
     return true;
@@ -344,9 +374,10 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     __syncthreads();
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), tau, reg_angle);
+    RegSums ws;
+    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), tau, reg_angle, ws);
     if (n < 2) return false;
-    region2rect(C, n, reg_angle, prec, p, rec);
+    region2rect(C, n, reg_angle, prec, p, rec, &ws);
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density < density_th) return reduce_region_radius(C, n, reg_angle, prec, p, rec, density, density_th);
     return true;
@@ -386,10 +417,11 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
             const int j = __ffsll((long long)mask) - 1;
             const int seed = base + j;
             double reg_angle;
-            int n = region_grow(C, seed % W, seed / W, prec, reg_angle);
+            RegSums ws;
+            int n = region_grow(C, seed % W, seed / W, prec, reg_angle, ws);
             if (n >= g.min_reg_size) {
                 LsdRect rec;
-                region2rect(C, n, reg_angle, prec, p, rec);
+                region2rect(C, n, reg_angle, prec, p, rec, &ws);
                 if (refine(C, n, reg_angle, prec, p, rec, 0.7)) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
                     else if (lane == 0) atomicOr(status, 1);
@@ -428,12 +460,29 @@ __device__ __forceinline__ bool double_equal_d(double a, double b)
     return (abs_diff / abs_max) <= (100.0 * 2.2204460492503131e-16);
 }
 
-__device__ double nfa_d(double LOG_NT, int n, int k, double p)
+// log_gamma(i) for integer i in [0, LGAM_N): filled once per handle by k_lsd_lgamma_table with the very same
+// device function, so a lookup is bit-identical to evaluating it in place (3 calls x ~15 transcendentals saved
+// per NFA evaluation).
+#define LGAM_N 65536
+__device__ const double *g_lgam_table = nullptr;
+
+__global__ void k_lsd_lgamma_table(double *tab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < LGAM_N) tab[i] = i > 0 ? log_gamma_d((double)i) : 0.0;
+}
+
+__device__ __forceinline__ double log_gamma_int(const double *__restrict__ tab, int i)
+{
+    return (i > 0 && i < LGAM_N) ? tab[i] : log_gamma_d((double)i);
+}
+
+__device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, int k, double p)
 {
     if (n == 0 || k == 0) return -LOG_NT;
     if (n == k) return -LOG_NT - (double)n * log10(p);
     const double p_term = p / (1 - p);
-    const double log1term = log_gamma_d((double)n + 1) - log_gamma_d((double)k + 1) - log_gamma_d((double)(n - k) + 1) +
+    const double log1term = log_gamma_int(lgam, n + 1) - log_gamma_int(lgam, k + 1) - log_gamma_int(lgam, n - k + 1) +
                             (double)k * log(p) + (double)(n - k) * log(1.0 - p);
     double term = exp(log1term);
     if (double_equal_d(term, 0)) {
@@ -457,11 +506,10 @@ __device__ double nfa_d(double LOG_NT, int n, int k, double p)
 
 struct EdgePt { int x, y, taken; };
 
-// rect_nfa: the scan-line walk (with upstream's integer-division slopes and the `tailp->p.x` slip) is replayed
-// serially to get each row's [left, right] span; the pixel tests are then spread over the lanes, one row per lane.
-__device__ double rect_nfa(const float *__restrict__ ang, int W, int H, double LOG_NT, const LsdRect &rec, int *span /*LDS 2*H*/)
+// rect_nfa, one LANE per rectangle: the scan-line walk (with upstream's integer-division slopes and the
+// `tailp->p.x` slip) and the pixel tests run exactly like the reference loop; 64 rectangles advance per wave.
+__device__ double rect_nfa(const float *__restrict__ ang, const double *__restrict__ lgam, int W, int H, double LOG_NT, const LsdRect &rec)
 {
-    const int lane = plf_lane();
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     EdgePt o[4];
@@ -496,44 +544,33 @@ __device__ double rect_nfa(const float *__restrict__ ang, int W, int H, double L
     const double srstep = (rt.y != tl.x) ? (double)((rt.x - tl.x) / (rt.y - tl.x)) : 0;
     double lstep = flstep, rstep = frstep;
     double left_x = mn.x, right_x = mn.x;
-    const int y_lo = max(mn.y, 0), y_hi = min(mx.y, H - 1);
     // rows outside the image are skipped BEFORE the step update (upstream `continue`), so the walk starts at y_lo
-    if (lane == 0) {
-        for (int y = y_lo; y <= y_hi; ++y) {
-            span[2 * (y - y_lo)] = (int)left_x;
-            span[2 * (y - y_lo) + 1] = (int)right_x;
-            if (y >= lf.y) lstep = slstep;
-            if (y >= rt.y) rstep = srstep;
-            left_x += lstep;
-            right_x += rstep;
-        }
-    }
-    __syncthreads();
+    const int y_lo = max(mn.y, 0), y_hi = min(mx.y, H - 1);
     int total = 0, alg = 0;
-    for (int y = y_lo + lane; y <= y_hi; y += 64) {
-        const int xl = max(span[2 * (y - y_lo)], 0), xr = min(span[2 * (y - y_lo) + 1], W - 1);
+    for (int y = y_lo; y <= y_hi; ++y) {
+        const int xl = max((int)left_x, 0), xr = min((int)right_x, W - 1);
         const float *row = ang + (size_t)y * W;
         for (int x = xl; x <= xr; ++x) {
             ++total;
             if (aligned_deg(row[x], rec.theta, rec.prec)) ++alg;
         }
+        if (y >= lf.y) lstep = slstep;
+        if (y >= rt.y) rstep = srstep;
+        left_x += lstep;
+        right_x += rstep;
     }
-    __syncthreads();
-    total = plf_wave_sum(total);
-    alg = plf_wave_sum(alg);
-    return nfa_d(LOG_NT, total, alg, rec.p);
+    return nfa_d(lgam, LOG_NT, total, alg, rec.p);
 }
 
-__device__ double rect_improve(const float *ang, int W, int H, double LOG_NT, LsdRect &rec, double LOG_EPS, int *span)
+// rect_improve after its first rect_nfa call (log_nfa = that first value, known to be <= LOG_EPS)
+__device__ double rect_improve_rest(const float *ang, const double *lgam, int W, int H, double LOG_NT, LsdRect &rec, double LOG_EPS, double log_nfa)
 {
     const double delta = 0.5, delta_2 = delta / 2.0;
-    double log_nfa = rect_nfa(ang, W, H, LOG_NT, rec, span);
-    if (log_nfa > LOG_EPS) return log_nfa;
     LsdRect r = rec;
     for (int n = 0; n < 5; ++n) {
         r.p /= 2;
         r.prec = r.p * PI_D;
-        const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+        const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
         if (v > log_nfa) { log_nfa = v; rec = r; }
     }
     if (log_nfa > LOG_EPS) return log_nfa;
@@ -541,7 +578,7 @@ __device__ double rect_improve(const float *ang, int W, int H, double LOG_NT, Ls
     for (int n = 0; n < 5; ++n) {
         if ((r.width - delta) >= 0.5) {
             r.width -= delta;
-            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
             if (v > log_nfa) { rec = r; log_nfa = v; }
         }
     }
@@ -552,7 +589,7 @@ __device__ double rect_improve(const float *ang, int W, int H, double LOG_NT, Ls
             r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
             r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
             r.width -= delta;
-            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
             if (v > log_nfa) { rec = r; log_nfa = v; }
         }
     }
@@ -563,7 +600,7 @@ __device__ double rect_improve(const float *ang, int W, int H, double LOG_NT, Ls
             r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
             r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
             r.width -= delta;
-            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
             if (v > log_nfa) { rec = r; log_nfa = v; }
         }
     }
@@ -573,36 +610,63 @@ __device__ double rect_improve(const float *ang, int W, int H, double LOG_NT, Ls
         if ((r.width - delta) >= 0.5) {
             r.p /= 2;
             r.prec = r.p * PI_D;
-            const double v = rect_nfa(ang, W, H, LOG_NT, r, span);
+            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
             if (v > log_nfa) { rec = r; log_nfa = v; }
         }
     }
     return log_nfa;
 }
 
-// grid (blocks_per_frame, B); each wave loops over the frame's rectangles.  seg[i] = (x1,y1,x2,y2) as float,
-// keep[i] = 1 when log_nfa > LOG_EPS.
-__global__ void __launch_bounds__(64) k_lsd_nfa(const float *__restrict__ ang_all, const LsdRect *__restrict__ rects_all,
-                                                const int *__restrict__ nrect, float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all,
-                                                LsdGeom g)
+__device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *span = (int *)smem;
+    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+    rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
+    *seg = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
+}
+
+// NFA validation in two passes so that the lanes of a wave do similar amounts of work:
+//   k_lsd_nfa_first    one lane per rectangle: the first rect_nfa of rect_improve.  Meaningful rectangles
+//                      (log_nfa > 0, i.e. most real segments) finish here; the others are queued.
+//   k_lsd_nfa_improve  one lane per QUEUED rectangle: the remaining <= 25 evaluations of rect_improve.
+// grid (ceil(rect_cap / 64), B).  seg[i] = (x1,y1,x2,y2) as float, keep[i] = 1 when log_nfa > LOG_EPS.
+__global__ void __launch_bounds__(64) k_lsd_nfa_first(const float *__restrict__ ang_all, const double *__restrict__ lgam,
+                                                      const LsdRect *__restrict__ rects_all, const int *__restrict__ nrect,
+                                                      float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, int *__restrict__ nfail,
+                                                      int2 *__restrict__ fail_all, LsdGeom g)
+{
     const int f = blockIdx.y;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nrect[f]) return;
     const float *ang = ang_all + (size_t)f * g.s_stride;
-    const int nr = nrect[f];
-    for (int i = blockIdx.x; i < nr; i += gridDim.x) {
-        LsdRect rec = rects_all[(size_t)f * g.rect_cap + i];
-        const double log_nfa = rect_improve(ang, g.sw, g.sh, g.log_nt, rec, 0.0, span);
-        if (threadIdx.x == 0) {
-            const bool keep = log_nfa > 0.0;
-            keep_all[(size_t)f * g.rect_cap + i] = keep ? 1 : 0;
-            if (keep) {
-                rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-                rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
-                seg_all[(size_t)f * g.rect_cap + i] = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
-            }
-        }
-        __syncthreads();
+    const LsdRect rec = rects_all[(size_t)f * g.rect_cap + i];
+    const double log_nfa = rect_nfa(ang, lgam, g.sw, g.sh, g.log_nt, rec);
+    if (log_nfa > 0.0) {
+        keep_all[(size_t)f * g.rect_cap + i] = 1;
+        emit_segment(rec, &seg_all[(size_t)f * g.rect_cap + i]);
+    } else {
+        keep_all[(size_t)f * g.rect_cap + i] = 0;
+        const int q = atomicAdd(&nfail[f], 1);
+        // the first log_nfa is passed on bit-exactly through two ints
+        fail_all[((size_t)f * g.rect_cap + q) * 2] = make_int2(i, 0);
+        fail_all[((size_t)f * g.rect_cap + q) * 2 + 1] = make_int2(__double2loint(log_nfa), __double2hiint(log_nfa));
+    }
+}
+
+__global__ void __launch_bounds__(64) k_lsd_nfa_improve(const float *__restrict__ ang_all, const double *__restrict__ lgam,
+                                                        const LsdRect *__restrict__ rects_all, const int *__restrict__ nfail,
+                                                        const int2 *__restrict__ fail_all, float4 *__restrict__ seg_all,
+                                                        uint8_t *__restrict__ keep_all, LsdGeom g)
+{
+    const int f = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= nfail[f]) return;
+    const int i = fail_all[((size_t)f * g.rect_cap + q) * 2].x;
+    const int2 lv = fail_all[((size_t)f * g.rect_cap + q) * 2 + 1];
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    LsdRect rec = rects_all[(size_t)f * g.rect_cap + i];
+    const double log_nfa = rect_improve_rest(ang, lgam, g.sw, g.sh, g.log_nt, rec, 0.0, __hiloint2double(lv.y, lv.x));
+    if (log_nfa > 0.0) {
+        keep_all[(size_t)f * g.rect_cap + i] = 1;
+        emit_segment(rec, &seg_all[(size_t)f * g.rect_cap + i]);
     }
 }

@@ -1,0 +1,285 @@
+// match_host.hip -- host side of the matchers: scratch handle, grid construction, launch sequence, C ABI.
+// Mirrors the tracking overloads of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:44,61,78) and
+// ORB_SLAM2::LSDmatcher (include/LSDmatcher.h:32,40,43).
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "plf_common.h"
+
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define GRID_CELLS (GRID_COLS * GRID_ROWS)
+
+struct FrameDev {
+    int n;
+    const int *n_dev;
+    const plf_keypoint *keys;
+    const float *uright;
+    const uint8_t *desc;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;
+    const float *scale_factors;
+    int nlevels;
+    const int *cell_start;
+    const int *cell_idx;
+};
+struct MapDev { int m; const float *proj_x, *proj_y, *proj_xr; const int *level; const float *view_cos; const uint8_t *in_view, *desc, *obs_positive; };
+struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; };
+struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const uint8_t *desc; const float *scale_factors; };
+struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
+
+__global__ void k_build_grid(const FrameDev *, int *, int *, int *, int);
+__global__ void k_match_project_points(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int);
+__global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, float, int, int, int *, int *, uint8_t *, float4 *, int);
+__global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
+__global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
+__global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int);
+__global__ void k_match_project_lines(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
+__global__ void k_hamming_matrix(const uint8_t *, int, const uint8_t *, int, int *);
+
+struct plf_matcher {
+    int device, max_kp, max_mp, max_lines, max_batch;
+    hipStream_t stream;
+    FrameDev *d_frames;
+    LineFrameDev *d_lframes;
+    int *d_cell_start, *d_cell_idx, *d_cell_of, *d_knn_idx, *d_knn_dist;
+    uint8_t *d_done;
+    float4 *d_proj;
+    plf_dmatch *d_dm;
+    FrameDev *h_frames;      // host copy of the frame table last uploaded (skips the upload + sync when unchanged)
+    LineFrameDev *h_lframes;
+    int h_nframes, h_nlframes;
+};
+
+static void matcher_free(plf_matcher *h)
+{
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    free(h->h_frames); free(h->h_lframes);
+}
+
+extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t max_mappoints, int32_t max_lines, int32_t max_batch,
+                                  plf_matcher **out)
+{
+    if (!out || max_keypoints < 1 || max_mappoints < 1 || max_lines < 1 || max_batch < 1) return PLF_E_BADARG;
+    *out = nullptr;
+    if (max_keypoints > 18000 || max_lines > 18000) return PLF_E_BADARG;  // claim/owner arrays live in LDS
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[plf] no HIP device available: the matchers have no CPU path\n");
+        return PLF_E_HIP;
+    }
+    if (device < 0 || device >= ndev) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(device));
+    plf_matcher *h = (plf_matcher *)calloc(1, sizeof(plf_matcher));
+    if (!h) return PLF_E_NOMEM;
+    h->device = device; h->max_kp = max_keypoints; h->max_mp = max_mappoints; h->max_lines = max_lines; h->max_batch = max_batch;
+    const size_t B = (size_t)max_batch;
+    const size_t items = (size_t)(max_mappoints > max_keypoints ? max_mappoints : max_keypoints);
+#define ALLOC(ptr, bytes)                                                             \
+    do {                                                                              \
+        if (hipMalloc((void **)&(ptr), (bytes) > 0 ? (bytes) : 256) != hipSuccess) { \
+            matcher_free(h); free(h); return PLF_E_NOMEM;                             \
+        }                                                                             \
+    } while (0)
+    ALLOC(h->d_frames, B * sizeof(FrameDev));
+    ALLOC(h->d_lframes, B * sizeof(LineFrameDev));
+    ALLOC(h->d_cell_start, B * (GRID_CELLS + 1) * sizeof(int));
+    ALLOC(h->d_cell_idx, B * (size_t)max_keypoints * sizeof(int));
+    ALLOC(h->d_cell_of, B * (size_t)max_keypoints * sizeof(int));
+    ALLOC(h->d_done, B * items);
+    ALLOC(h->d_proj, (size_t)max_keypoints * sizeof(float4));
+    ALLOC(h->d_knn_idx, 2 * (size_t)max_lines * sizeof(int));
+    ALLOC(h->d_knn_dist, 2 * (size_t)max_lines * sizeof(int));
+    ALLOC(h->d_dm, 2 * (size_t)max_lines * sizeof(plf_dmatch));
+#undef ALLOC
+    h->h_frames = (FrameDev *)calloc(B, sizeof(FrameDev));
+    h->h_lframes = (LineFrameDev *)calloc(B, sizeof(LineFrameDev));
+    if (!h->h_frames || !h->h_lframes) { matcher_free(h); free(h); return PLF_E_NOMEM; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { matcher_free(h); free(h); return PLF_E_HIP; }
+    (void)hipFuncSetAttribute((const void *)k_match_project_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = h;
+    return PLF_OK;
+}
+
+extern "C" void plf_matcher_destroy(plf_matcher *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    matcher_free(h);
+    free(h);
+}
+
+static FrameDev make_frame(const plf_matcher *h, const plf_frame_view &v, int f)
+{
+    FrameDev d;
+    memset(&d, 0, sizeof(d));  // padding bytes take part in the memcmp cache test
+    d.n = v.n; d.n_dev = v.n_device; d.keys = v.keys_un; d.uright = v.uright; d.desc = v.desc;
+    d.min_x = v.min_x; d.min_y = v.min_y; d.max_x = v.max_x; d.max_y = v.max_y;
+    // mfGridElementWidthInv = float(FRAME_GRID_COLS) / float(mnMaxX - mnMinX)   (Frame ctor, so@0xfa27e)
+    d.inv_w = (float)GRID_COLS / (v.max_x - v.min_x);
+    d.inv_h = (float)GRID_ROWS / (v.max_y - v.min_y);
+    d.scale_factors = v.scale_factors; d.nlevels = v.nlevels;
+    d.cell_start = h->d_cell_start + (size_t)f * (GRID_CELLS + 1);
+    d.cell_idx = h->d_cell_idx + (size_t)f * h->max_kp;
+    return d;
+}
+
+extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *frames, int32_t n_frames, const plf_mappoint_view *mp, float th,
+                                        float nnratio, int32_t *match_of_kp, int32_t kp_stride, int32_t *nmatches, void *stream)
+{
+    if (!h || !frames || !mp || !match_of_kp || !nmatches || n_frames < 1 || n_frames > h->max_batch || mp->m < 0 || mp->m > h->max_mp)
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    std::vector<FrameDev> fd(n_frames);
+    int maxn = 1;
+    for (int f = 0; f < n_frames; f++) {
+        if (frames[f].n < 0 || frames[f].n > h->max_kp || frames[f].n > kp_stride || !(frames[f].max_x > frames[f].min_x) ||
+            !(frames[f].max_y > frames[f].min_y))
+            return PLF_E_BADARG;
+        fd[f] = make_frame(h, frames[f], f);
+        if (frames[f].n > maxn) maxn = frames[f].n;
+    }
+    if (h->h_nframes != n_frames || memcmp(h->h_frames, fd.data(), sizeof(FrameDev) * n_frames) != 0) {
+        PLF_HIP_TRY(hipStreamSynchronize(s));  // a previous launch may still read the old table
+        memcpy(h->h_frames, fd.data(), sizeof(FrameDev) * n_frames);
+        h->h_nframes = n_frames;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_frames, sizeof(FrameDev) * n_frames, hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_build_grid, dim3(n_frames), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
+    MapDev M;
+    M.m = mp->m; M.proj_x = mp->proj_x; M.proj_y = mp->proj_y; M.proj_xr = mp->proj_xr; M.level = mp->level; M.view_cos = mp->view_cos;
+    M.in_view = mp->in_view; M.desc = mp->desc; M.obs_positive = mp->obs_positive;
+    const int kp_cap = (maxn + 63) & ~63;
+    hipLaunchKernelGGL(k_match_project_points, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, M, th, nnratio, match_of_kp,
+                       kp_stride, nmatches, h->d_done, kp_cap);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose,
+                                           float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches,
+                                           void *stream)
+{
+    if (!h || !cur || !last || !pose || !match_of_kp || !nmatches || cur->n < 0 || cur->n > h->max_kp || last->n < 0 || last->n > h->max_kp ||
+        !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y))
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    FrameDev fd;
+    memset(&fd, 0, sizeof(fd));
+    fd = make_frame(h, *cur, 0);
+    if (h->h_nframes != 1 || memcmp(h->h_frames, &fd, sizeof(FrameDev)) != 0) {
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(h->h_frames, &fd, sizeof(FrameDev));
+        h->h_nframes = 1;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_frames, sizeof(FrameDev), hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_build_grid, dim3(1), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
+    LastDev L;
+    L.n = last->n; L.has_mp = last->has_mappoint; L.outlier = last->outlier; L.xw = last->world_pos; L.keys = last->keys; L.mp_desc = last->mp_desc;
+    const int kp_cap = ((cur->n > 0 ? cur->n : 1) + 63) & ~63;
+    hipLaunchKernelGGL(k_match_lastframe, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, L, *pose, th, mono, check_orientation, match_of_kp,
+                       nmatches, h->d_done, h->d_proj, kp_cap);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const uint8_t *train, int32_t nt, plf_dmatch *out,
+                                   int32_t mem, void *stream)
+{
+    if (!h || !query || !train || !out || nq < 1 || nt < 1 || nq > h->max_lines) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(128), 0, s, query, nq, train, nt, h->d_knn_idx, h->d_knn_dist);
+    plf_dmatch *d_out = mem == PLF_MEM_DEVICE ? out : h->d_dm;
+    hipLaunchKernelGGL(k_knn2_to_dmatch, dim3((2 * nq + 127) / 128), dim3(128), 0, s, h->d_knn_idx, h->d_knn_dist, nq, d_out);
+    PLF_HIP_TRY(hipGetLastError());
+    if (mem != PLF_MEM_DEVICE) {
+        PLF_HIP_TRY(hipMemcpyAsync(out, h->d_dm, sizeof(plf_dmatch) * 2 * nq, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return PLF_OK;
+}
+
+extern "C" int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_desc, int32_t nlast, const uint8_t *cur_desc, int32_t ncur,
+                                         const uint8_t *last_has_mapline, int32_t *match_of_line, int32_t *nmatches, void *stream)
+{
+    if (!h || !last_desc || !cur_desc || !last_has_mapline || !match_of_line || !nmatches || nlast > h->max_lines || ncur > h->max_lines)
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (nlast <= 0 || ncur < 2) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int), s)); return PLF_OK; }
+    hipLaunchKernelGGL(k_knn2, dim3((nlast + 127) / 128), dim3(128), 0, s, last_desc, nlast, cur_desc, ncur, h->d_knn_idx, h->d_knn_dist);
+    int P2 = 1;
+    while (P2 < nlast) P2 <<= 1;
+    hipLaunchKernelGGL(k_lines_lastframe, dim3(1), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_idx, h->d_knn_dist, nlast,
+                       last_has_mapline, match_of_line, nmatches, P2);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view *frames, int32_t n_frames, const plf_mapline_view *ml, float th,
+                                       float nnratio, int32_t *match_of_line, int32_t line_stride, int32_t *nmatches, void *stream)
+{
+    if (!h || !frames || !ml || !match_of_line || !nmatches || n_frames < 1 || n_frames > h->max_batch || ml->m < 0 || ml->m > h->max_mp)
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    std::vector<LineFrameDev> fd(n_frames);
+    memset(fd.data(), 0, sizeof(LineFrameDev) * n_frames);
+    int maxn = 1;
+    for (int f = 0; f < n_frames; f++) {
+        if (frames[f].n < 0 || frames[f].n > h->max_lines || frames[f].n > line_stride) return PLF_E_BADARG;
+        fd[f].n = frames[f].n; fd[f].n_dev = frames[f].n_device; fd[f].lines = frames[f].lines_un; fd[f].desc = frames[f].desc; fd[f].scale_factors = frames[f].scale_factors;
+        if (frames[f].n > maxn) maxn = frames[f].n;
+    }
+    if (h->h_nlframes != n_frames || memcmp(h->h_lframes, fd.data(), sizeof(LineFrameDev) * n_frames) != 0) {
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(h->h_lframes, fd.data(), sizeof(LineFrameDev) * n_frames);
+        h->h_nlframes = n_frames;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_lframes, h->h_lframes, sizeof(LineFrameDev) * n_frames, hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    MapLineDev M;
+    M.m = ml->m; M.x1 = ml->x1; M.y1 = ml->y1; M.x2 = ml->x2; M.y2 = ml->y2; M.level = ml->level; M.view_cos = ml->view_cos;
+    M.in_view = ml->in_view; M.desc = ml->desc;
+    const int cap = (maxn + 63) & ~63;
+    hipLaunchKernelGGL(k_match_project_lines, dim3(n_frames), dim3(256), (size_t)cap * 8, s, h->d_lframes, M, th, nnratio, match_of_line,
+                       line_stride, nmatches, h->d_done, cap);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_hamming256_matrix(const uint8_t *a, int32_t na, const uint8_t *b, int32_t nb, int32_t *dist, int32_t mem, int32_t device,
+                                     void *stream)
+{
+    if (!a || !b || !dist || na < 1 || nb < 1) return PLF_E_BADARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PLF_E_HIP;
+    PLF_HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *da = a, *db = b;
+    int *dd = dist;
+    void *ta = nullptr, *tb = nullptr, *td = nullptr;
+    if (mem != PLF_MEM_DEVICE) {
+        PLF_HIP_TRY(hipMalloc(&ta, (size_t)na * 32)); PLF_HIP_TRY(hipMalloc(&tb, (size_t)nb * 32)); PLF_HIP_TRY(hipMalloc(&td, (size_t)na * nb * 4));
+        PLF_HIP_TRY(hipMemcpyAsync(ta, a, (size_t)na * 32, hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipMemcpyAsync(tb, b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
+        da = (const uint8_t *)ta; db = (const uint8_t *)tb; dd = (int *)td;
+    }
+    hipLaunchKernelGGL(k_hamming_matrix, dim3((nb + 255) / 256, na), dim3(256), 0, s, da, na, db, nb, dd);
+    PLF_HIP_TRY(hipGetLastError());
+    if (mem != PLF_MEM_DEVICE) {
+        PLF_HIP_TRY(hipMemcpyAsync(dist, td, (size_t)na * nb * 4, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(ta); (void)hipFree(tb); (void)hipFree(td);
+    }
+    return PLF_OK;
+}

@@ -1,0 +1,504 @@
+// match_kernels.hip -- Hamming matchers of the tracking front-end on gfx950.
+//   k_build_grid            Frame::AssignFeaturesToGrid (so@0xf9120): 64x48 cell CSR, insertion order kept
+//   k_match_project_points  ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)   include/ORBmatcher.h:61, so@0x79f10
+//                           with Frame::GetFeaturesInArea (include/Frame.h:113, so@0xfbc60)
+//   k_match_lastframe       ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)  include/ORBmatcher.h:78, so@0x80d00
+//   k_knn2                  cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) (cv::batchDistance tie rules)
+//   k_lines_lastframe       LSDmatcher::SearchByProjection(Frame&, const Frame&) + Frame::lineDescriptorMAD
+//   k_match_project_lines   LSDmatcher::SearchByProjection(Frame&, vector<MapLine*>&, th) + Frame::GetLinesInArea
+//   k_hamming_matrix        DescriptorDistance over all pairs
+//
+// The reference loops are GREEDY: map point m skips key points claimed by map points before it, so its result
+// depends on theirs.  The kernels keep that order exactly with a conflict-free round scheme: in every round each
+// unfinished item posts its index (atomicMin) on all of its still-free candidates; an item that owns every one of
+// its candidates has no unfinished predecessor it could interact with, so it is decided now with the current
+// claims -- exactly what the sequential loop would see.  Items decided in one round never share a candidate, the
+// lowest unfinished item always qualifies, and the result equals the sequential loop for any schedule.
+// No MFMA: 256-bit XOR + popcount per candidate; the work is gather / compare bound.
+#include "plf_common.h"
+
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define GRID_CELLS (GRID_COLS * GRID_ROWS)
+#define TH_HIGH 100
+#define HISTO_LENGTH 30
+
+struct FrameDev {
+    int n;
+    const int *n_dev;
+    const plf_keypoint *keys;
+    const float *uright;
+    const uint8_t *desc;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;
+    const float *scale_factors;
+    int nlevels;
+    const int *cell_start;  // GRID_CELLS + 1
+    const int *cell_idx;    // n
+};
+
+__global__ void __launch_bounds__(256) k_build_grid(const FrameDev *__restrict__ frames, int *__restrict__ cell_start_all,
+                                                    int *__restrict__ cell_idx_all, int *__restrict__ cell_of_all, int kp_stride)
+{
+    __shared__ int cnt[GRID_CELLS + 1];
+    __shared__ int scan_tmp[260];
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    FrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int *cell_of = cell_of_all + (size_t)f * kp_stride;
+    int *cs = cell_start_all + (size_t)f * (GRID_CELLS + 1);
+    int *ci = cell_idx_all + (size_t)f * kp_stride;
+    for (int c = t; c <= GRID_CELLS; c += T) cnt[c] = 0;
+    __syncthreads();
+    for (int i = t; i < F.n; i += T) {
+        const plf_keypoint kp = F.keys[i];
+        const int px = (int)roundf((kp.x - F.min_x) * F.inv_w), py = (int)roundf((kp.y - F.min_y) * F.inv_h);
+        int c = -1;
+        if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) { c = px * GRID_ROWS + py; atomicAdd(&cnt[c], 1); }
+        cell_of[i] = c;
+    }
+    __syncthreads();
+    plf_block_excl_scan(cnt, GRID_CELLS + 1, scan_tmp);
+    for (int c = t; c <= GRID_CELLS; c += T) cs[c] = cnt[c];
+    __syncthreads();
+    // stable placement: rank of key point i among the earlier key points of the same cell
+    for (int i = t; i < F.n; i += T) {
+        const int c = cell_of[i];
+        if (c < 0) continue;
+        int r = 0;
+        for (int j = 0; j < i; j++) r += (cell_of[j] == c);
+        ci[cnt[c] + r] = i;
+    }
+}
+
+__device__ __forceinline__ float radius_by_viewing_cos(float vc) { return ((double)vc > 0.998) ? 2.5f : 4.0f; }
+
+__device__ __forceinline__ int hamming_g(const uint8_t *a, const uint8_t *b)
+{
+    const uint4 *pa = reinterpret_cast<const uint4 *>(a), *pb = reinterpret_cast<const uint4 *>(b);
+    const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+           __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// Frame::GetFeaturesInArea cell window
+struct CellWin { int x0, x1, y0, y1; bool ok; };
+__device__ __forceinline__ CellWin cell_window(const FrameDev &F, float x, float y, float r)
+{
+    CellWin w;
+    w.ok = false;
+    w.x0 = max(0, (int)floorf((x - F.min_x - r) * F.inv_w));
+    if (w.x0 >= GRID_COLS) return w;
+    w.x1 = min(GRID_COLS - 1, (int)ceilf((x - F.min_x + r) * F.inv_w));
+    if (w.x1 < 0) return w;
+    w.y0 = max(0, (int)floorf((y - F.min_y - r) * F.inv_h));
+    if (w.y0 >= GRID_ROWS) return w;
+    w.y1 = min(GRID_ROWS - 1, (int)ceilf((y - F.min_y + r) * F.inv_h));
+    if (w.y1 < 0) return w;
+    w.ok = true;
+    return w;
+}
+
+// iterate the candidates of GetFeaturesInArea(x, y, r, minLevel, maxLevel) in the reference order
+#define FOR_EACH_CANDIDATE(F, W, X, Y, R, MINL, MAXL, IDX, BODY)                                              \
+    {                                                                                                         \
+        const bool _chk = ((MINL) > 0) || ((MAXL) >= 0);                                                      \
+        for (int _ix = (W).x0; _ix <= (W).x1; _ix++)                                                          \
+            for (int _iy = (W).y0; _iy <= (W).y1; _iy++) {                                                    \
+                const int _c = _ix * GRID_ROWS + _iy;                                                         \
+                for (int _j = (F).cell_start[_c]; _j < (F).cell_start[_c + 1]; _j++) {                        \
+                    const int IDX = (F).cell_idx[_j];                                                         \
+                    const plf_keypoint _kp = (F).keys[IDX];                                                   \
+                    if (_chk) {                                                                               \
+                        if (_kp.octave < (MINL)) continue;                                                    \
+                        if ((MAXL) >= 0 && _kp.octave > (MAXL)) continue;                                     \
+                    }                                                                                         \
+                    if (!(fabsf(_kp.x - (X)) < (R) && fabsf(_kp.y - (Y)) < (R))) continue;                    \
+                    BODY                                                                                      \
+                }                                                                                             \
+            }                                                                                                 \
+    }
+
+struct MapDev {
+    int m;
+    const float *proj_x, *proj_y, *proj_xr;
+    const int *level;
+    const float *view_cos;
+    const uint8_t *in_view;
+    const uint8_t *desc;
+    const uint8_t *obs_positive;
+};
+
+__device__ __forceinline__ bool blocked(const int *claim, int k, const uint8_t *obs_positive)
+{
+    const int c = claim[k];
+    return c == -2 || (c >= 0 && (!obs_positive || obs_positive[c]));
+}
+
+// one block per frame; claim[] and owner[] live in LDS (kp_cap ints each)
+__global__ void __launch_bounds__(256) k_match_project_points(const FrameDev *__restrict__ frames, MapDev MP, float th, float nnratio,
+                                                              int *__restrict__ match_all, int kp_stride, int *__restrict__ nmatches,
+                                                              uint8_t *__restrict__ done_all, int kp_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + kp_cap;
+    __shared__ int s_left, s_acc;
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    FrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int *match = match_all + (size_t)f * kp_stride;
+    uint8_t *done = done_all + (size_t)f * MP.m;
+    const bool bFactor = th != 1.0f;
+    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    if (t == 0) s_acc = 0;
+    for (int m = t; m < MP.m; m += T) done[m] = MP.in_view[m] ? 0 : 1;
+    __syncthreads();
+    for (int round = 0; round <= MP.m; round++) {
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+        // post: every unfinished map point marks its free candidates with its index
+        for (int m = t; m < MP.m; m += T) {
+            if (done[m]) continue;
+            const int lvl = MP.level[m];
+            float r = radius_by_viewing_cos(MP.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            const float x = MP.proj_x[m], y = MP.proj_y[m];
+            const CellWin w = cell_window(F, x, y, rad);
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, { if (!blocked(claim, idx, MP.obs_positive)) atomicMin(&owner[idx], m); })
+        }
+        __syncthreads();
+        // decide: map points owning all their free candidates are independent of every unfinished predecessor
+        for (int m = t; m < MP.m; m += T) {
+            if (done[m]) continue;
+            const int lvl = MP.level[m];
+            float r = radius_by_viewing_cos(MP.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            const float x = MP.proj_x[m], y = MP.proj_y[m];
+            const CellWin w = cell_window(F, x, y, rad);
+            bool safe = true;
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, { if (!blocked(claim, idx, MP.obs_positive) && owner[idx] != m) safe = false; })
+            if (!safe) { atomicAdd(&s_left, 1); continue; }
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            const uint8_t *d = MP.desc + (size_t)m * 32;
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, {
+                if (blocked(claim, idx, MP.obs_positive)) continue;
+                if (F.uright) {
+                    const float ur = F.uright[idx];
+                    if (ur > 0) { const float er = fabsf(MP.proj_xr[m] - ur); if (er > rad) continue; }
+                }
+                const int dist = hamming_g(d, F.desc + (size_t)idx * 32);
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = _kp.octave; bestIdx = idx; }
+                else if (dist < bestDist2) { bestLevel2 = _kp.octave; bestDist2 = dist; }
+            })
+            done[m] = 1;
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+                claim[bestIdx] = m;  // only this map point can touch bestIdx in this round
+                atomicAdd(&s_acc, 1);
+            }
+        }
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) nmatches[f] = s_acc;
+}
+
+struct LastDev {
+    int n;
+    const uint8_t *has_mp, *outlier;
+    const float *xw;
+    const plf_keypoint *keys;
+    const uint8_t *mp_desc;
+};
+
+// one block; items = key points of the last frame.  proj[i] = (u, v, invzc, radius) prepared in the first phase.
+__global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf, plf_pose_pair P, float th, int mono, int check_ori,
+                                                         int *__restrict__ match, int *__restrict__ nmatches, uint8_t *__restrict__ done,
+                                                         float4 *__restrict__ proj, int kp_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + kp_cap;
+    __shared__ int s_left, s_acc, hist[HISTO_LENGTH], keepbin[3];
+    const int t = threadIdx.x, T = blockDim.x;
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    // twc = -Rcw^T tcw (generic double-accumulating gemm), tlc = Rlw twc + tlw (float small-matrix path)
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++)
+        twc[i] = (float)(-((double)P.Rcw[i] * P.tcw[0] + (double)P.Rcw[3 + i] * P.tcw[1] + (double)P.Rcw[6 + i] * P.tcw[2]));
+    for (int i = 0; i < 3; i++) tlc[i] = P.Rlw[i * 3] * twc[0] + P.Rlw[i * 3 + 1] * twc[1] + P.Rlw[i * 3 + 2] * twc[2] + P.tlw[i];
+    const bool bForward = tlc[2] > P.b && !mono, bBackward = -tlc[2] > P.b && !mono;
+    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    if (t < HISTO_LENGTH) hist[t] = 0;
+    if (t == 0) s_acc = 0;
+    for (int i = t; i < Lf.n; i += T) {
+        bool act = Lf.has_mp[i] && !Lf.outlier[i];
+        float4 pr = make_float4(0, 0, 0, 0);
+        if (act) {
+            const float *xw = Lf.xw + 3 * (size_t)i;
+            const float xc = P.Rcw[0] * xw[0] + P.Rcw[1] * xw[1] + P.Rcw[2] * xw[2] + P.tcw[0];
+            const float yc = P.Rcw[3] * xw[0] + P.Rcw[4] * xw[1] + P.Rcw[5] * xw[2] + P.tcw[1];
+            const float zc = P.Rcw[6] * xw[0] + P.Rcw[7] * xw[1] + P.Rcw[8] * xw[2] + P.tcw[2];
+            const float invzc = (float)(1.0 / (double)zc);
+            if (invzc < 0) act = false;
+            const float u = P.fx * xc * invzc + P.cx, v = P.fy * yc * invzc + P.cy;
+            if (u < F.min_x || u > F.max_x) act = false;
+            if (v < F.min_y || v > F.max_y) act = false;
+            if (act) pr = make_float4(u, v, invzc, th * F.scale_factors[Lf.keys[i].octave]);
+        }
+        proj[i] = pr;
+        done[i] = act ? 0 : 1;
+    }
+    __syncthreads();
+    for (int round = 0; round <= Lf.n; round++) {
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+        for (int i = t; i < Lf.n; i += T) {
+            if (done[i]) continue;
+            const float4 pr = proj[i];
+            const int oct = Lf.keys[i].octave;
+            const int minL = bForward ? oct : (bBackward ? 0 : oct - 1), maxL = bForward ? -1 : (bBackward ? oct : oct + 1);
+            const CellWin w = cell_window(F, pr.x, pr.y, pr.w);
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (claim[idx] == -1) atomicMin(&owner[idx], i); })
+        }
+        __syncthreads();
+        for (int i = t; i < Lf.n; i += T) {
+            if (done[i]) continue;
+            const float4 pr = proj[i];
+            const int oct = Lf.keys[i].octave;
+            const int minL = bForward ? oct : (bBackward ? 0 : oct - 1), maxL = bForward ? -1 : (bBackward ? oct : oct + 1);
+            const CellWin w = cell_window(F, pr.x, pr.y, pr.w);
+            bool safe = true;
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (claim[idx] == -1 && owner[idx] != i) safe = false; })
+            if (!safe) { atomicAdd(&s_left, 1); continue; }
+            int bestDist = 256, bestIdx2 = -1;
+            const uint8_t *d = Lf.mp_desc + 32 * (size_t)i;
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, {
+                if (claim[idx] != -1) continue;
+                if (F.uright) {
+                    const float urr = F.uright[idx];
+                    if (urr > 0) { const float ur = pr.x - P.bf * pr.z; const float er = fabsf(ur - urr); if (er > pr.w) continue; }
+                }
+                const int dist = hamming_g(d, F.desc + 32 * (size_t)idx);
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = idx; }
+            })
+            done[i] = 1;
+            if (bestDist <= TH_HIGH) {
+                claim[bestIdx2] = i;
+                atomicAdd(&s_acc, 1);
+                if (check_ori) {
+                    float rot = Lf.keys[i].angle - F.keys[bestIdx2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * (1.0f / 12.0f));  // this binary: HISTO_LENGTH / 360 (so@0x829b5)
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    atomicAdd(&hist[bin], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    if (check_ori) {
+        if (t == 0) {  // ComputeThreeMaxima (so@0x823eb)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            keepbin[0] = i1; keepbin[1] = i2; keepbin[2] = i3;
+        }
+        __syncthreads();
+        for (int k = t; k < F.n; k += T) {
+            const int i = claim[k];
+            if (i < 0 || match[k] >= 0) continue;  // only matches made by this call sit in the histogram
+            float rot = Lf.keys[i].angle - F.keys[k].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / 12.0f));
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { claim[k] = -1; atomicSub(&s_acc, 1); }
+        }
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) *nmatches = s_acc;
+}
+
+// cv::batchDistance, K = 2: strict '<' against the current worst, equal distances keep the earlier train index first
+__global__ void __launch_bounds__(128) k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ tr, int nt,
+                                              int *__restrict__ idx, int *__restrict__ dist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1, i1 = -1;
+    for (int j = 0; j < nt; j++) {
+        const int d = hamming_g(q + 32 * (size_t)i, tr + 32 * (size_t)j);
+        if (d < d1) {
+            if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+            else { d1 = d; i1 = j; }
+        }
+    }
+    idx[2 * i] = i0; idx[2 * i + 1] = i1;
+    dist[2 * i] = d0; dist[2 * i + 1] = d1;
+}
+
+__global__ void __launch_bounds__(128) k_knn2_to_dmatch(const int *__restrict__ idx, const int *__restrict__ dist, int nq, plf_dmatch *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * nq) return;
+    plf_dmatch m;
+    m.queryIdx = i >> 1; m.trainIdx = idx[i]; m.imgIdx = 0; m.distance = (float)dist[i];
+    out[i] = m;
+}
+
+__device__ void block_sort_floats(float *v, int n, int P2)
+{
+    const int t = threadIdx.x, T = blockDim.x;
+    for (int k2 = 2; k2 <= P2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P2; i += T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float a = v[i], b = v[ixj];
+                    const bool asc = (i & k2) == 0;
+                    if (asc ? (a > b) : (a < b)) { v[i] = b; v[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    (void)n;
+}
+
+// Frame::lineDescriptorMAD + LSDmatcher::SearchByProjection(CurrentFrame, LastFrame); one block, nlast <= cap (power of two >= nlast)
+__global__ void __launch_bounds__(256) k_lines_lastframe(const int *__restrict__ idx, const int *__restrict__ dist, int nlast,
+                                                         const uint8_t *__restrict__ last_has_mapline, int *__restrict__ match_of_line,
+                                                         int *__restrict__ nmatches, int P2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *v = (float *)smem;
+    __shared__ int s_cnt;
+    const int t = threadIdx.x, T = blockDim.x;
+    const float INF = 3.0e38f;
+    // nn12 MAD: median of (d1 - d0), then median of |d12 - median|
+    for (int i = t; i < P2; i += T) v[i] = i < nlast ? (float)dist[2 * i + 1] - (float)dist[2 * i] : INF;
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+    block_sort_floats(v, nlast, P2);
+    const double med = v[nlast / 2];
+    __syncthreads();
+    for (int i = t; i < P2; i += T)
+        v[i] = i < nlast ? fabsf((float)((double)((float)dist[2 * i + 1] - (float)dist[2 * i]) - med)) : INF;
+    __syncthreads();
+    block_sort_floats(v, nlast, P2);
+    const double th12 = 1.4826 * (double)v[nlast / 2] * 0.5;
+    __syncthreads();
+    for (int q = t; q < nlast; q += T) {
+        const double d12 = (double)((float)dist[2 * q + 1] - (float)dist[2 * q]);
+        if (d12 > th12 && last_has_mapline[q]) {
+            atomicMax(&match_of_line[idx[2 * q]], q);  // queries are visited in increasing order: the last one wins
+            atomicAdd(&s_cnt, 1);
+        }
+    }
+    __syncthreads();
+    if (t == 0) *nmatches = s_cnt;
+}
+
+struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const uint8_t *desc; const float *scale_factors; };
+struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
+
+// Frame::GetLinesInArea test for line i
+__device__ __forceinline__ bool line_in_area(const plf_keyline &kl, float x1, float y1, float x2, float y2, float r, int minLevel, int maxLevel)
+{
+    const double dx = 0.5 * (double)(x1 + x2) - (double)kl.pt_x, dy = 0.5 * (double)(y1 + y2) - (double)kl.pt_y;
+    const double distance = dx * dx + dy * dy;
+    if (distance > (double)(r * r)) return false;
+    const float slope = (y1 - y2) / (x1 - x2) - kl.angle;
+    if ((double)slope > (double)r * 0.01) return false;
+    if ((minLevel > 0) || (maxLevel > 0)) {
+        if (kl.octave < minLevel) return false;
+        if (maxLevel >= 0 && kl.octave > maxLevel) return false;
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
+                                                             int *__restrict__ match_all, int line_stride, int *__restrict__ nmatches,
+                                                             uint8_t *__restrict__ done_all, int line_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + line_cap;
+    __shared__ int s_left, s_acc;
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    LineFrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int *match = match_all + (size_t)f * line_stride;
+    uint8_t *done = done_all + (size_t)f * ML.m;
+    const bool bFactor = th != 1.0f;
+    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    if (t == 0) s_acc = 0;
+    for (int m = t; m < ML.m; m += T) done[m] = ML.in_view[m] ? 0 : 1;
+    __syncthreads();
+    for (int round = 0; round <= ML.m; round++) {
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+        for (int m = t; m < ML.m; m += T) {
+            if (done[m]) continue;
+            const int lvl = ML.level[m];
+            float r = radius_by_viewing_cos(ML.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            for (int i = 0; i < F.n; i++)
+                if (claim[i] == -1 && line_in_area(F.lines[i], ML.x1[m], ML.y1[m], ML.x2[m], ML.y2[m], rad, lvl - 1, lvl)) atomicMin(&owner[i], m);
+        }
+        __syncthreads();
+        for (int m = t; m < ML.m; m += T) {
+            if (done[m]) continue;
+            const int lvl = ML.level[m];
+            float r = radius_by_viewing_cos(ML.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            bool safe = true;
+            for (int i = 0; i < F.n; i++)
+                if (claim[i] == -1 && owner[i] != m && line_in_area(F.lines[i], ML.x1[m], ML.y1[m], ML.x2[m], ML.y2[m], rad, lvl - 1, lvl)) safe = false;
+            if (!safe) { atomicAdd(&s_left, 1); continue; }
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            const uint8_t *d = ML.desc + 32 * (size_t)m;
+            for (int i = 0; i < F.n; i++) {
+                if (claim[i] != -1) continue;
+                const plf_keyline kl = F.lines[i];
+                if (!line_in_area(kl, ML.x1[m], ML.y1[m], ML.x2[m], ML.y2[m], rad, lvl - 1, lvl)) continue;
+                const int dist = hamming_g(d, F.desc + 32 * (size_t)i);
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kl.octave; bestIdx = i; }
+                else if (dist < bestDist2) { bestLevel2 = kl.octave; bestDist2 = dist; }
+            }
+            done[m] = 1;
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+                claim[bestIdx] = m;
+                atomicAdd(&s_acc, 1);
+            }
+        }
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) nmatches[f] = s_acc;
+}
+
+__global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t *__restrict__ a, int na, const uint8_t *__restrict__ b, int nb,
+                                                        int *__restrict__ dist)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= nb || i >= na) return;
+    dist[(size_t)i * nb + j] = hamming_g(a + 32 * (size_t)i, b + 32 * (size_t)j);
+}

@@ -1,0 +1,99 @@
+"""Host-side mirror of the tracking matchers (ORB_SLAM2::ORBmatcher include/ORBmatcher.h:44,61,78 and
+ORB_SLAM2::LSDmatcher include/LSDmatcher.h:32,40,43) over the C ABI.  All feature arrays are device
+tensors (torch, cuda); nothing is computed on the host."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+
+def DescriptorDistance(a, b):
+    """static int ORBmatcher::DescriptorDistance(const Mat&, const Mat&) -- two 32-byte host descriptors"""
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return L.lib().plf_hamming256(L.vp(a), L.vp(b))
+
+
+class Matcher:
+    def __init__(self, max_keypoints=4096, max_mappoints=16384, max_lines=1024, max_batch=1, device=0):
+        self._h = C.c_void_p()
+        L.check(L.lib().plf_matcher_create(device, max_keypoints, max_mappoints, max_lines, max_batch, C.byref(self._h)), "plf_matcher_create")
+
+    def close(self):
+        if self._h:
+            L.lib().plf_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def frame_view(n, keys_un, desc, scale_factors, bounds, uright=None, n_device=None):
+        v = L.FrameView()
+        v.n = int(n); v.n_device = L.vp(n_device).value if n_device is not None else None
+        v.keys_un = L.vp(keys_un).value; v.uright = L.vp(uright).value if uright is not None else None
+        v.desc = L.vp(desc).value
+        v.min_x, v.min_y, v.max_x, v.max_y = bounds
+        v.scale_factors = L.vp(scale_factors).value; v.nlevels = int(scale_factors.shape[0])
+        return v
+
+    def SearchByProjection(self, frames, mp, th, nnratio, match_of_kp, kp_stride, nmatches, stream=None):
+        """frames: list of FrameView; mp: dict of device tensors (proj_x, proj_y, proj_xr, level, view_cos, in_view, desc[, obs_positive])"""
+        arr = (L.FrameView * len(frames))(*frames)
+        m = L.MapPointView()
+        m.m = int(mp["desc"].shape[0])
+        for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos", "in_view", "desc"):
+            setattr(m, k, L.vp(mp[k]).value)
+        m.obs_positive = L.vp(mp["obs_positive"]).value if mp.get("obs_positive") is not None else None
+        L.check(L.lib().plf_match_project_points(self._h, arr, len(frames), C.byref(m), C.c_float(th), C.c_float(nnratio), L.vp(match_of_kp),
+                                                 int(kp_stride), L.vp(nmatches), C.c_void_p(stream) if stream else None),
+                "plf_match_project_points")
+
+    def SearchByProjectionLastFrame(self, cur, last, pose, th, mono, check_ori, match_of_kp, nmatches, stream=None):
+        lv = L.LastFrameView()
+        lv.n = int(last["mp_desc"].shape[0])
+        lv.has_mappoint = L.vp(last["has_mappoint"]).value; lv.outlier = L.vp(last["outlier"]).value
+        lv.world_pos = L.vp(last["world_pos"]).value; lv.keys = L.vp(last["keys"]).value; lv.mp_desc = L.vp(last["mp_desc"]).value
+        pp = L.PosePair()
+        for name in ("Rcw", "tcw", "Rlw", "tlw"):
+            a = np.asarray(pose[name], np.float32).ravel()
+            getattr(pp, name)[:] = a.tolist()
+        for name in ("fx", "fy", "cx", "cy", "bf", "b"):
+            setattr(pp, name, float(pose[name]))
+        L.check(L.lib().plf_match_project_lastframe(self._h, C.byref(cur), C.byref(lv), C.byref(pp), C.c_float(th), int(mono), int(check_ori),
+                                                    L.vp(match_of_kp), L.vp(nmatches), C.c_void_p(stream) if stream else None),
+                "plf_match_project_lastframe")
+
+    def knnMatch(self, query, train):
+        """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
+        nq, nt = int(query.shape[0]), int(train.shape[0])
+        out = np.zeros((nq, 2), L.DMATCH_DTYPE)
+        L.check(L.lib().plf_match_lines_knn(self._h, L.vp(query), nq, L.vp(train), nt, L.vp(out), L.MEM_HOST, None), "plf_match_lines_knn")
+        return out
+
+    def SearchLinesLastFrame(self, last_desc, cur_desc, last_has_mapline, match_of_line, nmatches, stream=None):
+        L.check(L.lib().plf_match_lines_lastframe(self._h, L.vp(last_desc), int(last_desc.shape[0]), L.vp(cur_desc), int(cur_desc.shape[0]),
+                                                  L.vp(last_has_mapline), L.vp(match_of_line), L.vp(nmatches),
+                                                  C.c_void_p(stream) if stream else None), "plf_match_lines_lastframe")
+
+    @staticmethod
+    def lineframe_view(n, lines_un, desc, scale_factors, n_device=None):
+        v = L.LineFrameView()
+        v.n = int(n); v.n_device = L.vp(n_device).value if n_device is not None else None
+        v.lines_un = L.vp(lines_un).value; v.desc = L.vp(desc).value; v.scale_factors = L.vp(scale_factors).value
+        return v
+
+    def SearchLinesByProjection(self, frames, ml, th, nnratio, match_of_line, line_stride, nmatches, stream=None):
+        arr = (L.LineFrameView * len(frames))(*frames)
+        m = L.MapLineView()
+        m.m = int(ml["desc"].shape[0])
+        for k in ("x1", "y1", "x2", "y2", "level", "view_cos", "in_view", "desc"):
+            setattr(m, k, L.vp(ml[k]).value)
+        L.check(L.lib().plf_match_project_lines(self._h, arr, len(frames), C.byref(m), C.c_float(th), C.c_float(nnratio), L.vp(match_of_line),
+                                                int(line_stride), L.vp(nmatches), C.c_void_p(stream) if stream else None),
+                "plf_match_project_lines")

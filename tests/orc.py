@@ -150,3 +150,82 @@ def line_extract(gray, nkeep=100, seed_order=0):
     n = L.orc_line_extract(p(gray), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(nkeep), C.c_int(seed_order), p(kl), p(desc),
                            p(eq), C.c_int(cap), C.byref(nd))
     return dict(kl=kl[:n].copy(), desc=desc[:n].copy(), eq=eq[:n].copy(), ndetected=nd.value)
+
+
+# ---------------------------------------------------------------- matcher wrappers
+def _frame(kps, desc, uright, scale, bounds):
+    ux = np.ascontiguousarray(kps["x"]); uy = np.ascontiguousarray(kps["y"]); oc = np.ascontiguousarray(kps["octave"])
+    ang = np.ascontiguousarray(kps["angle"])
+    ur = np.ascontiguousarray(uright if uright is not None else np.full(len(kps), -1, np.float32), np.float32)
+    desc = np.ascontiguousarray(desc); scale = np.ascontiguousarray(scale, np.float32)
+    F = Frame()
+    F.n = len(kps); F.ux = p(ux).value; F.uy = p(uy).value; F.octave = p(oc).value; F.uright = p(ur).value; F.desc = p(desc).value
+    F.angle = p(ang).value
+    F.minx, F.miny, F.maxx, F.maxy = bounds
+    F.grid_inv_w = np.float32(64.0) / np.float32(bounds[2] - bounds[0]); F.grid_inv_h = np.float32(48.0) / np.float32(bounds[3] - bounds[1])
+    F.scale_factors = p(scale).value; F.nlevels = len(scale)
+    return F, (ux, uy, oc, ur, desc, scale, ang)
+
+
+def search_by_projection_map(kps, desc, uright, scale, bounds, mp, th, nnratio, match_init):
+    L = lib()
+    F, keep = _frame(kps, desc, uright, scale, bounds)
+    arrs = {k: np.ascontiguousarray(v) for k, v in mp.items()}
+    M = MapPoints()
+    M.m = len(arrs["desc"])
+    for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos", "in_view", "desc"):
+        setattr(M, k, p(arrs[k]).value)
+    M.obs_positive = p(arrs["obs_positive"]).value if "obs_positive" in arrs else None
+    match = np.ascontiguousarray(match_init, np.int32).copy()
+    n = L.orc_search_by_projection_map(C.byref(F), C.byref(M), C.c_float(th), C.c_float(nnratio), p(match))
+    return match, n
+
+
+def search_by_projection_last(kps, desc, uright, scale, bounds, last, pose, th, mono, check_ori, match_init):
+    L = lib()
+    F, keep = _frame(kps, desc, uright, scale, bounds)
+    lk = last["keys"]
+    oc = np.ascontiguousarray(lk["octave"]); ang = np.ascontiguousarray(lk["angle"])
+    arrs = {k: np.ascontiguousarray(last[k]) for k in ("has_mappoint", "outlier", "world_pos", "mp_desc")}
+    Lf = LastFrame()
+    Lf.n = len(lk); Lf.has_mp = p(arrs["has_mappoint"]).value; Lf.outlier = p(arrs["outlier"]).value; Lf.xw = p(arrs["world_pos"]).value
+    Lf.octave = p(oc).value; Lf.angle = p(ang).value; Lf.mp_desc = p(arrs["mp_desc"]).value
+    R = {k: np.ascontiguousarray(np.asarray(pose[k], np.float32).ravel()) for k in ("Rcw", "tcw", "Rlw", "tlw")}
+    match = np.ascontiguousarray(match_init, np.int32).copy()
+    n = L.orc_search_by_projection_last(C.byref(F), C.byref(Lf), p(R["Rcw"]), p(R["tcw"]), p(R["Rlw"]), p(R["tlw"]), C.c_float(pose["fx"]),
+                                        C.c_float(pose["fy"]), C.c_float(pose["cx"]), C.c_float(pose["cy"]), C.c_float(pose["bf"]),
+                                        C.c_float(pose["b"]), C.c_float(th), C.c_int(mono), C.c_int(check_ori), p(match))
+    return match, n
+
+
+def knn2(q, t):
+    L = lib()
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+    L.orc_knn2_hamming(p(q), C.c_int(len(q)), p(t), C.c_int(len(t)), p(idx), p(dist))
+    return idx, dist
+
+
+def match_lines_knn(last_desc, cur_desc, has_ml):
+    L = lib()
+    a = np.ascontiguousarray(last_desc); b = np.ascontiguousarray(cur_desc); hm = np.ascontiguousarray(has_ml, np.uint8)
+    match = np.full(len(b), -1, np.int32)
+    n = L.orc_match_lines_knn(p(a), C.c_int(len(a)), p(b), C.c_int(len(b)), p(hm), p(match))
+    return match, n
+
+
+def search_lines_by_projection(kl, ldesc, scale, ml, th, nnratio, match_init):
+    L = lib()
+    px = np.ascontiguousarray(kl["pt_x"]); py = np.ascontiguousarray(kl["pt_y"]); an = np.ascontiguousarray(kl["angle"])
+    oc = np.ascontiguousarray(kl["octave"]); d = np.ascontiguousarray(ldesc); sc = np.ascontiguousarray(scale, np.float32)
+    F = LineFrame()
+    F.n = len(kl); F.pt_x = p(px).value; F.pt_y = p(py).value; F.angle = p(an).value; F.octave = p(oc).value; F.desc = p(d).value
+    F.scale_factors = p(sc).value
+    arrs = {k: np.ascontiguousarray(v) for k, v in ml.items()}
+    M = MapLines()
+    M.m = len(arrs["desc"])
+    for k in ("x1", "y1", "x2", "y2", "level", "view_cos", "in_view", "desc"):
+        setattr(M, k, p(arrs[k]).value)
+    match = np.ascontiguousarray(match_init, np.int32).copy()
+    n = L.orc_search_by_projection_lines(C.byref(F), C.byref(M), C.c_float(th), C.c_float(nnratio), p(match))
+    return match, n
