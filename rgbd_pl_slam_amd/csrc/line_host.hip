@@ -194,8 +194,9 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
-    (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
     h->cur_w = -1; h->cur_h = -1;
     rc = line_configure(h, p->max_width, p->max_height);

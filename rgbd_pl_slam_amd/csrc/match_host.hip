@@ -97,9 +97,10 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     h->h_lframes = (LineFrameDev *)calloc(B, sizeof(LineFrameDev));
     if (!h->h_frames || !h->h_lframes) { matcher_free(h); free(h); return PLF_E_NOMEM; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { matcher_free(h); free(h); return PLF_E_HIP; }
-    (void)hipFuncSetAttribute((const void *)k_match_project_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_project_points, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();  // the attribute call is advisory; never leave a sticky error behind for other HIP users
     *out = h;
     return PLF_OK;
 }

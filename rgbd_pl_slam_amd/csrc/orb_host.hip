@@ -301,6 +301,7 @@ extern "C" int plf_orb_create(const plf_orb_params *p, plf_orb **out)
     (void)hipMemset(h->d_score, 0, B * g.blur_stride);
     plf_orb_upload_constants(h->umax);
     (void)hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_lds);
+    (void)hipGetLastError();
     h->cur_w = -1; h->cur_h = -1;
     rc = orb_configure(h, p->max_width, p->max_height);
     if (rc != PLF_OK) { orb_free(h); free(h); return rc; }

@@ -126,7 +126,8 @@ def test_line_matchers():
     has_ml = (rng.uniform(0, 1, len(a["desc"])) < 0.8).astype(np.uint8)
     ref_match, ref_n = orc.match_lines_knn(a["desc"], cur_desc, has_ml)
     match = torch.full((len(cur_desc),), -1, dtype=torch.int32, device="cuda"); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
-    m.SearchLinesLastFrame(_dev(a["desc"]), _dev(cur_desc), _dev(has_ml), match, nm)
+    d_last, d_cur, d_has = _dev(a["desc"]), _dev(cur_desc), _dev(has_ml)
+    m.SearchLinesLastFrame(d_last, d_cur, d_has, match, nm)
     torch.cuda.synchronize()
     assert int(nm[0]) == ref_n and ref_n > 10
     assert np.array_equal(match.cpu().numpy(), ref_match)
@@ -137,9 +138,11 @@ def test_line_matchers():
     ref_match, ref_n = orc.search_lines_by_projection(a["kl"], a["desc"], scale, ml, 3.0, 0.8, init)
     assert ref_n > 5
     dkl = torch.from_numpy(np.frombuffer(np.ascontiguousarray(a["kl"]).tobytes(), np.uint8).copy()).cuda()
-    view = Matcher.lineframe_view(len(a["kl"]), dkl, _dev(a["desc"]), _dev(scale))
+    dld = _dev(a["desc"]); dsc = _dev(scale)   # views hold raw addresses: keep the tensors alive
+    view = Matcher.lineframe_view(len(a["kl"]), dkl, dld, dsc)
+    dml = {k: _dev(v) for k, v in ml.items()}
     match = _dev(init); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
-    m.SearchLinesByProjection([view], {k: _dev(v) for k, v in ml.items()}, 3.0, 0.8, match, len(a["kl"]), nm)
+    m.SearchLinesByProjection([view], dml, 3.0, 0.8, match, len(a["kl"]), nm)
     torch.cuda.synchronize()
     assert int(nm[0]) == ref_n
     assert np.array_equal(match.cpu().numpy(), ref_match)
