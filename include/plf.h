@@ -129,6 +129,11 @@ int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int
                            int32_t height, ptrdiff_t pitch, ptrdiff_t frame_stride, plf_keyline *lines, uint8_t *ldesc,
                            double *line_eq, int32_t *n_out, int32_t out_mem, int32_t capacity, void *stream);
 
+/* Measurement hook (bench.py roofline): when enabled, every launch of the region-growing kernel -- the dominant
+ * kernel of the whole front-end -- is bracketed by HIP events on the stream it is launched on.  The call
+ * synchronises, then returns the accumulated kernel milliseconds and the number of launches since the last reset. */
+int plf_line_profile(plf_line *h, int32_t enable, int32_t reset, double *ms_total, int32_t *launches);
+
 /* Test hook: all LSD segments (x1,y1,x2,y2) of frame `frame` in detection order, before the top-N cut. */
 int plf_line_get_segments(plf_line *h, int32_t frame, float *segs, int32_t capacity, int32_t *n_out);
 

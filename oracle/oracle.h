@@ -153,6 +153,10 @@ void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const o
 int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
                      uint8_t *desc, double *lineeq, int cap, int *ndetected);
 
+/* ---- CPU baseline driver (bench_oracle.c) */
+double orc_frontend_throughput(const uint8_t *imgs, int n_distinct, int w, int h, int n_frames, int threads, int nfeatures, int nlines,
+                               const orc_mappoints *MP, const orc_maplines *ML, float th, float nnratio, long *checksum);
+
 #ifdef __cplusplus
 }
 #endif

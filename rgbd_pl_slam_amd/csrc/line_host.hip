@@ -47,6 +47,10 @@ struct plf_line {
     int *d_xofs, *d_yofs;
     float2 *d_xa, *d_yb;
     int last_frames;
+    int prof_on, prof_n;
+    hipEvent_t prof_ev[2 * 512];  // (start, stop) pairs of the region kernel
+    double prof_ms;
+    int prof_launches;
 };
 
 static void line_free(plf_line *h)
@@ -56,6 +60,7 @@ static void line_free(plf_line *h)
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_fail};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
 }
 
 static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
@@ -228,8 +233,14 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     hipLaunchKernelGGL(k_lsd_resize, gsc, dim3(256), 0, s, h->d_blur, h->d_scaled, g, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     hipLaunchKernelGGL(k_lsd_grad, gsc, dim3(256), 0, s, h->d_scaled, h->d_ang, h->d_modgrad, h->d_cs, g);
     hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
+    const bool prof = h->prof_on && h->prof_n < 512;
+    if (prof) {
+        if (!h->prof_ev[2 * h->prof_n]) { (void)hipEventCreate(&h->prof_ev[2 * h->prof_n]); (void)hipEventCreate(&h->prof_ev[2 * h->prof_n + 1]); }
+        (void)hipEventRecord(h->prof_ev[2 * h->prof_n], s);
+    }
     hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_rxy, h->d_rdeg, h->d_rmod,
                        h->d_rects, nrect, status, g);
+    if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     hipLaunchKernelGGL(k_lsd_nfa_first, dim3((g.rect_cap + 63) / 64, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_seg,
                        h->d_keep, nfail, h->d_fail, g);
     hipLaunchKernelGGL(k_lsd_nfa_improve, dim3((g.rect_cap + 63) / 64, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nfail, h->d_fail,
@@ -303,6 +314,31 @@ extern "C" int plf_line_extract(plf_line *h, const uint8_t *gray, int32_t width,
 {
     return plf_line_extract_batch(h, gray, PLF_MEM_HOST, 1, width, height, pitch, (ptrdiff_t)pitch * height, lines, ldesc, line_eq, n_out,
                                   PLF_MEM_HOST, capacity, nullptr);
+}
+
+static void line_prof_collect(plf_line *h)
+{
+    for (int i = 0; i < h->prof_n; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(h->prof_ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) == hipSuccess) {
+            h->prof_ms += ms;
+            h->prof_launches++;
+        }
+    }
+    h->prof_n = 0;
+}
+
+extern "C" int plf_line_profile(plf_line *h, int32_t enable, int32_t reset, double *ms_total, int32_t *launches)
+{
+    if (!h) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    line_prof_collect(h);
+    if (ms_total) *ms_total = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    if (reset) { h->prof_ms = 0; h->prof_launches = 0; }
+    h->prof_on = enable ? 1 : 0;
+    return PLF_OK;
 }
 
 extern "C" int plf_line_get_segments(plf_line *h, int32_t frame, float *segs, int32_t capacity, int32_t *n_out)

@@ -55,6 +55,12 @@ class LineSegment:
                                                L.vp(d_lines), L.vp(d_desc), L.vp(d_eq), L.vp(d_n), L.MEM_DEVICE, capacity,
                                                C.c_void_p(stream) if stream else None), "plf_line_extract_batch")
 
+    def profile(self, enable=True, reset=False):
+        """(accumulated ms, launches) of the region-growing kernel measured with HIP events on its stream"""
+        ms = C.c_double(0); n = C.c_int32(0)
+        L.check(L.lib().plf_line_profile(self._h, int(enable), int(reset), C.byref(ms), C.byref(n)), "plf_line_profile")
+        return ms.value, n.value
+
     def segments(self, frame=0):
         """test hook: all LSD segments of the last call in detection order"""
         n = C.c_int32()
