@@ -28,7 +28,8 @@ struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const u
 struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
 
 __global__ void k_build_grid(const FrameDev *, int *, int *, int *, int);
-__global__ void k_match_project_points(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int);
+__global__ void k_match_project_points(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, uint32_t *, int *, int, int *);
+__global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
@@ -45,6 +46,9 @@ struct plf_matcher {
     uint8_t *d_done;
     float4 *d_proj;
     plf_dmatch *d_dm;
+    uint32_t *d_cand;        // cached candidate lists of the projection matcher
+    int *d_cand_off, *d_overflow;
+    int cand_cap;
     FrameDev *h_frames;      // host copy of the frame table last uploaded (skips the upload + sync when unchanged)
     LineFrameDev *h_lframes;
     int h_nframes, h_nlframes;
@@ -52,7 +56,7 @@ struct plf_matcher {
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     free(h->h_frames); free(h->h_lframes);
@@ -92,12 +96,20 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     ALLOC(h->d_knn_idx, 2 * (size_t)max_lines * sizeof(int));
     ALLOC(h->d_knn_dist, 2 * (size_t)max_lines * sizeof(int));
     ALLOC(h->d_dm, 2 * (size_t)max_lines * sizeof(plf_dmatch));
+    // average of 64 cached candidates per map point; denser frames use the fallback kernel (PLF_MATCH_CAND_AVG: test hook)
+    const char *avg_env = getenv("PLF_MATCH_CAND_AVG");
+    const int cand_avg = (avg_env && atoi(avg_env) > 0) ? atoi(avg_env) : 64;
+    h->cand_cap = cand_avg * max_mappoints;
+    ALLOC(h->d_cand, B * (size_t)h->cand_cap * sizeof(uint32_t));
+    ALLOC(h->d_cand_off, B * ((size_t)max_mappoints + 1) * sizeof(int));
+    ALLOC(h->d_overflow, B * sizeof(int));
 #undef ALLOC
     h->h_frames = (FrameDev *)calloc(B, sizeof(FrameDev));
     h->h_lframes = (LineFrameDev *)calloc(B, sizeof(LineFrameDev));
     if (!h->h_frames || !h->h_lframes) { matcher_free(h); free(h); return PLF_E_NOMEM; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { matcher_free(h); free(h); return PLF_E_HIP; }
     (void)hipFuncSetAttribute((const void *)k_match_project_points, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_project_points_slow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();  // the attribute call is advisory; never leave a sticky error behind for other HIP users
@@ -157,8 +169,11 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
     M.m = mp->m; M.proj_x = mp->proj_x; M.proj_y = mp->proj_y; M.proj_xr = mp->proj_xr; M.level = mp->level; M.view_cos = mp->view_cos;
     M.in_view = mp->in_view; M.desc = mp->desc; M.obs_positive = mp->obs_positive;
     const int kp_cap = (maxn + 63) & ~63;
+    if (maxn > 65535) return PLF_E_BADARG;  // candidate cache packs key point indices in 16 bits
     hipLaunchKernelGGL(k_match_project_points, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, M, th, nnratio, match_of_kp,
-                       kp_stride, nmatches, h->d_done, kp_cap);
+                       kp_stride, nmatches, h->d_done, kp_cap, h->d_cand, h->d_cand_off, h->cand_cap, h->d_overflow);
+    hipLaunchKernelGGL(k_match_project_points_slow, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, M, th, nnratio, match_of_kp,
+                       kp_stride, nmatches, h->d_done, kp_cap, h->d_overflow);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

@@ -134,15 +134,19 @@ __device__ __forceinline__ bool blocked(const int *claim, int k, const uint8_t *
     return c == -2 || (c >= 0 && (!obs_positive || obs_positive[c]));
 }
 
+// Fallback used only for frames whose candidate lists do not fit the cache of k_match_project_points (gate:
+// overflow[f] != 0): same round scheme with the conservative rule "an item must own ALL its free candidates" and
+// the candidates re-enumerated from the grid in every round.
 // one block per frame; claim[] and owner[] live in LDS (kp_cap ints each)
-__global__ void __launch_bounds__(256) k_match_project_points(const FrameDev *__restrict__ frames, MapDev MP, float th, float nnratio,
-                                                              int *__restrict__ match_all, int kp_stride, int *__restrict__ nmatches,
-                                                              uint8_t *__restrict__ done_all, int kp_cap)
+__global__ void __launch_bounds__(256) k_match_project_points_slow(const FrameDev *__restrict__ frames, MapDev MP, float th, float nnratio,
+                                                                   int *__restrict__ match_all, int kp_stride, int *__restrict__ nmatches,
+                                                                   uint8_t *__restrict__ done_all, int kp_cap, const int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *claim = (int *)smem, *owner = claim + kp_cap;
     __shared__ int s_left, s_acc;
     const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    if (!overflow[f]) return;
     FrameDev F = frames[f];
     if (F.n_dev) F.n = min(F.n, *F.n_dev);
     int *match = match_all + (size_t)f * kp_stride;
@@ -196,6 +200,127 @@ __global__ void __launch_bounds__(256) k_match_project_points(const FrameDev *__
             if (bestDist <= TH_HIGH) {
                 if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
                 claim[bestIdx] = m;  // only this map point can touch bestIdx in this round
+                atomicAdd(&s_acc, 1);
+            }
+        }
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) nmatches[f] = s_acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SearchByProjection against the local map, fast path.
+// Phase 0 enumerates every map point's candidates ONCE (GetFeaturesInArea order, level / window / uRight tests,
+// statically occupied key points dropped) and caches (index, Hamming distance, octave) per candidate.
+// The greedy order is then resolved in rounds on the cached lists.  A map point's outcome is a function of its two
+// best still-free candidates only (best = first occurrence of the minimum distance, second = first occurrence of the
+// next value -- exactly what the reference's running best/second-best scan yields), so it can be decided as soon as
+// no UNFINISHED EARLIER map point lists either of those two key points among its own free candidates:
+//   post:   every unfinished map point writes its index (atomicMin) on all its free candidates;
+//   decide: a map point whose top-2 candidates both carry its own index is final.
+// Two map points decided in the same round can never take each other's top-2, the lowest unfinished one always
+// qualifies, so the result is the sequential loop's for any schedule.
+// cand entry: idx (16 bits) | dist (9 bits) << 16 | octave (4 bits) << 25.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_match_project_points(const FrameDev *__restrict__ frames, MapDev MP, float th, float nnratio,
+                                                              int *__restrict__ match_all, int kp_stride, int *__restrict__ nmatches,
+                                                              uint8_t *__restrict__ done_all, int kp_cap, uint32_t *__restrict__ cand_all,
+                                                              int *__restrict__ off_all, int cand_cap, int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + kp_cap;
+    __shared__ int s_left, s_acc;
+    __shared__ int scan_tmp[260];
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    FrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int *match = match_all + (size_t)f * kp_stride;
+    uint8_t *done = done_all + (size_t)f * MP.m;
+    uint32_t *cand = cand_all + (size_t)f * cand_cap;
+    int *off = off_all + (size_t)f * (MP.m + 1);
+    const bool bFactor = th != 1.0f;
+    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    if (t == 0) { s_acc = 0; overflow[f] = 0; }
+    __syncthreads();
+    // ---- phase 0a: count
+    for (int m = t; m < MP.m; m += T) {
+        int cnt = 0;
+        const bool act = MP.in_view[m] != 0;
+        if (act) {
+            const int lvl = MP.level[m];
+            float r = radius_by_viewing_cos(MP.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            const float x = MP.proj_x[m], y = MP.proj_y[m];
+            const CellWin w = cell_window(F, x, y, rad);
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, {
+                if (blocked(claim, idx, MP.obs_positive)) continue;   // occupied before this call: never becomes free
+                if (F.uright) { const float ur = F.uright[idx]; if (ur > 0 && fabsf(MP.proj_xr[m] - ur) > rad) continue; }
+                cnt++;
+            })
+        }
+        off[m] = cnt;
+        done[m] = (act && cnt > 0) ? 0 : 1;
+    }
+    if (t == 0) off[MP.m] = 0;
+    __syncthreads();
+    const int total = plf_block_excl_scan(off, MP.m + 1, scan_tmp);
+    if (total > cand_cap) {  // does not fit: leave this frame to k_match_project_points_slow
+        if (t == 0) overflow[f] = 1;
+        return;
+    }
+    // ---- phase 0b: fill (index, distance, octave)
+    for (int m = t; m < MP.m; m += T) {
+        if (done[m]) continue;
+        const int lvl = MP.level[m];
+        float r = radius_by_viewing_cos(MP.view_cos[m]);
+        if (bFactor) r *= th;
+        const float rad = r * F.scale_factors[lvl];
+        const float x = MP.proj_x[m], y = MP.proj_y[m];
+        const CellWin w = cell_window(F, x, y, rad);
+        const uint8_t *d = MP.desc + (size_t)m * 32;
+        int o = off[m];
+        FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, {
+            if (blocked(claim, idx, MP.obs_positive)) continue;
+            if (F.uright) { const float ur = F.uright[idx]; if (ur > 0 && fabsf(MP.proj_xr[m] - ur) > rad) continue; }
+            const int dist = hamming_g(d, F.desc + (size_t)idx * 32);
+            cand[o++] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(_kp.octave & 15) << 25);
+        })
+    }
+    __syncthreads();
+    // ---- rounds
+    for (int round = 0; round <= MP.m; round++) {
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+        for (int m = t; m < MP.m; m += T) {
+            if (done[m]) continue;
+            for (int j = off[m]; j < off[m + 1]; j++) {
+                const int idx = (int)(cand[j] & 0xFFFF);
+                if (!blocked(claim, idx, MP.obs_positive)) atomicMin(&owner[idx], m);
+            }
+        }
+        __syncthreads();
+        for (int m = t; m < MP.m; m += T) {
+            if (done[m]) continue;
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, idx2 = -1;
+            for (int j = off[m]; j < off[m + 1]; j++) {
+                const uint32_t e = cand[j];
+                const int idx = (int)(e & 0xFFFF);
+                if (blocked(claim, idx, MP.obs_positive)) continue;
+                const int dist = (int)((e >> 16) & 0x1FF), oct = (int)(e >> 25);
+                if (dist < bestDist) { bestDist2 = bestDist; bestLevel2 = bestLevel; idx2 = bestIdx; bestDist = dist; bestLevel = oct; bestIdx = idx; }
+                else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; idx2 = idx; }
+            }
+            const bool safe = (bestIdx < 0 || owner[bestIdx] == m) && (idx2 < 0 || owner[idx2] == m);
+            if (!safe) { atomicAdd(&s_left, 1); continue; }
+            done[m] = 1;
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+                claim[bestIdx] = m;
                 atomicAdd(&s_acc, 1);
             }
         }

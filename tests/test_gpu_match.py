@@ -60,6 +60,12 @@ def test_search_by_projection_map(M, th, with_ur):
     m.close()
 
 
+def test_search_by_projection_map_fallback_kernel(monkeypatch):
+    """candidate cache too small -> the frame is handed to the conservative fallback kernel; same result"""
+    monkeypatch.setenv("PLF_MATCH_CAND_AVG", "1")
+    test_search_by_projection_map(3000, 3.0, True)
+
+
 def _last_frame_case(seed):
     rng = np.random.default_rng(seed)
     kps, desc = _frame(seed)
