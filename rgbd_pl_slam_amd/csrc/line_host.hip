@@ -15,8 +15,13 @@ __global__ void k_lsd_resize(const double *, double *, LsdGeom, const int *, con
 __global__ void k_lsd_grad(const double *, float *, double *, double2 *, LsdGeom);
 __global__ void k_lsd_regions(const float *, const double *, const double2 *, uint32_t *, float *, double *, LsdRect *, int *, int *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
-__global__ void k_lsd_nfa_first(const float *, const double *, const LsdRect *, const int *, float4 *, uint8_t *, int *, int2 *, LsdGeom);
-__global__ void k_lsd_nfa_improve(const float *, const double *, const LsdRect *, const int *, const int2 *, float4 *, uint8_t *, LsdGeom);
+struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
+struct NfaCounts { int total, alg[6], pad; };
+struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
+__global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, NfaState *, int *, LsdGeom);
+__global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
+__global__ void k_nfa_math(int, const double *, const NfaCounts *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *,
+                           uint8_t *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
                                int, int *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
@@ -35,7 +40,10 @@ struct plf_line {
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
     double *d_tmp, *d_blur, *d_scaled, *d_modgrad, *d_rmod, *d_lineeq, *d_lgam;
-    int2 *d_fail;
+    NfaEntry *d_ent[2];
+    NfaState *d_st[2];
+    NfaCounts *d_cnt;
+    int *d_nfa_counters;
     double2 *d_cs;
     float *d_ang, *d_rdeg;
     uint32_t *d_rxy;
@@ -57,7 +65,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_tmp, h->d_blur, h->d_scaled, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rdeg, h->d_rxy, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_fail};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -194,7 +202,10 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
     ALLOC(h->d_counters, (4 * B + 16) * sizeof(int));
     ALLOC(h->d_lgam, 65536 * sizeof(double));
-    ALLOC(h->d_fail, B * R * 2 * sizeof(int2));
+    ALLOC(h->d_ent[0], B * R * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], B * R * 5 * sizeof(NfaEntry));
+    ALLOC(h->d_st[0], B * R * sizeof(NfaState)); ALLOC(h->d_st[1], B * R * sizeof(NfaState));
+    ALLOC(h->d_cnt, B * R * 5 * sizeof(NfaCounts));
+    ALLOC(h->d_nfa_counters, 16 * sizeof(int));
     ALLOC(h->d_xofs, sizeof(int) * (size_t)g.sw); ALLOC(h->d_xa, sizeof(float2) * (size_t)g.sw);
     ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
 #undef ALLOC
@@ -225,7 +236,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
 {
     const LsdGeom &g = h->g;
     const size_t MB = (size_t)h->prm.max_batch;
-    int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail = h->d_counters + 3 * MB + 16;
+    int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail_unused = h->d_counters + 3 * MB + 16;
+    (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
     dim3 gfull((g.w + 255) / 256, g.h, B), gsc((g.sw + 255) / 256, g.sh, B);
     hipLaunchKernelGGL(k_lsd_blur_rows, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_tmp, g, h->taps);
@@ -241,10 +253,18 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_rxy, h->d_rdeg, h->d_rmod,
                        h->d_rects, nrect, status, g);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
-    hipLaunchKernelGGL(k_lsd_nfa_first, dim3((g.rect_cap + 63) / 64, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_seg,
-                       h->d_keep, nfail, h->d_fail, g);
-    hipLaunchKernelGGL(k_lsd_nfa_improve, dim3((g.rect_cap + 63) / 64, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nfail, h->d_fail,
-                       h->d_seg, h->d_keep, g);
+    // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)
+    PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
+    hipLaunchKernelGGL(k_nfa_init, dim3((g.rect_cap + 255) / 256, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
+                       h->d_nfa_counters, g);
+    const int count_waves = 256 * 16, math_blocks = 1024;
+    for (int stage = 0; stage <= 4; stage++) {
+        const int in = stage & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage,
+                           (stage >= 1 && stage <= 3) ? 5 : 1, h->d_cnt, g);
+        hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_st[in], h->d_st[out],
+                           h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
+    }
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
                        d_lines, d_eq, d_nout, capacity, status, g);
     hipLaunchKernelGGL(k_lbd, dim3(capacity < g.nkeep ? capacity : g.nkeep, B), dim3(128), 0, s, h->d_grad, d_lines, d_nout, d_ldesc, capacity, g,

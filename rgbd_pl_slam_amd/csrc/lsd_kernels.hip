@@ -7,7 +7,7 @@
 //   k_lsd_resize                        resize(0.8, INTER_LINEAR) of the double image (float coefficients)
 //   k_lsd_grad                          ll_angle: 2x2 gradient, modgrad (double), level-line angle (cv::fastAtan2)
 //   k_lsd_regions                       seed scan + region_grow + region2rect + refine   (ORDER-DEPENDENT, see below)
-//   k_lsd_nfa                           rect_improve / rect_nfa / nfa per surviving rectangle (independent)
+//   k_nfa_init / k_nfa_count / k_nfa_math   rect_improve = 5 search stages of (pixel count, NFA math) per rectangle
 //   k_lsd_finalize                      ordered compaction -> segments -> KeyLine fields -> top-N by response
 //
 // The only inherently sequential part of LSD is k_lsd_regions: regions are grown greedily in seed order, every
@@ -506,10 +506,26 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
 
 struct EdgePt { int x, y, taken; };
 
-// rect_nfa, one LANE per rectangle: the scan-line walk (with upstream's integer-division slopes and the
-// `tailp->p.x` slip) and the pixel tests run exactly like the reference loop; 64 rectangles advance per wave.
-__device__ double rect_nfa(const float *__restrict__ ang, const double *__restrict__ lgam, int W, int H, double LOG_NT, const LsdRect &rec)
+// ------------------------------------------------------------------------------------------------
+// NFA validation = rect_improve (imgproc/lsd.cpp), restructured for the GPU without changing a decision:
+//   * the pixel COUNTING of a rectangle (rect_nfa's scan-line walk) is wave-parallel: upstream's left/right x
+//     walk adds integer-valued steps (its slopes are integer divisions), so the span of row y has a closed form
+//     and every lane takes a row; the counts for up to 6 angle precisions of the same geometry come from one pass;
+//   * the NFA MATH (log-gamma, binomial tail; fp64 transcendentals) is lane-parallel: one lane per rectangle;
+//   * rect_improve's 5 search stages stay sequential (stage s+1 starts from the best rectangle of stage s); inside
+//     a stage the 5 candidate rectangles do not depend on the comparisons, so they are counted together and the
+//     "keep it if better" chain is replayed in order by the lane that owns the rectangle.
+// Work lists are global (all frames of the batch) and compacted with atomics; order is irrelevant because every
+// result is written to its rectangle's own slot.
+// ------------------------------------------------------------------------------------------------
+struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };   // nprec: 0 = skip, 1 = r.prec only, 6 = r.prec and r.p/2^k, k=1..5
+struct NfaCounts { int total, alg[6], pad; };
+struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
+
+// wave-cooperative pixel count of one rectangle
+__device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, int nprec, NfaCounts &out)
 {
+    const int lane = plf_lane();
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     EdgePt o[4];
@@ -538,83 +554,46 @@ __device__ double rect_nfa(const float *__restrict__ ang, const double *__restri
     int it = -1;
     for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (it < 0) it = i; else if (o[it].x > o[i].x) it = i; }
     const EdgePt mn = o[imin], mx = o[imax], lf = o[il], rt = o[ir], tl = o[it];
-    const double flstep = (mn.y != lf.y) ? (double)((mn.x - lf.x) / (mn.y - lf.y)) : 0;
-    const double slstep = (lf.y != tl.x) ? (double)((lf.x - tl.x) / (lf.y - tl.x)) : 0;
-    const double frstep = (mn.y != rt.y) ? (double)((mn.x - rt.x) / (mn.y - rt.y)) : 0;
-    const double srstep = (rt.y != tl.x) ? (double)((rt.x - tl.x) / (rt.y - tl.x)) : 0;
-    double lstep = flstep, rstep = frstep;
-    double left_x = mn.x, right_x = mn.x;
-    // rows outside the image are skipped BEFORE the step update (upstream `continue`), so the walk starts at y_lo
+    // upstream: integer divisions, and `tailp->p.x` where p.y was meant
+    const long long flstep = (mn.y != lf.y) ? (mn.x - lf.x) / (mn.y - lf.y) : 0;
+    const long long slstep = (lf.y != tl.x) ? (lf.x - tl.x) / (lf.y - tl.x) : 0;
+    const long long frstep = (mn.y != rt.y) ? (mn.x - rt.x) / (mn.y - rt.y) : 0;
+    const long long srstep = (rt.y != tl.x) ? (rt.x - tl.x) / (rt.y - tl.x) : 0;
+    // rows outside the image are skipped BEFORE the step update (upstream `continue`): the walk starts at y_lo.
+    // After visiting row y' the walk adds (y' >= lf.y ? slstep : flstep); all terms are integers, so the span of
+    // row y is exact in closed form.
     const int y_lo = max(mn.y, 0), y_hi = min(mx.y, H - 1);
-    int total = 0, alg = 0;
-    for (int y = y_lo; y <= y_hi; ++y) {
-        const int xl = max((int)left_x, 0), xr = min((int)right_x, W - 1);
+    double precs[6];
+    precs[0] = rec.prec;
+    {
+        double pp = rec.p;
+        for (int k = 1; k < 6; k++) { pp /= 2; precs[k] = pp * PI_D; }
+    }
+    int total = 0, alg[6] = {0, 0, 0, 0, 0, 0};
+    for (int y = y_lo + lane; y <= y_hi; y += 64) {
+        const long long al = max(0, min(y, lf.y) - y_lo), bl = (long long)(y - y_lo) - al;
+        const long long ar = max(0, min(y, rt.y) - y_lo), br = (long long)(y - y_lo) - ar;
+        const long long left = (long long)mn.x + flstep * al + slstep * bl, right = (long long)mn.x + frstep * ar + srstep * br;
+        const int xl = (int)max(left, 0ll), xr = (int)min(right, (long long)(W - 1));
         const float *row = ang + (size_t)y * W;
         for (int x = xl; x <= xr; ++x) {
             ++total;
-            if (aligned_deg(row[x], rec.theta, rec.prec)) ++alg;
-        }
-        if (y >= lf.y) lstep = slstep;
-        if (y >= rt.y) rstep = srstep;
-        left_x += lstep;
-        right_x += rstep;
-    }
-    return nfa_d(lgam, LOG_NT, total, alg, rec.p);
-}
-
-// rect_improve after its first rect_nfa call (log_nfa = that first value, known to be <= LOG_EPS)
-__device__ double rect_improve_rest(const float *ang, const double *lgam, int W, int H, double LOG_NT, LsdRect &rec, double LOG_EPS, double log_nfa)
-{
-    const double delta = 0.5, delta_2 = delta / 2.0;
-    LsdRect r = rec;
-    for (int n = 0; n < 5; ++n) {
-        r.p /= 2;
-        r.prec = r.p * PI_D;
-        const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
-        if (v > log_nfa) { log_nfa = v; rec = r; }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.width -= delta;
-            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
+            const float deg = row[x];
+            if (deg == NOTDEF_F) continue;
+            const double a = (double)deg * DEG2RAD_D;
+            double n_theta = rec.theta - a;
+            if (n_theta < 0) n_theta = -n_theta;
+            if (n_theta > M_3_2_PI_D) {
+                n_theta -= M_2__PI_D;
+                if (n_theta < 0) n_theta = -n_theta;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (k < nprec && n_theta <= precs[k]) ++alg[k];
         }
     }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
-            r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
-            r.width -= delta;
-            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
-            r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
-            r.width -= delta;
-            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.p /= 2;
-            r.prec = r.p * PI_D;
-            const double v = rect_nfa(ang, lgam, W, H, LOG_NT, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
-    }
-    return log_nfa;
+    out.total = plf_wave_sum(total);
+#pragma unroll
+    for (int k = 0; k < 6; k++) out.alg[k] = plf_wave_sum(alg[k]);
 }
 
 __device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
@@ -624,49 +603,106 @@ __device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
     *seg = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
 }
 
-// NFA validation in two passes so that the lanes of a wave do similar amounts of work:
-//   k_lsd_nfa_first    one lane per rectangle: the first rect_nfa of rect_improve.  Meaningful rectangles
-//                      (log_nfa > 0, i.e. most real segments) finish here; the others are queued.
-//   k_lsd_nfa_improve  one lane per QUEUED rectangle: the remaining <= 25 evaluations of rect_improve.
-// grid (ceil(rect_cap / 64), B).  seg[i] = (x1,y1,x2,y2) as float, keep[i] = 1 when log_nfa > LOG_EPS.
-__global__ void __launch_bounds__(64) k_lsd_nfa_first(const float *__restrict__ ang_all, const double *__restrict__ lgam,
-                                                      const LsdRect *__restrict__ rects_all, const int *__restrict__ nrect,
-                                                      float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, int *__restrict__ nfail,
-                                                      int2 *__restrict__ fail_all, LsdGeom g)
+// one lane per rectangle of every frame: queue it for the first count
+__global__ void __launch_bounds__(256) k_nfa_init(const LsdRect *__restrict__ rects_all, const int *__restrict__ nrect,
+                                                  uint8_t *__restrict__ keep_all, NfaEntry *__restrict__ entries, NfaState *__restrict__ states,
+                                                  int *__restrict__ counters, LsdGeom g)
 {
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nrect[f]) return;
-    const float *ang = ang_all + (size_t)f * g.s_stride;
-    const LsdRect rec = rects_all[(size_t)f * g.rect_cap + i];
-    const double log_nfa = rect_nfa(ang, lgam, g.sw, g.sh, g.log_nt, rec);
-    if (log_nfa > 0.0) {
-        keep_all[(size_t)f * g.rect_cap + i] = 1;
-        emit_segment(rec, &seg_all[(size_t)f * g.rect_cap + i]);
-    } else {
-        keep_all[(size_t)f * g.rect_cap + i] = 0;
-        const int q = atomicAdd(&nfail[f], 1);
-        // the first log_nfa is passed on bit-exactly through two ints
-        fail_all[((size_t)f * g.rect_cap + q) * 2] = make_int2(i, 0);
-        fail_all[((size_t)f * g.rect_cap + q) * 2 + 1] = make_int2(__double2loint(log_nfa), __double2hiint(log_nfa));
+    keep_all[(size_t)f * g.rect_cap + i] = 0;
+    const int q = atomicAdd(&counters[0], 1);
+    NfaEntry e;
+    e.r = rects_all[(size_t)f * g.rect_cap + i]; e.frame = f; e.nprec = 6; e.pad0 = e.pad1 = 0;
+    entries[q] = e;
+    NfaState st;
+    st.rec = e.r; st.log_nfa = -1; st.frame = f; st.rect = i;
+    states[q] = st;
+}
+
+// persistent waves: entry e -> counts[e];  n = counters[cidx] * mult
+__global__ void __launch_bounds__(64) k_nfa_count(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
+                                                  const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
+{
+    const int n = counters[cidx] * mult;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const NfaEntry en = entries[e];
+        if (en.nprec == 0) continue;
+        NfaCounts c;
+        rect_count(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, en.nprec, c);
+        if (threadIdx.x == 0) counts[e] = c;
     }
 }
 
-__global__ void __launch_bounds__(64) k_lsd_nfa_improve(const float *__restrict__ ang_all, const double *__restrict__ lgam,
-                                                        const LsdRect *__restrict__ rects_all, const int *__restrict__ nfail,
-                                                        const int2 *__restrict__ fail_all, float4 *__restrict__ seg_all,
-                                                        uint8_t *__restrict__ keep_all, LsdGeom g)
+__device__ __forceinline__ void nfa_finish(const NfaState &st, float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, const LsdGeom &g)
 {
-    const int f = blockIdx.y;
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= nfail[f]) return;
-    const int i = fail_all[((size_t)f * g.rect_cap + q) * 2].x;
-    const int2 lv = fail_all[((size_t)f * g.rect_cap + q) * 2 + 1];
-    const float *ang = ang_all + (size_t)f * g.s_stride;
-    LsdRect rec = rects_all[(size_t)f * g.rect_cap + i];
-    const double log_nfa = rect_improve_rest(ang, lgam, g.sw, g.sh, g.log_nt, rec, 0.0, __hiloint2double(lv.y, lv.x));
-    if (log_nfa > 0.0) {
-        keep_all[(size_t)f * g.rect_cap + i] = 1;
-        emit_segment(rec, &seg_all[(size_t)f * g.rect_cap + i]);
+    keep_all[(size_t)st.frame * g.rect_cap + st.rect] = 1;
+    emit_segment(st.rec, &seg_all[(size_t)st.frame * g.rect_cap + st.rect]);
+}
+
+// stage: 0 = first evaluation + "finer precision" loop, 1..3 = the three width loops, 4 = final precision loop.
+// Reads the counts of the previous count pass, replays the "keep if better" chain, finishes meaningful rectangles
+// and queues the next stage's candidate rectangles for the others.
+__global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__restrict__ lgam, const NfaCounts *__restrict__ counts,
+                                                 const NfaEntry *__restrict__ entries, const NfaState *__restrict__ st_in,
+                                                 NfaState *__restrict__ st_out, NfaEntry *__restrict__ ent_out, int *__restrict__ counters,
+                                                 float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, LsdGeom g)
+{
+    const int n = counters[stage];
+    const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+        NfaState st = st_in[i];
+        if (stage == 0 || stage == 4) {
+            const NfaCounts c = counts[i];
+            const NfaEntry en = entries[i];
+            if (stage == 0) {
+                st.log_nfa = nfa_d(lgam, g.log_nt, c.total, c.alg[0], st.rec.p);
+                if (st.log_nfa > LOG_EPS) { nfa_finish(st, seg_all, keep_all, g); continue; }
+            }
+            if (en.nprec == 6) {
+                LsdRect r = st.rec;
+                for (int k = 1; k <= 5; ++k) {
+                    r.p /= 2;
+                    r.prec = r.p * PI_D;
+                    const double v = nfa_d(lgam, g.log_nt, c.total, c.alg[k], r.p);
+                    if (v > st.log_nfa) { st.log_nfa = v; st.rec = r; }
+                }
+            }
+            if (st.log_nfa > LOG_EPS) { nfa_finish(st, seg_all, keep_all, g); continue; }
+            if (stage == 4) continue;  // not meaningful
+        } else {
+            for (int k = 0; k < 5; ++k) {
+                const NfaEntry en = entries[5 * i + k];
+                if (en.nprec == 0) continue;
+                const NfaCounts c = counts[5 * i + k];
+                const double v = nfa_d(lgam, g.log_nt, c.total, c.alg[0], en.r.p);
+                if (v > st.log_nfa) { st.rec = en.r; st.log_nfa = v; }
+            }
+            if (st.log_nfa > LOG_EPS) { nfa_finish(st, seg_all, keep_all, g); continue; }
+        }
+        // queue the next stage
+        const int q = atomicAdd(&counters[stage + 1], 1);
+        st_out[q] = st;
+        LsdRect r = st.rec;
+        if (stage <= 2) {
+            // stage 0 -> "reduce width", 1 -> "reduce one side", 2 -> "reduce the other side"
+            for (int k = 0; k < 5; ++k) {
+                NfaEntry e;
+                e.frame = st.frame; e.pad0 = e.pad1 = 0; e.nprec = 0;
+                if ((r.width - delta) >= 0.5) {
+                    if (stage == 1) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+                    if (stage == 2) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+                    r.width -= delta;
+                    e.nprec = 1;
+                }
+                e.r = r;
+                ent_out[5 * q + k] = e;
+            }
+        } else {  // stage 3 -> final "finer precision" loop (upstream keeps the width test here too)
+            NfaEntry e;
+            e.r = r; e.frame = st.frame; e.pad0 = e.pad1 = 0;
+            e.nprec = ((r.width - delta) >= 0.5) ? 6 : 0;
+            ent_out[q] = e;
+        }
     }
 }
