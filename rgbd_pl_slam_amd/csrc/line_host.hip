@@ -12,8 +12,8 @@
 __global__ void k_lsd_blur_rows(const uint8_t *, ptrdiff_t, ptrdiff_t, double *, LsdGeom, LsdTaps);
 __global__ void k_lsd_blur_cols(const double *, double *, LsdGeom, LsdTaps);
 __global__ void k_lsd_resize(const double *, double *, LsdGeom, const int *, const float2 *, const int *, const float2 *);
-__global__ void k_lsd_grad(const double *, float *, double *, double2 *, LsdGeom);
-__global__ void k_lsd_regions(const float *, const double *, const double2 *, uint32_t *, float *, double *, LsdRect *, int *, int *, LsdGeom);
+__global__ void k_lsd_grad(const double *, float *, double *, double2 *, float2 *, LsdGeom);
+__global__ void k_lsd_regions(const float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
 struct NfaCounts { int total, alg[6], pad; };
@@ -45,6 +45,7 @@ struct plf_line {
     NfaCounts *d_cnt;
     int *d_nfa_counters;
     double2 *d_cs;
+    float2 *d_cs0;
     float *d_ang, *d_rdeg;
     uint32_t *d_rxy;
     LsdRect *d_rects;
@@ -64,7 +65,7 @@ struct plf_line {
 static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_tmp, h->d_blur, h->d_scaled, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
-                    h->d_ang, h->d_rdeg, h->d_rxy, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
+                    h->d_ang, h->d_rdeg, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -86,13 +87,16 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     g->log_nt = 5 * (log10((double)g->sw) + log10((double)g->sh)) / 2 + log10(11.0);
     g->min_reg_size = (int)(-g->log_nt / log10(g->p));
     g->used_words = (g->sw * g->sh + 31) / 32;
-    g->rcap = 8192;
+    g->rcap = 4096;
+    // LDS budget of k_lsd_regions: used bitmap + region list + neighbourhood ring (9 x (4 + 16) bytes per entry)
+    g->ring = 512;
+    while (g->ring > 32 && (size_t)g->used_words * 4 + (size_t)(g->rcap + 1) * 4 + (size_t)g->ring * 9 * 20 > 150 * 1024) g->ring >>= 1;
     int rc = 2048;
     while (rc < g->sw * g->sh / 48 && rc < 8192) rc <<= 1;
     g->rect_cap = rc;
     g->sort_cap = rc;
     g->nkeep = h->prm.nlines;
-    if ((size_t)g->used_words * 4 + (size_t)(g->rcap + 1) * 4 > 150 * 1024) return PLF_E_BADARG;
+    if ((size_t)g->used_words * 4 + (size_t)(g->rcap + 1) * 4 + (size_t)g->ring * 9 * 20 > 150 * 1024) return PLF_E_BADARG;
     return PLF_OK;
 }
 
@@ -131,7 +135,7 @@ static int line_configure(plf_line *h, int w, int hh)
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(float2) * g.sh, hipMemcpyHostToDevice));
     h->g = g;
-    h->regions_lds = (size_t)g.used_words * 4 + (size_t)(g.rcap + 1) * 4;
+    h->regions_lds = (size_t)g.used_words * 4 + (size_t)(g.rcap + 1) * 4 + (size_t)g.ring * 9 * 20 + 64;
     h->finalize_lds = (size_t)g.sort_cap * 8 + (size_t)g.rect_cap * 4 + 260 * 4;
     h->nfa_lds = (size_t)g.sh * 2 * sizeof(int) + 64;
     h->cur_w = w; h->cur_h = hh;
@@ -189,9 +193,8 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_modgrad, B * S * sizeof(double));
     ALLOC(h->d_cs, B * S * sizeof(double2));
     ALLOC(h->d_ang, B * S * sizeof(float));
+    ALLOC(h->d_cs0, B * S * sizeof(float2));
     ALLOC(h->d_rxy, B * S * sizeof(uint32_t));
-    ALLOC(h->d_rdeg, B * S * sizeof(float));
-    ALLOC(h->d_rmod, B * S * sizeof(double));
     ALLOC(h->d_rects, B * R * sizeof(LsdRect));
     ALLOC(h->d_seg, B * R * sizeof(float4));
     ALLOC(h->d_segs_out, B * R * sizeof(float4));
@@ -243,14 +246,14 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     hipLaunchKernelGGL(k_lsd_blur_rows, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_tmp, g, h->taps);
     hipLaunchKernelGGL(k_lsd_blur_cols, gfull, dim3(256), 0, s, h->d_tmp, h->d_blur, g, h->taps);
     hipLaunchKernelGGL(k_lsd_resize, gsc, dim3(256), 0, s, h->d_blur, h->d_scaled, g, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
-    hipLaunchKernelGGL(k_lsd_grad, gsc, dim3(256), 0, s, h->d_scaled, h->d_ang, h->d_modgrad, h->d_cs, g);
+    hipLaunchKernelGGL(k_lsd_grad, gsc, dim3(256), 0, s, h->d_scaled, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g);
     hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
     const bool prof = h->prof_on && h->prof_n < 512;
     if (prof) {
         if (!h->prof_ev[2 * h->prof_n]) { (void)hipEventCreate(&h->prof_ev[2 * h->prof_n]); (void)hipEventCreate(&h->prof_ev[2 * h->prof_n + 1]); }
         (void)hipEventRecord(h->prof_ev[2 * h->prof_n], s);
     }
-    hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_rxy, h->d_rdeg, h->d_rmod,
+    hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                        h->d_rects, nrect, status, g);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)

@@ -79,8 +79,9 @@ __global__ void __launch_bounds__(256) k_lsd_resize(const double *__restrict__ b
 // ll_angle.  ang: level-line angle in DEGREES as cv::fastAtan2 returns it (the reference stores
 // double(deg) * DEG_TO_RADS, recomputed on use), NOTDEF_F where the gradient is too small or on the last
 // row/column.  cs: cos and sin of the float-rounded angle, the increments region_grow adds to its sums.
+// cs0: float(cos(angle)), float(sin(angle)) of the un-rounded angle, the initial sums of a region seeded here.
 __global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ scaled, float *__restrict__ ang, double *__restrict__ modgrad,
-                                                  double2 *__restrict__ cs, LsdGeom g)
+                                                  double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
     if (x >= g.sw) return;
@@ -95,8 +96,10 @@ __global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ sca
     if (norm <= g.rho) { ang[a] = NOTDEF_F; return; }
     const float deg = plf_fast_atan2((float)gx, (float)-gy);
     ang[a] = deg;
-    const double af = (double)(float)((double)deg * DEG2RAD_D);
+    const double ad = (double)deg * DEG2RAD_D;
+    const double af = (double)(float)ad;
     cs[a] = make_double2(cos(af), sin(af));
+    cs0[a] = make_float2((float)cos(ad), (float)sin(ad));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -107,13 +110,17 @@ struct RegCtx {
     const float *ang;
     const double *modgrad;
     const double2 *cs;
+    const float2 *cs0;
     uint32_t *used;       // LDS bitmap, 1 = USED
     uint32_t *rxy_l;      // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;      // global overflow of the region list
     int rcap;
-    float *rdeg;          // global, per region point: angle in degrees
-    double *rmod;         // global, per region point: modgrad
+    float *ring_deg;      // LDS ring: 9 neighbour angles of queued region points
+    double2 *ring_cs;     // LDS ring: their cos/sin increments
+    int ring;             // ring entries (power of two)
 };
+
+#define CBAR() asm volatile("" ::: "memory")   // single-wave kernel: LDS ops stay in program order; only the compiler must not reorder
 
 __device__ __forceinline__ bool used_get(const RegCtx &C, int a) { return (C.used[a >> 5] >> (a & 31)) & 1u; }
 __device__ __forceinline__ void used_set(RegCtx &C, int a) { atomicOr(&C.used[a >> 5], 1u << (a & 31)); }
@@ -125,6 +132,12 @@ __device__ __forceinline__ double shfl_d(double v, int src)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+// broadcast from a wave-uniform lane (v_readlane: no LDS crossbar round trip)
+__device__ __forceinline__ double readlane_d(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
 
@@ -143,72 +156,96 @@ __device__ __forceinline__ bool aligned_deg(float deg, double theta, double prec
 
 // LineSegmentDetectorImpl::region_grow.  All lanes return the same (n, reg_angle).
 // The accept steps happen strictly in the reference order (centre by centre, neighbours in (yy, xx) order, the
-// region angle updated after every accepted pixel).  What is batched is only the DATA FETCH: the 3x3
-// neighbourhoods of up to 7 already-queued centres are gathered with one round trip (lanes 9s..9s+8 serve
-// centre i+s); `used` is read from LDS at the moment a centre is processed, so it is always current.
-// wsum (optional): the modgrad-weighted coordinate sums of region2rect, accumulated in list order as points
-// are appended (same additions in the same order as the reference's first region2rect loop).
-struct RegSums { double x, y, sum; };
-
-__device__ int region_grow(RegCtx &C, int sx, int sy, double prec, double &reg_angle_out, RegSums &ws)
+// region angle updated after every accepted pixel).  What is pipelined is only the DATA FETCH: while centre i is
+// processed, the 3x3 neighbourhoods (angle + cos/sin increment) of up to 7 further queued points are gathered from
+// HBM/L2 into registers and then parked in an LDS ring, so that a centre normally finds its data in LDS.  `used` is
+// read from LDS at the moment a centre is processed, so it is always current.  Nothing is written to global memory
+// on this path; modgrad / angle of the region points are re-gathered by coordinate where a region needs them.
+__device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, double &reg_angle_out)
 {
-    const int lane = plf_lane(), W = C.W, H = C.H;
-    const int addr0 = sy * W + sx;
-    const float deg0 = C.ang[addr0];
-    const double mg0 = C.modgrad[addr0];
+    const int lane = plf_lane(), W = C.W, H = C.H, RM = C.ring - 1;
     double reg_angle = (double)deg0 * DEG2RAD_D;
-    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    float sumdx = cs0.x, sumdy = cs0.y;   // float(cos(reg_angle)), float(sin(reg_angle))
     if (lane == 0) {
         rxy_put(C, 0, (uint32_t)sx | ((uint32_t)sy << 16));
-        C.rdeg[0] = deg0;
-        C.rmod[0] = mg0;
-        used_set(C, addr0);
+        used_set(C, sy * W + sx);
     }
-    ws.x = 0.0; ws.y = 0.0; ws.sum = 0.0;
-    ws.x += (double)sx * mg0; ws.y += (double)sy * mg0; ws.sum += mg0;
-    __syncthreads();
-    int n = 1;
+    CBAR();
+    int n = 1, i = 0, pf = 0, rd = 0;   // list size, next centre, next entry to prefetch, entries [i, rd) are in the ring
     const int slot = lane / 9, k9 = lane - slot * 9;
     const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;  // 3x3 neighbourhood in (yy, xx) order
-    int i = 0;
     while (i < n) {
-        const int gcount = min(7, n - i);
+        // ---- prefetch: neighbourhoods of list entries [pf, pf + pc) into registers
+        int pc = min(7, min(n, i + C.ring) - pf);
+        if (pc < 0) pc = 0;
+        float pdeg = NOTDEF_F;
+        double2 pcs = make_double2(0.0, 0.0);
+        const bool pact = lane < 63 && slot < pc;
+        if (pact) {
+            const uint32_t pxy = rxy_get(C, pf + slot);
+            const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                const int a = yy * W + xx;
+                pdeg = C.ang[a];
+                if (pdeg != NOTDEF_F) pcs = C.cs[a];
+            }
+        }
+        if (rd <= i) {  // nothing parked for the next centre: commit the fetch now (waits for the loads)
+            if (pact) { C.ring_deg[((pf + slot) & RM) * 9 + k9] = pdeg; C.ring_cs[((pf + slot) & RM) * 9 + k9] = pcs; }
+            rd = pf + pc; pf += pc; pc = 0;
+            CBAR();
+        }
+        // ---- process the parked centres i .. i + gcount - 1
+        const int gcount = min(7, rd - i);
         const bool active = lane < 63 && slot < gcount;
-        const uint32_t pxy = active ? rxy_get(C, i + slot) : 0u;
-        const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
-        const bool valid = active && xx >= 0 && xx < W && yy >= 0 && yy < H;
-        const int a = valid ? yy * W + xx : 0;
         float deg = NOTDEF_F;
         double2 csv = make_double2(0.0, 0.0);
-        double mg = 0.0;
-        if (valid) { deg = C.ang[a]; csv = C.cs[a]; mg = C.modgrad[a]; }
-        const bool defined = valid && deg != NOTDEF_F;
+        int xx = 0, yy = 0, a = 0;
+        if (active) {
+            const uint32_t pxy = rxy_get(C, i + slot);
+            xx = (int)(pxy & 0xFFFF) + kx; yy = (int)(pxy >> 16) + ky;
+            deg = C.ring_deg[((i + slot) & RM) * 9 + k9];   // NOTDEF for neighbours outside the image
+            csv = C.ring_cs[((i + slot) & RM) * 9 + k9];
+            a = yy * W + xx;
+        }
+        const bool defined = active && deg != NOTDEF_F;
+        const double adeg = (double)deg * DEG2RAD_D;
         for (int s = 0; s < gcount; s++) {
             bool cand = defined && slot == s && !used_get(C, a);
             while (true) {
-                const bool al = cand && aligned_deg(deg, reg_angle, prec);
+                bool al = false;
+                if (cand) {
+                    double n_theta = reg_angle - adeg;
+                    if (n_theta < 0) n_theta = -n_theta;
+                    if (n_theta > M_3_2_PI_D) {
+                        n_theta -= M_2__PI_D;
+                        if (n_theta < 0) n_theta = -n_theta;
+                    }
+                    al = n_theta <= prec;
+                }
                 const unsigned long long mask = __ballot(al);
                 if (!mask) break;
                 const int k = __ffsll((long long)mask) - 1;
                 if (lane == k) {
                     used_set(C, a);
                     rxy_put(C, n, (uint32_t)xx | ((uint32_t)yy << 16));
-                    C.rdeg[n] = deg;
-                    C.rmod[n] = mg;
                 }
-                const double cc = shfl_d(csv.x, k), ss = shfl_d(csv.y, k), mk = shfl_d(mg, k);
-                const int qx = __shfl(xx, k, 64), qy = __shfl(yy, k, 64);
+                const double cc = readlane_d(csv.x, k), ss = readlane_d(csv.y, k);
                 // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
                 sumdx = (float)((double)sumdx + cc);
                 sumdy = (float)((double)sumdy + ss);
                 reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
-                ws.x += (double)qx * mk; ws.y += (double)qy * mk; ws.sum += mk;
                 ++n;
                 cand = cand && lane > k;
             }
-            __syncthreads();
+            CBAR();
         }
         i += gcount;
+        if (pc > 0) {  // park the fetch issued at the top of this iteration
+            if (pact) { C.ring_deg[((pf + slot) & RM) * 9 + k9] = pdeg; C.ring_cs[((pf + slot) & RM) * 9 + k9] = pcs; }
+            rd = pf + pc; pf += pc;
+            CBAR();
+        }
     }
     reg_angle_out = reg_angle;
     return n;
@@ -225,27 +262,27 @@ __device__ __forceinline__ double angle_diff_signed_d(double a, double b)
     return diff;
 }
 
-// region2rect incl. get_theta.  Order-dependent sums are accumulated serially in list order; the lanes only
-// prefetch 64 points at a time.  Extents (min/max) are order-free and reduced across the wave.
-__device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, double p, LsdRect &rec, const RegSums *pre)
+// region2rect incl. get_theta.  The per-point products are order-free and computed by all lanes (64 points at a
+// time, modgrad gathered by coordinate); only the running sums are accumulated serially in list order, exactly the
+// reference's additions.  Extents (min/max) are order-free and reduced across the wave.
+__device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, double p, LsdRect &rec)
 {
     const int lane = plf_lane();
     double x = 0, y = 0, sum = 0;
-    if (pre) {  // sums already accumulated in list order while the region was grown
-        x = pre->x; y = pre->y; sum = pre->sum;
-    } else {
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            const uint32_t xy = i < n ? rxy_get(C, i) : 0u;
-            const double w = i < n ? C.rmod[i] : 0.0;
-            const int cnt = min(64, n - base);
-            for (int k = 0; k < cnt; k++) {
-                const double wk = shfl_d(w, k);
-                const uint32_t q = (uint32_t)__shfl((int)xy, k, 64);
-                x += (double)(int)(q & 0xFFFF) * wk;
-                y += (double)(int)(q >> 16) * wk;
-                sum += wk;
-            }
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double wx = 0.0, wy = 0.0, w = 0.0;
+        if (i < n) {
+            const uint32_t q = rxy_get(C, i);
+            w = C.modgrad[(int)(q >> 16) * C.W + (int)(q & 0xFFFF)];
+            wx = (double)(int)(q & 0xFFFF) * w;
+            wy = (double)(int)(q >> 16) * w;
+        }
+        const int cnt = min(64, n - base);
+        for (int k = 0; k < cnt; k++) {
+            x += readlane_d(wx, k);
+            y += readlane_d(wy, k);
+            sum += readlane_d(w, k);
         }
     }
     x /= sum;
@@ -253,11 +290,10 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
     double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        // the per-point products are order-free and computed by all lanes; only the running sums are serial
         double txx = 0.0, tyy = 0.0, txy = 0.0;
         if (i < n) {
             const uint32_t q = rxy_get(C, i);
-            const double w = C.rmod[i];
+            const double w = C.modgrad[(int)(q >> 16) * C.W + (int)(q & 0xFFFF)];
             const double dx = (double)(int)(q & 0xFFFF) - x, dy = (double)(int)(q >> 16) - y;
             txx = dy * dy * w;
             tyy = dx * dx * w;
@@ -265,9 +301,9 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
         }
         const int cnt = min(64, n - base);
         for (int k = 0; k < cnt; k++) {
-            Ixx += shfl_d(txx, k);
-            Iyy += shfl_d(tyy, k);
-            Ixy -= shfl_d(txy, k);
+            Ixx += readlane_d(txx, k);
+            Iyy += readlane_d(tyy, k);
+            Ixy -= readlane_d(txy, k);
         }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -320,9 +356,8 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
                 if (distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq) {
                     used_clr(C, (int)(q >> 16) * C.W + (int)(q & 0xFFFF));
                     const uint32_t ql = rxy_get(C, m - 1);
-                    const float dl = C.rdeg[m - 1]; const double ml = C.rmod[m - 1];
-                    rxy_put(C, m - 1, q); C.rdeg[m - 1] = C.rdeg[i]; C.rmod[m - 1] = C.rmod[i];
-                    rxy_put(C, i, ql); C.rdeg[i] = dl; C.rmod[i] = ml;
+                    rxy_put(C, m - 1, q);
+                    rxy_put(C, i, ql);
                     --m;
                     --i;
                 }
@@ -333,7 +368,7 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
         n = (int)C.rxy_l[C.rcap];
         __syncthreads();
         if (n < 2) return false;
-        region2rect(C, n, reg_angle, prec, p, rec, nullptr);
+        region2rect(C, n, reg_angle, prec, p, rec);
         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     }
     return true;
@@ -345,8 +380,10 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density >= density_th) return true;
     const uint32_t q0 = rxy_get(C, 0);
+    const int a0 = (int)(q0 >> 16) * C.W + (int)(q0 & 0xFFFF);
     const double xc = (double)(int)(q0 & 0xFFFF), yc = (double)(int)(q0 >> 16);
-    const double ang_c = (double)C.rdeg[0] * DEG2RAD_D;
+    const float deg_c = C.ang[a0];
+    const double ang_c = (double)deg_c * DEG2RAD_D;
     double sum = 0, s_sum = 0;
     int cnt = 0;
     for (int base = 0; base < n; base += 64) {
@@ -355,17 +392,18 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
         double ang_d = 0.0;
         if (i < n) {
             const uint32_t q = rxy_get(C, i);
-            used_clr(C, (int)(q >> 16) * C.W + (int)(q & 0xFFFF));
+            const int a = (int)(q >> 16) * C.W + (int)(q & 0xFFFF);
+            used_clr(C, a);
             if (dist_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) < rec.width) {
                 inc = true;
-                ang_d = angle_diff_signed_d((double)C.rdeg[i] * DEG2RAD_D, ang_c);
+                ang_d = angle_diff_signed_d((double)C.ang[a] * DEG2RAD_D, ang_c);
             }
         }
         unsigned long long m = __ballot(inc);
         while (m) {
             const int k = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const double d = shfl_d(ang_d, k);
+            const double d = readlane_d(ang_d, k);
             sum += d;
             s_sum += d * d;
             ++cnt;
@@ -374,20 +412,18 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     __syncthreads();
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    RegSums ws;
-    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), tau, reg_angle, ws);
+    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, reg_angle);
     if (n < 2) return false;
-    region2rect(C, n, reg_angle, prec, p, rec, &ws);
+    region2rect(C, n, reg_angle, prec, p, rec);
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density < density_th) return reduce_region_radius(C, n, reg_angle, prec, p, rec, density, density_th);
     return true;
 }
 
 __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
-                                                    const double2 *__restrict__ cs_all, uint32_t *__restrict__ rxy_all,
-                                                    float *__restrict__ rdeg_all, double *__restrict__ rmod_all,
-                                                    LsdRect *__restrict__ rects_all, int *__restrict__ nrect, int *__restrict__ status,
-                                                    LsdGeom g)
+                                                    const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
+                                                    uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
+                                                    int *__restrict__ status, LsdGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int f = blockIdx.x, lane = threadIdx.x;
@@ -397,12 +433,14 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     C.ang = ang_all + (size_t)f * g.s_stride;
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
-    C.used = (uint32_t *)smem;
+    C.cs0 = cs0_all + (size_t)f * g.s_stride;
+    C.ring = g.ring;
+    C.ring_cs = (double2 *)smem;                                  // 16-byte aligned first
+    C.ring_deg = (float *)(C.ring_cs + (size_t)g.ring * 9);
+    C.used = (uint32_t *)(C.ring_deg + (size_t)g.ring * 9);
     C.rxy_l = C.used + g.used_words;
     C.rcap = g.rcap;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
-    C.rdeg = rdeg_all + (size_t)f * g.s_stride;
-    C.rmod = rmod_all + (size_t)f * g.s_stride;
     for (int i = lane; i < g.used_words; i += 64) C.used[i] = 0u;
     __syncthreads();
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
@@ -411,23 +449,28 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     for (int base = 0; base < NP; base += 64) {
         const int px = base + lane;
         const float deg = px < NP ? C.ang[px] : NOTDEF_F;
+        float2 c0 = make_float2(0.f, 0.f);
+        if (deg != NOTDEF_F) c0 = C.cs0[px];
         bool ok = px < NP && deg != NOTDEF_F && !used_get(C, px);
         unsigned long long mask = __ballot(ok);
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;
             const int seed = base + j;
+            const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(deg), j));
+            const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
+                                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             double reg_angle;
-            RegSums ws;
-            int n = region_grow(C, seed % W, seed / W, prec, reg_angle, ws);
+            int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, reg_angle);
             if (n >= g.min_reg_size) {
                 LsdRect rec;
-                region2rect(C, n, reg_angle, prec, p, rec, &ws);
+                region2rect(C, n, reg_angle, prec, p, rec);
                 if (refine(C, n, reg_angle, prec, p, rec, 0.7)) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
                     else if (lane == 0) atomicOr(status, 1);
                     nr++;
                 }
             }
+            CBAR();
             ok = ok && lane > j && !used_get(C, px);
             mask = __ballot(ok);
         }
