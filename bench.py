@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames in flight per GPU and step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames in flight per GPU and step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample (0: skip)")
     args = ap.parse_args()
 

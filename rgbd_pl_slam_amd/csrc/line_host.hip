@@ -20,8 +20,8 @@ struct NfaCounts { int total, alg[6], pad; };
 struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
 __global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, NfaState *, int *, LsdGeom);
 __global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
-__global__ void k_nfa_math(int, const double *, const NfaCounts *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *,
-                           uint8_t *, LsdGeom);
+__global__ void k_nfa_eval(int, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
+__global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
                                int, int *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
@@ -44,6 +44,7 @@ struct plf_line {
     NfaState *d_st[2];
     NfaCounts *d_cnt;
     int *d_nfa_counters;
+    double *d_vals;
     double2 *d_cs;
     float2 *d_cs0;
     float *d_ang, *d_rdeg;
@@ -66,7 +67,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_tmp, h->d_blur, h->d_scaled, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rdeg, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -87,16 +88,22 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     g->log_nt = 5 * (log10((double)g->sw) + log10((double)g->sh)) / 2 + log10(11.0);
     g->min_reg_size = (int)(-g->log_nt / log10(g->p));
     g->used_words = (g->sw * g->sh + 31) / 32;
-    g->rcap = 4096;
-    // LDS budget of k_lsd_regions: used bitmap + region list + neighbourhood ring (9 x (4 + 16) bytes per entry)
-    g->ring = 512;
-    while (g->ring > 32 && (size_t)g->used_words * 4 + (size_t)(g->rcap + 1) * 4 + (size_t)g->ring * 9 * 20 > 150 * 1024) g->ring >>= 1;
+    // LDS budget of k_lsd_regions = used bitmap + region list (+1 mailbox word) + neighbourhood ring (9 x (4 + 16) B per
+    // entry).  The kernel is a latency-bound serial chain (one wave per frame), so what matters is how many frames a CU
+    // can host at once: aim for 4 workgroups per CU (<= 39 KB each) when the bitmap allows it, else 2, else 1.
+    g->ring = 32;
+    const size_t fixed = (size_t)g->used_words * 4 + (size_t)g->ring * 9 * 20 + 64;
+    const size_t budgets[3] = {39 * 1024, 78 * 1024, 150 * 1024};
+    g->rcap = 0;
+    for (int b = 0; b < 3 && g->rcap == 0; b++)
+        if (fixed + 1024 * 4 + 4 <= budgets[b]) g->rcap = (int)((budgets[b] - fixed) / 4) - 1;
+    if (g->rcap == 0) return PLF_E_BADARG;
+    if (g->rcap > 16384) g->rcap = 16384;
     int rc = 2048;
     while (rc < g->sw * g->sh / 48 && rc < 8192) rc <<= 1;
     g->rect_cap = rc;
     g->sort_cap = rc;
     g->nkeep = h->prm.nlines;
-    if ((size_t)g->used_words * 4 + (size_t)(g->rcap + 1) * 4 + (size_t)g->ring * 9 * 20 > 150 * 1024) return PLF_E_BADARG;
     return PLF_OK;
 }
 
@@ -209,6 +216,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_st[0], B * R * sizeof(NfaState)); ALLOC(h->d_st[1], B * R * sizeof(NfaState));
     ALLOC(h->d_cnt, B * R * 5 * sizeof(NfaCounts));
     ALLOC(h->d_nfa_counters, 16 * sizeof(int));
+    ALLOC(h->d_vals, B * R * 6 * sizeof(double));
     ALLOC(h->d_xofs, sizeof(int) * (size_t)g.sw); ALLOC(h->d_xa, sizeof(float2) * (size_t)g.sw);
     ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
 #undef ALLOC
@@ -265,7 +273,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         const int in = stage & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage,
                            (stage >= 1 && stage <= 3) ? 5 : 1, h->d_cnt, g);
-        hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_st[in], h->d_st[out],
+        hipLaunchKernelGGL(k_nfa_eval, dim3(4 * math_blocks), dim3(64), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
+                           h->d_vals, g);
+        hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],
                            h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
     }
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,

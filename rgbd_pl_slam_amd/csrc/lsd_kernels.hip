@@ -120,6 +120,16 @@ struct RegCtx {
     int ring;             // ring entries (power of two)
 };
 
+#ifdef PLF_LSD_TIMING
+__device__ long long g_lsd_t[16];
+#define TIC(v) const long long v = clock64()
+#define TOC(slot, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += clock64() - (v); } while (0)
+#define CNT(slot, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += (k); } while (0)
+#else
+#define TIC(v)
+#define TOC(slot, v)
+#define CNT(slot, k)
+#endif
 #define CBAR() asm volatile("" ::: "memory")   // single-wave kernel: LDS ops stay in program order; only the compiler must not reorder
 
 __device__ __forceinline__ bool used_get(const RegCtx &C, int a) { return (C.used[a >> 5] >> (a & 31)) & 1u; }
@@ -175,6 +185,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     const int slot = lane / 9, k9 = lane - slot * 9;
     const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;  // 3x3 neighbourhood in (yy, xx) order
     while (i < n) {
+        CNT(7, 1);
         // ---- prefetch: neighbourhoods of list entries [pf, pf + pc) into registers
         int pc = min(7, min(n, i + C.ring) - pf);
         if (pc < 0) pc = 0;
@@ -197,6 +208,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         }
         // ---- process the parked centres i .. i + gcount - 1
         const int gcount = min(7, rd - i);
+        CNT(8, gcount);
         const bool active = lane < 63 && slot < gcount;
         float deg = NOTDEF_F;
         double2 csv = make_double2(0.0, 0.0);
@@ -446,6 +458,7 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
     int nr = 0;
     const double prec = g.prec, p = g.p;
+    TIC(tall);
     for (int base = 0; base < NP; base += 64) {
         const int px = base + lane;
         const float deg = px < NP ? C.ang[px] : NOTDEF_F;
@@ -460,11 +473,18 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
             const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             double reg_angle;
+            TIC(t0);
             int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, reg_angle);
+            TOC(0, t0); CNT(4, 1); CNT(5, n);
             if (n >= g.min_reg_size) {
                 LsdRect rec;
+                TIC(t1);
                 region2rect(C, n, reg_angle, prec, p, rec);
-                if (refine(C, n, reg_angle, prec, p, rec, 0.7)) {
+                TOC(1, t1); CNT(6, 1);
+                TIC(t2);
+                const bool okr = refine(C, n, reg_angle, prec, p, rec, 0.7);
+                TOC(2, t2);
+                if (okr) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
                     else if (lane == 0) atomicOr(status, 1);
                     nr++;
@@ -475,8 +495,19 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
             mask = __ballot(ok);
         }
     }
+    TOC(3, tall);
     if (lane == 0) nrect[f] = min(nr, g.rect_cap);
 }
+
+#ifdef PLF_LSD_TIMING
+extern "C" void plf_lsd_timing_dump()
+{
+    long long t[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_lsd_t), sizeof(t));
+    printf("[lsd timing, frame 0 accumulated] grow %lld  rect %lld  refine %lld  total %lld cycles | regions %lld points %lld big %lld | iters %lld groups %lld accepts %lld\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // NFA validation (one wave per rectangle)
@@ -683,23 +714,53 @@ __device__ __forceinline__ void nfa_finish(const NfaState &st, float4 *__restric
     emit_segment(st.rec, &seg_all[(size_t)st.frame * g.rect_cap + st.rect]);
 }
 
+// NFA value of every counted candidate, one lane per (rectangle, candidate): the fp64-transcendental part is
+// spread over as many lanes as there are candidates so that no lane evaluates more than one binomial tail.
+// stage 0 / 4: item = rectangle * 6 + k (k-th precision of the same geometry); stages 1..3: item = entry index.
+__global__ void __launch_bounds__(64) k_nfa_eval(int stage, const double *__restrict__ lgam, const NfaCounts *__restrict__ counts,
+                                                 const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
+                                                 double *__restrict__ vals, LsdGeom g)
+{
+    const bool multi = (stage == 0 || stage == 4);
+    const int n = counters[stage] * (multi ? 6 : 5);
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < n; it += gridDim.x * 64) {
+        double v = -1.0e300;
+        if (multi) {
+            const int e = it / 6, k = it - e * 6;
+            const NfaEntry en = entries[e];
+            if (en.nprec == 6 && !(stage == 4 && k == 0)) {
+                const NfaCounts c = counts[e];
+                double pp = en.r.p;
+                for (int q = 0; q < k; q++) pp /= 2;
+                v = nfa_d(lgam, g.log_nt, c.total, c.alg[k], pp);
+            }
+        } else {
+            const NfaEntry en = entries[it];
+            if (en.nprec != 0) {
+                const NfaCounts c = counts[it];
+                v = nfa_d(lgam, g.log_nt, c.total, c.alg[0], en.r.p);
+            }
+        }
+        vals[it] = v;
+    }
+}
+
 // stage: 0 = first evaluation + "finer precision" loop, 1..3 = the three width loops, 4 = final precision loop.
-// Reads the counts of the previous count pass, replays the "keep if better" chain, finishes meaningful rectangles
-// and queues the next stage's candidate rectangles for the others.
-__global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__restrict__ lgam, const NfaCounts *__restrict__ counts,
-                                                 const NfaEntry *__restrict__ entries, const NfaState *__restrict__ st_in,
-                                                 NfaState *__restrict__ st_out, NfaEntry *__restrict__ ent_out, int *__restrict__ counters,
-                                                 float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, LsdGeom g)
+// Reads the NFA values of the previous eval pass, replays the "keep if better" chain in the reference order,
+// finishes meaningful rectangles and queues the next stage's candidate rectangles for the others.
+__global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__restrict__ vals, const NfaEntry *__restrict__ entries,
+                                                 const NfaState *__restrict__ st_in, NfaState *__restrict__ st_out,
+                                                 NfaEntry *__restrict__ ent_out, int *__restrict__ counters, float4 *__restrict__ seg_all,
+                                                 uint8_t *__restrict__ keep_all, LsdGeom g)
 {
     const int n = counters[stage];
     const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
     for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
         NfaState st = st_in[i];
         if (stage == 0 || stage == 4) {
-            const NfaCounts c = counts[i];
             const NfaEntry en = entries[i];
             if (stage == 0) {
-                st.log_nfa = nfa_d(lgam, g.log_nt, c.total, c.alg[0], st.rec.p);
+                st.log_nfa = vals[6 * i];
                 if (st.log_nfa > LOG_EPS) { nfa_finish(st, seg_all, keep_all, g); continue; }
             }
             if (en.nprec == 6) {
@@ -707,7 +768,7 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
                 for (int k = 1; k <= 5; ++k) {
                     r.p /= 2;
                     r.prec = r.p * PI_D;
-                    const double v = nfa_d(lgam, g.log_nt, c.total, c.alg[k], r.p);
+                    const double v = vals[6 * i + k];
                     if (v > st.log_nfa) { st.log_nfa = v; st.rec = r; }
                 }
             }
@@ -717,8 +778,7 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
             for (int k = 0; k < 5; ++k) {
                 const NfaEntry en = entries[5 * i + k];
                 if (en.nprec == 0) continue;
-                const NfaCounts c = counts[5 * i + k];
-                const double v = nfa_d(lgam, g.log_nt, c.total, c.alg[0], en.r.p);
+                const double v = vals[5 * i + k];
                 if (v > st.log_nfa) { st.rec = en.r; st.log_nfa = v; }
             }
             if (st.log_nfa > LOG_EPS) { nfa_finish(st, seg_all, keep_all, g); continue; }
