@@ -107,43 +107,58 @@ def main():
     lin = LineSegment(nlines=NLINES, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank)
     cap = orb.capacity
     mat = Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)
-    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
-    nk = torch.zeros(B, dtype=torch.int32, device="cuda")
-    lines = torch.zeros((B, NLINES, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, NLINES, 32), dtype=torch.uint8, device="cuda")
-    leq = torch.zeros((B, NLINES, 3), dtype=torch.float64, device="cuda"); nl = torch.zeros(B, dtype=torch.int32, device="cuda")
-    match_kp = torch.full((B, cap), -1, dtype=torch.int32, device="cuda"); nm_kp = torch.zeros(B, dtype=torch.int32, device="cuda")
-    match_ln = torch.full((B, NLINES), -1, dtype=torch.int32, device="cuda"); nm_ln = torch.zeros(B, dtype=torch.int32, device="cuda")
+    # feature / match buffers are double-buffered so that the extraction of step k+1 overlaps the matching of step k
+    def bufset():
+        return dict(
+            kps=torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+            nk=torch.zeros(B, dtype=torch.int32, device="cuda"),
+            lines=torch.zeros((B, NLINES, 17), dtype=torch.float32, device="cuda"), ldesc=torch.zeros((B, NLINES, 32), dtype=torch.uint8, device="cuda"),
+            leq=torch.zeros((B, NLINES, 3), dtype=torch.float64, device="cuda"), nl=torch.zeros(B, dtype=torch.int32, device="cuda"),
+            match_kp=torch.full((B, cap), -1, dtype=torch.int32, device="cuda"), nm_kp=torch.zeros(B, dtype=torch.int32, device="cuda"),
+            match_ln=torch.full((B, NLINES), -1, dtype=torch.int32, device="cuda"), nm_ln=torch.zeros(B, dtype=torch.int32, device="cuda"))
+    bufs = [bufset(), bufset()]
     scale = torch.from_numpy(np.ascontiguousarray(orb.GetScaleFactors())).cuda()
-    # two HIP streams: ORB + matching on sA, LSD/LBD on sB (the two extractors are independent, as the two
-    # threads of the PL-SLAM Frame constructor are); the matchers wait for both
-    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    # two HIP streams: LSD/LBD (the long pole: its region growing is a serial chain per frame) on a high-priority
+    # stream sB, ORB + matchers on sA.  The two extractors are independent, as the two threads of the PL-SLAM Frame
+    # constructor are; the matchers of step k wait for both extractors of step k.
+    sA, sB = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)
     stream, stream_b = sA.cuda_stream, sB.cuda_stream
 
     # local map built from the features of frame 0 (so that real matches exist); replicated per GPU
+    b0 = bufs[0]
     torch.cuda.synchronize()
-    orb.extract_batch_device(d_img, W_IMG, H_IMG, kps, desc, nk, cap, stream)
-    lin.extract_batch_device(d_img, W_IMG, H_IMG, lines, ldesc, leq, nl, NLINES, stream_b)
+    orb.extract_batch_device(d_img, W_IMG, H_IMG, b0["kps"], b0["desc"], b0["nk"], cap, stream)
+    lin.extract_batch_device(d_img, W_IMG, H_IMG, b0["lines"], b0["ldesc"], b0["leq"], b0["nl"], NLINES, stream_b)
     torch.cuda.synchronize()
     from rgbd_pl_slam_amd._lib import KP_DTYPE, KL_DTYPE
-    n0 = int(nk[0]); k0 = np.frombuffer(kps[0, :n0].cpu().numpy().tobytes(), KP_DTYPE)
-    l0n = int(nl[0]); l0 = np.frombuffer(lines[0, :l0n].cpu().numpy().tobytes(), KL_DTYPE)
-    mp = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in matchgen.make_local_map(k0, desc[0, :n0].cpu().numpy(), M_POINTS, 1).items()}
-    ml = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in matchgen.make_map_lines(l0, ldesc[0, :l0n].cpu().numpy(), M_LINES, 2).items()}
+    n0 = int(b0["nk"][0]); k0 = np.frombuffer(b0["kps"][0, :n0].cpu().numpy().tobytes(), KP_DTYPE)
+    l0n = int(b0["nl"][0]); l0 = np.frombuffer(b0["lines"][0, :l0n].cpu().numpy().tobytes(), KL_DTYPE)
+    mp = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in matchgen.make_local_map(k0, b0["desc"][0, :n0].cpu().numpy(), M_POINTS, 1).items()}
+    ml = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in matchgen.make_map_lines(l0, b0["ldesc"][0, :l0n].cpu().numpy(), M_LINES, 2).items()}
     bounds = (0.0, 0.0, float(W_IMG), float(H_IMG))
-    fviews = [Matcher.frame_view(cap, kps.data_ptr() + f * cap * 28, desc.data_ptr() + f * cap * 32, scale, bounds, None, nk.data_ptr() + 4 * f)
-              for f in range(B)]
-    lviews = [Matcher.lineframe_view(NLINES, lines.data_ptr() + f * NLINES * 68, ldesc.data_ptr() + f * NLINES * 32, scale, nl.data_ptr() + 4 * f)
-              for f in range(B)]
+    for bs in bufs:
+        bs["fviews"] = [Matcher.frame_view(cap, bs["kps"].data_ptr() + f * cap * 28, bs["desc"].data_ptr() + f * cap * 32, scale, bounds, None,
+                                           bs["nk"].data_ptr() + 4 * f) for f in range(B)]
+        bs["lviews"] = [Matcher.lineframe_view(NLINES, bs["lines"].data_ptr() + f * NLINES * 68, bs["ldesc"].data_ptr() + f * NLINES * 32, scale,
+                                               bs["nl"].data_ptr() + 4 * f) for f in range(B)]
+        bs["match_done"] = None
+    mats = [mat, Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)]
+    state = {"k": 0}
 
     def step():
-        sB.wait_stream(sA)            # the previous step's matchers still read the line buffers
-        orb.extract_batch_device(d_img, W_IMG, H_IMG, kps, desc, nk, cap, stream)
-        lin.extract_batch_device(d_img, W_IMG, H_IMG, lines, ldesc, leq, nl, NLINES, stream_b)
-        sA.wait_stream(sB)
+        k = state["k"]; state["k"] += 1
+        bs = bufs[k & 1]
+        if bs["match_done"] is not None:           # the matchers of step k-2 read this buffer set
+            sA.wait_event(bs["match_done"]); sB.wait_event(bs["match_done"])
+        lin.extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, stream_b)
+        ev_lines = torch.cuda.Event(); ev_lines.record(sB)
+        orb.extract_batch_device(d_img, W_IMG, H_IMG, bs["kps"], bs["desc"], bs["nk"], cap, stream)
         with torch.cuda.stream(sA):
-            match_kp.fill_(-1); match_ln.fill_(-1)
-        mat.SearchByProjection(fviews, mp, 3.0, 0.8, match_kp, cap, nm_kp, stream)
-        mat.SearchLinesByProjection(lviews, ml, 3.0, 0.8, match_ln, NLINES, nm_ln, stream)
+            bs["match_kp"].fill_(-1); bs["match_ln"].fill_(-1)
+        mats[k & 1].SearchByProjection(bs["fviews"], mp, 3.0, 0.8, bs["match_kp"], cap, bs["nm_kp"], stream)
+        sA.wait_event(ev_lines)
+        mats[k & 1].SearchLinesByProjection(bs["lviews"], ml, 3.0, 0.8, bs["match_ln"], NLINES, bs["nm_ln"], stream)
+        bs["match_done"] = torch.cuda.Event(); bs["match_done"].record(sA)
 
     for _ in range(args.warmup):
         step()
@@ -179,7 +194,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: VGA, 1000 ORB feats (8 levels) + 100 lines, plus config-5 matching "
                                    "(SearchByProjection vs 5000-point local map, line projection search vs 500 map lines)",
                        "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), no collective" % world},
-            "matches_frame0": {"points": int(nm_kp[0]), "lines": int(nm_ln[0])},
+            "matches_frame0": {"points": int(bufs[0]["nm_kp"][0]), "lines": int(bufs[0]["nm_ln"][0])},
             "pipeline_algorithmic_GBps": round(fps * BYTES_PER_FRAME / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": "k_lsd_regions", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
