@@ -104,7 +104,9 @@ def main():
     d_img = torch.from_numpy(imgs).cuda()
 
     orb = ORBextractor(nfeatures=NFEAT, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank)
-    lin = LineSegment(nlines=NLINES, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank)
+    # two line handles used alternately: the NFA / descriptor tail of batch k overlaps the region growing of batch k+1
+    lins = [LineSegment(nlines=NLINES, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank) for _ in range(2)]
+    lin = lins[0]
     cap = orb.capacity
     mat = Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)
     # feature / match buffers are double-buffered so that the extraction of step k+1 overlaps the matching of step k
@@ -121,7 +123,9 @@ def main():
     # two HIP streams: LSD/LBD (the long pole: its region growing is a serial chain per frame) on a high-priority
     # stream sB, ORB + matchers on sA.  The two extractors are independent, as the two threads of the PL-SLAM Frame
     # constructor are; the matchers of step k wait for both extractors of step k.
-    sA, sB = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)
+    sA = torch.cuda.Stream(priority=0)
+    sBs = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)]
+    sB = sBs[0]
     stream, stream_b = sA.cuda_stream, sB.cuda_stream
 
     # local map built from the features of frame 0 (so that real matches exist); replicated per GPU
@@ -148,10 +152,11 @@ def main():
     def step():
         k = state["k"]; state["k"] += 1
         bs = bufs[k & 1]
+        sBk = sBs[k & 1]
         if bs["match_done"] is not None:           # the matchers of step k-2 read this buffer set
-            sA.wait_event(bs["match_done"]); sB.wait_event(bs["match_done"])
-        lin.extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, stream_b)
-        ev_lines = torch.cuda.Event(); ev_lines.record(sB)
+            sA.wait_event(bs["match_done"]); sBk.wait_event(bs["match_done"])
+        lins[k & 1].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
+        ev_lines = torch.cuda.Event(); ev_lines.record(sBk)
         orb.extract_batch_device(d_img, W_IMG, H_IMG, bs["kps"], bs["desc"], bs["nk"], cap, stream)
         with torch.cuda.stream(sA):
             bs["match_kp"].fill_(-1); bs["match_ln"].fill_(-1)
@@ -163,7 +168,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    lin.profile(enable=True, reset=True)
+    for l in lins:
+        l.profile(enable=True, reset=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -175,7 +181,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    reg_ms, reg_launches = lin.profile(enable=False, reset=True)
+    reg_ms, reg_launches = 0.0, 0
+    for l in lins:
+        ms_, n_ = l.profile(enable=False, reset=True)
+        reg_ms += ms_; reg_launches += n_
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
