@@ -194,6 +194,15 @@ def main():
 
     if rank == 0:
         reg_avg_s = (reg_ms / max(reg_launches, 1)) * 1e-3
+        # HBM traffic of the dominant kernel from PMC counters (collected offline with rocprofv3 --pmc in separate
+        # passes on this very command; profiles/r01_pmc_traffic.json), scaled to this batch size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            traffic = int(pmc["k_lsd_regions"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
+        except Exception:
+            traffic = None
         achieved = (REGION_BYTES_PER_FRAME * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
         out = {
             "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at 640x480",
@@ -206,7 +215,7 @@ def main():
             "matches_frame0": {"points": int(bufs[0]["nm_kp"][0]), "lines": int(bufs[0]["nm_ln"][0])},
             "pipeline_algorithmic_GBps": round(fps * BYTES_PER_FRAME / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": "k_lsd_regions", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches,
                          "algorithmic_bytes_per_launch": REGION_BYTES_PER_FRAME * B},
         }

@@ -455,6 +455,9 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
     for (int i = lane; i < g.used_words; i += 64) C.used[i] = 0u;
     __syncthreads();
+    // This wave is one long dependent chain; waves of other kernels sharing its SIMD only ever delay it.
+    // Raise its issue priority so that co-running throughput kernels (ORB, matchers, NFA) fill the idle slots instead.
+    __builtin_amdgcn_s_setprio(3);
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
     int nr = 0;
     const double prec = g.prec, p = g.p;
