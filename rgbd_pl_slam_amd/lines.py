@@ -29,7 +29,11 @@ class LineSegment:
 
     def ExtractLineSegment(self, img):
         """returns (keylines[KL_DTYPE], ldesc[n,32] uint8, lineFunctions[n,3] float64)"""
-        img = np.ascontiguousarray(img, np.uint8)
+        img = np.asarray(img)
+        if img.ndim != 2 or img.dtype != np.uint8:
+            raise ValueError("8-bit single-channel image expected")
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
         h, w = img.shape
         kl = np.zeros(self.nlines, L.KL_DTYPE); desc = np.zeros((self.nlines, 32), np.uint8); eq = np.zeros((self.nlines, 3), np.float64)
         n = C.c_int32(0)

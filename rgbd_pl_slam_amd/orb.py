@@ -43,9 +43,11 @@ class ORBextractor:
     def GetFeaturesPerLevel(self): return self._tables["perLevel"]
 
     def __call__(self, image, mask=None):
-        image = np.ascontiguousarray(image, np.uint8)
-        if image.ndim != 2:
-            raise ValueError("8-bit single-channel image expected")
+        image = np.asarray(image)
+        if image.ndim != 2 or image.dtype != np.uint8:
+            raise ValueError("8-bit single-channel image expected")  # the reference asserts CV_8UC1
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)                      # rows may be padded (pitch > width), columns may not
         h, w = image.shape
         kps = np.zeros(self.capacity, L.KP_DTYPE); desc = np.zeros((self.capacity, 32), np.uint8)
         n = C.c_int32(0)

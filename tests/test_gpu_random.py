@@ -1,0 +1,138 @@
+"""GPU parity on randomised shapes and parameters, strided inputs, BASELINE config-3 batches and the
+device-resident API; plus size-independent properties at full batch size."""
+import numpy as np
+import pytest
+
+import orc
+from conftest import gpu_available
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not gpu_available():
+        pytest.fail("no GPU visible: the -m gpu tests need a real MI355X")
+
+
+def _eq_orb(kps, desc, ref):
+    assert len(kps) == len(ref["kps"])
+    for f in ("x", "y", "size", "angle", "response"):
+        assert np.array_equal(kps[f].view(np.uint32), ref["kps"][f].view(np.uint32)), f
+    assert np.array_equal(kps["octave"], ref["kps"]["octave"]) and np.array_equal(desc, ref["desc"])
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_orb_random_shapes_and_parameters(case):
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor
+    from rgbd_pl_slam_amd.synth import synth_frame
+    rng = np.random.default_rng(100 + case)
+    w = int(rng.integers(260, 900)); h = int(rng.integers(max(200, w // 2 + 40), min(700, w) + 1))
+    nlev = int(rng.integers(3, 9)); sf = float(np.float32(rng.choice([1.1, 1.2, 1.3, 1.5])))
+    nf = int(rng.integers(200, 3000)); ini = int(rng.integers(12, 40)); mn = int(rng.integers(3, 12))
+    # every level must keep at least one 30-px FAST cell
+    while min(w, h) / (sf ** (nlev - 1)) < 70:
+        nlev -= 1
+    img = synth_frame(1000 + case, w, h)
+    pad = np.zeros((h, w + int(rng.integers(0, 37))), np.uint8); pad[:, :w] = img
+    view = pad[:, :w]                                # pitch > width, same pixels
+    ext = ORBextractor(nfeatures=nf, scaleFactor=sf, nlevels=nlev, iniThFAST=ini, minThFAST=mn, max_width=w, max_height=h)
+    kps, desc = ext(view)
+    ref = orc.orb_extract(img, nfeatures=nf, scale_factor=sf, nlevels=nlev, ini_th=ini, min_th=mn)
+    _eq_orb(kps, desc, ref)
+    ext.close()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_lines_random_shapes(case):
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    rng = np.random.default_rng(200 + case)
+    w = int(rng.integers(200, 900)); h = int(rng.integers(160, 700)); nl = int(rng.choice([30, 100, 250]))
+    img = synth_frame(2000 + case, w, h)
+    ls = LineSegment(nlines=nl, max_width=w, max_height=h)
+    kl, desc, eq = ls.ExtractLineSegment(img)
+    ref = orc.line_extract(img, nl)
+    assert len(kl) == len(ref["kl"])
+    for name in kl.dtype.names:
+        assert np.array_equal(kl[name].view(np.uint32), ref["kl"][name].view(np.uint32)), name
+    assert np.array_equal(desc, ref["desc"])
+    assert np.allclose(eq, ref["eq"], rtol=0, atol=1e-9)
+    ls.close()
+
+
+def test_config3_batch8_2000_orb_200_lines():
+    """BASELINE configs[2]: 640x480, 2000 ORB + 200 lines, 8 frames in flight on one GPU"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment
+    from rgbd_pl_slam_amd.synth import synth_batch
+    imgs = synth_batch(300, 8)
+    ext = ORBextractor(nfeatures=2000, max_width=640, max_height=480, max_batch=8)
+    ls = LineSegment(nlines=200, max_width=640, max_height=480, max_batch=8)
+    ro = ext.extract_batch(imgs); rl = ls.extract_batch(imgs)
+    for f in range(8):
+        _eq_orb(ro[f][0], ro[f][1], orc.orb_extract(imgs[f], nfeatures=2000))
+        ref = orc.line_extract(imgs[f], 200)
+        assert np.array_equal(rl[f][1], ref["desc"])
+        assert np.array_equal(rl[f][0]["endPointY"].view(np.uint32), ref["kl"]["endPointY"].view(np.uint32))
+    ext.close(); ls.close()
+
+
+def test_device_resident_api_equals_host_api_and_is_deterministic():
+    """PLF_MEM_DEVICE in/out (the bench path) returns the same bytes as the host API; identical frames inside a
+    large batch give identical outputs (no cross-frame interference at 256 frames in flight)."""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment
+    from rgbd_pl_slam_amd.synth import synth_batch
+    from rgbd_pl_slam_amd._lib import KP_DTYPE
+    B = 256
+    base = synth_batch(400, 4)
+    imgs = np.concatenate([base] * (B // 4))
+    ext = ORBextractor(max_width=640, max_height=480, max_batch=B)
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
+    cap = ext.capacity
+    d = torch.from_numpy(imgs).cuda()
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    ext.extract_batch_device(d, 640, 480, kps, desc, n, cap, s.cuda_stream)
+    lines = torch.zeros((B, 100, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, 100, 32), dtype=torch.uint8, device="cuda")
+    leq = torch.zeros((B, 100, 3), dtype=torch.float64, device="cuda"); nl = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ls.extract_batch_device(d, 640, 480, lines, ldesc, leq, nl, 100, s.cuda_stream)
+    torch.cuda.synchronize()
+    nh = n.cpu().numpy(); dh = desc.cpu().numpy(); kh = kps.cpu().numpy(); lh = ldesc.cpu().numpy(); nlh = nl.cpu().numpy()
+    for f in range(4):
+        ref = orc.orb_extract(base[f])
+        assert nh[f] == len(ref["kps"]) and np.array_equal(dh[f, :nh[f]], ref["desc"])
+        k = np.frombuffer(kh[f, :nh[f]].tobytes(), KP_DTYPE)
+        assert np.array_equal(k["angle"].view(np.uint32), ref["kps"]["angle"].view(np.uint32))
+        assert np.array_equal(lh[f, :nlh[f]], orc.line_extract(base[f], 100)["desc"])
+    for f in range(4, B):  # every replica equals its original
+        assert nh[f] == nh[f % 4] and np.array_equal(dh[f, :nh[f]], dh[f % 4, :nh[f]])
+        assert nlh[f] == nlh[f % 4] and np.array_equal(lh[f, :nlh[f]], lh[f % 4, :nlh[f]])
+    ext.close(); ls.close()
+
+
+def test_hamming_properties_full_size():
+    """size-independent properties at BASELINE config-5 size: symmetry, identity, triangle inequality on 5000 x 1000"""
+    _need_gpu()
+    import torch
+    import ctypes as C
+    from rgbd_pl_slam_amd import _lib as L
+    rng = np.random.default_rng(9)
+    a = torch.from_numpy(rng.integers(0, 256, (5000, 32), dtype=np.uint8)).cuda()
+    b = torch.from_numpy(rng.integers(0, 256, (1000, 32), dtype=np.uint8)).cuda()
+    dab = torch.zeros((5000, 1000), dtype=torch.int32, device="cuda"); dba = torch.zeros((1000, 5000), dtype=torch.int32, device="cuda")
+    dbb = torch.zeros((1000, 1000), dtype=torch.int32, device="cuda")
+    lib = L.lib()
+    L.check(lib.plf_hamming256_matrix(L.vp(a), 5000, L.vp(b), 1000, L.vp(dab), L.MEM_DEVICE, 0, None), "hamming")
+    L.check(lib.plf_hamming256_matrix(L.vp(b), 1000, L.vp(a), 5000, L.vp(dba), L.MEM_DEVICE, 0, None), "hamming")
+    L.check(lib.plf_hamming256_matrix(L.vp(b), 1000, L.vp(b), 1000, L.vp(dbb), L.MEM_DEVICE, 0, None), "hamming")
+    torch.cuda.synchronize()
+    assert torch.equal(dab, dba.t().contiguous())
+    assert int(dbb.diagonal().abs().sum()) == 0 and int(dab.min()) >= 0 and int(dab.max()) <= 256
+    # triangle inequality d(a_i, b_j) <= d(a_i, b_k) + d(b_k, b_j) on a sample
+    i = torch.randint(0, 5000, (2000,), device="cuda"); j = torch.randint(0, 1000, (2000,), device="cuda"); k = torch.randint(0, 1000, (2000,), device="cuda")
+    assert bool((dab[i, j] <= dab[i, k] + dbb[k, j]).all())
