@@ -599,10 +599,11 @@ struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };   // nprec: 0 = sk
 struct NfaCounts { int total, alg[6], pad; };
 struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
 
-// wave-cooperative pixel count of one rectangle
+// pixel count of one rectangle by a group of 16 lanes (4 rectangles per wave: most candidate rectangles span
+// only a few rows, so a full wave per rectangle would idle)
 __device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, int nprec, NfaCounts &out)
 {
-    const int lane = plf_lane();
+    const int lane = plf_lane() & 15;
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     EdgePt o[4];
@@ -647,7 +648,7 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
         for (int k = 1; k < 6; k++) { pp /= 2; precs[k] = pp * PI_D; }
     }
     int total = 0, alg[6] = {0, 0, 0, 0, 0, 0};
-    for (int y = y_lo + lane; y <= y_hi; y += 64) {
+    for (int y = y_lo + lane; y <= y_hi; y += 16) {
         const long long al = max(0, min(y, lf.y) - y_lo), bl = (long long)(y - y_lo) - al;
         const long long ar = max(0, min(y, rt.y) - y_lo), br = (long long)(y - y_lo) - ar;
         const long long left = (long long)mn.x + flstep * al + slstep * bl, right = (long long)mn.x + frstep * ar + srstep * br;
@@ -668,9 +669,15 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
             for (int k = 0; k < 6; k++) if (k < nprec && n_theta <= precs[k]) ++alg[k];
         }
     }
-    out.total = plf_wave_sum(total);
 #pragma unroll
-    for (int k = 0; k < 6; k++) out.alg[k] = plf_wave_sum(alg[k]);
+    for (int o = 8; o > 0; o >>= 1) {  // butterfly inside the 16-lane group
+        total += __shfl_xor(total, o, 64);
+#pragma unroll
+        for (int k = 0; k < 6; k++) alg[k] += __shfl_xor(alg[k], o, 64);
+    }
+    out.total = total;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out.alg[k] = alg[k];
 }
 
 __device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
@@ -702,12 +709,15 @@ __global__ void __launch_bounds__(64) k_nfa_count(const float *__restrict__ ang_
                                                   const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
 {
     const int n = counters[cidx] * mult;
-    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const int grp = threadIdx.x >> 4;
+    for (int e0 = blockIdx.x * 4; e0 < n; e0 += gridDim.x * 4) {
+        const int e = e0 + grp;
+        if (e >= n) continue;     // (no wave-wide barrier below: groups are independent)
         const NfaEntry en = entries[e];
         if (en.nprec == 0) continue;
         NfaCounts c;
         rect_count(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, en.nprec, c);
-        if (threadIdx.x == 0) counts[e] = c;
+        if ((threadIdx.x & 15) == 0) counts[e] = c;
     }
 }
 
