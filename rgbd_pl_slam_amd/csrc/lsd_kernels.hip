@@ -105,19 +105,22 @@ __global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ sca
 // ------------------------------------------------------------------------------------------------
 // region growing (one wave per frame)
 // ------------------------------------------------------------------------------------------------
+// LDS pointers carry their address space in the type: a pointer that may be LDS or global would be lowered to FLAT
+// accesses, whose `s_waitcnt vmcnt(0)` also drains the outstanding neighbourhood prefetches.
+#define LDS_PTR(T) __attribute__((address_space(3))) T *
 struct RegCtx {
     int W, H;
     const float *ang;
     const double *modgrad;
     const double2 *cs;
     const float2 *cs0;
-    uint32_t *used;       // LDS bitmap, 1 = USED
-    uint32_t *rxy_l;      // LDS part of the region list (x | y << 16)
-    uint32_t *rxy_g;      // global overflow of the region list
+    LDS_PTR(uint32_t) used;    // LDS bitmap, 1 = USED
+    LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
+    uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
-    float *ring_deg;      // LDS ring: 9 neighbour angles of queued region points
-    double2 *ring_cs;     // LDS ring: their cos/sin increments
-    int ring;             // ring entries (power of two)
+    LDS_PTR(float) ring_deg;   // LDS ring: 9 neighbour angles of queued region points
+    LDS_PTR(double) ring_cs;   // LDS ring: their cos/sin increments (2 doubles per neighbour)
+    int ring;                  // ring entries (power of two)
 };
 
 #ifdef PLF_LSD_TIMING
@@ -133,10 +136,19 @@ __device__ long long g_lsd_t[16];
 #define CBAR() asm volatile("" ::: "memory")   // single-wave kernel: LDS ops stay in program order; only the compiler must not reorder
 
 __device__ __forceinline__ bool used_get(const RegCtx &C, int a) { return (C.used[a >> 5] >> (a & 31)) & 1u; }
-__device__ __forceinline__ void used_set(RegCtx &C, int a) { atomicOr(&C.used[a >> 5], 1u << (a & 31)); }
-__device__ __forceinline__ void used_clr(RegCtx &C, int a) { atomicAnd(&C.used[a >> 5], ~(1u << (a & 31))); }
-__device__ __forceinline__ uint32_t rxy_get(const RegCtx &C, int i) { return i < C.rcap ? C.rxy_l[i] : C.rxy_g[i]; }
-__device__ __forceinline__ void rxy_put(RegCtx &C, int i, uint32_t v) { if (i < C.rcap) C.rxy_l[i] = v; else C.rxy_g[i] = v; }
+__device__ __forceinline__ void used_set(RegCtx &C, int a) { __hip_atomic_fetch_or(&C.used[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void used_clr(RegCtx &C, int a) { __hip_atomic_fetch_and(&C.used[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t rxy_get(const RegCtx &C, int i)
+{
+    uint32_t v = C.rxy_l[i < C.rcap ? i : 0];   // always an LDS read
+    if (i >= C.rcap) v = C.rxy_g[i];            // rare: regions longer than the LDS list
+    return v;
+}
+__device__ __forceinline__ void rxy_put(RegCtx &C, int i, uint32_t v)
+{
+    if (i < C.rcap) C.rxy_l[i] = v;
+    else C.rxy_g[i] = v;
+}
 
 __device__ __forceinline__ double shfl_d(double v, int src)
 {
@@ -187,6 +199,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     while (i < n) {
         CNT(7, 1);
         // ---- prefetch: neighbourhoods of list entries [pf, pf + pc) into registers
+        TIC(tp);
         int pc = min(7, min(n, i + C.ring) - pf);
         if (pc < 0) pc = 0;
         float pdeg = NOTDEF_F;
@@ -201,12 +214,19 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                 if (pdeg != NOTDEF_F) pcs = C.cs[a];
             }
         }
+        TOC(12, tp);
         if (rd <= i) {  // nothing parked for the next centre: commit the fetch now (waits for the loads)
-            if (pact) { C.ring_deg[((pf + slot) & RM) * 9 + k9] = pdeg; C.ring_cs[((pf + slot) & RM) * 9 + k9] = pcs; }
+            TIC(ts);
+            if (pact) { const int ri = ((pf + slot) & RM) * 9 + k9; C.ring_deg[ri] = pdeg; C.ring_cs[2 * ri] = pcs.x; C.ring_cs[2 * ri + 1] = pcs.y; }
             rd = pf + pc; pf += pc; pc = 0;
             CBAR();
+#ifdef PLF_LSD_TIMING
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+            TOC(10, ts); CNT(11, 1);
         }
         // ---- process the parked centres i .. i + gcount - 1
+        TIC(tr);
         const int gcount = min(7, rd - i);
         CNT(8, gcount);
         const bool active = lane < 63 && slot < gcount;
@@ -216,12 +236,15 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         if (active) {
             const uint32_t pxy = rxy_get(C, i + slot);
             xx = (int)(pxy & 0xFFFF) + kx; yy = (int)(pxy >> 16) + ky;
-            deg = C.ring_deg[((i + slot) & RM) * 9 + k9];   // NOTDEF for neighbours outside the image
-            csv = C.ring_cs[((i + slot) & RM) * 9 + k9];
+            const int ri = ((i + slot) & RM) * 9 + k9;
+            deg = C.ring_deg[ri];   // NOTDEF for neighbours outside the image
+            csv = make_double2(C.ring_cs[2 * ri], C.ring_cs[2 * ri + 1]);
             a = yy * W + xx;
         }
         const bool defined = active && deg != NOTDEF_F;
         const double adeg = (double)deg * DEG2RAD_D;
+        TOC(13, tr);
+        TIC(ta);
         for (int s = 0; s < gcount; s++) {
             bool cand = defined && slot == s && !used_get(C, a);
             while (true) {
@@ -252,9 +275,10 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             }
             CBAR();
         }
+        TOC(14, ta);
         i += gcount;
         if (pc > 0) {  // park the fetch issued at the top of this iteration
-            if (pact) { C.ring_deg[((pf + slot) & RM) * 9 + k9] = pdeg; C.ring_cs[((pf + slot) & RM) * 9 + k9] = pcs; }
+            if (pact) { const int ri = ((pf + slot) & RM) * 9 + k9; C.ring_deg[ri] = pdeg; C.ring_cs[2 * ri] = pcs.x; C.ring_cs[2 * ri + 1] = pcs.y; }
             rd = pf + pc; pf += pc;
             CBAR();
         }
@@ -447,9 +471,9 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
     C.ring = g.ring;
-    C.ring_cs = (double2 *)smem;                                  // 16-byte aligned first
-    C.ring_deg = (float *)(C.ring_cs + (size_t)g.ring * 9);
-    C.used = (uint32_t *)(C.ring_deg + (size_t)g.ring * 9);
+    C.ring_cs = (LDS_PTR(double))smem;                            // 16-byte aligned first
+    C.ring_deg = (LDS_PTR(float))(C.ring_cs + (size_t)g.ring * 18);
+    C.used = (LDS_PTR(uint32_t))(C.ring_deg + (size_t)g.ring * 9);
     C.rxy_l = C.used + g.used_words;
     C.rcap = g.rcap;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
@@ -509,6 +533,7 @@ extern "C" void plf_lsd_timing_dump()
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_lsd_t), sizeof(t));
     printf("[lsd timing, frame 0 accumulated] grow %lld  rect %lld  refine %lld  total %lld cycles | regions %lld points %lld big %lld | iters %lld groups %lld accepts %lld\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+    printf("[lsd timing] stall-commit cycles %lld in %lld stalls | prefetch-issue %lld  ring-read %lld  accept-loops %lld\n", t[10], t[11], t[12], t[13], t[14]);
 }
 #endif
 
