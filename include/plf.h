@@ -241,6 +241,34 @@ int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view *frames, in
                             const plf_mapline_view *ml, float th, float nnratio, int32_t *match_of_line,
                             int32_t line_stride, int32_t *nmatches, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * RGB-D ingest, Frame tail and frustum projection -- the stages either side of
+ * the extractor + matcher hot path.  Stateless; all pointers are DEVICE memory; asynchronous on `stream`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float fx, fy, cx, cy, k1, k2, p1, p2, k3, bf; } plf_camera;      /* Camera.* keys of TUM1.yaml:8-32 */
+typedef struct { float Rcw[9], tcw[3], Ow[3]; } plf_frustum_pose;                  /* mRcw, mtcw, mOw of the Frame */
+
+/* Tracking::GrabImageRGBD colour conversion, cv::cvtColor(RGB2GRAY / BGR2GRAY) (so@0x522e6); 3 bytes per pixel */
+int plf_rgb_to_gray(const uint8_t *rgb, int32_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch, ptrdiff_t frame_stride,
+                    int32_t bgr_order, uint8_t *gray, ptrdiff_t gray_pitch, ptrdiff_t gray_frame_stride, int32_t device, void *stream);
+/* imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) (so@0x5206d); out: n_frames x height x width floats */
+int plf_depth_to_float(const uint16_t *depth, int32_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch_elems,
+                       ptrdiff_t frame_stride_elems, float factor, float *out, int32_t device, void *stream);
+/* Frame::UndistortKeyPoints (so@0xf8630) + Frame::ComputeStereoFromRGBD (so@0xf6860) for n_frames key point sets laid out
+ * like the outputs of plf_orb_extract_batch (kp_stride entries per frame; count per frame from n_device, or n_host).
+ * depth: n_frames x height x width floats (NULL: monocular, uright = -1).  keys_un = mvKeysUn, uright = mvuRight,
+ * kp_depth = mvDepth (may be NULL). */
+int plf_frame_tail(const plf_keypoint *keys, const int32_t *n_device, int32_t n_host, int32_t n_frames, int32_t kp_stride,
+                   const float *depth, int32_t width, int32_t height, const plf_camera *cam, plf_keypoint *keys_un, float *uright,
+                   float *kp_depth, int32_t device, void *stream);
+/* bool Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit) include/Frame.h:104 (so@0xf5190) with
+ * MapPoint::PredictScale (so@0x8fc20) for m map points: fills the plf_mappoint_view fields the matcher reads.
+ * min/max_distance = mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors are applied inside). */
+int plf_frustum_points(const float *world_pos, const float *normal, const float *min_distance, const float *max_distance, int32_t m,
+                       const plf_frustum_pose *pose, const plf_camera *cam, float min_x, float min_y, float max_x, float max_y,
+                       float log_scale_factor, int32_t nlevels, float viewing_cos_limit, float *proj_x, float *proj_y, float *proj_xr,
+                       int32_t *level, float *view_cos, uint8_t *in_view, int32_t device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

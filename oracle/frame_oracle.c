@@ -1,0 +1,112 @@
+/*
+ * frame_oracle.c -- CPU restatement of the Frame "tail" stages next to the extractor and of the projection that
+ * feeds the matcher.  TEST INFRASTRUCTURE ONLY (same rules as orb_oracle.c).
+ *
+ *   orc_rgb_to_gray            Tracking::GrabImageRGBD cv::cvtColor(RGB|BGR -> GRAY)      so@0x522e6  [UPSTREAM OpenCV 3.3 color.cpp, 8U fixed point]
+ *   orc_depth_to_float         imDepth.convertTo(CV_32F, mDepthMapFactor)                 so@0x5206d  [UPSTREAM cvtScale 16u->32f, float arithmetic]
+ *   orc_undistort_keypoints    Frame::UndistortKeyPoints                                  so@0xf8630  [UPSTREAM cv::undistortPoints, 5 iterations, double]
+ *   orc_stereo_from_rgbd       Frame::ComputeStereoFromRGBD                               so@0xf6860
+ *   orc_is_in_frustum          Frame::isInFrustum(MapPoint*, float) include/Frame.h:104   so@0xf5190, MapPoint::PredictScale so@0x8fc20 (logf, ceilf)
+ * The ORB-SLAM glue follows the disassembly sites above; the OpenCV internals are "parity unpinned".
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "oracle.h"
+
+/* cv::cvtColor 8U: Y = (R*4899 + G*9617 + B*1868 + 8192) >> 14 (yuv_shift = 14) */
+void orc_rgb_to_gray(const uint8_t *rgb, int w, int h, ptrdiff_t pitch, int bgr_order, uint8_t *gray, ptrdiff_t gpitch)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *p = rgb + (ptrdiff_t)y * pitch + 3 * x;
+            const int r = bgr_order ? p[2] : p[0], g = p[1], b = bgr_order ? p[0] : p[2];
+            gray[(ptrdiff_t)y * gpitch + x] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14);
+        }
+}
+
+void orc_depth_to_float(const uint16_t *d, int w, int h, ptrdiff_t pitch_elems, float factor, float *out)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) out[(size_t)y * w + x] = (float)d[(ptrdiff_t)y * pitch_elems + x] * factor + 0.0f;
+}
+
+/* cam: fx, fy, cx, cy, k1, k2, p1, p2, k3 (floats as stored in mK / mDistCoef) */
+void orc_undistort_keypoints(const orc_keypoint *keys, int n, const float *cam, orc_keypoint *keys_un)
+{
+    const float k1 = cam[4];
+    if (k1 == 0.0f) { /* mDistCoef.at<float>(0)==0.0: mvKeysUn = mvKeys */
+        for (int i = 0; i < n; i++) keys_un[i] = keys[i];
+        return;
+    }
+    const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k[5] = {cam[4], cam[5], cam[6], cam[7], cam[8]};
+    for (int i = 0; i < n; i++) {
+        double x = keys[i].x, y = keys[i].y;
+        double x0 = x = (x - cx) * ifx;
+        double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + 0 * r2 + 0 * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        /* P = K, R = I: RR = K */
+        const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+        keys_un[i] = keys[i];
+        keys_un[i].x = (float)(xx * ww);
+        keys_un[i].y = (float)(yy * ww);
+    }
+}
+
+void orc_stereo_from_rgbd(const orc_keypoint *keys, const orc_keypoint *keys_un, int n, const float *depth, int w, int h, float bf,
+                          float *uright, float *kdepth)
+{
+    for (int i = 0; i < n; i++) {
+        uright[i] = -1.f; kdepth[i] = -1.f;
+        const int v = (int)keys[i].y, u = (int)keys[i].x; /* at<float>(float, float): truncation */
+        if (u < 0 || v < 0 || u >= w || v >= h) continue;   /* reference reads out of bounds here */
+        const float d = depth[(size_t)v * w + u];
+        if (d > 0) { kdepth[i] = d; uright[i] = keys_un[i].x - bf / d; }
+    }
+}
+
+/* pose: Rcw (9, row-major), tcw (3), Ow (3); cam: fx, fy, cx, cy; bounds: minx, miny, maxx, maxy */
+void orc_is_in_frustum(const float *xw, const float *normal, const float *min_dist, const float *max_dist, int m, const float *Rcw,
+                       const float *tcw, const float *Ow, const float *cam, const float *bounds, float bf, float log_scale_factor, int nlevels,
+                       float cos_limit, float *proj_x, float *proj_y, float *proj_xr, int32_t *level, float *view_cos, uint8_t *in_view)
+{
+    for (int i = 0; i < m; i++) {
+        in_view[i] = 0;
+        const float *P = xw + 3 * (size_t)i;
+        const float PcX = Rcw[0] * P[0] + Rcw[1] * P[1] + Rcw[2] * P[2] + tcw[0];
+        const float PcY = Rcw[3] * P[0] + Rcw[4] * P[1] + Rcw[5] * P[2] + tcw[1];
+        const float PcZ = Rcw[6] * P[0] + Rcw[7] * P[1] + Rcw[8] * P[2] + tcw[2];
+        if (PcZ < 0.0f) continue;
+        const float invz = 1.0f / PcZ;
+        const float u = cam[0] * PcX * invz + cam[2];
+        const float v = cam[1] * PcY * invz + cam[3];
+        if (u < bounds[0] || u > bounds[2]) continue;
+        if (v < bounds[1] || v > bounds[3]) continue;
+        const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)PO[k] * (double)PO[k];   /* cv::norm(CV_32F): double accumulation */
+        const float dist = (float)sqrt(s);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float *Pn = normal + 3 * (size_t)i;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k]; /* Mat::dot(CV_32F): double accumulation */
+        const float viewCos = (float)(dot / (double)dist);
+        if (viewCos < cos_limit) continue;
+        const float ratio = max_dist[i] / dist;
+        int nScale = (int)ceilf(logf(ratio) / log_scale_factor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= nlevels) nScale = nlevels - 1;
+        in_view[i] = 1;
+        proj_x[i] = u; proj_xr[i] = u - bf * invz; proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
+    }
+}

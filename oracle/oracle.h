@@ -153,6 +153,16 @@ void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const o
 int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
                      uint8_t *desc, double *lineeq, int cap, int *ndetected);
 
+/* ---- Frame tail / ingest / frustum (frame_oracle.c) */
+void orc_rgb_to_gray(const uint8_t *rgb, int w, int h, ptrdiff_t pitch, int bgr_order, uint8_t *gray, ptrdiff_t gpitch);
+void orc_depth_to_float(const uint16_t *d, int w, int h, ptrdiff_t pitch_elems, float factor, float *out);
+void orc_undistort_keypoints(const orc_keypoint *keys, int n, const float *cam, orc_keypoint *keys_un);
+void orc_stereo_from_rgbd(const orc_keypoint *keys, const orc_keypoint *keys_un, int n, const float *depth, int w, int h, float bf,
+                          float *uright, float *kdepth);
+void orc_is_in_frustum(const float *xw, const float *normal, const float *min_dist, const float *max_dist, int m, const float *Rcw,
+                       const float *tcw, const float *Ow, const float *cam, const float *bounds, float bf, float log_scale_factor, int nlevels,
+                       float cos_limit, float *proj_x, float *proj_y, float *proj_xr, int32_t *level, float *view_cos, uint8_t *in_view);
+
 /* ---- CPU baseline driver (bench_oracle.c) */
 double orc_frontend_throughput(const uint8_t *imgs, int n_distinct, int w, int h, int n_frames, int threads, int nfeatures, int nlines,
                                const orc_mappoints *MP, const orc_maplines *ML, float th, float nnratio, long *checksum);

@@ -5,3 +5,4 @@ from ._lib import PlfError, LIB_PATH  # noqa: F401
 from .orb import ORBextractor  # noqa: F401
 from .lines import LineSegment  # noqa: F401
 from .matcher import Matcher, DescriptorDistance  # noqa: F401
+from . import frame  # noqa: F401

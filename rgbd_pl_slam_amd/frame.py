@@ -1,0 +1,62 @@
+"""Host-side mirror of the Frame stages around the extractor / matcher: RGB-D ingest
+(Tracking::GrabImageRGBD), Frame::UndistortKeyPoints + ComputeStereoFromRGBD, Frame::isInFrustum.  Device tensors in/out."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")]
+
+
+class FrustumPose(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3)]
+
+
+TUM1 = dict(fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, k1=0.262383, k2=-0.953104, p1=-0.005358, p2=0.002628,
+            k3=1.163314, bf=40.0)   # Examples/RGB-D/TUM1.yaml:8-32
+
+
+def camera(**kw):
+    c = Camera()
+    for k, v in kw.items():
+        setattr(c, k, float(v))
+    return c
+
+
+def _stream(s):
+    return C.c_void_p(s) if s else None
+
+
+def rgb_to_gray(d_rgb, d_gray, bgr_order=True, device=0, stream=None):
+    """d_rgb: (B,H,W,3) uint8 device tensor -> d_gray (B,H,W) uint8"""
+    B, H, W, _ = d_rgb.shape
+    L.check(L.lib().plf_rgb_to_gray(L.vp(d_rgb), B, W, H, C.c_ssize_t(3 * W), C.c_ssize_t(3 * W * H), int(bgr_order), L.vp(d_gray),
+                                    C.c_ssize_t(W), C.c_ssize_t(W * H), device, _stream(stream)), "plf_rgb_to_gray")
+
+
+def depth_to_float(d_depth16, d_out, factor, device=0, stream=None):
+    B, H, W = d_depth16.shape
+    L.check(L.lib().plf_depth_to_float(L.vp(d_depth16), B, W, H, C.c_ssize_t(W), C.c_ssize_t(W * H), C.c_float(factor), L.vp(d_out), device,
+                                       _stream(stream)), "plf_depth_to_float")
+
+
+def frame_tail(d_keys, n, n_frames, kp_stride, d_depth, W, H, cam, d_keys_un, d_uright, d_kdepth, device=0, stream=None):
+    """n: int (host count, single frame) or a device int32 tensor with one count per frame"""
+    n_dev, n_host = (None, int(n)) if isinstance(n, int) else (L.vp(n), 0)
+    L.check(L.lib().plf_frame_tail(L.vp(d_keys), n_dev, n_host, n_frames, kp_stride, L.vp(d_depth) if d_depth is not None else None, W, H,
+                                   C.byref(cam), L.vp(d_keys_un), L.vp(d_uright), L.vp(d_kdepth), device, _stream(stream)), "plf_frame_tail")
+
+
+def frustum_points(d_xw, d_normal, d_min, d_max, pose, cam, bounds, log_scale_factor, nlevels, cos_limit, out, device=0, stream=None):
+    """out: dict of device tensors proj_x, proj_y, proj_xr, level, view_cos, in_view (the plf_mappoint_view fields)"""
+    pp = FrustumPose()
+    for name in ("Rcw", "tcw", "Ow"):
+        getattr(pp, name)[:] = np.asarray(pose[name], np.float32).ravel().tolist()
+    m = int(d_xw.shape[0])
+    L.check(L.lib().plf_frustum_points(L.vp(d_xw), L.vp(d_normal), L.vp(d_min), L.vp(d_max), m, C.byref(pp), C.byref(cam), C.c_float(bounds[0]),
+                                       C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), C.c_float(log_scale_factor), nlevels,
+                                       C.c_float(cos_limit), L.vp(out["proj_x"]), L.vp(out["proj_y"]), L.vp(out["proj_xr"]), L.vp(out["level"]),
+                                       L.vp(out["view_cos"]), L.vp(out["in_view"]), device, _stream(stream)), "plf_frustum_points")

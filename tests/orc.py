@@ -229,3 +229,39 @@ def search_lines_by_projection(kl, ldesc, scale, ml, th, nnratio, match_init):
     match = np.ascontiguousarray(match_init, np.int32).copy()
     n = L.orc_search_by_projection_lines(C.byref(F), C.byref(M), C.c_float(th), C.c_float(nnratio), p(match))
     return match, n
+
+
+# ---------------------------------------------------------------- frame tail / frustum wrappers
+def rgb_to_gray(rgb, bgr=True):
+    h, w, _ = rgb.shape
+    rgb = np.ascontiguousarray(rgb); out = np.zeros((h, w), np.uint8)
+    lib().orc_rgb_to_gray(p(rgb), C.c_int(w), C.c_int(h), C.c_ssize_t(3 * w), C.c_int(int(bgr)), p(out), C.c_ssize_t(w))
+    return out
+
+
+def depth_to_float(d16, factor):
+    h, w = d16.shape
+    d16 = np.ascontiguousarray(d16); out = np.zeros((h, w), np.float32)
+    lib().orc_depth_to_float(p(d16), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_float(factor), p(out))
+    return out
+
+
+def frame_tail(kps, depth, cam9, bf):
+    kps = np.ascontiguousarray(kps); un = np.zeros(len(kps), KP_DTYPE)
+    cam = np.ascontiguousarray(cam9, np.float32)
+    lib().orc_undistort_keypoints(p(kps), C.c_int(len(kps)), p(cam), p(un))
+    ur = np.zeros(len(kps), np.float32); kd = np.zeros(len(kps), np.float32)
+    h, w = depth.shape
+    depth = np.ascontiguousarray(depth, np.float32)
+    lib().orc_stereo_from_rgbd(p(kps), p(un), C.c_int(len(kps)), p(depth), C.c_int(w), C.c_int(h), C.c_float(bf), p(ur), p(kd))
+    return un, ur, kd
+
+
+def is_in_frustum(xw, normal, dmin, dmax, Rcw, tcw, Ow, cam4, bounds, bf, logsf, nlevels, coslim):
+    m = len(xw)
+    a = [np.ascontiguousarray(v, np.float32) for v in (xw, normal, dmin, dmax, np.asarray(Rcw).ravel(), tcw, Ow, cam4, bounds)]
+    px = np.zeros(m, np.float32); py = np.zeros(m, np.float32); pxr = np.zeros(m, np.float32); lv = np.zeros(m, np.int32)
+    vc = np.zeros(m, np.float32); iv = np.zeros(m, np.uint8)
+    lib().orc_is_in_frustum(p(a[0]), p(a[1]), p(a[2]), p(a[3]), C.c_int(m), p(a[4]), p(a[5]), p(a[6]), p(a[7]), p(a[8]), C.c_float(bf),
+                            C.c_float(logsf), C.c_int(nlevels), C.c_float(coslim), p(px), p(py), p(pxr), p(lv), p(vc), p(iv))
+    return dict(proj_x=px, proj_y=py, proj_xr=pxr, level=lv, view_cos=vc, in_view=iv)
