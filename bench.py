@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="frames in flight per GPU and step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample (0: skip)")
+    ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -125,6 +126,8 @@ def main():
     # constructor are; the matchers of step k wait for both extractors of step k.
     sA = torch.cuda.Stream(priority=0)
     sBs = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)]
+    if args.serial:
+        sBs = [sA, sA]
     sB = sBs[0]
     stream, stream_b = sA.cuda_stream, sB.cuda_stream
 

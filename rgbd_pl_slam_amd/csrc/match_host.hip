@@ -21,6 +21,7 @@ struct FrameDev {
     int nlevels;
     const int *cell_start;
     const int *cell_idx;
+    const float4 *cell_kp;
 };
 struct MapDev { int m; const float *proj_x, *proj_y, *proj_xr; const int *level; const float *view_cos; const uint8_t *in_view, *desc, *obs_positive; };
 struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; };
@@ -28,7 +29,8 @@ struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const u
 struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
 
 __global__ void k_build_grid(const FrameDev *, int *, int *, int *, int);
-__global__ void k_match_project_points(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, uint32_t *, int *, int, int *);
+__global__ void k_mp_candidates(const FrameDev *, MapDev, float, const int *, int, uint8_t *, uint32_t *, int2 *, int, int *, int *);
+__global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, const uint8_t *, int, const uint32_t *, const int2 *, int, const int *);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
@@ -43,6 +45,7 @@ struct plf_matcher {
     FrameDev *d_frames;
     LineFrameDev *d_lframes;
     int *d_cell_start, *d_cell_idx, *d_cell_of, *d_knn_idx, *d_knn_dist;
+    float4 *d_cell_kp;
     uint8_t *d_done;
     float4 *d_proj;
     plf_dmatch *d_dm;
@@ -56,7 +59,7 @@ struct plf_matcher {
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     free(h->h_frames); free(h->h_lframes);
@@ -91,6 +94,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     ALLOC(h->d_cell_start, B * (GRID_CELLS + 1) * sizeof(int));
     ALLOC(h->d_cell_idx, B * (size_t)max_keypoints * sizeof(int));
     ALLOC(h->d_cell_of, B * (size_t)max_keypoints * sizeof(int));
+    ALLOC(h->d_cell_kp, B * (size_t)max_keypoints * sizeof(float4));
     ALLOC(h->d_done, B * items);
     ALLOC(h->d_proj, (size_t)max_keypoints * sizeof(float4));
     ALLOC(h->d_knn_idx, 2 * (size_t)max_lines * sizeof(int));
@@ -101,14 +105,14 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     const int cand_avg = (avg_env && atoi(avg_env) > 0) ? atoi(avg_env) : 64;
     h->cand_cap = cand_avg * max_mappoints;
     ALLOC(h->d_cand, B * (size_t)h->cand_cap * sizeof(uint32_t));
-    ALLOC(h->d_cand_off, B * ((size_t)max_mappoints + 1) * sizeof(int));
-    ALLOC(h->d_overflow, B * sizeof(int));
+    ALLOC(h->d_cand_off, B * (size_t)max_mappoints * sizeof(int2));   // (start, count) of every map point's span in the pool
+    ALLOC(h->d_overflow, 2 * B * sizeof(int));                         // [0, B) overflow flags, [B, 2B) pool fill
 #undef ALLOC
     h->h_frames = (FrameDev *)calloc(B, sizeof(FrameDev));
     h->h_lframes = (LineFrameDev *)calloc(B, sizeof(LineFrameDev));
     if (!h->h_frames || !h->h_lframes) { matcher_free(h); free(h); return PLF_E_NOMEM; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { matcher_free(h); free(h); return PLF_E_HIP; }
-    (void)hipFuncSetAttribute((const void *)k_match_project_points, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_mp_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_points_slow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -138,6 +142,7 @@ static FrameDev make_frame(const plf_matcher *h, const plf_frame_view &v, int f)
     d.scale_factors = v.scale_factors; d.nlevels = v.nlevels;
     d.cell_start = h->d_cell_start + (size_t)f * (GRID_CELLS + 1);
     d.cell_idx = h->d_cell_idx + (size_t)f * h->max_kp;
+    d.cell_kp = h->d_cell_kp + (size_t)f * h->max_kp;
     return d;
 }
 
@@ -170,8 +175,16 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
     M.in_view = mp->in_view; M.desc = mp->desc; M.obs_positive = mp->obs_positive;
     const int kp_cap = (maxn + 63) & ~63;
     if (maxn > 65535) return PLF_E_BADARG;  // candidate cache packs key point indices in 16 bits
-    hipLaunchKernelGGL(k_match_project_points, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, M, th, nnratio, match_of_kp,
-                       kp_stride, nmatches, h->d_done, kp_cap, h->d_cand, h->d_cand_off, h->cand_cap, h->d_overflow);
+    // fast path needs 16-bit map point indices and its lists in LDS; otherwise every frame takes the fallback kernel
+    const size_t lds_fast = (size_t)kp_cap * 8 + 2 * (size_t)((M.m + 1) & ~1) * sizeof(uint16_t);
+    const bool fast = M.m <= 65535 && lds_fast <= 150 * 1024;
+    PLF_HIP_TRY(hipMemsetAsync(h->d_overflow, fast ? 0 : 1, 2 * (size_t)h->max_batch * sizeof(int), s));
+    if (fast && M.m > 0) {
+        hipLaunchKernelGGL(k_mp_candidates, dim3((M.m + 255) / 256, n_frames), dim3(256), 0, s, h->d_frames, M, th, match_of_kp, kp_stride,
+                           h->d_done, h->d_cand, (int2 *)h->d_cand_off, h->cand_cap, h->d_overflow, h->d_overflow + h->max_batch);
+        hipLaunchKernelGGL(k_mp_rounds, dim3(n_frames), dim3(256), lds_fast, s, h->d_frames, M, nnratio, match_of_kp, kp_stride, nmatches,
+                           h->d_done, kp_cap, h->d_cand, (const int2 *)h->d_cand_off, h->cand_cap, h->d_overflow);
+    }
     hipLaunchKernelGGL(k_match_project_points_slow, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, M, th, nnratio, match_of_kp,
                        kp_stride, nmatches, h->d_done, kp_cap, h->d_overflow);
     PLF_HIP_TRY(hipGetLastError());

@@ -1,6 +1,6 @@
 // match_kernels.hip -- Hamming matchers of the tracking front-end on gfx950.
 //   k_build_grid            Frame::AssignFeaturesToGrid (so@0xf9120): 64x48 cell CSR, insertion order kept
-//   k_match_project_points  ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)   include/ORBmatcher.h:61, so@0x79f10
+//   k_mp_candidates/_rounds ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)   include/ORBmatcher.h:61, so@0x79f10
 //                           with Frame::GetFeaturesInArea (include/Frame.h:113, so@0xfbc60)
 //   k_match_lastframe       ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)  include/ORBmatcher.h:78, so@0x80d00
 //   k_knn2                  cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) (cv::batchDistance tie rules)
@@ -34,6 +34,7 @@ struct FrameDev {
     int nlevels;
     const int *cell_start;  // GRID_CELLS + 1
     const int *cell_idx;    // n
+    const float4 *cell_kp;  // n: (x, y, octave, index) of the key points in cell order (cell_idx order)
 };
 
 __global__ void __launch_bounds__(256) k_build_grid(const FrameDev *__restrict__ frames, int *__restrict__ cell_start_all,
@@ -67,6 +68,8 @@ __global__ void __launch_bounds__(256) k_build_grid(const FrameDev *__restrict__
         int r = 0;
         for (int j = 0; j < i; j++) r += (cell_of[j] == c);
         ci[cnt[c] + r] = i;
+        const plf_keypoint kp = F.keys[i];
+        const_cast<float4 *>(F.cell_kp)[cnt[c] + r] = make_float4(kp.x, kp.y, __int_as_float(kp.octave), __int_as_float(i));
     }
 }
 
@@ -134,7 +137,7 @@ __device__ __forceinline__ bool blocked(const int *claim, int k, const uint8_t *
     return c == -2 || (c >= 0 && (!obs_positive || obs_positive[c]));
 }
 
-// Fallback used only for frames whose candidate lists do not fit the cache of k_match_project_points (gate:
+// Fallback used only for frames whose candidate lists do not fit the cache of k_mp_candidates (gate:
 // overflow[f] != 0): same round scheme with the conservative rule "an item must own ALL its free candidates" and
 // the candidates re-enumerated from the grid in every round.
 // one block per frame; claim[] and owner[] live in LDS (kp_cap ints each)
@@ -212,120 +215,164 @@ __global__ void __launch_bounds__(256) k_match_project_points_slow(const FrameDe
 }
 
 // ------------------------------------------------------------------------------------------------
-// SearchByProjection against the local map, fast path.
-// Phase 0 enumerates every map point's candidates ONCE (GetFeaturesInArea order, level / window / uRight tests,
-// statically occupied key points dropped) and caches (index, Hamming distance, octave) per candidate.
-// The greedy order is then resolved in rounds on the cached lists.  A map point's outcome is a function of its two
-// best still-free candidates only (best = first occurrence of the minimum distance, second = first occurrence of the
-// next value -- exactly what the reference's running best/second-best scan yields), so it can be decided as soon as
-// no UNFINISHED EARLIER map point lists either of those two key points among its own free candidates:
+// SearchByProjection against the local map, fast path: two kernels.
+// k_mp_candidates (one thread per (frame, map point), whole GPU busy) enumerates every map point's candidates ONCE
+// (GetFeaturesInArea order, level / window / uRight tests, statically occupied key points dropped) and caches
+// (index, Hamming distance, octave) per candidate in a span allocated from the frame's candidate pool.
+// k_mp_rounds (one block per frame) then resolves the greedy order in rounds on the cached lists.  A map point's
+// outcome is a function of its two best still-free candidates only (best = first occurrence of the minimum distance,
+// second = first occurrence of the next value -- exactly what the reference's running best/second-best scan yields),
+// so it can be decided as soon as no UNFINISHED EARLIER map point lists either of those two key points among its own
+// free candidates:
 //   post:   every unfinished map point writes its index (atomicMin) on all its free candidates;
 //   decide: a map point whose top-2 candidates both carry its own index is final.
 // Two map points decided in the same round can never take each other's top-2, the lowest unfinished one always
-// qualifies, so the result is the sequential loop's for any schedule.
+// qualifies, so the result is the sequential loop's for any schedule (and for any placement of the spans).
 // cand entry: idx (16 bits) | dist (9 bits) << 16 | octave (4 bits) << 25.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_match_project_points(const FrameDev *__restrict__ frames, MapDev MP, float th, float nnratio,
-                                                              int *__restrict__ match_all, int kp_stride, int *__restrict__ nmatches,
-                                                              uint8_t *__restrict__ done_all, int kp_cap, uint32_t *__restrict__ cand_all,
-                                                              int *__restrict__ off_all, int cand_cap, int *__restrict__ overflow)
+__global__ void __launch_bounds__(256) k_mp_candidates(const FrameDev *__restrict__ frames, MapDev MP, float th,
+                                                       const int *__restrict__ match_all, int kp_stride, uint8_t *__restrict__ done_all,
+                                                       uint32_t *__restrict__ cand_all, int2 *__restrict__ span_all, int cand_cap,
+                                                       int *__restrict__ overflow, int *__restrict__ total)
+{
+    const int f = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+    FrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    const int *claim = match_all + (size_t)f * kp_stride;   // occupancy before this call: never becomes free
+    uint32_t *cand = cand_all + (size_t)f * cand_cap;
+    const bool in = m < MP.m;
+    const bool act = in && MP.in_view[m] != 0;
+    int ub = 0, lvl = 0;
+    float rad = 0.f, x = 0.f, y = 0.f, xr = 0.f;
+    CellWin w;
+    w.ok = false;
+    if (act) {
+        lvl = MP.level[m];
+        float r = radius_by_viewing_cos(MP.view_cos[m]);
+        if (th != 1.0f) r *= th;
+        rad = r * F.scale_factors[lvl];
+        x = MP.proj_x[m]; y = MP.proj_y[m];
+        if (F.uright) xr = MP.proj_xr[m];
+        w = cell_window(F, x, y, rad);
+        // cells (ix, y0..y1) are consecutive in the CSR, so a window column is ONE index range; the pool span is
+        // sized by the number of key points in the window (an upper bound of the candidates)
+        if (w.ok)
+            for (int ix = w.x0; ix <= w.x1; ix++) ub += F.cell_start[ix * GRID_ROWS + w.y1 + 1] - F.cell_start[ix * GRID_ROWS + w.y0];
+    }
+    const int excl = plf_wave_excl_scan(ub), wsum = plf_wave_sum(ub);
+    int base = 0;
+    if (wsum > 0) {
+        if (plf_lane() == 0) base = atomicAdd(&total[f], wsum);
+        base = __shfl(base, 0, 64);
+    }
+    const bool fits = base + wsum <= cand_cap;
+    if (!fits && plf_lane() == 0) overflow[f] = 1;   // this frame is left to k_match_project_points_slow
+    if (!in) return;
+    const int o0 = base + excl;
+    int o = o0;
+    if (ub > 0 && fits) {
+        const uint4 *dp = reinterpret_cast<const uint4 *>(MP.desc + (size_t)m * 32);
+        const uint4 d0 = dp[0], d1 = dp[1];
+        for (int ix = w.x0; ix <= w.x1; ix++) {
+            const int j1 = F.cell_start[ix * GRID_ROWS + w.y1 + 1];
+            for (int j = F.cell_start[ix * GRID_ROWS + w.y0]; j < j1; j++) {
+                const float4 e = F.cell_kp[j];
+                const int oct = __float_as_int(e.z), idx = __float_as_int(e.w);
+                if (oct < lvl - 1 || oct > lvl) continue;
+                if (!(fabsf(e.x - x) < rad && fabsf(e.y - y) < rad)) continue;
+                if (blocked(claim, idx, MP.obs_positive)) continue;
+                if (F.uright) { const float ur = F.uright[idx]; if (ur > 0 && fabsf(xr - ur) > rad) continue; }
+                const uint4 *kp = reinterpret_cast<const uint4 *>(F.desc + (size_t)idx * 32);
+                const uint4 k0 = kp[0], k1 = kp[1];
+                const int dist = __popc(d0.x ^ k0.x) + __popc(d0.y ^ k0.y) + __popc(d0.z ^ k0.z) + __popc(d0.w ^ k0.w) + __popc(d1.x ^ k1.x) +
+                                 __popc(d1.y ^ k1.y) + __popc(d1.z ^ k1.z) + __popc(d1.w ^ k1.w);
+                cand[o++] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 15) << 25);
+            }
+        }
+    }
+    span_all[(size_t)f * MP.m + m] = make_int2(o0, o - o0);
+    done_all[(size_t)f * MP.m + m] = (o > o0) ? 0 : 1;
+}
+
+// LDS: claim[kp_cap], owner[kp_cap] (int), two lists of unfinished map points (uint16, MP.m <= 65535 each)
+__global__ void __launch_bounds__(256) k_mp_rounds(const FrameDev *__restrict__ frames, MapDev MP, float nnratio, int *__restrict__ match_all,
+                                                   int kp_stride, int *__restrict__ nmatches, const uint8_t *__restrict__ done_all, int kp_cap,
+                                                   const uint32_t *__restrict__ cand_all, const int2 *__restrict__ span_all, int cand_cap,
+                                                   const int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *claim = (int *)smem, *owner = claim + kp_cap;
-    __shared__ int s_left, s_acc;
-    __shared__ int scan_tmp[260];
-    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    uint16_t *la = (uint16_t *)(owner + kp_cap), *lb = la + ((MP.m + 1) & ~1);
+    __shared__ int s_n[2], s_acc;
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x, lane = plf_lane();
+    if (overflow[f]) return;
     FrameDev F = frames[f];
     if (F.n_dev) F.n = min(F.n, *F.n_dev);
     int *match = match_all + (size_t)f * kp_stride;
-    uint8_t *done = done_all + (size_t)f * MP.m;
-    uint32_t *cand = cand_all + (size_t)f * cand_cap;
-    int *off = off_all + (size_t)f * (MP.m + 1);
-    const bool bFactor = th != 1.0f;
+    const uint8_t *done = done_all + (size_t)f * MP.m;
+    const uint32_t *cand = cand_all + (size_t)f * cand_cap;
+    const int2 *span = span_all + (size_t)f * MP.m;
     for (int k = t; k < F.n; k += T) claim[k] = match[k];
-    if (t == 0) { s_acc = 0; overflow[f] = 0; }
+    if (t == 0) { s_acc = 0; s_n[0] = 0; s_n[1] = 0; }
     __syncthreads();
-    // ---- phase 0a: count
-    for (int m = t; m < MP.m; m += T) {
-        int cnt = 0;
-        const bool act = MP.in_view[m] != 0;
-        if (act) {
-            const int lvl = MP.level[m];
-            float r = radius_by_viewing_cos(MP.view_cos[m]);
-            if (bFactor) r *= th;
-            const float rad = r * F.scale_factors[lvl];
-            const float x = MP.proj_x[m], y = MP.proj_y[m];
-            const CellWin w = cell_window(F, x, y, rad);
-            if (w.ok) FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, {
-                if (blocked(claim, idx, MP.obs_positive)) continue;   // occupied before this call: never becomes free
-                if (F.uright) { const float ur = F.uright[idx]; if (ur > 0 && fabsf(MP.proj_xr[m] - ur) > rad) continue; }
-                cnt++;
-            })
-        }
-        off[m] = cnt;
-        done[m] = (act && cnt > 0) ? 0 : 1;
-    }
-    if (t == 0) off[MP.m] = 0;
-    __syncthreads();
-    const int total = plf_block_excl_scan(off, MP.m + 1, scan_tmp);
-    if (total > cand_cap) {  // does not fit: leave this frame to k_match_project_points_slow
-        if (t == 0) overflow[f] = 1;
-        return;
-    }
-    // ---- phase 0b: fill (index, distance, octave)
-    for (int m = t; m < MP.m; m += T) {
-        if (done[m]) continue;
-        const int lvl = MP.level[m];
-        float r = radius_by_viewing_cos(MP.view_cos[m]);
-        if (bFactor) r *= th;
-        const float rad = r * F.scale_factors[lvl];
-        const float x = MP.proj_x[m], y = MP.proj_y[m];
-        const CellWin w = cell_window(F, x, y, rad);
-        const uint8_t *d = MP.desc + (size_t)m * 32;
-        int o = off[m];
-        FOR_EACH_CANDIDATE(F, w, x, y, rad, lvl - 1, lvl, idx, {
-            if (blocked(claim, idx, MP.obs_positive)) continue;
-            if (F.uright) { const float ur = F.uright[idx]; if (ur > 0 && fabsf(MP.proj_xr[m] - ur) > rad) continue; }
-            const int dist = hamming_g(d, F.desc + (size_t)idx * 32);
-            cand[o++] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(_kp.octave & 15) << 25);
-        })
+    for (int m0 = 0; m0 < MP.m; m0 += T) {
+        const int m = m0 + t;
+        const bool un = m < MP.m && !done[m];
+        const unsigned long long mask = __ballot(un);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&s_n[0], __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (un) la[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)m;
     }
     __syncthreads();
-    // ---- rounds
+    int cur = 0;
     for (int round = 0; round <= MP.m; round++) {
+        const int nact = s_n[cur];
+        if (nact == 0) break;
         for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
-        if (t == 0) s_left = 0;
         __syncthreads();
-        for (int m = t; m < MP.m; m += T) {
-            if (done[m]) continue;
-            for (int j = off[m]; j < off[m + 1]; j++) {
+        for (int i = t; i < nact; i += T) {
+            const int m = la[i];
+            const int2 sp = span[m];
+            for (int j = sp.x; j < sp.x + sp.y; j++) {
                 const int idx = (int)(cand[j] & 0xFFFF);
                 if (!blocked(claim, idx, MP.obs_positive)) atomicMin(&owner[idx], m);
             }
         }
         __syncthreads();
-        for (int m = t; m < MP.m; m += T) {
-            if (done[m]) continue;
-            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, idx2 = -1;
-            for (int j = off[m]; j < off[m + 1]; j++) {
-                const uint32_t e = cand[j];
-                const int idx = (int)(e & 0xFFFF);
-                if (blocked(claim, idx, MP.obs_positive)) continue;
-                const int dist = (int)((e >> 16) & 0x1FF), oct = (int)(e >> 25);
-                if (dist < bestDist) { bestDist2 = bestDist; bestLevel2 = bestLevel; idx2 = bestIdx; bestDist = dist; bestLevel = oct; bestIdx = idx; }
-                else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; idx2 = idx; }
+        for (int i0 = 0; i0 < nact; i0 += T) {
+            const int i = i0 + t;
+            bool keep = false;
+            int m = 0;
+            if (i < nact) {
+                m = la[i];
+                const int2 sp = span[m];
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, idx2 = -1;
+                for (int j = sp.x; j < sp.x + sp.y; j++) {
+                    const uint32_t e = cand[j];
+                    const int idx = (int)(e & 0xFFFF);
+                    if (blocked(claim, idx, MP.obs_positive)) continue;
+                    const int dist = (int)((e >> 16) & 0x1FF), oct = (int)(e >> 25);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestLevel2 = bestLevel; idx2 = bestIdx; bestDist = dist; bestLevel = oct; bestIdx = idx; }
+                    else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; idx2 = idx; }
+                }
+                const bool safe = (bestIdx < 0 || owner[bestIdx] == m) && (idx2 < 0 || owner[idx2] == m);
+                keep = !safe;
+                if (safe && bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) {
+                    claim[bestIdx] = m;   // only this map point can touch bestIdx in this round
+                    atomicAdd(&s_acc, 1);
+                }
             }
-            const bool safe = (bestIdx < 0 || owner[bestIdx] == m) && (idx2 < 0 || owner[idx2] == m);
-            if (!safe) { atomicAdd(&s_left, 1); continue; }
-            done[m] = 1;
-            if (bestDist <= TH_HIGH) {
-                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
-                claim[bestIdx] = m;
-                atomicAdd(&s_acc, 1);
-            }
+            const unsigned long long mask = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&s_n[cur ^ 1], __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (keep) lb[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)m;
         }
         __syncthreads();
-        if (s_left == 0) break;
+        if (t == 0) s_n[cur] = 0;
+        uint16_t *tmp = la; la = lb; lb = tmp;
+        cur ^= 1;
         __syncthreads();
     }
     for (int k = t; k < F.n; k += T) match[k] = claim[k];
