@@ -273,7 +273,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         const int in = stage & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage,
                            (stage >= 1 && stage <= 3) ? 5 : 1, h->d_cnt, g);
-        hipLaunchKernelGGL(k_nfa_eval, dim3(4 * math_blocks), dim3(64), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
+        hipLaunchKernelGGL(k_nfa_eval, dim3(2 * math_blocks), dim3(256), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
                            h->d_vals, g);
         hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],
                            h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);

@@ -631,32 +631,40 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
     const int lane = plf_lane() & 15;
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
-    EdgePt o[4];
-    o[0].x = (int)(rec.x1 - dyhw); o[0].y = (int)(rec.y1 + dxhw); o[0].taken = 0;
-    o[1].x = (int)(rec.x2 - dyhw); o[1].y = (int)(rec.y2 + dxhw); o[1].taken = 0;
-    o[2].x = (int)(rec.x2 + dyhw); o[2].y = (int)(rec.y2 - dxhw); o[2].taken = 0;
-    o[3].x = (int)(rec.x1 + dyhw); o[3].y = (int)(rec.y1 - dxhw); o[3].taken = 0;
-    for (int i = 1; i < 4; i++) {  // std::sort on 4 elements = insertion sort, AsmallerB_XoverY
-        const EdgePt t = o[i];
-        int j = i - 1;
-        while (j >= 0 && (o[j].x > t.x || (o[j].x == t.x && o[j].y > t.y))) { o[j + 1] = o[j]; j--; }
-        o[j + 1] = t;
+    // the four corners, kept in registers (no indexed array: that would live in scratch memory)
+    int px0 = (int)(rec.x1 - dyhw), py0 = (int)(rec.y1 + dxhw);
+    int px1 = (int)(rec.x2 - dyhw), py1 = (int)(rec.y2 + dxhw);
+    int px2 = (int)(rec.x2 + dyhw), py2 = (int)(rec.y2 - dxhw);
+    int px3 = (int)(rec.x1 + dyhw), py3 = (int)(rec.y1 - dxhw);
+    // std::sort with AsmallerB_XoverY is a total order on (x, y): a sorting network yields the same sequence
+#define PLF_CSWAP(xa, ya, xb, yb) { const bool sw = (xa > xb) || (xa == xb && ya > yb); const int tx = sw ? xb : xa, ty = sw ? yb : ya; \
+                                    xb = sw ? xa : xb; yb = sw ? ya : yb; xa = tx; ya = ty; }
+    PLF_CSWAP(px0, py0, px1, py1) PLF_CSWAP(px2, py2, px3, py3) PLF_CSWAP(px0, py0, px2, py2) PLF_CSWAP(px1, py1, px3, py3) PLF_CSWAP(px1, py1, px2, py2)
+#undef PLF_CSWAP
+#define PLF_SELX(i) ((i) == 0 ? px0 : (i) == 1 ? px1 : (i) == 2 ? px2 : px3)
+#define PLF_SELY(i) ((i) == 0 ? py0 : (i) == 1 ? py1 : (i) == 2 ? py2 : py3)
+    int imin = 0, imax = 0;   // first minimum / first maximum of y in sorted order (strict comparisons)
+    {
+        int ymin = py0, ymax = py0;
+        if (ymin > py1) { imin = 1; ymin = py1; }
+        if (ymin > py2) { imin = 2; ymin = py2; }
+        if (ymin > py3) { imin = 3; ymin = py3; }
+        if (ymax < py1) { imax = 1; ymax = py1; }
+        if (ymax < py2) { imax = 2; ymax = py2; }
+        if (ymax < py3) { imax = 3; ymax = py3; }
     }
-    int imin = 0, imax = 0;
-    for (int i = 1; i < 4; ++i) {
-        if (o[imin].y > o[i].y) imin = i;
-        if (o[imax].y < o[i].y) imax = i;
-    }
-    o[imin].taken = 1;
-    int il = -1;
-    for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (il < 0) il = i; else if (o[il].x > o[i].x) il = i; }
-    o[il].taken = 1;
-    int ir = -1;
-    for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (ir < 0) ir = i; else if (o[ir].x < o[i].x) ir = i; }
-    o[ir].taken = 1;
-    int it = -1;
-    for (int i = 0; i < 4; ++i) if (!o[i].taken) { if (it < 0) it = i; else if (o[it].x > o[i].x) it = i; }
-    const EdgePt mn = o[imin], mx = o[imax], lf = o[il], rt = o[ir], tl = o[it];
+    // only `min` is marked taken before the next picks (upstream); the list is sorted by x, so the leftmost of the
+    // rest is the lowest free index, the rightmost is the later of the remaining two unless their x are equal
+    const int il = (imin == 0) ? 1 : 0;
+    int ra = -1, rb = -1;
+    for (int i = 0; i < 4; ++i) if (i != imin && i != il) { if (ra < 0) ra = i; else rb = i; }
+    const int ir = (PLF_SELX(ra) < PLF_SELX(rb)) ? rb : ra;
+    const int it = (ir == ra) ? rb : ra;
+    EdgePt mn, mx, lf, rt, tl;
+    mn.x = PLF_SELX(imin); mn.y = PLF_SELY(imin); mx.x = PLF_SELX(imax); mx.y = PLF_SELY(imax);
+    lf.x = PLF_SELX(il); lf.y = PLF_SELY(il); rt.x = PLF_SELX(ir); rt.y = PLF_SELY(ir); tl.x = PLF_SELX(it); tl.y = PLF_SELY(it);
+#undef PLF_SELX
+#undef PLF_SELY
     // upstream: integer divisions, and `tailp->p.x` where p.y was meant
     const long long flstep = (mn.y != lf.y) ? (mn.x - lf.x) / (mn.y - lf.y) : 0;
     const long long slstep = (lf.y != tl.x) ? (lf.x - tl.x) / (lf.y - tl.x) : 0;
@@ -673,13 +681,17 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
         for (int k = 1; k < 6; k++) { pp /= 2; precs[k] = pp * PI_D; }
     }
     int total = 0, alg[6] = {0, 0, 0, 0, 0, 0};
-    for (int y = y_lo + lane; y <= y_hi; y += 16) {
+    // 16 lanes = ry_n rows x rx_n interleaved columns: rectangles along the x axis have few, long rows
+    int ry_n = 16;
+    while (ry_n > 1 && ry_n > y_hi - y_lo + 1) ry_n >>= 1;
+    const int rx_n = 16 / ry_n, ry = lane & (ry_n - 1), rx = lane / ry_n;
+    for (int y = y_lo + ry; y <= y_hi; y += ry_n) {
         const long long al = max(0, min(y, lf.y) - y_lo), bl = (long long)(y - y_lo) - al;
         const long long ar = max(0, min(y, rt.y) - y_lo), br = (long long)(y - y_lo) - ar;
         const long long left = (long long)mn.x + flstep * al + slstep * bl, right = (long long)mn.x + frstep * ar + srstep * br;
         const int xl = (int)max(left, 0ll), xr = (int)min(right, (long long)(W - 1));
         const float *row = ang + (size_t)y * W;
-        for (int x = xl; x <= xr; ++x) {
+        for (int x = xl + rx; x <= xr; x += rx_n) {
             ++total;
             const float deg = row[x];
             if (deg == NOTDEF_F) continue;
@@ -755,31 +767,77 @@ __device__ __forceinline__ void nfa_finish(const NfaState &st, float4 *__restric
 // NFA value of every counted candidate, one lane per (rectangle, candidate): the fp64-transcendental part is
 // spread over as many lanes as there are candidates so that no lane evaluates more than one binomial tail.
 // stage 0 / 4: item = rectangle * 6 + k (k-th precision of the same geometry); stages 1..3: item = entry index.
-__global__ void __launch_bounds__(64) k_nfa_eval(int stage, const double *__restrict__ lgam, const NfaCounts *__restrict__ counts,
-                                                 const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
-                                                 double *__restrict__ vals, LsdGeom g)
+// The length of the binomial-tail loop varies from 1 to thousands of iterations between items (it runs from k + 1
+// to about n / 2), so a block first orders its chunk of items by the predicted loop length (LDS counting sort on
+// half-octave buckets): the 64 lanes of a wave then run loops of similar length instead of idling behind the
+// longest one.  The order only decides which lane evaluates which item.
+#define EV_T 256
+#define EV_PER 8
+#define EV_CHUNK (EV_T * EV_PER)
+__device__ __forceinline__ bool nfa_item(int stage, bool multi, int it, const NfaEntry *__restrict__ entries, const NfaCounts *__restrict__ counts,
+                                         int &n, int &k, double &p)
 {
+    if (multi) {
+        const int e = it / 6, q = it - e * 6;
+        if (entries[e].nprec != 6 || (stage == 4 && q == 0)) return false;
+        double pp = entries[e].r.p;
+        for (int j = 0; j < q; j++) pp /= 2;
+        n = counts[e].total; k = counts[e].alg[q]; p = pp;   // (indexed straight from memory: no by-value struct in scratch)
+        return true;
+    }
+    if (entries[it].nprec == 0) return false;
+    n = counts[it].total; k = counts[it].alg[0]; p = entries[it].r.p;
+    return true;
+}
+
+__global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__restrict__ lgam, const NfaCounts *__restrict__ counts,
+                                                   const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
+                                                   double *__restrict__ vals, LsdGeom g)
+{
+    __shared__ uint16_t order[EV_CHUNK];
+    __shared__ int hist[32];
     const bool multi = (stage == 0 || stage == 4);
-    const int n = counters[stage] * (multi ? 6 : 5);
-    for (int it = blockIdx.x * 64 + threadIdx.x; it < n; it += gridDim.x * 64) {
-        double v = -1.0e300;
-        if (multi) {
-            const int e = it / 6, k = it - e * 6;
-            const NfaEntry en = entries[e];
-            if (en.nprec == 6 && !(stage == 4 && k == 0)) {
-                const NfaCounts c = counts[e];
-                double pp = en.r.p;
-                for (int q = 0; q < k; q++) pp /= 2;
-                v = nfa_d(lgam, g.log_nt, c.total, c.alg[k], pp);
-            }
-        } else {
-            const NfaEntry en = entries[it];
-            if (en.nprec != 0) {
-                const NfaCounts c = counts[it];
-                v = nfa_d(lgam, g.log_nt, c.total, c.alg[0], en.r.p);
+    const int total = counters[stage] * (multi ? 6 : 5), t = threadIdx.x;
+    for (int c0 = blockIdx.x * EV_CHUNK; c0 < total; c0 += gridDim.x * EV_CHUNK) {
+        if (t < 32) hist[t] = 0;
+        __syncthreads();
+        int bkt[EV_PER], rnk[EV_PER];
+#pragma unroll
+        for (int q = 0; q < EV_PER; q++) {
+            const int it = c0 + q * EV_T + t;
+            bkt[q] = -1; rnk[q] = 0;
+            if (it < total) {
+                int n = 0, k = 0;
+                double p;
+                int b = 0;
+                if (nfa_item(stage, multi, it, entries, counts, n, k, p) && n != 0 && k != 0 && n != k) {
+                    const int L = max(1, (n + 1) / 2 - k);
+                    const int lz = 31 - __clz(L);
+                    b = min(31, 1 + 2 * lz + (lz > 0 ? ((L >> (lz - 1)) & 1) : 0));
+                }
+                bkt[q] = b;
+                rnk[q] = atomicAdd(&hist[b], 1);
             }
         }
-        vals[it] = v;
+        __syncthreads();
+        if (t == 0) {   // longest loops first
+            int run = 0;
+            for (int b = 31; b >= 0; b--) { const int v = hist[b]; hist[b] = run; run += v; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EV_PER; q++)
+            if (bkt[q] >= 0) order[hist[bkt[q]] + rnk[q]] = (uint16_t)(q * EV_T + t);
+        __syncthreads();
+        const int cnt = min(EV_CHUNK, total - c0);
+        for (int i = t; i < cnt; i += EV_T) {
+            const int it = c0 + order[i];
+            int n = 0, k = 0;
+            double p = 0.0, v = -1.0e300;
+            if (nfa_item(stage, multi, it, entries, counts, n, k, p)) v = nfa_d(lgam, g.log_nt, n, k, p);
+            vals[it] = v;
+        }
+        __syncthreads();
     }
 }
 
