@@ -25,8 +25,6 @@ struct OrbLevel {
     uint32_t sel_off;    // selected keypoints: first entry inside one frame's sel block
     uint32_t sel_cap;    // quota + 8
     uint32_t tabx_off, taby_off;  // resize coefficient tables (levels >= 1)
-    int tile_base;       // first 64x16 score/blur tile of this level in the flattened tile list
-    int tiles_x, tiles_y;
 };
 
 struct OrbGeom {
@@ -34,7 +32,6 @@ struct OrbGeom {
     int iniTh, minTh;
     int in_w, in_h;
     int cells_total;
-    int tiles_total;
     int maxsel;            // max over levels of sel_cap
     uint32_t pyr_stride;   // bytes per frame
     uint32_t blur_stride;  // bytes per frame

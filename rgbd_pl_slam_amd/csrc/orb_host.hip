@@ -12,9 +12,8 @@
 void plf_orb_upload_constants(const int *umax16);
 __global__ void k_pyr_level0(const uint8_t *, ptrdiff_t, ptrdiff_t, uint8_t *, OrbGeom);
 __global__ void k_pyr_resize(uint8_t *, OrbGeom, int, const int *, const short2 *, const int *, const short2 *);
-__global__ void k_fast_score(const uint8_t *, uint8_t *, OrbGeom);
 __global__ void k_fast_cells(const uint8_t *, const int4 *, int2 *, uint2 *, int *, int *, OrbGeom);
-__global__ void k_blur7(const uint8_t *, uint8_t *, OrbGeom, int4);
+__global__ void k_score_blur(const uint8_t *, uint8_t *, uint8_t *, OrbGeom, int4);
 __global__ void k_octree(const int2 *, const uint2 *, int *, uint2 *, int *, uint8_t *, uint2 *, int *, int *, int *, OrbGeom, int, int);
 __global__ void k_orient_brief(const uint8_t *, const uint8_t *, const uint2 *, const int *, plf_keypoint *, uint8_t *, int *, int,
                                int *, OrbGeom);
@@ -100,7 +99,7 @@ static int orb_geometry(plf_orb *h, int w, int h_, OrbGeom *g, std::vector<int4>
     g->in_w = w; g->in_h = h_;
     size_t pyr = 0, blur = 0;
     uint32_t pool = 0, sel = 0, tabx = 0, taby = 0;
-    int cellbase = 0, tilebase = 0, maxsel = 0;
+    int cellbase = 0, maxsel = 0;
     for (int l = 0; l < g->nlevels; l++) {
         OrbLevel &L = g->lv[l];
         L.w = cv_round_f((float)w * h->inv[l]);  // so@0x7051e: float multiply, cvtss2si
@@ -154,11 +153,8 @@ static int orb_geometry(plf_orb *h, int w, int h_, OrbGeom *g, std::vector<int4>
         if ((int)L.sel_cap > maxsel) maxsel = (int)L.sel_cap;
         L.tabx_off = tabx; L.taby_off = taby;
         tabx += (uint32_t)L.w; taby += (uint32_t)L.h;
-        L.tiles_x = (L.w + 63) / 64; L.tiles_y = (L.h + 15) / 16;
-        L.tile_base = tilebase;
-        tilebase += L.tiles_x * L.tiles_y;
     }
-    g->cells_total = cellbase; g->tiles_total = tilebase; g->maxsel = maxsel;
+    g->cells_total = cellbase; g->maxsel = maxsel;
     g->pyr_stride = (uint32_t)pyr; g->blur_stride = (uint32_t)blur; g->pool_stride = pool; g->sel_stride = sel;
     return PLF_OK;
 }
@@ -356,8 +352,11 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
         dim3 grid((L.ppitch + 255) / 256, L.h + 2 * PLF_EDGE, B);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, h->d_pyr, g, l, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     }
-    hipLaunchKernelGGL(k_fast_score, dim3(g.tiles_total, B), dim3(256), 0, s, h->d_pyr, h->d_score, g);
-    hipLaunchKernelGGL(k_blur7, dim3(g.tiles_total, B), dim3(256), 0, s, h->d_pyr, h->d_blur, g, h->taps);
+    {
+        int sb_tiles = 0;   // waves of k_score_blur: 64 strips of 4 x 16 (SB_RS) pixels each, per level
+        for (int l = 0; l < nl; l++) sb_tiles += (((g.lv[l].w + 3) / 4) * ((g.lv[l].h + 15) / 16) + 63) / 64;
+        hipLaunchKernelGGL(k_score_blur, dim3(sb_tiles, B), dim3(64), 0, s, h->d_pyr, h->d_score, h->d_blur, g, h->taps);
+    }
     hipLaunchKernelGGL(k_fast_cells, dim3(g.cells_total, B), dim3(64), 0, s, h->d_score, h->d_cells, h->d_cellinfo, h->d_pool, poolcnt,
                        status, g);
     hipLaunchKernelGGL(k_octree, dim3(nl, B), dim3(256), h->octree_lds, s, h->d_cellinfo, h->d_pool, h->d_celloff, h->d_keys,

@@ -2,10 +2,10 @@
 //
 // Pipeline per batch of B frames (every launch covers all frames; most cover all levels):
 //   k_pyr_level0 / k_pyr_resize   ORBextractor::ComputePyramid           (include/ORBextractor.h:89, so@0x70430)
-//   k_fast_score                  per-pixel FAST-9/16 corner score        (cv::FAST inside so@0x75fa0)
+//   k_score_blur                  per-pixel FAST-9/16 corner score        (cv::FAST inside so@0x75fa0) fused with
+//                                 GaussianBlur 7x7 sigma 2, 8-bit fixed    (operator(), so@0x77487)
 //   k_fast_cells                  per-cell threshold/retry + 3x3 NMS      (ComputeKeyPointsOctTree cell loop)
 //   k_octree                      DistributeOctTree / DivideNode          (orb_octree.hip)
-//   k_blur7                       GaussianBlur 7x7 sigma 2, 8-bit fixed    (operator(), so@0x77487)
 //   k_orient_brief                IC_Angle + steered BRIEF + final layout (so@0x6fb10, so@0x777b5)
 //
 // Design notes (MI355X): the work is byte/integer stencil, gather and compaction -- HBM/L2 bound,
@@ -68,35 +68,25 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t *__restrict__ pyr, O
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 corner score map.  score(p) = cornerScore<16>(p) = (max over the 16 arcs of 9 contiguous
-// ring pixels of the minimum |I_p - I_x| with a common sign) - 1, clamped at 0.  A pixel is a corner
-// at threshold t iff score >= t, and cv::FAST stores exactly this score, so the per-cell
-// threshold/retry logic and the NMS can run afterwards on the map (k_fast_cells).
-// Tile: 64 x 16 pixels per 256-thread block, staged through LDS with a 3-pixel halo.
+// Fused FAST score + GaussianBlur 7x7 (the two full-resolution passes over every pyramid level).
+// FAST-9/16 score(p) = cornerScore<16>(p) = (max over the 16 arcs of 9 contiguous ring pixels of the minimum
+// |I_p - I_x| with a common sign) - 1, clamped at 0.  A pixel is a corner at threshold t iff score >= t, and
+// cv::FAST stores exactly this score, so the per-cell threshold/retry logic and the NMS can run afterwards on the
+// map (k_fast_cells).
+// GaussianBlur(7x7, sigma 2) on 8U: OpenCV 3.3 separable fixed-point path, taps round(k*256) per axis (sum 257, not
+// renormalised), exact int32 sums, rounded once like the SSE2 column filter (sum/65536 to nearest-even) for
+// x < (w & ~3) and (sum + 32768) >> 16 for the last w % 4 columns.  The padded pyramid plane already holds the
+// REFLECT_101 border the blur needs.
+// A lane owns a strip of 4 pixels x SB_RS rows and walks it top to bottom with a
+// 7-row sliding window held in registers: per input row 3 dword loads (12 bytes = the 4 pixels and their 3-pixel
+// halo), no LDS, no barrier.  From the window it produces, for the centre row, the 4 blur bytes (exact integer
+// sum of taps, both passes) and the 4 FAST scores.
 // ------------------------------------------------------------------------------------------------
-#define TILE_W 64
-#define TILE_H 16
-#define LT_PITCH 72
+#define SB_RS 16
+typedef uint32_t __attribute__((aligned(1))) plf_u32u;
 
-__device__ __forceinline__ int find_level_by_tile(const OrbGeom &g, int tile)
+__device__ __forceinline__ int fast_score_ring(const int d[16], int t)
 {
-    int l = 0;
-    for (int i = 1; i < g.nlevels; i++)
-        if (tile >= g.lv[i].tile_base) l = i;
-    return l;
-}
-
-__device__ __forceinline__ int fast_score16(const uint8_t *c, int minTh)
-{
-    // ring offsets (x,y): same circle as cv::FAST; only contiguity matters
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * LT_PITCH + 0];  d[1] = v - c[3 * LT_PITCH + 1];  d[2] = v - c[2 * LT_PITCH + 2];  d[3] = v - c[1 * LT_PITCH + 3];
-    d[4] = v - c[3];                 d[5] = v - c[-1 * LT_PITCH + 3]; d[6] = v - c[-2 * LT_PITCH + 2]; d[7] = v - c[-3 * LT_PITCH + 1];
-    d[8] = v - c[-3 * LT_PITCH];     d[9] = v - c[-3 * LT_PITCH - 1]; d[10] = v - c[-2 * LT_PITCH - 2]; d[11] = v - c[-1 * LT_PITCH - 3];
-    d[12] = v - c[-3];               d[13] = v - c[1 * LT_PITCH - 3]; d[14] = v - c[2 * LT_PITCH - 2]; d[15] = v - c[3 * LT_PITCH - 1];
-    // cheap necessary condition at the lowest threshold: every 9-arc contains one pixel of each opposite pair
-    const int t = minTh;
     bool br = true, dk = true;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -120,35 +110,92 @@ __device__ __forceinline__ int fast_score16(const uint8_t *c, int minTh)
     return s < 0 ? 0 : s;
 }
 
-__global__ void __launch_bounds__(256) k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score, OrbGeom g)
+// byte i (0..11) of the 12-byte row segment held in three dwords
+#define SB_BYTE(R, i) ((int)(((R)[(i) >> 2] >> (8 * ((i) & 3))) & 0xFFu))
+
+__global__ void __launch_bounds__(64) k_score_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score, uint8_t *__restrict__ blur,
+                                                   OrbGeom g, int4 taps)
 {
-    __shared__ uint8_t tile[(TILE_H + 6) * LT_PITCH];
-    const int f = blockIdx.y;
-    const int l = find_level_by_tile(g, blockIdx.x);
-    const OrbLevel &L = g.lv[l];
-    const int tl = blockIdx.x - L.tile_base;
-    const int tx = tl % L.tiles_x, ty = tl / L.tiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-    const uint8_t *img = pyr + (size_t)f * g.pyr_stride + L.plane_off + (size_t)PLF_EDGE * L.ppitch + PLF_EDGE;
-    for (int i = threadIdx.x; i < (TILE_H + 6) * (TILE_W + 6); i += 256) {
-        const int r = i / (TILE_W + 6), c = i - r * (TILE_W + 6);
-        int gx = x0 - 3 + c, gy = y0 - 3 + r;
-        gx = min(gx, L.w + PLF_EDGE - 1);  // stays inside the padded plane
-        gy = min(gy, L.h + PLF_EDGE - 1);
-        tile[r * LT_PITCH + c] = img[(ptrdiff_t)gy * L.ppitch + gx];
+    // strips (4 px x SB_RS rows) of all levels are numbered linearly, level-major, row-major inside a level; a wave
+    // takes 64 consecutive strips of one level, so only the last wave of a level has idle lanes
+    const int f = blockIdx.y, lane = threadIdx.x;
+    int l = 0, base = 0, sx_n = 1, ns = 0;
+    for (int i = 0; i < g.nlevels; i++) {
+        sx_n = (g.lv[i].w + 3) >> 2;
+        ns = sx_n * ((g.lv[i].h + SB_RS - 1) / SB_RS);
+        const int nw = (ns + 63) >> 6;
+        l = i;
+        if ((int)blockIdx.x < base + nw) break;
+        base += nw;
     }
-    __syncthreads();
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const OrbLevel &L = g.lv[l];
+    const int sid = ((int)blockIdx.x - base) * 64 + lane;
+    if (sid >= ns) return;
+    const int x = (sid % sx_n) * 4, y0 = (sid / sx_n) * SB_RS;
+    if (x >= L.w) return;
+    const uint8_t *colp = pyr + (size_t)f * g.pyr_stride + L.plane_off + (size_t)PLF_EDGE * L.ppitch + PLF_EDGE + (x - 4);
+    uint8_t *bp = blur + (size_t)f * g.blur_stride + L.blur_off;
     uint8_t *sp = score + (size_t)f * g.blur_stride + L.blur_off;
+    const int k0 = taps.x, k1 = taps.y, k2 = taps.z, k3 = taps.w;
+    const bool even_round = x < (L.w & ~3), full = x + 3 < L.w;
+    uint32_t raw[7][3];
+    int hs[7][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int r = ry + 4 * k;
-        const int gx = x0 + cx, gy = y0 + r;
-        // the FAST cells only ever look at x in [19, w-19), y in [19, h-19)
-        if (gx >= PLF_EDGE && gy >= PLF_EDGE && gx < L.w - PLF_EDGE && gy < L.h - PLF_EDGE) {
-            const int s = fast_score16(&tile[(r + 3) * LT_PITCH + cx + 3], g.minTh);
-            sp[(size_t)gy * L.bpitch + gx] = (uint8_t)s;
+    for (int i = 0; i < 7; i++) {
+        raw[i][0] = raw[i][1] = raw[i][2] = 0u;
+        hs[i][0] = hs[i][1] = hs[i][2] = hs[i][3] = 0;
+    }
+    for (int r = 0; r < SB_RS + 6; r++) {
+        const int gy = min(y0 - 3 + r, L.h + PLF_EDGE - 1);   // stays inside the padded plane
+        const uint8_t *rp = colp + (ptrdiff_t)gy * L.ppitch;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            raw[i][0] = raw[i + 1][0]; raw[i][1] = raw[i + 1][1]; raw[i][2] = raw[i + 1][2];
+            hs[i][0] = hs[i + 1][0]; hs[i][1] = hs[i + 1][1]; hs[i][2] = hs[i + 1][2]; hs[i][3] = hs[i + 1][3];
         }
+        raw[6][0] = *(const plf_u32u *)rp; raw[6][1] = *(const plf_u32u *)(rp + 4); raw[6][2] = *(const plf_u32u *)(rp + 8);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            hs[6][j] = k0 * (SB_BYTE(raw[6], j + 1) + SB_BYTE(raw[6], j + 7)) + k1 * (SB_BYTE(raw[6], j + 2) + SB_BYTE(raw[6], j + 6)) +
+                       k2 * (SB_BYTE(raw[6], j + 3) + SB_BYTE(raw[6], j + 5)) + k3 * SB_BYTE(raw[6], j + 4);
+        const int oy = y0 + r - 6;
+        if (r < 6 || oy >= L.h) continue;
+        // ---- blur of row oy
+        uint32_t bw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sm = k0 * (hs[0][j] + hs[6][j]) + k1 * (hs[1][j] + hs[5][j]) + k2 * (hs[2][j] + hs[4][j]) + k3 * hs[3][j];
+            int v;
+            if (even_round) {
+                v = sm >> 16;
+                const int rem = sm & 0xFFFF;
+                if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
+            } else {
+                v = (sm + 32768) >> 16;
+            }
+            bw |= (uint32_t)min(v, 255) << (8 * j);
+        }
+        uint8_t *bo = bp + (size_t)oy * L.bpitch + x;
+        if (full) *(uint32_t *)bo = bw;
+        else for (int j = 0; j < 4 && x + j < L.w; j++) bo[j] = (uint8_t)(bw >> (8 * j));
+        // ---- FAST score of row oy (the cells only ever look at x in [19, w-19), y in [19, h-19))
+        if (oy < PLF_EDGE || oy >= L.h - PLF_EDGE || x + 3 < PLF_EDGE || x >= L.w - PLF_EDGE) continue;
+        uint32_t sw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gx = x + j;
+            if (gx < PLF_EDGE || gx >= L.w - PLF_EDGE) continue;
+            const int c = 4 + j, v = SB_BYTE(raw[3], c);
+            int d[16];
+            d[0] = v - SB_BYTE(raw[6], c);      d[1] = v - SB_BYTE(raw[6], c + 1);  d[2] = v - SB_BYTE(raw[5], c + 2);  d[3] = v - SB_BYTE(raw[4], c + 3);
+            d[4] = v - SB_BYTE(raw[3], c + 3);  d[5] = v - SB_BYTE(raw[2], c + 3);  d[6] = v - SB_BYTE(raw[1], c + 2);  d[7] = v - SB_BYTE(raw[0], c + 1);
+            d[8] = v - SB_BYTE(raw[0], c);      d[9] = v - SB_BYTE(raw[0], c - 1);  d[10] = v - SB_BYTE(raw[1], c - 2); d[11] = v - SB_BYTE(raw[2], c - 3);
+            d[12] = v - SB_BYTE(raw[3], c - 3); d[13] = v - SB_BYTE(raw[4], c - 3); d[14] = v - SB_BYTE(raw[5], c - 2); d[15] = v - SB_BYTE(raw[6], c - 1);
+            sw |= (uint32_t)fast_score_ring(d, g.minTh) << (8 * j);
+        }
+        uint8_t *so = sp + (size_t)oy * L.bpitch + x;
+        if (full) *(uint32_t *)so = sw;
+        else for (int j = 0; j < 4 && x + j < L.w; j++) so[j] = (uint8_t)(sw >> (8 * j));
     }
 }
 
@@ -221,60 +268,6 @@ __global__ void __launch_bounds__(64) k_fast_cells(const uint8_t *__restrict__ s
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// GaussianBlur(7x7, sigma 2) on 8U: OpenCV 3.3 separable fixed-point path, taps round(k*256) per axis
-// (sum 257, not renormalised), int32 row pass, column pass rounded like the SSE2 column filter
-// (exact sum/65536 to nearest-even) for x < (w & ~3) and (sum + 32768) >> 16 for the last w % 4
-// columns.  The padded pyramid plane already holds the REFLECT_101 border the blur needs.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_blur7(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, OrbGeom g, int4 taps)
-{
-    __shared__ uint8_t raw[(TILE_H + 6) * LT_PITCH];
-    __shared__ int hrow[(TILE_H + 6) * TILE_W];
-    const int f = blockIdx.y;
-    const int l = find_level_by_tile(g, blockIdx.x);
-    const OrbLevel &L = g.lv[l];
-    const int tl = blockIdx.x - L.tile_base;
-    const int tx = tl % L.tiles_x, ty = tl / L.tiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-    const uint8_t *img = pyr + (size_t)f * g.pyr_stride + L.plane_off + (size_t)PLF_EDGE * L.ppitch + PLF_EDGE;
-    for (int i = threadIdx.x; i < (TILE_H + 6) * (TILE_W + 6); i += 256) {
-        const int r = i / (TILE_W + 6), c = i - r * (TILE_W + 6);
-        int gx = x0 - 3 + c, gy = y0 - 3 + r;
-        gx = min(gx, L.w + PLF_EDGE - 1);
-        gy = min(gy, L.h + PLF_EDGE - 1);
-        raw[r * LT_PITCH + c] = img[(ptrdiff_t)gy * L.ppitch + gx];
-    }
-    __syncthreads();
-    const int k0 = taps.x, k1 = taps.y, k2 = taps.z, k3 = taps.w;
-    for (int i = threadIdx.x; i < (TILE_H + 6) * TILE_W; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t *p = &raw[r * LT_PITCH + c];
-        hrow[i] = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
-    }
-    __syncthreads();
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int wvec = L.w & ~3;
-    uint8_t *bp = blur + (size_t)f * g.blur_stride + L.blur_off;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int r = ry + 4 * k;
-        const int gx = x0 + cx, gy = y0 + r;
-        if (gx < L.w && gy < L.h) {
-            const int *q = &hrow[r * TILE_W + cx];
-            const int s = k0 * (q[0] + q[6 * TILE_W]) + k1 * (q[TILE_W] + q[5 * TILE_W]) + k2 * (q[2 * TILE_W] + q[4 * TILE_W]) + k3 * q[3 * TILE_W];
-            int v;
-            if (gx < wvec) {
-                v = s >> 16;
-                const int rem = s & 0xFFFF;
-                if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
-            } else {
-                v = (s + 32768) >> 16;
-            }
-            bp[(size_t)gy * L.bpitch + gx] = (uint8_t)min(v, 255);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Orientation + descriptor: one wave per selected keypoint.
