@@ -88,12 +88,12 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     g->log_nt = 5 * (log10((double)g->sw) + log10((double)g->sh)) / 2 + log10(11.0);
     g->min_reg_size = (int)(-g->log_nt / log10(g->p));
     g->used_words = (g->sw * g->sh + 31) / 32;
-    // LDS budget of k_lsd_regions = used bitmap + region list (+1 mailbox word) + neighbourhood ring (9 x (4 + 16) B per
-    // entry).  The kernel is a latency-bound serial chain (one wave per frame), so what matters is how many frames a CU
-    // can host at once: aim for 4 workgroups per CU (<= 39 KB each) when the bitmap allows it, else 2, else 1.
-    g->ring = 32;
-    const size_t fixed = (size_t)g->used_words * 4 + (size_t)g->ring * 9 * 20 + 64;
-    const size_t budgets[3] = {39 * 1024, 78 * 1024, 150 * 1024};
+    // LDS budget of k_lsd_regions = used bitmap + region list (+1 mailbox word).  The kernel is a latency-bound serial
+    // chain (one wave per frame), so what matters is how many frames a CU can host at once: aim for 4 workgroups per CU
+    // (<= 39 KB each) when the bitmap allows it, else 2, else 1.  PLF_LSD_LDS_KB overrides the first budget (experiments).
+    const size_t fixed = (size_t)g->used_words * 4 + 64;
+    size_t budgets[3] = {39 * 1024, 78 * 1024, 150 * 1024};
+    if (const char *e = getenv("PLF_LSD_LDS_KB")) { if (atoi(e) >= 8 && atoi(e) <= 150) budgets[0] = (size_t)atoi(e) * 1024; }
     g->rcap = 0;
     for (int b = 0; b < 3 && g->rcap == 0; b++)
         if (fixed + 1024 * 4 + 4 <= budgets[b]) g->rcap = (int)((budgets[b] - fixed) / 4) - 1;
@@ -142,7 +142,7 @@ static int line_configure(plf_line *h, int w, int hh)
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(float2) * g.sh, hipMemcpyHostToDevice));
     h->g = g;
-    h->regions_lds = (size_t)g.used_words * 4 + (size_t)(g.rcap + 1) * 4 + (size_t)g.ring * 9 * 20 + 64;
+    h->regions_lds = (size_t)g.used_words * 4 + (size_t)(g.rcap + 1) * 4 + 64;
     h->finalize_lds = (size_t)g.sort_cap * 8 + (size_t)g.rect_cap * 4 + 260 * 4;
     h->nfa_lds = (size_t)g.sh * 2 * sizeof(int) + 64;
     h->cur_w = w; h->cur_h = hh;

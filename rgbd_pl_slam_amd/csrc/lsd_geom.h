@@ -18,7 +18,6 @@ struct LsdGeom {
     int min_reg_size;
     int used_words;       // LDS words of the `used` bitmap
     int rcap;             // region-list entries kept in LDS (one spare word follows)
-    int ring;             // entries of the LDS neighbourhood ring (power of two)
     int rect_cap;         // rectangles / segments per frame
     int nkeep;            // lines kept after the response sort
     int sort_cap;         // power of two >= rect_cap

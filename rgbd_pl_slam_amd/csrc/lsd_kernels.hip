@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ sca
 // region growing (one wave per frame)
 // ------------------------------------------------------------------------------------------------
 // LDS pointers carry their address space in the type: a pointer that may be LDS or global would be lowered to FLAT
-// accesses, whose `s_waitcnt vmcnt(0)` also drains the outstanding neighbourhood prefetches.
+// accesses, whose `s_waitcnt vmcnt(0)` also drains the outstanding neighbourhood loads.
 #define LDS_PTR(T) __attribute__((address_space(3))) T *
 struct RegCtx {
     int W, H;
@@ -118,9 +118,6 @@ struct RegCtx {
     LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
-    LDS_PTR(float) ring_deg;   // LDS ring: 9 neighbour angles of queued region points
-    LDS_PTR(double) ring_cs;   // LDS ring: their cos/sin increments (2 doubles per neighbour)
-    int ring;                  // ring entries (power of two)
 };
 
 #ifdef PLF_LSD_TIMING
@@ -163,94 +160,100 @@ __device__ __forceinline__ double readlane_d(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ bool aligned_deg(float deg, double theta, double prec)
+// Thresholds of the cheap alignment pre-test of region_grow (see there): tan(prec -/+ delta), delta = 0.05 degrees.
+// t1 < 0 switches the pre-test off (every decision is then taken by the exact test).
+struct GrowTh { float t1, t2; };
+__device__ __forceinline__ GrowTh grow_thresholds(double prec)
 {
-    if (deg == NOTDEF_F) return false;
-    const double a = (double)deg * DEG2RAD_D;
-    double n_theta = theta - a;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > M_3_2_PI_D) {
-        n_theta -= M_2__PI_D;
-        if (n_theta < 0) n_theta = -n_theta;
+    const double delta = 8.7266462599716e-4;
+    GrowTh t;
+    t.t1 = -1.f; t.t2 = 0.f;
+    if (prec - delta > 0.0 && prec + delta < 1.55) {
+        t.t1 = (float)tan(prec - delta) * (1.0f - 1.0e-6f);
+        t.t2 = (float)tan(prec + delta) * (1.0f + 1.0e-6f);
     }
-    return n_theta <= prec;
+    return t;
+}
+
+// 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order
+struct Grp { float deg; double csx, csy; int a; uint32_t xy; };
+__device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, int lane, int slot, int kx, int ky)
+{
+    Grp G;
+    G.deg = NOTDEF_F; G.csx = 0.0; G.csy = 0.0; G.a = -1; G.xy = 0u;
+    if (lane < 63 && slot < cnt) {
+        const uint32_t pxy = rxy_get(C, first + slot);
+        const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
+        if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
+            G.a = yy * C.W + xx;
+            G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
+            G.deg = C.ang[G.a];
+            const double2 c = C.cs[G.a];
+            G.csx = c.x; G.csy = c.y;
+        }
+    }
+    return G;
 }
 
 // LineSegmentDetectorImpl::region_grow.  All lanes return the same (n, reg_angle).
 // The accept steps happen strictly in the reference order (centre by centre, neighbours in (yy, xx) order, the
-// region angle updated after every accepted pixel).  What is pipelined is only the DATA FETCH: while centre i is
-// processed, the 3x3 neighbourhoods (angle + cos/sin increment) of up to 7 further queued points are gathered from
-// HBM/L2 into registers and then parked in an LDS ring, so that a centre normally finds its data in LDS.  `used` is
-// read from LDS at the moment a centre is processed, so it is always current.  Nothing is written to global memory
-// on this path; modgrad / angle of the region points are re-gathered by coordinate where a region needs them.
-__device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, double &reg_angle_out)
+// region angle a function of the sums after every accepted pixel).  Up to 7 queued centres are handled as one
+// group of 63 lanes whose lane order IS the reference's test order; the data of the next group (angle + cos/sin
+// increment per neighbour) is loaded while the current group is processed.
+//
+// The reference recomputes reg_angle = fastAtan2(sumdy, sumdx) after every accept and tests every later neighbour
+// against it.  Here the fastAtan2 + exact double test is only evaluated when it can matter: with S = (sumdx, sumdy)
+// and u = (cos a, sin a) of a candidate, the angle between S and u is atan2(|S x u|, S . u); fastAtan2 differs from
+// the true angle of S by < 0.0096 degrees, so a candidate whose angle to S is below prec - 0.05 deg is aligned and
+// one above prec + 0.05 deg is not, whatever the exact test would compute.  Only candidates inside that 0.1 degree
+// band ("border") are decided by the exact test.  `used` is read once per group; a pixel accepted inside the group
+// is removed from the later lanes by comparing addresses.
+__device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out)
 {
-    const int lane = plf_lane(), W = C.W, H = C.H, RM = C.ring - 1;
+    const int lane = plf_lane();
     double reg_angle = (double)deg0 * DEG2RAD_D;
+    bool theta_valid = true;              // reg_angle is the value the reference holds for the current sums
     float sumdx = cs0.x, sumdy = cs0.y;   // float(cos(reg_angle)), float(sin(reg_angle))
     if (lane == 0) {
         rxy_put(C, 0, (uint32_t)sx | ((uint32_t)sy << 16));
-        used_set(C, sy * W + sx);
+        used_set(C, sy * C.W + sx);
     }
     CBAR();
-    int n = 1, i = 0, pf = 0, rd = 0;   // list size, next centre, next entry to prefetch, entries [i, rd) are in the ring
+    int n = 1, i = 0;
     const int slot = lane / 9, k9 = lane - slot * 9;
-    const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;  // 3x3 neighbourhood in (yy, xx) order
+    const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;
+    int cur_n = 1;
+    Grp cur = load_group(C, 0, 1, lane, slot, kx, ky);
     while (i < n) {
         CNT(7, 1);
-        // ---- prefetch: neighbourhoods of list entries [pf, pf + pc) into registers
-        TIC(tp);
-        int pc = min(7, min(n, i + C.ring) - pf);
-        if (pc < 0) pc = 0;
-        float pdeg = NOTDEF_F;
-        double2 pcs = make_double2(0.0, 0.0);
-        const bool pact = lane < 63 && slot < pc;
-        if (pact) {
-            const uint32_t pxy = rxy_get(C, pf + slot);
-            const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
-            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-                const int a = yy * W + xx;
-                pdeg = C.ang[a];
-                if (pdeg != NOTDEF_F) pcs = C.cs[a];
+        // ---- issue the loads of the next group: list entries that exist now
+        int nx_n = min(7, n - (i + cur_n));
+        if (nx_n < 0) nx_n = 0;
+        Grp nx = load_group(C, i + cur_n, nx_n, lane, slot, kx, ky);
+        // ---- process the current group
+        CNT(8, cur_n);
+        bool cand = cur.a >= 0 && cur.deg != NOTDEF_F && !used_get(C, cur.a);
+        const float ux = (float)cur.csx, uy = (float)cur.csy;
+        while (true) {
+            // classification against the current sums
+            bool sA = false, bd = cand;
+            if (th.t1 >= 0.f && sumdx * sumdx + sumdy * sumdy >= 0.25f) {
+                const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
+                sA = cand && dot > 0.f && acr <= th.t1 * dot;
+                const bool sR = !(dot > 0.f) || acr >= th.t2 * dot;
+                bd = cand && !sA && !sR;
             }
-        }
-        TOC(12, tp);
-        if (rd <= i) {  // nothing parked for the next centre: commit the fetch now (waits for the loads)
-            TIC(ts);
-            if (pact) { const int ri = ((pf + slot) & RM) * 9 + k9; C.ring_deg[ri] = pdeg; C.ring_cs[2 * ri] = pcs.x; C.ring_cs[2 * ri + 1] = pcs.y; }
-            rd = pf + pc; pf += pc; pc = 0;
-            CBAR();
-#ifdef PLF_LSD_TIMING
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-            TOC(10, ts); CNT(11, 1);
-        }
-        // ---- process the parked centres i .. i + gcount - 1
-        TIC(tr);
-        const int gcount = min(7, rd - i);
-        CNT(8, gcount);
-        const bool active = lane < 63 && slot < gcount;
-        float deg = NOTDEF_F;
-        double2 csv = make_double2(0.0, 0.0);
-        int xx = 0, yy = 0, a = 0;
-        if (active) {
-            const uint32_t pxy = rxy_get(C, i + slot);
-            xx = (int)(pxy & 0xFFFF) + kx; yy = (int)(pxy >> 16) + ky;
-            const int ri = ((i + slot) & RM) * 9 + k9;
-            deg = C.ring_deg[ri];   // NOTDEF for neighbours outside the image
-            csv = make_double2(C.ring_cs[2 * ri], C.ring_cs[2 * ri + 1]);
-            a = yy * W + xx;
-        }
-        const bool defined = active && deg != NOTDEF_F;
-        const double adeg = (double)deg * DEG2RAD_D;
-        TOC(13, tr);
-        TIC(ta);
-        for (int s = 0; s < gcount; s++) {
-            bool cand = defined && slot == s && !used_get(C, a);
-            while (true) {
+            const unsigned long long mA = __ballot(sA);
+            unsigned long long mB = __ballot(bd);
+            int k = -1;
+            while (mA | mB) {
+                const int j = __ffsll((long long)(mA | mB)) - 1;
+                if (!((mB >> j) & 1ull)) { k = j; break; }   // surely aligned
+                // border lane: the reference's own test
+                if (!theta_valid) { reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D; theta_valid = true; }
                 bool al = false;
-                if (cand) {
-                    double n_theta = reg_angle - adeg;
+                if (lane == j) {
+                    double n_theta = reg_angle - (double)cur.deg * DEG2RAD_D;
                     if (n_theta < 0) n_theta = -n_theta;
                     if (n_theta > M_3_2_PI_D) {
                         n_theta -= M_2__PI_D;
@@ -258,31 +261,33 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                     }
                     al = n_theta <= prec;
                 }
-                const unsigned long long mask = __ballot(al);
-                if (!mask) break;
-                const int k = __ffsll((long long)mask) - 1;
-                if (lane == k) {
-                    used_set(C, a);
-                    rxy_put(C, n, (uint32_t)xx | ((uint32_t)yy << 16));
-                }
-                const double cc = readlane_d(csv.x, k), ss = readlane_d(csv.y, k);
-                // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
-                sumdx = (float)((double)sumdx + cc);
-                sumdy = (float)((double)sumdy + ss);
-                reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
-                ++n;
-                cand = cand && lane > k;
+                if (__ballot(al)) { k = j; break; }
+                mB &= ~(1ull << j);   // not aligned; the sums did not change, the other masks stay valid
             }
-            CBAR();
+            if (k < 0) break;
+            CNT(9, 1);
+            if (lane == k) {
+                used_set(C, cur.a);
+                rxy_put(C, n, cur.xy);
+            }
+            const double cc = readlane_d(cur.csx, k), ss = readlane_d(cur.csy, k);
+            const int ka = __builtin_amdgcn_readlane(cur.a, k);
+            // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
+            sumdx = (float)((double)sumdx + cc);
+            sumdy = (float)((double)sumdy + ss);
+            theta_valid = false;
+            ++n;
+            cand = cand && lane > k && cur.a != ka;
         }
-        TOC(14, ta);
-        i += gcount;
-        if (pc > 0) {  // park the fetch issued at the top of this iteration
-            if (pact) { const int ri = ((pf + slot) & RM) * 9 + k9; C.ring_deg[ri] = pdeg; C.ring_cs[2 * ri] = pcs.x; C.ring_cs[2 * ri + 1] = pcs.y; }
-            rd = pf + pc; pf += pc;
-            CBAR();
+        CBAR();
+        i += cur_n;
+        if (nx_n == 0 && i < n) {   // nothing could be loaded ahead (short list): load the next group now
+            nx_n = min(7, n - i);
+            nx = load_group(C, i, nx_n, lane, slot, kx, ky);
         }
+        cur = nx; cur_n = nx_n;
     }
+    if (!theta_valid) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
     return n;
 }
@@ -448,7 +453,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     __syncthreads();
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, reg_angle);
+    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
     if (n < 2) return false;
     region2rect(C, n, reg_angle, prec, p, rec);
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -470,10 +475,7 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
-    C.ring = g.ring;
-    C.ring_cs = (LDS_PTR(double))smem;                            // 16-byte aligned first
-    C.ring_deg = (LDS_PTR(float))(C.ring_cs + (size_t)g.ring * 18);
-    C.used = (LDS_PTR(uint32_t))(C.ring_deg + (size_t)g.ring * 9);
+    C.used = (LDS_PTR(uint32_t))smem;
     C.rxy_l = C.used + g.used_words;
     C.rcap = g.rcap;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
@@ -485,6 +487,7 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
     int nr = 0;
     const double prec = g.prec, p = g.p;
+    const GrowTh th0 = grow_thresholds(prec);
     TIC(tall);
     for (int base = 0; base < NP; base += 64) {
         const int px = base + lane;
@@ -501,7 +504,7 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             double reg_angle;
             TIC(t0);
-            int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, reg_angle);
+            int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
             if (n >= g.min_reg_size) {
                 LsdRect rec;
@@ -533,7 +536,6 @@ extern "C" void plf_lsd_timing_dump()
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_lsd_t), sizeof(t));
     printf("[lsd timing, frame 0 accumulated] grow %lld  rect %lld  refine %lld  total %lld cycles | regions %lld points %lld big %lld | iters %lld groups %lld accepts %lld\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
-    printf("[lsd timing] stall-commit cycles %lld in %lld stalls | prefetch-issue %lld  ring-read %lld  accept-loops %lld\n", t[10], t[11], t[12], t[13], t[14]);
 }
 #endif
 
