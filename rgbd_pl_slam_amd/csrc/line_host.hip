@@ -13,7 +13,7 @@ __global__ void k_lsd_blur_rows(const uint8_t *, ptrdiff_t, ptrdiff_t, double *,
 __global__ void k_lsd_blur_cols(const double *, double *, LsdGeom, LsdTaps);
 __global__ void k_lsd_resize(const double *, double *, LsdGeom, const int *, const float2 *, const int *, const float2 *);
 __global__ void k_lsd_grad(const double *, float *, double *, double2 *, float2 *, LsdGeom);
-__global__ void k_lsd_regions(const float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom);
+__global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
 struct NfaCounts { int total, alg[6], pad; };
@@ -87,18 +87,11 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     g->rho = QUANT / sin(g->prec);
     g->log_nt = 5 * (log10((double)g->sw) + log10((double)g->sh)) / 2 + log10(11.0);
     g->min_reg_size = (int)(-g->log_nt / log10(g->p));
-    g->used_words = (g->sw * g->sh + 31) / 32;
-    // LDS budget of k_lsd_regions = used bitmap + region list (+1 mailbox word).  The kernel is a latency-bound serial
-    // chain (one wave per frame), so what matters is how many frames a CU can host at once: aim for 4 workgroups per CU
-    // (<= 39 KB each) when the bitmap allows it, else 2, else 1.  PLF_LSD_LDS_KB overrides the first budget (experiments).
-    const size_t fixed = (size_t)g->used_words * 4 + 64;
-    size_t budgets[3] = {39 * 1024, 78 * 1024, 150 * 1024};
-    if (const char *e = getenv("PLF_LSD_LDS_KB")) { if (atoi(e) >= 8 && atoi(e) <= 150) budgets[0] = (size_t)atoi(e) * 1024; }
-    g->rcap = 0;
-    for (int b = 0; b < 3 && g->rcap == 0; b++)
-        if (fixed + 1024 * 4 + 4 <= budgets[b]) g->rcap = (int)((budgets[b] - fixed) / 4) - 1;
-    if (g->rcap == 0) return PLF_E_BADARG;
-    if (g->rcap > 16384) g->rcap = 16384;
+    // LDS of k_lsd_regions = the first rcap entries of the region list (+1 mailbox word); longer regions spill to HBM.
+    // The USED flags live in the angle map, so a workgroup needs ~6 KB and a CU hosts as many frames as it has wave
+    // slots: the kernel is a latency-bound serial chain per frame and its throughput is the number of frames in flight.
+    g->rcap = 1535;
+    if (const char *e = getenv("PLF_LSD_RCAP")) { if (atoi(e) >= 63 && atoi(e) <= 16384) g->rcap = atoi(e); }
     int rc = 2048;
     while (rc < g->sw * g->sh / 48 && rc < 8192) rc <<= 1;
     g->rect_cap = rc;
@@ -142,7 +135,7 @@ static int line_configure(plf_line *h, int w, int hh)
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(float2) * g.sh, hipMemcpyHostToDevice));
     h->g = g;
-    h->regions_lds = (size_t)g.used_words * 4 + (size_t)(g.rcap + 1) * 4 + 64;
+    h->regions_lds = (size_t)(g.rcap + 1) * 4 + 64;
     h->finalize_lds = (size_t)g.sort_cap * 8 + (size_t)g.rect_cap * 4 + 260 * 4;
     h->nfa_lds = (size_t)g.sh * 2 * sizeof(int) + 64;
     h->cur_w = w; h->cur_h = hh;

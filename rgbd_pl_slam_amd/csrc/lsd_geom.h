@@ -16,7 +16,6 @@ struct LsdGeom {
     uint32_t s_stride;    // elements per frame of the scaled maps
     double rho, prec, p, log_nt;
     int min_reg_size;
-    int used_words;       // LDS words of the `used` bitmap
     int rcap;             // region-list entries kept in LDS (one spare word follows)
     int rect_cap;         // rectangles / segments per frame
     int nkeep;            // lines kept after the response sort

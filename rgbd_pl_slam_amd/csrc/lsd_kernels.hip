@@ -108,13 +108,20 @@ __global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ sca
 // LDS pointers carry their address space in the type: a pointer that may be LDS or global would be lowered to FLAT
 // accesses, whose `s_waitcnt vmcnt(0)` also drains the outstanding neighbourhood loads.
 #define LDS_PTR(T) __attribute__((address_space(3))) T *
+// The USED flag of a pixel is the SIGN BIT of its entry in the frame's angle map (angles are in [0, 360), NOTDEF is
+// -1024): a pixel is a candidate iff its word is < 0x80000000.  The map lives in HBM/L2, not LDS, so that a
+// workgroup needs only a few KB of LDS and a CU hosts many frames at once -- the kernel is a chain of dependent
+// memory accesses per frame, and its throughput is the number of frames in flight.  Flag updates are relaxed
+// device-scope atomics and flag reads relaxed device-scope atomic loads: per-location program order holds, so the
+// single wave that owns the frame always reads its own latest write.  k_nfa_count strips the sign afterwards.
 struct RegCtx {
     int W, H;
-    const float *ang;
+    uint32_t *ang;             // angle map words (float bits), sign bit = USED
     const double *modgrad;
     const double2 *cs;
     const float2 *cs0;
-    LDS_PTR(uint32_t) used;    // LDS bitmap, 1 = USED
+    int cbase;                 // first pixel of the 64-pixel seed chunk being scanned
+    unsigned long long cused;  // pixels of that chunk accepted into a region since the chunk was loaded
     LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
@@ -132,9 +139,10 @@ __device__ long long g_lsd_t[16];
 #endif
 #define CBAR() asm volatile("" ::: "memory")   // single-wave kernel: LDS ops stay in program order; only the compiler must not reorder
 
-__device__ __forceinline__ bool used_get(const RegCtx &C, int a) { return (C.used[a >> 5] >> (a & 31)) & 1u; }
-__device__ __forceinline__ void used_set(RegCtx &C, int a) { __hip_atomic_fetch_or(&C.used[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void used_clr(RegCtx &C, int a) { __hip_atomic_fetch_and(&C.used[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t ang_load(const RegCtx &C, int a) { return __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ang_value(uint32_t w) { return __uint_as_float(w & 0x7FFFFFFFu); }   // of a defined pixel
+__device__ __forceinline__ void used_set(RegCtx &C, int a) { __hip_atomic_fetch_or(&C.ang[a], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void used_clr(RegCtx &C, int a) { __hip_atomic_fetch_and(&C.ang[a], 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t rxy_get(const RegCtx &C, int i)
 {
     uint32_t v = C.rxy_l[i < C.rcap ? i : 0];   // always an LDS read
@@ -176,18 +184,18 @@ __device__ __forceinline__ GrowTh grow_thresholds(double prec)
 }
 
 // 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order
-struct Grp { float deg; double csx, csy; int a; uint32_t xy; };
+struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle word (candidate iff < 0x80000000)
 __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, int lane, int slot, int kx, int ky)
 {
     Grp G;
-    G.deg = NOTDEF_F; G.csx = 0.0; G.csy = 0.0; G.a = -1; G.xy = 0u;
+    G.w = 0xFFFFFFFFu; G.csx = 0.0; G.csy = 0.0; G.a = -1; G.xy = 0u;
     if (lane < 63 && slot < cnt) {
         const uint32_t pxy = rxy_get(C, first + slot);
         const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
         if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
             G.a = yy * C.W + xx;
             G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            G.deg = C.ang[G.a];
+            G.w = ang_load(C, G.a);
             const double2 c = C.cs[G.a];
             G.csx = c.x; G.csy = c.y;
         }
@@ -206,8 +214,9 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
 // and u = (cos a, sin a) of a candidate, the angle between S and u is atan2(|S x u|, S . u); fastAtan2 differs from
 // the true angle of S by < 0.0096 degrees, so a candidate whose angle to S is below prec - 0.05 deg is aligned and
 // one above prec + 0.05 deg is not, whatever the exact test would compute.  Only candidates inside that 0.1 degree
-// band ("border") are decided by the exact test.  `used` is read once per group; a pixel accepted inside the group
-// is removed from the later lanes by comparing addresses.
+// band ("border") are decided by the exact test.  The USED flags arrive with the angle words of a group, i.e. they
+// are as old as the group's load: a pixel accepted since then is removed from the later lanes of the current group
+// and from the lanes of the already-loaded next group by comparing addresses.
 __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out)
 {
     const int lane = plf_lane();
@@ -224,15 +233,17 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;
     int cur_n = 1;
     Grp cur = load_group(C, 0, 1, lane, slot, kx, ky);
+    bool cur_stale = false;   // this lane's pixel was accepted after its word was loaded
     while (i < n) {
         CNT(7, 1);
         // ---- issue the loads of the next group: list entries that exist now
         int nx_n = min(7, n - (i + cur_n));
         if (nx_n < 0) nx_n = 0;
         Grp nx = load_group(C, i + cur_n, nx_n, lane, slot, kx, ky);
+        bool nx_stale = false;
         // ---- process the current group
         CNT(8, cur_n);
-        bool cand = cur.a >= 0 && cur.deg != NOTDEF_F && !used_get(C, cur.a);
+        bool cand = cur.w < 0x80000000u && !cur_stale;
         const float ux = (float)cur.csx, uy = (float)cur.csy;
         while (true) {
             // classification against the current sums
@@ -253,7 +264,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                 if (!theta_valid) { reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D; theta_valid = true; }
                 bool al = false;
                 if (lane == j) {
-                    double n_theta = reg_angle - (double)cur.deg * DEG2RAD_D;
+                    double n_theta = reg_angle - (double)__uint_as_float(cur.w) * DEG2RAD_D;
                     if (n_theta < 0) n_theta = -n_theta;
                     if (n_theta > M_3_2_PI_D) {
                         n_theta -= M_2__PI_D;
@@ -278,14 +289,17 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             theta_valid = false;
             ++n;
             cand = cand && lane > k && cur.a != ka;
+            nx_stale = nx_stale || nx.a == ka;
+            if ((unsigned)(ka - C.cbase) < 64u) C.cused |= 1ull << (ka - C.cbase);
         }
         CBAR();
         i += cur_n;
         if (nx_n == 0 && i < n) {   // nothing could be loaded ahead (short list): load the next group now
             nx_n = min(7, n - i);
             nx = load_group(C, i, nx_n, lane, slot, kx, ky);
+            nx_stale = false;
         }
-        cur = nx; cur_n = nx_n;
+        cur = nx; cur_n = nx_n; cur_stale = nx_stale;
     }
     if (!theta_valid) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
@@ -423,7 +437,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     const uint32_t q0 = rxy_get(C, 0);
     const int a0 = (int)(q0 >> 16) * C.W + (int)(q0 & 0xFFFF);
     const double xc = (double)(int)(q0 & 0xFFFF), yc = (double)(int)(q0 >> 16);
-    const float deg_c = C.ang[a0];
+    const float deg_c = ang_value(ang_load(C, a0));
     const double ang_c = (double)deg_c * DEG2RAD_D;
     double sum = 0, s_sum = 0;
     int cnt = 0;
@@ -437,7 +451,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
             used_clr(C, a);
             if (dist_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) < rec.width) {
                 inc = true;
-                ang_d = angle_diff_signed_d((double)C.ang[a] * DEG2RAD_D, ang_c);
+                ang_d = angle_diff_signed_d((double)ang_value(ang_load(C, a)) * DEG2RAD_D, ang_c);
             }
         }
         unsigned long long m = __ballot(inc);
@@ -461,7 +475,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     return true;
 }
 
-__global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+__global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                     const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                     uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                     int *__restrict__ status, LsdGeom g)
@@ -471,16 +485,13 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     const int W = g.sw, H = g.sh, NP = W * H;
     RegCtx C;
     C.W = W; C.H = H;
-    C.ang = ang_all + (size_t)f * g.s_stride;
+    C.ang = reinterpret_cast<uint32_t *>(ang_all) + (size_t)f * g.s_stride;
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
-    C.used = (LDS_PTR(uint32_t))smem;
-    C.rxy_l = C.used + g.used_words;
+    C.rxy_l = (LDS_PTR(uint32_t))smem;
     C.rcap = g.rcap;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
-    for (int i = lane; i < g.used_words; i += 64) C.used[i] = 0u;
-    __syncthreads();
     // This wave is one long dependent chain; waves of other kernels sharing its SIMD only ever delay it.
     // Raise its issue priority so that co-running throughput kernels (ORB, matchers, NFA) fill the idle slots instead.
     __builtin_amdgcn_s_setprio(3);
@@ -491,10 +502,12 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
     TIC(tall);
     for (int base = 0; base < NP; base += 64) {
         const int px = base + lane;
-        const float deg = px < NP ? C.ang[px] : NOTDEF_F;
+        uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
+        bool ok = w < 0x80000000u;
+        const float deg = __uint_as_float(w);
         float2 c0 = make_float2(0.f, 0.f);
-        if (deg != NOTDEF_F) c0 = C.cs0[px];
-        bool ok = px < NP && deg != NOTDEF_F && !used_get(C, px);
+        if (ok) c0 = C.cs0[px];
+        C.cbase = base; C.cused = 0ull;
         unsigned long long mask = __ballot(ok);
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;
@@ -506,7 +519,8 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
             TIC(t0);
             int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
-            if (n >= g.min_reg_size) {
+            const bool big = n >= g.min_reg_size;
+            if (big) {
                 LsdRect rec;
                 TIC(t1);
                 region2rect(C, n, reg_angle, prec, p, rec);
@@ -521,7 +535,13 @@ __global__ void __launch_bounds__(64) k_lsd_regions(const float *__restrict__ an
                 }
             }
             CBAR();
-            ok = ok && lane > j && !used_get(C, px);
+            if (big) {   // refine / reduce may have released pixels again: take the flags from memory
+                w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
+                C.cused = 0ull;
+                ok = ok && lane > j && w < 0x80000000u;
+            } else {
+                ok = ok && lane > j && !((C.cused >> lane) & 1ull);
+            }
             mask = __ballot(ok);
         }
     }
@@ -695,9 +715,9 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
         const float *row = ang + (size_t)y * W;
         for (int x = xl + rx; x <= xr; x += rx_n) {
             ++total;
-            const float deg = row[x];
-            if (deg == NOTDEF_F) continue;
-            const double a = (double)deg * DEG2RAD_D;
+            const float dw = row[x];
+            if (dw == NOTDEF_F) continue;
+            const double a = (double)fabsf(dw) * DEG2RAD_D;   // the sign bit is k_lsd_regions' USED flag
             double n_theta = rec.theta - a;
             if (n_theta < 0) n_theta = -n_theta;
             if (n_theta > M_3_2_PI_D) {
