@@ -5,14 +5,13 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "plf_common.h"
 #include "lsd_geom.h"
 
-__global__ void k_lsd_blur_rows(const uint8_t *, ptrdiff_t, ptrdiff_t, double *, LsdGeom, LsdTaps);
-__global__ void k_lsd_blur_cols(const double *, double *, LsdGeom, LsdTaps);
-__global__ void k_lsd_resize(const double *, double *, LsdGeom, const int *, const float2 *, const int *, const float2 *);
-__global__ void k_lsd_grad(const double *, float *, double *, double2 *, float2 *, LsdGeom);
+__global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
+                          const int *, const float2 *);
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
@@ -39,7 +38,7 @@ struct plf_line {
     size_t regions_lds, finalize_lds, nfa_lds;
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
-    double *d_tmp, *d_blur, *d_scaled, *d_modgrad, *d_rmod, *d_lineeq, *d_lgam;
+    double *d_modgrad, *d_rmod, *d_lineeq, *d_lgam;
     NfaEntry *d_ent[2];
     NfaState *d_st[2];
     NfaCounts *d_cnt;
@@ -65,7 +64,7 @@ struct plf_line {
 
 static void line_free(plf_line *h)
 {
-    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_tmp, h->d_blur, h->d_scaled, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
+    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rdeg, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -127,6 +126,13 @@ static int line_configure(plf_line *h, int w, int hh)
         yofs[dy] = sy; yb[dy].x = 1.f - fy; yb[dy].y = fy;
     }
     g.xmax = xmax;
+    // k_lsd_pre keeps the blurred source pixels of a 65 x 17 scaled tile in LDS: PRE_SC x PRE_SR
+    for (int d0 = 0; d0 < g.sw; d0 += 64)
+        if (std::min(xofs[std::min(d0 + 64, g.sw - 1)] + 1, w - 1) - xofs[d0] + 1 > 88) return PLF_E_BADARG;
+    for (int d0 = 0; d0 < g.sh; d0 += 16) {
+        const int lo = std::min(std::max(yofs[d0], 0), hh - 1), hi = std::min(std::max(yofs[std::min(d0 + 16, g.sh - 1)] + 1, 0), hh - 1);
+        if (hi - lo + 1 > 26) return PLF_E_BADARG;
+    }
     // keep the allocation strides so that per-frame offsets stay inside the buffers
     g.full_stride = (uint32_t)h->alloc_full; g.s_stride = (uint32_t)h->alloc_scaled; g.rect_cap = h->alloc_rect_cap;
     g.sort_cap = h->alloc_rect_cap;
@@ -186,10 +192,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
         }                                                                             \
     } while (0)
     ALLOC(h->d_in, B * (size_t)p->max_width * p->max_height);
-    ALLOC(h->d_tmp, B * F * sizeof(double));
-    ALLOC(h->d_blur, B * F * sizeof(double));
     ALLOC(h->d_grad, B * F * sizeof(short2));
-    ALLOC(h->d_scaled, B * S * sizeof(double));
     ALLOC(h->d_modgrad, B * S * sizeof(double));
     ALLOC(h->d_cs, B * S * sizeof(double2));
     ALLOC(h->d_ang, B * S * sizeof(float));
@@ -243,11 +246,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail_unused = h->d_counters + 3 * MB + 16;
     (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
-    dim3 gfull((g.w + 255) / 256, g.h, B), gsc((g.sw + 255) / 256, g.sh, B);
-    hipLaunchKernelGGL(k_lsd_blur_rows, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_tmp, g, h->taps);
-    hipLaunchKernelGGL(k_lsd_blur_cols, gfull, dim3(256), 0, s, h->d_tmp, h->d_blur, g, h->taps);
-    hipLaunchKernelGGL(k_lsd_resize, gsc, dim3(256), 0, s, h->d_blur, h->d_scaled, g, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
-    hipLaunchKernelGGL(k_lsd_grad, gsc, dim3(256), 0, s, h->d_scaled, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g);
+    dim3 gfull((g.w + 255) / 256, g.h, B);
+    hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
+                       h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
     const bool prof = h->prof_on && h->prof_n < 512;
     if (prof) {

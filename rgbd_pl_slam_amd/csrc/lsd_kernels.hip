@@ -3,9 +3,8 @@
 // (include/ExtractLineSegment.h:38; OpenCV 3.3 imgproc/lsd.cpp, LSD_REFINE_ADV, default parameters).
 //
 // Stage map (B frames per launch):
-//   k_lsd_blur_rows / k_lsd_blur_cols   GaussianBlur(7x7, sigma 0.75) on the image converted to double
-//   k_lsd_resize                        resize(0.8, INTER_LINEAR) of the double image (float coefficients)
-//   k_lsd_grad                          ll_angle: 2x2 gradient, modgrad (double), level-line angle (cv::fastAtan2)
+//   k_lsd_pre                           GaussianBlur(7x7, sigma 0.75) on the image converted to double, resize(0.8,
+//                                       INTER_LINEAR), ll_angle: 2x2 gradient, modgrad, level-line angle (cv::fastAtan2)
 //   k_lsd_regions                       seed scan + region_grow + region2rect + refine   (ORDER-DEPENDENT, see below)
 //   k_nfa_init / k_nfa_count / k_nfa_math   rect_improve = 5 search stages of (pixel count, NFA math) per rectangle
 //   k_lsd_finalize                      ordered compaction -> segments -> KeyLine fields -> top-N by response
@@ -28,78 +27,101 @@
 #define DEG2RAD_D (PI_D / 180)
 
 // ------------------------------------------------------------------------------------------------
-// blur + resize (double data, identical operation order to cv::RowFilter / SymmColumnFilter / resize)
+// k_lsd_pre: GaussianBlur(7x7, sigma 0.75) of the image converted to double, resize(0.8, INTER_LINEAR) with float
+// coefficients, and ll_angle, fused per 64 x 16 tile of the scaled image; every intermediate lives in LDS
+// (identical operation order to cv::RowFilter / SymmColumnFilter / resize / ll_angle, see oracle/lsd_oracle.c).
+//   row pass   tmp(y, x)  = sum_i k[i] * double(u8(y, refl101(x - 3 + i)))                      i = 0..6, in this order
+//   col pass   blur(y, x) = k[3] * tmp(y, x) + 0.0, then += k[3+i] * (tmp(refl(y+i)) + tmp(refl(y-i)))   i = 1..3
+//   resize     r0 = S0[sx] * a.x + S0[sx+1] * a.y (or S0[sx] * 1.0 for dx >= xmax), same for r1; out = r0 * b.x + r1 * b.y
+//   ll_angle   2x2 gradient, modgrad (double), level-line angle in DEGREES as cv::fastAtan2 returns it (the reference
+//              stores double(deg) * DEG_TO_RADS, recomputed on use), NOTDEF_F where the gradient is too small or on
+//              the last row/column.  cs: cos and sin of the float-rounded angle, the increments region_grow adds to
+//              its sums.  cs0: float(cos(angle)), float(sin(angle)) of the un-rounded angle, the initial sums of a
+//              region seeded here.
+// A tile of 65 x 17 scaled pixels (one more column/row for the gradient) needs at most PRE_SC x PRE_SR blurred source
+// pixels (checked on the host for the actual geometry) and 6 more rows of the row pass.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_lsd_blur_rows(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride,
-                                                       double *__restrict__ tmp, LsdGeom g, LsdTaps t)
+#define PRE_TW 64
+#define PRE_TH 16
+#define PRE_SC 88
+#define PRE_SR 26
+__global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, float *__restrict__ ang,
+                                                 double *__restrict__ modgrad, double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g,
+                                                 LsdTaps t, const int *__restrict__ xofs, const float2 *__restrict__ xa,
+                                                 const int *__restrict__ yofs, const float2 *__restrict__ yb)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x >= g.w) return;
-    const uint8_t *row = in + (size_t)f * fstride + (size_t)y * pitch;
-    double s = t.k[0] * (double)row[plf_reflect101(x - 3, g.w)];
+    __shared__ double s_tmp[(PRE_SR + 6) * PRE_SC];
+    __shared__ double s_blur[PRE_SR * PRE_SC];
+    double *s_sc = s_tmp;   // the scaled tile reuses the row-pass buffer
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int dx0 = blockIdx.x * PRE_TW, dy0 = blockIdx.y * PRE_TH;
+    const int dx1 = min(dx0 + PRE_TW, g.sw - 1), dy1 = min(dy0 + PRE_TH, g.sh - 1);
+    const int c_lo = xofs[dx0], c_hi = min(xofs[dx1] + 1, g.w - 1);
+    const int r_lo = min(max(yofs[dy0], 0), g.h - 1), r_hi = min(max(yofs[dy1] + 1, 0), g.h - 1);
+    const int nc = c_hi - c_lo + 1, nr = r_hi - r_lo + 1;
+    const uint8_t *img = in + (size_t)f * fstride;
+    for (int i = tid; i < (nr + 6) * PRE_SC; i += 256) {
+        const int r = i / PRE_SC, c = i - r * PRE_SC;
+        if (c >= nc) continue;
+        const uint8_t *row = img + (size_t)plf_reflect101(r_lo - 3 + r, g.h) * pitch;
+        const int x = c_lo + c;
+        double s = t.k[0] * (double)row[plf_reflect101(x - 3, g.w)];
 #pragma unroll
-    for (int i = 1; i < 7; i++) s += t.k[i] * (double)row[plf_reflect101(x - 3 + i, g.w)];
-    tmp[(size_t)f * g.full_stride + (size_t)y * g.w + x] = s;
-}
-
-__global__ void __launch_bounds__(256) k_lsd_blur_cols(const double *__restrict__ tmp, double *__restrict__ blur, LsdGeom g, LsdTaps t)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x >= g.w) return;
-    const double *p = tmp + (size_t)f * g.full_stride + x;
-    double s = t.k[3] * p[(size_t)y * g.w] + 0.0;
-#pragma unroll
-    for (int i = 1; i <= 3; i++)
-        s += t.k[3 + i] * (p[(size_t)plf_reflect101(y + i, g.h) * g.w] + p[(size_t)plf_reflect101(y - i, g.h) * g.w]);
-    blur[(size_t)f * g.full_stride + (size_t)y * g.w + x] = s;
-}
-
-__global__ void __launch_bounds__(256) k_lsd_resize(const double *__restrict__ blur, double *__restrict__ scaled, LsdGeom g,
-                                                    const int *__restrict__ xofs, const float2 *__restrict__ xa,
-                                                    const int *__restrict__ yofs, const float2 *__restrict__ yb)
-{
-    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, f = blockIdx.z;
-    if (dx >= g.sw) return;
-    const double *src = blur + (size_t)f * g.full_stride;
-    const int sx = xofs[dx], sy = yofs[dy];
-    const float2 a = xa[dx], b = yb[dy];
-    const int y0 = min(max(sy, 0), g.h - 1), y1 = min(max(sy + 1, 0), g.h - 1);
-    const double *S0 = src + (size_t)y0 * g.w, *S1 = src + (size_t)y1 * g.w;
-    double r0, r1;
-    if (dx < g.xmax) {
-        r0 = S0[sx] * (double)a.x + S0[sx + 1] * (double)a.y;
-        r1 = S1[sx] * (double)a.x + S1[sx + 1] * (double)a.y;
-    } else {
-        r0 = S0[sx] * 1.0;
-        r1 = S1[sx] * 1.0;
+        for (int q = 1; q < 7; q++) s += t.k[q] * (double)row[plf_reflect101(x - 3 + q, g.w)];
+        s_tmp[i] = s;
     }
-    scaled[(size_t)f * g.s_stride + (size_t)dy * g.sw + dx] = r0 * (double)b.x + r1 * (double)b.y;
-}
-
-// ll_angle.  ang: level-line angle in DEGREES as cv::fastAtan2 returns it (the reference stores
-// double(deg) * DEG_TO_RADS, recomputed on use), NOTDEF_F where the gradient is too small or on the last
-// row/column.  cs: cos and sin of the float-rounded angle, the increments region_grow adds to its sums.
-// cs0: float(cos(angle)), float(sin(angle)) of the un-rounded angle, the initial sums of a region seeded here.
-__global__ void __launch_bounds__(256) k_lsd_grad(const double *__restrict__ scaled, float *__restrict__ ang, double *__restrict__ modgrad,
-                                                  double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x >= g.sw) return;
-    const size_t a = (size_t)f * g.s_stride + (size_t)y * g.sw + x;
-    if (x == g.sw - 1 || y == g.sh - 1) { ang[a] = NOTDEF_F; modgrad[a] = 0.0; return; }
-    const double *im = scaled + a;
-    const double DA = im[g.sw + 1] - im[0];
-    const double BC = im[1] - im[g.sw];
-    const double gx = DA + BC, gy = DA - BC;
-    const double norm = sqrt((gx * gx + gy * gy) / 4);
-    modgrad[a] = norm;
-    if (norm <= g.rho) { ang[a] = NOTDEF_F; return; }
-    const float deg = plf_fast_atan2((float)gx, (float)-gy);
-    ang[a] = deg;
-    const double ad = (double)deg * DEG2RAD_D;
-    const double af = (double)(float)ad;
-    cs[a] = make_double2(cos(af), sin(af));
-    cs0[a] = make_float2((float)cos(ad), (float)sin(ad));
+    __syncthreads();
+    for (int i = tid; i < nr * PRE_SC; i += 256) {
+        const int r = i / PRE_SC, c = i - r * PRE_SC;
+        if (c >= nc) continue;
+        const double *p = s_tmp + (r + 3) * PRE_SC + c;
+        double s = t.k[3] * p[0] + 0.0;
+#pragma unroll
+        for (int q = 1; q <= 3; q++) s += t.k[3 + q] * (p[q * PRE_SC] + p[-q * PRE_SC]);
+        s_blur[i] = s;
+    }
+    __syncthreads();
+    const int ncs = dx1 - dx0 + 1, nrs = dy1 - dy0 + 1;
+    for (int i = tid; i < nrs * (PRE_TW + 1); i += 256) {
+        const int ry = i / (PRE_TW + 1), rx = i - ry * (PRE_TW + 1);
+        if (rx >= ncs) continue;
+        const int dx = dx0 + rx, dy = dy0 + ry;
+        const int sx = xofs[dx] - c_lo, sy = yofs[dy];
+        const float2 a = xa[dx], b = yb[dy];
+        const double *S0 = s_blur + (min(max(sy, 0), g.h - 1) - r_lo) * PRE_SC, *S1 = s_blur + (min(max(sy + 1, 0), g.h - 1) - r_lo) * PRE_SC;
+        double r0, r1;
+        if (dx < g.xmax) {
+            r0 = S0[sx] * (double)a.x + S0[sx + 1] * (double)a.y;
+            r1 = S1[sx] * (double)a.x + S1[sx + 1] * (double)a.y;
+        } else {
+            r0 = S0[sx] * 1.0;
+            r1 = S1[sx] * 1.0;
+        }
+        s_sc[i] = r0 * (double)b.x + r1 * (double)b.y;
+    }
+    __syncthreads();
+    const int tx = tid & 63;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ty = (tid >> 6) + 4 * k;
+        const int x = dx0 + tx, y = dy0 + ty;
+        if (x >= g.sw || y >= g.sh) continue;
+        const size_t o = (size_t)f * g.s_stride + (size_t)y * g.sw + x;
+        if (x == g.sw - 1 || y == g.sh - 1) { ang[o] = NOTDEF_F; modgrad[o] = 0.0; continue; }
+        const double *im = s_sc + ty * (PRE_TW + 1) + tx;
+        const double DA = im[PRE_TW + 2] - im[0];
+        const double BC = im[1] - im[PRE_TW + 1];
+        const double gx = DA + BC, gy = DA - BC;
+        const double norm = sqrt((gx * gx + gy * gy) / 4);
+        modgrad[o] = norm;
+        if (norm <= g.rho) { ang[o] = NOTDEF_F; continue; }
+        const float deg = plf_fast_atan2((float)gx, (float)-gy);
+        ang[o] = deg;
+        const double ad = (double)deg * DEG2RAD_D;
+        const double af = (double)(float)ad;
+        cs[o] = make_double2(cos(af), sin(af));
+        cs0[o] = make_float2((float)cos(ad), (float)sin(ad));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
