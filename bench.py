@@ -77,8 +77,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="frames in flight per GPU and step")
+    ap.add_argument("--batch", type=int, default=4096, help="frames in flight per GPU and step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample (0: skip)")
+    ap.add_argument("--line-handles", type=int, default=1, help="line extractor handles used alternately (1 or 2)")
     ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
     args = ap.parse_args()
 
@@ -105,8 +106,9 @@ def main():
     d_img = torch.from_numpy(imgs).cuda()
 
     orb = ORBextractor(nfeatures=NFEAT, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank)
-    # two line handles used alternately: the NFA / descriptor tail of batch k overlaps the region growing of batch k+1
-    lins = [LineSegment(nlines=NLINES, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank) for _ in range(2)]
+    # (--line-handles 2: two handles used alternately so that the NFA / descriptor tail of batch k overlaps the region
+    # growing of batch k+1; at >= 3072 frames per batch the GPU is already saturated and one handle is as fast)
+    lins = [LineSegment(nlines=NLINES, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank) for _ in range(max(1, min(2, args.line_handles)))]
     lin = lins[0]
     cap = orb.capacity
     mat = Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)
@@ -125,9 +127,9 @@ def main():
     # stream sB, ORB + matchers on sA.  The two extractors are independent, as the two threads of the PL-SLAM Frame
     # constructor are; the matchers of step k wait for both extractors of step k.
     sA = torch.cuda.Stream(priority=0)
-    sBs = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)]
+    sBs = [torch.cuda.Stream(priority=-1) for _ in lins]   # one stream per line handle (a handle's scratch buffers are stream-ordered)
     if args.serial:
-        sBs = [sA, sA]
+        sBs = [sA for _ in lins]
     sB = sBs[0]
     stream, stream_b = sA.cuda_stream, sB.cuda_stream
 
@@ -155,10 +157,10 @@ def main():
     def step():
         k = state["k"]; state["k"] += 1
         bs = bufs[k & 1]
-        sBk = sBs[k & 1]
+        sBk = sBs[k % len(lins)]
         if bs["match_done"] is not None:           # the matchers of step k-2 read this buffer set
             sA.wait_event(bs["match_done"]); sBk.wait_event(bs["match_done"])
-        lins[k & 1].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
+        lins[k % len(lins)].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
         ev_lines = torch.cuda.Event(); ev_lines.record(sBk)
         orb.extract_batch_device(d_img, W_IMG, H_IMG, bs["kps"], bs["desc"], bs["nk"], cap, stream)
         with torch.cuda.stream(sA):
