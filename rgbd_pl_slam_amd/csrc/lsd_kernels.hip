@@ -283,7 +283,14 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                 const int j = __ffsll((long long)(mA | mB)) - 1;
                 if (!((mB >> j) & 1ull)) { k = j; break; }   // surely aligned
                 // border lane: the reference's own test
-                if (!theta_valid) { reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D; theta_valid = true; }
+                if (!theta_valid) {
+                    // (the empty asm pins the fastAtan2 -- two IEEE divisions -- inside this rarely taken branch; the
+                    // compiler would otherwise evaluate it speculatively on every accept step)
+                    float fx = sumdx, fy = sumdy;
+                    asm volatile("" : "+v"(fx), "+v"(fy));
+                    reg_angle = (double)plf_fast_atan2(fy, fx) * DEG2RAD_D;
+                    theta_valid = true;
+                }
                 bool al = false;
                 if (lane == j) {
                     double n_theta = reg_angle - (double)__uint_as_float(cur.w) * DEG2RAD_D;
