@@ -344,12 +344,12 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
     PLF_HIP_TRY(hipMemsetAsync(h->d_counters, 0, (3 * (size_t)h->prm.max_batch * nl + 16) * sizeof(int), s));
     {
         const OrbLevel &L = g.lv[0];
-        dim3 grid((L.ppitch + 255) / 256, L.h + 2 * PLF_EDGE, B);
+        dim3 grid((((L.ppitch + 3) / 4) * (L.h + 2 * PLF_EDGE) + 255) / 256, 1, B);
         hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_gray, pitch, fstride, h->d_pyr, g);
     }
     for (int l = 1; l < nl; l++) {
         const OrbLevel &L = g.lv[l];
-        dim3 grid((L.ppitch + 255) / 256, L.h + 2 * PLF_EDGE, B);
+        dim3 grid((((L.ppitch + 3) / 4) * (L.h + 2 * PLF_EDGE) + 255) / 256, 1, B);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, h->d_pyr, g, l, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     }
     {

@@ -17,6 +17,10 @@
 #include "orb_geom.h"
 #include "orb_pattern.inc"
 
+typedef uint32_t __attribute__((aligned(1))) plf_u32u;   // dword access at byte alignment (legal on gfx950 global memory)
+typedef unsigned long long __attribute__((aligned(1))) plf_u64u;
+struct __attribute__((aligned(4))) plf_int4u { int x, y, z, w; };
+
 __constant__ signed char c_pattern[1024];
 __constant__ int c_umax[16];
 
@@ -28,43 +32,83 @@ void plf_orb_upload_constants(const int *umax16)
 
 // ------------------------------------------------------------------------------------------------
 // Pyramid.  Padded plane of level l: (w+38) x (h+38), interior at (19,19), REFLECT_101 border.
-// One thread per padded byte; border pixels recompute the value of their mirror source, so a
+// One thread per 4 padded bytes of a row; border pixels recompute the value of their mirror source, so a
 // level is finished by a single pass (no separate copyMakeBorder pass).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t *__restrict__ in, ptrdiff_t in_pitch, ptrdiff_t in_fstride,
                                                     uint8_t *__restrict__ pyr, OrbGeom g)
 {
     const OrbLevel &L = g.lv[0];
-    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y, f = blockIdx.z;
-    if (px >= L.ppitch) return;
-    const int sx = plf_reflect101(px - PLF_EDGE, L.w), sy = plf_reflect101(py - PLF_EDGE, L.h);
-    pyr[(size_t)f * g.pyr_stride + L.plane_off + (size_t)py * L.ppitch + px] = in[(size_t)f * in_fstride + (size_t)sy * in_pitch + sx];
+    const int gpr = (L.ppitch + 3) >> 2, id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
+    const int py = id / gpr, px0 = (id - py * gpr) * 4;
+    if (py >= L.h + 2 * PLF_EDGE) return;
+    const uint8_t *row = in + (size_t)f * in_fstride + (size_t)plf_reflect101(py - PLF_EDGE, L.h) * in_pitch;
+    uint8_t *dst = pyr + (size_t)f * g.pyr_stride + L.plane_off + (size_t)py * L.ppitch + px0;
+    const int x = px0 - PLF_EDGE;
+    if (x >= 0 && x + 3 < L.w) { *(plf_u32u *)dst = *(const plf_u32u *)(row + x); return; }   // interior: straight copy
+    for (int j = 0; j < 4 && px0 + j < L.ppitch; j++) dst[j] = row[plf_reflect101(x + j, L.w)];
 }
 
 // cv::resize INTER_LINEAR 8UC1: coefficient tables (xofs, ialpha, yofs, ibeta) are built on the host
 // exactly as OpenCV does (double -> float -> 11-bit fixed point); the kernel evaluates
 //   dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+// A thread produces 4 consecutive bytes of one padded row (row terms shared, one dword store).
 __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t *__restrict__ pyr, OrbGeom g, int l, const int *__restrict__ xofs,
                                                     const short2 *__restrict__ xa, const int *__restrict__ yofs,
                                                     const short2 *__restrict__ yb)
 {
     const OrbLevel &D = g.lv[l];
     const OrbLevel &S = g.lv[l - 1];
-    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y, f = blockIdx.z;
-    if (px >= D.ppitch) return;
-    const int dx = plf_reflect101(px - PLF_EDGE, D.w), dy = plf_reflect101(py - PLF_EDGE, D.h);
+    // (row, 4-byte group) pairs are numbered linearly so that every workgroup is full whatever the level width
+    const int gpr = (D.ppitch + 3) >> 2, id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
+    const int py = id / gpr, px0 = (id - py * gpr) * 4;
+    if (py >= D.h + 2 * PLF_EDGE) return;
+    const int dy = plf_reflect101(py - PLF_EDGE, D.h);
     const uint8_t *src = pyr + (size_t)f * g.pyr_stride + S.plane_off + (size_t)PLF_EDGE * S.ppitch + PLF_EDGE;
-    const int sx = xofs[D.tabx_off + dx];
-    const short2 a = xa[D.tabx_off + dx];
     const int sy = yofs[D.taby_off + dy];
     const short2 b = yb[D.taby_off + dy];
     const int y0 = min(max(sy, 0), S.h - 1), y1 = min(max(sy + 1, 0), S.h - 1);
-    const int sx1 = min(sx + 1, S.w - 1);
     const uint8_t *r0 = src + (size_t)y0 * S.ppitch, *r1 = src + (size_t)y1 * S.ppitch;
-    const int s0 = r0[sx] * a.x + r0[sx1] * a.y;
-    const int s1 = r1[sx] * a.x + r1[sx1] * a.y;
-    const int v = (((b.x * (s0 >> 4)) >> 16) + ((b.y * (s1 >> 4)) >> 16) + 2) >> 2;
-    pyr[(size_t)f * g.pyr_stride + D.plane_off + (size_t)py * D.ppitch + px] = (uint8_t)v;
+    uint32_t out = 0;
+    const int x = px0 - PLF_EDGE;
+    bool done = false;
+    if (x >= 0 && x + 3 < D.w) {
+        // interior group: 4 consecutive table entries (two 16-byte loads) and the <= 8 source bytes per row they
+        // address (two 8-byte loads) instead of 24 scalar gathers
+        const plf_int4u so = *(const plf_int4u *)(xofs + D.tabx_off + x);
+        const int base = so.x;
+        if (so.w + 1 - base <= 7) {
+            const plf_int4u ar = *(const plf_int4u *)(xa + D.tabx_off + x);   // 4 x short2
+            const unsigned long long w0 = *(const plf_u64u *)(r0 + base), w1 = *(const plf_u64u *)(r1 + base);
+            const int sxs[4] = {so.x, so.y, so.z, so.w}, as[4] = {ar.x, ar.y, ar.z, ar.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int o0 = 8 * (sxs[j] - base), o1 = 8 * (min(sxs[j] + 1, S.w - 1) - base);
+                const int ax = (short)(as[j] & 0xFFFF), ay = as[j] >> 16;
+                const int s0 = (int)((w0 >> o0) & 0xFF) * ax + (int)((w0 >> o1) & 0xFF) * ay;
+                const int s1 = (int)((w1 >> o0) & 0xFF) * ax + (int)((w1 >> o1) & 0xFF) * ay;
+                const int v = (((b.x * (s0 >> 4)) >> 16) + ((b.y * (s1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 0xFF) << (8 * j);
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dx = plf_reflect101(min(px0 + j, D.ppitch - 1) - PLF_EDGE, D.w);
+            const int sx = xofs[D.tabx_off + dx];
+            const short2 a = xa[D.tabx_off + dx];
+            const int sx1 = min(sx + 1, S.w - 1);
+            const int s0 = r0[sx] * a.x + r0[sx1] * a.y;
+            const int s1 = r1[sx] * a.x + r1[sx1] * a.y;
+            const int v = (((b.x * (s0 >> 4)) >> 16) + ((b.y * (s1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xFF) << (8 * j);
+        }
+    }
+    uint8_t *dst = pyr + (size_t)f * g.pyr_stride + D.plane_off + (size_t)py * D.ppitch + px0;
+    if (px0 + 3 < D.ppitch) *(plf_u32u *)dst = out;
+    else for (int j = 0; j < 4 && px0 + j < D.ppitch; j++) dst[j] = (uint8_t)(out >> (8 * j));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -83,7 +127,6 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t *__restrict__ pyr, O
 // sum of taps, both passes) and the 4 FAST scores.
 // ------------------------------------------------------------------------------------------------
 #define SB_RS 16
-typedef uint32_t __attribute__((aligned(1))) plf_u32u;
 
 __device__ __forceinline__ int fast_score_ring(const int d[16], int t)
 {
