@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="frames in flight per GPU and step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--line-handles", type=int, default=1, help="line extractor handles used alternately (1 or 2)")
+    ap.add_argument("--no-front-wait", action="store_true", help="diagnostic: let ORB start together with the line front stages")
     ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
     args = ap.parse_args()
 
@@ -162,6 +163,10 @@ def main():
             sA.wait_event(bs["match_done"]); sBk.wait_event(bs["match_done"])
         lins[k % len(lins)].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
         ev_lines = torch.cuda.Event(); ev_lines.record(sBk)
+        # ORB starts when the line extractor reaches region growing: that kernel is a latency-bound chain that leaves
+        # issue slots idle, whereas the line front stages (blur/resize/gradient/Sobel) are throughput-bound like ORB
+        if not (args.no_front_wait or args.serial):
+            lins[k % len(lins)].wait_front(stream)
         orb.extract_batch_device(d_img, W_IMG, H_IMG, bs["kps"], bs["desc"], bs["nk"], cap, stream)
         with torch.cuda.stream(sA):
             bs["match_kp"].fill_(-1); bs["match_ln"].fill_(-1)

@@ -129,6 +129,13 @@ int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int
                            int32_t height, ptrdiff_t pitch, ptrdiff_t frame_stride, plf_keyline *lines, uint8_t *ldesc,
                            double *line_eq, int32_t *n_out, int32_t out_mem, int32_t capacity, void *stream);
 
+/* Scheduling hook for pipelines that run several extractors on different streams: makes `stream` wait (device side,
+ * hipStreamWaitEvent) until the throughput-bound front stages of the most recent plf_line_extract_batch -- blur,
+ * resize, gradient, Sobel: everything before region growing -- have finished.  Region growing is a latency-bound
+ * chain that leaves most issue slots idle; work queued behind this point overlaps with it instead of competing with
+ * the front stages.  No-op if no batch was enqueued yet. */
+int plf_line_wait_front(plf_line *h, void *stream);
+
 /* Measurement hook (bench.py roofline): when enabled, every launch of the region-growing kernel -- the dominant
  * kernel of the whole front-end -- is bracketed by HIP events on the stream it is launched on.  The call
  * synchronises, then returns the accumulated kernel milliseconds and the number of launches since the last reset. */

@@ -58,6 +58,8 @@ struct plf_line {
     int last_frames;
     int prof_on, prof_n;
     hipEvent_t prof_ev[2 * 512];  // (start, stop) pairs of the region kernel
+    hipEvent_t ev_front;          // recorded after the front stages of the last batch (plf_line_wait_front)
+    bool ev_front_set;
     double prof_ms;
     int prof_launches;
 };
@@ -70,6 +72,7 @@ static void line_free(plf_line *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
+    if (h->ev_front) (void)hipEventDestroy(h->ev_front);
 }
 
 static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
@@ -250,6 +253,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
                        h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
+    if (!h->ev_front) PLF_HIP_TRY(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
+    PLF_HIP_TRY(hipEventRecord(h->ev_front, s));
+    h->ev_front_set = true;
     const bool prof = h->prof_on && h->prof_n < 512;
     if (prof) {
         if (!h->prof_ev[2 * h->prof_n]) { (void)hipEventCreate(&h->prof_ev[2 * h->prof_n]); (void)hipEventCreate(&h->prof_ev[2 * h->prof_n + 1]); }
@@ -353,6 +359,15 @@ static void line_prof_collect(plf_line *h)
         }
     }
     h->prof_n = 0;
+}
+
+extern "C" int plf_line_wait_front(plf_line *h, void *stream)
+{
+    if (!h) return PLF_E_BADARG;
+    if (!h->ev_front_set) return PLF_OK;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    PLF_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->ev_front, 0));
+    return PLF_OK;
 }
 
 extern "C" int plf_line_profile(plf_line *h, int32_t enable, int32_t reset, double *ms_total, int32_t *launches)

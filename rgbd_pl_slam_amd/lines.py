@@ -59,6 +59,10 @@ class LineSegment:
                                                L.vp(d_lines), L.vp(d_desc), L.vp(d_eq), L.vp(d_n), L.MEM_DEVICE, capacity,
                                                C.c_void_p(stream) if stream else None), "plf_line_extract_batch")
 
+    def wait_front(self, stream):
+        """make `stream` wait until the stages before region growing of the last enqueued batch are done"""
+        L.check(L.lib().plf_line_wait_front(self._h, C.c_void_p(stream) if stream else None), "plf_line_wait_front")
+
     def profile(self, enable=True, reset=False):
         """(accumulated ms, launches) of the region-growing kernel measured with HIP events on its stream"""
         ms = C.c_double(0); n = C.c_int32(0)
