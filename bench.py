@@ -124,9 +124,9 @@ def main():
             match_ln=torch.full((B, NLINES), -1, dtype=torch.int32, device="cuda"), nm_ln=torch.zeros(B, dtype=torch.int32, device="cuda"))
     bufs = [bufset(), bufset()]
     scale = torch.from_numpy(np.ascontiguousarray(orb.GetScaleFactors())).cuda()
-    # two HIP streams: LSD/LBD (the long pole: its region growing is a serial chain per frame) on a high-priority
-    # stream sB, ORB + matchers on sA.  The two extractors are independent, as the two threads of the PL-SLAM Frame
-    # constructor are; the matchers of step k wait for both extractors of step k.
+    # HIP streams: LSD/LBD on a high-priority stream per line handle (its region growing is a serial chain per frame and
+    # the long pole), ORB on sA, the matchers on sM.  The two extractors are independent, as the two threads of the
+    # PL-SLAM Frame constructor are; the matchers of step k wait for both extractors of step k.
     sA = torch.cuda.Stream(priority=0)
     sBs = [torch.cuda.Stream(priority=-1) for _ in lins]   # one stream per line handle (a handle's scratch buffers are stream-ordered)
     if args.serial:
@@ -155,25 +155,30 @@ def main():
     mats = [mat, Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)]
     state = {"k": 0}
 
+    sM = sA if args.serial else torch.cuda.Stream(priority=0)   # matchers: their own stream, so that ORB of step k+1 need not wait for lines of step k
+
     def step():
         k = state["k"]; state["k"] += 1
         bs = bufs[k & 1]
-        sBk = sBs[k % len(lins)]
+        li = k % len(lins)
+        sBk = sBs[li]
         if bs["match_done"] is not None:           # the matchers of step k-2 read this buffer set
             sA.wait_event(bs["match_done"]); sBk.wait_event(bs["match_done"])
-        lins[k % len(lins)].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
+        lins[li].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
         ev_lines = torch.cuda.Event(); ev_lines.record(sBk)
         # ORB starts when the line extractor reaches region growing: that kernel is a latency-bound chain that leaves
         # issue slots idle, whereas the line front stages (blur/resize/gradient/Sobel) are throughput-bound like ORB
         if not (args.no_front_wait or args.serial):
-            lins[k % len(lins)].wait_front(stream)
+            lins[li].wait_front(stream)
         orb.extract_batch_device(d_img, W_IMG, H_IMG, bs["kps"], bs["desc"], bs["nk"], cap, stream)
-        with torch.cuda.stream(sA):
+        ev_orb = torch.cuda.Event(); ev_orb.record(sA)
+        sM.wait_event(ev_orb)
+        with torch.cuda.stream(sM):
             bs["match_kp"].fill_(-1); bs["match_ln"].fill_(-1)
-        mats[k & 1].SearchByProjection(bs["fviews"], mp, 3.0, 0.8, bs["match_kp"], cap, bs["nm_kp"], stream)
-        sA.wait_event(ev_lines)
-        mats[k & 1].SearchLinesByProjection(bs["lviews"], ml, 3.0, 0.8, bs["match_ln"], NLINES, bs["nm_ln"], stream)
-        bs["match_done"] = torch.cuda.Event(); bs["match_done"].record(sA)
+        mats[k & 1].SearchByProjection(bs["fviews"], mp, 3.0, 0.8, bs["match_kp"], cap, bs["nm_kp"], sM.cuda_stream)
+        sM.wait_event(ev_lines)
+        mats[k & 1].SearchLinesByProjection(bs["lviews"], ml, 3.0, 0.8, bs["match_ln"], NLINES, bs["nm_ln"], sM.cuda_stream)
+        bs["match_done"] = torch.cuda.Event(); bs["match_done"].record(sM)
 
     for _ in range(args.warmup):
         step()
