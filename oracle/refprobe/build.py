@@ -20,10 +20,6 @@ STUBS = os.path.join(OUT, "stubs")
 SONAMES = ["libpangolin.so", "libDBoW2.so", "libg2o.so", "libopencv_calib3d3.so.3.3",
            "libopencv_features2d3.so.3.3", "libopencv_highgui3.so.3.3", "libopencv_imgproc3.so.3.3",
            "libopencv_core3.so.3.3"]
-# entry points probe.cpp defines itself (must not be shadowed by an abort stub in link order)
-OWN = {"_ZN2cv9fastAtan2Eff", "_ZN2cv8fastFreeEPv", "_ZN2cv3Mat10deallocateEv",
-       "_ZN2cv3MatC1ERKS0_RKNS_5RangeES5_", "_ZN2cv4FASTERKNS_11_InputArrayERSt6vectorINS_8KeyPointESaIS4_EEib"}
-
 
 def sh(cmd):
     print("+", " ".join(cmd))
@@ -35,13 +31,22 @@ def main():
         print("reference binary not present; nothing to do (fixtures are committed)")
         return 0
     os.makedirs(STUBS, exist_ok=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    # entry points probe.cpp defines itself (the OpenCV substitutes of tiers B and C) must not be shadowed by abort stubs
+    sh(["g++", "-c", "-O1", "-std=c++14", "-fno-builtin-malloc", "-I", os.path.join(ROOT, "oracle"), os.path.join(here, "probe.cpp"),
+        "-o", os.path.join(OUT, "probe.o")])
+    own = set()
+    for ln in subprocess.check_output(["nm", "--defined-only", os.path.join(OUT, "probe.o")], text=True).splitlines():
+        f = ln.split()
+        if len(f) == 3 and f[1] in "TW" and (f[2].startswith("_ZN2cv") or f[2].startswith("_ZNK2cv")):
+            own.add(f[2])
     syms = subprocess.check_output(["readelf", "-Ws", "--dyn-syms", REF], text=True).splitlines()
     funcs, objs = set(), set()
     for ln in syms:
         f = ln.split()
         if len(f) < 8 or f[6] != "UND" or "@" in f[7]:
             continue
-        if f[3] == "FUNC" and f[7] not in OWN:
+        if f[3] == "FUNC" and f[7] not in own:
             funcs.add(f[7])
         elif f[3] == "OBJECT":
             objs.add(f[7])
@@ -58,10 +63,9 @@ def main():
         sh(["gcc", "-shared", "-fPIC", "-w", "-Wl,-soname," + so, "-o", os.path.join(STUBS, so),
             os.path.join(STUBS, src)])
     probe = os.path.join(OUT, "probe")
-    here = os.path.dirname(os.path.abspath(__file__))
     sh(["gcc", "-c", "-O2", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "oracle"),
         os.path.join(ROOT, "oracle/orb_oracle.c"), "-o", os.path.join(OUT, "orb_oracle_probe.o")])
-    sh(["g++", "-O1", "-std=c++14", "-rdynamic", "-fno-builtin-malloc", os.path.join(here, "probe.cpp"),
+    sh(["g++", "-rdynamic", os.path.join(OUT, "probe.o"),
         os.path.join(OUT, "orb_oracle_probe.o"), "-o", probe, "-L/root/reference/lib", "-l:libORB_SLAM2.so",
         "-L" + STUBS, "-Wl,--allow-shlib-undefined", "-Wl,-rpath-link," + STUBS, "-ldl", "-lm"])
     env = dict(os.environ)

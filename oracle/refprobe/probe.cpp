@@ -53,6 +53,12 @@ static void arena_reset() { g_arena_off = 0; }
 namespace cv {
 struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
 struct Range { int start, end; };
+// cv::Size_ of 3.3 has a user-provided copy constructor: by-value arguments travel by reference (Itanium ABI)
+template <class T> struct Size_ { T width, height; Size_() : width(0), height(0) {} Size_(const Size_ &s) : width(s.width), height(s.height) {} };
+template <class T> struct Rect_ { T x, y, width, height; };
+template <class T> struct Scalar_ { T v[4]; };
+struct _OutputArray;
+struct MatExpr;
 struct Mat {  // OpenCV 3.3 layout, 96 bytes
     int flags, dims, rows, cols;
     unsigned char *data;
@@ -62,16 +68,43 @@ struct Mat {  // OpenCV 3.3 layout, 96 bytes
     size_t *step_p;
     size_t step_buf[2];
     Mat() {}
+    Mat(const Mat &m) { memcpy((void *)this, &m, sizeof(Mat)); size_p = &rows; step_p = step_buf; u = nullptr; }
+    Mat &operator=(const Mat &m) { memcpy((void *)this, &m, sizeof(Mat)); size_p = &rows; step_p = step_buf; u = nullptr; return *this; }
+    ~Mat();
     Mat(const Mat &m, const Range &rowRange, const Range &colRange);
+    Mat(const Mat &m, const Rect_<int> &roi);
     void deallocate();
+    void create(int ndims, const int *sizes, int type);
+    void copyTo(const _OutputArray &dst) const;
+    void copySize(const Mat &m);
+    static MatExpr zeros(int rows, int cols, int type);
 };
-struct _InputArray { int flags; void *obj; int sz_w, sz_h; };
+struct _InputArray {
+    int flags; void *obj; int sz_w, sz_h;
+    int kind() const;
+    bool empty() const;
+    Mat getMat_(int idx) const;
+};
+struct _OutputArray : _InputArray {
+    void create(int rows, int cols, int type, int i, bool allowTransposed, int fixedDepthMask) const;
+    void release() const;
+};
+struct MatOp {  // vtable: [0],[1] destructors, [2] elementWise, [3] assign  (the binary calls slot 3 after Mat::zeros)
+    virtual ~MatOp() {}
+    virtual bool elementWise(const MatExpr &) const { return false; }
+    virtual void assign(const MatExpr &, Mat &m, int type) const;
+};
+struct MatExpr { const MatOp *op; int flags; Mat a, b, c; double alpha, beta; Scalar_<double> s; };
+void resize(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
+void copyMakeBorder(const _InputArray &, const _OutputArray &, int, int, int, int, int, const Scalar_<double> &);
+void GaussianBlur(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
 float fastAtan2(float y, float x);
 void fastFree(void *);
 void FAST(const _InputArray &, std::vector<KeyPoint> &, int, bool);
 }  // namespace cv
 static_assert(sizeof(cv::Mat) == 96, "cv::Mat 3.3 layout");
 static_assert(sizeof(cv::KeyPoint) == 28, "cv::KeyPoint layout");
+static_assert(sizeof(cv::MatExpr) == 352, "cv::MatExpr 3.3 layout");
 
 static void mat_init(cv::Mat *m, unsigned char *data, int rows, int cols, size_t pitch)
 {
@@ -127,6 +160,85 @@ void cv::FAST(const _InputArray &arr, std::vector<KeyPoint> &kps, int th, bool n
     }
 }
 
+// ---- tier C: the OpenCV 3.3 entry points ORBextractor::operator() / ComputePyramid reach (so@0x76da0, so@0x70430).
+// Headers and ownership only (u = NULL: nothing is reference counted, memory comes from the bump arena); the pixel
+// work is done by oracle/orb_oracle.c.
+static void mat_empty(cv::Mat *m)
+{
+    memset((void *)m, 0, sizeof(*m));
+    m->flags = 0x42FF0000; m->size_p = &m->rows; m->step_p = m->step_buf;
+}
+static void mat_alloc(cv::Mat *m, int rows, int cols, int type)
+{
+    if (type != 0) { fprintf(stderr, "refprobe: unexpected Mat type %d\n", type); abort(); }
+    if (m->data && m->dims == 2 && m->rows == rows && m->cols == cols) return;   // Mat::create keeps a matching buffer
+    unsigned char *d = (unsigned char *)bump((size_t)rows * cols + 64);
+    mat_init(m, d, rows, cols, (size_t)cols);
+    m->flags |= 0x4000;  // CONTINUOUS
+}
+cv::Mat::~Mat() {}
+cv::Mat::Mat(const Mat &m, const Rect_<int> &roi)
+{
+    memcpy((void *)this, &m, sizeof(Mat));
+    size_p = &rows; step_p = step_buf; u = nullptr;
+    data += step_buf[0] * roi.y + roi.x; rows = roi.height; cols = roi.width;
+    if (roi.width < m.cols) flags &= ~0x4000;
+}
+void cv::Mat::create(int ndims, const int *sizes, int type)
+{
+    if (ndims != 2) { fprintf(stderr, "refprobe: Mat::create ndims %d\n", ndims); abort(); }
+    mat_alloc(this, sizes[0], sizes[1], type & 0xFFF);
+}
+void cv::Mat::copySize(const Mat &m) { dims = m.dims; rows = m.rows; cols = m.cols; step_buf[0] = m.step_buf[0]; step_buf[1] = m.step_buf[1]; }
+void cv::Mat::copyTo(const _OutputArray &dst) const
+{
+    Mat *d = (Mat *)dst.obj;
+    mat_alloc(d, rows, cols, flags & 0xFFF);
+    for (int y = 0; y < rows; y++) memcpy(d->data + d->step_buf[0] * y, data + step_buf[0] * y, (size_t)cols);
+}
+void cv::MatOp::assign(const MatExpr &, Mat &m, int) const   // the only expression the path builds: Mat::zeros
+{
+    for (int y = 0; y < m.rows; y++) memset(m.data + m.step_buf[0] * y, 0, (size_t)m.cols);
+}
+static cv::MatOp g_zero_op;
+static int g_zeros_rows = 0;
+cv::MatExpr cv::Mat::zeros(int rows, int cols, int type)
+{
+    MatExpr e;
+    e.op = &g_zero_op; e.flags = 0; e.alpha = 0; e.beta = 0; memset(&e.s, 0, sizeof(e.s));
+    mat_empty(&e.a); mat_empty(&e.b); mat_empty(&e.c);
+    g_zeros_rows = rows; (void)cols; (void)type;
+    return e;
+}
+int cv::_InputArray::kind() const { return flags & (31 << 16); }
+bool cv::_InputArray::empty() const { const Mat *m = (const Mat *)obj; return m->data == nullptr || m->rows * m->cols == 0; }
+cv::Mat cv::_InputArray::getMat_(int) const { return *(const Mat *)obj; }
+void cv::_OutputArray::create(int rows, int cols, int type, int, bool, int) const { mat_alloc((Mat *)obj, rows, cols, type & 0xFFF); }
+void cv::_OutputArray::release() const { mat_empty((Mat *)obj); }
+void cv::resize(const _InputArray &src, const _OutputArray &dst, Size_<int> sz, double, double, int interp)
+{
+    const Mat *s = (const Mat *)src.obj; Mat *d = (Mat *)dst.obj;
+    if (interp != 1 || d->cols != sz.width || d->rows != sz.height) { fprintf(stderr, "refprobe: unexpected resize call\n"); abort(); }
+    orc_resize_linear_8u(s->data, s->cols, s->rows, (ptrdiff_t)s->step_buf[0], d->data, d->cols, d->rows, (ptrdiff_t)d->step_buf[0]);
+}
+void cv::copyMakeBorder(const _InputArray &src, const _OutputArray &dst, int t, int b, int l, int r, int type, const Scalar_<double> &)
+{
+    const Mat *s = (const Mat *)src.obj; Mat *d = (Mat *)dst.obj;
+    if (t != 19 || b != 19 || l != 19 || r != 19 || (type & 15) != 4) { fprintf(stderr, "refprobe: unexpected copyMakeBorder call\n"); abort(); }
+    mat_alloc(d, s->rows + 38, s->cols + 38, 0);
+    unsigned char *inner = d->data + 19 * d->step_buf[0] + 19;
+    if (inner != s->data)
+        for (int y = 0; y < s->rows; y++) memmove(inner + d->step_buf[0] * y, s->data + s->step_buf[0] * y, (size_t)s->cols);
+    orc_border_reflect101(d->data, s->cols, s->rows, (ptrdiff_t)d->step_buf[0], 19);
+}
+void cv::GaussianBlur(const _InputArray &src, const _OutputArray &dst, Size_<int> k, double sx, double sy, int border)
+{
+    const Mat *s = (const Mat *)src.obj; Mat *d = (Mat *)dst.obj;
+    if (k.width != 7 || k.height != 7 || sx != 2.0 || sy != 2.0 || border != 4) { fprintf(stderr, "refprobe: unexpected GaussianBlur call\n"); abort(); }
+    mat_alloc(d, s->rows, s->cols, 0);
+    orc_gaussian_blur7_8u(s->data, (ptrdiff_t)s->step_buf[0], d->data, (ptrdiff_t)d->step_buf[0], s->cols, s->rows);
+}
+
 // ---------------------------------------------------------------- look-alike reference classes
 namespace ORB_SLAM2 {
 class ORBextractor {
@@ -135,6 +247,8 @@ public:
     std::vector<cv::KeyPoint> DistributeOctTree(const std::vector<cv::KeyPoint> &, const int &, const int &,
                                                 const int &, const int &, const int &, const int &);
     void ComputeKeyPointsOctTree(std::vector<std::vector<cv::KeyPoint>> &);
+    void operator()(const cv::_InputArray &image, const cv::_InputArray &mask, std::vector<cv::KeyPoint> &keypoints,
+                    const cv::_OutputArray &descriptors);
     char storage[1024];
 };
 class ORBmatcher {
@@ -419,6 +533,45 @@ int main(int argc, char **argv)
         }
         fprintf(JC, "]}\n"); fclose(JC);
         fprintf(JG, "]}\n"); fclose(JG);
+    }
+    // ------------------------------------------------------------ C: the whole ORBextractor::operator() (glue)
+    {
+        path = std::string(outdir) + "/ref_glue_operator.json";
+        FILE *JO = fopen(path.c_str(), "w");
+        fprintf(JO, "{\"_doc\": \"ORBextractor::operator() (so@0x76da0) executed from the reference binary on tests/refgen.py:synth_image; cv::resize / copyMakeBorder / "
+                    "GaussianBlur / FAST / fastAtan2 are this repo's restatements (oracle/orb_oracle.c), everything else -- pyramid sizes, cell loop, octree, "
+                    "orientation, blur-then-BRIEF with sincosf and FMA, scaling, output order -- is the reference's machine code. kp: x,y,size,angle,response "
+                    "bit patterns, octave; desc: hex\", \"cases\": [\n");
+        struct { int w, h, nf; uint64_t seed; } oc[] = {{640, 480, 1000, 9101}, {320, 240, 500, 9102}, {752, 480, 1200, 9103}};
+        const int NO = 3;
+        g_fast_mode = 1; g_force_retry = 0; g_mode = 1;
+        for (int c = 0; c < NO; c++) {
+            arena_reset();
+            ORBextractor *e = new ORBextractor(oc[c].nf, 1.2f, 8, 20, 7);
+            std::vector<unsigned char> img;
+            synth_image(oc[c].seed, oc[c].w, oc[c].h, img);
+            cv::Mat im, dm, mm;
+            mat_init(&im, img.data(), oc[c].h, oc[c].w, (size_t)oc[c].w);
+            im.flags |= 0x4000;
+            mat_empty(&dm); mat_empty(&mm);
+            cv::_InputArray ia; ia.flags = 0x01010000; ia.obj = &im; ia.sz_w = ia.sz_h = 0;
+            cv::_InputArray ma; ma.flags = 0x01010000; ma.obj = &mm; ma.sz_w = ma.sz_h = 0;
+            cv::_OutputArray oa; oa.flags = 0x02010000; oa.obj = &dm; oa.sz_w = oa.sz_h = 0;
+            std::vector<cv::KeyPoint> kps;
+            (*e)(ia, ma, kps, oa);
+            std::vector<float> flat; std::vector<int> oct;
+            for (const cv::KeyPoint &k : kps) { flat.push_back(k.x); flat.push_back(k.y); flat.push_back(k.size); flat.push_back(k.angle); flat.push_back(k.response); oct.push_back(k.octave); }
+            fprintf(JO, "{\"seed\": %llu, \"w\": %d, \"h\": %d, \"nfeatures\": %d, \"n\": %d, \"desc_rows\": %d, ", (unsigned long long)oc[c].seed, oc[c].w, oc[c].h,
+                    oc[c].nf, (int)kps.size(), dm.rows);
+            J = JO;
+            jarr_f("kp", flat);
+            jarr_i("octave", oct);
+            fprintf(JO, "\"desc\": \"");
+            for (int r = 0; r < dm.rows; r++)
+                for (int b = 0; b < 32; b++) fprintf(JO, "%02x", dm.data[dm.step_buf[0] * r + b]);
+            fprintf(JO, "\"}%s\n", c + 1 < NO ? "," : "");
+        }
+        fprintf(JO, "]}\n"); fclose(JO);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

@@ -105,3 +105,24 @@ def test_orb_errors():
     with pytest.raises(PlfError):
         ORBextractor(max_width=40, max_height=40)   # the reference divides by zero on such sizes
     ext.close()
+
+
+def test_gpu_equals_reference_operator_fixture():
+    """HIP extractor vs tests/golden/ref_glue_operator.json: the output of the reference binary's own
+    ORBextractor::operator() (so@0x76da0) on the same seeded images, key points and descriptors bit for bit."""
+    import json, os
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_operator.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for c in cases:
+        img = refgen.synth_image(c["seed"], c["w"], c["h"])
+        ext = ORBextractor(nfeatures=c["nfeatures"], max_width=c["w"], max_height=c["h"])
+        kps, desc = ext(img)
+        ref = np.array(c["kp"], np.uint32).view(np.float32).reshape(-1, 5)
+        assert len(kps) == c["n"], c["w"]
+        for j, f in enumerate(("x", "y", "size", "angle", "response")):
+            assert np.array_equal(kps[f].view(np.uint32), ref[:, j].view(np.uint32)), (c["w"], f)
+        assert np.array_equal(kps["octave"], np.array(c["octave"], np.int32)), c["w"]
+        assert np.array_equal(desc, np.frombuffer(bytes.fromhex(c["desc"]), np.uint8).reshape(-1, 32)), c["w"]
+
