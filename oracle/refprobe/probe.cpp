@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 #include <dlfcn.h>
+#include <execinfo.h>
 #include <link.h>
 
 #include "../oracle.h"
@@ -36,7 +37,7 @@ static void *bump(size_t n)
 {
     if (!g_arena) { g_arena_cap = (size_t)3 << 30; g_arena = (char *)malloc(g_arena_cap); }
     n = (n + 15) & ~(size_t)15;
-    if (g_arena_off + n > g_arena_cap) { fprintf(stderr, "arena exhausted\n"); abort(); }
+    if (g_arena_off + n > g_arena_cap) { fprintf(stderr, "arena exhausted: request %zu at offset %zu\n", n, g_arena_off); void *bt[16]; int k = backtrace(bt, 16); backtrace_symbols_fd(bt, k, 2); abort(); }
     void *p = g_arena + g_arena_off;
     g_arena_off += n;
     return p;
@@ -47,7 +48,7 @@ void operator delete(void *) noexcept {}
 void operator delete[](void *) noexcept {}
 void operator delete(void *, size_t) noexcept {}
 void operator delete[](void *, size_t) noexcept {}
-static void arena_reset() { g_arena_off = 0; }
+static void arena_reset() {}   // (no reuse: long-lived std::vectors of this file also live in the arena)
 
 // ---------------------------------------------------------------- look-alike OpenCV 3.3 PODs
 namespace cv {
@@ -251,9 +252,15 @@ public:
                     const cv::_OutputArray &descriptors);
     char storage[1024];
 };
+class MapPoint;
+class Frame {   // only the exported statics are named; the object itself is hand-laid raw memory (tier D)
+public:
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+};
 class ORBmatcher {
 public:
     ORBmatcher(float nnratio, bool checkOri);
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -572,6 +579,122 @@ int main(int argc, char **argv)
             fprintf(JO, "\"}%s\n", c + 1 < NO ? "," : "");
         }
         fprintf(JO, "]}\n"); fclose(JO);
+    }
+    // ------------------------------------------------------------ D: ORBmatcher::SearchByProjection(Frame&, map points, th) (glue)
+    // Frame / MapPoint objects are hand-laid at the offsets the binary's code uses (read from the disassembly of
+    // so@0x79f10, Frame::GetFeaturesInArea so@0xfbc60, MapPoint::isBad / Observations / GetDescriptor):
+    //   Frame: N @0xec, mvKeysUn @0x120, mvuRight @0x138, mDescriptors @0x1c8, mvpMapPoints @0x288, mGrid[64][48] @0x2c8,
+    //          mvScaleFactors @0x12348; statics mnMinX/mnMinY/mfGridElement{Width,Height}Inv are exported data symbols
+    //   MapPoint: nObs @0x18, mTrackProjX/Y/XR @0x1c/0x20/0x24, mnTrackScaleLevel @0x28, mTrackViewCos @0x2c,
+    //          mbTrackInView @0x30, mDescriptor @0x1c8, mbBad @0x238, mutexes zero-initialised
+    {
+        path = std::string(outdir) + "/ref_glue_search_map.json";
+        FILE *JS = fopen(path.c_str(), "w");
+        fprintf(JS, "{\"_doc\": \"ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (so@0x79f10) with Frame::GetFeaturesInArea, MapPoint::isBad/"
+                    "Observations/GetDescriptor, DescriptorDistance, RadiusByViewingCos all executed from the reference binary on hand-laid objects. floats as "
+                    "uint32 bit patterns; match[k] = index of the map point assigned to key point k, -1 none, -2 occupied before the call by a point with "
+                    "observations\", \"cases\": [\n");
+        struct { int n, m; float th; int with_ur; uint64_t seed; } sc[] = {{400, 1500, 3.0f, 0, 9201}, {300, 900, 1.0f, 1, 9202}, {500, 2500, 5.0f, 1, 9203}};
+        const int NS = 3;
+        for (int c = 0; c < NS; c++) {
+            arena_reset();
+            rng_seed(sc[c].seed);
+            const int N = sc[c].n, M = sc[c].m;
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            std::vector<cv::KeyPoint> keys(N);
+            std::vector<float> uright(N);
+            std::vector<uint8_t> desc((size_t)N * 32);
+            for (int i = 0; i < N; i++) {
+                keys[i].x = 20.f + uf() * 600.f; keys[i].y = 20.f + uf() * 440.f; keys[i].size = 31.f; keys[i].angle = uf() * 360.f;
+                keys[i].response = 30.f; keys[i].octave = (int)rng_below(8); keys[i].class_id = -1;
+                uright[i] = (sc[c].with_ur && uf() < 0.7f) ? keys[i].x - (2.f + uf() * 28.f) : -1.f;
+                for (int b = 0; b < 32; b++) desc[(size_t)i * 32 + b] = (uint8_t)rng_below(256);
+            }
+            // map points
+            std::vector<float> px(M), py(M), pxr(M), vc(M);
+            std::vector<int> lvl(M), nobs(M), inview(M), bad(M);
+            std::vector<uint8_t> mdesc((size_t)M * 32);
+            for (int m = 0; m < M; m++) {
+                const int src = (int)rng_below(N);
+                const bool real = uf() < 0.6f;
+                px[m] = real ? keys[src].x + (uf() - 0.5f) * 6.f : -40.f + uf() * 720.f;
+                py[m] = real ? keys[src].y + (uf() - 0.5f) * 6.f : -40.f + uf() * 560.f;
+                lvl[m] = real ? std::min(7, keys[src].octave + (int)rng_below(2)) : (int)rng_below(8);
+                for (int b = 0; b < 32; b++) mdesc[(size_t)m * 32 + b] = real ? desc[(size_t)src * 32 + b] : (uint8_t)rng_below(256);
+                if (real) { const int flips = (int)rng_below(41); for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); mdesc[(size_t)m * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); } }
+                vc[m] = 0.99f + uf() * 0.01f;
+                inview[m] = uf() < 0.9f; bad[m] = uf() < 0.05f;
+                pxr[m] = px[m] - (2.f + uf() * 28.f);
+                nobs[m] = uf() < 0.1f ? 0 : 1 + (int)rng_below(4);
+            }
+            // key points already holding a map point before the call: with observations (blocks) or without (does not)
+            std::vector<int> init(N, -1);
+            char *frame = (char *)bump(0x12800); memset(frame, 0, 0x12800);
+            char *mps = (char *)bump((size_t)(M + 2) * 0x300); memset(mps, 0, (size_t)(M + 2) * 0x300);
+            char *occ_obs = mps + (size_t)M * 0x300, *occ_noobs = mps + (size_t)(M + 1) * 0x300;
+            *(int *)(occ_obs + 0x18) = 2; *(int *)(occ_noobs + 0x18) = 0;
+            std::vector<void *> fmp(N, nullptr);
+            for (int i = 0; i < N; i++) { const float u = uf(); if (u < 0.08f) { fmp[i] = occ_obs; init[i] = -2; } else if (u < 0.12f) fmp[i] = occ_noobs; }
+            cv::Mat *mdm = (cv::Mat *)bump(sizeof(cv::Mat));
+            std::vector<void *> vp(M);
+            for (int m = 0; m < M; m++) {
+                char *o = mps + (size_t)m * 0x300;
+                *(int *)(o + 0x18) = nobs[m]; *(float *)(o + 0x1c) = px[m]; *(float *)(o + 0x20) = py[m]; *(float *)(o + 0x24) = pxr[m];
+                *(int *)(o + 0x28) = lvl[m]; *(float *)(o + 0x2c) = vc[m]; *(bool *)(o + 0x30) = inview[m] != 0; *(bool *)(o + 0x238) = bad[m] != 0;
+                mat_init((cv::Mat *)(o + 0x1c8), &mdesc[(size_t)m * 32], 1, 32, 32);
+                ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
+                vp[m] = o;
+            }
+            (void)mdm;
+            // frame
+            *(int *)(frame + 0xec) = N;
+            void **v;
+            v = (void **)(frame + 0x120); v[0] = keys.data(); v[1] = keys.data() + N; v[2] = keys.data() + N;
+            v = (void **)(frame + 0x138); v[0] = uright.data(); v[1] = uright.data() + N; v[2] = uright.data() + N;
+            mat_init((cv::Mat *)(frame + 0x1c8), desc.data(), N, 32, 32); ((cv::Mat *)(frame + 0x1c8))->flags |= 0x4000;
+            v = (void **)(frame + 0x288); v[0] = fmp.data(); v[1] = fmp.data() + N; v[2] = fmp.data() + N;
+            v = (void **)(frame + 0x12348); v[0] = scale; v[1] = scale + 8; v[2] = scale + 8;
+            Frame::mnMinX = 0.f; Frame::mnMinY = 0.f; Frame::mnMaxX = 640.f; Frame::mnMaxY = 480.f;
+            Frame::mfGridElementWidthInv = 64.f / (Frame::mnMaxX - Frame::mnMinX); Frame::mfGridElementHeightInv = 48.f / (Frame::mnMaxY - Frame::mnMinY);
+            // Frame::AssignFeaturesToGrid (so@0xf9120): push_back(i) into cell (round((x - minX) * invW), round((y - minY) * invH))
+            std::vector<std::vector<size_t>> cells(64 * 48);
+            for (int i = 0; i < N; i++) {
+                const int gx = (int)roundf((keys[i].x - Frame::mnMinX) * Frame::mfGridElementWidthInv), gy = (int)roundf((keys[i].y - Frame::mnMinY) * Frame::mfGridElementHeightInv);
+                if (gx < 0 || gx >= 64 || gy < 0 || gy >= 48) continue;
+                cells[gx * 48 + gy].push_back((size_t)i);
+            }
+            for (int cidx = 0; cidx < 64 * 48; cidx++) {
+                v = (void **)(frame + 0x2c8 + (size_t)cidx * 24);
+                v[0] = cells[cidx].data(); v[1] = cells[cidx].data() + cells[cidx].size(); v[2] = v[1];
+            }
+            ORBmatcher *mt = new ORBmatcher(0.8f, true);
+            const std::vector<MapPoint *> &vpr = *(const std::vector<MapPoint *> *)&vp;
+            const int nm = mt->SearchByProjection(*(Frame *)frame, vpr, sc[c].th);
+            std::vector<int> match(N);
+            for (int i = 0; i < N; i++) {
+                const char *q = (const char *)fmp[i];
+                match[i] = q == nullptr ? -1 : q == occ_obs ? -2 : q == occ_noobs ? -1 : (int)((q - mps) / 0x300);
+            }
+            // fixture: inputs + result
+            std::vector<float> kx(N), ky(N); std::vector<int> ko(N), iv(M), ob(M);
+            for (int i = 0; i < N; i++) { kx[i] = keys[i].x; ky[i] = keys[i].y; ko[i] = keys[i].octave; }
+            for (int m = 0; m < M; m++) { iv[m] = inview[m] && !bad[m]; ob[m] = nobs[m] > 0; }
+            std::vector<float> scv(scale, scale + 8);
+            uint32_t thb; memcpy(&thb, &sc[c].th, 4);
+            fprintf(JS, "{\"n\": %d, \"m\": %d, \"th_bits\": %u, \"with_uright\": %d, \"nmatches\": %d, ", N, M, thb, sc[c].with_ur, nm);
+            J = JS;
+            jarr_f("x", kx); jarr_f("y", ky); jarr_i("octave", ko); jarr_f("uright", uright); jarr_f("scale", scv);
+            jarr_f("proj_x", px); jarr_f("proj_y", py); jarr_f("proj_xr", pxr); jarr_i("level", lvl); jarr_f("view_cos", vc);
+            jarr_i("in_view", iv); jarr_i("obs_positive", ob); jarr_i("init", init); jarr_i("match", match);
+            fprintf(JS, "\"desc\": \"");
+            for (size_t b = 0; b < desc.size(); b++) fprintf(JS, "%02x", desc[b]);
+            fprintf(JS, "\", \"mp_desc\": \"");
+            for (size_t b = 0; b < mdesc.size(); b++) fprintf(JS, "%02x", mdesc[b]);
+            fprintf(JS, "\"}%s\n", c + 1 < NS ? "," : "");
+        }
+        fprintf(JS, "]}\n"); fclose(JS);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

@@ -69,3 +69,23 @@ def octree_case(seed, cluster, resp_levels):
             x = W - 1
         k[i] = (x, y, 7 + g.below(resp_levels))
     return W, H, N, k
+
+
+def load_search_map_cases(path):
+    """tests/golden/ref_glue_search_map.json -> list of dicts with numpy inputs and the reference binary's result"""
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = []
+    for c in json.load(open(path))["cases"]:
+        N, M = c["n"], c["m"]
+        kps = np.zeros(N, dtype=kp_dtype)
+        kps["x"] = f32(c["x"]); kps["y"] = f32(c["y"]); kps["octave"] = np.array(c["octave"], np.int32)
+        mp = dict(proj_x=f32(c["proj_x"]), proj_y=f32(c["proj_y"]), proj_xr=f32(c["proj_xr"]), level=np.array(c["level"], np.int32),
+                  view_cos=f32(c["view_cos"]), in_view=np.array(c["in_view"], np.uint8),
+                  desc=np.frombuffer(bytes.fromhex(c["mp_desc"]), np.uint8).reshape(M, 32).copy(), obs_positive=np.array(c["obs_positive"], np.uint8))
+        out.append(dict(kps=kps, desc=np.frombuffer(bytes.fromhex(c["desc"]), np.uint8).reshape(N, 32).copy(),
+                        uright=f32(c["uright"]) if c["with_uright"] else None, scale=f32(c["scale"]), mp=mp,
+                        th=float(np.array([c["th_bits"]], np.uint32).view(np.float32)[0]), init=np.array(c["init"], np.int32),
+                        match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
+    return out

@@ -166,3 +166,26 @@ def test_descriptor_distance_and_matrix():
     out = np.zeros((50, 70), np.int32)
     L.check(L.lib().plf_hamming256_matrix(L.vp(a), 50, L.vp(b), 70, L.vp(out), L.MEM_HOST, 0, None), "plf_hamming256_matrix")
     assert np.array_equal(out, D)
+
+
+def test_gpu_equals_reference_search_by_projection_fixture():
+    """HIP matcher vs tests/golden/ref_glue_search_map.json: the result of the reference binary's own
+    ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) on the same inputs."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_search_map_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_search_map.json")):
+        N = len(c["kps"])
+        m = Matcher(max_keypoints=1024, max_mappoints=4096, max_batch=1)
+        dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"])
+        du = _dev(c["uright"]) if c["uright"] is not None else None
+        dmp = {k: _dev(v) for k, v in c["mp"].items()}
+        match = _dev(c["init"][None, :]); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchByProjection([Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), du)], dmp, c["th"], 0.8, match, N, nm)
+        torch.cuda.synchronize()
+        assert int(nm[0]) == c["nmatches"]
+        assert np.array_equal(match[0].cpu().numpy(), c["match"])
+        m.close()
+
