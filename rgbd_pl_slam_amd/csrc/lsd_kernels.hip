@@ -218,8 +218,10 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
             G.a = yy * C.W + xx;
             G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
             G.w = ang_load(C, G.a);
-            const double2 c = C.cs[G.a];
-            G.csx = c.x; G.csy = c.y;
+            if (G.w < 0x80000000u) {   // only candidates can be accepted: no 16-byte increment fetch for NOTDEF / used pixels
+                const double2 c = C.cs[G.a];
+                G.csx = c.x; G.csy = c.y;
+            }
         }
     }
     return G;
