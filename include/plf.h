@@ -211,6 +211,28 @@ int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const
                                 const plf_pose_pair *pose, float th, int32_t mono, int32_t check_orientation,
                                 int32_t *match_of_kp, int32_t *nmatches, void *stream);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
+ * include/ORBmatcher.h:104 (so@0x80150) -- the tracker's reference-keyframe / relocalisation matcher.
+ * One view per (keyframe, frame) pair, all arrays in DEVICE memory.  The DBoW2 feature vectors
+ * (std::map<NodeId, std::vector<unsigned>>, KeyFrame::mFeatVec / Frame::mFeatVec) are passed flattened in key order:
+ * node ids (ascending), CSR starts (nodes + 1), feature indices.  kf_has_mp[i] = pKF->GetMapPointMatches()[i] != NULL
+ * && !isBad(); kf_angle = pKF->mvKeysUn[i].angle, f_angle = F.mvKeys[j].angle.  mfNNratio and mbCheckOrientation are
+ * the ORBmatcher constructor arguments.
+ * match_of_f (device, n_pairs x stride int32, overwritten): index of the keyframe feature whose map point frame
+ * feature j received (vpMapPointMatches[j] = vpMapPointsKF[match_of_f[j]]), -1 = NULL.  nmatches (device, n_pairs). */
+typedef struct plf_bow_view {
+    int32_t n_kf, n_f;
+    const uint8_t *kf_desc, *f_desc;
+    const float *kf_angle, *f_angle;
+    const uint8_t *kf_has_mp;
+    int32_t kf_nodes, f_nodes;
+    const uint32_t *kf_node_id, *f_node_id;
+    const int32_t *kf_node_start, *f_node_start;
+    const int32_t *kf_feat, *f_feat;
+} plf_bow_view;
+int plf_match_bow(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation,
+                  int32_t *match_of_f, int32_t stride, int32_t *nmatches, void *stream);
+
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as used by LSDmatcher (include/LSDmatcher.h:19-35).
  * out: nq x 2 plf_dmatch in `mem`. */
 int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const uint8_t *train, int32_t nt,

@@ -141,6 +141,11 @@ public:
         check(plf_match_project_lastframe(m_, &CurrentFrame, &LastFrame, &pose, th, bMono, mbCheckOrientation, match_of_kp_dev, nmatches_dev, stream),
               "SearchByProjection(last frame)");
     }
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
+    void SearchByBoW(const plf_bow_view &pKF_and_F, int32_t *match_of_f_dev, int32_t *nmatches_dev, void *stream = nullptr)
+    {
+        check(plf_match_bow(m_, &pKF_and_F, 1, mfNNratio, mbCheckOrientation, match_of_f_dev, pKF_and_F.n_f, nmatches_dev, stream), "SearchByBoW");
+    }
 
 private:
     plf_matcher *m_;

@@ -278,6 +278,75 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
     return nmatches;
 }
 
+/* ---------------------------------------------------------------- SearchByBoW */
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)  include/ORBmatcher.h:104,
+ * so@0x80150 (listing read; executed from the binary for tests/golden/ref_glue_bow.json).
+ * The two DBoW2 feature vectors (std::map<NodeId, vector<unsigned>>) arrive flattened in key order:
+ * node ids (ascending, unique), CSR starts, feature indices.  Walk of the binary: nodes present in both maps are
+ * visited in key order (the lower_bound jumps only skip unmatched keys); for every keyframe feature of the node that
+ * holds a good map point (kf_has_mp = vpMapPointsKF[i] != NULL && !isBad()): best / second-best Hamming distance
+ * over the node's frame features that are still unmatched (running scan: ties keep the first index, the second-best
+ * takes equal values), accept if best <= TH_LOW (so@0x808e0: cmpl $0x32) and float(best) < mfNNratio * float(second)
+ * (so@0x808fc-0x80914), rotation histogram bin = roundf(rot * (1/12)) with rot = kf_angle - f_angle (+360 if
+ * negative), bin 30 -> 0 (so@0x80980-0x809ad), then every match outside the three dominant bins is removed.
+ * match_of_f[j] = keyframe feature index whose map point frame feature j received, -1 otherwise (all entries are
+ * reset first, as the reference re-creates vpMapPointMatches).  Returns nmatches. */
+int orc_search_by_bow(int n_kf, int n_f, const uint8_t *kf_desc, const uint8_t *f_desc, const float *kf_angle, const float *f_angle,
+                      const uint8_t *kf_has_mp, int kf_nodes, const uint32_t *kf_node_id, const int32_t *kf_node_start,
+                      const int32_t *kf_feat, int f_nodes, const uint32_t *f_node_id, const int32_t *f_node_start,
+                      const int32_t *f_feat, float nnratio, int checkOri, int32_t *match_of_f)
+{
+    (void)n_kf;
+    int nmatches = 0;
+    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (n_f > 0 ? n_f : 1));
+    int histN[HISTO_LENGTH];
+    memset(histN, 0, sizeof(histN));
+    for (int j = 0; j < n_f; j++) match_of_f[j] = -1;
+    int a = 0, b = 0;
+    while (a < kf_nodes && b < f_nodes) {
+        if (kf_node_id[a] < f_node_id[b]) { a++; continue; }
+        if (kf_node_id[a] > f_node_id[b]) { b++; continue; }
+        for (int p = kf_node_start[a]; p < kf_node_start[a + 1]; p++) {
+            const int ikf = kf_feat[p];
+            if (!kf_has_mp[ikf]) continue;
+            const uint8_t *dKF = kf_desc + 32 * (size_t)ikf;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int q = f_node_start[b]; q < f_node_start[b + 1]; q++) {
+                const int jf = f_feat[q];
+                if (match_of_f[jf] >= 0) continue;
+                const int dist = orc_hamming256(dKF, f_desc + 32 * (size_t)jf);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                match_of_f[bestIdxF] = ikf;
+                if (checkOri) {
+                    float rot = kf_angle[ikf] - f_angle[bestIdxF];
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * (1.0f / 12.0f));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin * n_f + histN[bin]++] = bestIdxF;
+                }
+                nmatches++;
+            }
+        }
+        a++; b++;
+    }
+    if (checkOri) {
+        int i1, i2, i3;
+        orc_three_maxima(histN, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int bnum = 0; bnum < HISTO_LENGTH; bnum++) {
+            if (bnum == i1 || bnum == i2 || bnum == i3) continue;
+            for (int j = 0; j < histN[bnum]; j++) {
+                match_of_f[rotHist[bnum * n_f + j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    free(rotHist);
+    return nmatches;
+}
+
 /* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {

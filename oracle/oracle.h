@@ -127,6 +127,10 @@ int orc_lines_in_area(const orc_lineframe *F, float x1, float y1, float x2, floa
                       int maxLevel, int *out, int cap);
 int orc_search_by_projection_lines(const orc_lineframe *F, const orc_maplines *ML, float th, float nnratio,
                                    int32_t *match_of_line);
+int orc_search_by_bow(int n_kf, int n_f, const uint8_t *kf_desc, const uint8_t *f_desc, const float *kf_angle, const float *f_angle,
+                      const uint8_t *kf_has_mp, int kf_nodes, const uint32_t *kf_node_id, const int32_t *kf_node_start,
+                      const int32_t *kf_feat, int f_nodes, const uint32_t *f_node_id, const int32_t *f_node_start,
+                      const int32_t *f_feat, float nnratio, int checkOri, int32_t *match_of_f);
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq x 2*/,
                      int32_t *dist /*nq x 2*/);
 

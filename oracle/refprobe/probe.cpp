@@ -22,6 +22,7 @@
 #include <cmath>
 #include <climits>
 #include <new>
+#include <map>
 #include <string>
 #include <vector>
 #include <dlfcn.h>
@@ -253,6 +254,7 @@ public:
     char storage[1024];
 };
 class MapPoint;
+class KeyFrame;
 class Frame {   // only the exported statics are named; the object itself is hand-laid raw memory (tier D)
 public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
@@ -261,6 +263,7 @@ class ORBmatcher {
 public:
     ORBmatcher(float nnratio, bool checkOri);
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th);
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -695,6 +698,95 @@ int main(int argc, char **argv)
             fprintf(JS, "\"}%s\n", c + 1 < NS ? "," : "");
         }
         fprintf(JS, "]}\n"); fclose(JS);
+    }
+    // ------------------------------------------------------------ E: ORBmatcher::SearchByBoW(KeyFrame*, Frame&, matches) (glue)
+    // KeyFrame (offsets from so@0x80150 and KeyFrame::GetMapPointMatches so@0x9c4c0): mvKeysUn @0x170, mDescriptors @0x1b8,
+    // mFeatVec (std::map<unsigned, vector<unsigned>>) @0x248, mvpMapPoints @0x520, mMutexFeatures @0x690.
+    // Frame: N @0xec, mvKeys @0xf0, mFeatVec @0x198, mDescriptors @0x1c8.
+    {
+        path = std::string(outdir) + "/ref_glue_bow.json";
+        FILE *JB = fopen(path.c_str(), "w");
+        fprintf(JB, "{\"_doc\": \"ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (so@0x80150) executed from the reference binary on hand-laid KeyFrame / "
+                    "Frame / MapPoint objects with real std::map feature vectors. floats as uint32 bit patterns; match[j] = keyframe feature whose map point frame "
+                    "feature j received, -1 none\", \"cases\": [\n");
+        struct { int nkf, nf, nodes; int check; uint64_t seed; } bc[] = {{600, 500, 150, 1, 9301}, {300, 400, 60, 0, 9302}, {800, 900, 300, 1, 9303}};
+        const int NBC = 3;
+        typedef std::map<unsigned, std::vector<unsigned>> FeatVec;
+        for (int c = 0; c < NBC; c++) {
+            rng_seed(bc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int NK = bc[c].nkf, NF = bc[c].nf, NN = bc[c].nodes;
+            std::vector<cv::KeyPoint> kkeys(NK), fkeys(NF);
+            std::vector<uint8_t> kdesc((size_t)NK * 32), fdesc((size_t)NF * 32);
+            std::vector<int> has(NK), bad(NK);
+            std::vector<unsigned> knode(NK), fnode(NF);
+            for (int i = 0; i < NK; i++) {
+                kkeys[i].x = uf() * 640.f; kkeys[i].y = uf() * 480.f; kkeys[i].size = 31.f; kkeys[i].angle = uf() * 360.f; kkeys[i].response = 1.f; kkeys[i].octave = 0; kkeys[i].class_id = -1;
+                for (int b = 0; b < 32; b++) kdesc[(size_t)i * 32 + b] = (uint8_t)rng_below(256);
+                has[i] = uf() < 0.8f; bad[i] = uf() < 0.05f;
+                knode[i] = 1000u + 7u * rng_below((uint32_t)NN);
+            }
+            for (int j = 0; j < NF; j++) {
+                fkeys[j].x = uf() * 640.f; fkeys[j].y = uf() * 480.f; fkeys[j].size = 31.f; fkeys[j].response = 1.f; fkeys[j].octave = 0; fkeys[j].class_id = -1;
+                const float u = uf();
+                if (u < 0.7f) {   // a (noisy) observation of a keyframe feature: same word, similar descriptor, coherent rotation most of the time
+                    const int src = (int)rng_below((uint32_t)NK);
+                    for (int b = 0; b < 32; b++) fdesc[(size_t)j * 32 + b] = kdesc[(size_t)src * 32 + b];
+                    const int flips = (int)rng_below(36);
+                    for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); fdesc[(size_t)j * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                    fnode[j] = uf() < 0.9f ? knode[src] : 1000u + 7u * rng_below((uint32_t)NN) + (uf() < 0.3f ? 3u : 0u);
+                    float a = kkeys[src].angle - (uf() < 0.8f ? 20.f + uf() * 8.f : uf() * 360.f);
+                    if (a < 0.f) a += 360.f;
+                    fkeys[j].angle = a;
+                } else {
+                    for (int b = 0; b < 32; b++) fdesc[(size_t)j * 32 + b] = (uint8_t)rng_below(256);
+                    fnode[j] = 1000u + 7u * rng_below((uint32_t)NN) + (uf() < 0.3f ? 3u : 0u);
+                    fkeys[j].angle = uf() * 360.f;
+                }
+            }
+            char *kf = (char *)bump(0x800); memset(kf, 0, 0x800);
+            char *fr = (char *)bump(0x12800); memset(fr, 0, 0x12800);
+            char *mps = (char *)bump((size_t)NK * 0x300); memset(mps, 0, (size_t)NK * 0x300);
+            std::vector<void *> kmp(NK, nullptr);
+            for (int i = 0; i < NK; i++) if (has[i]) { kmp[i] = mps + (size_t)i * 0x300; *(bool *)(mps + (size_t)i * 0x300 + 0x238) = bad[i] != 0; }
+            void **v;
+            v = (void **)(kf + 0x170); v[0] = kkeys.data(); v[1] = kkeys.data() + NK; v[2] = v[1];
+            mat_init((cv::Mat *)(kf + 0x1b8), kdesc.data(), NK, 32, 32); ((cv::Mat *)(kf + 0x1b8))->flags |= 0x4000;
+            FeatVec *kfv = new (kf + 0x248) FeatVec();
+            for (int i = 0; i < NK; i++) (*kfv)[knode[i]].push_back((unsigned)i);
+            v = (void **)(kf + 0x520); v[0] = kmp.data(); v[1] = kmp.data() + NK; v[2] = v[1];
+            *(int *)(fr + 0xec) = NF;
+            v = (void **)(fr + 0xf0); v[0] = fkeys.data(); v[1] = fkeys.data() + NF; v[2] = v[1];
+            FeatVec *ffv = new (fr + 0x198) FeatVec();
+            for (int j = 0; j < NF; j++) (*ffv)[fnode[j]].push_back((unsigned)j);
+            mat_init((cv::Mat *)(fr + 0x1c8), fdesc.data(), NF, 32, 32); ((cv::Mat *)(fr + 0x1c8))->flags |= 0x4000;
+            ORBmatcher *mt = new ORBmatcher(0.7f, bc[c].check != 0);
+            std::vector<MapPoint *> out;
+            const int nm = mt->SearchByBoW((KeyFrame *)kf, *(Frame *)fr, out);
+            std::vector<int> match(NF, -1);
+            for (int j = 0; j < NF && j < (int)out.size(); j++) if (out[j]) match[j] = (int)(((char *)out[j] - mps) / 0x300);
+            // fixture: flattened inputs + result
+            std::vector<float> ka(NK), fa(NF); std::vector<int> hm(NK);
+            for (int i = 0; i < NK; i++) { ka[i] = kkeys[i].angle; hm[i] = has[i] && !bad[i]; }
+            for (int j = 0; j < NF; j++) fa[j] = fkeys[j].angle;
+            auto flat = [&](FeatVec *fv, std::vector<int> &ids, std::vector<int> &starts, std::vector<int> &feats) {
+                for (auto &kv : *fv) { ids.push_back((int)kv.first); starts.push_back((int)feats.size()); for (unsigned x : kv.second) feats.push_back((int)x); }
+                starts.push_back((int)feats.size());
+            };
+            std::vector<int> kid, kst, kfe, fid, fst, ffe;
+            flat(kfv, kid, kst, kfe); flat(ffv, fid, fst, ffe);
+            fprintf(JB, "{\"n_kf\": %d, \"n_f\": %d, \"nnratio\": 0.7, \"check_orientation\": %d, \"nmatches\": %d, ", NK, NF, bc[c].check, nm);
+            J = JB;
+            jarr_f("kf_angle", ka); jarr_f("f_angle", fa); jarr_i("kf_has_mp", hm);
+            jarr_i("kf_node_id", kid); jarr_i("kf_node_start", kst); jarr_i("kf_feat", kfe);
+            jarr_i("f_node_id", fid); jarr_i("f_node_start", fst); jarr_i("f_feat", ffe); jarr_i("match", match);
+            fprintf(JB, "\"kf_desc\": \"");
+            for (size_t b = 0; b < kdesc.size(); b++) fprintf(JB, "%02x", kdesc[b]);
+            fprintf(JB, "\", \"f_desc\": \"");
+            for (size_t b = 0; b < fdesc.size(); b++) fprintf(JB, "%02x", fdesc[b]);
+            fprintf(JB, "\"}%s\n", c + 1 < NBC ? "," : "");
+        }
+        fprintf(JB, "]}\n"); fclose(JB);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

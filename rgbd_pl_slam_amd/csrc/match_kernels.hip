@@ -6,6 +6,7 @@
 //   k_knn2                  cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) (cv::batchDistance tie rules)
 //   k_lines_lastframe       LSDmatcher::SearchByProjection(Frame&, const Frame&) + Frame::lineDescriptorMAD
 //   k_match_project_lines   LSDmatcher::SearchByProjection(Frame&, vector<MapLine*>&, th) + Frame::GetLinesInArea
+//   k_match_bow             ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)     include/ORBmatcher.h:104, so@0x80150
 //   k_hamming_matrix        DescriptorDistance over all pairs
 //
 // The reference loops are GREEDY: map point m skips key points claimed by map points before it, so its result
@@ -21,6 +22,7 @@
 #define GRID_ROWS 48
 #define GRID_CELLS (GRID_COLS * GRID_ROWS)
 #define TH_HIGH 100
+#define TH_LOW 50
 #define HISTO_LENGTH 30
 
 struct FrameDev {
@@ -502,6 +504,125 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
     }
     for (int k = t; k < F.n; k += T) match[k] = claim[k];
     if (t == 0) *nmatches = s_acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)   include/ORBmatcher.h:104, so@0x80150
+// One block per (keyframe, frame) pair.  The two DBoW2 feature vectors arrive flattened (node ids ascending, CSR).
+// The reference walks the common nodes in key order; a node only reads / writes the match slots of its own frame
+// features, so as long as no frame feature sits in two common nodes (never the case for a DBoW2 FeatureVector, where
+// every feature has exactly one node at the chosen level) the nodes are independent and each thread takes whole
+// nodes.  Otherwise thread 0 replays the reference loop alone (same result, no parallelism).
+// ------------------------------------------------------------------------------------------------
+struct BowDev {
+    int n_kf, n_f;
+    const uint8_t *kf_desc, *f_desc;
+    const float *kf_angle, *f_angle;
+    const uint8_t *kf_has_mp;
+    int kf_nodes, f_nodes;
+    const uint32_t *kf_node_id, *f_node_id;
+    const int *kf_node_start, *f_node_start;
+    const int *kf_feat, *f_feat;
+};
+
+__device__ __forceinline__ int bow_node(const BowDev &P, int a, int b, float nnratio, int *__restrict__ match)
+{
+    int acc = 0;
+    for (int p = P.kf_node_start[a]; p < P.kf_node_start[a + 1]; p++) {
+        const int ikf = P.kf_feat[p];
+        if (!P.kf_has_mp[ikf]) continue;
+        const uint8_t *dKF = P.kf_desc + (size_t)ikf * 32;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int q = P.f_node_start[b]; q < P.f_node_start[b + 1]; q++) {
+            const int jf = P.f_feat[q];
+            if (match[jf] >= 0) continue;
+            const int dist = hamming_g(dKF, P.f_desc + (size_t)jf * 32);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) { match[bestIdxF] = ikf; acc++; }
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pairs, float nnratio, int check_ori, int *__restrict__ match_all,
+                                                   int stride, int *__restrict__ nmatches, int *__restrict__ fnode_all)
+{
+    __shared__ int hist[HISTO_LENGTH], keepbin[3], s_acc, s_shared;
+    const int pr = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    const BowDev P = pairs[pr];
+    int *match = match_all + (size_t)pr * stride;
+    int *fnode = fnode_all + (size_t)pr * stride;   // frame feature -> first common node that lists it (scratch)
+    for (int j = t; j < P.n_f; j += T) { match[j] = -1; fnode[j] = 0x7fffffff; }
+    if (t < HISTO_LENGTH) hist[t] = 0;
+    if (t == 0) { s_acc = 0; s_shared = 0; }
+    __syncthreads();
+    // common nodes: binary search of every keyframe node in the frame's node list; detect frame features listed twice
+    for (int a = t; a < P.kf_nodes; a += T) {
+        const uint32_t id = P.kf_node_id[a];
+        int lo = 0, hi = P.f_nodes;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.f_node_id[mid] < id) lo = mid + 1; else hi = mid; }
+        if (lo < P.f_nodes && P.f_node_id[lo] == id)
+            for (int q = P.f_node_start[lo]; q < P.f_node_start[lo + 1]; q++)
+                if (atomicMin(&fnode[P.f_feat[q]], a) != 0x7fffffff) s_shared = 1;
+    }
+    __syncthreads();
+    if (!s_shared) {
+        int acc = 0;
+        for (int a = t; a < P.kf_nodes; a += T) {
+            const uint32_t id = P.kf_node_id[a];
+            int lo = 0, hi = P.f_nodes;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.f_node_id[mid] < id) lo = mid + 1; else hi = mid; }
+            if (lo < P.f_nodes && P.f_node_id[lo] == id) acc += bow_node(P, a, lo, nnratio, match);
+        }
+        if (acc) atomicAdd(&s_acc, acc);
+    } else if (t == 0) {
+        int a = 0, b = 0, acc = 0;
+        while (a < P.kf_nodes && b < P.f_nodes) {
+            if (P.kf_node_id[a] < P.f_node_id[b]) { a++; continue; }
+            if (P.kf_node_id[a] > P.f_node_id[b]) { b++; continue; }
+            acc += bow_node(P, a, b, nnratio, match);
+            a++; b++;
+        }
+        s_acc = acc;
+    }
+    __syncthreads();
+    if (check_ori) {
+        for (int j = t; j < P.n_f; j += T) {
+            const int i = match[j];
+            if (i < 0) continue;
+            float rot = P.kf_angle[i] - P.f_angle[j];
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / 12.0f));
+            if (bin == HISTO_LENGTH) bin = 0;
+            atomicAdd(&hist[bin], 1);
+        }
+        __syncthreads();
+        if (t == 0) {  // ComputeThreeMaxima (so@0x79c40)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                else if (sz > max3) { max3 = sz; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            keepbin[0] = i1; keepbin[1] = i2; keepbin[2] = i3;
+        }
+        __syncthreads();
+        for (int j = t; j < P.n_f; j += T) {
+            const int i = match[j];
+            if (i < 0) continue;
+            float rot = P.kf_angle[i] - P.f_angle[j];
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / 12.0f));
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { match[j] = -1; atomicSub(&s_acc, 1); }
+        }
+        __syncthreads();
+    }
+    if (t == 0) nmatches[pr] = s_acc;
 }
 
 // cv::batchDistance, K = 2: strict '<' against the current worst, equal distances keep the earlier train index first

@@ -265,3 +265,16 @@ def is_in_frustum(xw, normal, dmin, dmax, Rcw, tcw, Ow, cam4, bounds, bf, logsf,
     lib().orc_is_in_frustum(p(a[0]), p(a[1]), p(a[2]), p(a[3]), C.c_int(m), p(a[4]), p(a[5]), p(a[6]), p(a[7]), p(a[8]), C.c_float(bf),
                             C.c_float(logsf), C.c_int(nlevels), C.c_float(coslim), p(px), p(py), p(pxr), p(lv), p(vc), p(iv))
     return dict(proj_x=px, proj_y=py, proj_xr=pxr, level=lv, view_cos=vc, in_view=iv)
+
+
+def search_by_bow(kf_desc, f_desc, kf_angle, f_angle, kf_has_mp, kf_nodes, f_nodes, nnratio, check_ori):
+    """kf_nodes / f_nodes = (node_id uint32[K], node_start int32[K+1], feat int32[*]) flattened DBoW2 feature vectors"""
+    L = lib()
+    a = [np.ascontiguousarray(x) for x in (kf_desc, f_desc, np.asarray(kf_angle, np.float32), np.asarray(f_angle, np.float32), np.asarray(kf_has_mp, np.uint8))]
+    kn = [np.ascontiguousarray(kf_nodes[0], np.uint32), np.ascontiguousarray(kf_nodes[1], np.int32), np.ascontiguousarray(kf_nodes[2], np.int32)]
+    fn = [np.ascontiguousarray(f_nodes[0], np.uint32), np.ascontiguousarray(f_nodes[1], np.int32), np.ascontiguousarray(f_nodes[2], np.int32)]
+    match = np.full(len(a[1]), -1, np.int32)
+    n = L.orc_search_by_bow(C.c_int(len(a[0])), C.c_int(len(a[1])), p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), C.c_int(len(kn[0])), p(kn[0]), p(kn[1]),
+                            p(kn[2]), C.c_int(len(fn[0])), p(fn[0]), p(fn[1]), p(fn[2]), C.c_float(nnratio), C.c_int(int(check_ori)), p(match))
+    return match, n
+

@@ -89,3 +89,19 @@ def load_search_map_cases(path):
                         th=float(np.array([c["th_bits"]], np.uint32).view(np.float32)[0]), init=np.array(c["init"], np.int32),
                         match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
     return out
+
+
+def load_bow_cases(path):
+    """tests/golden/ref_glue_bow.json -> list of dicts with numpy inputs and the reference binary's result"""
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    out = []
+    for c in json.load(open(path))["cases"]:
+        out.append(dict(kf_desc=np.frombuffer(bytes.fromhex(c["kf_desc"]), np.uint8).reshape(c["n_kf"], 32).copy(),
+                        f_desc=np.frombuffer(bytes.fromhex(c["f_desc"]), np.uint8).reshape(c["n_f"], 32).copy(),
+                        kf_angle=f32(c["kf_angle"]), f_angle=f32(c["f_angle"]), kf_has_mp=np.array(c["kf_has_mp"], np.uint8),
+                        kf_nodes=(np.array(c["kf_node_id"], np.uint32), np.array(c["kf_node_start"], np.int32), np.array(c["kf_feat"], np.int32)),
+                        f_nodes=(np.array(c["f_node_id"], np.uint32), np.array(c["f_node_start"], np.int32), np.array(c["f_feat"], np.int32)),
+                        nnratio=float(c["nnratio"]), check=int(c["check_orientation"]), match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
+    return out
+

@@ -189,3 +189,63 @@ def test_gpu_equals_reference_search_by_projection_fixture():
         assert np.array_equal(match[0].cpu().numpy(), c["match"])
         m.close()
 
+
+def _bow_random_case(seed, nkf, nf, nnodes, shared=False):
+    """random (keyframe, frame) pair in the flattened layout; shared=True lists some frame features in two nodes"""
+    rng = np.random.default_rng(seed)
+    kf_desc = rng.integers(0, 256, (nkf, 32), dtype=np.uint8)
+    src = rng.integers(0, nkf, nf)
+    f_desc = matchgen.flip_bits(kf_desc[src].copy(), rng, 35)
+    rnd = rng.uniform(0, 1, nf) < 0.3
+    f_desc[rnd] = rng.integers(0, 256, (int(rnd.sum()), 32), dtype=np.uint8)
+    knode = rng.integers(0, nnodes, nkf).astype(np.uint32) * 5 + 100
+    fnode = np.where(rng.uniform(0, 1, nf) < 0.85, knode[src], rng.integers(0, nnodes, nf).astype(np.uint32) * 5 + 100 + rng.integers(0, 2, nf).astype(np.uint32) * 2).astype(np.uint32)
+    kf_angle = rng.uniform(0, 360, nkf).astype(np.float32)
+    f_angle = np.mod(kf_angle[src] - np.where(rng.uniform(0, 1, nf) < 0.8, rng.uniform(20, 28, nf), rng.uniform(0, 360, nf)), 360).astype(np.float32)
+    has = (rng.uniform(0, 1, nkf) < 0.8).astype(np.uint8)
+
+    def flat(node, extra=None):
+        ids = np.unique(node)
+        lists = [list(np.nonzero(node == i)[0]) for i in ids]
+        if extra is not None:
+            for j, k in extra:
+                lists[k % len(lists)].append(int(j))
+        start = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+        return ids.astype(np.uint32), start, np.concatenate([np.array(l, np.int32) for l in lists]).astype(np.int32)
+    extra = [(int(rng.integers(0, nf)), int(rng.integers(0, 1 << 20))) for _ in range(20)] if shared else None
+    return dict(kf_desc=kf_desc, f_desc=f_desc, kf_angle=kf_angle, f_angle=f_angle, kf_has_mp=has, kf_nodes=flat(knode), f_nodes=flat(fnode, extra))
+
+
+def test_search_by_bow():
+    """plf_match_bow vs the reference binary's fixture and vs the oracle on random pairs (incl. the serial fallback)"""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    cases = [dict(c, expect=(c["match"], c["nmatches"])) for c in refgen.load_bow_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_bow.json"))]
+    for seed, (nkf, nf, nn, sh, ratio, chk) in enumerate([(1000, 1000, 400, False, 0.7, 1), (700, 1200, 90, False, 0.9, 0), (500, 600, 120, True, 0.75, 1), (64, 1, 8, False, 0.7, 1)]):
+        c = _bow_random_case(100 + seed, nkf, nf, nn, sh)
+        c["nnratio"], c["check"] = ratio, chk
+        c["expect"] = orc.search_by_bow(c["kf_desc"], c["f_desc"], c["kf_angle"], c["f_angle"], c["kf_has_mp"], c["kf_nodes"], c["f_nodes"], ratio, chk)
+        cases.append(c)
+    m = Matcher(max_keypoints=2048, max_mappoints=16, max_batch=8)
+    by_setting = {}
+    for c in cases:
+        by_setting.setdefault((c["nnratio"], c["check"]), []).append(c)
+    for (ratio, chk), group in by_setting.items():     # pairs with the same matcher settings go in one batched call
+        keep, views = [], []
+        for c in group:
+            t = [_dev(c[k]) for k in ("kf_desc", "f_desc", "kf_angle", "f_angle", "kf_has_mp")]
+            kn = tuple(_dev(x) for x in c["kf_nodes"]); fn = tuple(_dev(x) for x in c["f_nodes"])
+            keep.append((t, kn, fn))
+            views.append(Matcher.bow_view(t[0], t[1], t[2], t[3], t[4], kn, fn))
+        match = torch.full((len(group), 2048), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(len(group), dtype=torch.int32, device="cuda")
+        m.SearchByBoW(views, ratio, chk, match, 2048, nm)
+        torch.cuda.synchronize()
+        for i, c in enumerate(group):
+            nf = len(c["f_desc"])
+            assert int(nm[i]) == c["expect"][1], (ratio, chk, i)
+            assert np.array_equal(match[i, :nf].cpu().numpy(), c["expect"][0]), (ratio, chk, i)
+    m.close()
+
