@@ -226,8 +226,9 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
         const float zc = Rcw[6] * xw[0] + Rcw[7] * xw[1] + Rcw[8] * xw[2] + tcw[2];
         const float invzc = (float)(1.0 / (double)zc);
         if (invzc < 0) continue;
-        const float u = fx * xc * invzc + cx;
-        const float v = fy * yc * invzc + cy;
+        /* the binary contracts these three expressions into FMAs (so@0x81cba vfmadd213ss, 0x81cd9 vfmadd213ss, 0x81eb5 vfnmadd132ss) */
+        const float u = fmaf(fx * xc, invzc, cx);
+        const float v = fmaf(fy * yc, invzc, cy);
         if (u < Cur->minx || u > Cur->maxx) continue;
         if (v < Cur->miny || v > Cur->maxy) continue;
         const int nLastOctave = Last->octave[i];
@@ -244,7 +245,7 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
             const int cur = match_of_kp[i2];
             if (cur == -2 || cur >= 0) continue; /* map points of the last frame all have observations */
             if (Cur->uright[i2] > 0) {
-                const float ur = u - bf * invzc;
+                const float ur = fmaf(-bf, invzc, u);
                 const float er = fabsf(ur - Cur->uright[i2]);
                 if (er > radius) continue;
             }

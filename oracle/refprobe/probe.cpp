@@ -22,6 +22,7 @@
 #include <cmath>
 #include <climits>
 #include <new>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -80,6 +81,7 @@ struct Mat {  // OpenCV 3.3 layout, 96 bytes
     void copyTo(const _OutputArray &dst) const;
     void copySize(const Mat &m);
     static MatExpr zeros(int rows, int cols, int type);
+    MatExpr t() const;
 };
 struct _InputArray {
     int flags; void *obj; int sz_w, sz_h;
@@ -96,7 +98,11 @@ struct MatOp {  // vtable: [0],[1] destructors, [2] elementWise, [3] assign  (th
     virtual bool elementWise(const MatExpr &) const { return false; }
     virtual void assign(const MatExpr &, Mat &m, int type) const;
 };
-struct MatExpr { const MatOp *op; int flags; Mat a, b, c; double alpha, beta; Scalar_<double> s; };
+struct MatExpr { const MatOp *op; int flags; Mat a, b, c; double alpha, beta; Scalar_<double> s; MatExpr() {} ~MatExpr(); };
+MatExpr operator*(const Mat &a, const Mat &b);
+MatExpr operator*(const MatExpr &e, const Mat &b);
+MatExpr operator+(const MatExpr &e, const Mat &b);
+MatExpr operator-(const MatExpr &e);
 void resize(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
 void copyMakeBorder(const _InputArray &, const _OutputArray &, int, int, int, int, int, const Scalar_<double> &);
 void GaussianBlur(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
@@ -138,7 +144,7 @@ cv::Mat::Mat(const Mat &m, const Range &rr, const Range &cr)
     memcpy((void *)this, &m, sizeof(Mat));
     size_p = &rows; step_p = step_buf; u = nullptr;
     if (!(rr.start == INT_MIN && rr.end == INT_MAX)) { data += step_buf[0] * rr.start; rows = rr.end - rr.start; }
-    if (!(cr.start == INT_MIN && cr.end == INT_MAX)) { data += (size_t)cr.start; cols = cr.end - cr.start; }
+    if (!(cr.start == INT_MIN && cr.end == INT_MAX)) { data += (size_t)cr.start * ((flags & 0xFFF) == 5 ? 4 : 1); cols = cr.end - cr.start; }
 }
 void cv::FAST(const _InputArray &arr, std::vector<KeyPoint> &kps, int th, bool nonmax)
 {
@@ -172,11 +178,13 @@ static void mat_empty(cv::Mat *m)
 }
 static void mat_alloc(cv::Mat *m, int rows, int cols, int type)
 {
-    if (type != 0) { fprintf(stderr, "refprobe: unexpected Mat type %d\n", type); abort(); }
-    if (m->data && m->dims == 2 && m->rows == rows && m->cols == cols) return;   // Mat::create keeps a matching buffer
-    unsigned char *d = (unsigned char *)bump((size_t)rows * cols + 64);
-    mat_init(m, d, rows, cols, (size_t)cols);
-    m->flags |= 0x4000;  // CONTINUOUS
+    if (type != 0 && type != 5) { fprintf(stderr, "refprobe: unexpected Mat type %d\n", type); abort(); }
+    const size_t esz = type == 5 ? 4 : 1;   // CV_8UC1 / CV_32FC1
+    if (m->data && m->dims == 2 && m->rows == rows && m->cols == cols && (m->flags & 0xFFF) == type) return;   // Mat::create keeps a matching buffer
+    unsigned char *d = (unsigned char *)bump((size_t)rows * cols * esz + 64);
+    mat_init(m, d, rows, cols, (size_t)cols * esz);
+    m->step_buf[1] = esz;
+    m->flags = 0x42FF0000 | 0x4000 | type;  // MAGIC | CONTINUOUS | type
 }
 cv::Mat::~Mat() {}
 cv::Mat::Mat(const Mat &m, const Rect_<int> &roi)
@@ -196,7 +204,7 @@ void cv::Mat::copyTo(const _OutputArray &dst) const
 {
     Mat *d = (Mat *)dst.obj;
     mat_alloc(d, rows, cols, flags & 0xFFF);
-    for (int y = 0; y < rows; y++) memcpy(d->data + d->step_buf[0] * y, data + step_buf[0] * y, (size_t)cols);
+    for (int y = 0; y < rows; y++) memcpy(d->data + d->step_buf[0] * y, data + step_buf[0] * y, (size_t)cols * ((flags & 0xFFF) == 5 ? 4 : 1));
 }
 void cv::MatOp::assign(const MatExpr &, Mat &m, int) const   // the only expression the path builds: Mat::zeros
 {
@@ -211,6 +219,54 @@ cv::MatExpr cv::Mat::zeros(int rows, int cols, int type)
     mat_empty(&e.a); mat_empty(&e.b); mat_empty(&e.c);
     g_zeros_rows = rows; (void)cols; (void)type;
     return e;
+}
+// ---- the little matrix algebra of SearchByProjection(CurrentFrame, LastFrame): -Rcw.t()*tcw, Rlw*twc+tlw, Rcw*x3Dw+tcw
+// (3x3 and 3x1 CV_32F).  Arithmetic as cv::gemm of OpenCV 3.3 does it (matmul.cpp): A*B(+C) with flags == 0 takes the
+// small-matrix float path d = float(double(t)*alpha + beta*double(c)), t = a0*b0 + a1*b1 + a2*b2 in float;
+// the transposed product goes through GEMMSingleMul<float,double>: d = float(double-sum * alpha).
+struct GemmOp : cv::MatOp { void assign(const cv::MatExpr &e, cv::Mat &m, int) const override; };
+struct TransOp : cv::MatOp { void assign(const cv::MatExpr &, cv::Mat &, int) const override { fprintf(stderr, "refprobe: bare transpose\n"); abort(); } };
+static GemmOp g_gemm_op;
+static TransOp g_trans_op;
+static float matf(const cv::Mat &m, int r, int c) { return *(const float *)(m.data + m.step_buf[0] * r + 4 * (size_t)c); }
+static void expr_init(cv::MatExpr *e, const cv::MatOp *op)
+{
+    e->op = op; e->flags = 0; e->alpha = 1; e->beta = 0; memset(&e->s, 0, sizeof(e->s));
+    mat_empty(&e->a); mat_empty(&e->b); mat_empty(&e->c);
+}
+void GemmOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const
+{
+    const cv::Mat &A = e.a, &B = e.b, &Cm = e.c;
+    const bool tr = (e.flags & 1) != 0;
+    if ((A.flags & 0xFFF) != 5 || A.rows != 3 || A.cols != 3 || B.rows != 3 || B.cols != 1) { fprintf(stderr, "refprobe: unexpected gemm shape\n"); abort(); }
+    float d[3];
+    for (int i = 0; i < 3; i++) {
+        if (tr) {
+            double sum = 0;
+            for (int k = 0; k < 3; k++) sum += (double)matf(A, k, i) * (double)matf(B, k, 0);
+            d[i] = (float)(sum * e.alpha);
+            if (Cm.data) { fprintf(stderr, "refprobe: unexpected gemm form\n"); abort(); }
+        } else {
+            const float t = matf(A, i, 0) * matf(B, 0, 0) + matf(A, i, 1) * matf(B, 1, 0) + matf(A, i, 2) * matf(B, 2, 0);
+            d[i] = (float)((double)t * e.alpha + (Cm.data ? e.beta * (double)matf(Cm, i, 0) : 0.0));
+        }
+    }
+    mat_alloc(&m, 3, 1, 5);
+    for (int i = 0; i < 3; i++) *(float *)(m.data + m.step_buf[0] * i) = d[i];
+}
+cv::MatExpr::~MatExpr() {}
+cv::MatExpr cv::Mat::t() const { MatExpr e; expr_init(&e, &g_trans_op); e.a = *this; return e; }
+cv::MatExpr cv::operator-(const MatExpr &x) { MatExpr e; expr_init(&e, x.op); e.flags = x.flags; e.a = x.a; e.b = x.b; e.c = x.c; e.alpha = -x.alpha; e.beta = -x.beta; return e; }
+cv::MatExpr cv::operator*(const Mat &a, const Mat &b) { MatExpr e; expr_init(&e, &g_gemm_op); e.a = a; e.b = b; return e; }
+cv::MatExpr cv::operator*(const MatExpr &x, const Mat &b)
+{
+    if (x.op != &g_trans_op) { fprintf(stderr, "refprobe: unexpected expr * Mat\n"); abort(); }
+    MatExpr e; expr_init(&e, &g_gemm_op); e.flags = 1; e.a = x.a; e.b = b; e.alpha = x.alpha; return e;
+}
+cv::MatExpr cv::operator+(const MatExpr &x, const Mat &c)
+{
+    if (x.op != &g_gemm_op || x.c.data) { fprintf(stderr, "refprobe: unexpected expr + Mat\n"); abort(); }
+    MatExpr e; expr_init(&e, &g_gemm_op); e.flags = x.flags; e.a = x.a; e.b = x.b; e.alpha = x.alpha; e.c = c; e.beta = 1; return e;
 }
 int cv::_InputArray::kind() const { return flags & (31 << 16); }
 bool cv::_InputArray::empty() const { const Mat *m = (const Mat *)obj; return m->data == nullptr || m->rows * m->cols == 0; }
@@ -257,13 +313,14 @@ class MapPoint;
 class KeyFrame;
 class Frame {   // only the exported statics are named; the object itself is hand-laid raw memory (tier D)
 public:
-    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv, fx, fy, cx, cy;
 };
 class ORBmatcher {
 public:
     ORBmatcher(float nnratio, bool checkOri);
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th);
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -787,6 +844,147 @@ int main(int argc, char **argv)
             fprintf(JB, "\"}%s\n", c + 1 < NBC ? "," : "");
         }
         fprintf(JB, "]}\n"); fclose(JB);
+    }
+    // ------------------------------------------------------------ F: ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (glue)
+    // Frame (offsets from so@0x80d00): mbf @0xe0, mb @0xe4, N @0xec, mvKeys @0xf0, mvKeysUn @0x120, mvuRight @0x138, mDescriptors @0x1c8,
+    // mvpMapPoints @0x288, mvbOutlier (vector<bool>) @0x2a0, mGrid @0x2c8, mTcw (4x4 CV_32F) @0x122c8, mvScaleFactors @0x12348; statics
+    // fx, fy, cx, cy, mnMin/Max*, mfGridElement*Inv.  MapPoint: nObs @0x18, mWorldPos (3x1 CV_32F) @0xd8, mDescriptor @0x1c8.
+    {
+        path = std::string(outdir) + "/ref_glue_search_last.json";
+        FILE *JL = fopen(path.c_str(), "w");
+        fprintf(JL, "{\"_doc\": \"ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (so@0x80d00) executed from the reference binary on "
+                    "hand-laid Frame / MapPoint objects; cv::Mat algebra (gemm) supplied by oracle/refprobe/probe.cpp. floats as uint32 bit patterns; match[k] = "
+                    "last-frame index assigned to current key point k, -1 none, -2 occupied before the call\", \"cases\": [\n");
+        struct { int n; float th; int mono, check; float dz; uint64_t seed; } lc[] = {{500, 7.0f, 0, 1, 0.02f, 9401}, {400, 15.0f, 0, 1, -0.6f, 9402}, {450, 7.0f, 0, 0, 0.7f, 9403}, {350, 15.0f, 1, 1, 0.5f, 9404}};
+        const int NLC = 4;
+        for (int c = 0; c < NLC; c++) {
+            rng_seed(lc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int NL = lc[c].n;
+            const float fx = 520.9f, fy = 521.0f, cx = 325.1f, cy = 249.7f, bf = 40.0f, mb = bf / fx;
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            // poses: small rotations about y / x, translation mostly along z
+            auto pose = [&](float ay, float ax, float tx, float ty, float tz, float *T) {
+                const float cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float R[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) T[r * 4 + q] = R[r * 3 + q]; }
+                T[3] = tx; T[7] = ty; T[11] = tz; T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+            };
+            float *Tl = (float *)bump(64), *Tc = (float *)bump(64);
+            pose(0.01f, -0.02f, 0.05f, -0.03f, 0.1f, Tl);
+            pose(0.03f, -0.01f, 0.02f, 0.01f, 0.1f - lc[c].dz, Tc);
+            // last frame: key points with map points at depth z in the last camera; world = Rl^T (Xl - tl)
+            std::vector<cv::KeyPoint> lk(NL);
+            std::vector<float> wpos((size_t)NL * 3);
+            std::vector<int> lhas(NL), lout(NL);
+            std::vector<uint8_t> mdesc((size_t)NL * 32);
+            for (int i = 0; i < NL; i++) {
+                lk[i].x = 30.f + uf() * 580.f; lk[i].y = 30.f + uf() * 420.f; lk[i].size = 31.f; lk[i].angle = uf() * 360.f; lk[i].response = 1.f;
+                lk[i].octave = (int)rng_below(8); lk[i].class_id = -1;
+                const float z = 1.0f + uf() * 5.0f;
+                const float Xl[3] = {(lk[i].x - cx) / fx * z, (lk[i].y - cy) / fy * z, z};
+                for (int r = 0; r < 3; r++) wpos[(size_t)i * 3 + r] = Tl[0 * 4 + r] * (Xl[0] - Tl[3]) + Tl[1 * 4 + r] * (Xl[1] - Tl[7]) + Tl[2 * 4 + r] * (Xl[2] - Tl[11]);
+                lhas[i] = uf() < 0.85f; lout[i] = uf() < 0.08f;
+                for (int b = 0; b < 32; b++) mdesc[(size_t)i * 32 + b] = (uint8_t)rng_below(256);
+            }
+            // current frame: noisy re-observations + clutter
+            const int NC = NL + NL / 3;
+            std::vector<cv::KeyPoint> ck(NC);
+            std::vector<float> cur(NC);
+            std::vector<uint8_t> cdesc((size_t)NC * 32);
+            for (int k = 0; k < NC; k++) {
+                ck[k].size = 31.f; ck[k].response = 1.f; ck[k].class_id = -1;
+                if (k < NL) {
+                    const float *w = &wpos[(size_t)k * 3];
+                    const float xc = Tc[0] * w[0] + Tc[1] * w[1] + Tc[2] * w[2] + Tc[3], yc = Tc[4] * w[0] + Tc[5] * w[1] + Tc[6] * w[2] + Tc[7],
+                                zc = Tc[8] * w[0] + Tc[9] * w[1] + Tc[10] * w[2] + Tc[11];
+                    ck[k].x = fx * xc / zc + cx + (uf() - 0.5f) * 8.f; ck[k].y = fy * yc / zc + cy + (uf() - 0.5f) * 8.f;
+                    ck[k].octave = std::max(0, std::min(7, lk[k].octave + (int)rng_below(3) - 1));
+                    float a = lk[k].angle - (uf() < 0.8f ? 10.f + uf() * 9.f : uf() * 360.f);
+                    if (a < 0.f) a += 360.f;
+                    ck[k].angle = a;
+                    for (int b = 0; b < 32; b++) cdesc[(size_t)k * 32 + b] = mdesc[(size_t)k * 32 + b];
+                    const int flips = (int)rng_below(70);
+                    for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); cdesc[(size_t)k * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                    cur[k] = uf() < 0.6f ? ck[k].x - bf / zc + (uf() - 0.5f) * (uf() < 0.8f ? 4.f : 60.f) : -1.f;
+                } else {
+                    ck[k].x = uf() * 640.f; ck[k].y = uf() * 480.f; ck[k].octave = (int)rng_below(8); ck[k].angle = uf() * 360.f;
+                    for (int b = 0; b < 32; b++) cdesc[(size_t)k * 32 + b] = (uint8_t)rng_below(256);
+                    cur[k] = uf() < 0.5f ? ck[k].x - uf() * 30.f : -1.f;
+                }
+            }
+            // objects
+            char *lf = (char *)bump(0x12800), *cf = (char *)bump(0x12800); memset(lf, 0, 0x12800); memset(cf, 0, 0x12800);
+            char *mps = (char *)bump((size_t)(NL + 2) * 0x300); memset(mps, 0, (size_t)(NL + 2) * 0x300);
+            char *occ_obs = mps + (size_t)NL * 0x300, *occ_noobs = mps + (size_t)(NL + 1) * 0x300;
+            *(int *)(occ_obs + 0x18) = 3; *(int *)(occ_noobs + 0x18) = 0;
+            std::vector<void *> lmp(NL, nullptr), cmp_(NC, nullptr);
+            std::vector<uint64_t> obits((NL + 63) / 64 + 1, 0);
+            std::vector<int> init(NC, -1);
+            for (int i = 0; i < NL; i++) {
+                char *o = mps + (size_t)i * 0x300;
+                *(int *)(o + 0x18) = 1 + (int)rng_below(3);
+                mat_init((cv::Mat *)(o + 0xd8), (unsigned char *)&wpos[(size_t)i * 3], 3, 1, 4);
+                ((cv::Mat *)(o + 0xd8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0xd8))->step_buf[1] = 4;
+                mat_init((cv::Mat *)(o + 0x1c8), &mdesc[(size_t)i * 32], 1, 32, 32); ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
+                if (lhas[i]) lmp[i] = o;
+                if (lout[i]) obits[i / 64] |= 1ull << (i % 64);
+            }
+            for (int k = 0; k < NC; k++) { const float u = uf(); if (u < 0.06f) { cmp_[k] = occ_obs; init[k] = -2; } else if (u < 0.09f) cmp_[k] = occ_noobs; }
+            auto lay = [&](char *f, std::vector<cv::KeyPoint> &keys, int n, float *T) {
+                *(float *)(f + 0xe0) = bf; *(float *)(f + 0xe4) = mb; *(int *)(f + 0xec) = n;
+                void **v;
+                v = (void **)(f + 0xf0); v[0] = keys.data(); v[1] = keys.data() + n; v[2] = v[1];
+                v = (void **)(f + 0x120); v[0] = keys.data(); v[1] = keys.data() + n; v[2] = v[1];
+                mat_init((cv::Mat *)(f + 0x122c8), (unsigned char *)T, 4, 4, 16);
+                ((cv::Mat *)(f + 0x122c8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(f + 0x122c8))->step_buf[1] = 4;
+                v = (void **)(f + 0x12348); v[0] = scale; v[1] = scale + 8; v[2] = scale + 8;
+            };
+            lay(lf, lk, NL, Tl); lay(cf, ck, NC, Tc);
+            void **v;
+            v = (void **)(lf + 0x288); v[0] = lmp.data(); v[1] = lmp.data() + NL; v[2] = v[1];
+            v = (void **)(lf + 0x2a0); v[0] = obits.data();
+            v = (void **)(cf + 0x138); v[0] = cur.data(); v[1] = cur.data() + NC; v[2] = v[1];
+            mat_init((cv::Mat *)(cf + 0x1c8), cdesc.data(), NC, 32, 32); ((cv::Mat *)(cf + 0x1c8))->flags |= 0x4000;
+            v = (void **)(cf + 0x288); v[0] = cmp_.data(); v[1] = cmp_.data() + NC; v[2] = v[1];
+            Frame::fx = fx; Frame::fy = fy; Frame::cx = cx; Frame::cy = cy;
+            Frame::mnMinX = 0.f; Frame::mnMinY = 0.f; Frame::mnMaxX = 640.f; Frame::mnMaxY = 480.f;
+            Frame::mfGridElementWidthInv = 64.f / 640.f; Frame::mfGridElementHeightInv = 48.f / 480.f;
+            std::vector<std::vector<size_t>> cells(64 * 48);
+            for (int k = 0; k < NC; k++) {
+                const int gx = (int)roundf((ck[k].x - Frame::mnMinX) * Frame::mfGridElementWidthInv), gy = (int)roundf((ck[k].y - Frame::mnMinY) * Frame::mfGridElementHeightInv);
+                if (gx < 0 || gx >= 64 || gy < 0 || gy >= 48) continue;
+                cells[gx * 48 + gy].push_back((size_t)k);
+            }
+            for (int cidx = 0; cidx < 64 * 48; cidx++) {
+                v = (void **)(cf + 0x2c8 + (size_t)cidx * 24);
+                v[0] = cells[cidx].data(); v[1] = cells[cidx].data() + cells[cidx].size(); v[2] = v[1];
+            }
+            ORBmatcher *mt = new ORBmatcher(0.9f, lc[c].check != 0);
+            const int nm = mt->SearchByProjection(*(Frame *)cf, *(const Frame *)lf, lc[c].th, lc[c].mono != 0);
+            std::vector<int> match(NC);
+            for (int k = 0; k < NC; k++) {
+                const char *q = (const char *)cmp_[k];
+                match[k] = q == nullptr ? -1 : q == occ_obs ? -2 : q == occ_noobs ? -3 : (int)((q - mps) / 0x300);
+            }
+            std::vector<float> kx(NC), ky(NC), ka(NC), la(NL), Tlv(Tl, Tl + 16), Tcv(Tc, Tc + 16), scv(scale, scale + 8), cam = {fx, fy, cx, cy, bf, mb, lc[c].th};
+            std::vector<int> ko(NC), lo(NL);
+            for (int k = 0; k < NC; k++) { kx[k] = ck[k].x; ky[k] = ck[k].y; ka[k] = ck[k].angle; ko[k] = ck[k].octave; }
+            for (int i = 0; i < NL; i++) { la[i] = lk[i].angle; lo[i] = lk[i].octave; }
+            fprintf(JL, "{\"n_cur\": %d, \"n_last\": %d, \"mono\": %d, \"check_orientation\": %d, \"nmatches\": %d, ", NC, NL, lc[c].mono, lc[c].check, nm);
+            J = JL;
+            jarr_f("cam", cam); jarr_f("Tcw", Tcv); jarr_f("Tlw", Tlv); jarr_f("scale", scv);
+            jarr_f("x", kx); jarr_f("y", ky); jarr_f("angle", ka); jarr_i("octave", ko); jarr_f("uright", cur); jarr_i("init", init);
+            jarr_f("last_angle", la); jarr_i("last_octave", lo); jarr_i("last_has_mp", lhas); jarr_i("last_outlier", lout); jarr_f("world_pos", wpos);
+            jarr_i("match", match);
+            fprintf(JL, "\"desc\": \"");
+            for (size_t b = 0; b < cdesc.size(); b++) fprintf(JL, "%02x", cdesc[b]);
+            fprintf(JL, "\", \"mp_desc\": \"");
+            for (size_t b = 0; b < mdesc.size(); b++) fprintf(JL, "%02x", mdesc[b]);
+            fprintf(JL, "\"}%s\n", c + 1 < NLC ? "," : "");
+        }
+        fprintf(JL, "]}\n"); fclose(JL);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

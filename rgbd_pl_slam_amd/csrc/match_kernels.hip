@@ -418,7 +418,8 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
             const float zc = P.Rcw[6] * xw[0] + P.Rcw[7] * xw[1] + P.Rcw[8] * xw[2] + P.tcw[2];
             const float invzc = (float)(1.0 / (double)zc);
             if (invzc < 0) act = false;
-            const float u = P.fx * xc * invzc + P.cx, v = P.fy * yc * invzc + P.cy;
+            // the reference binary contracts these into FMAs (so@0x81cba, so@0x81cd9; the uRight test below: so@0x81eb5)
+            const float u = fmaf(P.fx * xc, invzc, P.cx), v = fmaf(P.fy * yc, invzc, P.cy);
             if (u < F.min_x || u > F.max_x) act = false;
             if (v < F.min_y || v > F.max_y) act = false;
             if (act) pr = make_float4(u, v, invzc, th * F.scale_factors[Lf.keys[i].octave]);
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
                 if (claim[idx] != -1) continue;
                 if (F.uright) {
                     const float urr = F.uright[idx];
-                    if (urr > 0) { const float ur = pr.x - P.bf * pr.z; const float er = fabsf(ur - urr); if (er > pr.w) continue; }
+                    if (urr > 0) { const float ur = fmaf(-P.bf, pr.z, pr.x); const float er = fabsf(ur - urr); if (er > pr.w) continue; }
                 }
                 const int dist = hamming_g(d, F.desc + 32 * (size_t)idx);
                 if (dist < bestDist) { bestDist = dist; bestIdx2 = idx; }

@@ -105,3 +105,28 @@ def load_bow_cases(path):
                         nnratio=float(c["nnratio"]), check=int(c["check_orientation"]), match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
     return out
 
+
+
+def load_search_last_cases(path):
+    """tests/golden/ref_glue_search_last.json -> inputs of SearchByProjection(CurrentFrame, LastFrame) + the binary's result"""
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = []
+    for c in json.load(open(path))["cases"]:
+        NC, NL = c["n_cur"], c["n_last"]
+        kps = np.zeros(NC, dtype=kp_dtype)
+        kps["x"] = f32(c["x"]); kps["y"] = f32(c["y"]); kps["angle"] = f32(c["angle"]); kps["octave"] = np.array(c["octave"], np.int32)
+        lk = np.zeros(NL, dtype=kp_dtype)
+        lk["angle"] = f32(c["last_angle"]); lk["octave"] = np.array(c["last_octave"], np.int32)
+        cam = f32(c["cam"]); Tc = f32(c["Tcw"]).reshape(4, 4); Tl = f32(c["Tlw"]).reshape(4, 4)
+        last = dict(keys=lk, has_mappoint=np.array(c["last_has_mp"], np.uint8), outlier=np.array(c["last_outlier"], np.uint8),
+                    world_pos=f32(c["world_pos"]).reshape(NL, 3).copy(), mp_desc=np.frombuffer(bytes.fromhex(c["mp_desc"]), np.uint8).reshape(NL, 32).copy())
+        pose = dict(Rcw=Tc[:3, :3].copy(), tcw=Tc[:3, 3].copy(), Rlw=Tl[:3, :3].copy(), tlw=Tl[:3, 3].copy(), fx=float(cam[0]), fy=float(cam[1]),
+                    cx=float(cam[2]), cy=float(cam[3]), bf=float(cam[4]), b=float(cam[5]))
+        match = np.array(c["match"], np.int32)
+        match[match == -3] = -1     # still held by a pre-existing point without observations: free in the match protocol
+        out.append(dict(kps=kps, desc=np.frombuffer(bytes.fromhex(c["desc"]), np.uint8).reshape(NC, 32).copy(), uright=f32(c["uright"]),
+                        scale=f32(c["scale"]), last=last, pose=pose, th=float(cam[6]), mono=int(c["mono"]), check=int(c["check_orientation"]),
+                        init=np.array(c["init"], np.int32), match=match, nmatches=c["nmatches"]))
+    return out

@@ -249,3 +249,27 @@ def test_search_by_bow():
             assert np.array_equal(match[i, :nf].cpu().numpy(), c["expect"][0]), (ratio, chk, i)
     m.close()
 
+
+def test_gpu_equals_reference_search_by_projection_lastframe_fixture():
+    """HIP matcher vs tests/golden/ref_glue_search_last.json: the result of the reference binary's own
+    ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the same inputs."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_search_last_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_search_last.json")):
+        N = len(c["kps"])
+        m = Matcher(max_keypoints=1024)
+        dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"]); du = _dev(c["uright"])
+        cur = Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), du)
+        last = c["last"]
+        dl = dict(keys=_kp_tensor(last["keys"]), has_mappoint=_dev(last["has_mappoint"]), outlier=_dev(last["outlier"]), world_pos=_dev(last["world_pos"]),
+                  mp_desc=_dev(last["mp_desc"]))
+        match = _dev(c["init"]); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchByProjectionLastFrame(cur, dl, c["pose"], c["th"], c["mono"], c["check"], match, nm)
+        torch.cuda.synchronize()
+        assert int(nm[0]) == c["nmatches"]
+        assert np.array_equal(match.cpu().numpy(), c["match"])
+        m.close()
+
