@@ -225,6 +225,7 @@ typedef struct plf_bow_view {
     const uint8_t *kf_desc, *f_desc;
     const float *kf_angle, *f_angle;
     const uint8_t *kf_has_mp;
+    const uint8_t *f_has_mp;                  /* plf_match_bow_kf only (second keyframe); NULL for a Frame */
     int32_t kf_nodes, f_nodes;
     const uint32_t *kf_node_id, *f_node_id;
     const int32_t *kf_node_start, *f_node_start;
@@ -232,6 +233,14 @@ typedef struct plf_bow_view {
 } plf_bow_view;
 int plf_match_bow(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation,
                   int32_t *match_of_f, int32_t stride, int32_t *nmatches, void *stream);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint*> &vpMatches12)
+ * include/ORBmatcher.h:105 (so@0x82cc0, loop closing).  Same view type: kf_* = pKF1, f_* = pKF2 (f_angle =
+ * pKF2->mvKeysUn[j].angle, f_has_mp = pKF2 map point present && !isBad()).  match12 (device, n_pairs x stride, overwritten):
+ * per KF1 feature the KF2 feature whose map point it received, -1 = NULL.  nmatches[i] = -1 flags a pair whose first
+ * feature vector lists a feature twice (not a DBoW2 FeatureVector). */
+int plf_match_bow_kf(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation,
+                     int32_t *match12, int32_t stride, int32_t *nmatches, void *stream);
 
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as used by LSDmatcher (include/LSDmatcher.h:19-35).
  * out: nq x 2 plf_dmatch in `mem`. */

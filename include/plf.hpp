@@ -14,6 +14,7 @@
 #pragma once
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include "plf.h"
 
@@ -145,6 +146,12 @@ public:
     void SearchByBoW(const plf_bow_view &pKF_and_F, int32_t *match_of_f_dev, int32_t *nmatches_dev, void *stream = nullptr)
     {
         check(plf_match_bow(m_, &pKF_and_F, 1, mfNNratio, mbCheckOrientation, match_of_f_dev, pKF_and_F.n_f, nmatches_dev, stream), "SearchByBoW");
+    }
+    // int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint*> &vpMatches12)
+    void SearchByBoW(const plf_bow_view &pKF1_and_pKF2, int32_t *match12_dev, int32_t *nmatches_dev, bool /*keyframes*/, void *stream = nullptr)
+    {
+        check(plf_match_bow_kf(m_, &pKF1_and_pKF2, 1, mfNNratio, mbCheckOrientation, match12_dev, std::max(pKF1_and_pKF2.n_kf, pKF1_and_pKF2.n_f), nmatches_dev, stream),
+              "SearchByBoW(keyframes)");
     }
 
 private:

@@ -348,6 +348,68 @@ int orc_search_by_bow(int n_kf, int n_f, const uint8_t *kf_desc, const uint8_t *
     return nmatches;
 }
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12)  include/ORBmatcher.h:105,
+ * so@0x82cc0 (loop closing; executed from the binary for tests/golden/ref_glue_bow_kf.json).  Same node walk as above
+ * with these differences: both sides need a good map point (has_mp1 / has_mp2), occupancy is tracked on the KF2
+ * features (vbMatched2), the acceptance threshold is STRICT (bestDist1 < TH_LOW, so@0x83490: cmpl $0x31), the output is
+ * indexed by KF1 features: match12[i1] = KF2 feature whose map point KF1 feature i1 received, -1 otherwise. */
+int orc_search_by_bow_kf(int n1, int n2, const uint8_t *desc1, const uint8_t *desc2, const float *angle1, const float *angle2,
+                         const uint8_t *has_mp1, const uint8_t *has_mp2, int nodes1, const uint32_t *node_id1, const int32_t *node_start1,
+                         const int32_t *feat1, int nodes2, const uint32_t *node_id2, const int32_t *node_start2, const int32_t *feat2,
+                         float nnratio, int checkOri, int32_t *match12)
+{
+    int nmatches = 0;
+    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (n1 > 0 ? n1 : 1));
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1);
+    int histN[HISTO_LENGTH];
+    memset(histN, 0, sizeof(histN));
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nodes1 && b < nodes2) {
+        if (node_id1[a] < node_id2[b]) { a++; continue; }
+        if (node_id1[a] > node_id2[b]) { b++; continue; }
+        for (int p = node_start1[a]; p < node_start1[a + 1]; p++) {
+            const int i1 = feat1[p];
+            if (!has_mp1[i1]) continue;
+            const uint8_t *d1 = desc1 + 32 * (size_t)i1;
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int q = node_start2[b]; q < node_start2[b + 1]; q++) {
+                const int i2 = feat2[q];
+                if (matched2[i2] || !has_mp2[i2]) continue;
+                const int dist = orc_hamming256(d1, desc2 + 32 * (size_t)i2);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 < TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                match12[i1] = bestIdx2;
+                matched2[bestIdx2] = 1;
+                if (checkOri) {
+                    float rot = angle1[i1] - angle2[bestIdx2];
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * (1.0f / 12.0f));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin * n1 + histN[bin]++] = i1;
+                }
+                nmatches++;
+            }
+        }
+        a++; b++;
+    }
+    if (checkOri) {
+        int i1, i2, i3;
+        orc_three_maxima(histN, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int bnum = 0; bnum < HISTO_LENGTH; bnum++) {
+            if (bnum == i1 || bnum == i2 || bnum == i3) continue;
+            for (int j = 0; j < histN[bnum]; j++) {
+                match12[rotHist[bnum * n1 + j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    free(rotHist); free(matched2);
+    return nmatches;
+}
+
 /* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {

@@ -131,6 +131,10 @@ int orc_search_by_bow(int n_kf, int n_f, const uint8_t *kf_desc, const uint8_t *
                       const uint8_t *kf_has_mp, int kf_nodes, const uint32_t *kf_node_id, const int32_t *kf_node_start,
                       const int32_t *kf_feat, int f_nodes, const uint32_t *f_node_id, const int32_t *f_node_start,
                       const int32_t *f_feat, float nnratio, int checkOri, int32_t *match_of_f);
+int orc_search_by_bow_kf(int n1, int n2, const uint8_t *desc1, const uint8_t *desc2, const float *angle1, const float *angle2,
+                         const uint8_t *has_mp1, const uint8_t *has_mp2, int nodes1, const uint32_t *node_id1, const int32_t *node_start1,
+                         const int32_t *feat1, int nodes2, const uint32_t *node_id2, const int32_t *node_start2, const int32_t *feat2,
+                         float nnratio, int checkOri, int32_t *match12);
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq x 2*/,
                      int32_t *dist /*nq x 2*/);
 

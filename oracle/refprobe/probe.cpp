@@ -321,6 +321,7 @@ public:
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th);
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+    int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -985,6 +986,88 @@ int main(int argc, char **argv)
             fprintf(JL, "\"}%s\n", c + 1 < NLC ? "," : "");
         }
         fprintf(JL, "]}\n"); fclose(JL);
+    }
+    // ------------------------------------------------------------ G: ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, matches12) (glue)
+    {
+        path = std::string(outdir) + "/ref_glue_bow_kf.json";
+        FILE *JB = fopen(path.c_str(), "w");
+        fprintf(JB, "{\"_doc\": \"ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (so@0x82cc0) executed from the reference binary on hand-laid "
+                    "KeyFrame / MapPoint objects. match12[i1] = KF2 feature whose map point KF1 feature i1 received, -1 none\", \"cases\": [\n");
+        struct { int n1, n2, nodes; int check; uint64_t seed; } bc[] = {{500, 600, 140, 1, 9501}, {700, 400, 80, 0, 9502}};
+        const int NBC = 2;
+        typedef std::map<unsigned, std::vector<unsigned>> FeatVec;
+        for (int c = 0; c < NBC; c++) {
+            rng_seed(bc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int N1 = bc[c].n1, N2 = bc[c].n2, NN = bc[c].nodes;
+            std::vector<cv::KeyPoint> k1(N1), k2(N2);
+            std::vector<uint8_t> d1((size_t)N1 * 32), d2((size_t)N2 * 32);
+            std::vector<int> has1(N1), bad1(N1), has2(N2), bad2(N2);
+            std::vector<unsigned> nd1(N1), nd2(N2);
+            for (int i = 0; i < N1; i++) {
+                k1[i].x = uf() * 640.f; k1[i].y = uf() * 480.f; k1[i].size = 31.f; k1[i].angle = uf() * 360.f; k1[i].response = 1.f; k1[i].octave = 0; k1[i].class_id = -1;
+                for (int b = 0; b < 32; b++) d1[(size_t)i * 32 + b] = (uint8_t)rng_below(256);
+                has1[i] = uf() < 0.8f; bad1[i] = uf() < 0.05f; nd1[i] = 500u + 3u * rng_below((uint32_t)NN);
+            }
+            for (int j = 0; j < N2; j++) {
+                k2[j].x = uf() * 640.f; k2[j].y = uf() * 480.f; k2[j].size = 31.f; k2[j].response = 1.f; k2[j].octave = 0; k2[j].class_id = -1;
+                has2[j] = uf() < 0.8f; bad2[j] = uf() < 0.05f;
+                if (uf() < 0.7f) {
+                    const int src = (int)rng_below((uint32_t)N1);
+                    for (int b = 0; b < 32; b++) d2[(size_t)j * 32 + b] = d1[(size_t)src * 32 + b];
+                    const int flips = (int)rng_below(36);
+                    for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); d2[(size_t)j * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                    nd2[j] = uf() < 0.9f ? nd1[src] : 500u + 3u * rng_below((uint32_t)NN) + (uf() < 0.3f ? 1u : 0u);
+                    float a = k1[src].angle - (uf() < 0.8f ? 40.f + uf() * 8.f : uf() * 360.f);
+                    if (a < 0.f) a += 360.f;
+                    k2[j].angle = a;
+                } else {
+                    for (int b = 0; b < 32; b++) d2[(size_t)j * 32 + b] = (uint8_t)rng_below(256);
+                    nd2[j] = 500u + 3u * rng_below((uint32_t)NN) + (uf() < 0.3f ? 1u : 0u);
+                    k2[j].angle = uf() * 360.f;
+                }
+            }
+            char *kfa = (char *)bump(0x800), *kfb = (char *)bump(0x800); memset(kfa, 0, 0x800); memset(kfb, 0, 0x800);
+            char *mp1 = (char *)bump((size_t)N1 * 0x300), *mp2 = (char *)bump((size_t)N2 * 0x300); memset(mp1, 0, (size_t)N1 * 0x300); memset(mp2, 0, (size_t)N2 * 0x300);
+            std::vector<void *> m1(N1, nullptr), m2(N2, nullptr);
+            for (int i = 0; i < N1; i++) if (has1[i]) { m1[i] = mp1 + (size_t)i * 0x300; *(bool *)(mp1 + (size_t)i * 0x300 + 0x238) = bad1[i] != 0; }
+            for (int j = 0; j < N2; j++) if (has2[j]) { m2[j] = mp2 + (size_t)j * 0x300; *(bool *)(mp2 + (size_t)j * 0x300 + 0x238) = bad2[j] != 0; }
+            auto layk = [&](char *kf, std::vector<cv::KeyPoint> &keys, std::vector<uint8_t> &desc, std::vector<unsigned> &node, std::vector<void *> &mps, int n) {
+                void **v;
+                v = (void **)(kf + 0x170); v[0] = keys.data(); v[1] = keys.data() + n; v[2] = v[1];
+                mat_init((cv::Mat *)(kf + 0x1b8), desc.data(), n, 32, 32); ((cv::Mat *)(kf + 0x1b8))->flags |= 0x4000;
+                FeatVec *fv = new (kf + 0x248) FeatVec();
+                for (int i = 0; i < n; i++) (*fv)[node[i]].push_back((unsigned)i);
+                v = (void **)(kf + 0x520); v[0] = mps.data(); v[1] = mps.data() + n; v[2] = v[1];
+                return fv;
+            };
+            FeatVec *fv1 = layk(kfa, k1, d1, nd1, m1, N1), *fv2 = layk(kfb, k2, d2, nd2, m2, N2);
+            ORBmatcher *mt = new ORBmatcher(0.75f, bc[c].check != 0);
+            std::vector<MapPoint *> out;
+            const int nm = mt->SearchByBoW((KeyFrame *)kfa, (KeyFrame *)kfb, out);
+            std::vector<int> match(N1, -1);
+            for (int i = 0; i < N1 && i < (int)out.size(); i++) if (out[i]) match[i] = (int)(((char *)out[i] - mp2) / 0x300);
+            std::vector<float> a1(N1), a2(N2); std::vector<int> h1(N1), h2(N2);
+            for (int i = 0; i < N1; i++) { a1[i] = k1[i].angle; h1[i] = has1[i] && !bad1[i]; }
+            for (int j = 0; j < N2; j++) { a2[j] = k2[j].angle; h2[j] = has2[j] && !bad2[j]; }
+            auto flat = [&](FeatVec *fv, std::vector<int> &ids, std::vector<int> &starts, std::vector<int> &feats) {
+                for (auto &kv : *fv) { ids.push_back((int)kv.first); starts.push_back((int)feats.size()); for (unsigned x : kv.second) feats.push_back((int)x); }
+                starts.push_back((int)feats.size());
+            };
+            std::vector<int> id1, st1, fe1, id2, st2, fe2;
+            flat(fv1, id1, st1, fe1); flat(fv2, id2, st2, fe2);
+            fprintf(JB, "{\"n1\": %d, \"n2\": %d, \"nnratio\": 0.75, \"check_orientation\": %d, \"nmatches\": %d, ", N1, N2, bc[c].check, nm);
+            J = JB;
+            jarr_f("angle1", a1); jarr_f("angle2", a2); jarr_i("has_mp1", h1); jarr_i("has_mp2", h2);
+            jarr_i("node_id1", id1); jarr_i("node_start1", st1); jarr_i("feat1", fe1);
+            jarr_i("node_id2", id2); jarr_i("node_start2", st2); jarr_i("feat2", fe2); jarr_i("match", match);
+            fprintf(JB, "\"desc1\": \"");
+            for (size_t b = 0; b < d1.size(); b++) fprintf(JB, "%02x", d1[b]);
+            fprintf(JB, "\", \"desc2\": \"");
+            for (size_t b = 0; b < d2.size(); b++) fprintf(JB, "%02x", d2[b]);
+            fprintf(JB, "\"}%s\n", c + 1 < NBC ? "," : "");
+        }
+        fprintf(JB, "]}\n"); fclose(JB);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

@@ -64,7 +64,7 @@ class MapLineView(C.Structure):
 
 class BowView(C.Structure):
     _fields_ = [("n_kf", C.c_int32), ("n_f", C.c_int32), ("kf_desc", C.c_void_p), ("f_desc", C.c_void_p), ("kf_angle", C.c_void_p),
-                ("f_angle", C.c_void_p), ("kf_has_mp", C.c_void_p), ("kf_nodes", C.c_int32), ("f_nodes", C.c_int32),
+                ("f_angle", C.c_void_p), ("kf_has_mp", C.c_void_p), ("f_has_mp", C.c_void_p), ("kf_nodes", C.c_int32), ("f_nodes", C.c_int32),
                 ("kf_node_id", C.c_void_p), ("f_node_id", C.c_void_p), ("kf_node_start", C.c_void_p), ("f_node_start", C.c_void_p),
                 ("kf_feat", C.c_void_p), ("f_feat", C.c_void_p)]
 

@@ -25,7 +25,7 @@ struct FrameDev {
 };
 struct MapDev { int m; const float *proj_x, *proj_y, *proj_xr; const int *level; const float *view_cos; const uint8_t *in_view, *desc, *obs_positive; };
 struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; };
-struct BowDev { int n_kf, n_f; const uint8_t *kf_desc, *f_desc; const float *kf_angle, *f_angle; const uint8_t *kf_has_mp; int kf_nodes, f_nodes;
+struct BowDev { int n_kf, n_f; const uint8_t *kf_desc, *f_desc; const float *kf_angle, *f_angle; const uint8_t *kf_has_mp, *f_has_mp; int kf_nodes, f_nodes;
                 const uint32_t *kf_node_id, *f_node_id; const int *kf_node_start, *f_node_start; const int *kf_feat, *f_feat; };
 struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const uint8_t *desc; const float *scale_factors; };
 struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
@@ -33,7 +33,7 @@ struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; con
 __global__ void k_build_grid(const FrameDev *, int *, int *, int *, int);
 __global__ void k_mp_candidates(const FrameDev *, MapDev, float, const int *, int, uint8_t *, uint32_t *, int2 *, int, int *, int *);
 __global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, const uint8_t *, int, const uint32_t *, const int2 *, int, const int *);
-__global__ void k_match_bow(const BowDev *, float, int, int *, int, int *, int *);
+__global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
@@ -51,6 +51,7 @@ struct plf_matcher {
     float4 *d_cell_kp;
     BowDev *d_bow;       // pair table of plf_match_bow
     int *d_bow_fnode;    // scratch: frame feature -> first common node
+    int *d_bow_used;     // scratch: vbMatched2 of the (KeyFrame, KeyFrame) overload
     uint8_t *d_done;
     float4 *d_proj;
     plf_dmatch *d_dm;
@@ -64,7 +65,7 @@ struct plf_matcher {
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     free(h->h_frames); free(h->h_lframes);
@@ -102,6 +103,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     ALLOC(h->d_cell_kp, B * (size_t)max_keypoints * sizeof(float4));
     ALLOC(h->d_bow, B * sizeof(BowDev));
     ALLOC(h->d_bow_fnode, B * (size_t)max_keypoints * sizeof(int));
+    ALLOC(h->d_bow_used, B * (size_t)max_keypoints * sizeof(int));
     ALLOC(h->d_done, B * items);
     ALLOC(h->d_proj, (size_t)max_keypoints * sizeof(float4));
     ALLOC(h->d_knn_idx, 2 * (size_t)max_lines * sizeof(int));
@@ -198,28 +200,41 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
     return PLF_OK;
 }
 
-extern "C" int plf_match_bow(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation,
-                             int32_t *match_of_f, int32_t stride, int32_t *nmatches, void *stream)
+static int match_bow_impl(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation, int kfkf,
+                          int32_t *match, int32_t stride, int32_t *nmatches, void *stream)
 {
-    if (!h || !pairs || !match_of_f || !nmatches || n_pairs < 1 || n_pairs > h->max_batch || stride < 1 || stride > h->max_kp) return PLF_E_BADARG;
+    if (!h || !pairs || !match || !nmatches || n_pairs < 1 || n_pairs > h->max_batch || stride < 1 || stride > h->max_kp) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     std::vector<BowDev> pd(n_pairs);
     for (int i = 0; i < n_pairs; i++) {
         const plf_bow_view &v = pairs[i];
-        if (v.n_kf < 0 || v.n_f < 0 || v.n_f > stride || v.kf_nodes < 0 || v.f_nodes < 0) return PLF_E_BADARG;
+        if (v.n_kf < 0 || v.n_f < 0 || v.n_f > stride || v.kf_nodes < 0 || v.f_nodes < 0 || (kfkf && (v.n_kf > stride || !v.f_has_mp))) return PLF_E_BADARG;
         BowDev d;
         d.n_kf = v.n_kf; d.n_f = v.n_f; d.kf_desc = v.kf_desc; d.f_desc = v.f_desc; d.kf_angle = v.kf_angle; d.f_angle = v.f_angle;
-        d.kf_has_mp = v.kf_has_mp; d.kf_nodes = v.kf_nodes; d.f_nodes = v.f_nodes; d.kf_node_id = v.kf_node_id; d.f_node_id = v.f_node_id;
-        d.kf_node_start = v.kf_node_start; d.f_node_start = v.f_node_start; d.kf_feat = v.kf_feat; d.f_feat = v.f_feat;
+        d.kf_has_mp = v.kf_has_mp; d.f_has_mp = v.f_has_mp; d.kf_nodes = v.kf_nodes; d.f_nodes = v.f_nodes; d.kf_node_id = v.kf_node_id;
+        d.f_node_id = v.f_node_id; d.kf_node_start = v.kf_node_start; d.f_node_start = v.f_node_start; d.kf_feat = v.kf_feat; d.f_feat = v.f_feat;
         pd[i] = d;
     }
     PLF_HIP_TRY(hipStreamSynchronize(s));   // a previous launch may still read the pair table
     PLF_HIP_TRY(hipMemcpyAsync(h->d_bow, pd.data(), sizeof(BowDev) * n_pairs, hipMemcpyHostToDevice, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
-    hipLaunchKernelGGL(k_match_bow, dim3(n_pairs), dim3(256), 0, s, h->d_bow, nnratio, check_orientation, match_of_f, stride, nmatches, h->d_bow_fnode);
+    hipLaunchKernelGGL(k_match_bow, dim3(n_pairs), dim3(256), 0, s, h->d_bow, nnratio, check_orientation, kfkf, match, stride, nmatches, h->d_bow_fnode,
+                       h->d_bow_used);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
+}
+
+extern "C" int plf_match_bow(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation,
+                             int32_t *match_of_f, int32_t stride, int32_t *nmatches, void *stream)
+{
+    return match_bow_impl(h, pairs, n_pairs, nnratio, check_orientation, 0, match_of_f, stride, nmatches, stream);
+}
+
+extern "C" int plf_match_bow_kf(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs, float nnratio, int32_t check_orientation,
+                                int32_t *match12, int32_t stride, int32_t *nmatches, void *stream)
+{
+    return match_bow_impl(h, pairs, n_pairs, nnratio, check_orientation, 1, match12, stride, nmatches, stream);
 }
 
 extern "C" int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose,

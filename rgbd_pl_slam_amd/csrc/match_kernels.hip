@@ -519,14 +519,17 @@ struct BowDev {
     int n_kf, n_f;
     const uint8_t *kf_desc, *f_desc;
     const float *kf_angle, *f_angle;
-    const uint8_t *kf_has_mp;
+    const uint8_t *kf_has_mp, *f_has_mp;   // f_has_mp: second keyframe of the (KeyFrame, KeyFrame) overload, NULL for a Frame
     int kf_nodes, f_nodes;
     const uint32_t *kf_node_id, *f_node_id;
     const int *kf_node_start, *f_node_start;
     const int *kf_feat, *f_feat;
 };
 
-__device__ __forceinline__ int bow_node(const BowDev &P, int a, int b, float nnratio, int *__restrict__ match)
+// one common node.  kfkf = 0: SearchByBoW(KeyFrame*, Frame&): slot = frame feature, value = keyframe feature, accept best <= TH_LOW.
+// kfkf = 1: SearchByBoW(KeyFrame*, KeyFrame*) (include/ORBmatcher.h:105, so@0x82cc0): slot = KF1 feature, value = KF2 feature,
+// KF2 features need a good map point and are marked in used2 (vbMatched2), accept best < TH_LOW (so@0x83490).
+__device__ __forceinline__ int bow_node(const BowDev &P, int a, int b, float nnratio, int kfkf, int *__restrict__ match, int *__restrict__ used2)
 {
     int acc = 0;
     for (int p = P.kf_node_start[a]; p < P.kf_node_start[a + 1]; p++) {
@@ -536,29 +539,36 @@ __device__ __forceinline__ int bow_node(const BowDev &P, int a, int b, float nnr
         int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
         for (int q = P.f_node_start[b]; q < P.f_node_start[b + 1]; q++) {
             const int jf = P.f_feat[q];
-            if (match[jf] >= 0) continue;
+            if (kfkf ? (used2[jf] != 0 || !P.f_has_mp[jf]) : (match[jf] >= 0)) continue;
             const int dist = hamming_g(dKF, P.f_desc + (size_t)jf * 32);
             if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
             else if (dist < bestDist2) bestDist2 = dist;
         }
-        if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) { match[bestIdxF] = ikf; acc++; }
+        if ((kfkf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) && (float)bestDist1 < nnratio * (float)bestDist2) {
+            if (kfkf) { match[ikf] = bestIdxF; used2[bestIdxF] = 1; }
+            else match[bestIdxF] = ikf;
+            acc++;
+        }
     }
     return acc;
 }
 
-__global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pairs, float nnratio, int check_ori, int *__restrict__ match_all,
-                                                   int stride, int *__restrict__ nmatches, int *__restrict__ fnode_all)
+__global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pairs, float nnratio, int check_ori, int kfkf, int *__restrict__ match_all,
+                                                   int stride, int *__restrict__ nmatches, int *__restrict__ fnode_all, int *__restrict__ used_all)
 {
-    __shared__ int hist[HISTO_LENGTH], keepbin[3], s_acc, s_shared;
+    __shared__ int hist[HISTO_LENGTH], keepbin[3], s_acc, s_shared, s_dup1;
     const int pr = blockIdx.x, t = threadIdx.x, T = blockDim.x;
     const BowDev P = pairs[pr];
     int *match = match_all + (size_t)pr * stride;
-    int *fnode = fnode_all + (size_t)pr * stride;   // frame feature -> first common node that lists it (scratch)
-    for (int j = t; j < P.n_f; j += T) { match[j] = -1; fnode[j] = 0x7fffffff; }
+    int *fnode = fnode_all + (size_t)pr * stride;   // second-side feature -> first common node that lists it (scratch)
+    int *used2 = used_all + (size_t)pr * stride;    // kfkf: vbMatched2, then reused to detect KF1 features listed twice
+    const int nslot = kfkf ? P.n_kf : P.n_f;
+    for (int j = t; j < nslot; j += T) match[j] = -1;
+    for (int j = t; j < P.n_f; j += T) { fnode[j] = 0x7fffffff; used2[j] = 0; }
     if (t < HISTO_LENGTH) hist[t] = 0;
-    if (t == 0) { s_acc = 0; s_shared = 0; }
+    if (t == 0) { s_acc = 0; s_shared = 0; s_dup1 = 0; }
     __syncthreads();
-    // common nodes: binary search of every keyframe node in the frame's node list; detect frame features listed twice
+    // common nodes: binary search of every first-side node in the second side's node list; detect second-side features listed twice
     for (int a = t; a < P.kf_nodes; a += T) {
         const uint32_t id = P.kf_node_id[a];
         int lo = 0, hi = P.f_nodes;
@@ -567,14 +577,24 @@ __global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pa
             for (int q = P.f_node_start[lo]; q < P.f_node_start[lo + 1]; q++)
                 if (atomicMin(&fnode[P.f_feat[q]], a) != 0x7fffffff) s_shared = 1;
     }
+    if (kfkf) {   // a KF1 feature listed twice would make the nodes depend on each other through its output slot
+        for (int q = t; q < P.kf_node_start[P.kf_nodes]; q += T)
+            if (atomicExch(&match[P.kf_feat[q]], -3) == -3) s_dup1 = 1;
+        __syncthreads();
+        for (int j = t; j < nslot; j += T) match[j] = -1;
+    }
     __syncthreads();
+    if (kfkf && s_dup1) {   // not a DBoW2 feature vector: refuse instead of guessing
+        if (t == 0) nmatches[pr] = -1;
+        return;
+    }
     if (!s_shared) {
         int acc = 0;
         for (int a = t; a < P.kf_nodes; a += T) {
             const uint32_t id = P.kf_node_id[a];
             int lo = 0, hi = P.f_nodes;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.f_node_id[mid] < id) lo = mid + 1; else hi = mid; }
-            if (lo < P.f_nodes && P.f_node_id[lo] == id) acc += bow_node(P, a, lo, nnratio, match);
+            if (lo < P.f_nodes && P.f_node_id[lo] == id) acc += bow_node(P, a, lo, nnratio, kfkf, match, used2);
         }
         if (acc) atomicAdd(&s_acc, acc);
     } else if (t == 0) {
@@ -582,46 +602,39 @@ __global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pa
         while (a < P.kf_nodes && b < P.f_nodes) {
             if (P.kf_node_id[a] < P.f_node_id[b]) { a++; continue; }
             if (P.kf_node_id[a] > P.f_node_id[b]) { b++; continue; }
-            acc += bow_node(P, a, b, nnratio, match);
+            acc += bow_node(P, a, b, nnratio, kfkf, match, used2);
             a++; b++;
         }
         s_acc = acc;
     }
     __syncthreads();
     if (check_ori) {
-        for (int j = t; j < P.n_f; j += T) {
-            const int i = match[j];
-            if (i < 0) continue;
-            float rot = P.kf_angle[i] - P.f_angle[j];
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * (1.0f / 12.0f));
-            if (bin == HISTO_LENGTH) bin = 0;
-            atomicAdd(&hist[bin], 1);
-        }
-        __syncthreads();
-        if (t == 0) {  // ComputeThreeMaxima (so@0x79c40)
-            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
-            for (int i = 0; i < HISTO_LENGTH; i++) {
-                const int sz = hist[i];
-                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
-                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
-                else if (sz > max3) { max3 = sz; i3 = i; }
+        for (int pass = 0; pass < 2; pass++) {
+            for (int j = t; j < nslot; j += T) {
+                const int i = match[j];
+                if (i < 0) continue;
+                float rot = kfkf ? P.kf_angle[j] - P.f_angle[i] : P.kf_angle[i] - P.f_angle[j];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / 12.0f));
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (pass == 0) atomicAdd(&hist[bin], 1);
+                else if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { match[j] = -1; atomicSub(&s_acc, 1); }
             }
-            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
-            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
-            keepbin[0] = i1; keepbin[1] = i2; keepbin[2] = i3;
+            __syncthreads();
+            if (pass == 0 && t == 0) {  // ComputeThreeMaxima (so@0x79c40)
+                int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+                for (int i = 0; i < HISTO_LENGTH; i++) {
+                    const int sz = hist[i];
+                    if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                    else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                    else if (sz > max3) { max3 = sz; i3 = i; }
+                }
+                if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+                else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+                keepbin[0] = i1; keepbin[1] = i2; keepbin[2] = i3;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int j = t; j < P.n_f; j += T) {
-            const int i = match[j];
-            if (i < 0) continue;
-            float rot = P.kf_angle[i] - P.f_angle[j];
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * (1.0f / 12.0f));
-            if (bin == HISTO_LENGTH) bin = 0;
-            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { match[j] = -1; atomicSub(&s_acc, 1); }
-        }
-        __syncthreads();
     }
     if (t == 0) nmatches[pr] = s_acc;
 }

@@ -89,12 +89,13 @@ class Matcher:
         return v
 
     @staticmethod
-    def bow_view(kf_desc, f_desc, kf_angle, f_angle, kf_has_mp, kf_nodes, f_nodes):
+    def bow_view(kf_desc, f_desc, kf_angle, f_angle, kf_has_mp, kf_nodes, f_nodes, f_has_mp=None):
         """one (keyframe, frame) pair of SearchByBoW; *_nodes = (node_id uint32[K], node_start int32[K+1], feat int32[*]) device tensors"""
         v = L.BowView()
         v.n_kf = int(kf_desc.shape[0]); v.n_f = int(f_desc.shape[0])
         v.kf_desc = L.vp(kf_desc).value; v.f_desc = L.vp(f_desc).value; v.kf_angle = L.vp(kf_angle).value; v.f_angle = L.vp(f_angle).value
         v.kf_has_mp = L.vp(kf_has_mp).value
+        v.f_has_mp = L.vp(f_has_mp).value if f_has_mp is not None else None
         v.kf_nodes = int(kf_nodes[0].shape[0]); v.f_nodes = int(f_nodes[0].shape[0])
         v.kf_node_id = L.vp(kf_nodes[0]).value; v.kf_node_start = L.vp(kf_nodes[1]).value; v.kf_feat = L.vp(kf_nodes[2]).value
         v.f_node_id = L.vp(f_nodes[0]).value; v.f_node_start = L.vp(f_nodes[1]).value; v.f_feat = L.vp(f_nodes[2]).value
@@ -105,6 +106,12 @@ class Matcher:
         arr = (L.BowView * len(pairs))(*pairs)
         L.check(L.lib().plf_match_bow(self._h, arr, len(pairs), C.c_float(nnratio), int(bool(check_orientation)), L.vp(match_of_f), int(stride),
                                       L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_bow")
+
+    def SearchByBoWKeyFrames(self, pairs, nnratio, check_orientation, match12, stride, nmatches, stream=None):
+        """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) for a batch of keyframe pairs"""
+        arr = (L.BowView * len(pairs))(*pairs)
+        L.check(L.lib().plf_match_bow_kf(self._h, arr, len(pairs), C.c_float(nnratio), int(bool(check_orientation)), L.vp(match12), int(stride),
+                                         L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_bow_kf")
 
     def SearchLinesByProjection(self, frames, ml, th, nnratio, match_of_line, line_stride, nmatches, stream=None):
         arr = (L.LineFrameView * len(frames))(*frames)

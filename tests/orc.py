@@ -278,3 +278,15 @@ def search_by_bow(kf_desc, f_desc, kf_angle, f_angle, kf_has_mp, kf_nodes, f_nod
                             p(kn[2]), C.c_int(len(fn[0])), p(fn[0]), p(fn[1]), p(fn[2]), C.c_float(nnratio), C.c_int(int(check_ori)), p(match))
     return match, n
 
+
+def search_by_bow_kf(desc1, desc2, angle1, angle2, has_mp1, has_mp2, nodes1, nodes2, nnratio, check_ori):
+    L = lib()
+    a = [np.ascontiguousarray(x) for x in (desc1, desc2, np.asarray(angle1, np.float32), np.asarray(angle2, np.float32), np.asarray(has_mp1, np.uint8),
+                                           np.asarray(has_mp2, np.uint8))]
+    n1 = [np.ascontiguousarray(nodes1[0], np.uint32), np.ascontiguousarray(nodes1[1], np.int32), np.ascontiguousarray(nodes1[2], np.int32)]
+    n2 = [np.ascontiguousarray(nodes2[0], np.uint32), np.ascontiguousarray(nodes2[1], np.int32), np.ascontiguousarray(nodes2[2], np.int32)]
+    match = np.full(len(a[0]), -1, np.int32)
+    n = L.orc_search_by_bow_kf(C.c_int(len(a[0])), C.c_int(len(a[1])), p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), C.c_int(len(n1[0])), p(n1[0]),
+                               p(n1[1]), p(n1[2]), C.c_int(len(n2[0])), p(n2[0]), p(n2[1]), p(n2[2]), C.c_float(nnratio), C.c_int(int(check_ori)), p(match))
+    return match, n
+

@@ -130,3 +130,18 @@ def load_search_last_cases(path):
                         scale=f32(c["scale"]), last=last, pose=pose, th=float(cam[6]), mono=int(c["mono"]), check=int(c["check_orientation"]),
                         init=np.array(c["init"], np.int32), match=match, nmatches=c["nmatches"]))
     return out
+
+
+def load_bow_kf_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    out = []
+    for c in json.load(open(path))["cases"]:
+        out.append(dict(desc1=np.frombuffer(bytes.fromhex(c["desc1"]), np.uint8).reshape(c["n1"], 32).copy(),
+                        desc2=np.frombuffer(bytes.fromhex(c["desc2"]), np.uint8).reshape(c["n2"], 32).copy(),
+                        angle1=f32(c["angle1"]), angle2=f32(c["angle2"]), has_mp1=np.array(c["has_mp1"], np.uint8), has_mp2=np.array(c["has_mp2"], np.uint8),
+                        nodes1=(np.array(c["node_id1"], np.uint32), np.array(c["node_start1"], np.int32), np.array(c["feat1"], np.int32)),
+                        nodes2=(np.array(c["node_id2"], np.uint32), np.array(c["node_start2"], np.int32), np.array(c["feat2"], np.int32)),
+                        nnratio=float(c["nnratio"]), check=int(c["check_orientation"]), match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
+    return out
+

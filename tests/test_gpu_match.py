@@ -273,3 +273,33 @@ def test_gpu_equals_reference_search_by_projection_lastframe_fixture():
         assert np.array_equal(match.cpu().numpy(), c["match"])
         m.close()
 
+
+def test_search_by_bow_keyframes():
+    """plf_match_bow_kf vs the reference binary's fixture and vs the oracle on random keyframe pairs"""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    cases = []
+    for c in refgen.load_bow_kf_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_bow_kf.json")):
+        cases.append(dict(c, expect=(c["match"], c["nmatches"])))
+    for seed, (n1, n2, nn, ratio, chk) in enumerate([(900, 1000, 300, 0.75, 1), (400, 300, 50, 0.9, 0)]):
+        r = _bow_random_case(200 + seed, n1, n2, nn)
+        rng = np.random.default_rng(seed)
+        c = dict(desc1=r["kf_desc"], desc2=r["f_desc"], angle1=r["kf_angle"], angle2=r["f_angle"], has_mp1=r["kf_has_mp"],
+                 has_mp2=(rng.uniform(0, 1, n2) < 0.8).astype(np.uint8), nodes1=r["kf_nodes"], nodes2=r["f_nodes"], nnratio=ratio, check=chk)
+        c["expect"] = orc.search_by_bow_kf(c["desc1"], c["desc2"], c["angle1"], c["angle2"], c["has_mp1"], c["has_mp2"], c["nodes1"], c["nodes2"], ratio, chk)
+        cases.append(c)
+    m = Matcher(max_keypoints=2048, max_mappoints=16, max_batch=4)
+    for c in cases:
+        t = [_dev(c[k]) for k in ("desc1", "desc2", "angle1", "angle2", "has_mp1", "has_mp2")]
+        k1 = tuple(_dev(x) for x in c["nodes1"]); k2 = tuple(_dev(x) for x in c["nodes2"])
+        view = Matcher.bow_view(t[0], t[1], t[2], t[3], t[4], k1, k2, f_has_mp=t[5])
+        match = torch.full((1, 2048), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchByBoWKeyFrames([view], c["nnratio"], c["check"], match, 2048, nm)
+        torch.cuda.synchronize()
+        assert int(nm[0]) == c["expect"][1]
+        assert np.array_equal(match[0, :len(c["desc1"])].cpu().numpy(), c["expect"][0])
+    m.close()
+
