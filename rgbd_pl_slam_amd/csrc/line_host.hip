@@ -38,7 +38,7 @@ struct plf_line {
     size_t regions_lds, finalize_lds, nfa_lds;
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
-    double *d_modgrad, *d_rmod, *d_lineeq, *d_lgam;
+    double *d_modgrad, *d_lineeq, *d_lgam;
     NfaEntry *d_ent[2];
     NfaState *d_st[2];
     NfaCounts *d_cnt;
@@ -46,7 +46,7 @@ struct plf_line {
     double *d_vals;
     double2 *d_cs;
     float2 *d_cs0;
-    float *d_ang, *d_rdeg;
+    float *d_ang;
     uint32_t *d_rxy;
     LsdRect *d_rects;
     float4 *d_seg, *d_segs_out;
@@ -66,8 +66,8 @@ struct plf_line {
 
 static void line_free(plf_line *h)
 {
-    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_rmod, h->d_lineeq, h->d_cs,
-                    h->d_ang, h->d_rdeg, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
+    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_lineeq, h->d_cs,
+                    h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
