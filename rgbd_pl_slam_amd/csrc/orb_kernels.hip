@@ -153,6 +153,53 @@ __device__ __forceinline__ int fast_score_ring(const int d[16], int t)
     return s < 0 ? 0 : s;
 }
 
+// FAST score of TWO horizontally adjacent pixels at once in packed int16 lanes (v_pk_sub/min/max_i16): the ring
+// differences are in [-255, 255].  Same arithmetic as fast_score_ring: the opposite-pair precheck at the lowest
+// threshold gates each pixel separately, the min3/max3 sliding windows give the score.
+typedef short plf_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ plf_s2 pk_min(plf_s2 a, plf_s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ plf_s2 pk_max(plf_s2 a, plf_s2 b) { return __builtin_elementwise_max(a, b); }
+// bytes i and i+1 (0 <= i <= 10) of the 12-byte row segment R as two zero-extended int16 (one v_perm_b32)
+#define SB_PAIR(R, i) __builtin_bit_cast(plf_s2, __builtin_amdgcn_perm((R)[((i) >> 2) < 2 ? ((i) >> 2) + 1 : 2], (R)[(i) >> 2], \
+                                                                       (uint32_t)((i) & 3) | 0x0C000C00u | ((uint32_t)(((i) & 3) + 1) << 16)))
+
+__device__ __forceinline__ void fast_score_pair(const uint32_t (*raw)[3], int j, int t, int &s_lo, int &s_hi)
+{
+    const int c = 4 + j;
+    const plf_s2 v = SB_PAIR(raw[3], c);
+    plf_s2 d[16];
+    d[0] = v - SB_PAIR(raw[6], c);      d[1] = v - SB_PAIR(raw[6], c + 1);  d[2] = v - SB_PAIR(raw[5], c + 2);  d[3] = v - SB_PAIR(raw[4], c + 3);
+    d[4] = v - SB_PAIR(raw[3], c + 3);  d[5] = v - SB_PAIR(raw[2], c + 3);  d[6] = v - SB_PAIR(raw[1], c + 2);  d[7] = v - SB_PAIR(raw[0], c + 1);
+    d[8] = v - SB_PAIR(raw[0], c);      d[9] = v - SB_PAIR(raw[0], c - 1);  d[10] = v - SB_PAIR(raw[1], c - 2); d[11] = v - SB_PAIR(raw[2], c - 3);
+    d[12] = v - SB_PAIR(raw[3], c - 3); d[13] = v - SB_PAIR(raw[4], c - 3); d[14] = v - SB_PAIR(raw[5], c - 2); d[15] = v - SB_PAIR(raw[6], c - 1);
+    // every 9-arc contains one pixel of each opposite pair: bright needs min_k max(d[k], d[k+8]) > t, dark max_k min(...) < -t
+    plf_s2 bmin = pk_max(d[0], d[8]), dmax = pk_min(d[0], d[8]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        bmin = pk_min(bmin, pk_max(d[k], d[k + 8]));
+        dmax = pk_max(dmax, pk_min(d[k], d[k + 8]));
+    }
+    const bool p_lo = bmin.x > t || dmax.x < -t, p_hi = bmin.y > t || dmax.y < -t;
+    s_lo = 0; s_hi = 0;
+    if (!(p_lo || p_hi)) return;
+    plf_s2 m3[16], M3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        m3[k] = pk_min(d[k], pk_min(d[(k + 1) & 15], d[(k + 2) & 15]));
+        M3[k] = pk_max(d[k], pk_max(d[(k + 1) & 15], d[(k + 2) & 15]));
+    }
+    plf_s2 sb = {-256, -256}, sd = {256, 256};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        sb = pk_max(sb, pk_min(m3[k], pk_min(m3[(k + 3) & 15], m3[(k + 6) & 15])));
+        sd = pk_min(sd, pk_max(M3[k], pk_max(M3[(k + 3) & 15], M3[(k + 6) & 15])));
+    }
+    const plf_s2 zero = {0, 0}, one = {1, 1};
+    const plf_s2 sc = pk_max(pk_max(sb, zero - sd) - one, zero);
+    if (p_lo) s_lo = sc.x;
+    if (p_hi) s_hi = sc.y;
+}
+
 // byte i (0..11) of the 12-byte row segment held in three dwords
 #define SB_BYTE(R, i) ((int)(((R)[(i) >> 2] >> (8 * ((i) & 3))) & 0xFFu))
 
@@ -225,16 +272,12 @@ __global__ void __launch_bounds__(64) k_score_blur(const uint8_t *__restrict__ p
         if (oy < PLF_EDGE || oy >= L.h - PLF_EDGE || x + 3 < PLF_EDGE || x >= L.w - PLF_EDGE) continue;
         uint32_t sw = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int gx = x + j;
-            if (gx < PLF_EDGE || gx >= L.w - PLF_EDGE) continue;
-            const int c = 4 + j, v = SB_BYTE(raw[3], c);
-            int d[16];
-            d[0] = v - SB_BYTE(raw[6], c);      d[1] = v - SB_BYTE(raw[6], c + 1);  d[2] = v - SB_BYTE(raw[5], c + 2);  d[3] = v - SB_BYTE(raw[4], c + 3);
-            d[4] = v - SB_BYTE(raw[3], c + 3);  d[5] = v - SB_BYTE(raw[2], c + 3);  d[6] = v - SB_BYTE(raw[1], c + 2);  d[7] = v - SB_BYTE(raw[0], c + 1);
-            d[8] = v - SB_BYTE(raw[0], c);      d[9] = v - SB_BYTE(raw[0], c - 1);  d[10] = v - SB_BYTE(raw[1], c - 2); d[11] = v - SB_BYTE(raw[2], c - 3);
-            d[12] = v - SB_BYTE(raw[3], c - 3); d[13] = v - SB_BYTE(raw[4], c - 3); d[14] = v - SB_BYTE(raw[5], c - 2); d[15] = v - SB_BYTE(raw[6], c - 1);
-            sw |= (uint32_t)fast_score_ring(d, g.minTh) << (8 * j);
+        for (int j = 0; j < 4; j += 2) {
+            int s0, s1;
+            fast_score_pair(raw, j, g.minTh, s0, s1);
+            if (x + j < PLF_EDGE || x + j >= L.w - PLF_EDGE) s0 = 0;
+            if (x + j + 1 < PLF_EDGE || x + j + 1 >= L.w - PLF_EDGE) s1 = 0;
+            sw |= ((uint32_t)s0 | ((uint32_t)s1 << 8)) << (8 * j);
         }
         uint8_t *so = sp + (size_t)oy * L.bpitch + x;
         if (full) *(uint32_t *)so = sw;
