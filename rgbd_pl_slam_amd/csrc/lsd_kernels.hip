@@ -257,29 +257,29 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;
     int cur_n = 1;
     Grp cur = load_group(C, 0, 1, lane, slot, kx, ky);
-    bool cur_stale = false;   // this lane's pixel was accepted after its word was loaded
+    unsigned long long cur_stale = 0ull;   // lanes whose pixel was accepted after its word was loaded
+    // All per-lane predicates of the accept loop are kept as wave-uniform 64-bit masks (the compares write them
+    // directly), so the loop control is scalar and nothing bounces between VGPR booleans and masks.
     while (i < n) {
         CNT(7, 1);
         // ---- issue the loads of the next group: list entries that exist now
         int nx_n = min(7, n - (i + cur_n));
         if (nx_n < 0) nx_n = 0;
         Grp nx = load_group(C, i + cur_n, nx_n, lane, slot, kx, ky);
-        bool nx_stale = false;
+        unsigned long long nx_stale = 0ull;
         // ---- process the current group
         CNT(8, cur_n);
-        bool cand = cur.w < 0x80000000u && !cur_stale;
+        unsigned long long candm = __ballot(cur.w < 0x80000000u) & ~cur_stale;
         const float ux = (float)cur.csx, uy = (float)cur.csy;
-        while (true) {
-            // classification against the current sums
-            bool sA = false, bd = cand;
+        while (candm) {
+            // classification of the remaining candidates against the current sums
+            unsigned long long mA = 0ull, mB = candm;
             if (th.t1 >= 0.f && sumdx * sumdx + sumdy * sumdy >= 0.25f) {
                 const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
-                sA = cand && dot > 0.f && acr <= th.t1 * dot;
-                const bool sR = !(dot > 0.f) || acr >= th.t2 * dot;
-                bd = cand && !sA && !sR;
+                const unsigned long long pos = __ballot(dot > 0.f);
+                mA = candm & pos & __ballot(acr <= th.t1 * dot);
+                mB = candm & ~mA & pos & ~__ballot(acr >= th.t2 * dot);
             }
-            const unsigned long long mA = __ballot(sA);
-            unsigned long long mB = __ballot(bd);
             int k = -1;
             while (mA | mB) {
                 const int j = __ffsll((long long)(mA | mB)) - 1;
@@ -319,8 +319,8 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             sumdy = (float)((double)sumdy + ss);
             theta_valid = false;
             ++n;
-            cand = cand && lane > k && cur.a != ka;
-            nx_stale = nx_stale || nx.a == ka;
+            candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.a == ka);   // lanes up to k are decided; the pixel is taken
+            nx_stale |= __ballot(nx.a == ka);
             if ((unsigned)(ka - C.cbase) < 64u) C.cused |= 1ull << (ka - C.cbase);
         }
         CBAR();
@@ -328,7 +328,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         if (nx_n == 0 && i < n) {   // nothing could be loaded ahead (short list): load the next group now
             nx_n = min(7, n - i);
             nx = load_group(C, i, nx_n, lane, slot, kx, ky);
-            nx_stale = false;
+            nx_stale = 0ull;
         }
         cur = nx; cur_n = nx_n; cur_stale = nx_stale;
     }
@@ -450,9 +450,9 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
             }
             C.rxy_l[C.rcap] = (uint32_t)m;  // one spare LDS word carries the new size to the other lanes
         }
-        __syncthreads();
+        CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
         n = (int)C.rxy_l[C.rcap];
-        __syncthreads();
+        CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
         if (n < 2) return false;
         region2rect(C, n, reg_angle, prec, p, rec);
         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -495,7 +495,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
             ++cnt;
         }
     }
-    __syncthreads();
+    CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
     n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
