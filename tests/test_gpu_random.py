@@ -136,3 +136,44 @@ def test_hamming_properties_full_size():
     # triangle inequality d(a_i, b_j) <= d(a_i, b_k) + d(b_k, b_j) on a sample
     i = torch.randint(0, 5000, (2000,), device="cuda"); j = torch.randint(0, 1000, (2000,), device="cuda"); k = torch.randint(0, 1000, (2000,), device="cuda")
     assert bool((dab[i, j] <= dab[i, k] + dbb[k, j]).all())
+
+
+def test_bench_size_batch_is_exact_and_deterministic():
+    """BASELINE-size run: 4096 frames in flight (the default of bench.py; 16 region-growing chains per CU).  Every replica of a
+    frame must reproduce the bytes of its original, and the originals must equal the oracle: key lines, LBD rows, line
+    equations, key points, descriptors.  (Size-independent property: idempotence under batching.)"""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment
+    from rgbd_pl_slam_amd.synth import synth_batch
+    from rgbd_pl_slam_amd._lib import KP_DTYPE
+    B, R = 4096, 8
+    base = synth_batch(900, R)
+    d = torch.from_numpy(np.concatenate([base] * (B // R))).cuda()
+    ext = ORBextractor(max_width=640, max_height=480, max_batch=B)
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
+    cap = ext.capacity
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    lines = torch.zeros((B, 100, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, 100, 32), dtype=torch.uint8, device="cuda")
+    leq = torch.zeros((B, 100, 3), dtype=torch.float64, device="cuda"); nl = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ext.extract_batch_device(d, 640, 480, kps, desc, n, cap, s)
+    ls.extract_batch_device(d, 640, 480, lines, ldesc, leq, nl, 100, s)
+    torch.cuda.synchronize()
+    nh, nlh = n.cpu().numpy(), nl.cpu().numpy()
+    assert (nh.reshape(-1, R) == nh[:R]).all() and (nlh.reshape(-1, R) == nlh[:R]).all()
+    for f in range(R):   # replicas == originals, compared on the device (the full arrays are ~1 GB)
+        k = int(nh[f]); l = int(nlh[f])
+        assert bool((desc[f::R, :k] == desc[f, :k]).all()) and bool((kps[f::R, :k].view(torch.int32) == kps[f, :k].view(torch.int32)).all())
+        assert bool((ldesc[f::R, :l] == ldesc[f, :l]).all()) and bool((lines[f::R, :l].view(torch.int32) == lines[f, :l].view(torch.int32)).all())
+        assert bool((leq[f::R, :l].view(torch.int64) == leq[f, :l].view(torch.int64)).all())
+        ref = orc.orb_extract(base[f])
+        assert k == len(ref["kps"]) and np.array_equal(desc[f, :k].cpu().numpy(), ref["desc"])
+        kk = np.frombuffer(kps[f, :k].cpu().numpy().tobytes(), KP_DTYPE)
+        for fld in ("x", "y", "angle", "response"):
+            assert np.array_equal(kk[fld].view(np.uint32), ref["kps"][fld].view(np.uint32)), fld
+        rl = orc.line_extract(base[f], 100)
+        assert l == len(rl["kl"]) and np.array_equal(ldesc[f, :l].cpu().numpy(), rl["desc"])
+    ext.close(); ls.close()
+
