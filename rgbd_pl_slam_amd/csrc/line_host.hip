@@ -7,12 +7,15 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <hipcub/hipcub.hpp>
 #include "plf_common.h"
 #include "lsd_geom.h"
 
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *);
-__global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom);
+__global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
+__global__ void k_lsd_maxgrad(const float *, const double *, double *, LsdGeom);
+__global__ void k_lsd_seedkeys(const double *, const double *, uint32_t *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
 struct NfaCounts { int total, alg[6], pad; };
@@ -39,6 +42,12 @@ struct plf_line {
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
     double *d_modgrad, *d_lineeq, *d_lgam;
+    // seed_order = 1 only: per-frame max gradient, (bin, pixel) keys before / after the segmented sort, segment offsets, sort scratch
+    double *d_maxgrad;
+    uint32_t *d_keys[2];
+    int *d_seg_off;
+    void *d_sort_tmp;
+    size_t sort_tmp_bytes;
     NfaEntry *d_ent[2];
     NfaState *d_st[2];
     NfaCounts *d_cnt;
@@ -66,7 +75,7 @@ struct plf_line {
 
 static void line_free(plf_line *h)
 {
-    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_lineeq, h->d_cs,
+    void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -156,7 +165,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     if (!p || !out) return PLF_E_BADARG;
     *out = nullptr;
     if (p->nlines < 1 || p->max_batch < 1 || p->max_width < 16 || p->max_height < 16) return PLF_E_BADARG;
-    if (p->seed_order != 0) return PLF_E_BADARG;  // only the OpenCV 3.0-3.3 raster seed order is implemented on the GPU
+    if (p->seed_order != 0 && p->seed_order != 1) return PLF_E_BADARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fprintf(stderr, "[plf] no HIP device available: the line extractor has no CPU path\n");
@@ -216,6 +225,16 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_cnt, B * R * 5 * sizeof(NfaCounts));
     ALLOC(h->d_nfa_counters, 16 * sizeof(int));
     ALLOC(h->d_vals, B * R * 6 * sizeof(double));
+    if (p->seed_order == 1) {
+        if ((size_t)g.sw * g.sh >= (1u << 20)) { line_free(h); free(h); return PLF_E_BADARG; }   // pixel index must fit the 20 low key bits
+        ALLOC(h->d_maxgrad, B * sizeof(double));
+        ALLOC(h->d_keys[0], B * S * sizeof(uint32_t)); ALLOC(h->d_keys[1], B * S * sizeof(uint32_t));
+        ALLOC(h->d_seg_off, (2 * B) * sizeof(int));
+        h->sort_tmp_bytes = 0;
+        if (hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, h->sort_tmp_bytes, h->d_keys[0], h->d_keys[1], (int)(B * S), (int)B, h->d_seg_off,
+                                                       h->d_seg_off + B, 0, 30, (hipStream_t)0) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
+        ALLOC(h->d_sort_tmp, h->sort_tmp_bytes + 256);
+    }
     ALLOC(h->d_xofs, sizeof(int) * (size_t)g.sw); ALLOC(h->d_xa, sizeof(float2) * (size_t)g.sw);
     ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
 #undef ALLOC
@@ -261,8 +280,22 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (!h->prof_ev[2 * h->prof_n]) { (void)hipEventCreate(&h->prof_ev[2 * h->prof_n]); (void)hipEventCreate(&h->prof_ev[2 * h->prof_n + 1]); }
         (void)hipEventRecord(h->prof_ev[2 * h->prof_n], s);
     }
+    const uint32_t *seeds = nullptr;
+    if (h->prm.seed_order == 1) {   // published LSD order: bins descending, raster inside a bin
+        std::vector<int> off(2 * (size_t)B);
+        for (int f = 0; f < B; f++) { off[f] = (int)((size_t)f * g.s_stride); off[B + f] = off[f] + g.sw * g.sh; }
+        PLF_HIP_TRY(hipStreamSynchronize(s));   // a previous sort may still read the offsets
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_seg_off, off.data(), sizeof(int) * 2 * B, hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_lsd_maxgrad, dim3(B), dim3(256), 0, s, h->d_ang, h->d_modgrad, h->d_maxgrad, g);
+        hipLaunchKernelGGL(k_lsd_seedkeys, dim3((g.sw * g.sh + 255) / 256, B), dim3(256), 0, s, h->d_modgrad, h->d_maxgrad, h->d_keys[0], g);
+        size_t tmp = h->sort_tmp_bytes;
+        PLF_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(h->d_sort_tmp, tmp, h->d_keys[0], h->d_keys[1], (int)((size_t)h->prm.max_batch * g.s_stride), B,
+                                                               h->d_seg_off, h->d_seg_off + B, 0, 30, s));
+        seeds = h->d_keys[1];
+    }
     hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
-                       h->d_rects, nrect, status, g);
+                       h->d_rects, nrect, status, g, seeds);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)
     PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));

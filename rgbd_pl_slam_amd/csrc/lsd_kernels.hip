@@ -125,6 +125,47 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Published LSD seed order (seed_order = 1; every OpenCV release except 3.0-3.3): pixels sorted by gradient-magnitude
+// bin, strongest bin first, raster order inside a bin (a stable counting sort upstream).  The key packs
+// (1023 - bin) << 20 | pixel, so an ascending sort of the keys of a frame is exactly that order.
+// bin = int(modgrad * (1023 / max_grad)), max_grad over the pixels with a defined angle (oracle/lsd_oracle.c).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lsd_maxgrad(const float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                     double *__restrict__ maxgrad, LsdGeom g)
+{
+    __shared__ double red[256];
+    const int f = blockIdx.x, t = threadIdx.x, NP = g.sw * g.sh;
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    const double *mg = modgrad_all + (size_t)f * g.s_stride;
+    double m = -1.0;
+    for (int a = t; a < NP; a += 256)
+        if (ang[a] != NOTDEF_F && mg[a] > m) m = mg[a];
+    red[t] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) maxgrad[f] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_lsd_seedkeys(const double *__restrict__ modgrad_all, const double *__restrict__ maxgrad,
+                                                      uint32_t *__restrict__ keys_all, LsdGeom g)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y, NP = g.sw * g.sh;
+    if (a >= NP) return;
+    const double mx = maxgrad[f];
+    const double bin_coef = (mx > 0) ? 1023.0 / mx : 0.0;
+    const int x = a % g.sw, y = a / g.sw;
+    int b = 0;   // last row / column: never seeds (angle NOTDEF), parked in the weakest bin
+    if (x < g.sw - 1 && y < g.sh - 1) {
+        b = (int)(modgrad_all[(size_t)f * g.s_stride + a] * bin_coef);
+        if (b > 1023) b = 1023;
+    }
+    keys_all[(size_t)f * g.s_stride + a] = ((uint32_t)(1023 - b) << 20) | (uint32_t)a;
+}
+
+// ------------------------------------------------------------------------------------------------
 // region growing (one wave per frame)
 // ------------------------------------------------------------------------------------------------
 // LDS pointers carry their address space in the type: a pointer that may be LDS or global would be lowered to FLAT
@@ -509,10 +550,11 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
 __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                     const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                     uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                                    int *__restrict__ status, LsdGeom g)
+                                                    int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int f = blockIdx.x, lane = threadIdx.x;
+    const uint32_t *seeds = seeds_all ? seeds_all + (size_t)f * g.s_stride : nullptr;   // sorted keys (seed_order 1) or raster
     const int W = g.sw, H = g.sh, NP = W * H;
     RegCtx C;
     C.W = W; C.H = H;
@@ -532,17 +574,19 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
     const GrowTh th0 = grow_thresholds(prec);
     TIC(tall);
     for (int base = 0; base < NP; base += 64) {
-        const int px = base + lane;
+        int px = base + lane;
+        if (seeds) px = px < NP ? (int)(seeds[px] & 0xFFFFFu) : NP;
         uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
         const float deg = __uint_as_float(w);
         float2 c0 = make_float2(0.f, 0.f);
         if (ok) c0 = C.cs0[px];
-        C.cbase = base; C.cused = 0ull;
+        C.cbase = seeds ? -0x40000000 : base;   // (list order: the chunk is not contiguous, flags are re-read after every region)
+        C.cused = 0ull;
         unsigned long long mask = __ballot(ok);
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;
-            const int seed = base + j;
+            const int seed = __builtin_amdgcn_readlane(px, j);
             const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(deg), j));
             const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
@@ -566,7 +610,7 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
                 }
             }
             CBAR();
-            if (big) {   // refine / reduce may have released pixels again: take the flags from memory
+            if (big || seeds) {   // refine / reduce may have released pixels again: take the flags from memory
                 w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
                 C.cused = 0ull;
                 ok = ok && lane > j && w < 0x80000000u;

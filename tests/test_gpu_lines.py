@@ -92,3 +92,34 @@ def test_lines_batch_equals_single():
         assert np.array_equal(res[f][1], ref["desc"])
         assert np.array_equal(res[f][0]["startPointX"].view(np.uint32), ref["kl"]["startPointX"].view(np.uint32))
     ext.close()
+
+
+def test_lines_published_seed_order():
+    """seed_order = 1 (bins descending, raster inside a bin: every OpenCV release except 3.0-3.3) on the GPU == the oracle
+    run with the same switch, bit for bit, single frame and inside a batch; and it differs from the default order."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame, synth_batch
+    for img in (synth_frame(21), synth_frame(22, 320, 240), synth_frame(23, 752, 480)):
+        h, w = img.shape
+        ext = LineSegment(nlines=100, max_width=w, max_height=h, seed_order=1)
+        kl, desc, eq = ext.ExtractLineSegment(img)
+        segs = ext.segments(0)
+        ref_seg = orc.lsd_detect(img, seed_order=1)["lines"]
+        ref = orc.line_extract(img, 100, seed_order=1)
+        assert len(segs) == len(ref_seg) and np.array_equal(segs.view(np.uint32), ref_seg.view(np.uint32))
+        assert len(kl) == len(ref["kl"]) and np.array_equal(desc, ref["desc"])
+        for name in kl.dtype.names:
+            assert np.array_equal(kl[name].view(np.uint32), ref["kl"][name].view(np.uint32)), name
+        ext.close()
+    imgs = synth_batch(30, 6)
+    ext = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=6, seed_order=1)
+    res = ext.extract_batch(imgs)
+    differs = False
+    for f in range(6):
+        ref = orc.line_extract(imgs[f], 100, seed_order=1)
+        assert np.array_equal(res[f][1], ref["desc"])
+        differs = differs or not np.array_equal(orc.lsd_detect(imgs[f], seed_order=1)["lines"], orc.lsd_detect(imgs[f])["lines"])
+    assert differs   # the two seed orders are genuinely different detectors
+    ext.close()
+
