@@ -361,7 +361,10 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
                        status, g);
     hipLaunchKernelGGL(k_octree, dim3(nl, B), dim3(256), h->octree_lds, s, h->d_cellinfo, h->d_pool, h->d_celloff, h->d_keys,
                        h->d_nodeof, h->d_quad, h->d_sel, selcnt, ncand, status, g, h->cap_nodes, h->cap_sort);
-    hipLaunchKernelGGL(k_orient_brief, dim3(g.maxsel, nl, B), dim3(64), 0, s, h->d_pyr, h->d_blur, h->d_sel, selcnt, d_kps, d_desc,
+    int slots = 0;   // at most sum of the per-level selection caps, and never more than the caller can take
+    for (int l = 0; l < nl; l++) slots += (int)g.lv[l].sel_cap;
+    if (slots > capacity) slots = capacity;
+    hipLaunchKernelGGL(k_orient_brief, dim3(slots, B), dim3(64), 0, s, h->d_pyr, h->d_blur, h->d_sel, selcnt, d_kps, d_desc,
                        d_nout, capacity, status, g);
     PLF_HIP_TRY(hipGetLastError());
     h->last_frames = B;

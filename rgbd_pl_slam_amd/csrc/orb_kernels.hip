@@ -370,21 +370,21 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
                                                      plf_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                      int *__restrict__ n_out, int capacity, int *__restrict__ status, OrbGeom g)
 {
-    const int idx = blockIdx.x, l = blockIdx.y, f = blockIdx.z, lane = threadIdx.x;
+    // one wave per OUTPUT slot o of the frame (level-major order); its level follows from the per-level counts
+    const int o = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const int *cnt = selcnt + f * g.nlevels;
-    int offset = 0, total = 0;
+    int offset = 0, total = 0, l = -1;
     for (int i = 0; i < g.nlevels; i++) {
         const int c = cnt[i];
-        if (i < l) offset += c;
+        if (l < 0 && o < total + c) { l = i; offset = total; }
         total += c;
     }
-    if (idx == 0 && l == 0 && lane == 0) {
+    if (o == 0 && lane == 0) {
         n_out[f] = min(total, capacity);
         if (total > capacity) atomicOr(status, 2);
     }
-    if (idx >= cnt[l]) return;
-    const int o = offset + idx;
-    if (o >= capacity) return;
+    if (l < 0 || o >= capacity) return;
+    const int idx = o - offset;
     const OrbLevel &L = g.lv[l];
     const uint2 s = sel[(size_t)f * g.sel_stride + L.sel_off + idx];
     const int x = (int)(s.x & 0xFFFF) + PLF_MINB, y = (int)(s.x >> 16) + PLF_MINB;  // level coordinates (integers)
@@ -394,15 +394,26 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
     if (lane < PLF_PATCH) {
         const int v = lane - PLF_HALF_PATCH;
         const int d = c_umax[v < 0 ? -v : v];
-        const uint8_t *row = center + (ptrdiff_t)v * L.ppitch;
-        int su = 0, si = 0;
-        for (int u = -d; u <= d; ++u) {
-            const int I = row[u];
-            su += u * I;
-            si += I;
+        // the row segment u = -16..15 as 8 dwords (the padded plane has 19 border pixels) and two byte dot products per
+        // dword: sum (u + 16) * I and sum I over |u| <= d, so m10 = sum u * I = first - 16 * second (exact integers)
+        const uint8_t *row = center + (ptrdiff_t)v * L.ppitch - 16;
+        uint32_t sw = 0, si = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t px4 = *(const plf_u32u *)(row + 4 * q);
+            uint32_t wgt = 0, one = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int u = 4 * q + e - 16;
+                const bool in = (u < 0 ? -u : u) <= d;
+                wgt |= (in ? (uint32_t)(u + 16) : 0u) << (8 * e);
+                one |= (in ? 1u : 0u) << (8 * e);
+            }
+            sw = __builtin_amdgcn_udot4(px4, wgt, sw, false);
+            si = __builtin_amdgcn_udot4(px4, one, si, false);
         }
-        m10 = su;
-        m01 = v * si;
+        m10 = (int)sw - 16 * (int)si;
+        m01 = v * (int)si;
     }
     m10 = plf_wave_sum(m10);
     m01 = plf_wave_sum(m01);
