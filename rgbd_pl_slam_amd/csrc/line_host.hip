@@ -268,10 +268,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail_unused = h->d_counters + 3 * MB + 16;
     (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
-    dim3 gfull((g.w + 255) / 256, g.h, B);
     hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
                        h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
-    hipLaunchKernelGGL(k_sobel3, gfull, dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
+    hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
     if (!h->ev_front) PLF_HIP_TRY(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
     PLF_HIP_TRY(hipEventRecord(h->ev_front, s));
     h->ev_front_set = true;

@@ -99,18 +99,42 @@ __global__ void __launch_bounds__(256) k_lsd_finalize(const float4 *__restrict__
     if (t == 0) n_out[f] = nout;
 }
 
+typedef unsigned long long __attribute__((aligned(1))) plf_u64u;   // 8-byte access at byte alignment (legal on gfx950 global memory)
+struct __attribute__((aligned(4))) plf_short8 { short2 a, b, c, d; };
+
+// A thread produces 4 consecutive pixels: 3 x 8 source bytes (one unaligned 8-byte load per row) instead of 32 byte
+// gathers; the image border (REFLECT_101) takes the scalar path.
 __global__ void __launch_bounds__(256) k_sobel3(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, short2 *__restrict__ grad,
                                                 LsdGeom g)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x >= g.w) return;
+    const int gpr = (g.w + 3) >> 2, id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
+    const int y = id / gpr, x0 = (id - y * gpr) * 4;
+    if (y >= g.h) return;
     const uint8_t *img = in + (size_t)f * fstride;
     const uint8_t *r0 = img + (size_t)plf_reflect101(y - 1, g.h) * pitch, *r1 = img + (size_t)y * pitch,
                   *r2 = img + (size_t)plf_reflect101(y + 1, g.h) * pitch;
-    const int xm = plf_reflect101(x - 1, g.w), xp = plf_reflect101(x + 1, g.w);
-    const int gx = (r0[xp] + 2 * r1[xp] + r2[xp]) - (r0[xm] + 2 * r1[xm] + r2[xm]);
-    const int gy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
-    grad[(size_t)f * g.full_stride + (size_t)y * g.w + x] = make_short2((short)gx, (short)gy);
+    short2 *out = grad + (size_t)f * g.full_stride + (size_t)y * g.w + x0;
+    if (x0 >= 1 && x0 + 7 <= g.w) {   // bytes x0-1 .. x0+6 exist: pixels x0 .. x0+3 need x0-1 .. x0+4
+        const unsigned long long a0 = *(const plf_u64u *)(r0 + x0 - 1), a1 = *(const plf_u64u *)(r1 + x0 - 1), a2 = *(const plf_u64u *)(r2 + x0 - 1);
+        short2 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#define B_(A, k) ((int)(((A) >> (8 * (k))) & 0xFF))
+            const int gx = (B_(a0, j + 2) + 2 * B_(a1, j + 2) + B_(a2, j + 2)) - (B_(a0, j) + 2 * B_(a1, j) + B_(a2, j));
+            const int gy = (B_(a2, j) + 2 * B_(a2, j + 1) + B_(a2, j + 2)) - (B_(a0, j) + 2 * B_(a0, j + 1) + B_(a0, j + 2));
+#undef B_
+            o[j] = make_short2((short)gx, (short)gy);
+        }
+        plf_short8 v; v.a = o[0]; v.b = o[1]; v.c = o[2]; v.d = o[3];
+        *(plf_short8 *)out = v;
+        return;
+    }
+    for (int j = 0; j < 4 && x0 + j < g.w; j++) {
+        const int x = x0 + j, xm = plf_reflect101(x - 1, g.w), xp = plf_reflect101(x + 1, g.w);
+        const int gx = (r0[xp] + 2 * r1[xp] + r2[xp]) - (r0[xm] + 2 * r1[xm] + r2[xm]);
+        const int gy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
+        out[j] = make_short2((short)gx, (short)gy);
+    }
 }
 
 __constant__ int c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3, 2, 4, 2, 5, 2, 6, 2, 7,

@@ -41,6 +41,7 @@
 // A tile of 65 x 17 scaled pixels (one more column/row for the gradient) needs at most PRE_SC x PRE_SR blurred source
 // pixels (checked on the host for the actual geometry) and 6 more rows of the row pass.
 // ------------------------------------------------------------------------------------------------
+typedef unsigned long long __attribute__((aligned(1))) plf_u64u;   // 8-byte access at byte alignment (legal on gfx950 global memory)
 #define PRE_TW 64
 #define PRE_TH 16
 #define PRE_SC 88
@@ -65,9 +66,17 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
         if (c >= nc) continue;
         const uint8_t *row = img + (size_t)plf_reflect101(r_lo - 3 + r, g.h) * pitch;
         const int x = c_lo + c;
-        double s = t.k[0] * (double)row[plf_reflect101(x - 3, g.w)];
+        double s;
+        if (x >= 3 && x + 4 < g.w) {   // interior: the 7 taps come from one unaligned 8-byte load
+            const unsigned long long px8 = *(const plf_u64u *)(row + x - 3);
+            s = t.k[0] * (double)(int)(px8 & 0xFF);
 #pragma unroll
-        for (int q = 1; q < 7; q++) s += t.k[q] * (double)row[plf_reflect101(x - 3 + q, g.w)];
+            for (int q = 1; q < 7; q++) s += t.k[q] * (double)(int)((px8 >> (8 * q)) & 0xFF);
+        } else {
+            s = t.k[0] * (double)row[plf_reflect101(x - 3, g.w)];
+#pragma unroll
+            for (int q = 1; q < 7; q++) s += t.k[q] * (double)row[plf_reflect101(x - 3 + q, g.w)];
+        }
         s_tmp[i] = s;
     }
     __syncthreads();
