@@ -1,0 +1,39 @@
+"""Extraction throughput (ORB + LSD/LBD on two streams, device-resident frames) at the other BASELINE configurations:
+   python tools/bench_configs.py  ->  config 3 (VGA, 2000 ORB + 200 lines, 8 in flight), config 4 (1280x960, 4000 + 400, 64 in
+   flight = 8 per GPU x 8) and the same shapes with many frames in flight."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from rgbd_pl_slam_amd import ORBextractor, LineSegment
+from rgbd_pl_slam_amd.synth import synth_frame
+
+def run(w, h, nf, nl, B, K=6):
+    imgs = np.stack([synth_frame(700 + i, w, h) for i in range(min(B, 8))])
+    imgs = np.concatenate([imgs] * ((B + len(imgs) - 1) // len(imgs)))[:B]
+    d = torch.from_numpy(imgs).cuda()
+    ext = ORBextractor(nfeatures=nf, max_width=w, max_height=h, max_batch=B)
+    ls = LineSegment(nlines=nl, max_width=w, max_height=h, max_batch=B)
+    cap = ext.capacity
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    lines = torch.zeros((B, nl, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, nl, 32), dtype=torch.uint8, device="cuda")
+    leq = torch.zeros((B, nl, 3), dtype=torch.float64, device="cuda"); nlo = torch.zeros(B, dtype=torch.int32, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    def step():
+        ls.extract_batch_device(d, w, h, lines, ldesc, leq, nlo, nl, sb.cuda_stream)
+        ls.wait_front(sa.cuda_stream)
+        ext.extract_batch_device(d, w, h, kps, desc, n, cap, sa.cuda_stream)
+    for _ in range(2): step()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(K): step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / K
+    print("%dx%d  %d ORB + %d lines  %5d frames in flight: %8.2f ms/batch  %8.0f frames/s   (n_kp %d, n_lines %d)" %
+          (w, h, nf, nl, B, dt * 1e3, B / dt, int(n[0]), int(nlo[0])))
+    ext.close(); ls.close()
+
+run(640, 480, 2000, 200, 8)
+run(640, 480, 2000, 200, 4096)
+run(1280, 960, 4000, 400, 64)
+run(1280, 960, 4000, 400, 1024)
