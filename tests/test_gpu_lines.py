@@ -123,3 +123,29 @@ def test_lines_published_seed_order():
     assert differs   # the two seed orders are genuinely different detectors
     ext.close()
 
+
+def test_line_and_matcher_errors():
+    """argument errors come back as PLF_E_BADARG (never a crash, never a silent wrong answer); an empty image is the
+    reference's silent return (PLF_E_EMPTY, outputs untouched)"""
+    _need_gpu()
+    import ctypes as C
+    import torch
+    from rgbd_pl_slam_amd import LineSegment, Matcher, PlfError
+    import rgbd_pl_slam_amd._lib as L
+    with pytest.raises(PlfError):
+        LineSegment(nlines=100, max_width=640, max_height=480, seed_order=2)
+    ls = LineSegment(nlines=100, max_width=320, max_height=240)
+    with pytest.raises(PlfError):
+        ls.ExtractLineSegment(np.zeros((480, 640), np.uint8))        # larger than the handle was created for
+    n = C.c_int32(-5)
+    st = L.lib().plf_line_extract(ls._h, None, 0, 0, C.c_ssize_t(0), None, None, None, 100, C.byref(n))
+    assert st == L.PLF_E_EMPTY and n.value == -5
+    ls.close()
+    m = Matcher(max_keypoints=256, max_mappoints=64, max_batch=2)
+    z = torch.zeros(16, dtype=torch.int32, device="cuda")
+    view = L.BowView()
+    assert L.lib().plf_match_bow(m._h, C.byref(view), 3, C.c_float(0.7), 1, L.vp(z), 256, L.vp(z), None) == L.PLF_E_BADARG     # n_pairs > max_batch
+    assert L.lib().plf_match_bow(m._h, C.byref(view), 1, C.c_float(0.7), 1, L.vp(z), 100000, L.vp(z), None) == L.PLF_E_BADARG  # stride > max_keypoints
+    assert L.lib().plf_match_bow_kf(m._h, C.byref(view), 1, C.c_float(0.7), 1, L.vp(z), 256, L.vp(z), None) == L.PLF_E_BADARG  # f_has_mp missing
+    m.close()
+
