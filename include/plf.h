@@ -211,6 +211,18 @@ int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const
                                 const plf_pose_pair *pose, float th, int32_t mono, int32_t check_orientation,
                                 int32_t *match_of_kp, int32_t *nmatches, void *stream);
 
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint*> &sAlreadyFound,
+ *                                    const float th, const int ORBdist)   include/ORBmatcher.h:82 (so@0x7e8c0, relocalisation).
+ * kf: the keyframe's features -- has_mappoint[i] = pKF->GetMapPointMatches()[i] != NULL && !isBad() && !sAlreadyFound.count(pMP),
+ * world_pos, mp_desc, keys = pKF->mvKeysUn (angle); `outlier` is not read.  min_distance / max_distance (device, kf->n floats) =
+ * MapPoint::mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors are applied here); log_scale_factor =
+ * CurrentFrame.mfLogScaleFactor; pose: Rcw, tcw, fx, fy, cx, cy of the current frame (Rlw, tlw, bf, b unused).
+ * match_of_kp as above: values >= 0 are keyframe feature indices; EVERY key point that already holds a map point must be
+ * pre-set to -2 (this overload tests the pointer only, not Observations()). */
+int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *kf, const float *min_distance,
+                               const float *max_distance, const plf_pose_pair *pose, float log_scale_factor, float th, int32_t orb_dist,
+                               int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches, void *stream);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
  * include/ORBmatcher.h:104 (so@0x80150) -- the tracker's reference-keyframe / relocalisation matcher.
  * One view per (keyframe, frame) pair, all arrays in DEVICE memory.  The DBoW2 feature vectors

@@ -142,6 +142,14 @@ public:
         check(plf_match_project_lastframe(m_, &CurrentFrame, &LastFrame, &pose, th, bMono, mbCheckOrientation, match_of_kp_dev, nmatches_dev, stream),
               "SearchByProjection(last frame)");
     }
+    // int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist)
+    void SearchByProjection(const plf_frame_view &CurrentFrame, const plf_lastframe_view &pKF, const float *min_distance_dev, const float *max_distance_dev,
+                            const plf_pose_pair &pose, float log_scale_factor, float th, int ORBdist, int32_t *match_of_kp_dev, int32_t *nmatches_dev,
+                            void *stream = nullptr)
+    {
+        check(plf_match_project_keyframe(m_, &CurrentFrame, &pKF, min_distance_dev, max_distance_dev, &pose, log_scale_factor, th, ORBdist,
+                                         mbCheckOrientation, match_of_kp_dev, nmatches_dev, stream), "SearchByProjection(keyframe)");
+    }
     // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
     void SearchByBoW(const plf_bow_view &pKF_and_F, int32_t *match_of_f_dev, int32_t *nmatches_dev, void *stream = nullptr)
     {

@@ -87,8 +87,9 @@ void orc_is_in_frustum(const float *xw, const float *normal, const float *min_di
         const float PcZ = Rcw[6] * P[0] + Rcw[7] * P[1] + Rcw[8] * P[2] + tcw[2];
         if (PcZ < 0.0f) continue;
         const float invz = 1.0f / PcZ;
-        const float u = cam[0] * PcX * invz + cam[2];
-        const float v = cam[1] * PcY * invz + cam[3];
+        /* the reference binary contracts both projections into FMAs (so@0xf5772, so@0xf57c0: vfmadd213ss) */
+        const float u = fmaf(cam[0] * PcX, invz, cam[2]);
+        const float v = fmaf(cam[1] * PcY, invz, cam[3]);
         if (u < bounds[0] || u > bounds[2]) continue;
         if (v < bounds[1] || v > bounds[3]) continue;
         const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];

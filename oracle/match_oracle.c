@@ -279,6 +279,91 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
     return nmatches;
 }
 
+/* ---------------------------------------------------------------- relocalisation SearchByProjection */
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * include/ORBmatcher.h:82, so@0x7e8c0 (listing read; executed from the binary for tests/golden/ref_glue_search_reloc.json).
+ * valid[i] = pKF->GetMapPointMatches()[i] != NULL && !isBad() && !sAlreadyFound.count(pMP).  Per valid point:
+ * x3Dc = Rcw*x3Dw + tcw; invzc = 1/zc (no sign test in this overload); u, v with the binary's FMA contraction
+ * (so@0x7f4dc, so@0x7f4fb); image bounds; PO = x3Dw - Ow with Ow = -Rcw^T tcw; dist3D = float(cv::norm(PO)) (double
+ * accumulation); reject outside [0.8*mfMinDistance, 1.2*mfMaxDistance] (MapPoint::Get{Min,Max}DistanceInvariance,
+ * so@0x8fa40 / 0x8fad0); level = MapPoint::PredictScale(dist3D, &CurrentFrame) (so@0x8fc20: ceilf(logf(max/dist) /
+ * mfLogScaleFactor), clamped to [0, mnScaleLevels-1]); radius = th * mvScaleFactors[level]; candidates of
+ * GetFeaturesInArea(u, v, radius, level-1, level+1) that hold NO map point at all (match_of_kp == -1; every occupant
+ * must be passed as -2); best Hamming distance <= ORBdist; rotation histogram over pKF->mvKeysUn[i].angle -
+ * CurrentFrame.mvKeysUn[k].angle, everything outside the three dominant bins removed.
+ * match_of_kp values >= 0 are keyframe feature indices.  Last->octave and Last->outlier are not read. */
+int orc_search_by_projection_reloc(const orc_frame *Cur, const orc_lastframe *KF, const float *min_dist, const float *max_dist,
+                                   const float *Rcw, const float *tcw, float fx, float fy, float cx, float cy, float log_scale_factor,
+                                   float th, int ORBdist, int checkOri, int32_t *match_of_kp)
+{
+    int nmatches = 0;
+    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (Cur->n > 0 ? Cur->n : 1));
+    int histN[HISTO_LENGTH];
+    memset(histN, 0, sizeof(histN));
+    float Ow[3];
+    for (int i = 0; i < 3; i++)
+        Ow[i] = (float)(-((double)Rcw[0 * 3 + i] * tcw[0] + (double)Rcw[1 * 3 + i] * tcw[1] + (double)Rcw[2 * 3 + i] * tcw[2]));
+    grid_t g; grid_build(Cur, &g);
+    int *cand = (int *)malloc(sizeof(int) * (Cur->n > 0 ? Cur->n : 1));
+    for (int i = 0; i < KF->n; i++) {
+        if (!KF->has_mp[i]) continue;
+        const float *xw = KF->xw + 3 * (size_t)i;
+        const float xc = Rcw[0] * xw[0] + Rcw[1] * xw[1] + Rcw[2] * xw[2] + tcw[0];
+        const float yc = Rcw[3] * xw[0] + Rcw[4] * xw[1] + Rcw[5] * xw[2] + tcw[1];
+        const float zc = Rcw[6] * xw[0] + Rcw[7] * xw[1] + Rcw[8] * xw[2] + tcw[2];
+        const float invzc = (float)(1.0 / (double)zc);
+        const float u = fmaf(fx * xc, invzc, cx);
+        const float v = fmaf(fy * yc, invzc, cy);
+        if (u < Cur->minx || u > Cur->maxx) continue;
+        if (v < Cur->miny || v > Cur->maxy) continue;
+        const float PO[3] = {xw[0] - Ow[0], xw[1] - Ow[1], xw[2] - Ow[2]};
+        double s2 = 0;
+        for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
+        const float dist3D = (float)sqrt(s2);
+        const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float ratio = max_dist[i] / dist3D;
+        int lvl = (int)ceilf(logf(ratio) / log_scale_factor);
+        if (lvl < 0) lvl = 0;
+        else if (lvl >= Cur->nlevels) lvl = Cur->nlevels - 1;
+        const float radius = th * Cur->scale_factors[lvl];
+        const int nc = features_in_area(Cur, &g, u, v, radius, lvl - 1, lvl + 1, cand, Cur->n);
+        if (nc == 0) continue;
+        const uint8_t *dMP = KF->mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            if (match_of_kp[i2] != -1) continue;
+            const int dist = orc_hamming256(dMP, Cur->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            match_of_kp[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                float rot = KF->angle[i] - Cur->angle[bestIdx2];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / 12.0f));
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin * Cur->n + histN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (checkOri) {
+        int i1, i2, i3;
+        orc_three_maxima(histN, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int bnum = 0; bnum < HISTO_LENGTH; bnum++) {
+            if (bnum == i1 || bnum == i2 || bnum == i3) continue;
+            for (int j = 0; j < histN[bnum]; j++) {
+                match_of_kp[rotHist[bnum * Cur->n + j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    free(cand); free(rotHist); grid_free(&g);
+    return nmatches;
+}
+
 /* ---------------------------------------------------------------- SearchByBoW */
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)  include/ORBmatcher.h:104,
  * so@0x80150 (listing read; executed from the binary for tests/golden/ref_glue_bow.json).

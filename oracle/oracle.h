@@ -127,6 +127,9 @@ int orc_lines_in_area(const orc_lineframe *F, float x1, float y1, float x2, floa
                       int maxLevel, int *out, int cap);
 int orc_search_by_projection_lines(const orc_lineframe *F, const orc_maplines *ML, float th, float nnratio,
                                    int32_t *match_of_line);
+int orc_search_by_projection_reloc(const orc_frame *Cur, const orc_lastframe *KF, const float *min_dist, const float *max_dist,
+                                   const float *Rcw, const float *tcw, float fx, float fy, float cx, float cy, float log_scale_factor,
+                                   float th, int ORBdist, int checkOri, int32_t *match_of_kp);
 int orc_search_by_bow(int n_kf, int n_f, const uint8_t *kf_desc, const uint8_t *f_desc, const float *kf_angle, const float *f_angle,
                       const uint8_t *kf_has_mp, int kf_nodes, const uint32_t *kf_node_id, const int32_t *kf_node_start,
                       const int32_t *kf_feat, int f_nodes, const uint32_t *f_node_id, const int32_t *f_node_start,

@@ -24,6 +24,7 @@
 #include <new>
 #include <algorithm>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include <dlfcn.h>
@@ -103,6 +104,9 @@ MatExpr operator*(const Mat &a, const Mat &b);
 MatExpr operator*(const MatExpr &e, const Mat &b);
 MatExpr operator+(const MatExpr &e, const Mat &b);
 MatExpr operator-(const MatExpr &e);
+MatExpr operator-(const Mat &a, const Mat &b);
+double norm(const _InputArray &src, int normType, const _InputArray &mask);
+const _InputArray &noArray();
 void resize(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
 void copyMakeBorder(const _InputArray &, const _OutputArray &, int, int, int, int, int, const Scalar_<double> &);
 void GaussianBlur(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
@@ -268,6 +272,27 @@ cv::MatExpr cv::operator+(const MatExpr &x, const Mat &c)
     if (x.op != &g_gemm_op || x.c.data) { fprintf(stderr, "refprobe: unexpected expr + Mat\n"); abort(); }
     MatExpr e; expr_init(&e, &g_gemm_op); e.flags = x.flags; e.a = x.a; e.b = x.b; e.alpha = x.alpha; e.c = c; e.beta = 1; return e;
 }
+struct SubOp : cv::MatOp { void assign(const cv::MatExpr &e, cv::Mat &m, int) const override; };
+static SubOp g_sub_op;
+void SubOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const   // a - b, 3x1 CV_32F
+{
+    if ((e.a.flags & 0xFFF) != 5 || e.a.rows != 3 || e.a.cols != 1 || e.b.rows != 3 || e.b.cols != 1) { fprintf(stderr, "refprobe: unexpected a - b shape\n"); abort(); }
+    float d[3];
+    for (int i = 0; i < 3; i++) d[i] = matf(e.a, i, 0) - matf(e.b, i, 0);
+    mat_alloc(&m, 3, 1, 5);
+    for (int i = 0; i < 3; i++) *(float *)(m.data + m.step_buf[0] * i) = d[i];
+}
+cv::MatExpr cv::operator-(const Mat &a, const Mat &b) { MatExpr e; expr_init(&e, &g_sub_op); e.a = a; e.b = b; return e; }
+static cv::_InputArray g_no_array = {0, nullptr, 0, 0};
+const cv::_InputArray &cv::noArray() { return g_no_array; }
+double cv::norm(const _InputArray &src, int normType, const _InputArray &)   // NORM_L2 of a CV_32F vector: double accumulation (normL2Sqr_<float, double>)
+{
+    const Mat *m = (const Mat *)src.obj;
+    if (normType != 4 || (m->flags & 0xFFF) != 5 || m->cols != 1) { fprintf(stderr, "refprobe: unexpected norm call\n"); abort(); }
+    double s2 = 0;
+    for (int i = 0; i < m->rows; i++) { const double v = (double)matf(*m, i, 0); s2 += v * v; }
+    return sqrt(s2);
+}
 int cv::_InputArray::kind() const { return flags & (31 << 16); }
 bool cv::_InputArray::empty() const { const Mat *m = (const Mat *)obj; return m->data == nullptr || m->rows * m->cols == 0; }
 cv::Mat cv::_InputArray::getMat_(int) const { return *(const Mat *)obj; }
@@ -322,6 +347,7 @@ public:
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
+    int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -1068,6 +1094,133 @@ int main(int argc, char **argv)
             fprintf(JB, "\"}%s\n", c + 1 < NBC ? "," : "");
         }
         fprintf(JB, "]}\n"); fclose(JB);
+    }
+    // ------------------------------------------------------------ H: ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (glue)
+    // extra offsets (MapPoint::Get{Min,Max}DistanceInvariance so@0x8fa40/0x8fad0, PredictScale(float, Frame*) so@0x8fc20):
+    // MapPoint mfMinDistance @0x248, mfMaxDistance @0x24c; Frame mnScaleLevels @0x12338, mfLogScaleFactor @0x12340.
+    {
+        path = std::string(outdir) + "/ref_glue_search_reloc.json";
+        FILE *JR = fopen(path.c_str(), "w");
+        fprintf(JR, "{\"_doc\": \"ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) (so@0x7e8c0, relocalisation) executed from "
+                    "the reference binary on hand-laid objects; cv::Mat algebra / cv::norm supplied by oracle/refprobe/probe.cpp. floats as uint32 bit patterns; "
+                    "match[k] = keyframe feature assigned to current key point k, -1 none, -2 occupied before the call\", \"cases\": [\n");
+        struct { int n; float th; int orbdist, check; uint64_t seed; } rc[] = {{500, 10.0f, 100, 1, 9601}, {400, 3.0f, 64, 1, 9602}, {450, 10.0f, 100, 0, 9603}};
+        const int NRC = 3;
+        for (int c = 0; c < NRC; c++) {
+            rng_seed(rc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int NK = rc[c].n;
+            const float fx = 520.9f, fy = 521.0f, cx = 325.1f, cy = 249.7f;
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            const float logsf = logf(1.2f);
+            float *Tc = (float *)bump(64);
+            {
+                const float ay = 0.04f, ax = -0.03f, cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float R[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) Tc[r * 4 + q] = R[r * 3 + q];
+                Tc[3] = 0.1f; Tc[7] = -0.05f; Tc[11] = 0.2f; Tc[12] = Tc[13] = Tc[14] = 0.f; Tc[15] = 1.f;
+            }
+            float Ow[3];
+            for (int i = 0; i < 3; i++) Ow[i] = -(Tc[0 * 4 + i] * Tc[3] + Tc[1 * 4 + i] * Tc[7] + Tc[2 * 4 + i] * Tc[11]);
+            std::vector<cv::KeyPoint> kk(NK);
+            std::vector<float> wpos((size_t)NK * 3), dmin(NK), dmax(NK);
+            std::vector<int> has(NK), bad(NK), found(NK), plev(NK);
+            std::vector<uint8_t> mdesc((size_t)NK * 32);
+            const int NC = NK + NK / 3;
+            std::vector<cv::KeyPoint> ck(NC);
+            std::vector<uint8_t> cdesc((size_t)NC * 32);
+            for (int i = 0; i < NK; i++) {
+                // a point in front of the current camera, placed by back-projecting a pixel of the current image
+                const float u0 = (uf() < 0.9f ? 20.f + uf() * 600.f : -60.f + uf() * 760.f), v0 = 20.f + uf() * 440.f, z = 0.8f + uf() * 6.f;
+                const float Xc[3] = {(u0 - cx) / fx * z - Tc[3], (v0 - cy) / fy * z - Tc[7], z - Tc[11]};
+                for (int r = 0; r < 3; r++) wpos[(size_t)i * 3 + r] = Tc[0 * 4 + r] * Xc[0] + Tc[1 * 4 + r] * Xc[1] + Tc[2 * 4 + r] * Xc[2];
+                const float dx = wpos[(size_t)i * 3] - Ow[0], dy = wpos[(size_t)i * 3 + 1] - Ow[1], dz = wpos[(size_t)i * 3 + 2] - Ow[2];
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                plev[i] = (int)rng_below(8);
+                dmax[i] = dist * powf(1.2f, (float)plev[i] - 0.5f + uf());
+                dmin[i] = dmax[i] / powf(1.2f, 7.f);
+                if (uf() < 0.07f) { dmax[i] = dist * 0.5f; dmin[i] = dmax[i] / 4.f; }   // out of the scale-invariance range
+                kk[i].x = uf() * 640.f; kk[i].y = uf() * 480.f; kk[i].size = 31.f; kk[i].angle = uf() * 360.f; kk[i].response = 1.f; kk[i].octave = plev[i]; kk[i].class_id = -1;
+                has[i] = uf() < 0.85f; bad[i] = uf() < 0.05f; found[i] = uf() < 0.1f;
+                for (int b = 0; b < 32; b++) mdesc[(size_t)i * 32 + b] = (uint8_t)rng_below(256);
+                // its (noisy) observation in the current frame
+                ck[i].size = 31.f; ck[i].response = 1.f; ck[i].class_id = -1;
+                ck[i].x = u0 + (uf() - 0.5f) * 6.f; ck[i].y = v0 + (uf() - 0.5f) * 6.f;
+                ck[i].octave = std::max(0, std::min(7, plev[i] + (int)rng_below(4) - 1));
+                float a = kk[i].angle - (uf() < 0.8f ? 30.f + uf() * 9.f : uf() * 360.f);
+                if (a < 0.f) a += 360.f;
+                ck[i].angle = a;
+                for (int b = 0; b < 32; b++) cdesc[(size_t)i * 32 + b] = mdesc[(size_t)i * 32 + b];
+                const int flips = (int)rng_below(90);
+                for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); cdesc[(size_t)i * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+            }
+            for (int k = NK; k < NC; k++) {
+                ck[k].size = 31.f; ck[k].response = 1.f; ck[k].class_id = -1;
+                ck[k].x = uf() * 640.f; ck[k].y = uf() * 480.f; ck[k].octave = (int)rng_below(8); ck[k].angle = uf() * 360.f;
+                for (int b = 0; b < 32; b++) cdesc[(size_t)k * 32 + b] = (uint8_t)rng_below(256);
+            }
+            char *kf = (char *)bump(0x800), *cf = (char *)bump(0x12800); memset(kf, 0, 0x800); memset(cf, 0, 0x12800);
+            char *mps = (char *)bump((size_t)(NK + 1) * 0x300); memset(mps, 0, (size_t)(NK + 1) * 0x300);
+            char *occ = mps + (size_t)NK * 0x300;
+            std::vector<void *> kmp(NK, nullptr), cmp_(NC, nullptr);
+            std::set<MapPoint *> sfound;
+            std::vector<int> init(NC, -1);
+            for (int i = 0; i < NK; i++) {
+                char *o = mps + (size_t)i * 0x300;
+                mat_init((cv::Mat *)(o + 0xd8), (unsigned char *)&wpos[(size_t)i * 3], 3, 1, 4);
+                ((cv::Mat *)(o + 0xd8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0xd8))->step_buf[1] = 4;
+                mat_init((cv::Mat *)(o + 0x1c8), &mdesc[(size_t)i * 32], 1, 32, 32); ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
+                *(bool *)(o + 0x238) = bad[i] != 0; *(float *)(o + 0x248) = dmin[i]; *(float *)(o + 0x24c) = dmax[i];
+                if (has[i]) { kmp[i] = o; if (found[i]) sfound.insert((MapPoint *)o); }
+            }
+            for (int k = 0; k < NC; k++) if (uf() < 0.08f) { cmp_[k] = occ; init[k] = -2; }
+            void **v;
+            v = (void **)(kf + 0x170); v[0] = kk.data(); v[1] = kk.data() + NK; v[2] = v[1];
+            v = (void **)(kf + 0x520); v[0] = kmp.data(); v[1] = kmp.data() + NK; v[2] = v[1];
+            *(int *)(cf + 0xec) = NC;
+            v = (void **)(cf + 0xf0); v[0] = ck.data(); v[1] = ck.data() + NC; v[2] = v[1];
+            v = (void **)(cf + 0x120); v[0] = ck.data(); v[1] = ck.data() + NC; v[2] = v[1];
+            mat_init((cv::Mat *)(cf + 0x1c8), cdesc.data(), NC, 32, 32); ((cv::Mat *)(cf + 0x1c8))->flags |= 0x4000;
+            v = (void **)(cf + 0x288); v[0] = cmp_.data(); v[1] = cmp_.data() + NC; v[2] = v[1];
+            mat_init((cv::Mat *)(cf + 0x122c8), (unsigned char *)Tc, 4, 4, 16);
+            ((cv::Mat *)(cf + 0x122c8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(cf + 0x122c8))->step_buf[1] = 4;
+            *(int *)(cf + 0x12338) = 8; *(float *)(cf + 0x12340) = logsf;
+            v = (void **)(cf + 0x12348); v[0] = scale; v[1] = scale + 8; v[2] = scale + 8;
+            Frame::fx = fx; Frame::fy = fy; Frame::cx = cx; Frame::cy = cy;
+            Frame::mnMinX = 0.f; Frame::mnMinY = 0.f; Frame::mnMaxX = 640.f; Frame::mnMaxY = 480.f;
+            Frame::mfGridElementWidthInv = 64.f / 640.f; Frame::mfGridElementHeightInv = 48.f / 480.f;
+            std::vector<std::vector<size_t>> cells(64 * 48);
+            for (int k = 0; k < NC; k++) {
+                const int gx = (int)roundf((ck[k].x - Frame::mnMinX) * Frame::mfGridElementWidthInv), gy = (int)roundf((ck[k].y - Frame::mnMinY) * Frame::mfGridElementHeightInv);
+                if (gx < 0 || gx >= 64 || gy < 0 || gy >= 48) continue;
+                cells[gx * 48 + gy].push_back((size_t)k);
+            }
+            for (int cidx = 0; cidx < 64 * 48; cidx++) {
+                v = (void **)(cf + 0x2c8 + (size_t)cidx * 24);
+                v[0] = cells[cidx].data(); v[1] = cells[cidx].data() + cells[cidx].size(); v[2] = v[1];
+            }
+            ORBmatcher *mt = new ORBmatcher(0.9f, rc[c].check != 0);
+            const int nm = mt->SearchByProjection(*(Frame *)cf, (KeyFrame *)kf, sfound, rc[c].th, rc[c].orbdist);
+            std::vector<int> match(NC);
+            for (int k = 0; k < NC; k++) { const char *q = (const char *)cmp_[k]; match[k] = q == nullptr ? -1 : q == occ ? -2 : (int)((q - mps) / 0x300); }
+            std::vector<float> kx(NC), ky(NC), ka(NC), kfa(NK), Tcv(Tc, Tc + 16), scv(scale, scale + 8), cam = {fx, fy, cx, cy, logsf, rc[c].th};
+            std::vector<int> ko(NC), valid(NK);
+            for (int k = 0; k < NC; k++) { kx[k] = ck[k].x; ky[k] = ck[k].y; ka[k] = ck[k].angle; ko[k] = ck[k].octave; }
+            for (int i = 0; i < NK; i++) { kfa[i] = kk[i].angle; valid[i] = has[i] && !bad[i] && !found[i]; }
+            fprintf(JR, "{\"n_cur\": %d, \"n_kf\": %d, \"orbdist\": %d, \"check_orientation\": %d, \"nmatches\": %d, ", NC, NK, rc[c].orbdist, rc[c].check, nm);
+            J = JR;
+            jarr_f("cam", cam); jarr_f("Tcw", Tcv); jarr_f("scale", scv);
+            jarr_f("x", kx); jarr_f("y", ky); jarr_f("angle", ka); jarr_i("octave", ko); jarr_i("init", init);
+            jarr_f("kf_angle", kfa); jarr_i("valid", valid); jarr_f("world_pos", wpos); jarr_f("min_dist", dmin); jarr_f("max_dist", dmax);
+            jarr_i("match", match);
+            fprintf(JR, "\"desc\": \"");
+            for (size_t b = 0; b < cdesc.size(); b++) fprintf(JR, "%02x", cdesc[b]);
+            fprintf(JR, "\", \"mp_desc\": \"");
+            for (size_t b = 0; b < mdesc.size(); b++) fprintf(JR, "%02x", mdesc[b]);
+            fprintf(JR, "\"}%s\n", c + 1 < NRC ? "," : "");
+        }
+        fprintf(JR, "]}\n"); fclose(JR);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

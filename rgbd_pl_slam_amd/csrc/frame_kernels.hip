@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(256) k_frustum_points(const float *__restrict_
     const float PcZ = P.Rcw[6] * p0 + P.Rcw[7] * p1 + P.Rcw[8] * p2 + P.tcw[2];
     if (PcZ < 0.0f) return;
     const float invz = 1.0f / PcZ;
-    const float u = cam.fx * PcX * invz + cam.cx;
-    const float v = cam.fy * PcY * invz + cam.cy;
+    // the reference binary contracts both projections into FMAs (so@0xf5772, so@0xf57c0: vfmadd213ss)
+    const float u = fmaf(cam.fx * PcX, invz, cam.cx);
+    const float v = fmaf(cam.fy * PcY, invz, cam.cy);
     if (u < bounds.x || u > bounds.z) return;
     if (v < bounds.y || v > bounds.w) return;
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];

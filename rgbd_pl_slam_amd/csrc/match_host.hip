@@ -24,6 +24,7 @@ struct FrameDev {
     const float4 *cell_kp;
 };
 struct MapDev { int m; const float *proj_x, *proj_y, *proj_xr; const int *level; const float *view_cos; const uint8_t *in_view, *desc, *obs_positive; };
+struct RelocDev { int on; const float *min_dist, *max_dist; float log_scale; int orb_dist; };
 struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; };
 struct BowDev { int n_kf, n_f; const uint8_t *kf_desc, *f_desc; const float *kf_angle, *f_angle; const uint8_t *kf_has_mp, *f_has_mp; int kf_nodes, f_nodes;
                 const uint32_t *kf_node_id, *f_node_id; const int *kf_node_start, *f_node_start; const int *kf_feat, *f_feat; };
@@ -35,7 +36,7 @@ __global__ void k_mp_candidates(const FrameDev *, MapDev, float, const int *, in
 __global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, const uint8_t *, int, const uint32_t *, const int2 *, int, const int *);
 __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
-__global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, float, int, int, int *, int *, uint8_t *, float4 *, int);
+__global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, RelocDev, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
 __global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int);
@@ -237,12 +238,11 @@ extern "C" int plf_match_bow_kf(plf_matcher *h, const plf_bow_view *pairs, int32
     return match_bow_impl(h, pairs, n_pairs, nnratio, check_orientation, 1, match12, stride, nmatches, stream);
 }
 
-extern "C" int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose,
-                                           float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches,
-                                           void *stream)
+static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose, RelocDev RL,
+                                float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches, void *stream)
 {
     if (!h || !cur || !last || !pose || !match_of_kp || !nmatches || cur->n < 0 || cur->n > h->max_kp || last->n < 0 || last->n > h->max_kp ||
-        !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y))
+        !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y) || !last->has_mappoint || (!RL.on && !last->outlier))
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -260,10 +260,29 @@ extern "C" int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view 
     LastDev L;
     L.n = last->n; L.has_mp = last->has_mappoint; L.outlier = last->outlier; L.xw = last->world_pos; L.keys = last->keys; L.mp_desc = last->mp_desc;
     const int kp_cap = ((cur->n > 0 ? cur->n : 1) + 63) & ~63;
-    hipLaunchKernelGGL(k_match_lastframe, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, L, *pose, th, mono, check_orientation, match_of_kp,
+    hipLaunchKernelGGL(k_match_lastframe, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, L, *pose, RL, th, mono, check_orientation, match_of_kp,
                        nmatches, h->d_done, h->d_proj, kp_cap);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
+}
+
+extern "C" int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose,
+                                           float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches,
+                                           void *stream)
+{
+    RelocDev RL;
+    memset(&RL, 0, sizeof(RL));
+    return match_lastframe_impl(h, cur, last, pose, RL, th, mono, check_orientation, match_of_kp, nmatches, stream);
+}
+
+extern "C" int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *kf, const float *min_distance,
+                                          const float *max_distance, const plf_pose_pair *pose, float log_scale_factor, float th, int32_t orb_dist,
+                                          int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches, void *stream)
+{
+    if (!min_distance || !max_distance || !(log_scale_factor > 0.f) || !cur || cur->nlevels < 1 || cur->nlevels > 64) return PLF_E_BADARG;
+    RelocDev RL;
+    RL.on = 1; RL.min_dist = min_distance; RL.max_dist = max_distance; RL.log_scale = log_scale_factor; RL.orb_dist = orb_dist;
+    return match_lastframe_impl(h, cur, kf, pose, RL, th, 1, check_orientation, match_of_kp, nmatches, stream);
 }
 
 extern "C" int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const uint8_t *train, int32_t nt, plf_dmatch *out,

@@ -390,7 +390,12 @@ struct LastDev {
 };
 
 // one block; items = key points of the last frame.  proj[i] = (u, v, invzc, radius) prepared in the first phase.
-__global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf, plf_pose_pair P, float th, int mono, int check_ori,
+// Relocalisation overload, ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist)
+// (include/ORBmatcher.h:82, so@0x7e8c0), shares the kernel: items = keyframe features with a usable map point, no depth-sign
+// and no uRight test, level window from MapPoint::PredictScale (so@0x8fc20), acceptance threshold ORBdist.
+struct RelocDev { int on; const float *min_dist, *max_dist; float log_scale; int orb_dist; };
+
+__global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf, plf_pose_pair P, RelocDev RL, float th, int mono, int check_ori,
                                                          int *__restrict__ match, int *__restrict__ nmatches, uint8_t *__restrict__ done,
                                                          float4 *__restrict__ proj, int kp_cap)
 {
@@ -409,23 +414,38 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
     if (t < HISTO_LENGTH) hist[t] = 0;
     if (t == 0) s_acc = 0;
     for (int i = t; i < Lf.n; i += T) {
-        bool act = Lf.has_mp[i] && !Lf.outlier[i];
+        bool act = Lf.has_mp[i] && (RL.on || !Lf.outlier[i]);
         float4 pr = make_float4(0, 0, 0, 0);
+        int lvl = 0;
         if (act) {
             const float *xw = Lf.xw + 3 * (size_t)i;
             const float xc = P.Rcw[0] * xw[0] + P.Rcw[1] * xw[1] + P.Rcw[2] * xw[2] + P.tcw[0];
             const float yc = P.Rcw[3] * xw[0] + P.Rcw[4] * xw[1] + P.Rcw[5] * xw[2] + P.tcw[1];
             const float zc = P.Rcw[6] * xw[0] + P.Rcw[7] * xw[1] + P.Rcw[8] * xw[2] + P.tcw[2];
             const float invzc = (float)(1.0 / (double)zc);
-            if (invzc < 0) act = false;
+            if (!RL.on && invzc < 0) act = false;
             // the reference binary contracts these into FMAs (so@0x81cba, so@0x81cd9; the uRight test below: so@0x81eb5)
             const float u = fmaf(P.fx * xc, invzc, P.cx), v = fmaf(P.fy * yc, invzc, P.cy);
             if (u < F.min_x || u > F.max_x) act = false;
             if (v < F.min_y || v > F.max_y) act = false;
-            if (act) pr = make_float4(u, v, invzc, th * F.scale_factors[Lf.keys[i].octave]);
+            if (act && RL.on) {
+                // dist3D = float(cv::norm(x3Dw - Ow)) (double accumulation), Ow = twc; invariance range; predicted level
+                const float PO[3] = {xw[0] - twc[0], xw[1] - twc[1], xw[2] - twc[2]};
+                double s2 = 0;
+                for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
+                const float dist3D = (float)sqrt(s2);
+                const float maxDistance = 1.2f * RL.max_dist[i], minDistance = 0.8f * RL.min_dist[i];
+                if (dist3D < minDistance || dist3D > maxDistance) act = false;
+                const float ratio = RL.max_dist[i] / dist3D;
+                // logf of the reference's libm is (almost always) the correctly rounded value; the double log rounded to float is too
+                lvl = (int)ceilf((float)log((double)ratio) / RL.log_scale);
+                if (lvl < 0) lvl = 0;
+                else if (lvl >= F.nlevels) lvl = F.nlevels - 1;
+            }
+            if (act) pr = make_float4(u, v, invzc, th * F.scale_factors[RL.on ? lvl : Lf.keys[i].octave]);
         }
         proj[i] = pr;
-        done[i] = act ? 0 : 1;
+        done[i] = act ? (uint8_t)(lvl << 1) : 1;   // bit 0: finished, bits 1..: predicted level (relocalisation)
     }
     __syncthreads();
     for (int round = 0; round <= Lf.n; round++) {
@@ -433,19 +453,19 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
         if (t == 0) s_left = 0;
         __syncthreads();
         for (int i = t; i < Lf.n; i += T) {
-            if (done[i]) continue;
+            if (done[i] & 1) continue;
             const float4 pr = proj[i];
-            const int oct = Lf.keys[i].octave;
-            const int minL = bForward ? oct : (bBackward ? 0 : oct - 1), maxL = bForward ? -1 : (bBackward ? oct : oct + 1);
+            const int oct = RL.on ? (done[i] >> 1) : Lf.keys[i].octave;
+            const int minL = RL.on ? oct - 1 : (bForward ? oct : (bBackward ? 0 : oct - 1)), maxL = RL.on ? oct + 1 : (bForward ? -1 : (bBackward ? oct : oct + 1));
             const CellWin w = cell_window(F, pr.x, pr.y, pr.w);
             if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (claim[idx] == -1) atomicMin(&owner[idx], i); })
         }
         __syncthreads();
         for (int i = t; i < Lf.n; i += T) {
-            if (done[i]) continue;
+            if (done[i] & 1) continue;
             const float4 pr = proj[i];
-            const int oct = Lf.keys[i].octave;
-            const int minL = bForward ? oct : (bBackward ? 0 : oct - 1), maxL = bForward ? -1 : (bBackward ? oct : oct + 1);
+            const int oct = RL.on ? (done[i] >> 1) : Lf.keys[i].octave;
+            const int minL = RL.on ? oct - 1 : (bForward ? oct : (bBackward ? 0 : oct - 1)), maxL = RL.on ? oct + 1 : (bForward ? -1 : (bBackward ? oct : oct + 1));
             const CellWin w = cell_window(F, pr.x, pr.y, pr.w);
             bool safe = true;
             if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (claim[idx] == -1 && owner[idx] != i) safe = false; })
@@ -454,15 +474,15 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
             const uint8_t *d = Lf.mp_desc + 32 * (size_t)i;
             if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, {
                 if (claim[idx] != -1) continue;
-                if (F.uright) {
+                if (F.uright && !RL.on) {
                     const float urr = F.uright[idx];
                     if (urr > 0) { const float ur = fmaf(-P.bf, pr.z, pr.x); const float er = fabsf(ur - urr); if (er > pr.w) continue; }
                 }
                 const int dist = hamming_g(d, F.desc + 32 * (size_t)idx);
                 if (dist < bestDist) { bestDist = dist; bestIdx2 = idx; }
             })
-            done[i] = 1;
-            if (bestDist <= TH_HIGH) {
+            done[i] |= 1;
+            if (bestDist <= (RL.on ? RL.orb_dist : TH_HIGH)) {
                 claim[bestIdx2] = i;
                 atomicAdd(&s_acc, 1);
                 if (check_ori) {

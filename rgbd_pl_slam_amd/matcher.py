@@ -69,6 +69,22 @@ class Matcher:
                                                     L.vp(match_of_kp), L.vp(nmatches), C.c_void_p(stream) if stream else None),
                 "plf_match_project_lastframe")
 
+    def SearchByProjectionKeyFrame(self, cur, kf, pose, log_scale_factor, th, orb_dist, check_ori, match_of_kp, nmatches, stream=None):
+        """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (relocalisation); kf: device tensors keys, valid,
+        world_pos, min_dist, max_dist, mp_desc"""
+        lv = L.LastFrameView()
+        lv.n = int(kf["mp_desc"].shape[0])
+        lv.has_mappoint = L.vp(kf["valid"]).value; lv.outlier = None
+        lv.world_pos = L.vp(kf["world_pos"]).value; lv.keys = L.vp(kf["keys"]).value; lv.mp_desc = L.vp(kf["mp_desc"]).value
+        pp = L.PosePair()
+        for name in ("Rcw", "tcw"):
+            getattr(pp, name)[:] = np.asarray(pose[name], np.float32).ravel().tolist()
+        for name in ("fx", "fy", "cx", "cy"):
+            setattr(pp, name, float(pose[name]))
+        L.check(L.lib().plf_match_project_keyframe(self._h, C.byref(cur), C.byref(lv), L.vp(kf["min_dist"]), L.vp(kf["max_dist"]), C.byref(pp),
+                                                   C.c_float(log_scale_factor), C.c_float(th), int(orb_dist), int(check_ori), L.vp(match_of_kp),
+                                                   L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_project_keyframe")
+
     def knnMatch(self, query, train):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
         nq, nt = int(query.shape[0]), int(train.shape[0])

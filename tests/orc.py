@@ -290,3 +290,21 @@ def search_by_bow_kf(desc1, desc2, angle1, angle2, has_mp1, has_mp2, nodes1, nod
                                p(n1[1]), p(n1[2]), C.c_int(len(n2[0])), p(n2[0]), p(n2[1]), p(n2[2]), C.c_float(nnratio), C.c_int(int(check_ori)), p(match))
     return match, n
 
+
+def search_by_projection_reloc(kps, desc, scale, bounds, kf, pose, log_scale_factor, th, orbdist, check_ori, match_init):
+    """kf: dict(keys (angle), valid, world_pos, min_dist, max_dist, mp_desc); pose: Rcw, tcw, fx, fy, cx, cy"""
+    L = lib()
+    F, keep = _frame(kps, desc, None, scale, bounds)
+    ang = np.ascontiguousarray(kf["keys"]["angle"]); oc = np.ascontiguousarray(kf["keys"]["octave"])
+    arrs = {k: np.ascontiguousarray(kf[k]) for k in ("valid", "world_pos", "mp_desc")}
+    mn = np.ascontiguousarray(kf["min_dist"], np.float32); mx = np.ascontiguousarray(kf["max_dist"], np.float32)
+    Lf = LastFrame()
+    Lf.n = len(ang); Lf.has_mp = p(arrs["valid"]).value; Lf.outlier = None; Lf.xw = p(arrs["world_pos"]).value
+    Lf.octave = p(oc).value; Lf.angle = p(ang).value; Lf.mp_desc = p(arrs["mp_desc"]).value
+    R = {k: np.ascontiguousarray(np.asarray(pose[k], np.float32).ravel()) for k in ("Rcw", "tcw")}
+    match = np.ascontiguousarray(match_init, np.int32).copy()
+    n = L.orc_search_by_projection_reloc(C.byref(F), C.byref(Lf), p(mn), p(mx), p(R["Rcw"]), p(R["tcw"]), C.c_float(pose["fx"]), C.c_float(pose["fy"]),
+                                         C.c_float(pose["cx"]), C.c_float(pose["cy"]), C.c_float(log_scale_factor), C.c_float(th), C.c_int(orbdist),
+                                         C.c_int(check_ori), p(match))
+    return match, n
+

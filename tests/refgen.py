@@ -145,3 +145,23 @@ def load_bow_kf_cases(path):
                         nnratio=float(c["nnratio"]), check=int(c["check_orientation"]), match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
     return out
 
+
+def load_search_reloc_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = []
+    for c in json.load(open(path))["cases"]:
+        NC, NK = c["n_cur"], c["n_kf"]
+        kps = np.zeros(NC, dtype=kp_dtype)
+        kps["x"] = f32(c["x"]); kps["y"] = f32(c["y"]); kps["angle"] = f32(c["angle"]); kps["octave"] = np.array(c["octave"], np.int32)
+        kk = np.zeros(NK, dtype=kp_dtype); kk["angle"] = f32(c["kf_angle"])
+        cam = f32(c["cam"]); Tc = f32(c["Tcw"]).reshape(4, 4)
+        kf = dict(keys=kk, valid=np.array(c["valid"], np.uint8), world_pos=f32(c["world_pos"]).reshape(NK, 3).copy(), min_dist=f32(c["min_dist"]),
+                  max_dist=f32(c["max_dist"]), mp_desc=np.frombuffer(bytes.fromhex(c["mp_desc"]), np.uint8).reshape(NK, 32).copy())
+        pose = dict(Rcw=Tc[:3, :3].copy(), tcw=Tc[:3, 3].copy(), fx=float(cam[0]), fy=float(cam[1]), cx=float(cam[2]), cy=float(cam[3]))
+        out.append(dict(kps=kps, desc=np.frombuffer(bytes.fromhex(c["desc"]), np.uint8).reshape(NC, 32).copy(), scale=f32(c["scale"]), kf=kf, pose=pose,
+                        logsf=float(cam[4]), th=float(cam[5]), orbdist=int(c["orbdist"]), check=int(c["check_orientation"]),
+                        init=np.array(c["init"], np.int32), match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
+    return out
+

@@ -303,3 +303,27 @@ def test_search_by_bow_keyframes():
         assert np.array_equal(match[0, :len(c["desc1"])].cpu().numpy(), c["expect"][0])
     m.close()
 
+
+def test_gpu_equals_reference_search_by_projection_reloc_fixture():
+    """HIP matcher vs tests/golden/ref_glue_search_reloc.json: the reference binary's own relocalisation
+    SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) on the same inputs."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_search_reloc_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_search_reloc.json")):
+        N = len(c["kps"])
+        m = Matcher(max_keypoints=1024)
+        dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"])
+        cur = Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), None)
+        kf = c["kf"]
+        dkf = dict(keys=_kp_tensor(kf["keys"]), valid=_dev(kf["valid"]), world_pos=_dev(kf["world_pos"]), min_dist=_dev(kf["min_dist"]),
+                   max_dist=_dev(kf["max_dist"]), mp_desc=_dev(kf["mp_desc"]))
+        match = _dev(c["init"]); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchByProjectionKeyFrame(cur, dkf, c["pose"], c["logsf"], c["th"], c["orbdist"], c["check"], match, nm)
+        torch.cuda.synchronize()
+        assert int(nm[0]) == c["nmatches"]
+        assert np.array_equal(match.cpu().numpy(), c["match"])
+        m.close()
+
