@@ -108,6 +108,7 @@ void orc_is_in_frustum(const float *xw, const float *normal, const float *min_di
         if (nScale < 0) nScale = 0;
         else if (nScale >= nlevels) nScale = nlevels - 1;
         in_view[i] = 1;
-        proj_x[i] = u; proj_xr[i] = u - bf * invz; proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
+        /* mTrackProjXR = u - mbf*invz is contracted too (so@0xf5dec: vfnmadd132ss) */
+        proj_x[i] = u; proj_xr[i] = fmaf(-bf, invz, u); proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
     }
 }

@@ -61,6 +61,7 @@ struct Range { int start, end; };
 template <class T> struct Size_ { T width, height; Size_() : width(0), height(0) {} Size_(const Size_ &s) : width(s.width), height(s.height) {} };
 template <class T> struct Rect_ { T x, y, width, height; };
 template <class T> struct Scalar_ { T v[4]; };
+struct _InputArray;
 struct _OutputArray;
 struct MatExpr;
 struct Mat {  // OpenCV 3.3 layout, 96 bytes
@@ -83,6 +84,7 @@ struct Mat {  // OpenCV 3.3 layout, 96 bytes
     void copySize(const Mat &m);
     static MatExpr zeros(int rows, int cols, int type);
     MatExpr t() const;
+    double dot(const _InputArray &m) const;
 };
 struct _InputArray {
     int flags; void *obj; int sz_w, sz_h;
@@ -283,6 +285,14 @@ void SubOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const   // a - b, 3x1 
     for (int i = 0; i < 3; i++) *(float *)(m.data + m.step_buf[0] * i) = d[i];
 }
 cv::MatExpr cv::operator-(const Mat &a, const Mat &b) { MatExpr e; expr_init(&e, &g_sub_op); e.a = a; e.b = b; return e; }
+double cv::Mat::dot(const _InputArray &o) const   // CV_32F vectors: dotProd_<float> accumulates in double, element by element
+{
+    const Mat *b = (const Mat *)o.obj;
+    if ((flags & 0xFFF) != 5 || cols != 1 || b->cols != 1 || b->rows != rows) { fprintf(stderr, "refprobe: unexpected dot call\n"); abort(); }
+    double r = 0;
+    for (int i = 0; i < rows; i++) r += (double)matf(*this, i, 0) * (double)matf(*b, i, 0);
+    return r;
+}
 static cv::_InputArray g_no_array = {0, nullptr, 0, 0};
 const cv::_InputArray &cv::noArray() { return g_no_array; }
 double cv::norm(const _InputArray &src, int normType, const _InputArray &)   // NORM_L2 of a CV_32F vector: double accumulation (normL2Sqr_<float, double>)
@@ -339,6 +349,7 @@ class KeyFrame;
 class Frame {   // only the exported statics are named; the object itself is hand-laid raw memory (tier D)
 public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv, fx, fy, cx, cy;
+    bool isInFrustum(MapPoint *pMP, float viewingCosLimit);
 };
 class ORBmatcher {
 public:
@@ -1221,6 +1232,68 @@ int main(int argc, char **argv)
             fprintf(JR, "\"}%s\n", c + 1 < NRC ? "," : "");
         }
         fprintf(JR, "]}\n"); fclose(JR);
+    }
+    // ------------------------------------------------------------ I: Frame::isInFrustum(MapPoint*, viewingCosLimit) (glue)
+    // Frame (so@0xf5190): mbf @0xe0, mRcw @0x123a8, mtcw @0x12408, mOw @0x124c8 (CV_32F), mnScaleLevels @0x12338, mfLogScaleFactor @0x12340;
+    // MapPoint: mWorldPos @0xd8, mNormalVector @0x168 (GetNormal so@0x917b0), mfMinDistance/mfMaxDistance @0x248/0x24c; results written to
+    // mTrackProjX/Y/XR @0x1c/0x20/0x24, mnTrackScaleLevel @0x28, mTrackViewCos @0x2c, mbTrackInView @0x30.
+    {
+        path = std::string(outdir) + "/ref_glue_frustum.json";
+        FILE *JF = fopen(path.c_str(), "w");
+        fprintf(JF, "{\"_doc\": \"Frame::isInFrustum(MapPoint*, float) (so@0xf5190) executed from the reference binary for every map point of a random local map; "
+                    "cv::Mat algebra, cv::norm and Mat::dot supplied by oracle/refprobe/probe.cpp. floats as uint32 bit patterns\", \"cases\": [\n");
+        const int NFC = 2;
+        for (int c = 0; c < NFC; c++) {
+            rng_seed(9701 + c);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int M = 3000;
+            const float fx = 517.3f, fy = 516.5f, cx = 318.6f, cy = 255.3f, bf = 40.0f, coslim = c == 0 ? 0.5f : 0.9f;
+            const float logsf = logf(1.2f);
+            float *R = (float *)bump(36), *t = (float *)bump(12), *Ow = (float *)bump(12);
+            {
+                const float ay = 0.2f - 0.3f * c, ax = 0.1f, cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float Rr[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                memcpy(R, Rr, 36); t[0] = 0.3f; t[1] = -0.1f; t[2] = 0.5f;
+                for (int i = 0; i < 3; i++) Ow[i] = (float)(-((double)R[0 * 3 + i] * t[0] + (double)R[1 * 3 + i] * t[1] + (double)R[2 * 3 + i] * t[2]));
+            }
+            char *fr = (char *)bump(0x12800); memset(fr, 0, 0x12800);
+            auto mat32 = [&](char *at, float *data, int rows, int cols) {
+                mat_init((cv::Mat *)at, (unsigned char *)data, rows, cols, (size_t)cols * 4);
+                ((cv::Mat *)at)->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)at)->step_buf[1] = 4;
+            };
+            mat32(fr + 0x123a8, R, 3, 3); mat32(fr + 0x12408, t, 3, 1); mat32(fr + 0x124c8, Ow, 3, 1);
+            *(float *)(fr + 0xe0) = bf; *(int *)(fr + 0x12338) = 8; *(float *)(fr + 0x12340) = logsf;
+            Frame::fx = fx; Frame::fy = fy; Frame::cx = cx; Frame::cy = cy;
+            Frame::mnMinX = 0.f; Frame::mnMinY = 0.f; Frame::mnMaxX = 640.f; Frame::mnMaxY = 480.f;
+            std::vector<float> wpos((size_t)M * 3), nrm((size_t)M * 3), dmin(M), dmax(M);
+            char *mps = (char *)bump((size_t)M * 0x300); memset(mps, 0, (size_t)M * 0x300);
+            std::vector<int> inview(M), level(M);
+            std::vector<float> px(M), py(M), pxr(M), vcos(M);
+            for (int i = 0; i < M; i++) {
+                for (int r = 0; r < 3; r++) wpos[(size_t)i * 3 + r] = (uf() - 0.5f) * (r == 2 ? 16.f : 10.f) + (r == 2 ? 3.f : 0.f);
+                float nx = uf() - 0.5f, ny = uf() - 0.5f, nz = uf() - 0.5f;
+                if (uf() < 0.7f) { nx = wpos[(size_t)i * 3] - Ow[0] + (uf() - 0.5f); ny = wpos[(size_t)i * 3 + 1] - Ow[1] + (uf() - 0.5f); nz = wpos[(size_t)i * 3 + 2] - Ow[2] + (uf() - 0.5f); }
+                const float nl = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
+                nrm[(size_t)i * 3] = nx / nl; nrm[(size_t)i * 3 + 1] = ny / nl; nrm[(size_t)i * 3 + 2] = nz / nl;
+                dmax[i] = 1.f + uf() * 14.f; dmin[i] = dmax[i] / (2.f + uf() * 3.f);
+                char *o = mps + (size_t)i * 0x300;
+                mat32(o + 0xd8, &wpos[(size_t)i * 3], 3, 1); mat32(o + 0x168, &nrm[(size_t)i * 3], 3, 1);
+                *(float *)(o + 0x248) = dmin[i]; *(float *)(o + 0x24c) = dmax[i];
+                *(bool *)(o + 0x30) = true;   // must be cleared by the call
+                const bool in = ((Frame *)fr)->isInFrustum((MapPoint *)o, coslim);
+                inview[i] = in ? 1 : 0;
+                if ((bool)*(bool *)(o + 0x30) != in) { fprintf(stderr, "refprobe: mbTrackInView disagrees with the return value\n"); abort(); }
+                px[i] = *(float *)(o + 0x1c); py[i] = *(float *)(o + 0x20); pxr[i] = *(float *)(o + 0x24); level[i] = *(int *)(o + 0x28); vcos[i] = *(float *)(o + 0x2c);
+            }
+            std::vector<float> cam = {fx, fy, cx, cy, bf, logsf, coslim}, Rv(R, R + 9), tv(t, t + 3), Owv(Ow, Ow + 3);
+            fprintf(JF, "{\"m\": %d, ", M);
+            J = JF;
+            jarr_f("cam", cam); jarr_f("Rcw", Rv); jarr_f("tcw", tv); jarr_f("Ow", Owv); jarr_f("world_pos", wpos); jarr_f("normal", nrm); jarr_f("min_dist", dmin);
+            jarr_f("max_dist", dmax); jarr_i("in_view", inview); jarr_f("proj_x", px); jarr_f("proj_y", py); jarr_f("proj_xr", pxr); jarr_i("level", level);
+            jarr_f("view_cos", vcos, true);
+            fprintf(JF, "}%s\n", c + 1 < NFC ? "," : "");
+        }
+        fprintf(JF, "]}\n"); fclose(JF);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) k_frustum_points(const float *__restrict_
     if (nScale < 0) nScale = 0;
     else if (nScale >= nlevels) nScale = nlevels - 1;
     in_view[i] = 1;
-    proj_x[i] = u; proj_xr[i] = u - cam.bf * invz; proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
+    // mTrackProjXR = u - mbf * invz is contracted as well (so@0xf5dec: vfnmadd132ss)
+    proj_x[i] = u; proj_xr[i] = fmaf(-cam.bf, invz, u); proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
 }
 
 static int frame_dev_ok(int device)

@@ -165,3 +165,15 @@ def load_search_reloc_cases(path):
                         init=np.array(c["init"], np.int32), match=np.array(c["match"], np.int32), nmatches=c["nmatches"]))
     return out
 
+
+def load_frustum_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    out = []
+    for c in json.load(open(path))["cases"]:
+        M = c["m"]; cam = f32(c["cam"])
+        out.append(dict(xw=f32(c["world_pos"]).reshape(M, 3).copy(), normal=f32(c["normal"]).reshape(M, 3).copy(), dmin=f32(c["min_dist"]), dmax=f32(c["max_dist"]),
+                        Rcw=f32(c["Rcw"]).reshape(3, 3).copy(), tcw=f32(c["tcw"]), Ow=f32(c["Ow"]), cam=cam, in_view=np.array(c["in_view"], np.uint8),
+                        proj_x=f32(c["proj_x"]), proj_y=f32(c["proj_y"]), proj_xr=f32(c["proj_xr"]), level=np.array(c["level"], np.int32), view_cos=f32(c["view_cos"])))
+    return out
+

@@ -107,3 +107,29 @@ def test_frustum_projection():
     for k in ("proj_x", "proj_y", "proj_xr", "view_cos"):
         assert np.array_equal(out[k].cpu().numpy()[sel].view(np.uint32), ref[k][sel].view(np.uint32)), k
     assert np.array_equal(out["level"].cpu().numpy()[sel], ref["level"][sel])
+
+
+def test_gpu_equals_reference_is_in_frustum_fixture():
+    """plf_frustum_points vs tests/golden/ref_glue_frustum.json (outputs of the reference binary's Frame::isInFrustum)"""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import frame
+    for c in refgen.load_frustum_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_frustum.json")):
+        m = len(c["xw"]); cam = c["cam"]
+        out = dict(proj_x=torch.zeros(m, device="cuda"), proj_y=torch.zeros(m, device="cuda"), proj_xr=torch.zeros(m, device="cuda"),
+                   level=torch.zeros(m, dtype=torch.int32, device="cuda"), view_cos=torch.zeros(m, device="cuda"),
+                   in_view=torch.zeros(m, dtype=torch.uint8, device="cuda"))
+        keep = [_dev(c["xw"]), _dev(c["normal"]), _dev(c["dmin"]), _dev(c["dmax"])]
+        camd = dict(frame.TUM1); camd.update(fx=float(cam[0]), fy=float(cam[1]), cx=float(cam[2]), cy=float(cam[3]), bf=float(cam[4]))
+        frame.frustum_points(keep[0], keep[1], keep[2], keep[3], dict(Rcw=c["Rcw"], tcw=c["tcw"], Ow=c["Ow"]), frame.camera(**camd), (0.0, 0.0, 640.0, 480.0),
+                             float(cam[5]), 8, float(cam[6]), out)
+        torch.cuda.synchronize()
+        iv = out["in_view"].cpu().numpy()
+        assert np.array_equal(iv, c["in_view"])
+        sel = iv == 1
+        for k in ("proj_x", "proj_y", "proj_xr", "view_cos"):
+            assert np.array_equal(out[k].cpu().numpy()[sel].view(np.uint32), c[k][sel].view(np.uint32)), k
+        assert np.array_equal(out["level"].cpu().numpy()[sel], c["level"][sel])
+
