@@ -350,6 +350,7 @@ class Frame {   // only the exported statics are named; the object itself is han
 public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv, fx, fy, cx, cy;
     bool isInFrustum(MapPoint *pMP, float viewingCosLimit);
+    void ComputeStereoFromRGBD(const cv::Mat &imDepth);
 };
 class ORBmatcher {
 public:
@@ -1294,6 +1295,41 @@ int main(int argc, char **argv)
             fprintf(JF, "}%s\n", c + 1 < NFC ? "," : "");
         }
         fprintf(JF, "]}\n"); fclose(JF);
+    }
+    // ------------------------------------------------------------ J: Frame::ComputeStereoFromRGBD(const cv::Mat&) (so@0xf6860)
+    // N @0xec, mvKeys @0xf0, mvKeysUn @0x120, mvuRight @0x138, mvDepth @0x150, mbf @0xe0; no OpenCV code is reached.
+    {
+        path = std::string(outdir) + "/ref_glue_stereo.json";
+        FILE *JT = fopen(path.c_str(), "w");
+        fprintf(JT, "{\"_doc\": \"Frame::ComputeStereoFromRGBD (so@0xf6860) executed from the reference binary: mvuRight / mvDepth for random key points and a random "
+                    "depth image (LCG, see refgen.py: depth_image). floats as uint32 bit patterns\", \"cases\": [\n");
+        const int W = 640, H = 480, N = 1200;
+        rng_seed(9801);
+        auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+        std::vector<float> depth((size_t)W * H);
+        for (size_t i = 0; i < depth.size(); i++) { const float u = uf(); depth[i] = u < 0.08f ? 0.f : (u < 0.1f ? -1.f : 0.4f + uf() * 6.f); }
+        std::vector<cv::KeyPoint> keys(N), keysun(N);
+        for (int i = 0; i < N; i++) {
+            keys[i].x = uf() * 639.99f; keys[i].y = uf() * 479.99f; keys[i].size = 31.f; keys[i].angle = 0.f; keys[i].response = 1.f; keys[i].octave = 0; keys[i].class_id = -1;
+            keysun[i] = keys[i]; keysun[i].x += (uf() - 0.5f) * 3.f; keysun[i].y += (uf() - 0.5f) * 3.f;
+        }
+        char *fr = (char *)bump(0x12800); memset(fr, 0, 0x12800);
+        *(float *)(fr + 0xe0) = 40.0f; *(int *)(fr + 0xec) = N;
+        void **v;
+        v = (void **)(fr + 0xf0); v[0] = keys.data(); v[1] = keys.data() + N; v[2] = v[1];
+        v = (void **)(fr + 0x120); v[0] = keysun.data(); v[1] = keysun.data() + N; v[2] = v[1];
+        cv::Mat dm;
+        mat_init(&dm, (unsigned char *)depth.data(), H, W, (size_t)W * 4);
+        dm.flags = 0x42FF0000 | 0x4000 | 5; dm.step_buf[1] = 4;
+        ((Frame *)fr)->ComputeStereoFromRGBD(dm);
+        float **ur = (float **)(fr + 0x138), **dp = (float **)(fr + 0x150);
+        if (ur[1] - ur[0] != N || dp[1] - dp[0] != N) { fprintf(stderr, "refprobe: unexpected vector sizes\n"); abort(); }
+        std::vector<float> kx(N), ky(N), kux(N), urv(ur[0], ur[0] + N), dpv(dp[0], dp[0] + N);
+        for (int i = 0; i < N; i++) { kx[i] = keys[i].x; ky[i] = keys[i].y; kux[i] = keysun[i].x; }
+        fprintf(JT, "{\"w\": %d, \"h\": %d, \"n\": %d, \"bf_bits\": %u, \"seed\": 9801, ", W, H, N, 0x42200000u);
+        J = JT;
+        jarr_f("x", kx); jarr_f("y", ky); jarr_f("x_un", kux); jarr_f("uright", urv); jarr_f("depth_of_kp", dpv, true);
+        fprintf(JT, "}\n]}\n"); fclose(JT);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

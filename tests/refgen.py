@@ -177,3 +177,16 @@ def load_frustum_cases(path):
                         proj_x=f32(c["proj_x"]), proj_y=f32(c["proj_y"]), proj_xr=f32(c["proj_xr"]), level=np.array(c["level"], np.int32), view_cos=f32(c["view_cos"])))
     return out
 
+
+def stereo_case(seed=9801, w=640, h=480):
+    """mirror of oracle/refprobe/probe.cpp tier J: the random depth image (float32) the reference's ComputeStereoFromRGBD was run on"""
+    g = LCG(seed)
+    f = np.float32
+    def uf():
+        return f(g.u32() >> 8) * f(1.0 / 16777216.0)
+    depth = np.zeros(w * h, np.float32)
+    for i in range(w * h):
+        u = uf()
+        depth[i] = f(0.0) if u < f(0.08) else (f(-1.0) if u < f(0.1) else f(0.4) + uf() * f(6.0))
+    return depth.reshape(h, w)
+
