@@ -495,6 +495,90 @@ int orc_search_by_bow_kf(int n1, int n2, const uint8_t *desc1, const uint8_t *de
     return nmatches;
 }
 
+/* ---------------------------------------------------------------- Fuse */
+/* MapPoint::PredictScale(const float&, KeyFrame*)  so@0x8fb60: ceilf(logf(mfMaxDistance / dist) / mfLogScaleFactor) clamped */
+static int predict_scale(float max_dist, float dist, float log_scale_factor, int nlevels)
+{
+    const float ratio = max_dist / dist;
+    int lvl = (int)ceilf(logf(ratio) / log_scale_factor);
+    if (lvl < 0) lvl = 0;
+    else if (lvl >= nlevels) lvl = nlevels - 1;
+    return lvl;
+}
+
+/* ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th)  include/ORBmatcher.h:119, so@0x7a500
+ * (listing read; executed from the binary for tests/golden/ref_glue_fuse.json).  Per map point, in list order:
+ *   p3Dc = Rcw*p3Dw + tcw (cv::gemm small-matrix float path); skip if z < 0; invz = 1/z; x = X*invz, y = Y*invz;
+ *   u = fmaf(x, fx, cx), v = fmaf(fy, y, cy) -- contracted in the binary (so@0x7abc8, so@0x7abf0);
+ *   KeyFrame::IsInImage (so@0x97480: u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY);
+ *   dist3D = float(cv::norm(p3Dw - Ow)); skip unless 0.8f*mfMinDistance <= dist3D <= 1.2f*mfMaxDistance (so@0x8fa40/0x8fad0);
+ *   skip if PO.dot(Pn) < 0.5*dist3D (doubles, so@0x7b4b4-0x7b4d2); level = PredictScale; radius = th*mvScaleFactors[level];
+ *   candidates = KeyFrame::GetFeaturesInArea(u, v, radius) (so@0x96fe0: the Frame cell walk without a level filter);
+ *   keep key points with level-1 <= octave <= level; reprojection test with e = (u - kx, v - ky[, ur - kur]),
+ *   ur = fmaf(-bf, invz, u) (so@0x7b63e), e2 = fmaf(er, er, fmaf(ex, ex, ey*ey)) (so@0x7b649-0x7b652),
+ *   skip if double(e2 * mvInvLevelSigma2[octave]) > 7.8 (stereo key point, mvuRight >= 0) / 5.99 (mono);
+ *   best Hamming distance, first index wins ties; a point is fused when best <= TH_LOW.
+ * The map mutation that follows (Replace / AddObservation / AddMapPoint) reads nothing this search depends on and
+ * stays on the host: best_idx[i] = key point of pKF for map point i, -1 = none.  P->valid[i] = pMP != NULL &&
+ * !pMP->isBad() && !pMP->IsInKeyFrame(pKF).  Returns nFused. */
+int orc_fuse(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, float th, int32_t *best_idx, int32_t *best_dist)
+{
+    int nFused = 0;
+    grid_t g; grid_build(KF, &g);
+    int *cand = (int *)malloc(sizeof(int) * (KF->n > 0 ? KF->n : 1));
+    for (int i = 0; i < P->m; i++) {
+        best_idx[i] = -1;
+        if (best_dist) best_dist[i] = 256;
+        if (!P->valid[i]) continue;
+        const float *xw = P->xw + 3 * (size_t)i;
+        const float X = C->Rcw[0] * xw[0] + C->Rcw[1] * xw[1] + C->Rcw[2] * xw[2] + C->tcw[0];
+        const float Y = C->Rcw[3] * xw[0] + C->Rcw[4] * xw[1] + C->Rcw[5] * xw[2] + C->tcw[1];
+        const float Z = C->Rcw[6] * xw[0] + C->Rcw[7] * xw[1] + C->Rcw[8] * xw[2] + C->tcw[2];
+        if (Z < 0.0f) continue;
+        const float invz = 1.0f / Z;
+        const float x = X * invz, y = Y * invz;
+        const float u = fmaf(x, C->fx, C->cx), v = fmaf(C->fy, y, C->cy);
+        if (!(u >= KF->minx && u < KF->maxx && v >= KF->miny && v < KF->maxy)) continue;
+        const float PO[3] = {xw[0] - C->Ow[0], xw[1] - C->Ow[1], xw[2] - C->Ow[2]};
+        double s2 = 0;
+        for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
+        const float dist3D = (float)sqrt(s2);
+        const float maxDistance = 1.2f * P->max_dist[i], minDistance = 0.8f * P->min_dist[i];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float *Pn = P->normal + 3 * (size_t)i;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
+        if (dot < 0.5 * (double)dist3D) continue;
+        const int lvl = predict_scale(P->max_dist[i], dist3D, C->log_scale_factor, KF->nlevels);
+        const float radius = th * KF->scale_factors[lvl];
+        const int nc = features_in_area(KF, &g, u, v, radius, -1, -1, cand, KF->n);
+        if (nc == 0) continue;
+        const uint8_t *dMP = P->desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int kpLevel = KF->octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            const float ey = v - KF->uy[idx], ex = u - KF->ux[idx];
+            if (KF->uright && KF->uright[idx] >= 0.0f) {
+                const float ur = fmaf(-C->bf, invz, u);
+                const float er = ur - KF->uright[idx];
+                const float e2 = fmaf(er, er, fmaf(ex, ex, ey * ey));
+                if ((double)(e2 * C->inv_level_sigma2[kpLevel]) > 7.8) continue;
+            } else {
+                const float e2 = fmaf(ex, ex, ey * ey);
+                if ((double)(e2 * C->inv_level_sigma2[kpLevel]) > 5.99) continue;
+            }
+            const int dist = orc_hamming256(dMP, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+        if (best_dist) best_dist[i] = bestDist;
+    }
+    free(cand); grid_free(&g);
+    return nFused;
+}
+
 /* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {

@@ -138,6 +138,20 @@ int orc_search_by_bow_kf(int n1, int n2, const uint8_t *desc1, const uint8_t *de
                          const uint8_t *has_mp1, const uint8_t *has_mp2, int nodes1, const uint32_t *node_id1, const int32_t *node_start1,
                          const int32_t *feat1, int nodes2, const uint32_t *node_id2, const int32_t *node_start2, const int32_t *feat2,
                          float nnratio, int checkOri, int32_t *match12);
+typedef struct { /* map points handed to Fuse / the Sim3 searches */
+    int m;
+    const float *xw;                  /* m x 3: GetWorldPos() */
+    const float *normal;              /* m x 3: GetNormal() */
+    const float *min_dist, *max_dist; /* mfMinDistance, mfMaxDistance (the members, not the 0.8 / 1.2 scaled getters) */
+    const uint8_t *desc;              /* m x 32: GetDescriptor() */
+    const uint8_t *valid;             /* non-null, !isBad(), not already in the keyframe / found set */
+} orc_points3d;
+typedef struct { /* KeyFrame pose and intrinsics */
+    float Rcw[9], tcw[3], Ow[3];      /* GetRotation(), GetTranslation(), GetCameraCenter() */
+    float fx, fy, cx, cy, bf, log_scale_factor;
+    const float *inv_level_sigma2;    /* mvInvLevelSigma2 */
+} orc_kf_pose;
+int orc_fuse(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, float th, int32_t *best_idx, int32_t *best_dist);
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq x 2*/,
                      int32_t *dist /*nq x 2*/);
 

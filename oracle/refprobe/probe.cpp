@@ -344,8 +344,12 @@ public:
                     const cv::_OutputArray &descriptors);
     char storage[1024];
 };
-class MapPoint;
 class KeyFrame;
+class MapPoint {   // hand-laid raw memory; the two map-mutating members Fuse calls are defined HERE (recorders, tier K): the binary reaches
+public:            // them through its PLT, so the executable's definitions are the ones that run
+    void AddObservation(KeyFrame *pKF, size_t idx);
+    void Replace(MapPoint *pMP);
+};
 class Frame {   // only the exported statics are named; the object itself is hand-laid raw memory (tier D)
 public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv, fx, fy, cx, cy;
@@ -360,6 +364,7 @@ public:
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
+    int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -367,6 +372,12 @@ public:
     char storage[64];
 };
 }  // namespace ORB_SLAM2
+
+// recorders behind MapPoint::AddObservation / MapPoint::Replace (tier K)
+struct FuseEvent { int kind; void *a, *b; size_t idx; };   // kind 0: a->AddObservation(kf, idx); 1: a->Replace(b)
+static std::vector<FuseEvent> g_fuse_events;
+void ORB_SLAM2::MapPoint::AddObservation(KeyFrame *, size_t idx) { FuseEvent e = {0, this, nullptr, idx}; g_fuse_events.push_back(e); }
+void ORB_SLAM2::MapPoint::Replace(MapPoint *pMP) { FuseEvent e = {1, this, pMP, 0}; g_fuse_events.push_back(e); }
 
 // ---------------------------------------------------------------- shared PRNG (same LCG in tests/refgen.py)
 static uint64_t g_rng = 1;
@@ -1330,6 +1341,161 @@ int main(int argc, char **argv)
         J = JT;
         jarr_f("x", kx); jarr_f("y", ky); jarr_f("x_un", kux); jarr_f("uright", urv); jarr_f("depth_of_kp", dpv, true);
         fprintf(JT, "}\n]}\n"); fclose(JT);
+    }
+    // ------------------------------------------------------------ K: ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (so@0x7a500, glue)
+    // KeyFrame offsets (KeyFrame::GetFeaturesInArea so@0x96fe0, IsInImage so@0x97480, GetRotation/GetTranslation/GetCameraCenter so@0x97be0/0x97f30/0x97900,
+    // MapPoint::PredictScale(float, KeyFrame*) so@0x8fb60): mnGridCols/Rows @0x18/0x1c, mfGridElementWidthInv/HeightInv @0x20/0x24, fx, fy, cx, cy @0x130..0x13c,
+    // mbf @0x148, N @0x154, mvKeysUn @0x170, mvuRight @0x188, mDescriptors @0x1b8, mnScaleLevels @0x2d8, mfLogScaleFactor @0x2e0, mvScaleFactors @0x2e8,
+    // mvInvLevelSigma2 @0x318, mnMinX/MinY/MaxX/MaxY (int) @0x330..0x33c, Tcw @0x3a0, Ow @0x460, mvpMapPoints @0x520, mGrid @0x548, mMutexPose @0x640,
+    // mMutexFeatures @0x690.  MapPoint: mObservations (std::map<KeyFrame*, size_t>) @0x138 (IsInKeyFrame so@0x8f970).
+    // MapPoint::AddObservation / Replace are the recorders defined above; KeyFrame::GetMapPoint / AddMapPoint run from the binary.
+    {
+        path = std::string(outdir) + "/ref_glue_fuse.json";
+        FILE *JK = fopen(path.c_str(), "w");
+        fprintf(JK, "{\"_doc\": \"ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (so@0x7a500) executed from the reference binary on hand-laid objects; "
+                    "cv::Mat algebra / cv::norm / Mat::dot supplied by oracle/refprobe/probe.cpp, MapPoint::AddObservation / Replace replaced by recorders. floats as "
+                    "uint32 bit patterns; best_idx[i] = keyframe key point map point i was fused with (-1 none)\", \"cases\": [\n");
+        struct { int nk, m; float th; uint64_t seed; } kc[] = {{900, 700, 3.0f, 9901}, {600, 800, 4.0f, 9902}, {1000, 500, 2.5f, 9903}};
+        const int NKC = 3;
+        for (int c = 0; c < NKC; c++) {
+            rng_seed(kc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int NK = kc[c].nk, M = kc[c].m;
+            const float fx = 517.3f, fy = 516.5f, cx = 318.6f, cy = 255.3f, bf = 40.0f;
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            const float logsf = logf(1.2f);
+            float *Tc = (float *)bump(64), *Owp = (float *)bump(16);
+            {
+                const float ay = -0.05f + 0.02f * c, ax = 0.03f, cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float R[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) Tc[r * 4 + q] = R[r * 3 + q];
+                Tc[3] = -0.2f; Tc[7] = 0.07f; Tc[11] = 0.15f; Tc[12] = Tc[13] = Tc[14] = 0.f; Tc[15] = 1.f;
+            }
+            for (int i = 0; i < 3; i++) Owp[i] = -(Tc[0 * 4 + i] * Tc[3] + Tc[1 * 4 + i] * Tc[7] + Tc[2 * 4 + i] * Tc[11]);
+            std::vector<cv::KeyPoint> kk(NK);
+            std::vector<float> kur(NK), kz(NK);
+            std::vector<uint8_t> kdesc((size_t)NK * 32);
+            for (int k = 0; k < NK; k++) {
+                kk[k].x = uf() * 640.f; kk[k].y = uf() * 480.f; kk[k].size = 31.f; kk[k].angle = uf() * 360.f; kk[k].response = 1.f; kk[k].octave = (int)rng_below(8); kk[k].class_id = -1;
+                kz[k] = 0.6f + uf() * 7.f;
+                kur[k] = uf() < 0.7f ? kk[k].x - bf / kz[k] + (uf() - 0.5f) * 1.5f : -1.f;
+                for (int b = 0; b < 32; b++) kdesc[(size_t)k * 32 + b] = (uint8_t)rng_below(256);
+            }
+            std::vector<float> wpos((size_t)M * 3), nrm((size_t)M * 3), dmin(M), dmax(M);
+            std::vector<int> bad(M), inkf(M), nobs(M);
+            std::vector<uint8_t> mdesc((size_t)M * 32);
+            for (int i = 0; i < M; i++) {
+                // most points re-observe a key point of the keyframe (a few of them the same one), the rest fall anywhere (some outside / behind)
+                const int src = (int)rng_below(NK);
+                const bool tied = uf() < 0.85f;
+                float u0 = tied ? kk[src].x + (uf() - 0.5f) * 5.f * scale[kk[src].octave] : -80.f + uf() * 800.f;
+                float v0 = tied ? kk[src].y + (uf() - 0.5f) * 5.f * scale[kk[src].octave] : -60.f + uf() * 600.f;
+                float z = tied ? kz[src] * (1.f + (uf() - 0.5f) * 0.02f) : 0.5f + uf() * 8.f;
+                if (uf() < 0.03f) z = -z;
+                const float Xc[3] = {(u0 - cx) / fx * z - Tc[3], (v0 - cy) / fy * z - Tc[7], z - Tc[11]};
+                for (int r = 0; r < 3; r++) wpos[(size_t)i * 3 + r] = Tc[0 * 4 + r] * Xc[0] + Tc[1 * 4 + r] * Xc[1] + Tc[2 * 4 + r] * Xc[2];
+                const float dx = wpos[(size_t)i * 3] - Owp[0], dy = wpos[(size_t)i * 3 + 1] - Owp[1], dz = wpos[(size_t)i * 3 + 2] - Owp[2];
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                // viewing direction: around the ray from the camera, now and then more than 60 degrees off
+                float nv[3] = {dx / dist + (uf() - 0.5f) * 0.6f, dy / dist + (uf() - 0.5f) * 0.6f, dz / dist + (uf() - 0.5f) * 0.6f};
+                if (uf() < 0.08f) { nv[0] = -nv[0]; nv[2] = -nv[2]; }
+                if (uf() < 0.1f) { nv[0] += 1.5f; }
+                const float nn = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+                for (int r = 0; r < 3; r++) nrm[(size_t)i * 3 + r] = nv[r] / nn;
+                const int plev = tied ? kk[src].octave : (int)rng_below(8);
+                dmax[i] = dist * powf(1.2f, (float)plev + (uf() < 0.5f ? 0.f : 1.f) - 0.5f + (uf() - 0.5f) * 0.9f);
+                dmin[i] = dmax[i] / powf(1.2f, 7.f);
+                if (uf() < 0.05f) { dmax[i] = dist * 0.6f; dmin[i] = dmax[i] / 4.f; }
+                bad[i] = uf() < 0.04f; inkf[i] = uf() < 0.06f; nobs[i] = 1 + (int)rng_below(6);
+                for (int b = 0; b < 32; b++) mdesc[(size_t)i * 32 + b] = tied ? kdesc[(size_t)src * 32 + b] : (uint8_t)rng_below(256);
+                const int flips = (int)rng_below(80);
+                for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); mdesc[(size_t)i * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+            }
+            char *kf = (char *)bump(0x800); memset(kf, 0, 0x800);
+            const size_t MPS = 0x300;
+            char *mps = (char *)bump((size_t)(M + NK) * MPS); memset(mps, 0, (size_t)(M + NK) * MPS);
+            char *occ = mps + (size_t)M * MPS;   // occupant k = the map point key point k already holds (30 % of them)
+            std::vector<MapPoint *> list(M, nullptr);
+            std::vector<void *> kmp(NK, nullptr);
+            std::vector<int> isnull(M);
+            for (int i = 0; i < M; i++) {
+                char *o = mps + (size_t)i * MPS;
+                *(int *)(o + 0x18) = nobs[i];
+                new (o + 0x138) std::map<KeyFrame *, size_t>();
+                if (inkf[i]) (*(std::map<KeyFrame *, size_t> *)(o + 0x138))[(KeyFrame *)kf] = 0;
+                mat_init((cv::Mat *)(o + 0xd8), (unsigned char *)&wpos[(size_t)i * 3], 3, 1, 4);
+                ((cv::Mat *)(o + 0xd8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0xd8))->step_buf[1] = 4;
+                mat_init((cv::Mat *)(o + 0x168), (unsigned char *)&nrm[(size_t)i * 3], 3, 1, 4);
+                ((cv::Mat *)(o + 0x168))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0x168))->step_buf[1] = 4;
+                mat_init((cv::Mat *)(o + 0x1c8), &mdesc[(size_t)i * 32], 1, 32, 32); ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
+                *(bool *)(o + 0x238) = bad[i] != 0; *(float *)(o + 0x248) = dmin[i]; *(float *)(o + 0x24c) = dmax[i];
+                isnull[i] = uf() < 0.02f;
+                if (!isnull[i]) list[i] = (MapPoint *)o;
+            }
+            for (int k = 0; k < NK; k++) {
+                char *o = occ + (size_t)k * MPS;
+                *(int *)(o + 0x18) = 1 + (int)rng_below(6);
+                new (o + 0x138) std::map<KeyFrame *, size_t>();
+                if (uf() < 0.3f) kmp[k] = o;
+            }
+            *(int *)(kf + 0x18) = 64; *(int *)(kf + 0x1c) = 48; *(float *)(kf + 0x20) = 64.f / 640.f; *(float *)(kf + 0x24) = 48.f / 480.f;
+            *(float *)(kf + 0x130) = fx; *(float *)(kf + 0x134) = fy; *(float *)(kf + 0x138) = cx; *(float *)(kf + 0x13c) = cy; *(float *)(kf + 0x148) = bf;
+            *(int *)(kf + 0x154) = NK;
+            void **v;
+            v = (void **)(kf + 0x170); v[0] = kk.data(); v[1] = kk.data() + NK; v[2] = v[1];
+            v = (void **)(kf + 0x188); v[0] = kur.data(); v[1] = kur.data() + NK; v[2] = v[1];
+            mat_init((cv::Mat *)(kf + 0x1b8), kdesc.data(), NK, 32, 32); ((cv::Mat *)(kf + 0x1b8))->flags |= 0x4000;
+            *(int *)(kf + 0x2d8) = 8; *(float *)(kf + 0x2e0) = logsf;
+            v = (void **)(kf + 0x2e8); v[0] = scale; v[1] = scale + 8; v[2] = v[1];
+            v = (void **)(kf + 0x318); v[0] = is2; v[1] = is2 + 8; v[2] = v[1];
+            *(int *)(kf + 0x330) = 0; *(int *)(kf + 0x334) = 0; *(int *)(kf + 0x338) = 640; *(int *)(kf + 0x33c) = 480;
+            mat_init((cv::Mat *)(kf + 0x3a0), (unsigned char *)Tc, 4, 4, 16);
+            ((cv::Mat *)(kf + 0x3a0))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(kf + 0x3a0))->step_buf[1] = 4;
+            mat_init((cv::Mat *)(kf + 0x460), (unsigned char *)Owp, 3, 1, 4);
+            ((cv::Mat *)(kf + 0x460))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(kf + 0x460))->step_buf[1] = 4;
+            v = (void **)(kf + 0x520); v[0] = kmp.data(); v[1] = kmp.data() + NK; v[2] = v[1];
+            std::vector<std::vector<std::vector<size_t>>> G(64, std::vector<std::vector<size_t>>(48));
+            for (int k = 0; k < NK; k++) {
+                const int gx = (int)roundf(kk[k].x * (64.f / 640.f)), gy = (int)roundf(kk[k].y * (48.f / 480.f));
+                if (gx < 0 || gx >= 64 || gy < 0 || gy >= 48) continue;
+                G[gx][gy].push_back((size_t)k);
+            }
+            memcpy(kf + 0x548, (void *)&G, sizeof(G));
+            g_fuse_events.clear();
+            ORBmatcher *mt = new ORBmatcher(0.6f, true);
+            const int nf = mt->Fuse((KeyFrame *)kf, list, kc[c].th);
+            // decode: AddObservation names the key point directly; a Replace pairs the current point with the holder of its key point
+            std::vector<int> best(M, -1), valid(M);
+            auto mp_index = [&](void *q) { return (int)(((char *)q - mps) / MPS); };
+            for (const FuseEvent &e : g_fuse_events) {
+                if (e.kind == 0) { best[mp_index(e.a)] = (int)e.idx; continue; }
+                const int ia = mp_index(e.a), ib = mp_index(e.b);
+                // one of the two is a list point without a key point yet (the one being fused), the other holds the key point
+                auto holder_kp = [&](int q) { return q >= M ? q - M : best[q]; };
+                const int cur = (ia < M && best[ia] < 0) ? ia : ib, oth = cur == ia ? ib : ia;
+                if (cur >= M || holder_kp(oth) < 0) { fprintf(stderr, "refprobe: cannot decode a Replace event\n"); abort(); }
+                best[cur] = holder_kp(oth);
+            }
+            int cnt = 0;
+            for (int i = 0; i < M; i++) { valid[i] = !isnull[i] && !bad[i] && !inkf[i]; cnt += best[i] >= 0; }
+            if (cnt != nf) { fprintf(stderr, "refprobe: %d fused points decoded, the call returned %d\n", cnt, nf); abort(); }
+            std::vector<float> kx(NK), ky(NK), Tcv(Tc, Tc + 16), Owv(Owp, Owp + 3), scv(scale, scale + 8), isv(is2, is2 + 8), cam = {fx, fy, cx, cy, bf, logsf, kc[c].th};
+            std::vector<int> ko(NK);
+            for (int k = 0; k < NK; k++) { kx[k] = kk[k].x; ky[k] = kk[k].y; ko[k] = kk[k].octave; }
+            fprintf(JK, "{\"n_kf\": %d, \"m\": %d, \"nfused\": %d, ", NK, M, nf);
+            J = JK;
+            jarr_f("cam", cam); jarr_f("Tcw", Tcv); jarr_f("Ow", Owv); jarr_f("scale", scv); jarr_f("inv_sigma2", isv);
+            jarr_f("x", kx); jarr_f("y", ky); jarr_i("octave", ko); jarr_f("uright", kur);
+            jarr_f("world_pos", wpos); jarr_f("normal", nrm); jarr_f("min_dist", dmin); jarr_f("max_dist", dmax); jarr_i("valid", valid);
+            jarr_i("best_idx", best);
+            fprintf(JK, "\"desc\": \"");
+            for (size_t b = 0; b < kdesc.size(); b++) fprintf(JK, "%02x", kdesc[b]);
+            fprintf(JK, "\", \"mp_desc\": \"");
+            for (size_t b = 0; b < mdesc.size(); b++) fprintf(JK, "%02x", mdesc[b]);
+            fprintf(JK, "\"}%s\n", c + 1 < NKC ? "," : "");
+        }
+        fprintf(JK, "]}\n"); fclose(JK);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

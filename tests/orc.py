@@ -46,6 +46,16 @@ class LastFrame(C.Structure):
                 ("angle", C.c_void_p), ("mp_desc", C.c_void_p)]
 
 
+class Points3D(C.Structure):
+    _fields_ = [("m", C.c_int), ("xw", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
+                ("desc", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class KfPose(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float), ("log_scale_factor", C.c_float), ("inv_level_sigma2", C.c_void_p)]
+
+
 class LineFrame(C.Structure):
     _fields_ = [("n", C.c_int), ("pt_x", C.c_void_p), ("pt_y", C.c_void_p), ("angle", C.c_void_p), ("octave", C.c_void_p),
                 ("desc", C.c_void_p), ("scale_factors", C.c_void_p)]
@@ -308,3 +318,38 @@ def search_by_projection_reloc(kps, desc, scale, bounds, kf, pose, log_scale_fac
                                          C.c_int(check_ori), p(match))
     return match, n
 
+
+
+def _points3d(pts):
+    arrs = dict(xw=np.ascontiguousarray(pts["xw"], np.float32), normal=np.ascontiguousarray(pts["normal"], np.float32),
+                min_dist=np.ascontiguousarray(pts["min_dist"], np.float32), max_dist=np.ascontiguousarray(pts["max_dist"], np.float32),
+                desc=np.ascontiguousarray(pts["desc"], np.uint8), valid=np.ascontiguousarray(pts["valid"], np.uint8))
+    P = Points3D()
+    P.m = len(arrs["valid"])
+    for k, v in arrs.items():
+        setattr(P, k, p(v).value)
+    return P, arrs
+
+
+def _kf_pose(pose):
+    Cp = KfPose()
+    Cp.Rcw[:] = [float(x) for x in np.asarray(pose["Rcw"], np.float32).ravel()]
+    Cp.tcw[:] = [float(x) for x in np.asarray(pose["tcw"], np.float32).ravel()]
+    Cp.Ow[:] = [float(x) for x in np.asarray(pose["Ow"], np.float32).ravel()]
+    for k in ("fx", "fy", "cx", "cy", "bf", "log_scale_factor"):
+        setattr(Cp, k, float(pose[k]))
+    isg = np.ascontiguousarray(pose["inv_sigma2"], np.float32)
+    Cp.inv_level_sigma2 = p(isg).value
+    return Cp, isg
+
+
+def fuse(kps, desc, uright, scale, bounds, pose, pts, th):
+    """ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th): (best_idx, best_dist, nFused)"""
+    L = lib()
+    F, keep = _frame(kps, desc, uright, scale, bounds)
+    P, keep2 = _points3d(pts)
+    Cp, keep3 = _kf_pose(pose)
+    best = np.zeros(P.m, np.int32); bd = np.zeros(P.m, np.int32)
+    L.orc_fuse.restype = C.c_int
+    n = L.orc_fuse(C.byref(F), C.byref(Cp), C.byref(P), C.c_float(th), p(best), p(bd))
+    return best, bd, n
