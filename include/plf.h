@@ -223,6 +223,34 @@ int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *cur, const 
                                const float *max_distance, const plf_pose_pair *pose, float log_scale_factor, float th, int32_t orb_dist,
                                int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches, void *stream);
 
+/* Map points handed to Fuse / the Sim3 searches (vector<MapPoint*>), flattened; DEVICE memory */
+typedef struct {
+    int32_t m;
+    const float *world_pos;      /* m x 3: GetWorldPos() */
+    const float *normal;         /* m x 3: GetNormal() (unread by overloads without a viewing-angle test) */
+    const float *min_distance;   /* mfMinDistance (the 0.8 factor of GetMinDistanceInvariance is applied here) */
+    const float *max_distance;   /* mfMaxDistance (the 1.2 factor of GetMaxDistanceInvariance is applied here) */
+    const uint8_t *desc;         /* m x 32: GetDescriptor() */
+    const uint8_t *valid;        /* pMP != NULL && !isBad() && not already in the keyframe / found set */
+} plf_points3d_view;
+
+/* KeyFrame pose and intrinsics read by these searches; HOST struct */
+typedef struct {
+    float Rcw[9], tcw[3], Ow[3];   /* GetRotation(), GetTranslation(), GetCameraCenter() */
+    float fx, fy, cx, cy, bf;      /* KeyFrame::fx, fy, cx, cy, mbf */
+    float log_scale_factor;        /* mfLogScaleFactor */
+    const float *inv_level_sigma2; /* mvInvLevelSigma2 (host, kf->nlevels <= 16 floats) */
+} plf_kf_pose;
+
+/* int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th)   include/ORBmatcher.h:119 (so@0x7a500)
+ * -- the search half: for every map point the keyframe key point it is fused with.  kf = the keyframe's mvKeysUn / mvuRight /
+ * mDescriptors / image bounds / mvScaleFactors (KeyFrame::GetFeaturesInArea so@0x96fe0, IsInImage so@0x97480).
+ * best_idx (device, m int32): key point index, -1 = none; nfused (device int32) = the reference's return value.
+ * The map mutation of the reference loop -- Replace / AddObservation / AddMapPoint, decided by pKF->GetMapPoint(best_idx) --
+ * reads nothing the search depends on and is applied by the caller in list order. */
+int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const plf_kf_pose *pose, const plf_points3d_view *pts, float th,
+                   int32_t *best_idx, int32_t *nfused, void *stream);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
  * include/ORBmatcher.h:104 (so@0x80150) -- the tracker's reference-keyframe / relocalisation matcher.
  * One view per (keyframe, frame) pair, all arrays in DEVICE memory.  The DBoW2 feature vectors

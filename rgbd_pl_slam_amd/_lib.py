@@ -69,6 +69,16 @@ class BowView(C.Structure):
                 ("kf_feat", C.c_void_p), ("f_feat", C.c_void_p)]
 
 
+class Points3DView(C.Structure):
+    _fields_ = [("m", C.c_int32), ("world_pos", C.c_void_p), ("normal", C.c_void_p), ("min_distance", C.c_void_p), ("max_distance", C.c_void_p),
+                ("desc", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class KfPose(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float), ("log_scale_factor", C.c_float), ("inv_level_sigma2", C.c_void_p)]
+
+
 class PlfError(RuntimeError):
     def __init__(self, status, what):
         super().__init__("%s failed: %s (%d)" % (what, lib().plf_status_string(status).decode(), status))

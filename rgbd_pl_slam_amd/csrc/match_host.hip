@@ -28,6 +28,8 @@ struct RelocDev { int on; const float *min_dist, *max_dist; float log_scale; int
 struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; };
 struct BowDev { int n_kf, n_f; const uint8_t *kf_desc, *f_desc; const float *kf_angle, *f_angle; const uint8_t *kf_has_mp, *f_has_mp; int kf_nodes, f_nodes;
                 const uint32_t *kf_node_id, *f_node_id; const int *kf_node_start, *f_node_start; const int *kf_feat, *f_feat; };
+struct Pts3Dev { int m; const float *xw, *normal, *min_dist, *max_dist; const uint8_t *desc, *valid; };
+struct ProjKf { float R[9], t[3], R2[9], t2[3], Ow[3]; float fx, fy, cx, cy, bf, log_scale; float inv_sigma2[16]; int two_stage, view_test, chi2, accept; };
 struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const uint8_t *desc; const float *scale_factors; };
 struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
 
@@ -37,6 +39,7 @@ __global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, 
 __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, RelocDev, float, int, int, int *, int *, uint8_t *, float4 *, int);
+__global__ void k_project_kf(FrameDev, Pts3Dev, ProjKf, float, int *, int *, int *);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
 __global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int);
@@ -283,6 +286,60 @@ extern "C" int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *
     RelocDev RL;
     RL.on = 1; RL.min_dist = min_distance; RL.max_dist = max_distance; RL.log_scale = log_scale_factor; RL.orb_dist = orb_dist;
     return match_lastframe_impl(h, cur, kf, pose, RL, th, 1, check_orientation, match_of_kp, nmatches, stream);
+}
+
+// upload the keyframe's view as frame 0 of the handle's table and build its cell CSR
+static int stage_keyframe(plf_matcher *h, const plf_frame_view *kf, hipStream_t s, FrameDev *out)
+{
+    if (!kf || kf->n < 0 || kf->n > h->max_kp || !(kf->max_x > kf->min_x) || !(kf->max_y > kf->min_y) || kf->nlevels < 1 || kf->nlevels > 16) return PLF_E_BADARG;
+    FrameDev fd;
+    memset(&fd, 0, sizeof(fd));
+    fd = make_frame(h, *kf, 0);
+    if (h->h_nframes != 1 || memcmp(h->h_frames, &fd, sizeof(FrameDev)) != 0) {
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(h->h_frames, &fd, sizeof(FrameDev));
+        h->h_nframes = 1;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_frames, sizeof(FrameDev), hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_build_grid, dim3(1), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
+    *out = fd;
+    return PLF_OK;
+}
+
+static Pts3Dev make_points(const plf_points3d_view *p)
+{
+    Pts3Dev P;
+    P.m = p->m; P.xw = p->world_pos; P.normal = p->normal; P.min_dist = p->min_distance; P.max_dist = p->max_distance; P.desc = p->desc; P.valid = p->valid;
+    return P;
+}
+
+static void fill_camera(ProjKf *C, const plf_kf_pose *pose, int nlevels)
+{
+    memset(C, 0, sizeof(*C));
+    memcpy(C->R, pose->Rcw, sizeof(C->R)); memcpy(C->t, pose->tcw, sizeof(C->t)); memcpy(C->Ow, pose->Ow, sizeof(C->Ow));
+    C->fx = pose->fx; C->fy = pose->fy; C->cx = pose->cx; C->cy = pose->cy; C->bf = pose->bf; C->log_scale = pose->log_scale_factor;
+    for (int l = 0; l < nlevels && l < 16; l++) C->inv_sigma2[l] = pose->inv_level_sigma2[l];
+}
+
+extern "C" int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const plf_kf_pose *pose, const plf_points3d_view *pts, float th,
+                              int32_t *best_idx, int32_t *nfused, void *stream)
+{
+    if (!h || !kf || !pose || !pts || !best_idx || !nfused || pts->m < 0 || pts->m > h->max_mp || !(pose->log_scale_factor > 0.f)) return PLF_E_BADARG;
+    if (pts->m > 0 && (!pts->world_pos || !pts->normal || !pts->min_distance || !pts->max_distance || !pts->desc || !pts->valid)) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    FrameDev fd;
+    const int st = stage_keyframe(h, kf, s, &fd);
+    if (st != PLF_OK) return st;
+    ProjKf C;
+    fill_camera(&C, pose, kf->nlevels);
+    C.view_test = 1; C.chi2 = 1; C.accept = 50;   // ORBmatcher::TH_LOW
+    PLF_HIP_TRY(hipMemsetAsync(nfused, 0, sizeof(int), s));
+    if (pts->m > 0)
+        hipLaunchKernelGGL(k_project_kf, dim3((pts->m + 255) / 256), dim3(256), 0, s, fd, make_points(pts), C, th, best_idx, (int *)nullptr, nfused);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
 }
 
 extern "C" int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const uint8_t *train, int32_t nt, plf_dmatch *out,

@@ -7,6 +7,7 @@
 //   k_lines_lastframe       LSDmatcher::SearchByProjection(Frame&, const Frame&) + Frame::lineDescriptorMAD
 //   k_match_project_lines   LSDmatcher::SearchByProjection(Frame&, vector<MapLine*>&, th) + Frame::GetLinesInArea
 //   k_match_bow             ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)     include/ORBmatcher.h:104, so@0x80150
+//   k_project_kf            search half of ORBmatcher::Fuse (both overloads) and SearchBySim3    include/ORBmatcher.h:116-122
 //   k_hamming_matrix        DescriptorDistance over all pairs
 //
 // The reference loops are GREEDY: map point m skips key points claimed by map points before it, so its result
@@ -525,6 +526,103 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
     }
     for (int k = t; k < F.n; k += T) match[k] = claim[k];
     if (t == 0) *nmatches = s_acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// "Project map points into a keyframe and take the best key point": the search half of
+//   ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)                      include/ORBmatcher.h:119, so@0x7a500
+//   ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, ...)    include/ORBmatcher.h:122, so@0x7bb20
+//   ORBmatcher::SearchBySim3 (each direction)                                      include/ORBmatcher.h:116, so@0x838b0
+// One thread per map point: the searches read only immutable keyframe data, every map point is independent of the
+// others (the map mutations that follow in Fuse stay on the host).  KeyFrame::GetFeaturesInArea (so@0x96fe0) is the
+// Frame cell walk without a level filter; KeyFrame::IsInImage (so@0x97480) is half-open.
+// ------------------------------------------------------------------------------------------------
+struct Pts3Dev { int m; const float *xw, *normal, *min_dist, *max_dist; const uint8_t *desc, *valid; };
+struct ProjKf {
+    float R[9], t[3];      // camera <- world
+    float R2[9], t2[3];    // second stage (SearchBySim3: sR21 / t21 applied to the camera-1 point)
+    float Ow[3];
+    float fx, fy, cx, cy, bf, log_scale;
+    float inv_sigma2[16];
+    int two_stage;         // 1: p = R2 * (R * xw + t) + t2, dist3D = |p|; 0: p = R * xw + t, dist3D = |xw - Ow|
+    int view_test;         // PO . Pn < 0.5 * dist3D rejects
+    int chi2;              // reprojection test of Fuse(KeyFrame*, ...)
+    int accept;            // TH_LOW / TH_HIGH
+};
+
+__global__ void __launch_bounds__(256) k_project_kf(FrameDev F, Pts3Dev P, ProjKf C, float th, int *__restrict__ best_idx,
+                                                    int *__restrict__ best_dist, int *__restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.m) return;
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int bestDist = 256, bestIdx = -1;
+    bool act = P.valid[i] != 0;
+    float u = 0.f, v = 0.f, invz = 0.f, dist3D = 0.f;
+    if (act) {
+        const float *xw = P.xw + 3 * (size_t)i;
+        float X = C.R[0] * xw[0] + C.R[1] * xw[1] + C.R[2] * xw[2] + C.t[0];
+        float Y = C.R[3] * xw[0] + C.R[4] * xw[1] + C.R[5] * xw[2] + C.t[1];
+        float Z = C.R[6] * xw[0] + C.R[7] * xw[1] + C.R[8] * xw[2] + C.t[2];
+        if (C.two_stage) {
+            const float a = X, b = Y, c = Z;
+            X = C.R2[0] * a + C.R2[1] * b + C.R2[2] * c + C.t2[0];
+            Y = C.R2[3] * a + C.R2[4] * b + C.R2[5] * c + C.t2[1];
+            Z = C.R2[6] * a + C.R2[7] * b + C.R2[8] * c + C.t2[2];
+        }
+        if (Z < 0.0f) act = false;
+        invz = 1.0f / Z;
+        const float x = X * invz, y = Y * invz;
+        // contracted in the binary (so@0x7abc8 / 0x7abf0, so@0x7caac / 0x7cabe, so@0x84af1 / 0x84b03)
+        u = fmaf(x, C.fx, C.cx); v = fmaf(C.fy, y, C.cy);
+        if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) act = false;
+        const float PO[3] = {C.two_stage ? X : xw[0] - C.Ow[0], C.two_stage ? Y : xw[1] - C.Ow[1], C.two_stage ? Z : xw[2] - C.Ow[2]};
+        double s2 = 0;
+        for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
+        dist3D = (float)sqrt(s2);
+        const float maxDistance = 1.2f * P.max_dist[i], minDistance = 0.8f * P.min_dist[i];
+        if (dist3D < minDistance || dist3D > maxDistance) act = false;
+        if (act && C.view_test) {
+            const float *Pn = P.normal + 3 * (size_t)i;
+            double dot = 0;
+            for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
+            if (dot < 0.5 * (double)dist3D) act = false;
+        }
+    }
+    if (act) {
+        // MapPoint::PredictScale(float, KeyFrame*) so@0x8fb60 (logf of glibc: the correctly rounded value, see k_match_lastframe)
+        const float ratio = P.max_dist[i] / dist3D;
+        int lvl = (int)ceilf((float)log((double)ratio) / C.log_scale);
+        if (lvl < 0) lvl = 0;
+        else if (lvl >= F.nlevels) lvl = F.nlevels - 1;
+        const float radius = th * F.scale_factors[lvl];
+        const CellWin w = cell_window(F, u, v, radius);
+        const uint8_t *d = P.desc + 32 * (size_t)i;
+        if (w.ok) FOR_EACH_CANDIDATE(F, w, u, v, radius, -1, -1, idx, {
+            const int kpLevel = _kp.octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            if (C.chi2) {
+                const float ey = v - _kp.y;
+                const float ex = u - _kp.x;
+                const float kur = F.uright ? F.uright[idx] : -1.f;
+                if (kur >= 0.0f) {
+                    const float ur = fmaf(-C.bf, invz, u);   // so@0x7b63e
+                    const float er = ur - kur;
+                    const float e2 = fmaf(er, er, fmaf(ex, ex, ey * ey));
+                    if ((double)(e2 * C.inv_sigma2[kpLevel]) > 7.8) continue;
+                } else {
+                    const float e2 = fmaf(ex, ex, ey * ey);
+                    if ((double)(e2 * C.inv_sigma2[kpLevel]) > 5.99) continue;
+                }
+            }
+            const int dist = hamming_g(d, F.desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        })
+    }
+    const bool hit = bestIdx >= 0 && bestDist <= C.accept;
+    best_idx[i] = hit ? bestIdx : -1;
+    if (best_dist) best_dist[i] = bestDist;
+    if (count && hit) atomicAdd(count, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

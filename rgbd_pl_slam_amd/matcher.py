@@ -85,6 +85,35 @@ class Matcher:
                                                    C.c_float(log_scale_factor), C.c_float(th), int(orb_dist), int(check_ori), L.vp(match_of_kp),
                                                    L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_project_keyframe")
 
+    @staticmethod
+    def points3d_view(pts):
+        """pts: dict of device tensors world_pos (m,3) f32, normal (m,3) f32, min_dist, max_dist f32, desc (m,32) u8, valid u8"""
+        v = L.Points3DView()
+        v.m = int(pts["desc"].shape[0])
+        v.world_pos = L.vp(pts["world_pos"]).value; v.normal = L.vp(pts["normal"]).value if pts.get("normal") is not None else None
+        v.min_distance = L.vp(pts["min_dist"]).value; v.max_distance = L.vp(pts["max_dist"]).value
+        v.desc = L.vp(pts["desc"]).value; v.valid = L.vp(pts["valid"]).value
+        return v
+
+    @staticmethod
+    def kf_pose(pose):
+        """pose: Rcw (3,3), tcw, Ow, fx, fy, cx, cy, bf, log_scale_factor, inv_sigma2 (host values); returns (struct, keep-alive)"""
+        kp = L.KfPose()
+        for name in ("Rcw", "tcw", "Ow"):
+            getattr(kp, name)[:] = np.asarray(pose[name], np.float32).ravel().tolist()
+        for name in ("fx", "fy", "cx", "cy", "bf", "log_scale_factor"):
+            setattr(kp, name, float(pose[name]))
+        isg = np.ascontiguousarray(pose["inv_sigma2"], np.float32)
+        kp.inv_level_sigma2 = isg.ctypes.data
+        return kp, isg
+
+    def Fuse(self, kf, pose, pts, th, best_idx, nfused, stream=None):
+        """ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th), search half: best_idx[i] = key point of kf fused with map point i"""
+        kp, keep = self.kf_pose(pose)
+        pv = self.points3d_view(pts)
+        L.check(L.lib().plf_match_fuse(self._h, C.byref(kf), C.byref(kp), C.byref(pv), C.c_float(th), L.vp(best_idx), L.vp(nfused),
+                                       C.c_void_p(stream) if stream else None), "plf_match_fuse")
+
     def knnMatch(self, query, train):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
         nq, nt = int(query.shape[0]), int(train.shape[0])

@@ -327,3 +327,25 @@ def test_gpu_equals_reference_search_by_projection_reloc_fixture():
         assert np.array_equal(match.cpu().numpy(), c["match"])
         m.close()
 
+
+
+def test_gpu_equals_reference_fuse_fixture():
+    """HIP search half of ORBmatcher::Fuse(KeyFrame*, map points, th) vs tests/golden/ref_glue_fuse.json (the reference binary's own run)."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_fuse_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_fuse.json")):
+        N = len(c["kps"]); p = c["pts"]
+        m = Matcher(max_keypoints=1024, max_mappoints=1024)
+        dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"]); du = _dev(c["uright"])
+        kf = Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), du)
+        dp = dict(world_pos=_dev(p["xw"]), normal=_dev(p["normal"]), min_dist=_dev(p["min_dist"]), max_dist=_dev(p["max_dist"]), desc=_dev(p["desc"]),
+                  valid=_dev(p["valid"]))
+        best = torch.full((len(p["valid"]),), -7, dtype=torch.int32, device="cuda"); nf = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.Fuse(kf, c["pose"], dp, c["th"], best, nf)
+        torch.cuda.synchronize()
+        assert int(nf[0]) == c["nfused"]
+        assert np.array_equal(best.cpu().numpy(), c["best_idx"])
+        m.close()
