@@ -579,6 +579,115 @@ int orc_fuse(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, f
     return nFused;
 }
 
+/* Decomposition of a Sim3 matrix at the top of Fuse(KeyFrame*, Scw, ...) (so@0x7bb20) and SearchByProjection(KeyFrame*, Scw, ...) (so@0x880f0):
+ *   sRcw = Scw.rowRange(0,3).colRange(0,3); scw = float(sqrt(sRcw.row(0).dot(sRcw.row(0))))   (Mat::dot accumulates in double; so@0x7bda0-0x7bdc2)
+ *   Rcw = sRcw / scw; tcw = Scw.rowRange(0,3).col(3) / scw     cv::operator/(Mat, double) = a scale expression with alpha = 1.0 / double(scw), assigned by
+ *                                                              Mat::convertTo: OpenCV 3.3 cvtScale32f works in float, d = s * float(alpha) (+ 0)
+ *   Ow = -Rcw.t() * tcw                                        cv::gemm transposed path: float(double-sum * -1)
+ * OpenCV 3.3.0 (the reference's pinned dependency) is not in the image: this follows its published convert.cpp / matmul.cpp. */
+void orc_sim3_decompose(const float *Scw /*4x4 row-major*/, float *Rcw, float *tcw, float *Ow)
+{
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
+    const float scw = (float)sqrt(dot);
+    const float alpha = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Scw[r * 4 + c] * alpha;
+        tcw[r] = Scw[r * 4 + 3] * alpha;
+    }
+    for (int i = 0; i < 3; i++)
+        Ow[i] = (float)(((double)Rcw[0 * 3 + i] * tcw[0] + (double)Rcw[1 * 3 + i] * tcw[1] + (double)Rcw[2 * 3 + i] * tcw[2]) * -1.0);
+}
+
+/* shared gates of the two Scw overloads: camera point, image test, invariance range, viewing angle, predicted level.
+ * u = fmaf(x, fx, cx), v = fmaf(y, fy, cy) (so@0x7caac / 0x7cabe, so@0x8914e / 0x89160). */
+static int sim3_gates(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, int i, float *u, float *v, int *lvl)
+{
+    const float *xw = P->xw + 3 * (size_t)i;
+    const float X = C->Rcw[0] * xw[0] + C->Rcw[1] * xw[1] + C->Rcw[2] * xw[2] + C->tcw[0];
+    const float Y = C->Rcw[3] * xw[0] + C->Rcw[4] * xw[1] + C->Rcw[5] * xw[2] + C->tcw[1];
+    const float Z = C->Rcw[6] * xw[0] + C->Rcw[7] * xw[1] + C->Rcw[8] * xw[2] + C->tcw[2];
+    if (Z < 0.0f) return 0;
+    const float invz = 1.0f / Z;
+    const float x = X * invz, y = Y * invz;
+    *u = fmaf(x, C->fx, C->cx); *v = fmaf(y, C->fy, C->cy);
+    if (!(*u >= KF->minx && *u < KF->maxx && *v >= KF->miny && *v < KF->maxy)) return 0;
+    const float PO[3] = {xw[0] - C->Ow[0], xw[1] - C->Ow[1], xw[2] - C->Ow[2]};
+    double s2 = 0;
+    for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
+    const float dist3D = (float)sqrt(s2);
+    const float maxDistance = 1.2f * P->max_dist[i], minDistance = 0.8f * P->min_dist[i];
+    if (dist3D < minDistance || dist3D > maxDistance) return 0;
+    const float *Pn = P->normal + 3 * (size_t)i;
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
+    if (dot < 0.5 * (double)dist3D) return 0;
+    *lvl = predict_scale(P->max_dist[i], dist3D, C->log_scale_factor, KF->nlevels);
+    return 1;
+}
+
+/* ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint)
+ * include/ORBmatcher.h:122, so@0x7bb20 (loop closing).  C holds Rcw / tcw / Ow from orc_sim3_decompose and the keyframe intrinsics
+ * (bf and inv_level_sigma2 unread: this overload has no reprojection test).  P->valid[i] = !isBad() && !pKF->GetMapPoints().count(pMP).
+ * best_idx[i] = key point of pKF with the lowest distance among level-1 <= octave <= level, kept if <= TH_LOW.  The reference then
+ * either records vpReplacePoint[i] = pKF->GetMapPoint(best) or adds the observation: host work.  Returns nFused. */
+int orc_fuse_sim3(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, float th, int32_t *best_idx)
+{
+    int nFused = 0;
+    grid_t g; grid_build(KF, &g);
+    int *cand = (int *)malloc(sizeof(int) * (KF->n > 0 ? KF->n : 1));
+    for (int i = 0; i < P->m; i++) {
+        best_idx[i] = -1;
+        if (!P->valid[i]) continue;
+        float u, v; int lvl;
+        if (!sim3_gates(KF, C, P, i, &u, &v, &lvl)) continue;
+        const float radius = th * KF->scale_factors[lvl];
+        const int nc = features_in_area(KF, &g, u, v, radius, -1, -1, cand, KF->n);
+        const uint8_t *dMP = P->desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (KF->octave[idx] < lvl - 1 || KF->octave[idx] > lvl) continue;
+            const int dist = orc_hamming256(dMP, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    free(cand); grid_free(&g);
+    return nFused;
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th)
+ * include/ORBmatcher.h:86, so@0x880f0 (loop closing).  P->valid[i] = !isBad() && pMP not among vpMatched on entry.
+ * match_of_kp[k]: in  -1 = vpMatched[k] == NULL, -2 = occupied; out >= 0 = index of the map point stored by this call
+ * (key points taken earlier in the loop are skipped by later points: the loop is greedy in list order).  radius = float(th) *
+ * mvScaleFactors[level] (so@0x89b22).  Returns nmatches. */
+int orc_search_by_projection_sim3(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, int th, int32_t *match_of_kp)
+{
+    int nmatches = 0;
+    grid_t g; grid_build(KF, &g);
+    int *cand = (int *)malloc(sizeof(int) * (KF->n > 0 ? KF->n : 1));
+    for (int i = 0; i < P->m; i++) {
+        if (!P->valid[i]) continue;
+        float u, v; int lvl;
+        if (!sim3_gates(KF, C, P, i, &u, &v, &lvl)) continue;
+        const float radius = (float)th * KF->scale_factors[lvl];
+        const int nc = features_in_area(KF, &g, u, v, radius, -1, -1, cand, KF->n);
+        const uint8_t *dMP = P->desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (match_of_kp[idx] != -1) continue;
+            if (KF->octave[idx] < lvl - 1 || KF->octave[idx] > lvl) continue;
+            const int dist = orc_hamming256(dMP, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { match_of_kp[bestIdx] = i; nmatches++; }
+    }
+    free(cand); grid_free(&g);
+    return nmatches;
+}
+
 /* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {

@@ -107,6 +107,10 @@ MatExpr operator*(const MatExpr &e, const Mat &b);
 MatExpr operator+(const MatExpr &e, const Mat &b);
 MatExpr operator-(const MatExpr &e);
 MatExpr operator-(const Mat &a, const Mat &b);
+MatExpr operator/(const Mat &a, double s);
+MatExpr operator*(double s, const Mat &a);
+MatExpr operator*(double s, const MatExpr &e);
+MatExpr operator-(const Mat &a);
 double norm(const _InputArray &src, int normType, const _InputArray &mask);
 const _InputArray &noArray();
 void resize(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
@@ -231,9 +235,13 @@ cv::MatExpr cv::Mat::zeros(int rows, int cols, int type)
 // small-matrix float path d = float(double(t)*alpha + beta*double(c)), t = a0*b0 + a1*b1 + a2*b2 in float;
 // the transposed product goes through GEMMSingleMul<float,double>: d = float(double-sum * alpha).
 struct GemmOp : cv::MatOp { void assign(const cv::MatExpr &e, cv::Mat &m, int) const override; };
-struct TransOp : cv::MatOp { void assign(const cv::MatExpr &, cv::Mat &, int) const override { fprintf(stderr, "refprobe: bare transpose\n"); abort(); } };
+// a.t() * alpha assigned on its own (sR21 = (1.0 / s12) * R12.t()): cv::transpose, then Mat::convertTo with the scale -- cvtScale32f of
+// OpenCV 3.3 works in float: d = s * float(alpha).  a * alpha / a / s (cv::operator*(double, Mat), operator/(Mat, double), -Mat) is the same conversion.
+struct TransOp : cv::MatOp { void assign(const cv::MatExpr &e, cv::Mat &m, int) const override; };
+struct ScaleOp : cv::MatOp { void assign(const cv::MatExpr &e, cv::Mat &m, int) const override; };
 static GemmOp g_gemm_op;
 static TransOp g_trans_op;
+static ScaleOp g_scale_op;
 static float matf(const cv::Mat &m, int r, int c) { return *(const float *)(m.data + m.step_buf[0] * r + 4 * (size_t)c); }
 static void expr_init(cv::MatExpr *e, const cv::MatOp *op)
 {
@@ -260,12 +268,36 @@ void GemmOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const
     mat_alloc(&m, 3, 1, 5);
     for (int i = 0; i < 3; i++) *(float *)(m.data + m.step_buf[0] * i) = d[i];
 }
+static void mat_alloc(cv::Mat *m, int rows, int cols, int type);
+void TransOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const
+{
+    const cv::Mat &A = e.a;
+    if ((A.flags & 0xFFF) != 5 || A.rows > 4 || A.cols > 4) { fprintf(stderr, "refprobe: unexpected transpose shape\n"); abort(); }
+    float d[16];
+    const float al = (float)e.alpha;
+    for (int r = 0; r < A.cols; r++) for (int c = 0; c < A.rows; c++) d[r * A.rows + c] = e.alpha == 1.0 ? matf(A, c, r) : matf(A, c, r) * al;
+    const int R = A.cols, Cn = A.rows;
+    mat_alloc(&m, R, Cn, 5);
+    for (int r = 0; r < R; r++) for (int c = 0; c < Cn; c++) *(float *)(m.data + m.step_buf[0] * r + 4 * (size_t)c) = d[r * Cn + c];
+}
+void ScaleOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const
+{
+    const cv::Mat &A = e.a;
+    if ((A.flags & 0xFFF) != 5 || A.rows > 4 || A.cols > 4) { fprintf(stderr, "refprobe: unexpected scale shape\n"); abort(); }
+    float d[16];
+    const float al = (float)e.alpha;
+    for (int r = 0; r < A.rows; r++) for (int c = 0; c < A.cols; c++) d[r * A.cols + c] = matf(A, r, c) * al;
+    const int R = A.rows, Cn = A.cols;
+    mat_alloc(&m, R, Cn, 5);
+    for (int r = 0; r < R; r++) for (int c = 0; c < Cn; c++) *(float *)(m.data + m.step_buf[0] * r + 4 * (size_t)c) = d[r * Cn + c];
+}
 cv::MatExpr::~MatExpr() {}
 cv::MatExpr cv::Mat::t() const { MatExpr e; expr_init(&e, &g_trans_op); e.a = *this; return e; }
 cv::MatExpr cv::operator-(const MatExpr &x) { MatExpr e; expr_init(&e, x.op); e.flags = x.flags; e.a = x.a; e.b = x.b; e.c = x.c; e.alpha = -x.alpha; e.beta = -x.beta; return e; }
 cv::MatExpr cv::operator*(const Mat &a, const Mat &b) { MatExpr e; expr_init(&e, &g_gemm_op); e.a = a; e.b = b; return e; }
 cv::MatExpr cv::operator*(const MatExpr &x, const Mat &b)
 {
+    if (x.op == &g_scale_op) { MatExpr e; expr_init(&e, &g_gemm_op); e.a = x.a; e.b = b; e.alpha = x.alpha; return e; }   // (-A) * b = gemm(A, b, alpha = -1)
     if (x.op != &g_trans_op) { fprintf(stderr, "refprobe: unexpected expr * Mat\n"); abort(); }
     MatExpr e; expr_init(&e, &g_gemm_op); e.flags = 1; e.a = x.a; e.b = b; e.alpha = x.alpha; return e;
 }
@@ -284,13 +316,22 @@ void SubOp::assign(const cv::MatExpr &e, cv::Mat &m, int) const   // a - b, 3x1 
     mat_alloc(&m, 3, 1, 5);
     for (int i = 0; i < 3; i++) *(float *)(m.data + m.step_buf[0] * i) = d[i];
 }
+cv::MatExpr cv::operator/(const Mat &a, double sc) { MatExpr e; expr_init(&e, &g_scale_op); e.a = a; e.alpha = 1.0 / sc; return e; }
+cv::MatExpr cv::operator*(double sc, const Mat &a) { MatExpr e; expr_init(&e, &g_scale_op); e.a = a; e.alpha = sc; return e; }
+cv::MatExpr cv::operator-(const Mat &a) { MatExpr e; expr_init(&e, &g_scale_op); e.a = a; e.alpha = -1.0; return e; }
+cv::MatExpr cv::operator*(double sc, const MatExpr &x)
+{
+    if (x.op != &g_trans_op) { fprintf(stderr, "refprobe: unexpected double * expr\n"); abort(); }
+    MatExpr e; expr_init(&e, &g_trans_op); e.a = x.a; e.alpha = x.alpha * sc; return e;
+}
 cv::MatExpr cv::operator-(const Mat &a, const Mat &b) { MatExpr e; expr_init(&e, &g_sub_op); e.a = a; e.b = b; return e; }
 double cv::Mat::dot(const _InputArray &o) const   // CV_32F vectors: dotProd_<float> accumulates in double, element by element
 {
     const Mat *b = (const Mat *)o.obj;
-    if ((flags & 0xFFF) != 5 || cols != 1 || b->cols != 1 || b->rows != rows) { fprintf(stderr, "refprobe: unexpected dot call\n"); abort(); }
+    if ((flags & 0xFFF) != 5 || (cols != 1 && rows != 1) || b->cols != cols || b->rows != rows) { fprintf(stderr, "refprobe: unexpected dot call\n"); abort(); }
     double r = 0;
-    for (int i = 0; i < rows; i++) r += (double)matf(*this, i, 0) * (double)matf(*b, i, 0);
+    if (cols == 1) for (int i = 0; i < rows; i++) r += (double)matf(*this, i, 0) * (double)matf(*b, i, 0);
+    else for (int i = 0; i < cols; i++) r += (double)matf(*this, 0, i) * (double)matf(*b, 0, i);
     return r;
 }
 static cv::_InputArray g_no_array = {0, nullptr, 0, 0};
@@ -365,6 +406,8 @@ public:
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
     int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th);
+    int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint);
+    int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -1496,6 +1539,183 @@ int main(int argc, char **argv)
             fprintf(JK, "\"}%s\n", c + 1 < NKC ? "," : "");
         }
         fprintf(JK, "]}\n"); fclose(JK);
+    }
+    // ------------------------------------------------------------ L, M: the two Scw overloads of loop closing (glue)
+    //   L  ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float th, vector<MapPoint*>& vpReplacePoint)   so@0x7bb20
+    //   M  ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, int th)   so@0x880f0
+    // Same hand-laid KeyFrame / MapPoint objects as tier K; the Sim3 algebra (operator/, .t(), unary minus, gemm) is the restatement above.
+    for (int tierLM = 0; tierLM < 2; tierLM++) {
+        path = std::string(outdir) + (tierLM == 0 ? "/ref_glue_fuse_sim3.json" : "/ref_glue_search_sim3.json");
+        FILE *JL = fopen(path.c_str(), "w");
+        if (tierLM == 0)
+            fprintf(JL, "{\"_doc\": \"ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, vpReplacePoint) (so@0x7bb20) executed from the reference binary on "
+                        "hand-laid objects; cv::Mat algebra supplied by oracle/refprobe/probe.cpp, MapPoint::AddObservation replaced by a recorder. floats as uint32 bit "
+                        "patterns; best_idx[i] = keyframe key point chosen for map point i (-1 none)\", \"cases\": [\n");
+        else
+            fprintf(JL, "{\"_doc\": \"ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vpMatched, int th) (so@0x880f0) executed from the reference "
+                        "binary on hand-laid objects. floats as uint32 bit patterns; init[k] = -2 where vpMatched[k] was occupied on entry; match[k] = map point stored at key "
+                        "point k by the call (-1 none, -2 occupied before)\", \"cases\": [\n");
+        struct { int nk, m; float th; float s; uint64_t seed; } lc[] = {{900, 700, 4.0f, 1.07f, 10001}, {700, 900, 3.0f, 0.93f, 10002}, {1000, 600, 10.0f, 1.0f, 10003}};
+        const int NLC = 3;
+        for (int c = 0; c < NLC; c++) {
+            rng_seed(lc[c].seed + 100 * tierLM);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int NK = lc[c].nk, M = lc[c].m;
+            const float fx = 517.3f, fy = 516.5f, cx = 318.6f, cy = 255.3f, bf = 40.0f, ssc = lc[c].s;
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            const float logsf = logf(1.2f);
+            float *Sc = (float *)bump(64);
+            float Rm[9], tv[3], Owp[3];
+            {
+                const float ay = 0.06f - 0.03f * c, ax = -0.02f, cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float R[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                memcpy(Rm, R, sizeof(R)); tv[0] = 0.3f; tv[1] = -0.04f; tv[2] = -0.1f;
+                for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) Sc[r * 4 + q] = ssc * R[r * 3 + q]; Sc[r * 4 + 3] = ssc * tv[r]; }
+                Sc[12] = Sc[13] = Sc[14] = 0.f; Sc[15] = 1.f;
+            }
+            for (int i = 0; i < 3; i++) Owp[i] = -(Rm[0 * 3 + i] * tv[0] + Rm[1 * 3 + i] * tv[1] + Rm[2 * 3 + i] * tv[2]);
+            std::vector<cv::KeyPoint> kk(NK);
+            std::vector<float> kur(NK), kz(NK);
+            std::vector<uint8_t> kdesc((size_t)NK * 32);
+            for (int k = 0; k < NK; k++) {
+                kk[k].x = uf() * 640.f; kk[k].y = uf() * 480.f; kk[k].size = 31.f; kk[k].angle = uf() * 360.f; kk[k].response = 1.f; kk[k].octave = (int)rng_below(8); kk[k].class_id = -1;
+                kz[k] = 0.6f + uf() * 7.f; kur[k] = -1.f;
+                for (int b = 0; b < 32; b++) kdesc[(size_t)k * 32 + b] = (uint8_t)rng_below(256);
+            }
+            std::vector<float> wpos((size_t)M * 3), nrm((size_t)M * 3), dmin(M), dmax(M);
+            std::vector<int> bad(M), pre(M);
+            std::vector<uint8_t> mdesc((size_t)M * 32);
+            for (int i = 0; i < M; i++) {
+                const int src = (int)rng_below(NK);
+                const bool tied = uf() < 0.85f;
+                float u0 = tied ? kk[src].x + (uf() - 0.5f) * 6.f * scale[kk[src].octave] : -80.f + uf() * 800.f;
+                float v0 = tied ? kk[src].y + (uf() - 0.5f) * 6.f * scale[kk[src].octave] : -60.f + uf() * 600.f;
+                float z = tied ? kz[src] : 0.5f + uf() * 8.f;
+                if (uf() < 0.03f) z = -z;
+                const float Xc[3] = {(u0 - cx) / fx * z - tv[0], (v0 - cy) / fy * z - tv[1], z - tv[2]};
+                for (int r = 0; r < 3; r++) wpos[(size_t)i * 3 + r] = Rm[0 * 3 + r] * Xc[0] + Rm[1 * 3 + r] * Xc[1] + Rm[2 * 3 + r] * Xc[2];
+                const float dx = wpos[(size_t)i * 3] - Owp[0], dy = wpos[(size_t)i * 3 + 1] - Owp[1], dz = wpos[(size_t)i * 3 + 2] - Owp[2];
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                float nv[3] = {dx / dist + (uf() - 0.5f) * 0.6f, dy / dist + (uf() - 0.5f) * 0.6f, dz / dist + (uf() - 0.5f) * 0.6f};
+                if (uf() < 0.08f) { nv[0] = -nv[0]; nv[2] = -nv[2]; }
+                if (uf() < 0.1f) { nv[0] += 1.5f; }
+                const float nn = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+                for (int r = 0; r < 3; r++) nrm[(size_t)i * 3 + r] = nv[r] / nn;
+                const int plev = tied ? kk[src].octave : (int)rng_below(8);
+                dmax[i] = dist * powf(1.2f, (float)plev + (uf() < 0.5f ? 0.f : 1.f) - 0.5f + (uf() - 0.5f) * 0.9f);
+                dmin[i] = dmax[i] / powf(1.2f, 7.f);
+                if (uf() < 0.05f) { dmax[i] = dist * 0.6f; dmin[i] = dmax[i] / 4.f; }
+                bad[i] = uf() < 0.04f; pre[i] = uf() < 0.05f;   // pre: the point already sits in the keyframe (L) / in vpMatched (M)
+                for (int b = 0; b < 32; b++) mdesc[(size_t)i * 32 + b] = tied ? kdesc[(size_t)src * 32 + b] : (uint8_t)rng_below(256);
+                const int flips = (int)rng_below(80);
+                for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); mdesc[(size_t)i * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+            }
+            char *kf = (char *)bump(0x800); memset(kf, 0, 0x800);
+            const size_t MPS = 0x300;
+            char *mps = (char *)bump((size_t)(M + NK) * MPS); memset(mps, 0, (size_t)(M + NK) * MPS);
+            char *occ = mps + (size_t)M * MPS;
+            std::vector<MapPoint *> list(M, nullptr);
+            std::vector<void *> kmp(NK, nullptr);
+            for (int i = 0; i < M; i++) {
+                char *o = mps + (size_t)i * MPS;
+                *(int *)(o + 0x18) = 1 + (int)rng_below(6);
+                new (o + 0x138) std::map<KeyFrame *, size_t>();
+                mat_init((cv::Mat *)(o + 0xd8), (unsigned char *)&wpos[(size_t)i * 3], 3, 1, 4);
+                ((cv::Mat *)(o + 0xd8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0xd8))->step_buf[1] = 4;
+                mat_init((cv::Mat *)(o + 0x168), (unsigned char *)&nrm[(size_t)i * 3], 3, 1, 4);
+                ((cv::Mat *)(o + 0x168))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0x168))->step_buf[1] = 4;
+                mat_init((cv::Mat *)(o + 0x1c8), &mdesc[(size_t)i * 32], 1, 32, 32); ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
+                *(bool *)(o + 0x238) = bad[i] != 0; *(float *)(o + 0x248) = dmin[i]; *(float *)(o + 0x24c) = dmax[i];
+                list[i] = (MapPoint *)o;
+            }
+            // key points already holding a map point: an occupant object (25 %), or one of the listed points flagged `pre`
+            std::vector<int> init(NK, -1);
+            for (int k = 0; k < NK; k++) {
+                char *o = occ + (size_t)k * MPS;
+                *(int *)(o + 0x18) = 1 + (int)rng_below(6);
+                new (o + 0x138) std::map<KeyFrame *, size_t>();
+                if (uf() < 0.25f) { kmp[k] = o; init[k] = -2; }
+            }
+            for (int i = 0; i < M; i++) if (pre[i]) { const int k = (int)rng_below(NK); if (kmp[k] == nullptr && !bad[i]) {   // (a bad holder would make the choice unobservable)
+                kmp[k] = mps + (size_t)i * MPS; init[k] = -2; } else pre[i] = 0; }
+            *(int *)(kf + 0x18) = 64; *(int *)(kf + 0x1c) = 48; *(float *)(kf + 0x20) = 64.f / 640.f; *(float *)(kf + 0x24) = 48.f / 480.f;
+            *(float *)(kf + 0x130) = fx; *(float *)(kf + 0x134) = fy; *(float *)(kf + 0x138) = cx; *(float *)(kf + 0x13c) = cy; *(float *)(kf + 0x148) = bf;
+            *(int *)(kf + 0x154) = NK;
+            void **v;
+            v = (void **)(kf + 0x170); v[0] = kk.data(); v[1] = kk.data() + NK; v[2] = v[1];
+            v = (void **)(kf + 0x188); v[0] = kur.data(); v[1] = kur.data() + NK; v[2] = v[1];
+            mat_init((cv::Mat *)(kf + 0x1b8), kdesc.data(), NK, 32, 32); ((cv::Mat *)(kf + 0x1b8))->flags |= 0x4000;
+            *(int *)(kf + 0x2d8) = 8; *(float *)(kf + 0x2e0) = logsf;
+            v = (void **)(kf + 0x2e8); v[0] = scale; v[1] = scale + 8; v[2] = v[1];
+            v = (void **)(kf + 0x318); v[0] = is2; v[1] = is2 + 8; v[2] = v[1];
+            *(int *)(kf + 0x330) = 0; *(int *)(kf + 0x334) = 0; *(int *)(kf + 0x338) = 640; *(int *)(kf + 0x33c) = 480;
+            v = (void **)(kf + 0x520); v[0] = kmp.data(); v[1] = kmp.data() + NK; v[2] = v[1];
+            std::vector<std::vector<std::vector<size_t>>> G(64, std::vector<std::vector<size_t>>(48));
+            for (int k = 0; k < NK; k++) {
+                const int gx = (int)roundf(kk[k].x * (64.f / 640.f)), gy = (int)roundf(kk[k].y * (48.f / 480.f));
+                if (gx < 0 || gx >= 64 || gy < 0 || gy >= 48) continue;
+                G[gx][gy].push_back((size_t)k);
+            }
+            memcpy(kf + 0x548, (void *)&G, sizeof(G));
+            cv::Mat Scw;
+            mat_init(&Scw, (unsigned char *)Sc, 4, 4, 16);
+            Scw.flags = 0x42FF0000 | 0x4000 | 5; Scw.step_buf[1] = 4;
+            ORBmatcher *mt = new ORBmatcher(0.75f, true);
+            auto mp_index = [&](void *q) { return (int)(((char *)q - mps) / MPS); };
+            std::vector<int> valid(M), out;
+            int ret = 0;
+            if (tierLM == 0) {
+                g_fuse_events.clear();
+                std::vector<MapPoint *> repl(M, nullptr);
+                ret = mt->Fuse((KeyFrame *)kf, Scw, list, lc[c].th, repl);
+                std::vector<int> best(M, -1);
+                for (const FuseEvent &e : g_fuse_events) {
+                    if (e.kind != 0) { fprintf(stderr, "refprobe: unexpected Replace in Fuse(Scw)\n"); abort(); }
+                    best[mp_index(e.a)] = (int)e.idx;
+                }
+                // a replace candidate names the holder of the chosen key point: an occupant (its own index), a `pre` point or a point added earlier in this call
+                std::vector<int> kp_of_pre(M, -1);
+                for (int k = 0; k < NK; k++) if (kmp[k] && mp_index(kmp[k]) < M && init[k] == -2) kp_of_pre[mp_index(kmp[k])] = k;
+                for (int i = 0; i < M; i++) if (repl[i]) {
+                    const int q = mp_index(repl[i]);
+                    const int k = q >= M ? q - M : (kp_of_pre[q] >= 0 ? kp_of_pre[q] : best[q]);
+                    if (k < 0 || best[i] >= 0) { fprintf(stderr, "refprobe: cannot decode vpReplacePoint\n"); abort(); }
+                    best[i] = k;
+                }
+                int cnt = 0;
+                for (int i = 0; i < M; i++) { valid[i] = !bad[i] && !pre[i]; cnt += best[i] >= 0; }
+                if (cnt != ret) { fprintf(stderr, "refprobe: Fuse(Scw): %d decoded, %d returned\n", cnt, ret); abort(); }
+                out = best;
+            } else {
+                std::vector<MapPoint *> matched(NK, nullptr);
+                for (int k = 0; k < NK; k++) matched[k] = (MapPoint *)kmp[k];
+                ret = mt->SearchByProjection((KeyFrame *)kf, Scw, list, matched, (int)lc[c].th);
+                out.assign(NK, -1);
+                int cnt = 0;
+                for (int k = 0; k < NK; k++) {
+                    if (init[k] == -2) { out[k] = -2; if ((void *)matched[k] != kmp[k]) { fprintf(stderr, "refprobe: occupied slot overwritten\n"); abort(); } continue; }
+                    if (matched[k]) { out[k] = mp_index(matched[k]); cnt++; }
+                }
+                if (cnt != ret) { fprintf(stderr, "refprobe: SearchByProjection(Scw): %d decoded, %d returned\n", cnt, ret); abort(); }
+                for (int i = 0; i < M; i++) valid[i] = !bad[i] && !pre[i];
+            }
+            std::vector<float> kx(NK), ky(NK), Scv(Sc, Sc + 16), scv(scale, scale + 8), cam = {fx, fy, cx, cy, bf, logsf, lc[c].th};
+            std::vector<int> ko(NK);
+            for (int k = 0; k < NK; k++) { kx[k] = kk[k].x; ky[k] = kk[k].y; ko[k] = kk[k].octave; }
+            fprintf(JL, "{\"n_kf\": %d, \"m\": %d, \"ret\": %d, ", NK, M, ret);
+            J = JL;
+            jarr_f("cam", cam); jarr_f("Scw", Scv); jarr_f("scale", scv);
+            jarr_f("x", kx); jarr_f("y", ky); jarr_i("octave", ko); jarr_i("init", init);
+            jarr_f("world_pos", wpos); jarr_f("normal", nrm); jarr_f("min_dist", dmin); jarr_f("max_dist", dmax); jarr_i("valid", valid);
+            jarr_i("out", out);
+            fprintf(JL, "\"desc\": \"");
+            for (size_t b = 0; b < kdesc.size(); b++) fprintf(JL, "%02x", kdesc[b]);
+            fprintf(JL, "\", \"mp_desc\": \"");
+            for (size_t b = 0; b < mdesc.size(); b++) fprintf(JL, "%02x", mdesc[b]);
+            fprintf(JL, "\"}%s\n", c + 1 < NLC ? "," : "");
+        }
+        fprintf(JL, "]}\n"); fclose(JL);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

@@ -353,3 +353,39 @@ def fuse(kps, desc, uright, scale, bounds, pose, pts, th):
     L.orc_fuse.restype = C.c_int
     n = L.orc_fuse(C.byref(F), C.byref(Cp), C.byref(P), C.c_float(th), p(best), p(bd))
     return best, bd, n
+
+
+def sim3_decompose(Scw):
+    L = lib()
+    S = np.ascontiguousarray(Scw, np.float32)
+    R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); Ow = np.zeros(3, np.float32)
+    L.orc_sim3_decompose(p(S), p(R), p(t), p(Ow))
+    return R.reshape(3, 3), t, Ow
+
+
+def _sim3_pose(Scw, intr, nlevels):
+    R, t, Ow = sim3_decompose(Scw)
+    pose = dict(Rcw=R, tcw=t, Ow=Ow, inv_sigma2=np.ones(nlevels, np.float32), **intr)
+    return _kf_pose(pose)
+
+
+def fuse_sim3(kps, desc, scale, bounds, Scw, intr, pts, th):
+    """ORBmatcher::Fuse(KeyFrame*, Scw, points, th, vpReplacePoint): (best_idx, nFused)"""
+    L = lib()
+    F, keep = _frame(kps, desc, None, scale, bounds)
+    P, keep2 = _points3d(pts)
+    Cp, keep3 = _sim3_pose(Scw, intr, len(scale))
+    best = np.zeros(P.m, np.int32)
+    n = L.orc_fuse_sim3(C.byref(F), C.byref(Cp), C.byref(P), C.c_float(th), p(best))
+    return best, n
+
+
+def search_by_projection_sim3(kps, desc, scale, bounds, Scw, intr, pts, th, match_init):
+    """ORBmatcher::SearchByProjection(KeyFrame*, Scw, points, vpMatched, th): (match_of_kp, nmatches)"""
+    L = lib()
+    F, keep = _frame(kps, desc, None, scale, bounds)
+    P, keep2 = _points3d(pts)
+    Cp, keep3 = _sim3_pose(Scw, intr, len(scale))
+    match = np.ascontiguousarray(match_init, np.int32).copy()
+    n = L.orc_search_by_projection_sim3(C.byref(F), C.byref(Cp), C.byref(P), C.c_int(int(th)), p(match))
+    return match, n

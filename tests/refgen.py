@@ -186,6 +186,27 @@ def load_fuse_cases(path):
     return out
 
 
+def load_sim3_kf_cases(path):
+    """fixtures of the two Scw overloads (ref_glue_fuse_sim3.json / ref_glue_search_sim3.json)"""
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = []
+    for c in json.load(open(path))["cases"]:
+        NK, M = c["n_kf"], c["m"]
+        kps = np.zeros(NK, dtype=kp_dtype)
+        kps["x"] = f32(c["x"]); kps["y"] = f32(c["y"]); kps["octave"] = np.array(c["octave"], np.int32)
+        cam = f32(c["cam"])
+        intr = dict(fx=float(cam[0]), fy=float(cam[1]), cx=float(cam[2]), cy=float(cam[3]), bf=float(cam[4]), log_scale_factor=float(cam[5]))
+        pts = dict(xw=f32(c["world_pos"]).reshape(M, 3).copy(), normal=f32(c["normal"]).reshape(M, 3).copy(), min_dist=f32(c["min_dist"]),
+                   max_dist=f32(c["max_dist"]), valid=np.array(c["valid"], np.uint8),
+                   desc=np.frombuffer(bytes.fromhex(c["mp_desc"]), np.uint8).reshape(M, 32).copy())
+        out.append(dict(kps=kps, desc=np.frombuffer(bytes.fromhex(c["desc"]), np.uint8).reshape(NK, 32).copy(), scale=f32(c["scale"]),
+                        Scw=f32(c["Scw"]).reshape(4, 4).copy(), intr=intr, pts=pts, th=float(cam[6]), init=np.array(c["init"], np.int32),
+                        out=np.array(c["out"], np.int32), ret=c["ret"]))
+    return out
+
+
 def load_frustum_cases(path):
     import json
     f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
