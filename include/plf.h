@@ -251,6 +251,22 @@ typedef struct {
 int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const plf_kf_pose *pose, const plf_points3d_view *pts, float th,
                    int32_t *best_idx, int32_t *nfused, void *stream);
 
+/* int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint)
+ * include/ORBmatcher.h:122 (so@0x7bb20, loop closing) -- the search half.  Scw: the 4x4 CV_32F Sim3 matrix, row-major, HOST; it is
+ * decomposed as the reference does (scale from row 0, Rcw = sRcw / s, tcw, Ow = -Rcw.t() * tcw).  intr: fx, fy, cx, cy,
+ * log_scale_factor of the keyframe (Rcw, tcw, Ow, bf, inv_level_sigma2 unread).  valid[i] = !isBad() && !pKF->GetMapPoints().count(pMP).
+ * best_idx[i]: the caller sets vpReplacePoint[i] = pKF->GetMapPoint(best_idx[i]) when that slot holds a good point, otherwise adds
+ * the observation -- in list order, as the reference loop does. */
+int plf_match_fuse_sim3(plf_matcher *h, const plf_frame_view *kf, const float *Scw, const plf_kf_pose *intr, const plf_points3d_view *pts,
+                        float th, int32_t *best_idx, int32_t *nfused, void *stream);
+
+/* int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+ * include/ORBmatcher.h:86 (so@0x880f0, loop closing).  valid[i] = !isBad() && pMP not among vpMatched on entry.
+ * match_of_kp (device, kf->n int32), in/out: -1 = vpMatched[k] == NULL, -2 = occupied; on return >= 0 = index of the map point the call
+ * stored there (greedy in list order, exactly the reference loop).  nmatches (device int32) = the return value. */
+int plf_match_project_sim3(plf_matcher *h, const plf_frame_view *kf, const float *Scw, const plf_kf_pose *intr, const plf_points3d_view *pts,
+                           int32_t th, int32_t *match_of_kp, int32_t *nmatches, void *stream);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
  * include/ORBmatcher.h:104 (so@0x80150) -- the tracker's reference-keyframe / relocalisation matcher.
  * One view per (keyframe, frame) pair, all arrays in DEVICE memory.  The DBoW2 feature vectors

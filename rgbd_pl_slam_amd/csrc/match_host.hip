@@ -1,6 +1,7 @@
 // match_host.hip -- host side of the matchers: scratch handle, grid construction, launch sequence, C ABI.
 // Mirrors the tracking overloads of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:44,61,78) and
 // ORB_SLAM2::LSDmatcher (include/LSDmatcher.h:32,40,43).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -40,6 +41,7 @@ __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, 
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, RelocDev, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_project_kf(FrameDev, Pts3Dev, ProjKf, float, int *, int *, int *);
+__global__ void k_project_kf_greedy(FrameDev, Pts3Dev, ProjKf, float, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
 __global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int);
@@ -109,7 +111,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     ALLOC(h->d_bow_fnode, B * (size_t)max_keypoints * sizeof(int));
     ALLOC(h->d_bow_used, B * (size_t)max_keypoints * sizeof(int));
     ALLOC(h->d_done, B * items);
-    ALLOC(h->d_proj, (size_t)max_keypoints * sizeof(float4));
+    ALLOC(h->d_proj, (size_t)(max_keypoints > max_mappoints ? max_keypoints : max_mappoints) * sizeof(float4));
     ALLOC(h->d_knn_idx, 2 * (size_t)max_lines * sizeof(int));
     ALLOC(h->d_knn_dist, 2 * (size_t)max_lines * sizeof(int));
     ALLOC(h->d_dm, 2 * (size_t)max_lines * sizeof(plf_dmatch));
@@ -338,6 +340,68 @@ extern "C" int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const pl
     PLF_HIP_TRY(hipMemsetAsync(nfused, 0, sizeof(int), s));
     if (pts->m > 0)
         hipLaunchKernelGGL(k_project_kf, dim3((pts->m + 255) / 256), dim3(256), 0, s, fd, make_points(pts), C, th, best_idx, (int *)nullptr, nfused);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+// Sim3 decomposition at the top of the two Scw overloads (so@0x7bb20, so@0x880f0): scw = float(sqrt(row0 . row0)) with a double dot product,
+// Rcw = sRcw / scw and tcw = Scw(0:3, 3) / scw through cv::operator/(Mat, double) (a scale expression assigned by Mat::convertTo, which
+// for CV_32F multiplies by float(1.0 / double(scw)) -- OpenCV 3.3 convert.cpp), Ow = -Rcw.t() * tcw through cv::gemm's transposed path.
+static void sim3_decompose(const float *Scw, float *Rcw, float *tcw, float *Ow)
+{
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
+    const float scw = (float)sqrt(dot);
+    const float alpha = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Scw[r * 4 + c] * alpha;
+        tcw[r] = Scw[r * 4 + 3] * alpha;
+    }
+    for (int i = 0; i < 3; i++) Ow[i] = (float)(((double)Rcw[i] * tcw[0] + (double)Rcw[3 + i] * tcw[1] + (double)Rcw[6 + i] * tcw[2]) * -1.0);
+}
+
+static int sim3_common(plf_matcher *h, const plf_frame_view *kf, const float *Scw, const plf_kf_pose *intr, const plf_points3d_view *pts, hipStream_t s,
+                       FrameDev *fd, ProjKf *C)
+{
+    if (!h || !kf || !Scw || !intr || !pts || pts->m < 0 || pts->m > h->max_mp || !(intr->log_scale_factor > 0.f)) return PLF_E_BADARG;
+    if (pts->m > 0 && (!pts->world_pos || !pts->normal || !pts->min_distance || !pts->max_distance || !pts->desc || !pts->valid)) return PLF_E_BADARG;
+    const int st = stage_keyframe(h, kf, s, fd);
+    if (st != PLF_OK) return st;
+    memset(C, 0, sizeof(*C));
+    sim3_decompose(Scw, C->R, C->t, C->Ow);
+    C->fx = intr->fx; C->fy = intr->fy; C->cx = intr->cx; C->cy = intr->cy; C->bf = intr->bf; C->log_scale = intr->log_scale_factor;
+    C->view_test = 1; C->chi2 = 0; C->accept = 50;   // ORBmatcher::TH_LOW
+    return PLF_OK;
+}
+
+extern "C" int plf_match_fuse_sim3(plf_matcher *h, const plf_frame_view *kf, const float *Scw, const plf_kf_pose *intr, const plf_points3d_view *pts,
+                                   float th, int32_t *best_idx, int32_t *nfused, void *stream)
+{
+    if (!h || !best_idx || !nfused) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    FrameDev fd; ProjKf C;
+    const int st = sim3_common(h, kf, Scw, intr, pts, s, &fd, &C);
+    if (st != PLF_OK) return st;
+    PLF_HIP_TRY(hipMemsetAsync(nfused, 0, sizeof(int), s));
+    if (pts->m > 0)
+        hipLaunchKernelGGL(k_project_kf, dim3((pts->m + 255) / 256), dim3(256), 0, s, fd, make_points(pts), C, th, best_idx, (int *)nullptr, nfused);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_project_sim3(plf_matcher *h, const plf_frame_view *kf, const float *Scw, const plf_kf_pose *intr, const plf_points3d_view *pts,
+                                      int32_t th, int32_t *match_of_kp, int32_t *nmatches, void *stream)
+{
+    if (!h || !match_of_kp || !nmatches) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    FrameDev fd; ProjKf C;
+    const int st = sim3_common(h, kf, Scw, intr, pts, s, &fd, &C);
+    if (st != PLF_OK) return st;
+    const int kp_cap = ((kf->n > 0 ? kf->n : 1) + 63) & ~63;
+    hipLaunchKernelGGL(k_project_kf_greedy, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, make_points(pts), C, (float)th, match_of_kp, nmatches, h->d_done,
+                       h->d_proj, kp_cap);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

@@ -550,52 +550,57 @@ struct ProjKf {
     int accept;            // TH_LOW / TH_HIGH
 };
 
+// gates of one map point: camera point, KeyFrame::IsInImage, invariance range, viewing angle; predicted level and search radius
+__device__ __forceinline__ bool project_gate(const FrameDev &F, const Pts3Dev &P, const ProjKf &C, float th, int i, float &u, float &v, float &invz,
+                                             int &lvl, float &radius)
+{
+    if (!P.valid[i]) return false;
+    const float *xw = P.xw + 3 * (size_t)i;
+    float X = C.R[0] * xw[0] + C.R[1] * xw[1] + C.R[2] * xw[2] + C.t[0];
+    float Y = C.R[3] * xw[0] + C.R[4] * xw[1] + C.R[5] * xw[2] + C.t[1];
+    float Z = C.R[6] * xw[0] + C.R[7] * xw[1] + C.R[8] * xw[2] + C.t[2];
+    if (C.two_stage) {
+        const float a = X, b = Y, c = Z;
+        X = C.R2[0] * a + C.R2[1] * b + C.R2[2] * c + C.t2[0];
+        Y = C.R2[3] * a + C.R2[4] * b + C.R2[5] * c + C.t2[1];
+        Z = C.R2[6] * a + C.R2[7] * b + C.R2[8] * c + C.t2[2];
+    }
+    if (Z < 0.0f) return false;
+    invz = 1.0f / Z;
+    const float x = X * invz, y = Y * invz;
+    // contracted in the binary (so@0x7abc8 / 0x7abf0, so@0x7caac / 0x7cabe, so@0x8914e / 0x89160, so@0x84af1 / 0x84b03)
+    u = fmaf(x, C.fx, C.cx); v = fmaf(C.fy, y, C.cy);
+    if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) return false;
+    const float PO[3] = {C.two_stage ? X : xw[0] - C.Ow[0], C.two_stage ? Y : xw[1] - C.Ow[1], C.two_stage ? Z : xw[2] - C.Ow[2]};
+    double s2 = 0;
+    for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
+    const float dist3D = (float)sqrt(s2);
+    const float maxDistance = 1.2f * P.max_dist[i], minDistance = 0.8f * P.min_dist[i];
+    if (dist3D < minDistance || dist3D > maxDistance) return false;
+    if (C.view_test) {
+        const float *Pn = P.normal + 3 * (size_t)i;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
+        if (dot < 0.5 * (double)dist3D) return false;
+    }
+    // MapPoint::PredictScale(float, KeyFrame*) so@0x8fb60 (logf of glibc: the correctly rounded value, see k_match_lastframe)
+    const float ratio = P.max_dist[i] / dist3D;
+    lvl = (int)ceilf((float)log((double)ratio) / C.log_scale);
+    if (lvl < 0) lvl = 0;
+    else if (lvl >= F.nlevels) lvl = F.nlevels - 1;
+    radius = th * F.scale_factors[lvl];
+    return true;
+}
+
 __global__ void __launch_bounds__(256) k_project_kf(FrameDev F, Pts3Dev P, ProjKf C, float th, int *__restrict__ best_idx,
                                                     int *__restrict__ best_dist, int *__restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.m) return;
     if (F.n_dev) F.n = min(F.n, *F.n_dev);
-    int bestDist = 256, bestIdx = -1;
-    bool act = P.valid[i] != 0;
-    float u = 0.f, v = 0.f, invz = 0.f, dist3D = 0.f;
-    if (act) {
-        const float *xw = P.xw + 3 * (size_t)i;
-        float X = C.R[0] * xw[0] + C.R[1] * xw[1] + C.R[2] * xw[2] + C.t[0];
-        float Y = C.R[3] * xw[0] + C.R[4] * xw[1] + C.R[5] * xw[2] + C.t[1];
-        float Z = C.R[6] * xw[0] + C.R[7] * xw[1] + C.R[8] * xw[2] + C.t[2];
-        if (C.two_stage) {
-            const float a = X, b = Y, c = Z;
-            X = C.R2[0] * a + C.R2[1] * b + C.R2[2] * c + C.t2[0];
-            Y = C.R2[3] * a + C.R2[4] * b + C.R2[5] * c + C.t2[1];
-            Z = C.R2[6] * a + C.R2[7] * b + C.R2[8] * c + C.t2[2];
-        }
-        if (Z < 0.0f) act = false;
-        invz = 1.0f / Z;
-        const float x = X * invz, y = Y * invz;
-        // contracted in the binary (so@0x7abc8 / 0x7abf0, so@0x7caac / 0x7cabe, so@0x84af1 / 0x84b03)
-        u = fmaf(x, C.fx, C.cx); v = fmaf(C.fy, y, C.cy);
-        if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) act = false;
-        const float PO[3] = {C.two_stage ? X : xw[0] - C.Ow[0], C.two_stage ? Y : xw[1] - C.Ow[1], C.two_stage ? Z : xw[2] - C.Ow[2]};
-        double s2 = 0;
-        for (int k = 0; k < 3; k++) s2 += (double)PO[k] * (double)PO[k];
-        dist3D = (float)sqrt(s2);
-        const float maxDistance = 1.2f * P.max_dist[i], minDistance = 0.8f * P.min_dist[i];
-        if (dist3D < minDistance || dist3D > maxDistance) act = false;
-        if (act && C.view_test) {
-            const float *Pn = P.normal + 3 * (size_t)i;
-            double dot = 0;
-            for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
-            if (dot < 0.5 * (double)dist3D) act = false;
-        }
-    }
-    if (act) {
-        // MapPoint::PredictScale(float, KeyFrame*) so@0x8fb60 (logf of glibc: the correctly rounded value, see k_match_lastframe)
-        const float ratio = P.max_dist[i] / dist3D;
-        int lvl = (int)ceilf((float)log((double)ratio) / C.log_scale);
-        if (lvl < 0) lvl = 0;
-        else if (lvl >= F.nlevels) lvl = F.nlevels - 1;
-        const float radius = th * F.scale_factors[lvl];
+    int bestDist = 256, bestIdx = -1, lvl = 0;
+    float u = 0.f, v = 0.f, invz = 0.f, radius = 0.f;
+    if (project_gate(F, P, C, th, i, u, v, invz, lvl, radius)) {
         const CellWin w = cell_window(F, u, v, radius);
         const uint8_t *d = P.desc + 32 * (size_t)i;
         if (w.ok) FOR_EACH_CANDIDATE(F, w, u, v, radius, -1, -1, idx, {
@@ -623,6 +628,72 @@ __global__ void __launch_bounds__(256) k_project_kf(FrameDev F, Pts3Dev P, ProjK
     best_idx[i] = hit ? bestIdx : -1;
     if (best_dist) best_dist[i] = bestDist;
     if (count && hit) atomicAdd(count, 1);
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, int th)
+// include/ORBmatcher.h:86, so@0x880f0.  Greedy in list order through vpMatched: same conflict-free rounds as k_match_lastframe.
+// One block; proj[i] = (u, v, radius, level bits).
+__global__ void __launch_bounds__(256) k_project_kf_greedy(FrameDev F, Pts3Dev P, ProjKf C, float th, int *__restrict__ match, int *__restrict__ nmatches,
+                                                           uint8_t *__restrict__ done, float4 *__restrict__ proj, int kp_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + kp_cap;
+    __shared__ int s_left, s_acc;
+    const int t = threadIdx.x, T = blockDim.x;
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    if (t == 0) s_acc = 0;
+    for (int i = t; i < P.m; i += T) {
+        float u = 0.f, v = 0.f, invz = 0.f, radius = 0.f;
+        int lvl = 0;
+        const bool act = project_gate(F, P, C, th, i, u, v, invz, lvl, radius);
+        proj[i] = make_float4(u, v, radius, __int_as_float(lvl));
+        done[i] = act ? 0 : 1;
+    }
+    __syncthreads();
+    for (int round = 0; round <= P.m; round++) {
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+        for (int i = t; i < P.m; i += T) {
+            if (done[i]) continue;
+            const float4 pr = proj[i];
+            const int lvl = __float_as_int(pr.w);
+            const CellWin w = cell_window(F, pr.x, pr.y, pr.z);
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.z, -1, -1, idx, {
+                if (_kp.octave < lvl - 1 || _kp.octave > lvl) continue;
+                if (claim[idx] == -1) atomicMin(&owner[idx], i);
+            })
+        }
+        __syncthreads();
+        for (int i = t; i < P.m; i += T) {
+            if (done[i]) continue;
+            const float4 pr = proj[i];
+            const int lvl = __float_as_int(pr.w);
+            const CellWin w = cell_window(F, pr.x, pr.y, pr.z);
+            bool safe = true;
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.z, -1, -1, idx, {
+                if (_kp.octave < lvl - 1 || _kp.octave > lvl) continue;
+                if (claim[idx] == -1 && owner[idx] != i) safe = false;
+            })
+            if (!safe) { atomicAdd(&s_left, 1); continue; }
+            int bestDist = 256, bestIdx = -1;
+            const uint8_t *d = P.desc + 32 * (size_t)i;
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.z, -1, -1, idx, {
+                if (claim[idx] != -1) continue;
+                if (_kp.octave < lvl - 1 || _kp.octave > lvl) continue;
+                const int dist = hamming_g(d, F.desc + 32 * (size_t)idx);
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            })
+            done[i] = 1;
+            if (bestIdx >= 0 && bestDist <= C.accept) { claim[bestIdx] = i; atomicAdd(&s_acc, 1); }
+        }
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) *nmatches = s_acc;
 }
 
 // ------------------------------------------------------------------------------------------------

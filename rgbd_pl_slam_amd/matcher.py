@@ -114,6 +114,27 @@ class Matcher:
         L.check(L.lib().plf_match_fuse(self._h, C.byref(kf), C.byref(kp), C.byref(pv), C.c_float(th), L.vp(best_idx), L.vp(nfused),
                                        C.c_void_p(stream) if stream else None), "plf_match_fuse")
 
+    def _intr(self, intr):
+        pose = dict(Rcw=np.eye(3, dtype=np.float32), tcw=np.zeros(3, np.float32), Ow=np.zeros(3, np.float32), inv_sigma2=np.ones(1, np.float32),
+                    bf=intr.get("bf", 0.0), **{k: intr[k] for k in ("fx", "fy", "cx", "cy", "log_scale_factor")})
+        return self.kf_pose(pose)
+
+    def FuseSim3(self, kf, Scw, intr, pts, th, best_idx, nfused, stream=None):
+        """ORBmatcher::Fuse(KeyFrame*, Scw, points, th, vpReplacePoint), search half"""
+        kp, keep = self._intr(intr)
+        S = np.ascontiguousarray(Scw, np.float32)
+        pv = self.points3d_view(pts)
+        L.check(L.lib().plf_match_fuse_sim3(self._h, C.byref(kf), L.vp(S), C.byref(kp), C.byref(pv), C.c_float(th), L.vp(best_idx), L.vp(nfused),
+                                            C.c_void_p(stream) if stream else None), "plf_match_fuse_sim3")
+
+    def SearchByProjectionSim3(self, kf, Scw, intr, pts, th, match_of_kp, nmatches, stream=None):
+        """ORBmatcher::SearchByProjection(KeyFrame*, Scw, points, vpMatched, int th)"""
+        kp, keep = self._intr(intr)
+        S = np.ascontiguousarray(Scw, np.float32)
+        pv = self.points3d_view(pts)
+        L.check(L.lib().plf_match_project_sim3(self._h, C.byref(kf), L.vp(S), C.byref(kp), C.byref(pv), int(th), L.vp(match_of_kp), L.vp(nmatches),
+                                               C.c_void_p(stream) if stream else None), "plf_match_project_sim3")
+
     def knnMatch(self, query, train):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
         nq, nt = int(query.shape[0]), int(train.shape[0])

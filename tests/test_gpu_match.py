@@ -349,3 +349,33 @@ def test_gpu_equals_reference_fuse_fixture():
         assert int(nf[0]) == c["nfused"]
         assert np.array_equal(best.cpu().numpy(), c["best_idx"])
         m.close()
+
+
+def test_gpu_equals_reference_sim3_overloads_fixtures():
+    """HIP Fuse(KeyFrame*, Scw, ...) search half and SearchByProjection(KeyFrame*, Scw, ...) vs the reference binary's own runs
+    (tests/golden/ref_glue_fuse_sim3.json, ref_glue_search_sim3.json)."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("ref_glue_fuse_sim3.json", "ref_glue_search_sim3.json"):
+        for c in refgen.load_sim3_kf_cases(os.path.join(gold, name)):
+            N = len(c["kps"]); p = c["pts"]
+            m = Matcher(max_keypoints=1024, max_mappoints=1024)
+            dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"])
+            kf = Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), None)
+            dp = dict(world_pos=_dev(p["xw"]), normal=_dev(p["normal"]), min_dist=_dev(p["min_dist"]), max_dist=_dev(p["max_dist"]), desc=_dev(p["desc"]),
+                      valid=_dev(p["valid"]))
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            if "fuse" in name:
+                out = torch.full((len(p["valid"]),), -7, dtype=torch.int32, device="cuda")
+                m.FuseSim3(kf, c["Scw"], c["intr"], dp, c["th"], out, cnt)
+            else:
+                out = _dev(c["init"])
+                m.SearchByProjectionSim3(kf, c["Scw"], c["intr"], dp, int(c["th"]), out, cnt)
+            torch.cuda.synchronize()
+            assert int(cnt[0]) == c["ret"]
+            assert np.array_equal(out.cpu().numpy(), c["out"])
+            m.close()
