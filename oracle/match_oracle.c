@@ -688,6 +688,81 @@ int orc_search_by_projection_sim3(const orc_frame *KF, const orc_kf_pose *C, con
     return nmatches;
 }
 
+/* one direction of SearchBySim3: the points of the source keyframe into the target keyframe.  cam point = R2 * (R * xw + t) + t2 (two
+ * cv::gemm small-matrix float products), skip z < 0, u = fmaf(x, fx, cx), v = fmaf(y, fy, cy) (so@0x84af1 / 0x84b03, so@0x8589f / 0x858b1),
+ * KeyFrame::IsInImage, dist3D = float(cv::norm(cam point)) within [0.8 mfMinDistance, 1.2 mfMaxDistance], PredictScale on the target,
+ * radius = th * mvScaleFactors[level], best distance among level-1 <= octave <= level, kept if <= TH_HIGH (so@0x86692 / 0x866e9: cmpl $0x64). */
+static void sim3_direction(const orc_frame *T, const orc_kf_pose *Cs /*source pose*/, const orc_kf_pose *Ct /*target: scale pyramid*/,
+                           const orc_kf_pose *Ci /*intrinsics: ALWAYS keyframe 1's, so@0x84acc / 0x8586c load fx..cy from pKF1 in both directions*/, const float *R2,
+                           const float *t2, const orc_points3d *P, float th, int32_t *vnMatch)
+{
+    grid_t g; grid_build(T, &g);
+    int *cand = (int *)malloc(sizeof(int) * (T->n > 0 ? T->n : 1));
+    for (int i = 0; i < P->m; i++) {
+        vnMatch[i] = -1;
+        if (!P->valid[i]) continue;
+        const float *xw = P->xw + 3 * (size_t)i;
+        const float a = Cs->Rcw[0] * xw[0] + Cs->Rcw[1] * xw[1] + Cs->Rcw[2] * xw[2] + Cs->tcw[0];
+        const float b = Cs->Rcw[3] * xw[0] + Cs->Rcw[4] * xw[1] + Cs->Rcw[5] * xw[2] + Cs->tcw[1];
+        const float c = Cs->Rcw[6] * xw[0] + Cs->Rcw[7] * xw[1] + Cs->Rcw[8] * xw[2] + Cs->tcw[2];
+        const float X = R2[0] * a + R2[1] * b + R2[2] * c + t2[0];
+        const float Y = R2[3] * a + R2[4] * b + R2[5] * c + t2[1];
+        const float Z = R2[6] * a + R2[7] * b + R2[8] * c + t2[2];
+        if (Z < 0.0f) continue;
+        const float invz = 1.0f / Z;
+        const float x = X * invz, y = Y * invz;
+        const float u = fmaf(x, Ci->fx, Ci->cx), v = fmaf(y, Ci->fy, Ci->cy);
+        if (!(u >= T->minx && u < T->maxx && v >= T->miny && v < T->maxy)) continue;
+        const double s2 = (double)X * (double)X + (double)Y * (double)Y + (double)Z * (double)Z;
+        const float dist3D = (float)sqrt(s2);
+        const float maxDistance = 1.2f * P->max_dist[i], minDistance = 0.8f * P->min_dist[i];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int lvl = predict_scale(P->max_dist[i], dist3D, Ct->log_scale_factor, T->nlevels);
+        const float radius = th * T->scale_factors[lvl];
+        const int nc = features_in_area(T, &g, u, v, radius, -1, -1, cand, T->n);
+        const uint8_t *dMP = P->desc + 32 * (size_t)i;
+        int bestDist = 0x7fffffff, bestIdx = -1;
+        for (int q = 0; q < nc; q++) {
+            const int idx = cand[q];
+            if (T->octave[idx] < lvl - 1 || T->octave[idx] > lvl) continue;
+            const int dist = orc_hamming256(dMP, T->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+    }
+    free(cand); grid_free(&g);
+}
+
+/* ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+ *                          const cv::Mat& t12, const float th)   include/ORBmatcher.h:116, so@0x838b0 (loop closing).
+ * sR12 = s12 * R12 and sR21 = (1.0 / s12) * R12.t() are scale expressions assigned through Mat::convertTo (float work type in OpenCV 3.3:
+ * element * float(alpha)); t21 = -sR21 * t12 is cv::gemm with alpha = -1 (small-matrix float path).  P1 / P2 = the map points of the two
+ * keyframes (one per key point, m = n): valid = pointer non-null, !vbAlreadyMatched, !isBad().  A pair is accepted when both directions
+ * agree.  match12[i1] = key point of KF2 (the caller stores vpMapPoints2[match12[i1]]), -1 otherwise.  Returns nFound. */
+int orc_search_by_sim3(const orc_frame *KF1, const orc_frame *KF2, const orc_kf_pose *C1, const orc_kf_pose *C2, float s12, const float *R12,
+                       const float *t12, float th, const orc_points3d *P1, const orc_points3d *P2, int32_t *match12)
+{
+    float sR12[9], sR21[9], t21[3];
+    const float a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { sR12[r * 3 + c] = R12[r * 3 + c] * s12; sR21[r * 3 + c] = R12[c * 3 + r] * a21; }
+    for (int r = 0; r < 3; r++) {
+        const float t = sR21[r * 3] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+        t21[r] = (float)((double)t * -1.0);
+    }
+    int32_t *vn1 = (int32_t *)malloc(sizeof(int32_t) * (P1->m > 0 ? P1->m : 1)), *vn2 = (int32_t *)malloc(sizeof(int32_t) * (P2->m > 0 ? P2->m : 1));
+    sim3_direction(KF2, C1, C2, C1, sR21, t21, P1, th, vn1);
+    sim3_direction(KF1, C2, C1, C1, sR12, t12, P2, th, vn2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < P1->m; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vn1[i1];
+        if (idx2 >= 0 && idx2 < P2->m && vn2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+    }
+    free(vn1); free(vn2);
+    return nFound;
+}
+
 /* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {

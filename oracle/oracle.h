@@ -155,6 +155,8 @@ int orc_fuse(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, f
 void orc_sim3_decompose(const float *Scw, float *Rcw, float *tcw, float *Ow);
 int orc_fuse_sim3(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, float th, int32_t *best_idx);
 int orc_search_by_projection_sim3(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, int th, int32_t *match_of_kp);
+int orc_search_by_sim3(const orc_frame *KF1, const orc_frame *KF2, const orc_kf_pose *C1, const orc_kf_pose *C2, float s12, const float *R12,
+                       const float *t12, float th, const orc_points3d *P1, const orc_points3d *P2, int32_t *match12);
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq x 2*/,
                      int32_t *dist /*nq x 2*/);
 

@@ -408,6 +408,7 @@ public:
     int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th);
     int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint);
     int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
+    int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
     void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &, int &, int &);
@@ -1716,6 +1717,151 @@ int main(int argc, char **argv)
             fprintf(JL, "\"}%s\n", c + 1 < NLC ? "," : "");
         }
         fprintf(JL, "]}\n"); fclose(JL);
+    }
+    // ------------------------------------------------------------ N: ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (so@0x838b0, glue)
+    // KeyFrame::GetMapPointMatches and MapPoint::GetIndexInKeyFrame (so@0x91cd0) run from the binary on the hand-laid objects.
+    {
+        path = std::string(outdir) + "/ref_glue_sim3.json";
+        FILE *JN = fopen(path.c_str(), "w");
+        fprintf(JN, "{\"_doc\": \"ORBmatcher::SearchBySim3 (so@0x838b0) executed from the reference binary on two hand-laid keyframes; cv::Mat algebra supplied by "
+                    "oracle/refprobe/probe.cpp. floats as uint32 bit patterns; valid1/valid2 = map point present, not bad, not matched on entry; match12[i1] = key point of "
+                    "keyframe 2 stored by the call (-1 none)\", \"cases\": [\n");
+        struct { int n; float th, s12; uint64_t seed; } nc[] = {{800, 7.5f, 1.04f, 10101}, {600, 10.0f, 0.97f, 10102}, {900, 5.0f, 1.0f, 10103}};
+        const int NNC = 3;
+        for (int c = 0; c < NNC; c++) {
+            rng_seed(nc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int N = nc[c].n;
+            const float fxy[2][4] = {{517.3f, 516.5f, 318.6f, 255.3f}, {520.9f, 521.0f, 325.1f, 249.7f}};
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            const float logsf = logf(1.2f);
+            float *T[2] = {(float *)bump(64), (float *)bump(64)};
+            for (int q = 0; q < 2; q++) {
+                const float ay = q == 0 ? 0.05f : -0.04f, ax = q == 0 ? -0.02f : 0.03f, cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float R[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) T[q][r * 4 + k] = R[r * 3 + k];
+                T[q][3] = q == 0 ? 0.1f : -0.25f; T[q][7] = q == 0 ? 0.02f : -0.03f; T[q][11] = q == 0 ? -0.05f : 0.12f;
+                T[q][12] = T[q][13] = T[q][14] = 0.f; T[q][15] = 1.f;
+            }
+            // S12: camera 2 -> camera 1, R12 = R1w R2w^T, t12 = t1w - s R12 t2w (plus the scale under test)
+            float *R12 = (float *)bump(48), *t12 = (float *)bump(16);
+            for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { float a = 0; for (int j = 0; j < 3; j++) a += T[0][r * 4 + j] * T[1][k * 4 + j]; R12[r * 3 + k] = a; }
+            for (int r = 0; r < 3; r++) t12[r] = T[0][r * 4 + 3] - nc[c].s12 * (R12[r * 3] * T[1][3] + R12[r * 3 + 1] * T[1][7] + R12[r * 3 + 2] * T[1][11]);
+            std::vector<cv::KeyPoint> kk[2] = {std::vector<cv::KeyPoint>(N), std::vector<cv::KeyPoint>(N)};
+            std::vector<uint8_t> kdesc[2] = {std::vector<uint8_t>((size_t)N * 32), std::vector<uint8_t>((size_t)N * 32)}, mdesc[2] = {kdesc[0], kdesc[0]};
+            std::vector<float> wpos[2] = {std::vector<float>((size_t)N * 3), std::vector<float>((size_t)N * 3)}, dmin[2] = {std::vector<float>(N), std::vector<float>(N)}, dmax[2] = {dmin[0], dmin[0]};
+            std::vector<int> has[2] = {std::vector<int>(N), std::vector<int>(N)}, bad[2] = {has[0], has[0]}, pre1(N, -1);
+            auto cam_of = [&](int q, const float *xw, float *xc) { for (int r = 0; r < 3; r++) xc[r] = T[q][r * 4] * xw[0] + T[q][r * 4 + 1] * xw[1] + T[q][r * 4 + 2] * xw[2] + T[q][r * 4 + 3]; };
+            for (int i = 0; i < N; i++) {
+                // a world point seen by keyframe 1 at key point i; keyframe 2 gets its re-projection at key point i as well (then shuffled by index offset)
+                const int i2 = (i * 7 + 3) % N;   // N is not a multiple of 7: a permutation
+                const float u1 = 10.f + uf() * 620.f, v1 = 10.f + uf() * 460.f, z1 = 0.8f + uf() * 6.f;
+                const float Xc1[3] = {(u1 - fxy[0][2]) / fxy[0][0] * z1 - T[0][3], (v1 - fxy[0][3]) / fxy[0][1] * z1 - T[0][7], z1 - T[0][11]};
+                float Xw[3];
+                for (int r = 0; r < 3; r++) Xw[r] = T[0][0 * 4 + r] * Xc1[0] + T[0][1 * 4 + r] * Xc1[1] + T[0][2 * 4 + r] * Xc1[2];
+                float Xc2[3]; cam_of(1, Xw, Xc2);
+                const float u2 = fxy[1][0] * Xc2[0] / Xc2[2] + fxy[1][2], v2 = fxy[1][1] * Xc2[1] / Xc2[2] + fxy[1][3];
+                const int o1 = (int)rng_below(8), o2 = std::max(0, std::min(7, o1 + (int)rng_below(3) - 1));
+                cv::KeyPoint a = {u1 + (uf() - 0.5f) * 4.f, v1 + (uf() - 0.5f) * 4.f, 31.f, uf() * 360.f, 1.f, o1, -1};
+                cv::KeyPoint b = {u2 + (uf() - 0.5f) * 4.f, v2 + (uf() - 0.5f) * 4.f, 31.f, uf() * 360.f, 1.f, o2, -1};
+                if (uf() < 0.1f) { b.x = uf() * 640.f; b.y = uf() * 480.f; }
+                kk[0][i] = a; kk[1][i2] = b;
+                for (int k = 0; k < 32; k++) { kdesc[0][(size_t)i * 32 + k] = (uint8_t)rng_below(256); kdesc[1][(size_t)i2 * 32 + k] = kdesc[0][(size_t)i * 32 + k]; }
+                for (int q = 0, nf = (int)rng_below(70); q < nf; q++) { const int bit = (int)rng_below(256); kdesc[1][(size_t)i2 * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                // the two map points (one per keyframe) sit near the world point; each carries the descriptor of its own keyframe's key point, a little noisy
+                const float d1 = sqrtf(Xc1[0] * Xc1[0] + Xc1[1] * Xc1[1] + Xc1[2] * Xc1[2] + 2 * (Xc1[0] * T[0][3] + Xc1[1] * T[0][7] + Xc1[2] * T[0][11]) + T[0][3] * T[0][3] + T[0][7] * T[0][7] + T[0][11] * T[0][11]);
+                const float d2 = sqrtf(Xc2[0] * Xc2[0] + Xc2[1] * Xc2[1] + Xc2[2] * Xc2[2]);
+                for (int q = 0; q < 2; q++) {
+                    const int idx = q == 0 ? i : i2;
+                    for (int r = 0; r < 3; r++) wpos[q][(size_t)idx * 3 + r] = Xw[r] + (uf() - 0.5f) * 0.01f;
+                    // invariance range judged from the OTHER camera (the one the point is projected into), around that key point's octave
+                    const float dd = q == 0 ? d2 : d1; const int oo = q == 0 ? o2 : o1;
+                    dmax[q][idx] = dd * powf(1.2f, (float)oo + (uf() < 0.5f ? 0.f : 1.f) - 0.5f + (uf() - 0.5f) * 0.9f);
+                    dmin[q][idx] = dmax[q][idx] / powf(1.2f, 7.f);
+                    if (uf() < 0.05f) { dmax[q][idx] = dd * 0.6f; dmin[q][idx] = dmax[q][idx] / 4.f; }
+                    has[q][idx] = uf() < 0.85f; bad[q][idx] = uf() < 0.04f;
+                    for (int k = 0; k < 32; k++) mdesc[q][(size_t)idx * 32 + k] = kdesc[q][(size_t)idx * 32 + k];
+                    for (int w = 0, nf = (int)rng_below(30); w < nf; w++) { const int bit = (int)rng_below(256); mdesc[q][(size_t)idx * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                }
+                if (uf() < 0.06f) pre1[i] = i2;   // already matched on entry (vpMatches12[i] = map point of keyframe 2 at i2)
+            }
+            const size_t MPS = 0x300;
+            char *kfs[2] = {(char *)bump(0x800), (char *)bump(0x800)};
+            char *mps[2] = {(char *)bump((size_t)N * MPS), (char *)bump((size_t)N * MPS)};
+            std::vector<void *> kmp[2] = {std::vector<void *>(N, nullptr), std::vector<void *>(N, nullptr)};
+            std::vector<std::vector<std::vector<size_t>>> G[2];
+            for (int q = 0; q < 2; q++) {
+                char *kf = kfs[q]; memset(kf, 0, 0x800); memset(mps[q], 0, (size_t)N * MPS);
+                for (int i = 0; i < N; i++) {
+                    char *o = mps[q] + (size_t)i * MPS;
+                    *(int *)(o + 0x18) = 2;
+                    new (o + 0x138) std::map<KeyFrame *, size_t>();
+                    (*(std::map<KeyFrame *, size_t> *)(o + 0x138))[(KeyFrame *)kf] = (size_t)i;
+                    mat_init((cv::Mat *)(o + 0xd8), (unsigned char *)&wpos[q][(size_t)i * 3], 3, 1, 4);
+                    ((cv::Mat *)(o + 0xd8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0xd8))->step_buf[1] = 4;
+                    mat_init((cv::Mat *)(o + 0x1c8), &mdesc[q][(size_t)i * 32], 1, 32, 32); ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
+                    *(bool *)(o + 0x238) = bad[q][i] != 0; *(float *)(o + 0x248) = dmin[q][i]; *(float *)(o + 0x24c) = dmax[q][i];
+                    if (has[q][i]) kmp[q][i] = o;
+                }
+                *(int *)(kf + 0x18) = 64; *(int *)(kf + 0x1c) = 48; *(float *)(kf + 0x20) = 64.f / 640.f; *(float *)(kf + 0x24) = 48.f / 480.f;
+                *(float *)(kf + 0x130) = fxy[q][0]; *(float *)(kf + 0x134) = fxy[q][1]; *(float *)(kf + 0x138) = fxy[q][2]; *(float *)(kf + 0x13c) = fxy[q][3]; *(float *)(kf + 0x148) = 40.f;
+                *(int *)(kf + 0x154) = N;
+                void **v;
+                v = (void **)(kf + 0x170); v[0] = kk[q].data(); v[1] = kk[q].data() + N; v[2] = v[1];
+                mat_init((cv::Mat *)(kf + 0x1b8), kdesc[q].data(), N, 32, 32); ((cv::Mat *)(kf + 0x1b8))->flags |= 0x4000;
+                *(int *)(kf + 0x2d8) = 8; *(float *)(kf + 0x2e0) = logsf;
+                v = (void **)(kf + 0x2e8); v[0] = scale; v[1] = scale + 8; v[2] = v[1];
+                v = (void **)(kf + 0x318); v[0] = is2; v[1] = is2 + 8; v[2] = v[1];
+                *(int *)(kf + 0x330) = 0; *(int *)(kf + 0x334) = 0; *(int *)(kf + 0x338) = 640; *(int *)(kf + 0x33c) = 480;
+                mat_init((cv::Mat *)(kf + 0x3a0), (unsigned char *)T[q], 4, 4, 16);
+                ((cv::Mat *)(kf + 0x3a0))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(kf + 0x3a0))->step_buf[1] = 4;
+                v = (void **)(kf + 0x520); v[0] = kmp[q].data(); v[1] = kmp[q].data() + N; v[2] = v[1];
+                G[q].assign(64, std::vector<std::vector<size_t>>(48));
+                for (int k = 0; k < N; k++) {
+                    const int gx = (int)roundf(kk[q][k].x * (64.f / 640.f)), gy = (int)roundf(kk[q][k].y * (48.f / 480.f));
+                    if (gx < 0 || gx >= 64 || gy < 0 || gy >= 48) continue;
+                    G[q][gx][gy].push_back((size_t)k);
+                }
+                memcpy(kf + 0x548, (void *)&G[q], sizeof(G[q]));
+            }
+            std::vector<MapPoint *> m12(N, nullptr);
+            std::vector<int> valid[2] = {std::vector<int>(N), std::vector<int>(N)};
+            std::vector<int> am2(N, 0);
+            for (int i = 0; i < N; i++) if (pre1[i] >= 0 && has[1][pre1[i]]) { m12[i] = (MapPoint *)(mps[1] + (size_t)pre1[i] * MPS); am2[pre1[i]] = 1; } else pre1[i] = -1;
+            for (int i = 0; i < N; i++) { valid[0][i] = has[0][i] && !bad[0][i] && pre1[i] < 0; valid[1][i] = has[1][i] && !bad[1][i] && !am2[i]; }
+            cv::Mat R12m, t12m;
+            mat_init(&R12m, (unsigned char *)R12, 3, 3, 12); R12m.flags = 0x42FF0000 | 0x4000 | 5; R12m.step_buf[1] = 4;
+            mat_init(&t12m, (unsigned char *)t12, 3, 1, 4); t12m.flags = 0x42FF0000 | 0x4000 | 5; t12m.step_buf[1] = 4;
+            ORBmatcher *mt = new ORBmatcher(0.75f, true);
+            const float s12 = nc[c].s12;
+            const int nfound = mt->SearchBySim3((KeyFrame *)kfs[0], (KeyFrame *)kfs[1], m12, s12, R12m, t12m, nc[c].th);
+            std::vector<int> match(N, -1);
+            int cnt = 0;
+            for (int i = 0; i < N; i++) if (m12[i] && pre1[i] < 0) { match[i] = (int)(((char *)m12[i] - mps[1]) / MPS); cnt++; }
+            if (cnt != nfound) { fprintf(stderr, "refprobe: SearchBySim3: %d decoded, %d returned\n", cnt, nfound); abort(); }
+            fprintf(JN, "{\"n\": %d, \"nfound\": %d, ", N, nfound);
+            J = JN;
+            std::vector<float> cam = {fxy[0][0], fxy[0][1], fxy[0][2], fxy[0][3], fxy[1][0], fxy[1][1], fxy[1][2], fxy[1][3], logsf, nc[c].th, s12};
+            jarr_f("cam", cam); jarr_f("T1w", std::vector<float>(T[0], T[0] + 16)); jarr_f("T2w", std::vector<float>(T[1], T[1] + 16));
+            jarr_f("R12", std::vector<float>(R12, R12 + 9)); jarr_f("t12", std::vector<float>(t12, t12 + 3)); jarr_f("scale", std::vector<float>(scale, scale + 8));
+            for (int q = 0; q < 2; q++) {
+                std::vector<float> kx(N), ky(N); std::vector<int> ko(N);
+                for (int k = 0; k < N; k++) { kx[k] = kk[q][k].x; ky[k] = kk[q][k].y; ko[k] = kk[q][k].octave; }
+                const std::string sfx = q == 0 ? "1" : "2";
+                jarr_f(("x" + sfx).c_str(), kx); jarr_f(("y" + sfx).c_str(), ky); jarr_i(("octave" + sfx).c_str(), ko);
+                jarr_f(("world_pos" + sfx).c_str(), wpos[q]); jarr_f(("min_dist" + sfx).c_str(), dmin[q]); jarr_f(("max_dist" + sfx).c_str(), dmax[q]);
+                jarr_i(("valid" + sfx).c_str(), valid[q]);
+                fprintf(JN, "\"desc%s\": \"", sfx.c_str());
+                for (size_t b = 0; b < kdesc[q].size(); b++) fprintf(JN, "%02x", kdesc[q][b]);
+                fprintf(JN, "\", \"mp_desc%s\": \"", sfx.c_str());
+                for (size_t b = 0; b < mdesc[q].size(); b++) fprintf(JN, "%02x", mdesc[q][b]);
+                fprintf(JN, "\", ");
+            }
+            jarr_i("match12", match, true);
+            fprintf(JN, "}%s\n", c + 1 < NNC ? "," : "");
+        }
+        fprintf(JN, "]}\n"); fclose(JN);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

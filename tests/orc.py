@@ -389,3 +389,17 @@ def search_by_projection_sim3(kps, desc, scale, bounds, Scw, intr, pts, th, matc
     match = np.ascontiguousarray(match_init, np.int32).copy()
     n = L.orc_search_by_projection_sim3(C.byref(F), C.byref(Cp), C.byref(P), C.c_int(int(th)), p(match))
     return match, n
+
+
+def search_by_sim3(c, bounds=(0.0, 0.0, 640.0, 480.0)):
+    """ORBmatcher::SearchBySim3 on a case dict of refgen.load_sim3_cases: (match12, nFound)"""
+    L = lib()
+    F1, k1 = _frame(c["kps1"], c["desc1"], None, c["scale"], bounds)
+    F2, k2 = _frame(c["kps2"], c["desc2"], None, c["scale"], bounds)
+    P1, k3 = _points3d(c["pts1"]); P2, k4 = _points3d(c["pts2"])
+    C1, k5 = _kf_pose(c["pose1"]); C2, k6 = _kf_pose(c["pose2"])
+    R12 = np.ascontiguousarray(c["R12"], np.float32); t12 = np.ascontiguousarray(c["t12"], np.float32)
+    match = np.zeros(c["n"], np.int32)
+    n = L.orc_search_by_sim3(C.byref(F1), C.byref(F2), C.byref(C1), C.byref(C2), C.c_float(c["s12"]), p(R12), p(t12), C.c_float(c["th"]),
+                             C.byref(P1), C.byref(P2), p(match))
+    return match, n

@@ -207,6 +207,30 @@ def load_sim3_kf_cases(path):
     return out
 
 
+def load_sim3_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = []
+    for c in json.load(open(path))["cases"]:
+        N = c["n"]; cam = f32(c["cam"])
+        d = dict(n=N, th=float(cam[9]), s12=float(cam[10]), R12=f32(c["R12"]).reshape(3, 3).copy(), t12=f32(c["t12"]), scale=f32(c["scale"]),
+                 match12=np.array(c["match12"], np.int32), nfound=c["nfound"])
+        for q, sfx in enumerate(("1", "2")):
+            kps = np.zeros(N, dtype=kp_dtype)
+            kps["x"] = f32(c["x" + sfx]); kps["y"] = f32(c["y" + sfx]); kps["octave"] = np.array(c["octave" + sfx], np.int32)
+            T = f32(c["T%sw" % sfx]).reshape(4, 4)
+            d["kps" + sfx] = kps
+            d["desc" + sfx] = np.frombuffer(bytes.fromhex(c["desc" + sfx]), np.uint8).reshape(N, 32).copy()
+            d["pose" + sfx] = dict(Rcw=T[:3, :3].copy(), tcw=T[:3, 3].copy(), Ow=np.zeros(3, np.float32), fx=float(cam[4 * q]), fy=float(cam[4 * q + 1]),
+                                   cx=float(cam[4 * q + 2]), cy=float(cam[4 * q + 3]), bf=40.0, log_scale_factor=float(cam[8]), inv_sigma2=np.ones(8, np.float32))
+            d["pts" + sfx] = dict(xw=f32(c["world_pos" + sfx]).reshape(N, 3).copy(), normal=np.zeros((N, 3), np.float32), min_dist=f32(c["min_dist" + sfx]),
+                                  max_dist=f32(c["max_dist" + sfx]), valid=np.array(c["valid" + sfx], np.uint8),
+                                  desc=np.frombuffer(bytes.fromhex(c["mp_desc" + sfx]), np.uint8).reshape(N, 32).copy())
+        out.append(d)
+    return out
+
+
 def load_frustum_cases(path):
     import json
     f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
