@@ -267,6 +267,16 @@ int plf_match_fuse_sim3(plf_matcher *h, const plf_frame_view *kf, const float *S
 int plf_match_project_sim3(plf_matcher *h, const plf_frame_view *kf, const float *Scw, const plf_kf_pose *intr, const plf_points3d_view *pts,
                            int32_t th, int32_t *match_of_kp, int32_t *nmatches, void *stream);
 
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
+ *                              const cv::Mat &t12, const float th)   include/ORBmatcher.h:116 (so@0x838b0, loop closing).
+ * pts1 / pts2: one entry per key point of the keyframe (m == n): GetMapPointMatches() flattened, valid = pointer non-null && !isBad() &&
+ * not matched on entry (vbAlreadyMatched1/2).  pose1 / pose2: Rcw, tcw, log_scale_factor; fx, fy, cx, cy are taken from pose1 for BOTH
+ * directions, as the reference does.  R12 (9, row-major), t12 (3): HOST.  match12 (device, kf1->n int32): key point of keyframe 2 whose
+ * map point the caller stores in vpMatches12[i1], -1 = untouched.  nfound (device int32) = the return value. */
+int plf_match_sim3(plf_matcher *h, const plf_frame_view *kf1, const plf_frame_view *kf2, const plf_kf_pose *pose1, const plf_kf_pose *pose2,
+                   float s12, const float *R12, const float *t12, float th, const plf_points3d_view *pts1, const plf_points3d_view *pts2,
+                   int32_t *match12, int32_t *nfound, void *stream);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
  * include/ORBmatcher.h:104 (so@0x80150) -- the tracker's reference-keyframe / relocalisation matcher.
  * One view per (keyframe, frame) pair, all arrays in DEVICE memory.  The DBoW2 feature vectors

@@ -41,6 +41,7 @@ __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, 
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, RelocDev, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_project_kf(FrameDev, Pts3Dev, ProjKf, float, int *, int *, int *);
+__global__ void k_sim3_agree(const int *, int, const int *, int, int *, int *);
 __global__ void k_project_kf_greedy(FrameDev, Pts3Dev, ProjKf, float, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
@@ -402,6 +403,50 @@ extern "C" int plf_match_project_sim3(plf_matcher *h, const plf_frame_view *kf, 
     const int kp_cap = ((kf->n > 0 ? kf->n : 1) + 63) & ~63;
     hipLaunchKernelGGL(k_project_kf_greedy, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, make_points(pts), C, (float)th, match_of_kp, nmatches, h->d_done,
                        h->d_proj, kp_cap);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_sim3(plf_matcher *h, const plf_frame_view *kf1, const plf_frame_view *kf2, const plf_kf_pose *pose1, const plf_kf_pose *pose2,
+                              float s12, const float *R12, const float *t12, float th, const plf_points3d_view *pts1, const plf_points3d_view *pts2,
+                              int32_t *match12, int32_t *nfound, void *stream)
+{
+    if (!h || !kf1 || !kf2 || !pose1 || !pose2 || !R12 || !t12 || !pts1 || !pts2 || !match12 || !nfound || pts1->m != kf1->n || pts2->m != kf2->n ||
+        pts1->m > h->max_mp || pts2->m > h->max_mp || !(s12 > 0.f) || !(pose1->log_scale_factor > 0.f) || !(pose2->log_scale_factor > 0.f))
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    // sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t() (scale expressions, float work type), t21 = -sR21 * t12 (gemm, alpha = -1)
+    float sR12[9], sR21[9], t21[3];
+    const float a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { sR12[r * 3 + c] = R12[r * 3 + c] * s12; sR21[r * 3 + c] = R12[c * 3 + r] * a21; }
+    for (int r = 0; r < 3; r++) {
+        const float t = sR21[r * 3] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+        t21[r] = (float)((double)t * -1.0);
+    }
+    int *vn1 = h->d_bow_fnode, *vn2 = h->d_bow_used;   // max_kp ints each
+    PLF_HIP_TRY(hipMemsetAsync(nfound, 0, sizeof(int), s));
+    for (int dir = 0; dir < 2; dir++) {
+        const plf_frame_view *target = dir == 0 ? kf2 : kf1;
+        const plf_kf_pose *src = dir == 0 ? pose1 : pose2, *tgt = dir == 0 ? pose2 : pose1;
+        const plf_points3d_view *pts = dir == 0 ? pts1 : pts2;
+        FrameDev fd;
+        const int st = stage_keyframe(h, target, s, &fd);
+        if (st != PLF_OK) return st;
+        ProjKf C;
+        memset(&C, 0, sizeof(C));
+        memcpy(C.R, src->Rcw, sizeof(C.R)); memcpy(C.t, src->tcw, sizeof(C.t));
+        memcpy(C.R2, dir == 0 ? sR21 : sR12, sizeof(C.R2)); memcpy(C.t2, dir == 0 ? t21 : t12, sizeof(C.t2));
+        // the binary loads fx, fy, cx, cy from pKF1 for BOTH directions (so@0x84acc, so@0x8586c)
+        C.fx = pose1->fx; C.fy = pose1->fy; C.cx = pose1->cx; C.cy = pose1->cy; C.log_scale = tgt->log_scale_factor;
+        C.two_stage = 1; C.view_test = 0; C.chi2 = 0; C.accept = 100;   // ORBmatcher::TH_HIGH
+        if (pts->m > 0)
+            hipLaunchKernelGGL(k_project_kf, dim3((pts->m + 255) / 256), dim3(256), 0, s, fd, make_points(pts), C, th, dir == 0 ? vn1 : vn2, (int *)nullptr,
+                               (int *)nullptr);
+    }
+    if (pts1->m > 0)
+        hipLaunchKernelGGL(k_sim3_agree, dim3((pts1->m + 255) / 256), dim3(256), 0, s, vn1, pts1->m, vn2, pts2->m, match12, nfound);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

@@ -696,6 +696,18 @@ __global__ void __launch_bounds__(256) k_project_kf_greedy(FrameDev F, Pts3Dev P
     if (t == 0) *nmatches = s_acc;
 }
 
+// SearchBySim3, last loop (so@0x838b0): a pair stands when both directions chose each other
+__global__ void __launch_bounds__(256) k_sim3_agree(const int *__restrict__ vn1, int n1, const int *__restrict__ vn2, int n2, int *__restrict__ match12,
+                                                    int *__restrict__ nfound)
+{
+    const int i1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i1 >= n1) return;
+    const int idx2 = vn1[i1];
+    const bool ok = idx2 >= 0 && idx2 < n2 && vn2[idx2] == i1;
+    match12[i1] = ok ? idx2 : -1;
+    if (ok) atomicAdd(nfound, 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)   include/ORBmatcher.h:104, so@0x80150
 // One block per (keyframe, frame) pair.  The two DBoW2 feature vectors arrive flattened (node ids ascending, CSR).

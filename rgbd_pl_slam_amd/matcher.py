@@ -135,6 +135,14 @@ class Matcher:
         L.check(L.lib().plf_match_project_sim3(self._h, C.byref(kf), L.vp(S), C.byref(kp), C.byref(pv), int(th), L.vp(match_of_kp), L.vp(nmatches),
                                                C.c_void_p(stream) if stream else None), "plf_match_project_sim3")
 
+    def SearchBySim3(self, kf1, kf2, pose1, pose2, s12, R12, t12, th, pts1, pts2, match12, nfound, stream=None):
+        """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)"""
+        p1, k1 = self.kf_pose(pose1); p2, k2 = self.kf_pose(pose2)
+        R = np.ascontiguousarray(R12, np.float32); t = np.ascontiguousarray(t12, np.float32)
+        v1 = self.points3d_view(pts1); v2 = self.points3d_view(pts2)
+        L.check(L.lib().plf_match_sim3(self._h, C.byref(kf1), C.byref(kf2), C.byref(p1), C.byref(p2), C.c_float(s12), L.vp(R), L.vp(t), C.c_float(th),
+                                       C.byref(v1), C.byref(v2), L.vp(match12), L.vp(nfound), C.c_void_p(stream) if stream else None), "plf_match_sim3")
+
     def knnMatch(self, query, train):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
         nq, nt = int(query.shape[0]), int(train.shape[0])

@@ -379,3 +379,30 @@ def test_gpu_equals_reference_sim3_overloads_fixtures():
             assert int(cnt[0]) == c["ret"]
             assert np.array_equal(out.cpu().numpy(), c["out"])
             m.close()
+
+
+def test_gpu_equals_reference_search_by_sim3_fixture():
+    """HIP SearchBySim3 vs tests/golden/ref_glue_sim3.json (the reference binary's own run on two keyframes)."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_sim3_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_sim3.json")):
+        N = c["n"]
+        m = Matcher(max_keypoints=1024, max_mappoints=1024)
+        ds = _dev(c["scale"])
+        keep = []
+        views = []; pts = []
+        for sfx in ("1", "2"):
+            dk = _kp_tensor(c["kps" + sfx]); dd = _dev(c["desc" + sfx]); keep += [dk, dd]
+            views.append(Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), None))
+            p = c["pts" + sfx]
+            pts.append(dict(world_pos=_dev(p["xw"]), normal=None, min_dist=_dev(p["min_dist"]), max_dist=_dev(p["max_dist"]), desc=_dev(p["desc"]),
+                            valid=_dev(p["valid"])))
+        match = torch.full((N,), -7, dtype=torch.int32, device="cuda"); nf = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchBySim3(views[0], views[1], c["pose1"], c["pose2"], c["s12"], c["R12"], c["t12"], c["th"], pts[0], pts[1], match, nf)
+        torch.cuda.synchronize()
+        assert int(nf[0]) == c["nfound"]
+        assert np.array_equal(match.cpu().numpy(), c["match12"])
+        m.close()
