@@ -763,6 +763,112 @@ int orc_search_by_sim3(const orc_frame *KF1, const orc_frame *KF2, const orc_kf_
     return nFound;
 }
 
+/* ---------------------------------------------------------------- SearchForTriangulation */
+/* ORBmatcher::CheckDistEpipolarLine(kp1, kp2, F12, pKF2)  include/ORBmatcher.h (protected), so@0x79b90.  The binary's contractions:
+ *   a = fmaf(x1, F00, y1*F10) + F20;  b = fmaf(x1, F01, y1*F11) + F21;  c = fmaf(y1, F12, x1*F02) + F22;
+ *   den = fmaf(a, a, b*b) (== 0 -> false);  num = c + fmaf(b, y2, a*x2);  dsqr = num*num/den;
+ *   accept when 3.84 * double(mvLevelSigma2[kp2.octave]) > double(dsqr). */
+int orc_check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float *F12 /*3x3 row-major*/, float level_sigma2)
+{
+    const float b = fmaf(x1, F12[1], y1 * F12[4]) + F12[7];
+    const float a = fmaf(x1, F12[0], y1 * F12[3]) + F12[6];
+    const float den = fmaf(a, a, b * b);
+    if (den == 0.0f) return 0;
+    const float c = fmaf(y1, F12[5], x1 * F12[2]) + F12[8];
+    const float num = c + fmaf(b, y2, a * x2);
+    const float dsqr = num * num / den;
+    return 3.84 * (double)level_sigma2 > (double)dsqr;
+}
+
+/* Epipole of keyframe 1 in keyframe 2 (so@0x86b9c-0x86f95): C2 = R2w*Cw + t2w (cv::gemm small-matrix float path), invz = 1/C2z,
+ * ex = fmaf(fx*C2x, invz, cx), ey = fmaf(fy*C2y, invz, cy). */
+void orc_epipole(const float *Cw, const float *R2w, const float *t2w, float fx, float fy, float cx, float cy, float *ex, float *ey)
+{
+    float C2[3];
+    for (int r = 0; r < 3; r++) {
+        const float t = R2w[r * 3] * Cw[0] + R2w[r * 3 + 1] * Cw[1] + R2w[r * 3 + 2] * Cw[2];
+        C2[r] = (float)((double)t + (double)t2w[r]);
+    }
+    const float invz = 1.0f / C2[2];
+    *ex = fmaf(fx * C2[0], invz, cx);
+    *ey = fmaf(fy * C2[1], invz, cy);
+}
+
+/* ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t,size_t>>& vMatchedPairs,
+ *                                    const bool bOnlyStereo)   include/ORBmatcher.h:111, so@0x86b30 (LocalMapping::CreateNewMapPoints).
+ * Walk over the common DBoW2 nodes in key order (feature vectors flattened as for orc_search_by_bow_kf).  Per keyframe-1 feature WITHOUT a
+ * map point (has_mp1 = pKF1->GetMapPoint(i) != NULL -> skipped), optionally stereo only: over the node's keyframe-2 features that are
+ * unmatched (vbMatched2 -- this binary sets it, so@0x87bc9) and hold no map point: dist <= TH_LOW and dist <= bestDist (so@0x87a01-0x87a13:
+ * a later equal distance replaces the earlier one), for two mono key points the epipole test fmaf(dx, dx, dy*dy) < 100 * mvScaleFactors2[octave]
+ * rejects (so@0x87a52-0x87a91), then CheckDistEpipolarLine.  Orientation histogram: bin = roundf(rot * (1/12)) (so@0x87c07), 30 -> 0.
+ * match12[i1] = keyframe-2 feature, -1 none (the reference emits the pairs (i1, match12[i1]) in i1 order).  Returns nmatches. */
+int orc_search_for_triangulation(int n1, int n2, const float *x1, const float *y1, const float *angle1, const float *uright1, const uint8_t *desc1,
+                                 const uint8_t *has_mp1, const float *x2, const float *y2, const float *angle2, const int32_t *octave2,
+                                 const float *uright2, const uint8_t *desc2, const uint8_t *has_mp2, int nodes1, const uint32_t *node_id1,
+                                 const int32_t *node_start1, const int32_t *feat1, int nodes2, const uint32_t *node_id2, const int32_t *node_start2,
+                                 const int32_t *feat2, const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2_2,
+                                 int bOnlyStereo, int checkOri, int32_t *match12)
+{
+    int nmatches = 0;
+    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (n1 > 0 ? n1 : 1));
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1);
+    int histN[HISTO_LENGTH];
+    memset(histN, 0, sizeof(histN));
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nodes1 && b < nodes2) {
+        if (node_id1[a] < node_id2[b]) { a++; continue; }
+        if (node_id1[a] > node_id2[b]) { b++; continue; }
+        for (int p = node_start1[a]; p < node_start1[a + 1]; p++) {
+            const int idx1 = feat1[p];
+            if (has_mp1[idx1]) continue;
+            const int bStereo1 = uright1[idx1] >= 0.0f;
+            if (bOnlyStereo && !bStereo1) continue;
+            const uint8_t *d1 = desc1 + 32 * (size_t)idx1;
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int q = node_start2[b]; q < node_start2[b + 1]; q++) {
+                const int idx2 = feat2[q];
+                if (matched2[idx2] || has_mp2[idx2]) continue;
+                const int bStereo2 = uright2[idx2] >= 0.0f;
+                if (bOnlyStereo && !bStereo2) continue;
+                const int dist = orc_hamming256(d1, desc2 + 32 * (size_t)idx2);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = ex - x2[idx2], distey = ey - y2[idx2];
+                    if (fmaf(distex, distex, distey * distey) < 100.0f * scale_factors2[octave2[idx2]]) continue;
+                }
+                if (orc_check_dist_epipolar_line(x1[idx1], y1[idx1], x2[idx2], y2[idx2], F12, level_sigma2_2[octave2[idx2]])) { bestIdx2 = idx2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                match12[idx1] = bestIdx2;
+                matched2[bestIdx2] = 1;
+                nmatches++;
+                if (checkOri) {
+                    float rot = angle1[idx1] - angle2[bestIdx2];
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * (1.0f / 12.0f));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin * n1 + histN[bin]++] = idx1;
+                }
+            }
+        }
+        a++; b++;
+    }
+    if (checkOri) {
+        int i1, i2, i3;
+        orc_three_maxima(histN, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int bnum = 0; bnum < HISTO_LENGTH; bnum++) {
+            if (bnum == i1 || bnum == i2 || bnum == i3) continue;
+            for (int j = 0; j < histN[bnum]; j++) {
+                match12[rotHist[bnum * n1 + j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    free(rotHist); free(matched2);
+    return nmatches;
+}
+
 /* ---------------------------------------------------------------- BF kNN (k=2), cv::batchDistance semantics */
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {

@@ -157,6 +157,14 @@ int orc_fuse_sim3(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d 
 int orc_search_by_projection_sim3(const orc_frame *KF, const orc_kf_pose *C, const orc_points3d *P, int th, int32_t *match_of_kp);
 int orc_search_by_sim3(const orc_frame *KF1, const orc_frame *KF2, const orc_kf_pose *C1, const orc_kf_pose *C2, float s12, const float *R12,
                        const float *t12, float th, const orc_points3d *P1, const orc_points3d *P2, int32_t *match12);
+int orc_check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float *F12, float level_sigma2);
+void orc_epipole(const float *Cw, const float *R2w, const float *t2w, float fx, float fy, float cx, float cy, float *ex, float *ey);
+int orc_search_for_triangulation(int n1, int n2, const float *x1, const float *y1, const float *angle1, const float *uright1, const uint8_t *desc1,
+                                 const uint8_t *has_mp1, const float *x2, const float *y2, const float *angle2, const int32_t *octave2,
+                                 const float *uright2, const uint8_t *desc2, const uint8_t *has_mp2, int nodes1, const uint32_t *node_id1,
+                                 const int32_t *node_start1, const int32_t *feat1, int nodes2, const uint32_t *node_id2, const int32_t *node_start2,
+                                 const int32_t *feat2, const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2_2,
+                                 int bOnlyStereo, int checkOri, int32_t *match12);
 int orc_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq x 2*/,
                      int32_t *dist /*nq x 2*/);
 

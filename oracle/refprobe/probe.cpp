@@ -408,6 +408,7 @@ public:
     int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th);
     int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint);
     int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo);
     int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th);
     static int DescriptorDistance(const cv::Mat &, const cv::Mat &);
     float RadiusByViewingCos(const float &);
@@ -1862,6 +1863,138 @@ int main(int argc, char **argv)
             fprintf(JN, "}%s\n", c + 1 < NNC ? "," : "");
         }
         fprintf(JN, "]}\n"); fclose(JN);
+    }
+    // ------------------------------------------------------------ O: ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (so@0x86b30, glue)
+    // KeyFrame mvLevelSigma2 @0x300 (CheckDistEpipolarLine so@0x79b90); KeyFrame::GetMapPoint / GetCameraCenter / GetRotation / GetTranslation run from the binary.
+    {
+        path = std::string(outdir) + "/ref_glue_triangulation.json";
+        FILE *JO = fopen(path.c_str(), "w");
+        fprintf(JO, "{\"_doc\": \"ORBmatcher::SearchForTriangulation (so@0x86b30) executed from the reference binary on two hand-laid keyframes. floats as uint32 bit "
+                    "patterns; has_mp = GetMapPoint(i) != NULL (such features are skipped); match12[i1] = keyframe-2 feature paired with keyframe-1 feature i1, -1 none\", "
+                    "\"cases\": [\n");
+        struct { int n, nodes, only_stereo, check; float tz; uint64_t seed; } oc[] = {{710, 120, 0, 1, 0.02f, 10201}, {600, 90, 0, 1, 0.45f, 10202}, {650, 100, 1, 0, 0.1f, 10203}};
+        const int NOC = 3;
+        typedef std::map<unsigned, std::vector<unsigned>> FeatVec;
+        for (int c = 0; c < NOC; c++) {
+            rng_seed(oc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int N = oc[c].n, NN = oc[c].nodes;
+            const float fx = 517.3f, fy = 516.5f, cx = 318.6f, cy = 255.3f, bf = 40.f;
+            float scale[16], inv[16], s2[16], is2[16]; int per[16], um[16];
+            orc_orb_tables(1000, 1.2f, 8, scale, inv, s2, is2, per, um);
+            float *T[2] = {(float *)bump(64), (float *)bump(64)}, *Ow1 = (float *)bump(16);
+            for (int q = 0; q < 2; q++) {
+                const float ay = q == 0 ? 0.02f : -0.03f, ax = q == 0 ? -0.01f : 0.02f, cyw = cosf(ay), syw = sinf(ay), cxw = cosf(ax), sxw = sinf(ax);
+                const float R[9] = {cyw, syw * sxw, syw * cxw, 0.f, cxw, -sxw, -syw, cyw * sxw, cyw * cxw};
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) T[q][r * 4 + k] = R[r * 3 + k];
+                T[q][3] = q == 0 ? 0.0f : -0.12f; T[q][7] = q == 0 ? 0.0f : 0.03f; T[q][11] = q == 0 ? 0.0f : oc[c].tz;
+                T[q][12] = T[q][13] = T[q][14] = 0.f; T[q][15] = 1.f;
+            }
+            for (int i = 0; i < 3; i++) Ow1[i] = -(T[0][0 * 4 + i] * T[0][3] + T[0][1 * 4 + i] * T[0][7] + T[0][2 * 4 + i] * T[0][11]);
+            // F12 = K1^-T [t12]x R12 K2^-1 (LocalMapping::ComputeF12), same intrinsics for both keyframes
+            float *F12 = (float *)bump(48);
+            {
+                double R12[9], t12[3];
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { double a = 0; for (int j = 0; j < 3; j++) a += (double)T[0][r * 4 + j] * T[1][k * 4 + j]; R12[r * 3 + k] = a; }
+                for (int r = 0; r < 3; r++) t12[r] = T[0][r * 4 + 3] - (R12[r * 3] * T[1][3] + R12[r * 3 + 1] * T[1][7] + R12[r * 3 + 2] * T[1][11]);
+                const double tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+                double E[9];
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { double a = 0; for (int j = 0; j < 3; j++) a += tx[r * 3 + j] * R12[j * 3 + k]; E[r * 3 + k] = a; }
+                const double Ki[9] = {1.0 / fx, 0, -cx / (double)fx, 0, 1.0 / fy, -cy / (double)fy, 0, 0, 1};
+                double M[9];
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { double a = 0; for (int j = 0; j < 3; j++) a += Ki[j * 3 + r] * E[j * 3 + k]; M[r * 3 + k] = a; }   // K^-T E
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { double a = 0; for (int j = 0; j < 3; j++) a += M[r * 3 + j] * Ki[j * 3 + k]; F12[r * 3 + k] = (float)a; }
+            }
+            std::vector<cv::KeyPoint> kk[2] = {std::vector<cv::KeyPoint>(N), std::vector<cv::KeyPoint>(N)};
+            std::vector<uint8_t> kdesc[2] = {std::vector<uint8_t>((size_t)N * 32), std::vector<uint8_t>((size_t)N * 32)};
+            std::vector<float> ur[2] = {std::vector<float>(N), std::vector<float>(N)};
+            std::vector<int> has[2] = {std::vector<int>(N), std::vector<int>(N)};
+            std::vector<unsigned> nd[2] = {std::vector<unsigned>(N), std::vector<unsigned>(N)};
+            for (int i = 0; i < N; i++) {
+                const int i2 = (i * 7 + 5) % N;
+                const float u1 = 10.f + uf() * 620.f, v1 = 10.f + uf() * 460.f, z1 = 0.8f + uf() * 6.f;
+                const float Xc1[3] = {(u1 - cx) / fx * z1 - T[0][3], (v1 - cy) / fy * z1 - T[0][7], z1 - T[0][11]};
+                float Xw[3], Xc2[3];
+                for (int r = 0; r < 3; r++) Xw[r] = T[0][0 * 4 + r] * Xc1[0] + T[0][1 * 4 + r] * Xc1[1] + T[0][2 * 4 + r] * Xc1[2];
+                for (int r = 0; r < 3; r++) Xc2[r] = T[1][r * 4] * Xw[0] + T[1][r * 4 + 1] * Xw[1] + T[1][r * 4 + 2] * Xw[2] + T[1][r * 4 + 3];
+                const float u2 = fx * Xc2[0] / Xc2[2] + cx, v2 = fy * Xc2[1] / Xc2[2] + cy;
+                const int o1 = (int)rng_below(8), o2 = std::max(0, std::min(7, o1 + (int)rng_below(3) - 1));
+                const float noise = uf() < 0.8f ? 1.5f : 12.f;   // some pairs violate the epipolar constraint
+                cv::KeyPoint a = {u1, v1, 31.f, uf() * 360.f, 1.f, o1, -1};
+                float ang2 = a.angle - (uf() < 0.8f ? 20.f + uf() * 8.f : uf() * 360.f);
+                if (ang2 < 0.f) ang2 += 360.f;
+                cv::KeyPoint b = {u2 + (uf() - 0.5f) * noise * scale[o2], v2 + (uf() - 0.5f) * noise * scale[o2], 31.f, ang2, 1.f, o2, -1};
+                kk[0][i] = a; kk[1][i2] = b;
+                ur[0][i] = uf() < 0.5f ? u1 - bf / z1 : -1.f; ur[1][i2] = uf() < 0.5f ? b.x - bf / Xc2[2] : -1.f;
+                has[0][i] = uf() < 0.35f; has[1][i2] = uf() < 0.35f;
+                for (int k = 0; k < 32; k++) { kdesc[0][(size_t)i * 32 + k] = (uint8_t)rng_below(256); kdesc[1][(size_t)i2 * 32 + k] = kdesc[0][(size_t)i * 32 + k]; }
+                for (int q = 0, nf = (int)rng_below(64); q < nf; q++) { const int bit = (int)rng_below(256); kdesc[1][(size_t)i2 * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                nd[0][i] = 700u + 2u * rng_below((uint32_t)NN);
+                nd[1][i2] = uf() < 0.9f ? nd[0][i] : 700u + 2u * rng_below((uint32_t)NN) + (uf() < 0.3f ? 1u : 0u);
+            }
+            // a second look-alike of some keyframe-1 features inside the same node (ties / equal distances)
+            for (int t = 0; t < N / 10; t++) {
+                const int src = (int)rng_below(N), dst = (int)rng_below(N);
+                if (src == dst) continue;
+                kk[1][dst].x = kk[1][src].x + (uf() - 0.5f); kk[1][dst].y = kk[1][src].y + (uf() - 0.5f); kk[1][dst].octave = kk[1][src].octave;
+                memcpy(&kdesc[1][(size_t)dst * 32], &kdesc[1][(size_t)src * 32], 32); nd[1][dst] = nd[1][src]; ur[1][dst] = ur[1][src]; has[1][dst] = has[1][src];
+            }
+            char *kfs[2] = {(char *)bump(0x800), (char *)bump(0x800)};
+            char *mpb = (char *)bump(0x300); memset(mpb, 0, 0x300);
+            std::vector<void *> kmp[2] = {std::vector<void *>(N, nullptr), std::vector<void *>(N, nullptr)};
+            FeatVec *fv[2];
+            for (int q = 0; q < 2; q++) {
+                char *kf = kfs[q]; memset(kf, 0, 0x800);
+                for (int i = 0; i < N; i++) if (has[q][i]) kmp[q][i] = mpb;
+                *(float *)(kf + 0x130) = fx; *(float *)(kf + 0x134) = fy; *(float *)(kf + 0x138) = cx; *(float *)(kf + 0x13c) = cy; *(float *)(kf + 0x148) = bf;
+                *(int *)(kf + 0x154) = N;
+                void **v;
+                v = (void **)(kf + 0x170); v[0] = kk[q].data(); v[1] = kk[q].data() + N; v[2] = v[1];
+                v = (void **)(kf + 0x188); v[0] = ur[q].data(); v[1] = ur[q].data() + N; v[2] = v[1];
+                mat_init((cv::Mat *)(kf + 0x1b8), kdesc[q].data(), N, 32, 32); ((cv::Mat *)(kf + 0x1b8))->flags |= 0x4000;
+                fv[q] = new (kf + 0x248) FeatVec();
+                for (int i = 0; i < N; i++) (*fv[q])[nd[q][i]].push_back((unsigned)i);
+                *(int *)(kf + 0x2d8) = 8;
+                v = (void **)(kf + 0x2e8); v[0] = scale; v[1] = scale + 8; v[2] = v[1];
+                v = (void **)(kf + 0x300); v[0] = s2; v[1] = s2 + 8; v[2] = v[1];
+                mat_init((cv::Mat *)(kf + 0x3a0), (unsigned char *)T[q], 4, 4, 16);
+                ((cv::Mat *)(kf + 0x3a0))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(kf + 0x3a0))->step_buf[1] = 4;
+                if (q == 0) { mat_init((cv::Mat *)(kf + 0x460), (unsigned char *)Ow1, 3, 1, 4); ((cv::Mat *)(kf + 0x460))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(kf + 0x460))->step_buf[1] = 4; }
+                v = (void **)(kf + 0x520); v[0] = kmp[q].data(); v[1] = kmp[q].data() + N; v[2] = v[1];
+            }
+            cv::Mat Fm;
+            mat_init(&Fm, (unsigned char *)F12, 3, 3, 12); Fm.flags = 0x42FF0000 | 0x4000 | 5; Fm.step_buf[1] = 4;
+            ORBmatcher *mt = new ORBmatcher(0.6f, oc[c].check != 0);
+            std::vector<std::pair<size_t, size_t>> pairs;
+            const int nm = mt->SearchForTriangulation((KeyFrame *)kfs[0], (KeyFrame *)kfs[1], Fm, pairs, oc[c].only_stereo != 0);
+            if ((int)pairs.size() != nm) { fprintf(stderr, "refprobe: SearchForTriangulation: %zu pairs, %d returned\n", pairs.size(), nm); abort(); }
+            std::vector<int> match(N, -1);
+            for (auto &pr : pairs) match[pr.first] = (int)pr.second;
+            auto flat = [&](FeatVec *f, std::vector<int> &ids, std::vector<int> &starts, std::vector<int> &feats) {
+                for (auto &kv : *f) { ids.push_back((int)kv.first); starts.push_back((int)feats.size()); for (unsigned x : kv.second) feats.push_back((int)x); }
+                starts.push_back((int)feats.size());
+            };
+            fprintf(JO, "{\"n\": %d, \"only_stereo\": %d, \"check_orientation\": %d, \"nmatches\": %d, ", N, oc[c].only_stereo, oc[c].check, nm);
+            J = JO;
+            std::vector<float> cam = {fx, fy, cx, cy};
+            jarr_f("cam", cam); jarr_f("Ow1", std::vector<float>(Ow1, Ow1 + 3)); jarr_f("T2w", std::vector<float>(T[1], T[1] + 16));
+            jarr_f("F12", std::vector<float>(F12, F12 + 9)); jarr_f("scale", std::vector<float>(scale, scale + 8)); jarr_f("sigma2", std::vector<float>(s2, s2 + 8));
+            for (int q = 0; q < 2; q++) {
+                std::vector<float> kx(N), ky(N), ka(N); std::vector<int> ko(N), ids, st, fe;
+                for (int k = 0; k < N; k++) { kx[k] = kk[q][k].x; ky[k] = kk[q][k].y; ka[k] = kk[q][k].angle; ko[k] = kk[q][k].octave; }
+                flat(fv[q], ids, st, fe);
+                const std::string sfx = q == 0 ? "1" : "2";
+                jarr_f(("x" + sfx).c_str(), kx); jarr_f(("y" + sfx).c_str(), ky); jarr_f(("angle" + sfx).c_str(), ka); jarr_i(("octave" + sfx).c_str(), ko);
+                jarr_f(("uright" + sfx).c_str(), ur[q]); jarr_i(("has_mp" + sfx).c_str(), has[q]);
+                jarr_i(("node_id" + sfx).c_str(), ids); jarr_i(("node_start" + sfx).c_str(), st); jarr_i(("feat" + sfx).c_str(), fe);
+                fprintf(JO, "\"desc%s\": \"", sfx.c_str());
+                for (size_t b = 0; b < kdesc[q].size(); b++) fprintf(JO, "%02x", kdesc[q][b]);
+                fprintf(JO, "\", ");
+            }
+            jarr_i("match12", match, true);
+            fprintf(JO, "}%s\n", c + 1 < NOC ? "," : "");
+        }
+        fprintf(JO, "]}\n"); fclose(JO);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

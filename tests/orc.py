@@ -403,3 +403,28 @@ def search_by_sim3(c, bounds=(0.0, 0.0, 640.0, 480.0)):
     n = L.orc_search_by_sim3(C.byref(F1), C.byref(F2), C.byref(C1), C.byref(C2), C.c_float(c["s12"]), p(R12), p(t12), C.c_float(c["th"]),
                              C.byref(P1), C.byref(P2), p(match))
     return match, n
+
+
+def epipole(Cw, R2w, t2w, fx, fy, cx, cy):
+    L = lib()
+    a = [np.ascontiguousarray(x, np.float32) for x in (Cw, np.asarray(R2w).ravel(), t2w)]
+    ex = C.c_float(); ey = C.c_float()
+    L.orc_epipole(p(a[0]), p(a[1]), p(a[2]), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.byref(ex), C.byref(ey))
+    return ex.value, ey.value
+
+
+def search_for_triangulation(c):
+    """ORBmatcher::SearchForTriangulation on a case dict of refgen.load_triangulation_cases: (match12, nmatches)"""
+    L = lib()
+    ex, ey = epipole(c["Ow1"], c["R2w"], c["t2w"], c["fx"], c["fy"], c["cx"], c["cy"])
+    k1, k2 = c["kps1"], c["kps2"]
+    arr = dict(x1=k1["x"], y1=k1["y"], a1=k1["angle"], x2=k2["x"], y2=k2["y"], a2=k2["angle"], o2=k2["octave"])
+    arr = {k: np.ascontiguousarray(v) for k, v in arr.items()}
+    F = np.ascontiguousarray(c["F12"], np.float32)
+    n1 = c["nodes1"]; n2 = c["nodes2"]
+    match = np.zeros(c["n"], np.int32)
+    n = L.orc_search_for_triangulation(c["n"], c["n"], p(arr["x1"]), p(arr["y1"]), p(arr["a1"]), p(c["uright1"]), p(c["desc1"]), p(c["has_mp1"]),
+                                       p(arr["x2"]), p(arr["y2"]), p(arr["a2"]), p(arr["o2"]), p(c["uright2"]), p(c["desc2"]), p(c["has_mp2"]),
+                                       len(n1[0]), p(n1[0]), p(n1[1]), p(n1[2]), len(n2[0]), p(n2[0]), p(n2[1]), p(n2[2]), p(F), C.c_float(ex), C.c_float(ey),
+                                       p(c["scale"]), p(c["sigma2"]), int(c["only_stereo"]), int(c["check"]), p(match))
+    return match, n

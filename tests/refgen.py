@@ -231,6 +231,28 @@ def load_sim3_cases(path):
     return out
 
 
+def load_triangulation_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = []
+    for c in json.load(open(path))["cases"]:
+        N = c["n"]; cam = f32(c["cam"]); T2 = f32(c["T2w"]).reshape(4, 4)
+        d = dict(n=N, only_stereo=c["only_stereo"], check=c["check_orientation"], nmatches=c["nmatches"], match12=np.array(c["match12"], np.int32),
+                 F12=f32(c["F12"]).reshape(3, 3).copy(), scale=f32(c["scale"]), sigma2=f32(c["sigma2"]), Ow1=f32(c["Ow1"]), R2w=T2[:3, :3].copy(), t2w=T2[:3, 3].copy(),
+                 fx=float(cam[0]), fy=float(cam[1]), cx=float(cam[2]), cy=float(cam[3]))
+        for sfx in ("1", "2"):
+            kps = np.zeros(N, dtype=kp_dtype)
+            kps["x"] = f32(c["x" + sfx]); kps["y"] = f32(c["y" + sfx]); kps["angle"] = f32(c["angle" + sfx]); kps["octave"] = np.array(c["octave" + sfx], np.int32)
+            d["kps" + sfx] = kps
+            d["uright" + sfx] = f32(c["uright" + sfx])
+            d["has_mp" + sfx] = np.array(c["has_mp" + sfx], np.uint8)
+            d["desc" + sfx] = np.frombuffer(bytes.fromhex(c["desc" + sfx]), np.uint8).reshape(N, 32).copy()
+            d["nodes" + sfx] = (np.array(c["node_id" + sfx], np.uint32), np.array(c["node_start" + sfx], np.int32), np.array(c["feat" + sfx], np.int32))
+        out.append(d)
+    return out
+
+
 def load_frustum_cases(path):
     import json
     f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
