@@ -251,6 +251,29 @@ typedef struct {
 int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const plf_kf_pose *pose, const plf_points3d_view *pts, float th,
                    int32_t *best_idx, int32_t *nfused, void *stream);
 
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs,
+ *                                        const bool bOnlyStereo)   include/ORBmatcher.h:111 (so@0x86b30; LocalMapping::CreateNewMapPoints), with
+ * ORBmatcher::CheckDistEpipolarLine (so@0x79b90).  All arrays of the view in DEVICE memory; the DBoW2 feature vectors flattened as for plf_match_bow.
+ * has_mp1/2[i] = pKF->GetMapPoint(i) != NULL (only features WITHOUT a map point are paired).  F12 (9, row-major), Cw1 = pKF1->GetCameraCenter() (3): HOST.
+ * pose2: Rcw, tcw, fx, fy, cx, cy of pKF2 (epipole).  mbCheckOrientation = check_orientation.
+ * match12 (device, n1 int32, overwritten): keyframe-2 feature paired with keyframe-1 feature i1, -1 = none -- the reference's vMatchedPairs is
+ * {(i1, match12[i1])} in ascending i1.  nmatches (device int32) = the return value (-1: a feature listed in two nodes of keyframe 1). */
+typedef struct plf_tri_view {
+    int32_t n1, n2;
+    const plf_keypoint *keys1, *keys2;   /* mvKeysUn */
+    const float *uright1, *uright2;      /* mvuRight */
+    const uint8_t *desc1, *desc2;        /* mDescriptors */
+    const uint8_t *has_mp1, *has_mp2;
+    int32_t nodes1, nodes2;
+    const uint32_t *node_id1, *node_id2;
+    const int32_t *node_start1, *node_start2;
+    const int32_t *feat1, *feat2;
+    const float *scale_factors2;         /* pKF2->mvScaleFactors */
+    const float *level_sigma2_2;         /* pKF2->mvLevelSigma2 */
+} plf_tri_view;
+int plf_match_triangulation(plf_matcher *h, const plf_tri_view *v, const float *F12, const float *Cw1, const plf_kf_pose *pose2,
+                            int32_t only_stereo, int32_t check_orientation, int32_t *match12, int32_t *nmatches, void *stream);
+
 /* int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint)
  * include/ORBmatcher.h:122 (so@0x7bb20, loop closing) -- the search half.  Scw: the 4x4 CV_32F Sim3 matrix, row-major, HOST; it is
  * decomposed as the reference does (scale from row 0, Rcw = sRcw / s, tcw, Ow = -Rcw.t() * tcw).  intr: fx, fy, cx, cy,

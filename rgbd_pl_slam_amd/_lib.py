@@ -79,6 +79,13 @@ class KfPose(C.Structure):
                 ("cy", C.c_float), ("bf", C.c_float), ("log_scale_factor", C.c_float), ("inv_level_sigma2", C.c_void_p)]
 
 
+class TriView(C.Structure):
+    _fields_ = [("n1", C.c_int32), ("n2", C.c_int32), ("keys1", C.c_void_p), ("keys2", C.c_void_p), ("uright1", C.c_void_p), ("uright2", C.c_void_p),
+                ("desc1", C.c_void_p), ("desc2", C.c_void_p), ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p), ("nodes1", C.c_int32), ("nodes2", C.c_int32),
+                ("node_id1", C.c_void_p), ("node_id2", C.c_void_p), ("node_start1", C.c_void_p), ("node_start2", C.c_void_p), ("feat1", C.c_void_p),
+                ("feat2", C.c_void_p), ("scale_factors2", C.c_void_p), ("level_sigma2_2", C.c_void_p)]
+
+
 class PlfError(RuntimeError):
     def __init__(self, status, what):
         super().__init__("%s failed: %s (%d)" % (what, lib().plf_status_string(status).decode(), status))

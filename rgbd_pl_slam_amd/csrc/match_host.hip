@@ -37,7 +37,8 @@ struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; con
 __global__ void k_build_grid(const FrameDev *, int *, int *, int *, int);
 __global__ void k_mp_candidates(const FrameDev *, MapDev, float, const int *, int, uint8_t *, uint32_t *, int2 *, int, int *, int *);
 __global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, const uint8_t *, int, const uint32_t *, const int2 *, int, const int *);
-__global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *);
+struct TriDev { const plf_keypoint *keys1, *keys2; const float *uright1, *uright2, *scale2, *sigma2_2; float F[9]; float ex, ey; int only_stereo; };
+__global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *, TriDev);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
 __global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, RelocDev, float, int, int, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_project_kf(FrameDev, Pts3Dev, ProjKf, float, int *, int *, int *);
@@ -226,8 +227,10 @@ static int match_bow_impl(plf_matcher *h, const plf_bow_view *pairs, int32_t n_p
     PLF_HIP_TRY(hipStreamSynchronize(s));   // a previous launch may still read the pair table
     PLF_HIP_TRY(hipMemcpyAsync(h->d_bow, pd.data(), sizeof(BowDev) * n_pairs, hipMemcpyHostToDevice, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
+    TriDev none;
+    memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL(k_match_bow, dim3(n_pairs), dim3(256), 0, s, h->d_bow, nnratio, check_orientation, kfkf, match, stride, nmatches, h->d_bow_fnode,
-                       h->d_bow_used);
+                       h->d_bow_used, none);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }
@@ -242,6 +245,42 @@ extern "C" int plf_match_bow_kf(plf_matcher *h, const plf_bow_view *pairs, int32
                                 int32_t *match12, int32_t stride, int32_t *nmatches, void *stream)
 {
     return match_bow_impl(h, pairs, n_pairs, nnratio, check_orientation, 1, match12, stride, nmatches, stream);
+}
+
+extern "C" int plf_match_triangulation(plf_matcher *h, const plf_tri_view *v, const float *F12, const float *Cw1, const plf_kf_pose *pose2,
+                                       int32_t only_stereo, int32_t check_orientation, int32_t *match12, int32_t *nmatches, void *stream)
+{
+    if (!h || !v || !F12 || !Cw1 || !pose2 || !match12 || !nmatches || v->n1 < 0 || v->n2 < 0 || v->n1 > h->max_kp || v->n2 > h->max_kp ||
+        v->nodes1 < 0 || v->nodes2 < 0 || !v->has_mp1 || !v->has_mp2 || !v->uright1 || !v->uright2 || !v->keys1 || !v->keys2 || !v->scale_factors2 ||
+        !v->level_sigma2_2)
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    BowDev d;
+    memset(&d, 0, sizeof(d));
+    d.n_kf = v->n1; d.n_f = v->n2; d.kf_desc = v->desc1; d.f_desc = v->desc2; d.kf_has_mp = v->has_mp1; d.f_has_mp = v->has_mp2;
+    d.kf_nodes = v->nodes1; d.f_nodes = v->nodes2; d.kf_node_id = v->node_id1; d.f_node_id = v->node_id2; d.kf_node_start = v->node_start1;
+    d.f_node_start = v->node_start2; d.kf_feat = v->feat1; d.f_feat = v->feat2;
+    TriDev T;
+    memset(&T, 0, sizeof(T));
+    T.keys1 = v->keys1; T.keys2 = v->keys2; T.uright1 = v->uright1; T.uright2 = v->uright2; T.scale2 = v->scale_factors2; T.sigma2_2 = v->level_sigma2_2;
+    memcpy(T.F, F12, sizeof(T.F));
+    T.only_stereo = only_stereo != 0;
+    // epipole of keyframe 1 in keyframe 2 (so@0x86b9c-0x86f95): C2 = R2w*Cw + t2w (gemm small-matrix float path), ex = fmaf(fx*C2x, 1/C2z, cx)
+    float C2[3];
+    for (int r = 0; r < 3; r++) {
+        const float t = pose2->Rcw[r * 3] * Cw1[0] + pose2->Rcw[r * 3 + 1] * Cw1[1] + pose2->Rcw[r * 3 + 2] * Cw1[2];
+        C2[r] = (float)((double)t + (double)pose2->tcw[r]);
+    }
+    const float invz = 1.0f / C2[2];
+    T.ex = fmaf(pose2->fx * C2[0], invz, pose2->cx);
+    T.ey = fmaf(pose2->fy * C2[1], invz, pose2->cy);
+    PLF_HIP_TRY(hipStreamSynchronize(s));   // a previous launch may still read the pair table
+    PLF_HIP_TRY(hipMemcpyAsync(h->d_bow, &d, sizeof(BowDev), hipMemcpyHostToDevice, s));
+    PLF_HIP_TRY(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_match_bow, dim3(1), dim3(256), 0, s, h->d_bow, 0.f, check_orientation, 2, match12, h->max_kp, nmatches, h->d_bow_fnode, h->d_bow_used, T);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
 }
 
 static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose, RelocDev RL,

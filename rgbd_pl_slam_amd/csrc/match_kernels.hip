@@ -754,8 +754,55 @@ __device__ __forceinline__ int bow_node(const BowDev &P, int a, int b, float nnr
     return acc;
 }
 
+// kfkf = 2: ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)  include/ORBmatcher.h:111, so@0x86b30 -- the same node
+// walk; candidates are features WITHOUT a map point (kf_has_mp / f_has_mp = GetMapPoint(i) != NULL are skipped), gated by the epipole distance
+// (two mono key points) and ORBmatcher::CheckDistEpipolarLine (so@0x79b90, contractions as in the binary).
+struct TriDev { const plf_keypoint *keys1, *keys2; const float *uright1, *uright2, *scale2, *sigma2_2; float F[9]; float ex, ey; int only_stereo; };
+
+__device__ __forceinline__ bool check_dist_epipolar_line(const plf_keypoint &k1, const plf_keypoint &k2, const float *F, float level_sigma2)
+{
+    const float b = fmaf(k1.x, F[1], k1.y * F[4]) + F[7];
+    const float a = fmaf(k1.x, F[0], k1.y * F[3]) + F[6];
+    const float den = fmaf(a, a, b * b);
+    if (den == 0.0f) return false;
+    const float c = fmaf(k1.y, F[5], k1.x * F[2]) + F[8];
+    const float num = c + fmaf(b, k2.y, a * k2.x);
+    const float dsqr = num * num / den;
+    return 3.84 * (double)level_sigma2 > (double)dsqr;
+}
+
+__device__ __forceinline__ int tri_node(const BowDev &P, const TriDev &T, int a, int b, int *__restrict__ match, int *__restrict__ used2)
+{
+    int acc = 0;
+    for (int p = P.kf_node_start[a]; p < P.kf_node_start[a + 1]; p++) {
+        const int idx1 = P.kf_feat[p];
+        if (P.kf_has_mp[idx1]) continue;
+        const bool bStereo1 = T.uright1[idx1] >= 0.0f;
+        if (T.only_stereo && !bStereo1) continue;
+        const plf_keypoint kp1 = T.keys1[idx1];
+        const uint8_t *d1 = P.kf_desc + (size_t)idx1 * 32;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int q = P.f_node_start[b]; q < P.f_node_start[b + 1]; q++) {
+            const int idx2 = P.f_feat[q];
+            if (used2[idx2] != 0 || P.f_has_mp[idx2]) continue;
+            const bool bStereo2 = T.uright2[idx2] >= 0.0f;
+            if (T.only_stereo && !bStereo2) continue;
+            const int dist = hamming_g(d1, P.f_desc + (size_t)idx2 * 32);
+            if (dist > TH_LOW || dist > bestDist) continue;   // (an equal distance replaces the earlier candidate, so@0x87a0d)
+            const plf_keypoint kp2 = T.keys2[idx2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = T.ex - kp2.x, distey = T.ey - kp2.y;
+                if (fmaf(distex, distex, distey * distey) < 100.0f * T.scale2[kp2.octave]) continue;
+            }
+            if (check_dist_epipolar_line(kp1, kp2, T.F, T.sigma2_2[kp2.octave])) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) { match[idx1] = bestIdx2; used2[bestIdx2] = 1; acc++; }
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pairs, float nnratio, int check_ori, int kfkf, int *__restrict__ match_all,
-                                                   int stride, int *__restrict__ nmatches, int *__restrict__ fnode_all, int *__restrict__ used_all)
+                                                   int stride, int *__restrict__ nmatches, int *__restrict__ fnode_all, int *__restrict__ used_all, TriDev TR)
 {
     __shared__ int hist[HISTO_LENGTH], keepbin[3], s_acc, s_shared, s_dup1;
     const int pr = blockIdx.x, t = threadIdx.x, T = blockDim.x;
@@ -795,7 +842,7 @@ __global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pa
             const uint32_t id = P.kf_node_id[a];
             int lo = 0, hi = P.f_nodes;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.f_node_id[mid] < id) lo = mid + 1; else hi = mid; }
-            if (lo < P.f_nodes && P.f_node_id[lo] == id) acc += bow_node(P, a, lo, nnratio, kfkf, match, used2);
+            if (lo < P.f_nodes && P.f_node_id[lo] == id) acc += kfkf == 2 ? tri_node(P, TR, a, lo, match, used2) : bow_node(P, a, lo, nnratio, kfkf, match, used2);
         }
         if (acc) atomicAdd(&s_acc, acc);
     } else if (t == 0) {
@@ -803,7 +850,7 @@ __global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pa
         while (a < P.kf_nodes && b < P.f_nodes) {
             if (P.kf_node_id[a] < P.f_node_id[b]) { a++; continue; }
             if (P.kf_node_id[a] > P.f_node_id[b]) { b++; continue; }
-            acc += bow_node(P, a, b, nnratio, kfkf, match, used2);
+            acc += kfkf == 2 ? tri_node(P, TR, a, b, match, used2) : bow_node(P, a, b, nnratio, kfkf, match, used2);
             a++; b++;
         }
         s_acc = acc;
@@ -814,7 +861,7 @@ __global__ void __launch_bounds__(256) k_match_bow(const BowDev *__restrict__ pa
             for (int j = t; j < nslot; j += T) {
                 const int i = match[j];
                 if (i < 0) continue;
-                float rot = kfkf ? P.kf_angle[j] - P.f_angle[i] : P.kf_angle[i] - P.f_angle[j];
+                float rot = kfkf == 2 ? TR.keys1[j].angle - TR.keys2[i].angle : (kfkf ? P.kf_angle[j] - P.f_angle[i] : P.kf_angle[i] - P.f_angle[j]);
                 if (rot < 0.0f) rot += 360.0f;
                 int bin = (int)roundf(rot * (1.0f / 12.0f));
                 if (bin == HISTO_LENGTH) bin = 0;

@@ -143,6 +143,22 @@ class Matcher:
         L.check(L.lib().plf_match_sim3(self._h, C.byref(kf1), C.byref(kf2), C.byref(p1), C.byref(p2), C.c_float(s12), L.vp(R), L.vp(t), C.c_float(th),
                                        C.byref(v1), C.byref(v2), L.vp(match12), L.vp(nfound), C.c_void_p(stream) if stream else None), "plf_match_sim3")
 
+    def SearchForTriangulation(self, kf1, kf2, F12, Cw1, pose2, only_stereo, check_ori, match12, nmatches, stream=None):
+        """ORBmatcher::SearchForTriangulation; kf1 / kf2: dicts of device tensors keys, uright, desc, has_mp, nodes=(node_id, node_start, feat);
+        kf2 also scale_factors, level_sigma2"""
+        v = L.TriView()
+        v.n1 = int(kf1["desc"].shape[0]); v.n2 = int(kf2["desc"].shape[0])
+        for sfx, kf in (("1", kf1), ("2", kf2)):
+            setattr(v, "keys" + sfx, L.vp(kf["keys"]).value); setattr(v, "uright" + sfx, L.vp(kf["uright"]).value)
+            setattr(v, "desc" + sfx, L.vp(kf["desc"]).value); setattr(v, "has_mp" + sfx, L.vp(kf["has_mp"]).value)
+            setattr(v, "nodes" + sfx, int(kf["nodes"][0].shape[0])); setattr(v, "node_id" + sfx, L.vp(kf["nodes"][0]).value)
+            setattr(v, "node_start" + sfx, L.vp(kf["nodes"][1]).value); setattr(v, "feat" + sfx, L.vp(kf["nodes"][2]).value)
+        v.scale_factors2 = L.vp(kf2["scale_factors"]).value; v.level_sigma2_2 = L.vp(kf2["level_sigma2"]).value
+        kp, keep = self.kf_pose(pose2)
+        F = np.ascontiguousarray(F12, np.float32); Cw = np.ascontiguousarray(Cw1, np.float32)
+        L.check(L.lib().plf_match_triangulation(self._h, C.byref(v), L.vp(F), L.vp(Cw), C.byref(kp), int(only_stereo), int(check_ori), L.vp(match12),
+                                                L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_triangulation")
+
     def knnMatch(self, query, train):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
         nq, nt = int(query.shape[0]), int(train.shape[0])

@@ -406,3 +406,28 @@ def test_gpu_equals_reference_search_by_sim3_fixture():
         assert int(nf[0]) == c["nfound"]
         assert np.array_equal(match.cpu().numpy(), c["match12"])
         m.close()
+
+
+def test_gpu_equals_reference_search_for_triangulation_fixture():
+    """HIP SearchForTriangulation vs tests/golden/ref_glue_triangulation.json (the reference binary's own run)."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_triangulation_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_triangulation.json")):
+        N = c["n"]
+        m = Matcher(max_keypoints=1024, max_mappoints=1024)
+        kfs = []
+        for sfx in ("1", "2"):
+            kfs.append(dict(keys=_kp_tensor(c["kps" + sfx]), uright=_dev(c["uright" + sfx]), desc=_dev(c["desc" + sfx]), has_mp=_dev(c["has_mp" + sfx]),
+                            nodes=tuple(_dev(a) for a in c["nodes" + sfx])))
+        kfs[1]["scale_factors"] = _dev(c["scale"]); kfs[1]["level_sigma2"] = _dev(c["sigma2"])
+        pose2 = dict(Rcw=c["R2w"], tcw=c["t2w"], Ow=np.zeros(3, np.float32), fx=c["fx"], fy=c["fy"], cx=c["cx"], cy=c["cy"], bf=0.0, log_scale_factor=1.0,
+                     inv_sigma2=np.ones(8, np.float32))
+        match = torch.full((N,), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchForTriangulation(kfs[0], kfs[1], c["F12"], c["Ow1"], pose2, c["only_stereo"], c["check"], match, nm)
+        torch.cuda.synchronize()
+        assert int(nm[0]) == c["nmatches"]
+        assert np.array_equal(match.cpu().numpy(), c["match12"])
+        m.close()
