@@ -161,6 +161,38 @@ public:
         check(plf_match_bow_kf(m_, &pKF1_and_pKF2, 1, mfNNratio, mbCheckOrientation, match12_dev, std::max(pKF1_and_pKF2.n_kf, pKF1_and_pKF2.n_f), nmatches_dev, stream),
               "SearchByBoW(keyframes)");
     }
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs, const bool bOnlyStereo)
+    void SearchForTriangulation(const plf_tri_view &pKF1_and_pKF2, const float *F12, const float *Cw1, const plf_kf_pose &pose2, bool bOnlyStereo,
+                                int32_t *match12_dev, int32_t *nmatches_dev, void *stream = nullptr)
+    {
+        check(plf_match_triangulation(m_, &pKF1_and_pKF2, F12, Cw1, &pose2, bOnlyStereo, mbCheckOrientation, match12_dev, nmatches_dev, stream),
+              "SearchForTriangulation");
+    }
+    // int Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0)   (search half; the caller applies Replace / AddObservation)
+    void Fuse(const plf_frame_view &pKF, const plf_kf_pose &pose, const plf_points3d_view &vpMapPoints, float th, int32_t *best_idx_dev,
+              int32_t *nfused_dev, void *stream = nullptr)
+    {
+        check(plf_match_fuse(m_, &pKF, &pose, &vpMapPoints, th, best_idx_dev, nfused_dev, stream), "Fuse");
+    }
+    // int Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint)
+    void Fuse(const plf_frame_view &pKF, const float *Scw, const plf_kf_pose &intrinsics, const plf_points3d_view &vpPoints, float th,
+              int32_t *best_idx_dev, int32_t *nfused_dev, void *stream = nullptr)
+    {
+        check(plf_match_fuse_sim3(m_, &pKF, Scw, &intrinsics, &vpPoints, th, best_idx_dev, nfused_dev, stream), "Fuse(Scw)");
+    }
+    // int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+    void SearchByProjection(const plf_frame_view &pKF, const float *Scw, const plf_kf_pose &intrinsics, const plf_points3d_view &vpPoints, int th,
+                            int32_t *match_of_kp_dev, int32_t *nmatches_dev, void *stream = nullptr)
+    {
+        check(plf_match_project_sim3(m_, &pKF, Scw, &intrinsics, &vpPoints, th, match_of_kp_dev, nmatches_dev, stream), "SearchByProjection(Scw)");
+    }
+    // int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)
+    void SearchBySim3(const plf_frame_view &pKF1, const plf_frame_view &pKF2, const plf_kf_pose &pose1, const plf_kf_pose &pose2, float s12, const float *R12,
+                      const float *t12, float th, const plf_points3d_view &vpMapPoints1, const plf_points3d_view &vpMapPoints2, int32_t *match12_dev,
+                      int32_t *nfound_dev, void *stream = nullptr)
+    {
+        check(plf_match_sim3(m_, &pKF1, &pKF2, &pose1, &pose2, s12, R12, t12, th, &vpMapPoints1, &vpMapPoints2, match12_dev, nfound_dev, stream), "SearchBySim3");
+    }
 
 private:
     plf_matcher *m_;
