@@ -338,7 +338,10 @@ int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const 
 
 /* int LSDmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  include/LSDmatcher.h:32
  * with Frame::lineDescriptorMAD include/Frame.h:75.  last_has_mapline[q] = LastFrame.mvpMapLines[q] != NULL.
- * match_of_line (device, ncur int32, pre-set to -1): last-frame line index assigned to each current line. */
+ * match_of_line (device, ncur int32, pre-set to -1): last-frame line index assigned to each current line.
+ * The keyframe overload, int LSDmatcher::SearchByProjection(KeyFrame *pKF, Frame &F, vector<MapLine*> &vpMapLineMatches)
+ * include/LSDmatcher.h:35 (KeyFrame::lineDescriptorMAD include/KeyFrame.h:159), is the same rule with the keyframe's line descriptors as the
+ * query side: pass pKF->mLineDescriptors as last_desc and last_has_mapline[q] = pKF->GetMapLineMatches()[q] != NULL. */
 int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_desc, int32_t nlast, const uint8_t *cur_desc,
                               int32_t ncur, const uint8_t *last_has_mapline, int32_t *match_of_line, int32_t *nmatches,
                               void *stream);

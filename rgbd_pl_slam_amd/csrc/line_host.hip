@@ -14,6 +14,7 @@
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *);
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
+__global__ void k_lsd_regions_lat(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
 __global__ void k_lsd_maxgrad(const float *, const double *, double *, LsdGeom);
 __global__ void k_lsd_seedkeys(const double *, const double *, uint32_t *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
@@ -240,6 +241,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
     (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
@@ -293,8 +295,14 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                                                                h->d_seg_off, h->d_seg_off + B, 0, 30, s));
         seeds = h->d_keys[1];
     }
-    hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
-                       h->d_rects, nrect, status, g, seeds);
+    // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
+    static const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;
+    if (B <= lat_max)
+        hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+                           h->d_rects, nrect, status, g, seeds, status);
+    else
+        hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+                           h->d_rects, nrect, status, g, seeds);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)
     PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
