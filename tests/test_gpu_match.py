@@ -431,3 +431,69 @@ def test_gpu_equals_reference_search_for_triangulation_fixture():
         assert int(nm[0]) == c["nmatches"]
         assert np.array_equal(match.cpu().numpy(), c["match12"])
         m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,nk,m", [(1, 300, 64), (2, 2000, 5000), (3, 4000, 12000), (4, 50, 3000)])
+def test_keyframe_projection_family_random_scenes(seed, nk, m):
+    """Fuse (both overloads) and the Scw SearchByProjection on random scenes, HIP vs the oracle (itself pinned to the reference binary)."""
+    import kfgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    c = kfgen.keyframe_scene(seed, nk, m, sim3_scale=1.0 + 0.03 * seed)
+    p = c["pts"]
+    mt = Matcher(max_keypoints=4096, max_mappoints=16384)
+    dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"]); du = _dev(c["uright"])
+    kf = Matcher.frame_view(nk, dk, dd, ds, c["bounds"], du)
+    dp = dict(world_pos=_dev(p["xw"]), normal=_dev(p["normal"]), min_dist=_dev(p["min_dist"]), max_dist=_dev(p["max_dist"]), desc=_dev(p["desc"]), valid=_dev(p["valid"]))
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for th in (3.0, 7.5):
+        best = torch.full((m,), -7, dtype=torch.int32, device="cuda")
+        mt.Fuse(kf, c["pose"], dp, th, best, cnt); torch.cuda.synchronize()
+        eb, ed, en = orc.fuse(c["kps"], c["desc"], c["uright"], c["scale"], c["bounds"], c["pose"], p, th)
+        assert int(cnt[0]) == en and en > 0 and np.array_equal(best.cpu().numpy(), eb)
+        mt.FuseSim3(kf, c["Scw"], c["intr"], dp, th, best, cnt); torch.cuda.synchronize()
+        eb, en = orc.fuse_sim3(c["kps"], c["desc"], c["scale"], c["bounds"], c["Scw"], c["intr"], p, th)
+        assert int(cnt[0]) == en and np.array_equal(best.cpu().numpy(), eb)
+        match = _dev(c["init"])
+        mt.SearchByProjectionSim3(kf, c["Scw"], c["intr"], dp, int(th), match, cnt); torch.cuda.synchronize()
+        em, en = orc.search_by_projection_sim3(c["kps"], c["desc"], c["scale"], c["bounds"], c["Scw"], c["intr"], p, int(th), c["init"])
+        assert int(cnt[0]) == en and np.array_equal(match.cpu().numpy(), em)
+    mt.close()
+
+
+@pytest.mark.gpu
+def test_keyframe_projection_family_edge_cases():
+    """no map points, no key points, nothing valid, argument errors"""
+    import kfgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    from rgbd_pl_slam_amd._lib import PlfError
+    c = kfgen.keyframe_scene(9, 200, 100, sim3_scale=1.0)
+    p = c["pts"]
+    mt = Matcher(max_keypoints=256, max_mappoints=128)
+    dk = _kp_tensor(c["kps"]); dd = _dev(c["desc"]); ds = _dev(c["scale"]); du = _dev(c["uright"])
+    dp = dict(world_pos=_dev(p["xw"]), normal=_dev(p["normal"]), min_dist=_dev(p["min_dist"]), max_dist=_dev(p["max_dist"]), desc=_dev(p["desc"]), valid=_dev(p["valid"]))
+    cnt = torch.full((1,), 77, dtype=torch.int32, device="cuda"); best = torch.full((100,), -7, dtype=torch.int32, device="cuda")
+    empty_kf = Matcher.frame_view(0, dk, dd, ds, c["bounds"], du)
+    mt.Fuse(empty_kf, c["pose"], dp, 3.0, best, cnt); torch.cuda.synchronize()
+    assert int(cnt[0]) == 0 and (best.cpu().numpy() == -1).all()
+    kf = Matcher.frame_view(200, dk, dd, ds, c["bounds"], du)
+    none = dict(dp); none["valid"] = torch.zeros(100, dtype=torch.uint8, device="cuda")
+    mt.FuseSim3(kf, c["Scw"], c["intr"], none, 3.0, best, cnt); torch.cuda.synchronize()
+    assert int(cnt[0]) == 0 and (best.cpu().numpy() == -1).all()
+    zero = {k: v[:0] for k, v in dp.items()}
+    match = _dev(c["init"]); before = match.clone()
+    mt.SearchByProjectionSim3(kf, c["Scw"], c["intr"], zero, 3, match, cnt); torch.cuda.synchronize()
+    assert int(cnt[0]) == 0 and torch.equal(match, before)
+    big = kfgen.keyframe_scene(10, 200, 300)
+    bp = big["pts"]
+    dbig = dict(world_pos=_dev(bp["xw"]), normal=_dev(bp["normal"]), min_dist=_dev(bp["min_dist"]), max_dist=_dev(bp["max_dist"]), desc=_dev(bp["desc"]), valid=_dev(bp["valid"]))
+    with pytest.raises(PlfError):   # more map points than the handle was sized for
+        mt.Fuse(kf, c["pose"], dbig, 3.0, torch.zeros(300, dtype=torch.int32, device="cuda"), cnt)
+    bad = dict(c["pose"]); bad["log_scale_factor"] = 0.0
+    with pytest.raises(PlfError):
+        mt.Fuse(kf, bad, dp, 3.0, best, cnt)
+    mt.close()
