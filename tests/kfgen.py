@@ -64,3 +64,64 @@ def keyframe_scene(seed, nk, m, sim3_scale=None, width=640, height=480):
         out["intr"] = {k: pose[k] for k in ("fx", "fy", "cx", "cy", "bf", "log_scale_factor")}
         out["init"] = np.where(r.random(nk) < 0.25, -2, -1).astype(np.int32)
     return out
+
+
+def two_keyframe_scene(seed, n, nodes=100, s12=1.0, tz=0.2):
+    """two keyframes observing the same n world points (key point i of KF1 <-> key point perm[i] of KF2), with map points, uRight,
+    a vocabulary node per feature and the true fundamental matrix.  Returns a dict usable by orc.search_by_sim3 /
+    orc.search_for_triangulation and the HIP wrappers."""
+    r = np.random.default_rng(seed)
+    fx, fy, cx, cy, bf = 517.3, 516.5, 318.6, 255.3, 40.0
+    sc = scales(); sig2 = (sc.astype(np.float64) ** 2).astype(F)
+    R1 = _rot(0.02, -0.01).astype(np.float64); t1 = np.zeros(3)
+    R2 = _rot(-0.03, 0.02).astype(np.float64); t2 = np.array([-0.12, 0.03, tz])
+    perm = r.permutation(n)
+    u1 = r.uniform(10, 630, n); v1 = r.uniform(10, 470, n); z1 = r.uniform(0.8, 6.8, n)
+    Xc1 = np.stack([(u1 - cx) / fx * z1, (v1 - cy) / fy * z1, z1], 1)
+    Xw = (Xc1 - t1) @ R1
+    Xc2 = Xw @ R2.T + t2
+    u2 = fx * Xc2[:, 0] / Xc2[:, 2] + cx; v2 = fy * Xc2[:, 1] / Xc2[:, 2] + cy
+    o1 = r.integers(0, 8, n); o2 = np.clip(o1 + r.integers(-1, 2, n), 0, 7)
+    noise = np.where(r.random(n) < 0.8, 1.5, 12.0) * sc[o2]
+    k1 = np.zeros(n, KP_DTYPE); k2 = np.zeros(n, KP_DTYPE)
+    k1["x"] = u1; k1["y"] = v1; k1["octave"] = o1; k1["angle"] = r.uniform(0, 360, n)
+    a2 = k1["angle"] - np.where(r.random(n) < 0.8, r.uniform(20, 28, n), r.uniform(0, 360, n)); a2 = np.where(a2 < 0, a2 + 360, a2)
+    k2["x"][perm] = u2 + r.uniform(-0.5, 0.5, n) * noise; k2["y"][perm] = v2 + r.uniform(-0.5, 0.5, n) * noise
+    k2["octave"][perm] = o2; k2["angle"][perm] = a2
+    d1 = r.integers(0, 256, (n, 32), dtype=np.uint8); d2 = np.zeros_like(d1)
+    for i in range(n):
+        d = d1[i].copy()
+        for b in r.integers(0, 256, r.integers(0, 64)):
+            d[b >> 3] ^= np.uint8(1 << (b & 7))
+        d2[perm[i]] = d
+    ur1 = np.where(r.random(n) < 0.5, u1 - bf / z1, -1).astype(F); ur2 = np.full(n, -1, F)
+    st = r.random(n) < 0.5; ur2[perm[st]] = (k2["x"][perm[st]] - bf / Xc2[st, 2]).astype(F)
+    has1 = (r.random(n) < 0.35).astype(np.uint8); has2 = (r.random(n) < 0.35).astype(np.uint8)
+    nd1 = (700 + 2 * r.integers(0, nodes, n)).astype(np.uint32); nd2 = np.zeros(n, np.uint32)
+    nd2[perm] = np.where(r.random(n) < 0.9, nd1, 700 + 2 * r.integers(0, nodes, n) + (r.random(n) < 0.3))
+    def flat(nd):
+        ids = np.unique(nd); starts = [0]; feats = []
+        for k in ids:
+            f = np.nonzero(nd == k)[0]; feats += list(f); starts.append(len(feats))
+        return ids.astype(np.uint32), np.array(starts, np.int32), np.array(feats, np.int32)
+    R12 = R1 @ R2.T; t12 = t1 - R12 @ t2
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]]); Ki = np.linalg.inv(K)
+    F12 = (Ki.T @ tx @ R12 @ Ki).astype(F)
+    lsf = float(F(np.log(F(1.2))))
+    def pose(R, t):
+        return dict(Rcw=R.astype(F), tcw=t.astype(F), Ow=(-(R.T @ t)).astype(F), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, log_scale_factor=lsf, inv_sigma2=np.ones(8, F))
+    def pts(idx_of_world, dist_other, oct_other, desc, has):
+        m = len(desc)
+        xw = np.zeros((m, 3), F); xw[idx_of_world] = (Xw + r.uniform(-0.005, 0.005, Xw.shape)).astype(F)
+        dmax = np.zeros(m, F); dmax[idx_of_world] = (dist_other * 1.2 ** (oct_other + (r.random(n) < 0.5) - 0.5 + r.uniform(-0.45, 0.45, n))).astype(F)
+        md = desc.copy()
+        return dict(xw=xw, normal=np.zeros((m, 3), F), min_dist=(dmax / F(1.2 ** 7)).astype(F), max_dist=dmax, desc=md,
+                    valid=(has & (r.random(m) > 0.05)).astype(np.uint8))
+    ar = np.arange(n)
+    c = dict(n=n, scale=sc, sigma2=sig2, F12=F12, kps1=k1, kps2=k2, desc1=d1, desc2=d2, uright1=ur1, uright2=ur2, has_mp1=has1, has_mp2=has2,
+             nodes1=flat(nd1), nodes2=flat(nd2), Ow1=(-(R1.T @ t1)).astype(F), R2w=R2.astype(F), t2w=t2.astype(F), fx=fx, fy=fy, cx=cx, cy=cy,
+             pose1=pose(R1, t1), pose2=pose(R2, t2), s12=float(s12), R12=R12.astype(F), t12=(t1 - s12 * (R12 @ t2)).astype(F),
+             pts1=pts(ar, np.linalg.norm(Xc2, axis=1), o2, d1, (r.random(n) < 0.85).astype(np.uint8)),
+             pts2=pts(perm, np.linalg.norm(Xc1, axis=1), o1, d2, (r.random(n) < 0.85).astype(np.uint8)))
+    return c

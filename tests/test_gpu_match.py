@@ -497,3 +497,35 @@ def test_keyframe_projection_family_edge_cases():
     with pytest.raises(PlfError):
         mt.Fuse(kf, bad, dp, 3.0, best, cnt)
     mt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,tz,s12", [(1, 400, 0.05, 1.0), (2, 2500, 0.4, 1.05), (3, 4000, 0.2, 0.96)])
+def test_two_keyframe_overloads_random_scenes(seed, n, tz, s12):
+    """SearchBySim3 and SearchForTriangulation on random two-keyframe scenes, HIP vs the oracle (itself pinned to the reference binary)."""
+    import kfgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    c = kfgen.two_keyframe_scene(seed, n, nodes=max(20, n // 8), s12=s12, tz=tz)
+    mt = Matcher(max_keypoints=4096, max_mappoints=4096)
+    ds = _dev(c["scale"])
+    keep, views, pts, kfs = [], [], [], []
+    for sfx in ("1", "2"):
+        dk = _kp_tensor(c["kps" + sfx]); dd = _dev(c["desc" + sfx]); keep += [dk, dd]
+        views.append(Matcher.frame_view(n, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), None))
+        p = c["pts" + sfx]
+        pts.append(dict(world_pos=_dev(p["xw"]), normal=None, min_dist=_dev(p["min_dist"]), max_dist=_dev(p["max_dist"]), desc=_dev(p["desc"]), valid=_dev(p["valid"])))
+        kfs.append(dict(keys=dk, uright=_dev(c["uright" + sfx]), desc=dd, has_mp=_dev(c["has_mp" + sfx]), nodes=tuple(_dev(a) for a in c["nodes" + sfx])))
+    kfs[1]["scale_factors"] = ds; kfs[1]["level_sigma2"] = _dev(c["sigma2"])
+    match = torch.full((n,), -7, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    c["th"] = 7.5
+    mt.SearchBySim3(views[0], views[1], c["pose1"], c["pose2"], c["s12"], c["R12"], c["t12"], c["th"], pts[0], pts[1], match, cnt); torch.cuda.synchronize()
+    em, en = orc.search_by_sim3(c)
+    assert en > n // 20 and int(cnt[0]) == en and np.array_equal(match.cpu().numpy(), em)
+    for only_stereo, check in ((0, 1), (1, 0), (0, 0)):
+        c["only_stereo"] = only_stereo; c["check"] = check
+        mt.SearchForTriangulation(kfs[0], kfs[1], c["F12"], c["Ow1"], c["pose2"], only_stereo, check, match, cnt); torch.cuda.synchronize()
+        em, en = orc.search_for_triangulation(c)
+        assert en > 0 and int(cnt[0]) == en and np.array_equal(match.cpu().numpy(), em)
+    mt.close()
