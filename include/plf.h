@@ -223,6 +223,12 @@ int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *cur, const 
                                const float *max_distance, const plf_pose_pair *pose, float log_scale_factor, float th, int32_t orb_dist,
                                int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches, void *stream);
 
+/* void Frame::AssignFeaturesToGrid()  include/Frame.h:222 (so@0xf9120) with Frame::PosInGrid (so@0xf5fa0): the public
+ * std::vector<size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS] (include/Frame.h:226) of one frame as a CSR -- every matcher above builds
+ * it on the device; this entry hands it out.  cell_start (HOST, 64*48 + 1 int32; cell = ix*48 + iy), cell_idx (HOST, frame->n int32:
+ * key point indices, insertion order inside a cell). */
+int plf_match_assign_grid(plf_matcher *h, const plf_frame_view *frame, int32_t *cell_start, int32_t *cell_idx, void *stream);
+
 /* Map points handed to Fuse / the Sim3 searches (vector<MapPoint*>), flattened; DEVICE memory */
 typedef struct {
     int32_t m;

@@ -396,6 +396,8 @@ public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv, fx, fy, cx, cy;
     bool isInFrustum(MapPoint *pMP, float viewingCosLimit);
     void ComputeStereoFromRGBD(const cv::Mat &imDepth);
+    void AssignFeaturesToGrid();
+    void UndistortKeyPoints();
 };
 class ORBmatcher {
 public:
@@ -1995,6 +1997,51 @@ int main(int argc, char **argv)
             fprintf(JO, "}%s\n", c + 1 < NOC ? "," : "");
         }
         fprintf(JO, "]}\n"); fclose(JO);
+    }
+    // ------------------------------------------------------------ P: Frame::AssignFeaturesToGrid() (so@0xf9120) with Frame::PosInGrid (so@0xf5fa0)
+    // N @0xec, mvKeysUn @0x120, mGrid[64][48] @0x2c8 (std::vector<size_t>, 24 B each); statics mnMinX/Y, mfGridElementWidthInv/HeightInv.
+    {
+        path = std::string(outdir) + "/ref_glue_grid.json";
+        FILE *JP = fopen(path.c_str(), "w");
+        fprintf(JP, "{\"_doc\": \"Frame::AssignFeaturesToGrid (so@0xf9120) executed from the reference binary: the 64x48 cell lists (CSR over cell = ix*48+iy) for key "
+                    "points on and around the image, incl. half-cell and border positions. floats as uint32 bit patterns\", \"cases\": [\n");
+        struct { int n; float minx, miny, maxx, maxy; uint64_t seed; } pc[] = {{1500, 0.f, 0.f, 640.f, 480.f, 10301}, {900, -11.4f, -8.7f, 652.3f, 489.1f, 10302}};
+        for (int c = 0; c < 2; c++) {
+            rng_seed(pc[c].seed);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int N = pc[c].n;
+            Frame::mnMinX = pc[c].minx; Frame::mnMinY = pc[c].miny; Frame::mnMaxX = pc[c].maxx; Frame::mnMaxY = pc[c].maxy;
+            Frame::mfGridElementWidthInv = 64.f / (pc[c].maxx - pc[c].minx); Frame::mfGridElementHeightInv = 48.f / (pc[c].maxy - pc[c].miny);
+            std::vector<cv::KeyPoint> ku(N);
+            for (int i = 0; i < N; i++) {
+                float x = pc[c].minx - 6.f + uf() * (pc[c].maxx - pc[c].minx + 12.f), y = pc[c].miny - 6.f + uf() * (pc[c].maxy - pc[c].miny + 12.f);
+                const float wcell = (pc[c].maxx - pc[c].minx) / 64.f, hcell = (pc[c].maxy - pc[c].miny) / 48.f;
+                const float u = uf();
+                if (u < 0.15f) x = pc[c].minx + wcell * ((float)rng_below(65) + 0.5f);            // exactly between two cells (round-half cases)
+                else if (u < 0.3f) y = pc[c].miny + hcell * ((float)rng_below(49) + 0.5f);
+                else if (u < 0.35f) { x = uf() < 0.5f ? pc[c].minx : pc[c].maxx; }
+                else if (u < 0.4f) { y = uf() < 0.5f ? pc[c].miny : pc[c].maxy; }
+                ku[i].x = x; ku[i].y = y; ku[i].size = 31.f; ku[i].angle = 0.f; ku[i].response = 1.f; ku[i].octave = 0; ku[i].class_id = -1;
+            }
+            char *fr = (char *)bump(0x12800); memset(fr, 0, 0x12800);
+            *(int *)(fr + 0xec) = N;
+            void **v = (void **)(fr + 0x120); v[0] = ku.data(); v[1] = ku.data() + N; v[2] = v[1];
+            ((Frame *)fr)->AssignFeaturesToGrid();
+            std::vector<int> start(64 * 48 + 1, 0), idx;
+            for (int cell = 0; cell < 64 * 48; cell++) {
+                size_t **g = (size_t **)(fr + 0x2c8 + (size_t)cell * 24);
+                start[cell] = (int)idx.size();
+                for (size_t *q = g[0]; q != g[1]; q++) idx.push_back((int)*q);
+            }
+            start[64 * 48] = (int)idx.size();
+            std::vector<float> kx(N), ky(N), bnd = {pc[c].minx, pc[c].miny, pc[c].maxx, pc[c].maxy};
+            for (int i = 0; i < N; i++) { kx[i] = ku[i].x; ky[i] = ku[i].y; }
+            fprintf(JP, "{\"n\": %d, ", N);
+            J = JP;
+            jarr_f("bounds", bnd); jarr_f("x", kx); jarr_f("y", ky); jarr_i("cell_start", start); jarr_i("cell_idx", idx, true);
+            fprintf(JP, "}%s\n", c == 0 ? "," : "");
+        }
+        fprintf(JP, "]}\n"); fclose(JP);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

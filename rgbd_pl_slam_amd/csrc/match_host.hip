@@ -364,6 +364,24 @@ static void fill_camera(ProjKf *C, const plf_kf_pose *pose, int nlevels)
     for (int l = 0; l < nlevels && l < 16; l++) C->inv_sigma2[l] = pose->inv_level_sigma2[l];
 }
 
+extern "C" int plf_match_assign_grid(plf_matcher *h, const plf_frame_view *frame, int32_t *cell_start, int32_t *cell_idx, void *stream)
+{
+    if (!h || !frame || !cell_start || !cell_idx) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    FrameDev fd;
+    plf_frame_view v = *frame;
+    if (v.nlevels < 1) v.nlevels = 1;   // (the grid does not read the scale pyramid)
+    const int st = stage_keyframe(h, &v, s, &fd);
+    if (st != PLF_OK) return st;
+    PLF_HIP_TRY(hipMemcpyAsync(cell_start, h->d_cell_start, sizeof(int) * (GRID_CELLS + 1), hipMemcpyDeviceToHost, s));
+    PLF_HIP_TRY(hipStreamSynchronize(s));
+    const int total = cell_start[GRID_CELLS];
+    if (total > 0) PLF_HIP_TRY(hipMemcpyAsync(cell_idx, h->d_cell_idx, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, s));
+    PLF_HIP_TRY(hipStreamSynchronize(s));
+    return PLF_OK;
+}
+
 extern "C" int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const plf_kf_pose *pose, const plf_points3d_view *pts, float th,
                               int32_t *best_idx, int32_t *nfused, void *stream)
 {

@@ -159,6 +159,12 @@ class Matcher:
         L.check(L.lib().plf_match_triangulation(self._h, C.byref(v), L.vp(F), L.vp(Cw), C.byref(kp), int(only_stereo), int(check_ori), L.vp(match12),
                                                 L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_triangulation")
 
+    def AssignFeaturesToGrid(self, frame):
+        """Frame::AssignFeaturesToGrid: (cell_start[64*48+1], cell_idx[n]) host arrays, cell = ix*48 + iy"""
+        cs = np.zeros(64 * 48 + 1, np.int32); ci = np.zeros(max(1, int(frame.n)), np.int32)
+        L.check(L.lib().plf_match_assign_grid(self._h, C.byref(frame), L.vp(cs), L.vp(ci), None), "plf_match_assign_grid")
+        return cs, ci[:cs[-1]]
+
     def knnMatch(self, query, train):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2); device tensors in, host DMATCH array (nq,2) out"""
         nq, nt = int(query.shape[0]), int(train.shape[0])

@@ -428,3 +428,15 @@ def search_for_triangulation(c):
                                        len(n1[0]), p(n1[0]), p(n1[1]), p(n1[2]), len(n2[0]), p(n2[0]), p(n2[1]), p(n2[2]), p(F), C.c_float(ex), C.c_float(ey),
                                        p(c["scale"]), p(c["sigma2"]), int(c["only_stereo"]), int(c["check"]), p(match))
     return match, n
+
+
+def assign_grid(x, y, bounds):
+    """Frame::AssignFeaturesToGrid as restated in match_oracle.c: (cell_start, cell_idx)"""
+    L = lib()
+    n = len(x)
+    kps = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("octave", "<i4"), ("angle", "<f4")])
+    kps["x"] = x; kps["y"] = y
+    F, keep = _frame(kps, np.zeros((max(n, 1), 32), np.uint8), None, np.ones(1, np.float32), bounds)
+    cs = np.zeros(64 * 48 + 1, np.int32); ci = np.zeros(max(n, 1), np.int32)
+    L.orc_assign_grid(C.byref(F), p(cs), p(ci))
+    return cs, ci[:cs[-1]]

@@ -253,6 +253,13 @@ def load_triangulation_cases(path):
     return out
 
 
+def load_grid_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    return [dict(x=f32(c["x"]), y=f32(c["y"]), bounds=tuple(float(v) for v in f32(c["bounds"])), cell_start=np.array(c["cell_start"], np.int32),
+                 cell_idx=np.array(c["cell_idx"], np.int32)) for c in json.load(open(path))["cases"]]
+
+
 def load_frustum_cases(path):
     import json
     f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)

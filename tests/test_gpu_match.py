@@ -529,3 +529,21 @@ def test_two_keyframe_overloads_random_scenes(seed, n, tz, s12):
         em, en = orc.search_for_triangulation(c)
         assert en > 0 and int(cnt[0]) == en and np.array_equal(match.cpu().numpy(), em)
     mt.close()
+
+
+@pytest.mark.gpu
+def test_gpu_equals_reference_assign_features_to_grid_fixture():
+    """k_build_grid vs tests/golden/ref_glue_grid.json (Frame::AssignFeaturesToGrid run from the reference binary)."""
+    import os
+    import refgen
+    import kfgen
+    _need_gpu()
+    from rgbd_pl_slam_amd import Matcher
+    for c in refgen.load_grid_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_grid.json")):
+        n = len(c["x"])
+        kps = np.zeros(n, kfgen.KP_DTYPE); kps["x"] = c["x"]; kps["y"] = c["y"]
+        m = Matcher(max_keypoints=2048)
+        dk = _kp_tensor(kps); dd = _dev(np.zeros((n, 32), np.uint8)); ds = _dev(np.ones(8, np.float32))
+        cs, ci = m.AssignFeaturesToGrid(Matcher.frame_view(n, dk, dd, ds, c["bounds"], None))
+        assert np.array_equal(cs, c["cell_start"]) and np.array_equal(ci, c["cell_idx"])
+        m.close()
