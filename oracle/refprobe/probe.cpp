@@ -85,6 +85,7 @@ struct Mat {  // OpenCV 3.3 layout, 96 bytes
     static MatExpr zeros(int rows, int cols, int type);
     MatExpr t() const;
     double dot(const _InputArray &m) const;
+    Mat reshape(int cn, int rows = 0) const;
 };
 struct _InputArray {
     int flags; void *obj; int sz_w, sz_h;
@@ -116,6 +117,7 @@ const _InputArray &noArray();
 void resize(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
 void copyMakeBorder(const _InputArray &, const _OutputArray &, int, int, int, int, int, const Scalar_<double> &);
 void GaussianBlur(const _InputArray &, const _OutputArray &, Size_<int>, double, double, int);
+void undistortPoints(const _InputArray &src, const _OutputArray &dst, const _InputArray &cameraMatrix, const _InputArray &distCoeffs, const _InputArray &R, const _InputArray &P);
 float fastAtan2(float y, float x);
 void fastFree(void *);
 void FAST(const _InputArray &, std::vector<KeyPoint> &, int, bool);
@@ -371,6 +373,30 @@ void cv::GaussianBlur(const _InputArray &src, const _OutputArray &dst, Size_<int
     if (k.width != 7 || k.height != 7 || sx != 2.0 || sy != 2.0 || border != 4) { fprintf(stderr, "refprobe: unexpected GaussianBlur call\n"); abort(); }
     mat_alloc(d, s->rows, s->cols, 0);
     orc_gaussian_blur7_8u(s->data, (ptrdiff_t)s->step_buf[0], d->data, (ptrdiff_t)d->step_buf[0], s->cols, s->rows);
+}
+
+// ---- tier Q: Frame::UndistortKeyPoints (so@0xf8630) reaches Mat::reshape and cv::undistortPoints; the point arithmetic is oracle/frame_oracle.c
+cv::Mat cv::Mat::reshape(int cn, int) const
+{
+    Mat m(*this);
+    const int total_cols = cols * (((flags >> 3) & 511) + 1);
+    if ((flags & 7) != 5 || total_cols % cn) { fprintf(stderr, "refprobe: unexpected reshape\n"); abort(); }
+    m.cols = total_cols / cn;
+    m.flags = (flags & ~0xFFF) | 5 | ((cn - 1) << 3);
+    m.step_buf[1] = (size_t)4 * cn;
+    return m;
+}
+void cv::undistortPoints(const _InputArray &src, const _OutputArray &dst, const _InputArray &K, const _InputArray &D, const _InputArray &R, const _InputArray &P)
+{
+    const Mat *s = (const Mat *)src.obj, *k = (const Mat *)K.obj, *d = (const Mat *)D.obj, *r = (const Mat *)R.obj, *pm = (const Mat *)P.obj;
+    if (dst.obj != src.obj || (s->flags & 0xFFF) != 13 || s->cols != 1 || (r && r->data) || !pm || pm->data != k->data) { fprintf(stderr, "refprobe: unexpected undistortPoints call\n"); abort(); }
+    const int n = s->rows, nd = d->rows * d->cols;
+    float cam[9] = {matf(*k, 0, 0), matf(*k, 1, 1), matf(*k, 0, 2), matf(*k, 1, 2), 0, 0, 0, 0, 0};
+    for (int i = 0; i < nd && i < 5; i++) cam[4 + i] = d->cols == 1 ? matf(*d, i, 0) : matf(*d, 0, i);
+    std::vector<orc_keypoint> a(n), b(n);
+    for (int i = 0; i < n; i++) { memset(&a[i], 0, sizeof(a[i])); a[i].x = *(float *)(s->data + s->step_buf[0] * i); a[i].y = *(float *)(s->data + s->step_buf[0] * i + 4); }
+    orc_undistort_keypoints(a.data(), n, cam, b.data());
+    for (int i = 0; i < n; i++) { *(float *)(s->data + s->step_buf[0] * i) = b[i].x; *(float *)(s->data + s->step_buf[0] * i + 4) = b[i].y; }
 }
 
 // ---------------------------------------------------------------- look-alike reference classes
@@ -2042,6 +2068,44 @@ int main(int argc, char **argv)
             fprintf(JP, "}%s\n", c == 0 ? "," : "");
         }
         fprintf(JP, "]}\n"); fclose(JP);
+    }
+    // ------------------------------------------------------------ Q: Frame::UndistortKeyPoints() (so@0xf8630, glue): mK @0x20, mDistCoef @0x80, N @0xec, mvKeys @0xf0, mvKeysUn @0x120
+    {
+        path = std::string(outdir) + "/ref_glue_undistort.json";
+        FILE *JQ = fopen(path.c_str(), "w");
+        fprintf(JQ, "{\"_doc\": \"Frame::UndistortKeyPoints (so@0xf8630) executed from the reference binary (its Mat fill / reshape / copy-back glue; cv::undistortPoints is "
+                    "the restatement in oracle/frame_oracle.c). floats as uint32 bit patterns; cam = fx, fy, cx, cy, k1, k2, p1, p2, k3 (TUM1.yaml / no distortion)\", \"cases\": [\n");
+        const float cams[2][9] = {{517.306408f, 516.469215f, 318.643040f, 255.313989f, 0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f},
+                                  {535.4f, 539.2f, 320.1f, 247.6f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+        for (int c = 0; c < 2; c++) {
+            rng_seed(10401 + c);
+            auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
+            const int N = 800;
+            std::vector<cv::KeyPoint> keys(N);
+            for (int i = 0; i < N; i++) { keys[i].x = uf() * 640.f; keys[i].y = uf() * 480.f; keys[i].size = 31.f + (float)rng_below(80); keys[i].angle = uf() * 360.f; keys[i].response = (float)rng_below(200); keys[i].octave = (int)rng_below(8); keys[i].class_id = -1; }
+            float *Km = (float *)bump(48), *Dm = (float *)bump(32);
+            const float Kv[9] = {cams[c][0], 0, cams[c][2], 0, cams[c][1], cams[c][3], 0, 0, 1};
+            memcpy(Km, Kv, sizeof(Kv)); memcpy(Dm, &cams[c][4], 5 * sizeof(float));
+            char *fr = (char *)bump(0x12800); memset(fr, 0, 0x12800);
+            mat_init((cv::Mat *)(fr + 0x20), (unsigned char *)Km, 3, 3, 12); ((cv::Mat *)(fr + 0x20))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(fr + 0x20))->step_buf[1] = 4;
+            mat_init((cv::Mat *)(fr + 0x80), (unsigned char *)Dm, 5, 1, 4); ((cv::Mat *)(fr + 0x80))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(fr + 0x80))->step_buf[1] = 4;
+            *(int *)(fr + 0xec) = N;
+            void **v = (void **)(fr + 0xf0); v[0] = keys.data(); v[1] = keys.data() + N; v[2] = v[1];
+            ((Frame *)fr)->UndistortKeyPoints();
+            cv::KeyPoint **un = (cv::KeyPoint **)(fr + 0x120);
+            if (un[1] - un[0] != N) { fprintf(stderr, "refprobe: mvKeysUn has %ld entries\n", (long)(un[1] - un[0])); abort(); }
+            std::vector<float> kx(N), ky(N), ux(N), uy(N), cam(cams[c], cams[c] + 9);
+            int same = 1;
+            for (int i = 0; i < N; i++) {
+                kx[i] = keys[i].x; ky[i] = keys[i].y; ux[i] = un[0][i].x; uy[i] = un[0][i].y;
+                same &= un[0][i].size == keys[i].size && un[0][i].angle == keys[i].angle && un[0][i].response == keys[i].response && un[0][i].octave == keys[i].octave && un[0][i].class_id == keys[i].class_id;
+            }
+            fprintf(JQ, "{\"n\": %d, \"other_fields_copied\": %d, ", N, same);
+            J = JQ;
+            jarr_f("cam", cam); jarr_f("x", kx); jarr_f("y", ky); jarr_f("x_un", ux); jarr_f("y_un", uy, true);
+            fprintf(JQ, "}%s\n", c == 0 ? "," : "");
+        }
+        fprintf(JQ, "]}\n"); fclose(JQ);
     }
     printf("refprobe: fixtures written to %s\n", outdir);
     return 0;

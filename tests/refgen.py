@@ -260,6 +260,13 @@ def load_grid_cases(path):
                  cell_idx=np.array(c["cell_idx"], np.int32)) for c in json.load(open(path))["cases"]]
 
 
+def load_undistort_cases(path):
+    import json
+    f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)
+    return [dict(n=c["n"], cam=f32(c["cam"]), x=f32(c["x"]), y=f32(c["y"]), x_un=f32(c["x_un"]), y_un=f32(c["y_un"]), copied=c["other_fields_copied"])
+            for c in json.load(open(path))["cases"]]
+
+
 def load_frustum_cases(path):
     import json
     f32 = lambda a: np.array(a, dtype=np.uint32).view(np.float32)

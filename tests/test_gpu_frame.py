@@ -133,3 +133,24 @@ def test_gpu_equals_reference_is_in_frustum_fixture():
             assert np.array_equal(out[k].cpu().numpy()[sel].view(np.uint32), c[k][sel].view(np.uint32)), k
         assert np.array_equal(out["level"].cpu().numpy()[sel], c["level"][sel])
 
+
+
+def test_gpu_equals_reference_undistort_fixture():
+    """plf_frame_tail vs tests/golden/ref_glue_undistort.json (Frame::UndistortKeyPoints run from the reference binary)."""
+    import os
+    import refgen
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import frame
+    from rgbd_pl_slam_amd._lib import KP_DTYPE
+    for c in refgen.load_undistort_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glue_undistort.json")):
+        n = c["n"]
+        kps = np.zeros(n, KP_DTYPE); kps["x"] = c["x"]; kps["y"] = c["y"]; kps["octave"] = 2
+        cam = frame.camera(**dict(zip(("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3"), [float(v) for v in c["cam"]])), bf=40.0)
+        dk = torch.from_numpy(np.frombuffer(kps.tobytes(), np.uint8).copy()).cuda()
+        dun = torch.zeros(n * 28, dtype=torch.uint8, device="cuda"); dur = torch.zeros(n, dtype=torch.float32, device="cuda"); dkd = torch.zeros(n, dtype=torch.float32, device="cuda")
+        frame.frame_tail(dk, n, 1, n, torch.zeros((480, 640), dtype=torch.float32, device="cuda"), 640, 480, cam, dun, dur, dkd)
+        torch.cuda.synchronize()
+        gun = np.frombuffer(dun.cpu().numpy().tobytes(), KP_DTYPE)
+        assert np.array_equal(gun["x"].view(np.uint32), c["x_un"].view(np.uint32)) and np.array_equal(gun["y"].view(np.uint32), c["y_un"].view(np.uint32))
+        assert (gun["octave"] == 2).all()
