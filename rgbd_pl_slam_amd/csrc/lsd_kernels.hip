@@ -666,8 +666,8 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
         const int band = 32 * g.sw;
         for (int b0 = 0; b0 < NP; b0 += band) {
             const int b1 = min(NP, b0 + band);
-            for (int i = b0 + t * 32; i < b1; i += 192 * 32) acc ^= __builtin_nontemporal_load(a + i);
-            for (int i = b0 * 4 + t * 32; i < b1 * 4; i += 192 * 32) acc ^= __builtin_nontemporal_load(c + i);
+            for (int i = b0 + t * 32; i < b1; i += 192 * 32) acc ^= a[i];
+            for (int i = b0 * 4 + t * 32; i < b1 * 4; i += 192 * 32) acc ^= c[i];
         }
         if (acc == 0x9E3779B9u) *sink = (int)acc;   // keeps the loads alive
         return;
