@@ -275,6 +275,7 @@ static int reduce_region_radius(lsd_t *L, regpt *reg, int *reg_size, double reg_
     return 1;
 }
 
+static int g_last_regrow_n = 0;
 static int refine(lsd_t *L, regpt *reg, int *reg_size, double reg_angle, double prec, double p, rect_t *rec,
                   double density_th)
 {
@@ -297,6 +298,7 @@ static int refine(lsd_t *L, regpt *reg, int *reg_size, double reg_angle, double 
     double mean_angle = sum / (double)n;
     double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
     region_grow(L, reg[0].x, reg[0].y, reg, reg_size, &reg_angle, tau);
+    g_last_regrow_n = *reg_size;   /* (read by the band-speculation model below) */
     if (*reg_size < 2) return 0;
     region2rect(reg, *reg_size, reg_angle, prec, p, rec);
     density = (double)*reg_size / (dist_(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
@@ -582,6 +584,177 @@ int orc_lsd_detect(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int seed_
     }
     free(reg); free(seeds); free(L.img); free(L.angles); free(L.modgrad); free(L.used);
     return nlines;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Model of "banded speculative region growing" (DESIGN.md section 7): an exact parallelisation of the serial seed loop
+ * above, evaluated here on the CPU before any kernel is written.  Not part of any parity path.
+ *
+ * Phase 1 (parallel over K row bands): band b runs the whole per-seed pipeline (grow, rect, refine) over ITS seeds in raster
+ * order against a private, initially empty USED map -- i.e. it speculates that no earlier band touches what it touches.  Each
+ * effective seed leaves a record: seed, every pixel the pipeline ever accepted ("touched"), the pixels still marked at the
+ * end, the rectangle if one came out.
+ * Phase 2 (bands in order): T = true USED map so far, S = band b's private map replayed along its timeline, D = S xor T.
+ * Walking the band's pixels in raster order: a recorded region stands iff its seed is free in T and no pixel of the 3x3
+ * dilation of its touched set is in D (then every test it made saw the true value) -- it is committed by copying its marks;
+ * otherwise it is regrown serially on T.  A seed that speculation skipped but that is free in T is grown serially as well.
+ * D is updated with the symmetric difference of the speculative and the true marks.
+ * The model checks that T and the emitted rectangles equal the serial run bit for bit and counts accept steps:
+ * stats[0] serial accepts, [1] max over bands of speculative accepts (phase 1 critical path), [2] accepts redone serially in
+ * phase 2, [3] regions, [4] regions redone or new, [5] touched pixels validated, [6] 1 if identical to the serial result. */
+typedef struct { int seed, t0, nt, has_rect; rect_t rec; } band_rec;
+
+static int run_seed(lsd_t *L, int adx, regpt *reg, double prec, double p, int min_reg_size, int *touched, int *ntouched, rect_t *rec, long *accepts)
+{
+    int reg_size;
+    double reg_angle;
+    region_grow(L, adx % L->w, adx / L->w, reg, &reg_size, &reg_angle, prec);
+    *accepts += reg_size;
+    int nt = 0;
+    for (int i = 0; i < reg_size; i++) touched[nt++] = reg[i].y * L->w + reg[i].x;
+    *ntouched = nt;
+    if (reg_size < min_reg_size) return 0;
+    region2rect(reg, reg_size, reg_angle, prec, p, rec);
+    g_last_regrow_n = -1;
+    const int ok = refine(L, reg, &reg_size, reg_angle, prec, p, rec, 0.7);
+    if (g_last_regrow_n >= 0) {   /* the regrown list (reduce_region_radius only permutes it and shortens reg_size) */
+        *accepts += g_last_regrow_n;
+        for (int i = 0; i < g_last_regrow_n; i++) touched[nt++] = reg[i].y * L->w + reg[i].x;
+        *ntouched = nt;
+    }
+    return ok;
+}
+
+int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats)
+{
+    const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5;
+    lsd_t L;
+    const double prec = CV_PI_ * ANG_TH / 180, p = ANG_TH / 180, rho = QUANT / sin(prec);
+    double *img = (double *)malloc(sizeof(double) * (size_t)w * h);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) img[(size_t)y * w + x] = (double)gray[(size_t)y * pitch + x];
+    const double sigma = SIGMA_SCALE / SCALE;
+    const int ksize = 1 + 2 * (int)(unsigned)ceil(sigma * sqrt(2 * 3 * log(10.0)));
+    double kern[64];
+    orc_gauss_kernel_f64(ksize, sigma, kern);
+    double *blur = (double *)malloc(sizeof(double) * (size_t)w * h);
+    gaussian_blur_f64(img, blur, w, h, kern, ksize);
+    L.w = (int)lrint(w * SCALE); L.h = (int)lrint(h * SCALE);
+    L.img = (double *)malloc(sizeof(double) * (size_t)L.w * L.h);
+    resize_linear_f64(blur, w, h, L.img, L.w, L.h, SCALE, SCALE);
+    free(img); free(blur);
+    const int W = L.w, H = L.h;
+    const size_t NP = (size_t)W * H;
+    L.angles = (double *)malloc(sizeof(double) * NP);
+    L.modgrad = (double *)calloc(NP, sizeof(double));
+    for (int x = 0; x < W; x++) L.angles[(size_t)(H - 1) * W + x] = NOTDEF;
+    for (int y = 0; y < H; y++) L.angles[(size_t)y * W + (W - 1)] = NOTDEF;
+    for (int y = 0; y < H - 1; ++y)
+        for (int x = 0; x < W - 1; ++x) {
+            size_t a = (size_t)y * W + x;
+            double DA = L.img[a + W + 1] - L.img[a], BC = L.img[a + 1] - L.img[a + W];
+            double gx = DA + BC, gy = DA - BC, norm = sqrt((gx * gx + gy * gy) / 4);
+            L.modgrad[a] = norm;
+            L.angles[a] = norm <= rho ? NOTDEF : (double)orc_fast_atan2((float)gx, (float)-gy) * DEG_TO_RADS;
+        }
+    L.LOG_NT = 5 * (log10((double)W) + log10((double)H)) / 2 + log10(11.0);
+    const int min_reg_size = (int)(-L.LOG_NT / log10(p));
+    regpt *reg = (regpt *)malloc(sizeof(regpt) * NP);
+    int *touched = (int *)malloc(sizeof(int) * 2 * NP);
+    memset(stats, 0, sizeof(long) * 8);
+    /* ---- serial run */
+    uint8_t *used_serial = (uint8_t *)calloc(NP, 1);
+    rect_t *rects_serial = (rect_t *)malloc(sizeof(rect_t) * NP / 4);
+    int nrect_serial = 0;
+    L.used = used_serial;
+    for (int y = 0; y < H - 1; ++y)
+        for (int x = 0; x < W - 1; ++x) {
+            const int adx = y * W + x;
+            if (L.used[adx] != NOTUSED || L.angles[adx] == NOTDEF) continue;
+            int nt; rect_t rec;
+            stats[3]++;
+            if (run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &stats[0])) rects_serial[nrect_serial++] = rec;
+        }
+    /* ---- phase 1: speculation per band */
+    if (nbands < 1) nbands = 1;
+    const int rows = H - 1;
+    band_rec **recs = (band_rec **)calloc(nbands, sizeof(band_rec *));
+    int *nrecs = (int *)calloc(nbands, sizeof(int));
+    int **tl = (int **)calloc(nbands, sizeof(int *));
+    uint8_t *priv = (uint8_t *)malloc(NP);
+    for (int b = 0; b < nbands; b++) {
+        const int y0 = (int)((long)rows * b / nbands), y1 = (int)((long)rows * (b + 1) / nbands);
+        memset(priv, 0, NP);
+        L.used = priv;
+        recs[b] = (band_rec *)malloc(sizeof(band_rec) * ((size_t)(y1 - y0) * W + 1));
+        size_t tcap = 4 * NP, tn = 0;
+        tl[b] = (int *)malloc(sizeof(int) * tcap);
+        long acc = 0;
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < W - 1; ++x) {
+                const int adx = y * W + x;
+                if (L.used[adx] != NOTUSED || L.angles[adx] == NOTDEF) continue;
+                band_rec *r = &recs[b][nrecs[b]++];
+                int nt;
+                r->seed = adx;
+                r->has_rect = run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &r->rec, &acc);
+                if (tn + (size_t)nt > tcap) { tcap = 2 * (tn + nt); tl[b] = (int *)realloc(tl[b], sizeof(int) * tcap); }
+                r->t0 = (int)tn; r->nt = nt;
+                /* keep, per touched pixel, whether it is still marked at the end: sign bit */
+                for (int i = 0; i < nt; i++) tl[b][tn++] = touched[i] | (L.used[touched[i]] == USED ? (int)0x40000000 : 0);
+            }
+        if (acc > stats[1]) stats[1] = acc;
+    }
+    /* ---- phase 2: commit in band order */
+    uint8_t *T = (uint8_t *)calloc(NP, 1), *S = (uint8_t *)malloc(NP), *D = (uint8_t *)malloc(NP);
+    rect_t *rects_par = (rect_t *)malloc(sizeof(rect_t) * NP / 4);
+    int nrect_par = 0;
+    for (int b = 0; b < nbands; b++) {
+        const int y0 = (int)((long)rows * b / nbands), y1 = (int)((long)rows * (b + 1) / nbands);
+        memset(S, 0, NP);
+        memcpy(D, T, NP);
+        int ri = 0;
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < W - 1; ++x) {
+                const int adx = y * W + x;
+                const band_rec *r = (ri < nrecs[b] && recs[b][ri].seed == adx) ? &recs[b][ri] : NULL;
+                if (r) ri++;
+                const int true_eff = T[adx] == NOTUSED && L.angles[adx] != NOTDEF;
+                if (!r && !true_eff) continue;
+                int valid = r && true_eff;
+                if (valid) {
+                    stats[5] += r->nt;
+                    for (int i = 0; i < r->nt && valid; i++) {
+                        const int q = tl[b][r->t0 + i] & 0x3FFFFFFF, qx = q % W, qy = q / W;
+                        for (int dy = -1; dy <= 1 && valid; dy++)
+                            for (int dx = -1; dx <= 1; dx++) {
+                                const int xx = qx + dx, yy = qy + dy;
+                                if (xx < 0 || yy < 0 || xx >= W || yy >= H) continue;
+                                if (D[(size_t)yy * W + xx]) { valid = 0; break; }
+                            }
+                    }
+                }
+                if (valid) {   /* commit the speculative marks and rectangle */
+                    for (int i = 0; i < r->nt; i++) { const int e = tl[b][r->t0 + i]; if (e & 0x40000000) { T[e & 0x3FFFFFFF] = USED; S[e & 0x3FFFFFFF] = USED; } }
+                    if (r->has_rect) rects_par[nrect_par++] = r->rec;
+                    continue;
+                }
+                if (r)   /* the speculative timeline moves on with its own marks */
+                    for (int i = 0; i < r->nt; i++) { const int e = tl[b][r->t0 + i]; if (e & 0x40000000) { const int q = e & 0x3FFFFFFF; S[q] = USED; D[q] = S[q] != T[q]; } }
+                if (true_eff) {   /* grow on the true state */
+                    int nt; rect_t rec;
+                    L.used = T;
+                    stats[4]++;
+                    if (run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &stats[2])) rects_par[nrect_par++] = rec;
+                    for (int i = 0; i < nt; i++) D[touched[i]] = S[touched[i]] != T[touched[i]];
+                }
+            }
+    }
+    stats[6] = nrect_par == nrect_serial && memcmp(T, used_serial, NP) == 0 && memcmp(rects_par, rects_serial, sizeof(rect_t) * nrect_serial) == 0;
+    stats[7] = nrect_serial;
+    for (int b = 0; b < nbands; b++) { free(recs[b]); free(tl[b]); }
+    free(recs); free(nrecs); free(tl); free(priv); free(T); free(S); free(D); free(rects_par); free(rects_serial); free(used_serial);
+    free(reg); free(touched); free(L.img); free(L.angles); free(L.modgrad);
+    return (int)stats[6];
 }
 
 /* cv::line_descriptor::LSDDetector::detectImpl KeyLine fill (octave 0, octaveScale = 1) */
