@@ -30,8 +30,16 @@ __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, flo
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
 
+struct SpecRec { int seed, t0, nt, has_rect; LsdRect rec; };
+struct SpecBufs { uint32_t *rxy; uint32_t *tl; SpecRec *recs; int *cnt; uint32_t *seedmap; uint32_t *tl2; int tcap, rcap_rec, nbands, bm_words; };
+__global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
+__global__ void k_lsd_spec_commit(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
+
 struct plf_line {
     plf_line_params prm;
+    SpecBufs spec;            // banded speculative region growing (few frames in flight); allocated on first use
+    int spec_frames;          // frames the buffers were sized for (0: not allocated, -1: allocation failed / disabled)
+    int *d_spec_stats;
     int device;
     LsdGeom g;
     LsdTaps taps;
@@ -80,6 +88,8 @@ static void line_free(plf_line *h)
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->d_spec_stats};
+    for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
     if (h->ev_front) (void)hipEventDestroy(h->ev_front);
@@ -242,6 +252,8 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
     (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_grow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
@@ -297,7 +309,34 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
     static const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;
-    if (B <= lat_max)
+    static const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : 8;
+    const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
+    const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + 3 * bm_words) * 4;
+    bool spec = !seeds && spec_bands >= 2 && spec_bands <= 64 && B <= lat_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
+    if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
+        // (re)allocate for lat_max frames of the current geometry
+        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->d_spec_stats};
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        for (void *q : old) if (q) (void)hipFree(q);
+        memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
+        const size_t Fr = (size_t)(lat_max > B ? lat_max : B), K = (size_t)spec_bands;
+        h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192;
+        bool ok = hipMalloc((void **)&h->spec.rxy, Fr * K * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.tl, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.recs, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.cnt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.seedmap, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.tl2, Fr * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->d_spec_stats, Fr * 2 * sizeof(int)) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; }
+        else h->spec_frames = (int)Fr;
+    }
+    if (spec) {
+        PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
+        hipLaunchKernelGGL(k_lsd_spec_commit, dim3(B), dim3(64), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
+                           h->spec, h->d_spec_stats);
+    } else if (B <= lat_max)
         hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
     else

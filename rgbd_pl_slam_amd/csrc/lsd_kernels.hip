@@ -198,6 +198,9 @@ struct RegCtx {
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
     int eager;                 // few frames in flight (latency mode): fetch the cos/sin increment together with the angle word
+    int use_bm;                // speculative mode: the USED flags live in an LDS bitmap (bm), the angle words are read-only
+    LDS_PTR(uint32_t) bm;
+    int regrow_n;              // size of the list refine() regrew (-1: it did not regrow)
 };
 
 #ifdef PLF_LSD_TIMING
@@ -212,10 +215,27 @@ __device__ long long g_lsd_t[16];
 #endif
 #define CBAR() asm volatile("" ::: "memory")   // single-wave kernel: LDS ops stay in program order; only the compiler must not reorder
 
-__device__ __forceinline__ uint32_t ang_load(const RegCtx &C, int a) { return __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (bitmap mode returns the same word the flag-in-sign-bit mode would hold: every caller is unchanged)
+__device__ __forceinline__ uint32_t ang_load(const RegCtx &C, int a)
+{
+    if (C.use_bm) {
+        uint32_t w = C.ang[a];
+        if ((C.bm[a >> 5] >> (a & 31)) & 1u) w |= 0x80000000u;
+        return w;
+    }
+    return __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ float ang_value(uint32_t w) { return __uint_as_float(w & 0x7FFFFFFFu); }   // of a defined pixel
-__device__ __forceinline__ void used_set(RegCtx &C, int a) { __hip_atomic_fetch_or(&C.ang[a], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void used_clr(RegCtx &C, int a) { __hip_atomic_fetch_and(&C.ang[a], 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void used_set(RegCtx &C, int a)
+{
+    if (C.use_bm) { __hip_atomic_fetch_or(&C.bm[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+    __hip_atomic_fetch_or(&C.ang[a], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void used_clr(RegCtx &C, int a)
+{
+    if (C.use_bm) { __hip_atomic_fetch_and(&C.bm[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+    __hip_atomic_fetch_and(&C.ang[a], 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t rxy_get(const RegCtx &C, int i)
 {
     uint32_t v = C.rxy_l[i < C.rcap ? i : 0];   // always an LDS read
@@ -556,6 +576,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
     n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
+    C.regrow_n = n;
     if (n < 2) return false;
     region2rect(C, n, reg_angle, prec, p, rec);
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -581,6 +602,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.rxy_l = (LDS_PTR(uint32_t))smem;
     C.rcap = g.rcap;
     C.eager = eager;
+    C.use_bm = 0; C.bm = (LDS_PTR(uint32_t))smem; C.regrow_n = -1;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
     // This wave is one long dependent chain; waves of other kernels sharing its SIMD only ever delay it.
     // Raise its issue priority so that co-running throughput kernels (ORB, matchers, NFA) fill the idle slots instead.
@@ -673,6 +695,238 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
         return;
     }
     regions_body(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Banded speculative region growing (few frames in flight).  The serial seed loop is exact but one wave retires it at
+// ~11 cycles per instruction; this is the same loop made parallel WITHOUT changing any result (model and proof by
+// execution: oracle/lsd_oracle.c, orc_lsd_band_speculation):
+//   k_lsd_spec_grow   one wave per (band of rows, frame): the whole per-seed pipeline over the band's seeds against a private,
+//                     initially empty USED bitmap in LDS.  Every effective seed leaves a record (seed, every pixel the pipeline
+//                     ever accepted, which of them are still marked, the rectangle if any).
+//   k_lsd_spec_commit one wave per frame walks the bands in order with T (true flags), S (the band's speculative flags replayed)
+//                     and D = S xor T in LDS: a record stands iff its seed is free in T and the 3x3 dilation of its accepted set
+//                     misses D -- then every flag it read had the true value and its marks / rectangle are copied; otherwise the
+//                     seed is regrown on T.  Seeds speculation skipped but that are free in T are grown as well.
+// Overflowing record buffers only disable the records of that frame: the commit kernel then IS the serial loop.
+// ------------------------------------------------------------------------------------------------
+struct SpecRec { int seed, t0, nt, has_rect; LsdRect rec; };
+struct SpecBufs {
+    uint32_t *rxy;      // [frame][band][s_stride] list overflow of the band waves
+    uint32_t *tl;       // [frame][band][tcap] accepted pixels (bit 30: still marked at the end of the seed)
+    SpecRec *recs;      // [frame][band][rcap_rec]
+    int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
+    uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
+    uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel
+    int tcap, rcap_rec, nbands, bm_words;
+};
+
+// append the current region list [0, n) as pixel indices
+__device__ __forceinline__ void spec_append(const RegCtx &C, int n, uint32_t *__restrict__ dst, int &tn, int cap, int &ovf)
+{
+    if (tn + n > cap) { ovf = 1; return; }
+    for (int i = plf_lane(); i < n; i += 64) { const uint32_t q = rxy_get(C, i); dst[tn + i] = (q >> 16) * (uint32_t)C.W + (q & 0xFFFFu); }
+    tn += n;
+}
+
+// the per-seed pipeline of the serial loop; the accepted pixels go to dst[t0 ..) (first growth, then the regrowth of refine)
+__device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th0, int seed, float sdeg, float2 sc0, LsdRect &rec, uint32_t *__restrict__ dst,
+                                          int &tn, int cap, int &ovf)
+{
+    double reg_angle;
+    int n = region_grow(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
+    CBAR();
+    spec_append(C, n, dst, tn, cap, ovf);
+    if (n < g.min_reg_size) return false;
+    region2rect(C, n, reg_angle, g.prec, g.p, rec);
+    C.regrow_n = -1;
+    const bool okr = refine(C, n, reg_angle, g.prec, g.p, rec, 0.7);
+    CBAR();
+    if (C.regrow_n >= 0) spec_append(C, C.regrow_n, dst, tn, cap, ovf);   // (reduce_region_radius only permutes that list)
+    return okr;
+}
+
+__device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, float *ang_all, const double *modgrad_all, const double2 *cs_all, const float2 *cs0_all,
+                                         uint32_t *rxy_g, LDS_PTR(uint32_t) list, LDS_PTR(uint32_t) bm)
+{
+    C.W = g.sw; C.H = g.sh;
+    C.ang = reinterpret_cast<uint32_t *>(ang_all) + (size_t)f * g.s_stride;
+    C.modgrad = modgrad_all + (size_t)f * g.s_stride;
+    C.cs = cs_all + (size_t)f * g.s_stride;
+    C.cs0 = cs0_all + (size_t)f * g.s_stride;
+    C.rxy_l = list; C.rcap = g.rcap; C.rxy_g = rxy_g;
+    C.eager = 1; C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
+    C.cbase = -0x40000000; C.cused = 0ull;
+}
+
+__global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                      const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int band = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const int W = g.sw, H = g.sh, NP = W * H;
+    LDS_PTR(uint32_t) list = (LDS_PTR(uint32_t))smem;
+    LDS_PTR(uint32_t) bm = list + ((g.rcap + 1 + 15) & ~15);
+    for (int i = lane; i < SB.bm_words; i += 64) bm[i] = 0u;
+    CBAR();
+    const size_t fb = (size_t)f * SB.nbands + band;
+    RegCtx C;
+    spec_ctx(C, g, f, ang_all, modgrad_all, cs_all, cs0_all, SB.rxy + fb * g.s_stride, list, bm);
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t *tl = SB.tl + fb * SB.tcap;
+    SpecRec *recs = SB.recs + fb * SB.rcap_rec;
+    uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
+    const GrowTh th0 = grow_thresholds(g.prec);
+    const int rows = H - 1;   // (the last row and column are NOTDEF)
+    const int y0 = (int)((long long)rows * band / SB.nbands), y1 = (int)((long long)rows * (band + 1) / SB.nbands);
+    int nrec = 0, tn = 0, ovf = 0;
+    for (int base = y0 * W; base < y1 * W; base += 64) {
+        const int px = base + lane;
+        uint32_t w = px < y1 * W ? ang_load(C, px) : 0xFFFFFFFFu;
+        bool ok = w < 0x80000000u;
+        float2 c0 = make_float2(0.f, 0.f);
+        if (ok) c0 = C.cs0[px];
+        unsigned long long mask = __ballot(ok);
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            const int seed = base + j;
+            const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(__uint_as_float(w)), j));
+            const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
+                                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
+            LsdRect rec;
+            const int t0 = tn;
+            const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf);
+            if (nrec >= SB.rcap_rec) ovf = 1;
+            if (!ovf) {
+                for (int i = t0 + lane; i < tn; i += 64) { const uint32_t q = tl[i]; if ((bm[q >> 5] >> (q & 31)) & 1u) tl[i] = q | 0x40000000u; }
+                if (lane == 0) {
+                    SpecRec r; r.seed = seed; r.t0 = t0; r.nt = tn - t0; r.has_rect = okr ? 1 : 0; r.rec = rec;
+                    recs[nrec] = r;
+                    atomicOr(&seedmap[seed >> 5], 1u << (seed & 31));
+                }
+                nrec++;
+            }
+            CBAR();
+            w = px < y1 * W ? ang_load(C, px) : 0xFFFFFFFFu;   // flags from the bitmap: cheap, always current
+            ok = ok && lane > j && w < 0x80000000u;
+            mask = __ballot(ok);
+        }
+    }
+    if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; }
+}
+
+__device__ __forceinline__ bool bm_get(LDS_PTR(uint32_t) b, int a) { return (b[a >> 5] >> (a & 31)) & 1u; }
+__device__ __forceinline__ void bm_set(LDS_PTR(uint32_t) b, int a) { __hip_atomic_fetch_or(&b[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void bm_put(LDS_PTR(uint32_t) b, int a, bool v)
+{
+    if (v) __hip_atomic_fetch_or(&b[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_and(&b[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                        const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                        int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int W = g.sw, H = g.sh;
+    LDS_PTR(uint32_t) list = (LDS_PTR(uint32_t))smem;
+    LDS_PTR(uint32_t) T = list + ((g.rcap + 1 + 15) & ~15);
+    LDS_PTR(uint32_t) S = T + SB.bm_words;
+    LDS_PTR(uint32_t) D = S + SB.bm_words;
+    for (int i = lane; i < SB.bm_words; i += 64) T[i] = 0u;
+    CBAR();
+    RegCtx C;
+    spec_ctx(C, g, f, ang_all, modgrad_all, cs_all, cs0_all, rxy_all + (size_t)f * g.s_stride, list, T);
+    __builtin_amdgcn_s_setprio(3);
+    LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
+    uint32_t *tl2 = SB.tl2 + (size_t)f * 2 * g.s_stride;
+    const uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
+    const GrowTh th0 = grow_thresholds(g.prec);
+    const int rows = H - 1;
+    int use_recs = 1;
+    for (int b = 0; b < SB.nbands; b++) if (SB.cnt[((size_t)f * SB.nbands + b) * 4 + 2]) use_recs = 0;
+    int nr = 0, n_commit = 0, n_redo = 0;
+    for (int band = 0; band < SB.nbands; band++) {
+        const size_t fb = (size_t)f * SB.nbands + band;
+        const uint32_t *tl = SB.tl + fb * SB.tcap;
+        const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
+        const int y0 = (int)((long long)rows * band / SB.nbands), y1 = (int)((long long)rows * (band + 1) / SB.nbands);
+        for (int i = lane; i < SB.bm_words; i += 64) { S[i] = 0u; D[i] = T[i]; }
+        CBAR();
+        int ri = 0;
+        for (int base = y0 * W; base < y1 * W; base += 64) {
+            const int px = base + lane;
+            const bool inb = px < y1 * W;
+            const uint32_t w = inb ? C.ang[px] : 0xFFFFFFFFu;      // angle word itself (flags are in T)
+            const bool defined = w < 0x80000000u;
+            float2 c0 = make_float2(0.f, 0.f);
+            if (defined) c0 = C.cs0[px];
+            const bool isrec = use_recs && inb && ((seedmap[px >> 5] >> (px & 31)) & 1u);
+            unsigned long long todo = __ballot(isrec || (defined && !bm_get(T, px)));
+            const unsigned long long recm = __ballot(isrec);
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int seed = base + j;
+                const bool has_r = (recm >> j) & 1ull;
+                const int rj = ri;
+                if (has_r) ri++;
+                const bool defined_j = (__ballot(defined) >> j) & 1ull;
+                const bool true_eff = defined_j && !bm_get(T, seed);
+                if (!has_r && !true_eff) continue;   // taken by a region committed since the chunk was loaded
+                int t0 = 0, nt = 0, has_rect = 0;
+                if (has_r) { t0 = recs[rj].t0; nt = recs[rj].nt; has_rect = recs[rj].has_rect; }
+                bool valid = has_r && true_eff;
+                if (valid) {
+                    for (int i0 = 0; i0 < nt && valid; i0 += 64) {
+                        const int i = i0 + lane;
+                        bool hit = false;
+                        if (i < nt) {
+                            const int q = (int)(tl[t0 + i] & 0x3FFFFFFFu), qx = q % W, qy = q / W;
+                            for (int dy = -1; dy <= 1; dy++) {
+                                const int yy = qy + dy;
+                                if (yy < 0 || yy >= H) continue;
+                                for (int dx = -1; dx <= 1; dx++) {
+                                    const int xx = qx + dx;
+                                    if (xx < 0 || xx >= W) continue;
+                                    hit |= bm_get(D, yy * W + xx);
+                                }
+                            }
+                        }
+                        if (__ballot(hit)) valid = false;
+                    }
+                }
+                if (valid) {   // every flag the speculative run read was the true one: take its marks and its rectangle
+                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
+                    if (has_rect) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = recs[rj].rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
+                    n_commit++;
+                    CBAR();
+                    continue;
+                }
+                if (has_r) {   // the speculative timeline keeps its own marks
+                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); bm_set(S, q); } }
+                    CBAR();
+                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); bm_put(D, q, !bm_get(T, q)); } }
+                    CBAR();
+                }
+                if (true_eff) {   // grow on the true flags
+                    const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(__uint_as_float(w)), j));
+                    const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
+                                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
+                    LsdRect rec;
+                    int tn = 0, ovf = 0;
+                    const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl2, tn, 2 * (int)g.s_stride, ovf);
+                    if (okr) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
+                    CBAR();
+                    for (int i = lane; i < tn; i += 64) { const int q = (int)tl2[i]; bm_put(D, q, bm_get(S, q) != bm_get(T, q)); }
+                    CBAR();
+                    n_redo++;
+                }
+            }
+        }
+    }
+    if (lane == 0) { nrect[f] = min(nr, g.rect_cap); if (stats) { stats[2 * f] = n_commit; stats[2 * f + 1] = n_redo; } }
 }
 
 #ifdef PLF_LSD_TIMING
