@@ -30,8 +30,9 @@ __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, flo
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
 
-struct SpecRec { int seed, t0, nt, has_rect; LsdRect rec; };
-struct SpecBufs { uint32_t *rxy; uint32_t *tl; SpecRec *recs; int *cnt; uint32_t *seedmap; uint32_t *tl2; int tcap, rcap_rec, nbands, bm_words; };
+struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };
+struct SpecBufs { uint32_t *rxy; uint32_t *tl; SpecRec *recs; int *cnt; uint32_t *seedmap; uint32_t *tl2; int *band_y; int tcap, rcap_rec, nbands, bm_words; };
+__global__ void k_lsd_spec_bands(const float *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_commit(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
 
@@ -88,7 +89,7 @@ static void line_free(plf_line *h)
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->d_spec_stats};
+    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->d_spec_stats};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -308,31 +309,35 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         seeds = h->d_keys[1];
     }
     // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
-    static const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;
-    static const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : 8;
+    const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;               // (read per call: test hooks)
+    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : 8;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
-    const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + 3 * bm_words) * 4;
-    bool spec = !seeds && spec_bands >= 2 && spec_bands <= 64 && B <= lat_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
+    const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
+    const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + 3 * bm_words + coarse_words) * 4 + 64;
+    bool spec = !seeds && (g.sw % 32) == 0 && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= lat_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
-        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->d_spec_stats};
+        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->d_spec_stats};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
         const size_t Fr = (size_t)(lat_max > B ? lat_max : B), K = (size_t)spec_bands;
         h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192;
+        if (const char *e = getenv("PLF_LSD_SPEC_RECCAP")) { if (atoi(e) >= 1 && atoi(e) <= 8192) h->spec.rcap_rec = atoi(e); }   // test hook: force the overflow fallback
         bool ok = hipMalloc((void **)&h->spec.rxy, Fr * K * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.recs, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.cnt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.seedmap, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl2, Fr * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
-                  hipMalloc((void **)&h->d_spec_stats, Fr * 2 * sizeof(int)) == hipSuccess;
+                  hipMalloc((void **)&h->spec.band_y, Fr * (K + 1) * sizeof(int)) == hipSuccess &&
+                  hipMalloc((void **)&h->d_spec_stats, Fr * 8 * sizeof(int)) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; }
         else h->spec_frames = (int)Fr;
     }
     if (spec) {
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(256), 0, s, h->d_ang, g, h->spec);
         hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
         hipLaunchKernelGGL(k_lsd_spec_commit, dim3(B), dim3(64), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
                            h->spec, h->d_spec_stats);
@@ -438,6 +443,14 @@ static void line_prof_collect(plf_line *h)
         }
     }
     h->prof_n = 0;
+}
+
+extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
+{
+    if (!h || !out8 || !h->d_spec_stats) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    PLF_HIP_TRY(hipMemcpy(out8, h->d_spec_stats, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    return PLF_OK;
 }
 
 extern "C" int plf_line_wait_front(plf_line *h, void *stream)

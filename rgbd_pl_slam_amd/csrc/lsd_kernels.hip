@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
 //                     seed is regrown on T.  Seeds speculation skipped but that are free in T are grown as well.
 // Overflowing record buffers only disable the records of that frame: the commit kernel then IS the serial loop.
 // ------------------------------------------------------------------------------------------------
-struct SpecRec { int seed, t0, nt, has_rect; LsdRect rec; };
+struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };   // b*: bounding box of the accepted pixels, dilated by one
 struct SpecBufs {
     uint32_t *rxy;      // [frame][band][s_stride] list overflow of the band waves
     uint32_t *tl;       // [frame][band][tcap] accepted pixels (bit 30: still marked at the end of the seed)
@@ -718,6 +718,7 @@ struct SpecBufs {
     int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
     uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
     uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel
+    int *band_y;        // [frame][nbands + 1]: first row of every band (balanced by the number of defined pixels)
     int tcap, rcap_rec, nbands, bm_words;
 };
 
@@ -759,6 +760,36 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.cbase = -0x40000000; C.cused = 0ull;
 }
 
+// rows of the bands: equal shares of the frame's defined pixels (the work of a band is roughly its number of accepted pixels),
+// boundaries on multiples of 8 rows so that a coarse dirty tile belongs to one band
+__global__ void __launch_bounds__(256) k_lsd_spec_bands(const float *__restrict__ ang_all, LsdGeom g, SpecBufs SB)
+{
+    __shared__ int cnt[1024];
+    const int f = blockIdx.x, t = threadIdx.x, W = g.sw, H = g.sh;
+    const uint32_t *ang = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
+    const int units = (H - 1 + 7) >> 3;   // 8-row units
+    for (int u = t; u < 1024; u += 256) cnt[u] = 0;
+    __syncthreads();
+    for (int a = t; a < W * (H - 1); a += 256) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) >> 3, 1023)], 1);
+    __syncthreads();
+    if (t == 0) {
+        int total = 0;
+        for (int u = 0; u < units; u++) total += cnt[u];
+        int *by = SB.band_y + f * (SB.nbands + 1);
+        by[0] = 0;
+        int acc = 0, u = 0;
+        for (int b = 1; b < SB.nbands; b++) {
+            const long long target = (long long)total * b / SB.nbands;
+            while (u < units && acc + cnt[u] / 2 < target) acc += cnt[u++];
+            const int umin = (by[b - 1] >> 3) + 1;          // every band owns at least one unit
+            const int uu = min(max(u, umin), units - (SB.nbands - b));
+            by[b] = min(uu * 8, H - 1);
+        }
+        by[SB.nbands] = H - 1;
+        for (int b = 1; b <= SB.nbands; b++) by[b] = max(by[b], by[b - 1]);
+    }
+}
+
 __global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                       const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB)
 {
@@ -777,8 +808,7 @@ __global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_al
     SpecRec *recs = SB.recs + fb * SB.rcap_rec;
     uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
     const GrowTh th0 = grow_thresholds(g.prec);
-    const int rows = H - 1;   // (the last row and column are NOTDEF)
-    const int y0 = (int)((long long)rows * band / SB.nbands), y1 = (int)((long long)rows * (band + 1) / SB.nbands);
+    const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
     int nrec = 0, tn = 0, ovf = 0;
     for (int base = y0 * W; base < y1 * W; base += 64) {
         const int px = base + lane;
@@ -798,9 +828,21 @@ __global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_al
             const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf);
             if (nrec >= SB.rcap_rec) ovf = 1;
             if (!ovf) {
-                for (int i = t0 + lane; i < tn; i += 64) { const uint32_t q = tl[i]; if ((bm[q >> 5] >> (q & 31)) & 1u) tl[i] = q | 0x40000000u; }
+                int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
+                for (int i = t0 + lane; i < tn; i += 64) {
+                    const uint32_t q = tl[i];
+                    const int qx = (int)(q % (uint32_t)W), qy = (int)(q / (uint32_t)W);
+                    bx0 = min(bx0, qx); bx1 = max(bx1, qx); by0 = min(by0, qy); by1 = max(by1, qy);
+                    if ((bm[q >> 5] >> (q & 31)) & 1u) tl[i] = q | 0x40000000u;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    bx0 = min(bx0, __shfl_xor(bx0, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64));
+                    bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
+                }
                 if (lane == 0) {
                     SpecRec r; r.seed = seed; r.t0 = t0; r.nt = tn - t0; r.has_rect = okr ? 1 : 0; r.rec = rec;
+                    r.bx0 = max(bx0 - 1, 0); r.by0 = max(by0 - 1, 0); r.bx1 = min(bx1 + 1, W - 1); r.by1 = min(by1 + 1, H - 1);
                     recs[nrec] = r;
                     atomicOr(&seedmap[seed >> 5], 1u << (seed & 31));
                 }
@@ -817,6 +859,11 @@ __global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_al
 
 __device__ __forceinline__ bool bm_get(LDS_PTR(uint32_t) b, int a) { return (b[a >> 5] >> (a & 31)) & 1u; }
 __device__ __forceinline__ void bm_set(LDS_PTR(uint32_t) b, int a) { __hip_atomic_fetch_or(&b[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void dc_mark(LDS_PTR(uint32_t) Dc, int a, int W, int ctx)
+{
+    const int t = ((a / W) >> 3) * ctx + ((a % W) >> 3);
+    __hip_atomic_fetch_or(&Dc[t >> 5], 1u << (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void bm_put(LDS_PTR(uint32_t) b, int a, bool v)
 {
     if (v) __hip_atomic_fetch_or(&b[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -834,6 +881,9 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
     LDS_PTR(uint32_t) T = list + ((g.rcap + 1 + 15) & ~15);
     LDS_PTR(uint32_t) S = T + SB.bm_words;
     LDS_PTR(uint32_t) D = S + SB.bm_words;
+    // sticky coarse map of D: one bit per 8x8-pixel tile (set when a D bit of the tile is set, rebuilt per band)
+    const int ctx = (W + 7) >> 3, cty = (H + 7) >> 3, cwords = (ctx * cty + 31) >> 5;
+    LDS_PTR(uint32_t) Dc = D + SB.bm_words;
     for (int i = lane; i < SB.bm_words; i += 64) T[i] = 0u;
     CBAR();
     RegCtx C;
@@ -843,17 +893,26 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
     uint32_t *tl2 = SB.tl2 + (size_t)f * 2 * g.s_stride;
     const uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
     const GrowTh th0 = grow_thresholds(g.prec);
-    const int rows = H - 1;
     int use_recs = 1;
     for (int b = 0; b < SB.nbands; b++) if (SB.cnt[((size_t)f * SB.nbands + b) * 4 + 2]) use_recs = 0;
-    int nr = 0, n_commit = 0, n_redo = 0;
+    int nr = 0, n_commit = 0, n_redo = 0, n_fast = 0, n_slow = 0;
+    long long c_redo = 0, c_val = 0, c_setup = 0;
+    const long long c_t0 = clock64();
     for (int band = 0; band < SB.nbands; band++) {
+        const long long c_s0 = clock64();
         const size_t fb = (size_t)f * SB.nbands + band;
         const uint32_t *tl = SB.tl + fb * SB.tcap;
         const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
-        const int y0 = (int)((long long)rows * band / SB.nbands), y1 = (int)((long long)rows * (band + 1) / SB.nbands);
+        const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
         for (int i = lane; i < SB.bm_words; i += 64) { S[i] = 0u; D[i] = T[i]; }
+        for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
         CBAR();
+        for (int a0 = lane * 8; a0 < W * H; a0 += 64 * 8) {   // 8 pixels of one row at a time (W is a multiple of 32 on this path)
+            const uint32_t bits = (T[a0 >> 5] >> (a0 & 31)) & 0xFFu;
+            if (bits) { const int t = ((a0 / W) >> 3) * ctx + ((a0 % W) >> 3); __hip_atomic_fetch_or(&Dc[t >> 5], 1u << (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        }
+        CBAR();
+        c_setup += clock64() - c_s0;
         int ri = 0;
         for (int base = y0 * W; base < y1 * W; base += 64) {
             const int px = base + lane;
@@ -865,6 +924,36 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
             const bool isrec = use_recs && inb && ((seedmap[px >> 5] >> (px & 31)) & 1u);
             unsigned long long todo = __ballot(isrec || (defined && !bm_get(T, px)));
             const unsigned long long recm = __ballot(isrec);
+            // fast path: no dirty pixel in the chunk that could become a seed of its own, and every record of the chunk stays clear of the
+            // dirty tiles -> all of them stand; their marks (one contiguous range of the accepted-pixel log) and rectangles are copied at once
+            const bool seedless = !__ballot(inb && defined && !isrec && bm_get(D, px) && !bm_get(T, px));   // (a dirty pixel that is used in T cannot seed anything)
+            if (recm && seedless) {
+                const int cnt = __popcll(recm);
+                bool clean = true;
+                int has_rect = 0;
+                if (lane < cnt) {
+                    const SpecRec *r = &recs[ri + lane];
+                    has_rect = r->has_rect;
+                    const int tx0 = r->bx0 >> 3, tx1 = r->bx1 >> 3, ty0 = r->by0 >> 3, ty1 = r->by1 >> 3;
+                    for (int ty = ty0; ty <= ty1 && clean; ty++)
+                        for (int tx = tx0; tx <= tx1; tx++) { const int t = ty * ctx + tx; if ((Dc[t >> 5] >> (t & 31)) & 1u) { clean = false; break; } }
+                }
+                if (!__ballot(!clean)) {
+                    const int t_begin = recs[ri].t0, t_end = recs[ri + cnt - 1].t0 + recs[ri + cnt - 1].nt;
+                    for (int i = t_begin + lane; i < t_end; i += 64) { const uint32_t e = tl[i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
+                    const unsigned long long rm = __ballot(has_rect != 0);
+                    if (has_rect) {
+                        const int slot = nr + __popcll(rm & ((1ull << lane) - 1ull));
+                        if (slot < g.rect_cap) rects[slot] = recs[ri + lane].rec; else atomicOr(status, 1);
+                    }
+                    nr += __popcll(rm);
+                    n_commit += cnt;
+                    n_fast++;
+                    ri += cnt;
+                    CBAR();
+                    continue;
+                }
+            }
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -878,6 +967,8 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
                 int t0 = 0, nt = 0, has_rect = 0;
                 if (has_r) { t0 = recs[rj].t0; nt = recs[rj].nt; has_rect = recs[rj].has_rect; }
                 bool valid = has_r && true_eff;
+                const long long c_v0 = clock64();
+                if (has_r) n_slow++;
                 if (valid) {
                     for (int i0 = 0; i0 < nt && valid; i0 += 64) {
                         const int i = i0 + lane;
@@ -897,6 +988,7 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
                         if (__ballot(hit)) valid = false;
                     }
                 }
+                c_val += clock64() - c_v0;
                 if (valid) {   // every flag the speculative run read was the true one: take its marks and its rectangle
                     for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
                     if (has_rect) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = recs[rj].rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
@@ -907,7 +999,7 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
                 if (has_r) {   // the speculative timeline keeps its own marks
                     for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); bm_set(S, q); } }
                     CBAR();
-                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); bm_put(D, q, !bm_get(T, q)); } }
+                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); const bool d = !bm_get(T, q); bm_put(D, q, d); if (d) dc_mark(Dc, q, W, ctx); } }
                     CBAR();
                 }
                 if (true_eff) {   // grow on the true flags
@@ -916,17 +1008,25 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
                                                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
                     LsdRect rec;
                     int tn = 0, ovf = 0;
+                    const long long c_r0 = clock64();
                     const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl2, tn, 2 * (int)g.s_stride, ovf);
+                    c_redo += clock64() - c_r0;
                     if (okr) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
                     CBAR();
-                    for (int i = lane; i < tn; i += 64) { const int q = (int)tl2[i]; bm_put(D, q, bm_get(S, q) != bm_get(T, q)); }
+                    for (int i = lane; i < tn; i += 64) { const int q = (int)tl2[i]; const bool d = bm_get(S, q) != bm_get(T, q); bm_put(D, q, d); if (d) dc_mark(Dc, q, W, ctx); }
                     CBAR();
                     n_redo++;
                 }
             }
         }
     }
-    if (lane == 0) { nrect[f] = min(nr, g.rect_cap); if (stats) { stats[2 * f] = n_commit; stats[2 * f + 1] = n_redo; } }
+    if (lane == 0) {
+        nrect[f] = min(nr, g.rect_cap);
+        if (stats) {
+            int *st = stats + 8 * f;
+            st[0] = n_commit; st[1] = n_redo; st[2] = n_fast; st[3] = n_slow; st[4] = (int)(c_redo >> 10); st[5] = (int)(c_val >> 10); st[6] = (int)((clock64() - c_t0) >> 10); st[7] = (int)(c_setup >> 10);
+        }
+    }
 }
 
 #ifdef PLF_LSD_TIMING

@@ -149,3 +149,38 @@ def test_line_and_matcher_errors():
     assert L.lib().plf_match_bow_kf(m._h, C.byref(view), 1, C.c_float(0.7), 1, L.vp(z), 256, L.vp(z), None) == L.PLF_E_BADARG  # f_has_mp missing
     m.close()
 
+
+
+@pytest.mark.parametrize("bands", [2, 5, 8, 13, 32])
+def test_lines_speculative_bands(monkeypatch, bands):
+    """banded speculative region growing (<= 8 frames in flight) with different band counts: same bits as the serial oracle"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame, synth_batch
+    monkeypatch.setenv("PLF_LSD_SPEC_BANDS", str(bands))
+    ext = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=4)
+    for seed in (6, 7, 8):
+        _check(synth_frame(seed), 100, ext=ext)
+    rng = np.random.default_rng(bands)
+    img = (rng.integers(0, 256, (480, 640)) // 64 * 64).astype(np.uint8)          # blocky noise: thousands of tiny regions
+    _check(img, 100, ext=ext)
+    grad = np.add.outer(np.arange(480), np.arange(640)).astype(np.float64)
+    _check(((np.sin(grad / 17.0) * 0.5 + 0.5) * 255).astype(np.uint8), 100, ext=ext)  # long diagonal regions crossing every band
+    imgs = synth_batch(40 + bands, 4)
+    res = ext.extract_batch(imgs)
+    for f in range(4):
+        ref = orc.line_extract(imgs[f], 100)
+        assert np.array_equal(res[f][1], ref["desc"])
+        assert np.array_equal(res[f][0]["startPointX"].view(np.uint32), ref["kl"]["startPointX"].view(np.uint32))
+    ext.close()
+
+
+def test_lines_speculative_overflow_falls_back(monkeypatch):
+    """record buffers too small: the commit kernel ignores the records and runs the serial loop itself"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    monkeypatch.setenv("PLF_LSD_SPEC_RECCAP", "4")
+    ext = LineSegment(nlines=100, max_width=640, max_height=480)
+    _check(synth_frame(9), 100, ext=ext)
+    ext.close()
