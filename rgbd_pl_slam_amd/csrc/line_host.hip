@@ -311,17 +311,21 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
     const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;               // (read per call: test hooks)
     const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : 8;
+    // measured on one MI355X (VGA): speculation wins up to ~256 frames in flight (5.4k vs 4.0k frames/s), ties at 512, loses beyond
+    const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 256;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + 3 * bm_words + coarse_words) * 4 + 64;
-    bool spec = !seeds && (g.sw % 32) == 0 && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= lat_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
+    bool spec = !seeds && (g.sw % 32) == 0 && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->d_spec_stats};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
-        const size_t Fr = (size_t)(lat_max > B ? lat_max : B), K = (size_t)spec_bands;
+        size_t Fr = 8;   // frames the buffers are sized for: the batch rounded up to a power of two (~23 MB per VGA frame)
+        while (Fr < (size_t)B) Fr <<= 1;
+        const size_t K = (size_t)spec_bands;
         h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192;
         if (const char *e = getenv("PLF_LSD_SPEC_RECCAP")) { if (atoi(e) >= 1 && atoi(e) <= 8192) h->spec.rcap_rec = atoi(e); }   // test hook: force the overflow fallback
         bool ok = hipMalloc((void **)&h->spec.rxy, Fr * K * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
