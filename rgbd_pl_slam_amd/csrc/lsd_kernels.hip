@@ -927,32 +927,76 @@ __global__ void __launch_bounds__(64) k_lsd_spec_commit(float *__restrict__ ang_
             // fast path: no dirty pixel in the chunk that could become a seed of its own, and every record of the chunk stays clear of the
             // dirty tiles -> all of them stand; their marks (one contiguous range of the accepted-pixel log) and rectangles are copied at once
             const bool seedless = !__ballot(inb && defined && !isrec && bm_get(D, px) && !bm_get(T, px));   // (a dirty pixel that is used in T cannot seed anything)
+            // Chunk-at-a-time path (no dirty pixel of the chunk can become a seed of its own): lane i holds the header of the chunk's i-th record.
+            // Records clear of the dirty tiles stand as they are; the others are checked pixel by pixel, all at once (their accepted-pixel logs are
+            // one contiguous range).  Everything before the first record that fails is committed in bulk; the rest of the chunk goes through the
+            // one-at-a-time loop below.
             if (recm && seedless) {
                 const int cnt = __popcll(recm);
                 bool clean = true;
-                int has_rect = 0;
+                int h_t0 = 0, h_nt = 0, h_rect = 0;
                 if (lane < cnt) {
                     const SpecRec *r = &recs[ri + lane];
-                    has_rect = r->has_rect;
+                    h_t0 = r->t0; h_nt = r->nt; h_rect = r->has_rect;
                     const int tx0 = r->bx0 >> 3, tx1 = r->bx1 >> 3, ty0 = r->by0 >> 3, ty1 = r->by1 >> 3;
                     for (int ty = ty0; ty <= ty1 && clean; ty++)
                         for (int tx = tx0; tx <= tx1; tx++) { const int t = ty * ctx + tx; if ((Dc[t >> 5] >> (t & 31)) & 1u) { clean = false; break; } }
                 }
-                if (!__ballot(!clean)) {
-                    const int t_begin = recs[ri].t0, t_end = recs[ri + cnt - 1].t0 + recs[ri + cnt - 1].nt;
-                    for (int i = t_begin + lane; i < t_end; i += 64) { const uint32_t e = tl[i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
-                    const unsigned long long rm = __ballot(has_rect != 0);
-                    if (has_rect) {
+                const unsigned long long dirtym = __ballot(!clean);
+                const int t_begin = __builtin_amdgcn_readlane(h_t0, 0);
+                const int t_end = __builtin_amdgcn_readlane(h_t0, cnt - 1) + __builtin_amdgcn_readlane(h_nt, cnt - 1);
+                int first_bad = cnt;
+                if (dirtym) {
+                    const long long c_v0 = clock64();
+                    const int kd = __ffsll((long long)dirtym) - 1;
+                    for (int i0 = __builtin_amdgcn_readlane(h_t0, kd); i0 < t_end && first_bad == cnt; i0 += 64) {
+                        const int i = i0 + lane;
+                        int myk = 64;
+                        if (i < t_end) {
+                            int k = 0;
+                            for (int c = 1; c < cnt; c++) k += (i >= __builtin_amdgcn_readlane(h_t0, c)) ? 1 : 0;
+                            if ((dirtym >> k) & 1ull) {
+                                const int q = (int)(tl[i] & 0x3FFFFFFFu), qx = q % W, qy = q / W;
+                                bool hit = false;
+                                for (int dy = -1; dy <= 1; dy++) {
+                                    const int yy = qy + dy;
+                                    if (yy < 0 || yy >= H) continue;
+                                    for (int dx = -1; dx <= 1; dx++) {
+                                        const int xx = qx + dx;
+                                        if (xx < 0 || xx >= W) continue;
+                                        hit |= bm_get(D, yy * W + xx);
+                                    }
+                                }
+                                if (hit) myk = k;
+                            }
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) myk = min(myk, __shfl_xor(myk, o, 64));
+                        if (myk < 64) first_bad = myk;
+                    }
+                    c_val += clock64() - c_v0;
+                    n_slow += __popcll(dirtym);
+                }
+                if (first_bad > 0) {
+                    const int t_stop = first_bad < cnt ? __builtin_amdgcn_readlane(h_t0, first_bad) : t_end;
+                    for (int i = t_begin + lane; i < t_stop; i += 64) { const uint32_t e = tl[i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
+                    const unsigned long long rm = __ballot(h_rect != 0 && lane < first_bad);
+                    if (h_rect && lane < first_bad) {
                         const int slot = nr + __popcll(rm & ((1ull << lane) - 1ull));
                         if (slot < g.rect_cap) rects[slot] = recs[ri + lane].rec; else atomicOr(status, 1);
                     }
                     nr += __popcll(rm);
-                    n_commit += cnt;
+                    n_commit += first_bad;
                     n_fast++;
-                    ri += cnt;
+                    ri += first_bad;
                     CBAR();
-                    continue;
                 }
+                if (first_bad == cnt) continue;
+                // the rest of the chunk, from the seed of the failing record on, one seed at a time
+                unsigned long long mm = recm;
+                for (int c = 0; c < first_bad; c++) mm &= mm - 1;
+                const int pos = __ffsll((long long)mm) - 1;
+                todo &= ~((1ull << pos) - 1ull);
             }
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
