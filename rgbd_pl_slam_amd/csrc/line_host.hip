@@ -343,7 +343,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(256), 0, s, h->d_ang, g, h->spec);
         hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
-        hipLaunchKernelGGL(k_lsd_spec_commit, dim3(B), dim3(64), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
+        hipLaunchKernelGGL(k_lsd_spec_commit, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
                            h->spec, h->d_spec_stats);
     } else if (B <= lat_max)
         hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
