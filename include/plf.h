@@ -136,6 +136,11 @@ int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int
  * the front stages.  No-op if no batch was enqueued yet. */
 int plf_line_wait_front(plf_line *h, void *stream);
 
+/* Diagnostics of the banded speculative region growing used for <= 256 frames in flight, frame 0 of the last batch:
+ * out8 = {regions committed from the speculation, regions grown by the commit wave, chunks committed in one step, records checked pixel by pixel,
+ * kilo-cycles spent regrowing, validating, in total, in per-band setup}.  PLF_E_BADARG if the path has not run on this handle. */
+int plf_line_debug_spec_stats(plf_line *h, int32_t *out8);
+
 /* Measurement hook (bench.py roofline): when enabled, every launch of the region-growing kernel -- the dominant
  * kernel of the whole front-end -- is bracketed by HIP events on the stream it is launched on.  The call
  * synchronises, then returns the accumulated kernel milliseconds and the number of launches since the last reset. */
