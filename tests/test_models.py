@@ -35,3 +35,24 @@ def test_parallel_octree_model_matches_oracle_random(seed):
     ref = orc.distribute_octree(k, 16, 16 + W, 16, 16 + H, N)["class_id"]
     out = octree_model(k[:, 0].copy(), k[:, 1].copy(), k[:, 2].copy(), 16, 16 + W, 16, 16 + H, N)
     assert out.tolist() == ref.tolist()
+
+
+def test_banded_speculative_region_growing_model_is_exact():
+    """CPU model of the scheme behind k_lsd_spec_grow / k_lsd_spec_commit (oracle/lsd_oracle.c: orc_lsd_band_speculation): for every band
+    count the committed USED map and the rectangles equal the serial seed loop's bit for bit, and only a small share of the work is redone."""
+    import ctypes as C
+    import orc
+    from rgbd_pl_slam_amd.synth import synth_frame
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    imgs = [synth_frame(11), (rng.integers(0, 256, (480, 640)) // 64 * 64).astype(np.uint8)]
+    for img in imgs:
+        img = np.ascontiguousarray(img)
+        for nb in (1, 3, 8, 20):
+            st = (C.c_long * 8)()
+            ok = L.orc_lsd_band_speculation(img.ctypes.data_as(C.c_void_p), 640, 480, C.c_ssize_t(640), nb, st)
+            assert ok == 1 and st[6] == 1, (nb, list(st))
+            if nb == 1:
+                assert st[2] == 0 and st[4] == 0          # a single band is the serial loop: nothing to redo
+            if nb == 8:
+                assert st[2] < 0.25 * st[0]               # redone accept steps stay a small share
