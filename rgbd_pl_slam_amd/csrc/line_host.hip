@@ -31,7 +31,8 @@ __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeo
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
 
 struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };
-struct SpecBufs { uint32_t *rxy; uint32_t *tl; SpecRec *recs; int *cnt; uint32_t *seedmap; uint32_t *tl2; int *band_y; int tcap, rcap_rec, nbands, bm_words; };
+struct SpecBufs { uint32_t *rxy; uint32_t *tl; SpecRec *recs; int *cnt; uint32_t *seedmap; uint32_t *tl2; int *band_y; int *done; float stagger; int tcap, rcap_rec, nbands, bm_words; };
+__global__ void k_lsd_spec_fused(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
 __global__ void k_lsd_spec_bands(const float *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_commit(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
@@ -89,7 +90,7 @@ static void line_free(plf_line *h)
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->d_spec_stats};
+    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->d_spec_stats};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -255,6 +256,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_grow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
@@ -319,7 +321,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     bool spec = !seeds && (g.sw % 32) == 0 && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
-        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->d_spec_stats};
+        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->d_spec_stats};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
@@ -335,16 +337,27 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.seedmap, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl2, Fr * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.band_y, Fr * (K + 1) * sizeof(int)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.done, Fr * K * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->d_spec_stats, Fr * 8 * sizeof(int)) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; }
         else h->spec_frames = (int)Fr;
     }
     if (spec) {
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
+        PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
+        // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
+        // finish, and the bands are staggered for that; otherwise two launches with equal bands
+        const bool fused = (size_t)B * (spec_bands + 1) <= 448 && !getenv("PLF_LSD_SPEC_NOFUSE");
+        h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.35f) : 0.f;
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(256), 0, s, h->d_ang, g, h->spec);
+        if (fused) {
+            hipLaunchKernelGGL(k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
+                               status, g, h->spec, h->d_spec_stats, B);
+        } else {
         hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
         hipLaunchKernelGGL(k_lsd_spec_commit, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
                            h->spec, h->d_spec_stats);
+        }
     } else if (B <= lat_max)
         hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);

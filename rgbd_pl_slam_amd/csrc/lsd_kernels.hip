@@ -718,7 +718,9 @@ struct SpecBufs {
     int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
     uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
     uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel
-    int *band_y;        // [frame][nbands + 1]: first row of every band (balanced by the number of defined pixels)
+    int *band_y;        // [frame][nbands + 1]: first row of every band (shares of the frame's defined pixels)
+    int *done;          // [frame][band]: set (release) when the band wave has written its log; the commit wave waits for it (acquire)
+    float stagger;      // band b gets a share proportional to 1 + stagger * b: early bands finish early, the commit wave follows them
     int tcap, rcap_rec, nbands, bm_words;
 };
 
@@ -779,7 +781,9 @@ __global__ void __launch_bounds__(256) k_lsd_spec_bands(const float *__restrict_
         by[0] = 0;
         int acc = 0, u = 0;
         for (int b = 1; b < SB.nbands; b++) {
-            const long long target = (long long)total * b / SB.nbands;
+            // cumulative share of bands 0..b-1 with weights 1 + stagger * i
+            const float K = (float)SB.nbands, wsum = K + SB.stagger * K * (K - 1.f) * 0.5f, wcum = (float)b + SB.stagger * (float)b * (float)(b - 1) * 0.5f;
+            const long long target = (long long)((double)total * (double)(wcum / wsum));
             while (u < units && acc + cnt[u] / 2 < target) acc += cnt[u++];
             const int umin = (by[b - 1] >> 3) + 1;          // every band owns at least one unit
             const int uu = min(max(u, umin), units - (SB.nbands - b));
@@ -790,12 +794,12 @@ __global__ void __launch_bounds__(256) k_lsd_spec_bands(const float *__restrict_
     }
 }
 
-__global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
-                                                      const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB)
+__device__ __forceinline__ void spec_grow_body(int band, int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                               const float2 *__restrict__ cs0_all, const LsdGeom &g, const SpecBufs &SB)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int band = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-    const int W = g.sw, H = g.sh, NP = W * H;
+    const int lane = threadIdx.x;
+    const int W = g.sw, H = g.sh;
     LDS_PTR(uint32_t) list = (LDS_PTR(uint32_t))smem;
     LDS_PTR(uint32_t) bm = list + ((g.rcap + 1 + 15) & ~15);
     for (int i = lane; i < SB.bm_words; i += 64) bm[i] = 0u;
@@ -855,6 +859,14 @@ __global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_al
         }
     }
     if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; }
+    __threadfence();   // every lane's log entries are visible device-wide before the flag
+    if (lane == 0) __hip_atomic_store(&SB.done[fb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                      const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB)
+{
+    spec_grow_body(blockIdx.x, blockIdx.y, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
 }
 
 __device__ __forceinline__ bool bm_get(LDS_PTR(uint32_t) b, int a) { return (b[a >> 5] >> (a & 31)) & 1u; }
@@ -870,21 +882,27 @@ __device__ __forceinline__ void bm_put(LDS_PTR(uint32_t) b, int a, bool v)
     else __hip_atomic_fetch_and(&b[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
-                                                        const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
-                                                        int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
+__device__ __forceinline__ void spec_wait_band(const SpecBufs &SB, size_t fb)
+{
+    while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+    __threadfence();
+}
+
+__device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                 const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                 int *__restrict__ nrect, int *__restrict__ status, const LsdGeom &g, const SpecBufs &SB, int *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int f = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int W = g.sw, H = g.sh;
     if (threadIdx.x >= 64) {
         // waves 1..3 only pull what the commit wave will read (written by the band waves on other XCDs) into this XCD's L2, then leave
         const int t = threadIdx.x - 64;
         uint32_t acc = 0;
         const uint32_t *sm = SB.seedmap + (size_t)f * SB.bm_words;
-        for (int i = t * 32; i < SB.bm_words; i += 192 * 32) acc ^= sm[i];
         for (int b = 0; b < SB.nbands; b++) {
             const size_t fb = (size_t)f * SB.nbands + b;
+            spec_wait_band(SB, fb);
             const int nrec = SB.cnt[fb * 4 + 0], tn = SB.cnt[fb * 4 + 1];
             const uint32_t *r = reinterpret_cast<const uint32_t *>(SB.recs + fb * SB.rcap_rec);
             for (int i = t * 32; i < nrec * (int)(sizeof(SpecRec) / 4); i += 192 * 32) acc ^= r[i];
@@ -894,6 +912,7 @@ __global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang
             const uint32_t *a = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
             const uint32_t *c = reinterpret_cast<const uint32_t *>(cs0_all + (size_t)f * g.s_stride);
             for (int i = y0 * W + t * 32; i < y1 * W; i += 192 * 32) acc ^= a[i];
+            for (int i = (y0 * W >> 5) + t * 32; i < (y1 * W >> 5); i += 192 * 32) acc ^= sm[i];
             for (int i = y0 * W * 2 + t * 32; i < y1 * W * 2; i += 192 * 32) acc ^= c[i];
         }
         if (acc == 0x9E3779B9u) atomicOr(status, 0);   // keeps the loads alive
@@ -915,14 +934,14 @@ __global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang
     uint32_t *tl2 = SB.tl2 + (size_t)f * 2 * g.s_stride;
     const uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
     const GrowTh th0 = grow_thresholds(g.prec);
-    int use_recs = 1;
-    for (int b = 0; b < SB.nbands; b++) if (SB.cnt[((size_t)f * SB.nbands + b) * 4 + 2]) use_recs = 0;
     int nr = 0, n_commit = 0, n_redo = 0, n_fast = 0, n_slow = 0;
     long long c_redo = 0, c_val = 0, c_setup = 0;
     const long long c_t0 = clock64();
     for (int band = 0; band < SB.nbands; band++) {
         const long long c_s0 = clock64();
         const size_t fb = (size_t)f * SB.nbands + band;
+        spec_wait_band(SB, fb);
+        const int use_recs = SB.cnt[fb * 4 + 2] == 0;   // a band whose log overflowed is simply grown here
         const uint32_t *tl = SB.tl + fb * SB.tcap;
         const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
         const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
@@ -1092,6 +1111,29 @@ __global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang
             int *st = stats + 8 * f;
             st[0] = n_commit; st[1] = n_redo; st[2] = n_fast; st[3] = n_slow; st[4] = (int)(c_redo >> 10); st[5] = (int)(c_val >> 10); st[6] = (int)((clock64() - c_t0) >> 10); st[7] = (int)(c_setup >> 10);
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                        const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                        int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
+{
+    spec_commit_body(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+}
+
+// Both phases in one launch (few frames): workgroups [0, B * nbands) are the band waves, the last B the commit waves.  Workgroups are dispatched in
+// index order, so every band wave is resident or finished before a commit wave starts waiting for it; the commit wave then follows the
+// bands as they finish (band 0 is the smallest, see k_lsd_spec_bands).
+__global__ void __launch_bounds__(256) k_lsd_spec_fused(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                       const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                       int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats, int B)
+{
+    const int L = blockIdx.x, nb = B * SB.nbands;
+    if (L < nb) {
+        if (threadIdx.x >= 64) return;
+        spec_grow_body(L % SB.nbands, L / SB.nbands, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
+    } else {
+        spec_commit_body(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
     }
 }
 
