@@ -960,10 +960,9 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
             const bool inb = px < y1 * W;
             const uint32_t w = inb ? C.ang[px] : 0xFFFFFFFFu;      // angle word itself (flags are in T)
             const bool defined = w < 0x80000000u;
-            float2 c0 = make_float2(0.f, 0.f);
-            if (defined) c0 = C.cs0[px];
             const bool isrec = use_recs && inb && ((seedmap[px >> 5] >> (px & 31)) & 1u);
             unsigned long long todo = __ballot(isrec || (defined && !bm_get(T, px)));
+            if (!todo) continue;   // nothing recorded here and every defined pixel already taken
             const unsigned long long recm = __ballot(isrec);
             // fast path: no dirty pixel in the chunk that could become a seed of its own, and every record of the chunk stays clear of the
             // dirty tiles -> all of them stand; their marks (one contiguous range of the accepted-pixel log) and rectangles are copied at once
@@ -1089,8 +1088,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                 }
                 if (true_eff) {   // grow on the true flags
                     const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(__uint_as_float(w)), j));
-                    const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
-                                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
+                    const float2 sc0 = C.cs0[seed];
                     LsdRect rec;
                     int tn = 0, ovf = 0;
                     const long long c_r0 = clock64();
