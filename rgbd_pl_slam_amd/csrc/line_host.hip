@@ -318,7 +318,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + 3 * bm_words + coarse_words) * 4 + 64;
-    bool spec = !seeds && (g.sw % 32) == 0 && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
+    bool spec = !seeds && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->d_spec_stats};

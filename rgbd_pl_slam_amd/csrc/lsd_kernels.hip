@@ -948,9 +948,9 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         for (int i = lane; i < SB.bm_words; i += 64) { S[i] = 0u; D[i] = T[i]; }
         for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
         CBAR();
-        for (int a0 = lane * 8; a0 < W * H; a0 += 64 * 8) {   // 8 pixels of one row at a time (W is a multiple of 32 on this path)
-            const uint32_t bits = (T[a0 >> 5] >> (a0 & 31)) & 0xFFu;
-            if (bits) { const int t = ((a0 / W) >> 3) * ctx + ((a0 % W) >> 3); __hip_atomic_fetch_or(&Dc[t >> 5], 1u << (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        for (int wi = lane; wi < SB.bm_words; wi += 64) {   // (any width: every set bit marks its own tile)
+            uint32_t bits = T[wi];
+            while (bits) { const int a = wi * 32 + __ffs((int)bits) - 1; bits &= bits - 1; dc_mark(Dc, a, W, ctx); }
         }
         CBAR();
         c_setup += clock64() - c_s0;

@@ -184,3 +184,11 @@ def test_lines_speculative_overflow_falls_back(monkeypatch):
     ext = LineSegment(nlines=100, max_width=640, max_height=480)
     _check(synth_frame(9), 100, ext=ext)
     ext.close()
+
+
+def test_lines_speculative_odd_widths():
+    """scaled widths that are not multiples of 8 / 32 (752 -> 602, 600 -> 480, 333 -> 266) through the speculative path"""
+    _need_gpu()
+    from rgbd_pl_slam_amd.synth import synth_frame
+    for seed, (w, h) in enumerate([(752, 480), (600, 401), (333, 250)]):
+        _check(synth_frame(60 + seed, w, h), 100)
