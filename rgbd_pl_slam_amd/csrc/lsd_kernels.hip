@@ -721,6 +721,8 @@ struct SpecBufs {
     int *band_y;        // [frame][nbands + 1]: first row of every band (shares of the frame's defined pixels)
     int *done;          // [frame][band]: set (release) when the band wave has written its log; the commit wave waits for it (acquire)
     float stagger;      // band b gets a share proportional to 1 + stagger * b: early bands finish early, the commit wave follows them
+    uint32_t *sglob;    // [frame][bm_words]: S of the commit wave when it does not fit the LDS next to T (s_global)
+    int s_global;
     int tcap, rcap_rec, nbands, bm_words;
 };
 
@@ -882,12 +884,33 @@ __device__ __forceinline__ void bm_put(LDS_PTR(uint32_t) b, int a, bool v)
     else __hip_atomic_fetch_and(&b[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// the band's speculative flags S: in LDS next to T, or (frames whose two bitmaps exceed the LDS) in global memory
+template <bool SG> struct SpecS {
+    LDS_PTR(uint32_t) l;
+    uint32_t *g;
+    __device__ __forceinline__ bool get(int a) const
+    {
+        if (SG) return (__hip_atomic_load(&g[a >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (a & 31)) & 1u;
+        return (l[a >> 5] >> (a & 31)) & 1u;
+    }
+    __device__ __forceinline__ void set(int a) const
+    {
+        if (SG) __hip_atomic_fetch_or(&g[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_or(&l[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void clear_all(int words, int lane) const
+    {
+        for (int i = lane; i < words; i += 64) { if (SG) __hip_atomic_store(&g[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else l[i] = 0u; }
+    }
+};
+
 __device__ __forceinline__ void spec_wait_band(const SpecBufs &SB, size_t fb)
 {
     while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
     __threadfence();
 }
 
+template <bool SG>
 __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                  const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
                                                  int *__restrict__ nrect, int *__restrict__ status, const LsdGeom &g, const SpecBufs &SB, int *__restrict__ stats)
@@ -920,11 +943,12 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     }
     LDS_PTR(uint32_t) list = (LDS_PTR(uint32_t))smem;
     LDS_PTR(uint32_t) T = list + ((g.rcap + 1 + 15) & ~15);
-    LDS_PTR(uint32_t) S = T + SB.bm_words;
-    LDS_PTR(uint32_t) D = S + SB.bm_words;
-    // sticky coarse map of D: one bit per 8x8-pixel tile (set when a D bit of the tile is set, rebuilt per band)
+    // D = S xor T is never stored: a pixel is dirty when its two flags differ.  Sticky coarse map of D: one bit per 8x8-pixel tile (set when
+    // a pixel of the tile turns dirty, rebuilt per band).
+    SpecS<SG> S;
+    S.l = T + SB.bm_words; S.g = SB.sglob + (size_t)f * SB.bm_words;
     const int ctx = (W + 7) >> 3, cty = (H + 7) >> 3, cwords = (ctx * cty + 31) >> 5;
-    LDS_PTR(uint32_t) Dc = D + SB.bm_words;
+    LDS_PTR(uint32_t) Dc = T + (SG ? 1 : 2) * SB.bm_words;
     for (int i = lane; i < SB.bm_words; i += 64) T[i] = 0u;
     CBAR();
     RegCtx C;
@@ -945,7 +969,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         const uint32_t *tl = SB.tl + fb * SB.tcap;
         const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
         const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
-        for (int i = lane; i < SB.bm_words; i += 64) { S[i] = 0u; D[i] = T[i]; }
+        S.clear_all(SB.bm_words, lane);   // (D = T at the start of a band)
         for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
         CBAR();
         for (int wi = lane; wi < SB.bm_words; wi += 64) {   // (any width: every set bit marks its own tile)
@@ -966,7 +990,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
             const unsigned long long recm = __ballot(isrec);
             // fast path: no dirty pixel in the chunk that could become a seed of its own, and every record of the chunk stays clear of the
             // dirty tiles -> all of them stand; their marks (one contiguous range of the accepted-pixel log) and rectangles are copied at once
-            const bool seedless = !__ballot(inb && defined && !isrec && bm_get(D, px) && !bm_get(T, px));   // (a dirty pixel that is used in T cannot seed anything)
+            const bool seedless = !__ballot(inb && defined && !isrec && !bm_get(T, px) && S.get(px));   // (a dirty pixel that is used in T cannot seed anything)
             // Chunk-at-a-time path (no dirty pixel of the chunk can become a seed of its own): lane i holds the header of the chunk's i-th record.
             // Records clear of the dirty tiles stand as they are; the others are checked pixel by pixel, all at once (their accepted-pixel logs are
             // one contiguous range).  Everything before the first record that fails is committed in bulk; the rest of the chunk goes through the
@@ -1004,7 +1028,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                                     for (int dx = -1; dx <= 1; dx++) {
                                         const int xx = qx + dx;
                                         if (xx < 0 || xx >= W) continue;
-                                        hit |= bm_get(D, yy * W + xx);
+                                        hit |= bm_get(T, yy * W + xx) != S.get(yy * W + xx);
                                     }
                                 }
                                 if (hit) myk = k;
@@ -1019,7 +1043,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                 }
                 if (first_bad > 0) {
                     const int t_stop = first_bad < cnt ? __builtin_amdgcn_readlane(h_t0, first_bad) : t_end;
-                    for (int i = t_begin + lane; i < t_stop; i += 64) { const uint32_t e = tl[i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
+                    for (int i = t_begin + lane; i < t_stop; i += 64) { const uint32_t e = tl[i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); } }
                     const unsigned long long rm = __ballot(h_rect != 0 && lane < first_bad);
                     if (h_rect && lane < first_bad) {
                         const int slot = nr + __popcll(rm & ((1ull << lane) - 1ull));
@@ -1065,7 +1089,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                                 for (int dx = -1; dx <= 1; dx++) {
                                     const int xx = qx + dx;
                                     if (xx < 0 || xx >= W) continue;
-                                    hit |= bm_get(D, yy * W + xx);
+                                    hit |= bm_get(T, yy * W + xx) != S.get(yy * W + xx);
                                 }
                             }
                         }
@@ -1074,16 +1098,14 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                 }
                 c_val += clock64() - c_v0;
                 if (valid) {   // every flag the speculative run read was the true one: take its marks and its rectangle
-                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); bm_set(S, (int)(e & 0x3FFFFFFFu)); } }
+                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); } }
                     if (has_rect) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = recs[rj].rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
                     n_commit++;
                     CBAR();
                     continue;
                 }
                 if (has_r) {   // the speculative timeline keeps its own marks
-                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); bm_set(S, q); } }
-                    CBAR();
-                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); const bool d = !bm_get(T, q); bm_put(D, q, d); if (d) dc_mark(Dc, q, W, ctx); } }
+                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); S.set(q); if (!bm_get(T, q)) dc_mark(Dc, q, W, ctx); } }
                     CBAR();
                 }
                 if (true_eff) {   // grow on the true flags
@@ -1096,7 +1118,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     c_redo += clock64() - c_r0;
                     if (okr) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
                     CBAR();
-                    for (int i = lane; i < tn; i += 64) { const int q = (int)tl2[i]; const bool d = bm_get(S, q) != bm_get(T, q); bm_put(D, q, d); if (d) dc_mark(Dc, q, W, ctx); }
+                    for (int i = lane; i < tn; i += 64) { const int q = (int)tl2[i]; if (S.get(q) != bm_get(T, q)) dc_mark(Dc, q, W, ctx); }
                     CBAR();
                     n_redo++;
                 }
@@ -1116,7 +1138,8 @@ __global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang
                                                         const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
                                                         int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
 {
-    spec_commit_body(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+    if (SB.s_global) spec_commit_body<true>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+    else spec_commit_body<false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
 }
 
 // Both phases in one launch (few frames): workgroups [0, B * nbands) are the band waves, the last B the commit waves.  Workgroups are dispatched in
@@ -1131,7 +1154,8 @@ __global__ void __launch_bounds__(256) k_lsd_spec_fused(float *__restrict__ ang_
         if (threadIdx.x >= 64) return;
         spec_grow_body(L % SB.nbands, L / SB.nbands, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
     } else {
-        spec_commit_body(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+        if (SB.s_global) spec_commit_body<true>(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+        else spec_commit_body<false>(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
     }
 }
 
