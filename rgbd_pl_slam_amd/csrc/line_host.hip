@@ -321,6 +321,12 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const bool s_global = (size_t)(list_words + 2 * bm_words + coarse_words) * 4 + 64 > 150 * 1024;
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words) * 4 + 64;
     bool spec = !seeds && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
+    if (spec) {   // scratch of the speculation: ~23 MB per VGA frame, ~65 MB per 1280x960 frame; keep it below 8 GiB
+        size_t Fr = 8;
+        while (Fr < (size_t)B) Fr <<= 1;
+        const size_t per_frame = ((size_t)2 * spec_bands + 3) * g.s_stride * sizeof(uint32_t) + (size_t)spec_bands * 8192 * sizeof(SpecRec);
+        if (Fr * per_frame > ((size_t)8 << 30)) spec = false;
+    }
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->d_spec_stats};
