@@ -704,10 +704,12 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
 //   k_lsd_spec_grow   one wave per (band of rows, frame): the whole per-seed pipeline over the band's seeds against a private,
 //                     initially empty USED bitmap in LDS.  Every effective seed leaves a record (seed, every pixel the pipeline
 //                     ever accepted, which of them are still marked, the rectangle if any).
-//   k_lsd_spec_commit one wave per frame walks the bands in order with T (true flags), S (the band's speculative flags replayed)
-//                     and D = S xor T in LDS: a record stands iff its seed is free in T and the 3x3 dilation of its accepted set
-//                     misses D -- then every flag it read had the true value and its marks / rectangle are copied; otherwise the
-//                     seed is regrown on T.  Seeds speculation skipped but that are free in T are grown as well.
+//   k_lsd_spec_commit one wave per frame walks the bands in order with T (true flags, LDS) and S (the band's speculative flags replayed;
+//                     LDS or, for large frames, global memory); a pixel is dirty (D) where the two differ.  A record stands iff its seed is
+//                     free in T and the 3x3 dilation of its accepted set holds no dirty pixel -- then every flag it read had the true value
+//                     and its marks / rectangle are copied; otherwise the seed is regrown on T.  Seeds speculation skipped but that are
+//                     free in T are grown as well.
+//   k_lsd_spec_fused  both phases in one launch: the commit wave follows the (staggered) band waves through per-band done flags.
 // Overflowing record buffers only disable the records of that frame: the commit kernel then IS the serial loop.
 // ------------------------------------------------------------------------------------------------
 struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };   // b*: bounding box of the accepted pixels, dilated by one
@@ -877,11 +879,6 @@ __device__ __forceinline__ void dc_mark(LDS_PTR(uint32_t) Dc, int a, int W, int 
 {
     const int t = ((a / W) >> 3) * ctx + ((a % W) >> 3);
     __hip_atomic_fetch_or(&Dc[t >> 5], 1u << (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void bm_put(LDS_PTR(uint32_t) b, int a, bool v)
-{
-    if (v) __hip_atomic_fetch_or(&b[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_and(&b[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // the band's speculative flags S: in LDS next to T, or (frames whose two bitmaps exceed the LDS) in global memory
