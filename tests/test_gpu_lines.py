@@ -192,3 +192,20 @@ def test_lines_speculative_odd_widths():
     from rgbd_pl_slam_amd.synth import synth_frame
     for seed, (w, h) in enumerate([(752, 480), (600, 401), (333, 250)]):
         _check(synth_frame(60 + seed, w, h), 100)
+
+
+def test_lines_speculative_pathological_images():
+    """regions spanning every band, regions as long as the frame, and a log overflow caused by one giant region"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    y, x = np.mgrid[0:480, 0:640]
+    imgs = [((x * 7) % 256).astype(np.uint8),                                   # vertical sawtooth: frame-high regions, one per period
+            ((y * 9) % 256).astype(np.uint8),                                   # horizontal sawtooth: regions inside single bands
+            ((x * 3 + y * 5) % 256).astype(np.uint8),                           # diagonal sawtooth
+            (np.hypot(x - 320.0, y - 240.0) * 6 % 256).astype(np.uint8),        # rings: every angle, regions curving through all bands
+            (((x // 16 + y // 16) % 2) * 200 + 20).astype(np.uint8),            # checkerboard: many short edges, corners
+            np.clip(x * 0.6 + y * 0.4, 0, 255).astype(np.uint8)]                # gentle ramp: below the gradient threshold almost everywhere
+    ext = LineSegment(nlines=100, max_width=640, max_height=480)
+    for im in imgs:
+        _check(np.ascontiguousarray(im), 100, ext=ext)
+    ext.close()
