@@ -136,7 +136,7 @@ int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int
  * the front stages.  No-op if no batch was enqueued yet. */
 int plf_line_wait_front(plf_line *h, void *stream);
 
-/* Diagnostics of the banded speculative region growing used for <= 256 frames in flight, frame 0 of the last batch:
+/* Diagnostics of the banded speculative region growing used for <= 640 frames in flight, frame 0 of the last batch:
  * out8 = {regions committed from the speculation, regions grown by the commit wave, chunks committed in one step, records checked pixel by pixel,
  * kilo-cycles spent regrowing, validating, in total, in per-band setup}.  PLF_E_BADARG if the path has not run on this handle. */
 int plf_line_debug_spec_stats(plf_line *h, int32_t *out8);

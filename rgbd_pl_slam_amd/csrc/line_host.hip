@@ -312,9 +312,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
     const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;               // (read per call: test hooks)
-    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : 8;
-    // measured on one MI355X (VGA): speculation wins up to ~256 frames in flight (5.4k vs 4.0k frames/s), ties at 512, loses beyond
-    const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 256;
+    // measured on one MI355X (VGA): 8 bands win up to ~256 frames in flight (5.4k vs 4.0k frames/s) and tie at 512; 2 bands still win at 512
+    // (8.6k vs 7.2k) and lose at 1024 (9.8k vs 11.9k), where the batch itself hides the latency of the one-wave-per-frame kernel
+    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 256 ? 8 : 2);
+    const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
     // commit wave: T and S in LDS when they fit, otherwise S in global memory
