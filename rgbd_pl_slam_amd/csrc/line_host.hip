@@ -14,6 +14,7 @@
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *);
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
+__global__ void k_lsd_regions2(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int);
 __global__ void k_lsd_regions_lat(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
 __global__ void k_lsd_maxgrad(const float *, const double *, double *, LsdGeom);
 __global__ void k_lsd_seedkeys(const double *, const double *, uint32_t *, LsdGeom);
@@ -372,6 +373,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else if (B <= lat_max)
         hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
+    else if (!getenv("PLF_LSD_FPW1") && h->regions_lds <= 6400)   // two frames per workgroup: half the workgroup slots per CU, +2 % whole-pipeline throughput (co-running kernels get slots)
+        hipLaunchKernelGGL(k_lsd_regions2, dim3((B + 1) / 2), dim3(128), 2 * 6400, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+                           h->d_rects, nrect, status, g, seeds, B);
     else
         hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds);

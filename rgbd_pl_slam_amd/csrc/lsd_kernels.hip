@@ -584,13 +584,17 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     return true;
 }
 
+template <int LDSOFF, int FPW>
 __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                              const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                              uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                             int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int eager)
+                                             int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int eager, int nframes)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int f = blockIdx.x, lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem_base[];
+    // FPW = 2 (k_lsd_regions2): two frames per workgroup, one wave each, every wave instantiated with ITS constant LDS offset
+    const int f = FPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * FPW + (LDSOFF ? 1 : 0), lane = FPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    if (FPW > 1 && f >= nframes) return;
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_base + LDSOFF;
     const uint32_t *seeds = seeds_all ? seeds_all + (size_t)f * g.s_stride : nullptr;   // sorted keys (seed_order 1) or raster
     const int W = g.sw, H = g.sh, NP = W * H;
     RegCtx C;
@@ -668,7 +672,17 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
                                                     uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                     int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
 {
-    regions_body(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
+    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0, 0);
+}
+
+#define PLF_LSD_FPW2_LDS 6400
+__global__ void __launch_bounds__(128) k_lsd_regions2(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                      const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
+                                                      uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
+                                                      int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
+{
+    if (threadIdx.x < 64) regions_body<0, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0, nframes);
+    else regions_body<PLF_LSD_FPW2_LDS, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0, nframes);
 }
 
 // Latency mode (a handful of frames in flight, e.g. the live SLAM loop): the chain of one frame is all there is to run, so its memory round
@@ -694,7 +708,7 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
         if (acc == 0x9E3779B9u) *sink = (int)acc;   // keeps the loads alive
         return;
     }
-    regions_body(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 1);
+    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 1, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
