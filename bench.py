@@ -215,7 +215,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            traffic = int(pmc["k_lsd_regions"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
+            traffic = int(pmc["k_lsd_regions2"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
         except Exception:
             traffic = None
         achieved = (REGION_BYTES_PER_FRAME * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
@@ -229,7 +229,7 @@ def main():
                        "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), no collective" % world},
             "matches_frame0": {"points": int(bufs[0]["nm_kp"][0]), "lines": int(bufs[0]["nm_ln"][0])},
             "pipeline_algorithmic_GBps": round(fps * BYTES_PER_FRAME / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": "k_lsd_regions", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_lsd_regions2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches,
                          "algorithmic_bytes_per_launch": REGION_BYTES_PER_FRAME * B},

@@ -8,7 +8,7 @@ tag = sys.argv[1]
 bargs = sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
 out = {"_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) of `python bench.py %s` on one MI355X; "
                "KB per launch as reported by rocprofv3.  MI355X_MICROARCH.md: FETCH_SIZE under-counts wide (16 B/lane) streaming reads by 2x on "
-               "gfx950; k_lsd_regions issues 4-16-byte gathers, so no correction is applied to it; WRITE_SIZE is uncalibrated." % " ".join(bargs),
+               "gfx950; k_lsd_regions2 issues 4-16-byte gathers, so no correction is applied to it; WRITE_SIZE is uncalibrated." % " ".join(bargs),
        "counters": {}}
 env = dict(os.environ, TMPDIR="/tmp")
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -30,8 +30,8 @@ for i, a in enumerate(bargs):
     if a == "--batch":
         B = int(bargs[i + 1])
 out["frames_per_launch"] = B
-f = out["counters"]["FETCH_SIZE"].get("k_lsd_regions", {}).get("per_launch_KB", 0.0)
-w = out["counters"]["WRITE_SIZE"].get("k_lsd_regions", {}).get("per_launch_KB", 0.0)
-out["k_lsd_regions"] = {"hbm_bytes_per_launch": int((f + w) * 1024), "fetch_KB": f, "write_KB": w}
+f = out["counters"]["FETCH_SIZE"].get("k_lsd_regions2", {}).get("per_launch_KB", 0.0)
+w = out["counters"]["WRITE_SIZE"].get("k_lsd_regions2", {}).get("per_launch_KB", 0.0)
+out["k_lsd_regions2"] = {"hbm_bytes_per_launch": int((f + w) * 1024), "fetch_KB": f, "write_KB": w}
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "%s_pmc_traffic.json" % tag), "w"), indent=1)
-print(json.dumps(out["k_lsd_regions"]))
+print(json.dumps(out["k_lsd_regions2"]))
