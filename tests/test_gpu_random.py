@@ -177,3 +177,21 @@ def test_bench_size_batch_is_exact_and_deterministic():
         assert l == len(rl["kl"]) and np.array_equal(ldesc[f, :l].cpu().numpy(), rl["desc"])
     ext.close(); ls.close()
 
+
+
+def test_lines_odd_large_batch_two_frames_per_workgroup():
+    """1001 frames in flight: the large-batch region kernel packs two frames per workgroup, the last workgroup holds one"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_batch
+    import orc
+    base = synth_batch(300, 7)
+    imgs = np.concatenate([base] * 143)[:1001]
+    ext = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=1001)
+    res = ext.extract_batch(imgs)
+    ref = [orc.line_extract(base[f], 100) for f in range(7)]
+    for f in list(range(14)) + [500, 999, 1000]:
+        r = ref[f % 7]
+        assert np.array_equal(res[f][1], r["desc"])
+        assert np.array_equal(res[f][0]["startPointX"].view(np.uint32), r["kl"]["startPointX"].view(np.uint32))
+    ext.close()
