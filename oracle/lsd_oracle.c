@@ -625,6 +625,9 @@ static int run_seed(lsd_t *L, int adx, regpt *reg, double prec, double p, int mi
     return ok;
 }
 
+static int g_band_halo = 0;   /* rows above a band that its speculation grows first, unrecorded, to start from a realistic flag state */
+void orc_lsd_band_speculation_halo(int rows) { g_band_halo = rows; }
+
 int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats)
 {
     const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5;
@@ -681,6 +684,7 @@ int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch,
     int *nrecs = (int *)calloc(nbands, sizeof(int));
     int **tl = (int **)calloc(nbands, sizeof(int *));
     uint8_t *priv = (uint8_t *)malloc(NP);
+    uint8_t **halo = (uint8_t **)calloc(nbands, sizeof(uint8_t *));
     for (int b = 0; b < nbands; b++) {
         const int y0 = (int)((long)rows * b / nbands), y1 = (int)((long)rows * (b + 1) / nbands);
         memset(priv, 0, NP);
@@ -689,6 +693,18 @@ int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch,
         size_t tcap = 4 * NP, tn = 0;
         tl[b] = (int *)malloc(sizeof(int) * tcap);
         long acc = 0;
+        if (b > 0 && g_band_halo > 0) {   /* warm-up over the rows just above the band; what it marks is the band's initial speculative state */
+            const int yh = y0 - g_band_halo > 0 ? y0 - g_band_halo : 0;
+            for (int y = yh; y < y0; ++y)
+                for (int x = 0; x < W - 1; ++x) {
+                    const int adx = y * W + x;
+                    if (L.used[adx] != NOTUSED || L.angles[adx] == NOTDEF) continue;
+                    int nt; rect_t rec;
+                    run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &acc);
+                }
+        }
+        halo[b] = (uint8_t *)malloc(NP);
+        memcpy(halo[b], priv, NP);
         for (int y = y0; y < y1; ++y)
             for (int x = 0; x < W - 1; ++x) {
                 const int adx = y * W + x;
@@ -710,8 +726,8 @@ int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch,
     int nrect_par = 0;
     for (int b = 0; b < nbands; b++) {
         const int y0 = (int)((long)rows * b / nbands), y1 = (int)((long)rows * (b + 1) / nbands);
-        memset(S, 0, NP);
-        memcpy(D, T, NP);
+        memcpy(S, halo[b], NP);
+        for (size_t i = 0; i < NP; i++) D[i] = S[i] != T[i];
         int ri = 0;
         for (int y = y0; y < y1; ++y)
             for (int x = 0; x < W - 1; ++x) {
@@ -751,7 +767,8 @@ int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch,
     }
     stats[6] = nrect_par == nrect_serial && memcmp(T, used_serial, NP) == 0 && memcmp(rects_par, rects_serial, sizeof(rect_t) * nrect_serial) == 0;
     stats[7] = nrect_serial;
-    for (int b = 0; b < nbands; b++) { free(recs[b]); free(tl[b]); }
+    for (int b = 0; b < nbands; b++) { free(recs[b]); free(tl[b]); free(halo[b]); }
+    free(halo);
     free(recs); free(nrecs); free(tl); free(priv); free(T); free(S); free(D); free(rects_par); free(rects_serial); free(used_serial);
     free(reg); free(touched); free(L.img); free(L.angles); free(L.modgrad);
     return (int)stats[6];

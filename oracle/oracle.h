@@ -183,6 +183,7 @@ typedef struct {
 void orc_gauss_kernel_f64(int n, double sigma, double *k);
 int orc_lsd_detect(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int seed_order, float *lines, int cap,
                    orc_lsd_debug *dbg);
+void orc_lsd_band_speculation_halo(int rows);
 int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats /*8*/);
 int orc_keylines_from_segments(const float *lines, int n, int w, int h, orc_keyline *out);
 void orc_sobel3_16s(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int16_t *dxImg, int16_t *dyImg);
