@@ -31,8 +31,6 @@ __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, flo
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
 
-struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };
-struct SpecBufs { uint32_t *rxy; uint32_t *tl; SpecRec *recs; int *cnt; uint32_t *seedmap; uint32_t *tl2; int *band_y; int *done; float stagger; uint32_t *sglob; int s_global; int tcap, rcap_rec, nbands, bm_words; };
 __global__ void k_lsd_spec_fused(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
 __global__ void k_lsd_spec_bands(const float *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
@@ -91,7 +89,7 @@ static void line_free(plf_line *h)
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->d_spec_stats};
+    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -331,7 +329,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
-        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->d_spec_stats};
+        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
@@ -349,12 +347,14 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.band_y, Fr * (K + 1) * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.done, Fr * K * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.sglob, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.halo, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->d_spec_stats, Fr * 8 * sizeof(int)) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; }
         else h->spec_frames = (int)Fr;
     }
     if (spec) {
         h->spec.s_global = s_global ? 1 : 0;
+        h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : 16;
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
         PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they

@@ -21,3 +21,23 @@ struct LsdGeom {
     int nkeep;            // lines kept after the response sort
     int sort_cap;         // power of two >= rect_cap
 };
+
+// banded speculative region growing: one record per effective seed of a band wave, and the buffers of both phases
+struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };   // b*: bounding box of the accepted pixels, dilated by one
+struct SpecBufs {
+    uint32_t *rxy;      // [frame][band][s_stride] list overflow of the band waves
+    uint32_t *tl;       // [frame][band][tcap] accepted pixels (bit 30: still marked at the end of the seed)
+    SpecRec *recs;      // [frame][band][rcap_rec]
+    int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
+    uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
+    uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel
+    int *band_y;        // [frame][nbands + 1]: first row of every band (shares of the frame's defined pixels)
+    int *done;          // [frame][band]: set (release) when the band wave has written its log; the commit wave waits for it (acquire)
+    float stagger;      // band b gets a share proportional to 1 + stagger * b: early bands finish early, the commit wave follows them
+    uint32_t *sglob;    // [frame][bm_words]: S of the commit wave when it does not fit the LDS next to T (s_global)
+    uint32_t *halo;     // [frame][band][bm_words]: the band's speculative flags after its warm-up rows = its initial state S
+    int halo_rows;      // rows above a band that its wave grows first, unrecorded (model: orc_lsd_band_speculation_halo)
+    int s_global;
+    int tcap, rcap_rec, nbands, bm_words;
+};
+

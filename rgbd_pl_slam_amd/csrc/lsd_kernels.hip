@@ -726,21 +726,7 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
 //   k_lsd_spec_fused  both phases in one launch: the commit wave follows the (staggered) band waves through per-band done flags.
 // Overflowing record buffers only disable the records of that frame: the commit kernel then IS the serial loop.
 // ------------------------------------------------------------------------------------------------
-struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };   // b*: bounding box of the accepted pixels, dilated by one
-struct SpecBufs {
-    uint32_t *rxy;      // [frame][band][s_stride] list overflow of the band waves
-    uint32_t *tl;       // [frame][band][tcap] accepted pixels (bit 30: still marked at the end of the seed)
-    SpecRec *recs;      // [frame][band][rcap_rec]
-    int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
-    uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
-    uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel
-    int *band_y;        // [frame][nbands + 1]: first row of every band (shares of the frame's defined pixels)
-    int *done;          // [frame][band]: set (release) when the band wave has written its log; the commit wave waits for it (acquire)
-    float stagger;      // band b gets a share proportional to 1 + stagger * b: early bands finish early, the commit wave follows them
-    uint32_t *sglob;    // [frame][bm_words]: S of the commit wave when it does not fit the LDS next to T (s_global)
-    int s_global;
-    int tcap, rcap_rec, nbands, bm_words;
-};
+// (SpecRec / SpecBufs: lsd_geom.h, shared with line_host.hip)
 
 // append the current region list [0, n) as pixel indices
 __device__ __forceinline__ void spec_append(const RegCtx &C, int n, uint32_t *__restrict__ dst, int &tn, int cap, int &ovf)
@@ -832,9 +818,16 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     const GrowTh th0 = grow_thresholds(g.prec);
     const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
     int nrec = 0, tn = 0, ovf = 0;
-    for (int base = y0 * W; base < y1 * W; base += 64) {
+    // phase 0 (bands > 0): the rows just above the band, unrecorded -- what they mark (regions poking into the band) is the state the band's
+    // speculation starts from, handed to the commit wave as the initial S; phase 1: the band itself, recorded
+    uint32_t *halo = SB.halo + fb * SB.bm_words;
+    for (int phase = (band > 0 && SB.halo_rows > 0) ? 0 : 1; phase < 2; phase++) {
+    const bool record = phase == 1;
+    const int ya = record ? y0 : max(0, y0 - SB.halo_rows), yb = record ? y1 : y0;
+    if (record) { CBAR(); for (int i = lane; i < SB.bm_words; i += 64) halo[i] = bm[i]; }
+    for (int base = ya * W; base < yb * W; base += 64) {
         const int px = base + lane;
-        uint32_t w = px < y1 * W ? ang_load(C, px) : 0xFFFFFFFFu;
+        uint32_t w = px < yb * W ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
         float2 c0 = make_float2(0.f, 0.f);
         if (ok) c0 = C.cs0[px];
@@ -848,8 +841,9 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
             LsdRect rec;
             const int t0 = tn;
             const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf);
-            if (nrec >= SB.rcap_rec) ovf = 1;
-            if (!ovf) {
+            if (!record) { tn = 0; ovf = 0; }
+            if (record && nrec >= SB.rcap_rec) ovf = 1;
+            if (record && !ovf) {
                 int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
                 for (int i = t0 + lane; i < tn; i += 64) {
                     const uint32_t q = tl[i];
@@ -871,10 +865,11 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
                 nrec++;
             }
             CBAR();
-            w = px < y1 * W ? ang_load(C, px) : 0xFFFFFFFFu;   // flags from the bitmap: cheap, always current
+            w = px < yb * W ? ang_load(C, px) : 0xFFFFFFFFu;   // flags from the bitmap: cheap, always current
             ok = ok && lane > j && w < 0x80000000u;
             mask = __ballot(ok);
         }
+    }
     }
     if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; }
     __threadfence();   // every lane's log entries are visible device-wide before the flag
@@ -908,6 +903,11 @@ template <bool SG> struct SpecS {
     {
         if (SG) __hip_atomic_fetch_or(&g[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_or(&l[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ uint32_t word(int i) const { return SG ? __hip_atomic_load(&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : l[i]; }
+    __device__ __forceinline__ void load_from(const uint32_t *__restrict__ src, int words, int lane) const
+    {
+        for (int i = lane; i < words; i += 64) { const uint32_t v = src[i]; if (SG) __hip_atomic_store(&g[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else l[i] = v; }
     }
     __device__ __forceinline__ void clear_all(int words, int lane) const
     {
@@ -980,11 +980,12 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         const uint32_t *tl = SB.tl + fb * SB.tcap;
         const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
         const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
-        S.clear_all(SB.bm_words, lane);   // (D = T at the start of a band)
+        if (band > 0 && SB.halo_rows > 0) S.load_from(SB.halo + fb * SB.bm_words, SB.bm_words, lane);   // the band's flags after its warm-up rows
+        else S.clear_all(SB.bm_words, lane);
         for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
         CBAR();
-        for (int wi = lane; wi < SB.bm_words; wi += 64) {   // (any width: every set bit marks its own tile)
-            uint32_t bits = T[wi];
+        for (int wi = lane; wi < SB.bm_words; wi += 64) {   // (any width: every dirty bit marks its own tile)
+            uint32_t bits = T[wi] ^ S.word(wi);
             while (bits) { const int a = wi * 32 + __ffs((int)bits) - 1; bits &= bits - 1; dc_mark(Dc, a, W, ctx); }
         }
         CBAR();
