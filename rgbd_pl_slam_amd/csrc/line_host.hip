@@ -311,9 +311,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
     const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;               // (read per call: test hooks)
-    // measured on one MI355X (VGA): 8 bands win up to ~256 frames in flight (5.4k vs 4.0k frames/s) and tie at 512; 2 bands still win at 512
-    // (8.6k vs 7.2k) and lose at 1024 (9.8k vs 11.9k), where the batch itself hides the latency of the one-wave-per-frame kernel
-    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 256 ? 8 : 2);
+    // measured on one MI355X (VGA, frames/s with 16 / 8 / 4 / 2 bands): 8 frames 448 / 378 / 291 / 197; 32: 1277 / 1252 / 1079 / 679; 128: 3392 / 4321 /
+    // 4007 / 1511; 256: 3866 / 5713 / 6800 / 5381; 512: - / 7237 / 8352 / 8856 (serial kernel: 7220); at 1024 the batch itself hides the latency
+    // of the one-wave-per-frame kernel (9.8k with 2 bands vs 11.9k)
+    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);
     const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
@@ -360,7 +361,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
         // finish, and the bands are staggered for that; otherwise two launches with equal bands
         const bool fused = (size_t)B * (spec_bands + 1) <= 448 && !getenv("PLF_LSD_SPEC_NOFUSE");
-        h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.5f) : 0.f;
+        h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(256), 0, s, h->d_ang, g, h->spec);
         if (fused) {
             hipLaunchKernelGGL(k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
