@@ -209,3 +209,16 @@ def test_lines_speculative_pathological_images():
     for im in imgs:
         _check(np.ascontiguousarray(im), 100, ext=ext)
     ext.close()
+
+
+@pytest.mark.parametrize("halo", [0, 5, 40])
+def test_lines_speculative_halo_rows(monkeypatch, halo):
+    """warm-up rows above every band (default 16): any number of them, including none and more than a band is high, gives the serial result"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    monkeypatch.setenv("PLF_LSD_SPEC_HALO", str(halo))
+    ext = LineSegment(nlines=100, max_width=640, max_height=480)
+    for seed in (12, 13):
+        _check(synth_frame(seed), 100, ext=ext)
+    ext.close()

@@ -56,3 +56,9 @@ def test_banded_speculative_region_growing_model_is_exact():
                 assert st[2] == 0 and st[4] == 0          # a single band is the serial loop: nothing to redo
             if nb == 8:
                 assert st[2] < 0.25 * st[0]               # redone accept steps stay a small share
+                redo_plain = st[2]
+                L.orc_lsd_band_speculation_halo(16)       # warm-up rows above every band: still exact, far less to redo
+                st2 = (C.c_long * 8)()
+                ok2 = L.orc_lsd_band_speculation(img.ctypes.data_as(C.c_void_p), 640, 480, C.c_ssize_t(640), nb, st2)
+                L.orc_lsd_band_speculation_halo(0)
+                assert ok2 == 1 and st2[6] == 1 and st2[2] < 0.8 * redo_plain
