@@ -362,7 +362,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         // finish, and the bands are staggered for that; otherwise two launches with equal bands
         const bool fused = (size_t)B * (spec_bands + 1) <= 448 && !getenv("PLF_LSD_SPEC_NOFUSE");
         h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
-        hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(256), 0, s, h->d_ang, g, h->spec);
+        hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(1024), 0, s, h->d_ang, g, h->spec);
         if (fused) {
             hipLaunchKernelGGL(k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
                                status, g, h->spec, h->d_spec_stats, B);

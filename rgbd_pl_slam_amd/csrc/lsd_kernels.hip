@@ -768,15 +768,24 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
 
 // rows of the bands: equal shares of the frame's defined pixels (the work of a band is roughly its number of accepted pixels),
 // boundaries on multiples of 8 rows so that a coarse dirty tile belongs to one band
-__global__ void __launch_bounds__(256) k_lsd_spec_bands(const float *__restrict__ ang_all, LsdGeom g, SpecBufs SB)
+__global__ void __launch_bounds__(1024) k_lsd_spec_bands(const float *__restrict__ ang_all, LsdGeom g, SpecBufs SB)
 {
     __shared__ int cnt[1024];
     const int f = blockIdx.x, t = threadIdx.x, W = g.sw, H = g.sh;
     const uint32_t *ang = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
     const int units = (H - 1 + 7) >> 3;   // 8-row units
-    for (int u = t; u < 1024; u += 256) cnt[u] = 0;
+    for (int u = t; u < 1024; u += 1024) cnt[u] = 0;
     __syncthreads();
-    for (int a = t; a < W * (H - 1); a += 256) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) >> 3, 1023)], 1);
+    if ((W & 3) == 0 && (g.s_stride & 3) == 0) {   // four pixels of one row per load, one LDS atomic per thread and step
+        const uint4 *a4 = reinterpret_cast<const uint4 *>(ang);
+        for (int q = t; q < (W >> 2) * (H - 1); q += 1024) {
+            const uint4 v = a4[q];
+            const int c = (v.x < 0x80000000u) + (v.y < 0x80000000u) + (v.z < 0x80000000u) + (v.w < 0x80000000u);
+            if (c) atomicAdd(&cnt[min((q / (W >> 2)) >> 3, 1023)], c);
+        }
+    } else {
+        for (int a = t; a < W * (H - 1); a += 1024) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) >> 3, 1023)], 1);
+    }
     __syncthreads();
     if (t == 0) {
         int total = 0;
