@@ -349,7 +349,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.done, Fr * K * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.sglob, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.halo, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
-                  hipMalloc((void **)&h->d_spec_stats, Fr * 8 * sizeof(int)) == hipSuccess;
+                  hipMalloc((void **)&h->d_spec_stats, (Fr * 8 + 200) * sizeof(int)) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; }
         else h->spec_frames = (int)Fr;
     }
@@ -483,6 +483,14 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
     if (!h || !out8 || !h->d_spec_stats) return PLF_E_BADARG;
     PLF_HIP_TRY(hipDeviceSynchronize());
     PLF_HIP_TRY(hipMemcpy(out8, h->d_spec_stats, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    if (getenv("PLF_LSD_SPEC_TIMELINE")) {   // per band: grow end, commit start (100 MHz ticks); last: commit end
+        int tl[200];
+        PLF_HIP_TRY(hipMemcpy(tl, h->d_spec_stats + 8, 200 * sizeof(int), hipMemcpyDeviceToHost));
+        const int t0 = tl[1];
+        fprintf(stderr, "[plf] speculation timeline (us after the commit of band 0 started):");
+        for (int b = 0; b < h->spec.nbands && b < 63; b++) fprintf(stderr, " b%d grow_end %d commit_start %d |", b, (tl[3 * b] - t0) / 100, (tl[3 * b + 1] - t0) / 100);
+        fprintf(stderr, " commit_end %d\n", (tl[3 * 63 + 2] - t0) / 100);
+    }
     return PLF_OK;
 }
 

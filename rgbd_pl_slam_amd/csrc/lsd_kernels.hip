@@ -880,7 +880,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
         }
     }
     }
-    if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; }
+    if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; SB.cnt[fb * 4 + 3] = (int)(wall_clock64() & 0x7fffffff); }   // ([3]: 100 MHz timestamp, diagnostics)
     __threadfence();   // every lane's log entries are visible device-wide before the flag
     if (lane == 0) __hip_atomic_store(&SB.done[fb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -985,6 +985,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         const long long c_s0 = clock64();
         const size_t fb = (size_t)f * SB.nbands + band;
         spec_wait_band(SB, fb);
+        if (stats && f == 0 && lane == 0 && band < 64) { stats[8 + 3 * band] = SB.cnt[fb * 4 + 3]; stats[8 + 3 * band + 1] = (int)(wall_clock64() & 0x7fffffff); }
         const int use_recs = SB.cnt[fb * 4 + 2] == 0;   // a band whose log overflowed is simply grown here
         const uint32_t *tl = SB.tl + fb * SB.tcap;
         const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
@@ -993,9 +994,14 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         else S.clear_all(SB.bm_words, lane);
         for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
         CBAR();
-        for (int wi = lane; wi < SB.bm_words; wi += 64) {   // (any width: every dirty bit marks its own tile)
+        for (int wi = lane; wi < SB.bm_words; wi += 64) {
             uint32_t bits = T[wi] ^ S.word(wi);
-            while (bits) { const int a = wi * 32 + __ffs((int)bits) - 1; bits &= bits - 1; dc_mark(Dc, a, W, ctx); }
+            if (!bits) continue;
+            if ((W & 31) == 0) {   // a word is 32 pixels of one row = four tiles: one mark per dirty byte
+                for (int k = 0; k < 4; k++) if ((bits >> (8 * k)) & 0xFFu) dc_mark(Dc, wi * 32 + 8 * k, W, ctx);
+            } else {               // any width: every dirty bit marks its own tile
+                while (bits) { const int a = wi * 32 + __ffs((int)bits) - 1; bits &= bits - 1; dc_mark(Dc, a, W, ctx); }
+            }
         }
         CBAR();
         c_setup += clock64() - c_s0;
@@ -1146,6 +1152,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
             }
         }
     }
+    if (stats && f == 0 && lane == 0) stats[8 + 3 * 63 + 2] = (int)(wall_clock64() & 0x7fffffff);   // end of the commit
     if (lane == 0) {
         nrect[f] = min(nr, g.rect_cap);
         if (stats) {
