@@ -197,6 +197,7 @@ struct RegCtx {
     LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
+    int gcap;                  // entries of rxy_g (scratch beyond the list: reduce_region_radius)
     int eager;                 // few frames in flight (latency mode): fetch the cos/sin increment together with the angle word
     int use_bm;                // speculative mode: the USED flags live in an LDS bitmap (bm), the angle words are read-only
     LDS_PTR(uint32_t) bm;
@@ -512,24 +513,74 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
     double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
     while (density < density_th) {
         radSq *= 0.75 * 0.75;
+        const int m = n;
+        if (m + (m >> 1) + 64 <= C.gcap) {
+            // The reference removes a point by swapping the LAST point into its place and re-examining that slot.  The kept prefix that leaves
+            // behind is: every kept point below the new size stays where it is, and the removed ones there ("holes", ascending) are filled with the
+            // kept points from above the new size taken from the END downwards (checked against the literal loop on random cases).  All lanes work.
+            int m_new = 0;
+            for (int base = 0; base < m; base += 64) {
+                const int i = base + lane;
+                bool in = false;
+                if (i < m) {
+                    const uint32_t q = rxy_get(C, i);
+                    in = !(distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq);
+                    if (!in) used_clr(C, (int)(q >> 16) * C.W + (int)(q & 0xFFFF));
+                }
+                m_new += __popcll(__ballot(in));
+            }
+            uint32_t *tmp = C.rxy_g + m;   // hole positions (the list never reaches beyond m)
+            int hcount = 0;
+            for (int base = 0; base < m_new; base += 64) {
+                const int i = base + lane;
+                bool out = false;
+                if (i < m_new) {
+                    const uint32_t q = rxy_get(C, i);
+                    out = distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq;
+                }
+                const unsigned long long om = __ballot(out);
+                if (out) __hip_atomic_store(&tmp[hcount + __popcll(om & ((1ull << lane) - 1ull))], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hcount += __popcll(om);
+            }
+            CBAR();
+            int fcount = 0;
+            for (int base = ((m - 1) >> 6) << 6; base >= 0 && base + 64 > m_new && fcount < hcount; base -= 64) {
+                const int i = base + lane;
+                bool in = false;
+                uint32_t q = 0u;
+                if (i < m && i >= m_new) {
+                    q = rxy_get(C, i);
+                    in = !(distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq);
+                }
+                const unsigned long long im = __ballot(in);
+                if (in) {
+                    const int k = fcount + __popcll(im & ~((2ull << lane) - 1ull));   // kept points with a higher index come first
+                    rxy_put(C, (int)__hip_atomic_load(&tmp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q);
+                }
+                fcount += __popcll(im);
+            }
+            CBAR();
+            n = m_new;
+        } else {
         if (lane == 0) {
-            int m = n;
-            for (int i = 0; i < m; ++i) {
+            int mm = n;
+            for (int i = 0; i < mm; ++i) {
                 const uint32_t q = rxy_get(C, i);
                 if (distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq) {
                     used_clr(C, (int)(q >> 16) * C.W + (int)(q & 0xFFFF));
-                    const uint32_t ql = rxy_get(C, m - 1);
-                    rxy_put(C, m - 1, q);
+                    const uint32_t ql = rxy_get(C, mm - 1);
+                    rxy_put(C, mm - 1, q);
                     rxy_put(C, i, ql);
-                    --m;
+                    --mm;
                     --i;
                 }
             }
-            C.rxy_l[C.rcap] = (uint32_t)m;  // one spare LDS word carries the new size to the other lanes
+            C.rxy_l[C.rcap] = (uint32_t)mm;  // one spare LDS word carries the new size to the other lanes
         }
         CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
         n = (int)C.rxy_l[C.rcap];
         CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
+        }
         if (n < 2) return false;
         region2rect(C, n, reg_angle, prec, p, rec);
         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -605,6 +656,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
     C.rxy_l = (LDS_PTR(uint32_t))smem;
     C.rcap = g.rcap;
+    C.gcap = (int)g.s_stride;
     C.eager = eager;
     C.use_bm = 0; C.bm = (LDS_PTR(uint32_t))smem; C.regrow_n = -1;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
@@ -761,7 +813,7 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
-    C.rxy_l = list; C.rcap = g.rcap; C.rxy_g = rxy_g;
+    C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
     C.eager = 1; C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
     C.cbase = -0x40000000; C.cused = 0ull;
 }
