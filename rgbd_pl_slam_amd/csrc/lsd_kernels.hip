@@ -767,9 +767,9 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
 // Banded speculative region growing (few frames in flight).  The serial seed loop is exact but one wave retires it at
 // ~11 cycles per instruction; this is the same loop made parallel WITHOUT changing any result (model and proof by
 // execution: oracle/lsd_oracle.c, orc_lsd_band_speculation):
-//   k_lsd_spec_grow   one wave per (band of rows, frame): the whole per-seed pipeline over the band's seeds against a private,
-//                     initially empty USED bitmap in LDS.  Every effective seed leaves a record (seed, every pixel the pipeline
-//                     ever accepted, which of them are still marked, the rectangle if any).
+//   k_lsd_spec_grow   one wave per (band of rows, frame): the whole per-seed pipeline over the band's seeds against a private USED bitmap in
+//                     LDS, started from what growing the rows just above the band (unrecorded "halo") leaves marked.  Every effective
+//                     seed leaves a record (seed, every pixel the pipeline ever accepted, which of them are still marked, the rectangle if any).
 //   k_lsd_spec_commit one wave per frame walks the bands in order with T (true flags, LDS) and S (the band's speculative flags replayed;
 //                     LDS or, for large frames, global memory); a pixel is dirty (D) where the two differ.  A record stands iff its seed is
 //                     free in T and the 3x3 dilation of its accepted set holds no dirty pixel -- then every flag it read had the true value
