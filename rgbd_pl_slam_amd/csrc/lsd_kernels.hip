@@ -978,7 +978,7 @@ template <bool SG> struct SpecS {
 
 __device__ __forceinline__ void spec_wait_band(const SpecBufs &SB, size_t fb)
 {
-    while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+    while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(127);
     __threadfence();
 }
 
