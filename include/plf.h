@@ -402,6 +402,15 @@ int plf_depth_to_float(const uint16_t *depth, int32_t n_frames, int32_t width, i
 int plf_frame_tail(const plf_keypoint *keys, const int32_t *n_device, int32_t n_host, int32_t n_frames, int32_t kp_stride,
                    const float *depth, int32_t width, int32_t height, const plf_camera *cam, plf_keypoint *keys_un, float *uright,
                    float *kp_depth, int32_t device, void *stream);
+/* The line half of the Frame tail: void Frame::UndistortKeyLines() include/Frame.h:267 (-> mvKeylinesUn, :207) and the end-point fields
+ * mvuRightLineStart / mvuRightLineEnd / mvDepthLineStart / mvDepthLineEnd (include/Frame.h:208-211; KeyFrame.h:224-229 copies them).  The
+ * fork snapshot declares these without a body (and the binary is the point-only build), so they are defined exactly like the point fields:
+ * each end point goes through the UndistortKeyPoints arithmetic and the ComputeStereoFromRGBD rule (depth at the truncated distorted position,
+ * uRight = undistorted x - bf / d, -1 without a positive depth); every other KeyLine field is copied.  Layout like plf_line_extract_batch's
+ * outputs (line_stride entries per frame; counts from n_device or n_host).  Output pointers other than lines_un may be NULL. */
+int plf_frame_line_tail(const plf_keyline *lines, const int32_t *n_device, int32_t n_host, int32_t n_frames, int32_t line_stride,
+                        const float *depth, int32_t width, int32_t height, const plf_camera *cam, plf_keyline *lines_un,
+                        float *uright_start, float *uright_end, float *depth_start, float *depth_end, int32_t device, void *stream);
 /* bool Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit) include/Frame.h:104 (so@0xf5190) with
  * MapPoint::PredictScale (so@0x8fc20) for m map points: fills the plf_mappoint_view fields the matcher reads.
  * min/max_distance = mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors are applied inside). */
@@ -409,6 +418,15 @@ int plf_frustum_points(const float *world_pos, const float *normal, const float 
                        const plf_frustum_pose *pose, const plf_camera *cam, float min_x, float min_y, float max_x, float max_y,
                        float log_scale_factor, int32_t nlevels, float viewing_cos_limit, float *proj_x, float *proj_y, float *proj_xr,
                        int32_t *level, float *view_cos, uint8_t *in_view, int32_t device, void *stream);
+/* bool Frame::isInFrustum(MapLine *pML, float viewingCosLimit) include/Frame.h:107 for m map lines; fills the plf_mapline_view fields
+ * (mTrackProjX1/Y1/X1R, X2/Y2/X2R, mnTrackScaleLevel, mTrackViewCos, mbTrackInView: include/MapLine.h:113-129).  The snapshot declares it
+ * without a body: it is the MapPoint routine applied to the segment -- both end points (world_pos: m x 6 floats, start xyz then end xyz =
+ * MapLine::mWorldPos, include/MapLine.h:158) must project in front of the camera and inside the bounds; distance gate, viewing cosine against
+ * `normal` (mNormalVector, :166) and MapLine::PredictScale (:101) are taken at the midpoint.  x1r / x2r may be NULL. */
+int plf_frustum_lines(const float *world_pos, const float *normal, const float *min_distance, const float *max_distance, int32_t m,
+                      const plf_frustum_pose *pose, const plf_camera *cam, float min_x, float min_y, float max_x, float max_y,
+                      float log_scale_factor, int32_t nlevels, float viewing_cos_limit, float *x1, float *y1, float *x1r, float *x2,
+                      float *y2, float *x2r, int32_t *level, float *view_cos, uint8_t *in_view, int32_t device, void *stream);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,25 @@ void orc_stereo_from_rgbd(const orc_keypoint *keys, const orc_keypoint *keys_un,
     }
 }
 
+/* Line half of the Frame tail (include/Frame.h:207-211, :267): no body in the fork snapshot -- defined as the two routines above applied to both end
+ * points of every KeyLine (so the arithmetic is the one pinned for key points); all other KeyLine fields are copied. */
+void orc_line_tail(const orc_keyline *kl, int n, const float *cam, const float *depth, int w, int h, float bf, orc_keyline *kl_un,
+                   float *ur_s, float *ur_e, float *d_s, float *d_e)
+{
+    for (int i = 0; i < n; i++) {
+        orc_keypoint in[2] = {{0}}, un[2];
+        in[0].x = kl[i].startPointX; in[0].y = kl[i].startPointY;
+        in[1].x = kl[i].endPointX; in[1].y = kl[i].endPointY;
+        orc_undistort_keypoints(in, 2, cam, un);
+        kl_un[i] = kl[i];
+        kl_un[i].startPointX = un[0].x; kl_un[i].startPointY = un[0].y;
+        kl_un[i].endPointX = un[1].x; kl_un[i].endPointY = un[1].y;
+        float ur[2] = {-1.f, -1.f}, dd[2] = {-1.f, -1.f};
+        if (depth) orc_stereo_from_rgbd(in, un, 2, depth, w, h, bf, ur, dd);
+        ur_s[i] = ur[0]; ur_e[i] = ur[1]; d_s[i] = dd[0]; d_e[i] = dd[1];
+    }
+}
+
 /* pose: Rcw (9, row-major), tcw (3), Ow (3); cam: fx, fy, cx, cy; bounds: minx, miny, maxx, maxy */
 void orc_is_in_frustum(const float *xw, const float *normal, const float *min_dist, const float *max_dist, int m, const float *Rcw,
                        const float *tcw, const float *Ow, const float *cam, const float *bounds, float bf, float log_scale_factor, int nlevels,
@@ -110,5 +129,56 @@ void orc_is_in_frustum(const float *xw, const float *normal, const float *min_di
         in_view[i] = 1;
         /* mTrackProjXR = u - mbf*invz is contracted too (so@0xf5dec: vfnmadd132ss) */
         proj_x[i] = u; proj_xr[i] = fmaf(-bf, invz, u); proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
+    }
+}
+
+/* Frame::isInFrustum(MapLine*, viewingCosLimit) (include/Frame.h:107): no body in the snapshot -- the point routine above on both end points of
+ * the segment (xw: m x 6, start then end), distance / viewing cosine / PredictScale at the midpoint.  out: x1 y1 x1r x2 y2 x2r. */
+static int frustum_project1(const float *P, const float *Rcw, const float *tcw, const float *cam, const float *bounds, float bf, float *u, float *v,
+                            float *ur)
+{
+    const float PcX = Rcw[0] * P[0] + Rcw[1] * P[1] + Rcw[2] * P[2] + tcw[0];
+    const float PcY = Rcw[3] * P[0] + Rcw[4] * P[1] + Rcw[5] * P[2] + tcw[1];
+    const float PcZ = Rcw[6] * P[0] + Rcw[7] * P[1] + Rcw[8] * P[2] + tcw[2];
+    if (PcZ < 0.0f) return 0;
+    const float invz = 1.0f / PcZ;
+    *u = fmaf(cam[0] * PcX, invz, cam[2]);
+    *v = fmaf(cam[1] * PcY, invz, cam[3]);
+    if (*u < bounds[0] || *u > bounds[2]) return 0;
+    if (*v < bounds[1] || *v > bounds[3]) return 0;
+    *ur = fmaf(-bf, invz, *u);
+    return 1;
+}
+
+void orc_is_in_frustum_line(const float *xw, const float *normal, const float *min_dist, const float *max_dist, int m, const float *Rcw,
+                            const float *tcw, const float *Ow, const float *cam, const float *bounds, float bf, float log_scale_factor,
+                            int nlevels, float cos_limit, float *out6, int32_t *level, float *view_cos, uint8_t *in_view)
+{
+    for (int i = 0; i < m; i++) {
+        in_view[i] = 0;
+        const float *S = xw + 6 * (size_t)i, *E = S + 3;
+        float u1, v1, r1, u2, v2, r2;
+        if (!frustum_project1(S, Rcw, tcw, cam, bounds, bf, &u1, &v1, &r1)) continue;
+        if (!frustum_project1(E, Rcw, tcw, cam, bounds, bf, &u2, &v2, &r2)) continue;
+        const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+        float PO[3];
+        for (int k = 0; k < 3; k++) PO[k] = 0.5f * (S[k] + E[k]) - Ow[k];
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)PO[k] * (double)PO[k];
+        const float dist = (float)sqrt(s);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float *Pn = normal + 3 * (size_t)i;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
+        const float viewCos = (float)(dot / (double)dist);
+        if (viewCos < cos_limit) continue;
+        const float ratio = max_dist[i] / dist;
+        int nScale = (int)ceilf(logf(ratio) / log_scale_factor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= nlevels) nScale = nlevels - 1;
+        in_view[i] = 1;
+        float *o = out6 + 6 * (size_t)i;
+        o[0] = u1; o[1] = v1; o[2] = r1; o[3] = u2; o[4] = v2; o[5] = r2;
+        level[i] = nScale; view_cos[i] = viewCos;
     }
 }

@@ -199,9 +199,14 @@ void orc_depth_to_float(const uint16_t *d, int w, int h, ptrdiff_t pitch_elems, 
 void orc_undistort_keypoints(const orc_keypoint *keys, int n, const float *cam, orc_keypoint *keys_un);
 void orc_stereo_from_rgbd(const orc_keypoint *keys, const orc_keypoint *keys_un, int n, const float *depth, int w, int h, float bf,
                           float *uright, float *kdepth);
+void orc_line_tail(const orc_keyline *kl, int n, const float *cam, const float *depth, int w, int h, float bf, orc_keyline *kl_un,
+                   float *ur_s, float *ur_e, float *d_s, float *d_e);
 void orc_is_in_frustum(const float *xw, const float *normal, const float *min_dist, const float *max_dist, int m, const float *Rcw,
                        const float *tcw, const float *Ow, const float *cam, const float *bounds, float bf, float log_scale_factor, int nlevels,
                        float cos_limit, float *proj_x, float *proj_y, float *proj_xr, int32_t *level, float *view_cos, uint8_t *in_view);
+void orc_is_in_frustum_line(const float *xw, const float *normal, const float *min_dist, const float *max_dist, int m, const float *Rcw,
+                            const float *tcw, const float *Ow, const float *cam, const float *bounds, float bf, float log_scale_factor,
+                            int nlevels, float cos_limit, float *out6, int32_t *level, float *view_cos, uint8_t *in_view);
 
 /* ---- CPU baseline driver (bench_oracle.c) */
 double orc_frontend_throughput(const uint8_t *imgs, int n_distinct, int w, int h, int n_frames, int threads, int nfeatures, int nlines,

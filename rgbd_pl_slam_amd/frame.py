@@ -50,6 +50,17 @@ def frame_tail(d_keys, n, n_frames, kp_stride, d_depth, W, H, cam, d_keys_un, d_
                                    C.byref(cam), L.vp(d_keys_un), L.vp(d_uright), L.vp(d_kdepth), device, _stream(stream)), "plf_frame_tail")
 
 
+def frame_line_tail(d_lines, n, n_frames, line_stride, d_depth, W, H, cam, d_lines_un, d_ur_start, d_ur_end, d_depth_start, d_depth_end, device=0,
+                    stream=None):
+    """Frame::UndistortKeyLines + mvuRightLineStart/End, mvDepthLineStart/End (include/Frame.h:207-211, :267) for the KeyLines of n_frames frames
+    (layout of LineSegment.extract_batch's device outputs).  n: int or a device int32 tensor with one count per frame."""
+    n_dev, n_host = (None, int(n)) if isinstance(n, int) else (L.vp(n), 0)
+    opt = lambda t: L.vp(t) if t is not None else None
+    L.check(L.lib().plf_frame_line_tail(L.vp(d_lines), n_dev, n_host, n_frames, line_stride, opt(d_depth), W, H, C.byref(cam), L.vp(d_lines_un),
+                                        opt(d_ur_start), opt(d_ur_end), opt(d_depth_start), opt(d_depth_end), device, _stream(stream)),
+            "plf_frame_line_tail")
+
+
 def frustum_points(d_xw, d_normal, d_min, d_max, pose, cam, bounds, log_scale_factor, nlevels, cos_limit, out, device=0, stream=None):
     """out: dict of device tensors proj_x, proj_y, proj_xr, level, view_cos, in_view (the plf_mappoint_view fields)"""
     pp = FrustumPose()
@@ -60,3 +71,17 @@ def frustum_points(d_xw, d_normal, d_min, d_max, pose, cam, bounds, log_scale_fa
                                        C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), C.c_float(log_scale_factor), nlevels,
                                        C.c_float(cos_limit), L.vp(out["proj_x"]), L.vp(out["proj_y"]), L.vp(out["proj_xr"]), L.vp(out["level"]),
                                        L.vp(out["view_cos"]), L.vp(out["in_view"]), device, _stream(stream)), "plf_frustum_points")
+
+
+def frustum_lines(d_xw6, d_normal, d_min, d_max, pose, cam, bounds, log_scale_factor, nlevels, cos_limit, out, device=0, stream=None):
+    """Frame::isInFrustum(MapLine*) (include/Frame.h:107) for m map lines (d_xw6: m x 6 floats, start xyz then end xyz).
+    out: dict of device tensors x1, y1, x1r, x2, y2, x2r, level, view_cos, in_view (the plf_mapline_view fields; x1r / x2r optional)"""
+    pp = FrustumPose()
+    for name in ("Rcw", "tcw", "Ow"):
+        getattr(pp, name)[:] = np.asarray(pose[name], np.float32).ravel().tolist()
+    m = int(d_xw6.shape[0])
+    opt = lambda k: L.vp(out[k]) if out.get(k) is not None else None
+    L.check(L.lib().plf_frustum_lines(L.vp(d_xw6), L.vp(d_normal), L.vp(d_min), L.vp(d_max), m, C.byref(pp), C.byref(cam), C.c_float(bounds[0]),
+                                      C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), C.c_float(log_scale_factor), nlevels,
+                                      C.c_float(cos_limit), L.vp(out["x1"]), L.vp(out["y1"]), opt("x1r"), L.vp(out["x2"]), L.vp(out["y2"]), opt("x2r"),
+                                      L.vp(out["level"]), L.vp(out["view_cos"]), L.vp(out["in_view"]), device, _stream(stream)), "plf_frustum_lines")

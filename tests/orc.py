@@ -267,6 +267,20 @@ def frame_tail(kps, depth, cam9, bf):
     return un, ur, kd
 
 
+def line_tail(kls, depth, cam9, bf):
+    kls = np.ascontiguousarray(kls); n = len(kls); un = np.zeros(n, KL_DTYPE)
+    cam = np.ascontiguousarray(cam9, np.float32)
+    out = [np.zeros(n, np.float32) for _ in range(4)]
+    if depth is not None:
+        h, w = depth.shape
+        depth = np.ascontiguousarray(depth, np.float32)
+    else:
+        h = w = 0
+    lib().orc_line_tail(p(kls), C.c_int(n), p(cam), p(depth) if depth is not None else None, C.c_int(w), C.c_int(h), C.c_float(bf), p(un),
+                        p(out[0]), p(out[1]), p(out[2]), p(out[3]))
+    return un, out[0], out[1], out[2], out[3]
+
+
 def is_in_frustum(xw, normal, dmin, dmax, Rcw, tcw, Ow, cam4, bounds, bf, logsf, nlevels, coslim):
     m = len(xw)
     a = [np.ascontiguousarray(v, np.float32) for v in (xw, normal, dmin, dmax, np.asarray(Rcw).ravel(), tcw, Ow, cam4, bounds)]
@@ -275,6 +289,16 @@ def is_in_frustum(xw, normal, dmin, dmax, Rcw, tcw, Ow, cam4, bounds, bf, logsf,
     lib().orc_is_in_frustum(p(a[0]), p(a[1]), p(a[2]), p(a[3]), C.c_int(m), p(a[4]), p(a[5]), p(a[6]), p(a[7]), p(a[8]), C.c_float(bf),
                             C.c_float(logsf), C.c_int(nlevels), C.c_float(coslim), p(px), p(py), p(pxr), p(lv), p(vc), p(iv))
     return dict(proj_x=px, proj_y=py, proj_xr=pxr, level=lv, view_cos=vc, in_view=iv)
+
+
+def is_in_frustum_line(xw6, normal, dmin, dmax, Rcw, tcw, Ow, cam4, bounds, bf, logsf, nlevels, coslim):
+    m = len(xw6)
+    a = [np.ascontiguousarray(v, np.float32) for v in (xw6, normal, dmin, dmax, np.asarray(Rcw).ravel(), tcw, Ow, cam4, bounds)]
+    o6 = np.zeros((m, 6), np.float32); lv = np.zeros(m, np.int32); vc = np.zeros(m, np.float32); iv = np.zeros(m, np.uint8)
+    lib().orc_is_in_frustum_line(p(a[0]), p(a[1]), p(a[2]), p(a[3]), C.c_int(m), p(a[4]), p(a[5]), p(a[6]), p(a[7]), p(a[8]), C.c_float(bf),
+                                 C.c_float(logsf), C.c_int(nlevels), C.c_float(coslim), p(o6), p(lv), p(vc), p(iv))
+    return dict(x1=o6[:, 0].copy(), y1=o6[:, 1].copy(), x1r=o6[:, 2].copy(), x2=o6[:, 3].copy(), y2=o6[:, 4].copy(), x2r=o6[:, 5].copy(),
+                level=lv, view_cos=vc, in_view=iv)
 
 
 def search_by_bow(kf_desc, f_desc, kf_angle, f_angle, kf_has_mp, kf_nodes, f_nodes, nnratio, check_ori):

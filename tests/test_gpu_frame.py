@@ -154,3 +154,81 @@ def test_gpu_equals_reference_undistort_fixture():
         gun = np.frombuffer(dun.cpu().numpy().tobytes(), KP_DTYPE)
         assert np.array_equal(gun["x"].view(np.uint32), c["x_un"].view(np.uint32)) and np.array_equal(gun["y"].view(np.uint32), c["y_un"].view(np.uint32))
         assert (gun["octave"] == 2).all()
+
+
+def test_frame_line_tail_batch():
+    """plf_frame_line_tail on the device outputs of the batched line extractor == oracle (bit-exact), with and without distortion / depth"""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import frame, LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    from rgbd_pl_slam_amd._lib import KL_DTYPE
+    B = 3
+    fr = [synth_frame(40 + i, with_depth=True) for i in range(B)]
+    gray = np.stack([f[0] for f in fr]); d16 = np.stack([f[1] for f in fr])
+    depth = np.stack([orc.depth_to_float(d, np.float32(1.0) / np.float32(5000.0)) for d in d16])
+    ls = LineSegment(nlines=100, max_batch=B)
+    res = ls.extract_batch(gray)
+    cap = 100
+    host = np.zeros((B, cap), KL_DTYPE); counts = np.zeros(B, np.int32)
+    for f in range(B):
+        kl = res[f][0]; counts[f] = len(kl); host[f, :len(kl)] = kl
+    dl = torch.from_numpy(np.frombuffer(host.tobytes(), np.uint8).copy()).cuda()
+    dn = torch.from_numpy(counts).cuda()
+    ddepth = _dev(depth)
+    c = frame.TUM1
+    cam9 = [c[k] for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+    for dist, with_depth in ((True, True), (False, True), (True, False)):
+        cc = dict(c)
+        if not dist:
+            cc.update(k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0)
+        cam = frame.camera(**cc)
+        c9 = list(cam9) if dist else cam9[:4] + [0, 0, 0, 0, 0]
+        dun = torch.zeros(B * cap * 68, dtype=torch.uint8, device="cuda")
+        outs = [torch.full((B, cap), 7.0, dtype=torch.float32, device="cuda") for _ in range(4)]
+        frame.frame_line_tail(dl, dn, B, cap, ddepth if with_depth else None, 640, 480, cam, dun, *outs)
+        torch.cuda.synchronize()
+        gun = np.frombuffer(dun.cpu().numpy().tobytes(), KL_DTYPE).reshape(B, cap)
+        moved = 0.0
+        for f in range(B):
+            n = counts[f]
+            un, urs, ure, ds, de = orc.line_tail(host[f, :n], depth[f] if with_depth else None, c9, c["bf"])
+            assert gun[f, :n].tobytes() == un.tobytes()
+            for g, o in zip(outs, (urs, ure, ds, de)):
+                gg = g[f].cpu().numpy()
+                assert np.array_equal(gg[:n].view(np.uint32), o.view(np.uint32))
+                assert np.all(gg[n:] == 7.0)                                        # nothing written past the frame's count
+            moved = max(moved, float(np.abs(un["startPointX"] - host[f, :n]["startPointX"]).max()))
+            if with_depth:
+                assert (ds > 0).sum() > n // 2
+        assert (moved > 0.5) == dist
+
+
+def test_frustum_lines():
+    """plf_frustum_lines == oracle bit for bit; its outputs are the plf_mapline_view fields LSDmatcher::SearchByProjection reads"""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import frame
+    from test_oracle_frame import _line_scene
+    rng = np.random.default_rng(11)
+    m = 30001
+    xw6, nrm, dmin, dmax, Rcw, tcw, Ow = _line_scene(rng, m)
+    c = frame.TUM1
+    bounds = (-20.0, -15.0, 660.0, 495.0)
+    logsf = float(np.log(np.float32(1.2)).astype(np.float32))
+    ref = orc.is_in_frustum_line(xw6, nrm, dmin, dmax, Rcw, tcw, Ow, [c["fx"], c["fy"], c["cx"], c["cy"]], bounds, c["bf"], logsf, 8, 0.5)
+    assert 500 < ref["in_view"].sum() < m
+    for with_right in (True, False):
+        out = {k: torch.zeros(m, device="cuda") for k in ("x1", "y1", "x2", "y2", "view_cos")}
+        out["x1r"] = torch.zeros(m, device="cuda") if with_right else None
+        out["x2r"] = torch.zeros(m, device="cuda") if with_right else None
+        out["level"] = torch.zeros(m, dtype=torch.int32, device="cuda"); out["in_view"] = torch.full((m,), 9, dtype=torch.uint8, device="cuda")
+        keep = [_dev(xw6), _dev(nrm), _dev(dmin), _dev(dmax)]
+        frame.frustum_lines(keep[0], keep[1], keep[2], keep[3], dict(Rcw=Rcw, tcw=tcw, Ow=Ow), frame.camera(**c), bounds, logsf, 8, 0.5, out)
+        torch.cuda.synchronize()
+        iv = out["in_view"].cpu().numpy()
+        assert np.array_equal(iv, ref["in_view"])
+        sel = iv == 1
+        for k in ("x1", "y1", "x2", "y2", "view_cos") + (("x1r", "x2r") if with_right else ()):
+            assert np.array_equal(out[k].cpu().numpy()[sel].view(np.uint32), ref[k][sel].view(np.uint32)), k
+        assert np.array_equal(out["level"].cpu().numpy()[sel], ref["level"][sel])
