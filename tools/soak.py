@@ -1,0 +1,140 @@
+"""Time-bounded randomised parity soak: ORB and LSD+LBD extraction of many differently textured frames (synthetic scenes, their noisy /
+low-contrast / quantised / rotated variants, pure noise, stripes, checkerboards, flat images; random sizes and extractor parameters) on the GPU
+against the oracle, byte for byte.  The oracle runs on a thread pool (ctypes releases the GIL); the GPU paths exercised are the single-frame
+entry points (banded speculation), the batched ones (speculative and serial schedules) and the published seed order.
+
+    python tools/soak.py [seconds=300] [threads=16] [first_seed=0]
+
+Prints one summary line; every mismatch is listed with the seed that reproduces it.  Exit code 1 on any mismatch."""
+import sys, os, time
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import orc
+from rgbd_pl_slam_amd import ORBextractor, LineSegment
+from rgbd_pl_slam_amd.synth import synth_frame
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+THREADS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+SEED0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+
+
+def make_image(seed):
+    """one of a dozen texture families, size VGA two times out of three"""
+    rng = np.random.default_rng(77000 + seed)
+    if rng.random() < 0.67:
+        w, h = 640, 480
+    else:
+        w = int(rng.integers(8, 28)) * 32 + int(rng.choice([0, 0, 1, 7, 13, 31])); h = int(rng.integers(256, min(620, int(1.7 * (w - 40)))))   # (taller than ~2:1 the reference's octree starts with round(w/h) = 0 root nodes)
+    kind = int(rng.integers(0, 12))
+    base = synth_frame(5000 + seed, w, h)
+    f = base.astype(np.float32)
+    if kind == 0:
+        img = base
+    elif kind == 1:      # heavy pixel noise
+        img = np.clip(f + rng.normal(0, rng.uniform(4, 25), f.shape), 0, 255).astype(np.uint8)
+    elif kind == 2:      # low contrast
+        img = np.clip(128 + (f - 128) * rng.uniform(0.08, 0.4), 0, 255).astype(np.uint8)
+    elif kind == 3:      # high contrast / saturation
+        img = np.clip(128 + (f - 128) * rng.uniform(2, 6), 0, 255).astype(np.uint8)
+    elif kind == 4:      # coarse quantisation (plateaus, many equal gradients)
+        q = int(rng.choice([8, 16, 32, 64])); img = ((base // q) * q).astype(np.uint8)
+    elif kind == 5:      # transposed / flipped scene
+        img = np.ascontiguousarray(base[::-1, ::-1]) if rng.random() < 0.5 else np.ascontiguousarray(synth_frame(5000 + seed, h, w).T)
+    elif kind == 6:      # pure noise
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    elif kind == 7:      # stripes at a random angle and period
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        a = rng.uniform(0, np.pi); per = rng.uniform(3, 40)
+        img = (127.5 + 120 * np.sign(np.sin((xx * np.cos(a) + yy * np.sin(a)) * 2 * np.pi / per))).astype(np.uint8)
+    elif kind == 8:      # checkerboard
+        c = int(rng.integers(4, 48)); yy, xx = np.mgrid[0:h, 0:w]
+        img = ((((yy // c) + (xx // c)) & 1) * int(rng.integers(60, 256))).astype(np.uint8)
+    elif kind == 9:      # smooth ramps + a few sharp edges
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.clip(xx * rng.uniform(0.05, 0.4) + yy * rng.uniform(0.05, 0.4) + 60 * (xx > w * rng.uniform(0.2, 0.8)) + 50 * (yy > h * rng.uniform(0.2, 0.8)), 0, 255).astype(np.uint8)
+    elif kind == 10:     # flat (nothing to find)
+        img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+    else:                # scene with a black / white frame border and a saturated block
+        img = base.copy(); b = int(rng.integers(1, 30)); img[:b] = 0; img[-b:] = 255; img[:, :b] = 255; img[:, -b:] = 0
+        img[h // 3:h // 2, w // 3:w // 2] = 255
+    return np.ascontiguousarray(img), kind
+
+
+def eq_orb(got, ref):
+    kps, desc = got
+    if len(kps) != len(ref["kps"]):
+        return False
+    return kps.tobytes() == ref["kps"].tobytes() and np.array_equal(desc, ref["desc"])
+
+
+def eq_lines(got, ref):
+    kl, desc, eq = got
+    if len(kl) != len(ref["kl"]):
+        return False
+    return kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"]) and np.allclose(eq, ref["eq"], rtol=0, atol=1e-9)
+
+
+def main():
+    pool = ThreadPoolExecutor(THREADS)
+    t_end = time.time() + SECONDS
+    seed = SEED0
+    n_orb = n_line = n_batchline = 0
+    bad = []
+    vga_orb = ORBextractor(nfeatures=1000, max_width=640, max_height=480, max_batch=8)
+    vga_line = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=8)
+    while time.time() < t_end:
+        group = [make_image(seed + i) for i in range(THREADS)]
+        rng = np.random.default_rng(991 + seed)
+        nf = int(rng.choice([500, 1000, 2000])); nl = int(rng.choice([50, 100, 200]))
+        futs_o = [pool.submit(orc.orb_extract, im, nfeatures=(1000 if im.shape == (480, 640) else nf)) for im, _ in group]
+        futs_l = [pool.submit(orc.line_extract, im, (100 if im.shape == (480, 640) else nl)) for im, _ in group]
+        got_o, got_l = [], []
+        vga = [i for i, (im, _) in enumerate(group) if im.shape == (480, 640)]
+        for i, (im, kind) in enumerate(group):
+            if im.shape == (480, 640):
+                got_o.append(vga_orb(im)); got_l.append(vga_line.ExtractLineSegment(im))
+            else:
+                h, w = im.shape
+                e = ORBextractor(nfeatures=nf, max_width=w, max_height=h); got_o.append(e(im)); e.close()
+                ls = LineSegment(nlines=nl, max_width=w, max_height=h); got_l.append(ls.ExtractLineSegment(im)); ls.close()
+        # batches of the VGA frames: speculative schedule (8 frames -> 16 bands), then the serial schedule of the same frames
+        batch_res = []
+        for b0 in range(0, len(vga) - 7, 8):
+            ids = vga[b0:b0 + 8]
+            stack = np.stack([group[i][0] for i in ids])
+            r_spec = vga_line.extract_batch(stack)
+            os.environ["PLF_LSD_SPEC_BANDS"] = "0"
+            r_ser = vga_line.extract_batch(stack)
+            del os.environ["PLF_LSD_SPEC_BANDS"]
+            os.environ["PLF_LSD_SPEC_BANDS"] = "4"
+            r_4 = vga_line.extract_batch(stack)
+            del os.environ["PLF_LSD_SPEC_BANDS"]
+            r_orb = vga_orb.extract_batch(stack)
+            batch_res.append((ids, r_spec, r_ser, r_4, r_orb))
+        refs_o = [f.result() for f in futs_o]; refs_l = [f.result() for f in futs_l]
+        for i, (im, kind) in enumerate(group):
+            n_orb += 1; n_line += 1
+            if not eq_orb(got_o[i], refs_o[i]):
+                bad.append(("orb", seed + i, kind, im.shape))
+            if not eq_lines(got_l[i], refs_l[i]):
+                bad.append(("lines", seed + i, kind, im.shape))
+        for ids, r_spec, r_ser, r_4, r_orb in batch_res:
+            for k, i in enumerate(ids):
+                n_batchline += 3
+                for name, r in (("lines-batch-spec16", r_spec), ("lines-batch-serial", r_ser), ("lines-batch-spec4", r_4)):
+                    if not eq_lines(r[k], refs_l[i]):
+                        bad.append((name, seed + i, group[i][1], group[i][0].shape))
+                if not eq_orb(r_orb[k], refs_o[i]):
+                    bad.append(("orb-batch", seed + i, group[i][1], group[i][0].shape))
+        seed += THREADS
+    print("soak: %d frames (seeds %d..%d): %d ORB + %d line single-frame checks, %d batched line checks, %d mismatches" %
+          (seed - SEED0, SEED0, seed - 1, n_orb, n_line, n_batchline, len(bad)))
+    for b in bad[:40]:
+        print("MISMATCH", b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
