@@ -32,7 +32,10 @@ typedef enum {
     PLF_E_BADARG = -2,   /* unsupported size / parameter (reference: assert or UB) */
     PLF_E_CAPACITY = -3, /* caller's output capacity too small; outputs truncated */
     PLF_E_HIP = -4,      /* HIP runtime failure (no device, launch error, ...) */
-    PLF_E_NOMEM = -5
+    PLF_E_NOMEM = -5,
+    PLF_E_RECTS = -6     /* line extractor, fully device-resident batches only: the batch produced more LSD rectangles than the pooled NFA buffers
+                            hold (thousands per frame on average); its outputs are invalid -- redo it in smaller batches (calls that hand
+                            host buffers in or out do that themselves) */
 } plf_status;
 
 enum { PLF_MEM_HOST = 0, PLF_MEM_DEVICE = 1 };
@@ -135,6 +138,9 @@ int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int
  * chain that leaves most issue slots idle; work queued behind this point overlaps with it instead of competing with
  * the front stages.  No-op if no batch was enqueued yet. */
 int plf_line_wait_front(plf_line *h, void *stream);
+/* Status of the last batch enqueued with device-resident inputs AND outputs (that call returns before the GPU has run): waits for `stream`
+ * (NULL: the handle's stream), then PLF_OK, PLF_E_CAPACITY (a frame had more lines than `capacity`) or PLF_E_RECTS. */
+int plf_line_last_status(plf_line *h, void *stream);
 
 /* Diagnostics of the banded speculative region growing used for <= 640 frames in flight, frame 0 of the last batch:
  * out8 = {regions committed from the speculation, regions grown by the commit wave, chunks committed in one step, records checked pixel by pixel,

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libplf_hip.so")
 
-PLF_OK, PLF_E_EMPTY, PLF_E_BADARG, PLF_E_CAPACITY, PLF_E_HIP, PLF_E_NOMEM = 0, -1, -2, -3, -4, -5
+PLF_OK, PLF_E_EMPTY, PLF_E_BADARG, PLF_E_CAPACITY, PLF_E_HIP, PLF_E_NOMEM, PLF_E_RECTS = 0, -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),

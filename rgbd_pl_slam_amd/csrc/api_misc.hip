@@ -13,6 +13,7 @@ extern "C" const char *plf_status_string(int status)
         case PLF_E_CAPACITY: return "output capacity too small";
         case PLF_E_HIP: return "HIP runtime error";
         case PLF_E_NOMEM: return "out of memory";
+        case PLF_E_RECTS: return "more LSD rectangles than the line handle holds";
         default: return "unknown";
     }
 }

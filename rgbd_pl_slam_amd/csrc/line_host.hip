@@ -22,12 +22,13 @@ __global__ void k_lsd_lgamma_table(double *);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
 struct NfaCounts { int total, alg[6], pad; };
 struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
-__global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, NfaState *, int *, LsdGeom);
+__global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, NfaState *, int *, int *, LsdGeom);
+__global__ void k_nfa_clamp(int *, int *, LsdGeom);
 __global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_eval(int, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
-                               int, int *, LsdGeom);
+                               int, int *, unsigned long long *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
 
@@ -48,6 +49,7 @@ struct plf_line {
     int cur_w, cur_h;
     size_t alloc_full, alloc_scaled;  // elements per frame the buffers were sized for
     int alloc_rect_cap;
+    int alloc_nfa_pool;
     size_t regions_lds, finalize_lds, nfa_lds;
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
@@ -63,6 +65,7 @@ struct plf_line {
     NfaCounts *d_cnt;
     int *d_nfa_counters;
     double *d_vals;
+    unsigned long long *d_sort_scratch;   // [frame][sort_cap] when sort_cap > sort_lds
     double2 *d_cs;
     float2 *d_cs0;
     float *d_ang;
@@ -87,7 +90,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
     for (void *p : sp) if (p) (void)hipFree(p);
@@ -115,12 +118,29 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     // slots: the kernel is a latency-bound serial chain per frame and its throughput is the number of frames in flight.
     g->rcap = 1535;
     if (const char *e = getenv("PLF_LSD_RCAP")) { if (atoi(e) >= 63 && atoi(e) <= 16384) g->rcap = atoi(e); }
-    int rc = 2048;
-    while (rc < g->sw * g->sh / 48 && rc < 8192) rc <<= 1;
+    // Rectangles per frame: regions are disjoint and one that yields a rectangle owns >= min_reg_size pixels, so sw * sh / min_reg_size bounds
+    // their number for ANY image (13107 at VGA, 46k at 1280x960; real frames produce 500-1500): no frame can overflow its rows.  Only the NFA
+    // stage buffers are pooled over the batch (line_nfa_pool).
+    int rc = g->sw * g->sh / (g->min_reg_size > 0 ? g->min_reg_size : 1) + 1;
+    rc = (rc + 255) & ~255;
+    if (rc < 256) rc = 256;
     g->rect_cap = rc;
-    g->sort_cap = rc;
+    g->sort_cap = 256;
+    while (g->sort_cap < rc) g->sort_cap <<= 1;
+    g->sort_lds = g->sort_cap < 4096 ? g->sort_cap : 4096;
     g->nkeep = h->prm.nlines;
     return PLF_OK;
+}
+
+// NFA stage capacity in rectangles for a batch of B frames: the stage works on one list compacted over the batch, sized for 2048-8192 rectangles
+// per frame on average (by image area) and for at least one worst-case frame
+static size_t line_nfa_pool(const LsdGeom &g, size_t B)
+{
+    size_t per = 2048;
+    while (per < (size_t)g.sw * g.sh / 48 && per < 8192) per <<= 1;
+    size_t pool = B * per;
+    if (pool < (size_t)g.rect_cap) pool = (size_t)g.rect_cap;
+    return pool < 0x7fffffff / 8 ? pool : 0x7fffffff / 8;
 }
 
 static int line_configure(plf_line *h, int w, int hh)
@@ -129,7 +149,7 @@ static int line_configure(plf_line *h, int w, int hh)
     LsdGeom g;
     int rc = line_geometry(h, w, hh, &g);
     if (rc != PLF_OK) return rc;
-    if (g.full_stride > h->alloc_full || g.s_stride > h->alloc_scaled || g.rect_cap > h->alloc_rect_cap) return PLF_E_BADARG;
+    if (g.full_stride > h->alloc_full || g.s_stride > h->alloc_scaled) return PLF_E_BADARG;
     // cv::resize(double image, fx = fy = 0.8, INTER_LINEAR): float coefficients, see oracle/lsd_oracle.c
     const double scale = 1. / 0.8;
     std::vector<int> xofs(g.sw), yofs(g.sh);
@@ -159,14 +179,17 @@ static int line_configure(plf_line *h, int w, int hh)
     }
     // keep the allocation strides so that per-frame offsets stay inside the buffers
     g.full_stride = (uint32_t)h->alloc_full; g.s_stride = (uint32_t)h->alloc_scaled; g.rect_cap = h->alloc_rect_cap;
-    g.sort_cap = h->alloc_rect_cap;
+    g.sort_cap = 256;
+    while (g.sort_cap < g.rect_cap) g.sort_cap <<= 1;
+    g.sort_lds = g.sort_cap < 4096 ? g.sort_cap : 4096;
+    g.nfa_pool = h->alloc_nfa_pool;
     PLF_HIP_TRY(hipMemcpy(h->d_xofs, xofs.data(), sizeof(int) * g.sw, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_xa, xa.data(), sizeof(float2) * g.sw, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(float2) * g.sh, hipMemcpyHostToDevice));
     h->g = g;
     h->regions_lds = (size_t)(g.rcap + 1) * 4 + 64;
-    h->finalize_lds = (size_t)g.sort_cap * 8 + (size_t)g.rect_cap * 4 + 260 * 4;
+    h->finalize_lds = (size_t)g.sort_lds * 8 + 260 * 4;   // (the compaction flags alias the sort keys)
     h->nfa_lds = (size_t)g.sh * 2 * sizeof(int) + 64;
     h->cur_w = w; h->cur_h = hh;
     return PLF_OK;
@@ -192,6 +215,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     int rc = line_geometry(h, p->max_width, p->max_height, &g);
     if (rc != PLF_OK) { free(h); return rc; }
     h->alloc_full = g.full_stride; h->alloc_scaled = g.s_stride; h->alloc_rect_cap = g.rect_cap;
+    h->alloc_nfa_pool = (int)line_nfa_pool(g, (size_t)p->max_batch);
     // cv::getGaussianKernel(7, 0.6/0.8, CV_64F):  h = ceil(sigma * sqrt(2 * 3 * ln 10)) = 3 -> ksize 7
     {
         const double sigma = 0.6 / 0.8, scale2X = -0.5 / (sigma * sigma);
@@ -207,7 +231,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
         u = (9 * 7 - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
         for (int i = 0; i < 63; i++) { const double d = i - u; h->lbd.gG[i] = (float)exp(d * d * inv); }
     }
-    const size_t B = (size_t)p->max_batch, F = g.full_stride, S = g.s_stride, R = (size_t)g.rect_cap;
+    const size_t B = (size_t)p->max_batch, F = g.full_stride, S = g.s_stride, R = (size_t)g.rect_cap, NP = (size_t)h->alloc_nfa_pool;
     const int cap = p->nlines;
 #define ALLOC(ptr, bytes)                                                             \
     do {                                                                              \
@@ -232,11 +256,12 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
     ALLOC(h->d_counters, (4 * B + 16) * sizeof(int));
     ALLOC(h->d_lgam, 65536 * sizeof(double));
-    ALLOC(h->d_ent[0], B * R * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], B * R * 5 * sizeof(NfaEntry));
-    ALLOC(h->d_st[0], B * R * sizeof(NfaState)); ALLOC(h->d_st[1], B * R * sizeof(NfaState));
-    ALLOC(h->d_cnt, B * R * 5 * sizeof(NfaCounts));
+    ALLOC(h->d_ent[0], NP * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], NP * 5 * sizeof(NfaEntry));
+    ALLOC(h->d_st[0], NP * sizeof(NfaState)); ALLOC(h->d_st[1], NP * sizeof(NfaState));
+    ALLOC(h->d_cnt, NP * 5 * sizeof(NfaCounts));
     ALLOC(h->d_nfa_counters, 16 * sizeof(int));
-    ALLOC(h->d_vals, B * R * 6 * sizeof(double));
+    ALLOC(h->d_vals, NP * 6 * sizeof(double));
+    if (g.sort_cap > g.sort_lds) ALLOC(h->d_sort_scratch, B * (size_t)g.sort_cap * sizeof(unsigned long long));
     if (p->seed_order == 1) {
         if ((size_t)g.sw * g.sh >= (1u << 20)) { line_free(h); free(h); return PLF_E_BADARG; }   // pixel index must fit the 20 low key bits
         ALLOC(h->d_maxgrad, B * sizeof(double));
@@ -383,8 +408,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)
     PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
-    hipLaunchKernelGGL(k_nfa_init, dim3((g.rect_cap + 255) / 256, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
-                       h->d_nfa_counters, g);
+    hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
+                       h->d_nfa_counters, status, g);
+    hipLaunchKernelGGL(k_nfa_clamp, dim3(1), dim3(1), 0, s, h->d_nfa_counters, status, g);
     const int count_waves = 256 * 16, math_blocks = 1024;
     for (int stage = 0; stage <= 4; stage++) {
         const int in = stage & 1, out = in ^ 1;
@@ -396,7 +422,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                            h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
     }
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
-                       d_lines, d_eq, d_nout, capacity, status, g);
+                       d_lines, d_eq, d_nout, capacity, status, h->d_sort_scratch, g);
     hipLaunchKernelGGL(k_lbd, dim3(capacity < g.nkeep ? capacity : g.nkeep, B), dim3(128), 0, s, h->d_grad, d_lines, d_nout, d_ldesc, capacity, g,
                        h->lbd);
     PLF_HIP_TRY(hipGetLastError());
@@ -454,9 +480,33 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
         }
     }
     PLF_HIP_TRY(hipStreamSynchronize(s));
-    if (status & 1) return PLF_E_HIP;  // more rectangles than rect_cap
+    if (status & 1) {
+        // The batch as a whole produced more rectangles than the pooled NFA buffers hold (thousands per frame on average: synthetic textures).
+        // One frame always fits, so the batch is redone in halves.
+        if (n_frames == 1) return PLF_E_RECTS;
+        const int32_t h1 = n_frames / 2;
+        const int ra = plf_line_extract_batch(h, gray, in_mem, h1, width, height, pitch, frame_stride, lines, ldesc, line_eq, n_out, out_mem, capacity,
+                                              stream);
+        const int rb = plf_line_extract_batch(h, gray + (size_t)h1 * frame_stride, in_mem, n_frames - h1, width, height, pitch, frame_stride,
+                                              lines + (size_t)h1 * capacity, ldesc + (size_t)h1 * capacity * 32, line_eq + (size_t)h1 * capacity * 3,
+                                              n_out + h1, out_mem, capacity, stream);
+        if (ra != PLF_OK && ra != PLF_E_CAPACITY) return ra;
+        if (rb != PLF_OK && rb != PLF_E_CAPACITY) return rb;
+        return (ra == PLF_E_CAPACITY || rb == PLF_E_CAPACITY) ? PLF_E_CAPACITY : PLF_OK;
+    }
     if (status & 2) ret = PLF_E_CAPACITY;
     return ret;
+}
+
+extern "C" int plf_line_last_status(plf_line *h, void *stream)
+{
+    if (!h) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    int status = 0;
+    PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
+    PLF_HIP_TRY(hipStreamSynchronize(s));
+    return (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : PLF_OK;
 }
 
 extern "C" int plf_line_extract(plf_line *h, const uint8_t *gray, int32_t width, int32_t height, ptrdiff_t pitch, plf_keyline *lines,

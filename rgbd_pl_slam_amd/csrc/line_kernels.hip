@@ -13,14 +13,17 @@ __global__ void __launch_bounds__(256) k_lsd_finalize(const float4 *__restrict__
                                                       const int *__restrict__ nrect, float4 *__restrict__ segs_out, int *__restrict__ nseg_out,
                                                       plf_keyline *__restrict__ kl_tmp_all, plf_keyline *__restrict__ lines,
                                                       double *__restrict__ lineeq, int *__restrict__ n_out, int capacity,
-                                                      int *__restrict__ status, LsdGeom g)
+                                                      int *__restrict__ status, unsigned long long *__restrict__ sort_scratch, LsdGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long *skey = (unsigned long long *)smem;       // sort_cap
-    int *flag = (int *)(skey + g.sort_cap);                      // rect_cap
-    int *scan_tmp = flag + g.rect_cap;                           // 257
+    // LDS: g.sort_lds keys (the compaction flags alias them: dead before the first key is written, barrier below) + 257 scan words.  A frame with
+    // more rectangles / segments than that (textures of thousands of tiny regions) uses its row of the global scratch instead.
     const int f = blockIdx.x, T = blockDim.x, t = threadIdx.x;
     const int nr = nrect[f];
+    unsigned long long *grow = sort_scratch ? sort_scratch + (size_t)f * g.sort_cap : (unsigned long long *)smem;
+    unsigned long long *skey = (unsigned long long *)smem;
+    int *flag = nr <= 2 * g.sort_lds ? (int *)smem : (int *)grow;
+    int *scan_tmp = (int *)((unsigned long long *)smem + g.sort_lds);
     const float4 *seg = seg_all + (size_t)f * g.rect_cap;
     const uint8_t *keep = keep_all + (size_t)f * g.rect_cap;
     for (int i = t; i < nr; i += T) flag[i] = keep[i] ? 1 : 0;
@@ -67,6 +70,7 @@ __global__ void __launch_bounds__(256) k_lsd_finalize(const float4 *__restrict__
         // stable "response descending" order: key = (response bits, ~index), sorted descending
         int P2 = 1;
         while (P2 < ns) P2 <<= 1;
+        if (P2 > g.sort_lds) skey = grow;
         for (int i = t; i < P2; i += T)
             skey[i] = i < ns ? (((unsigned long long)__float_as_uint(klt[i].response) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i)) : 0ull;
         __syncthreads();

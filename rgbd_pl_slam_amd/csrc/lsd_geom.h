@@ -17,9 +17,11 @@ struct LsdGeom {
     double rho, prec, p, log_nt;
     int min_reg_size;
     int rcap;             // region-list entries kept in LDS (one spare word follows)
-    int rect_cap;         // rectangles / segments per frame
+    int rect_cap;         // rectangles / segments per frame: sw * sh / min_reg_size (every region owns >= min_reg_size pixels), at most 16384
     int nkeep;            // lines kept after the response sort
     int sort_cap;         // power of two >= rect_cap
+    int sort_lds;         // sort keys k_lsd_finalize keeps in LDS (frames with more segments sort in a global scratch row)
+    int nfa_pool;         // rectangles of the whole batch the NFA stage buffers hold (entries are compacted over the batch)
 };
 
 // banded speculative region growing: one record per effective seed of a band wave, and the buffers of both phases

@@ -1439,18 +1439,25 @@ __device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
 // one lane per rectangle of every frame: queue it for the first count
 __global__ void __launch_bounds__(256) k_nfa_init(const LsdRect *__restrict__ rects_all, const int *__restrict__ nrect,
                                                   uint8_t *__restrict__ keep_all, NfaEntry *__restrict__ entries, NfaState *__restrict__ states,
-                                                  int *__restrict__ counters, LsdGeom g)
+                                                  int *__restrict__ counters, int *__restrict__ status, LsdGeom g)
 {
-    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nrect[f]) return;
-    keep_all[(size_t)f * g.rect_cap + i] = 0;
-    const int q = atomicAdd(&counters[0], 1);
-    NfaEntry e;
-    e.r = rects_all[(size_t)f * g.rect_cap + i]; e.frame = f; e.nprec = 6; e.pad0 = e.pad1 = 0;
-    entries[q] = e;
-    NfaState st;
-    st.rec = e.r; st.log_nfa = -1; st.frame = f; st.rect = i;
-    states[q] = st;
+    const int f = blockIdx.y, n = nrect[f];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        keep_all[(size_t)f * g.rect_cap + i] = 0;
+        const int q = atomicAdd(&counters[0], 1);
+        if (q >= g.nfa_pool) { atomicOr(status, 1); continue; }   // the batch holds more rectangles than the pooled stage buffers (k_nfa_clamp trims the count)
+        NfaEntry e;
+        e.r = rects_all[(size_t)f * g.rect_cap + i]; e.frame = f; e.nprec = 6; e.pad0 = e.pad1 = 0;
+        entries[q] = e;
+        NfaState st;
+        st.rec = e.r; st.log_nfa = -1; st.frame = f; st.rect = i;
+        states[q] = st;
+    }
+}
+
+__global__ void k_nfa_clamp(int *__restrict__ counters, int *__restrict__ status, LsdGeom g)
+{
+    if (counters[0] > g.nfa_pool) { counters[0] = g.nfa_pool; atomicOr(status, 1); }
 }
 
 // persistent waves: entry e -> counts[e];  n = counters[cidx] * mult

@@ -59,6 +59,10 @@ class LineSegment:
                                                L.vp(d_lines), L.vp(d_desc), L.vp(d_eq), L.vp(d_n), L.MEM_DEVICE, capacity,
                                                C.c_void_p(stream) if stream else None), "plf_line_extract_batch")
 
+    def last_status(self, stream=None):
+        """status of the last extract_batch_device call (waits for the stream): 0, PLF_E_CAPACITY or PLF_E_RECTS"""
+        return int(L.lib().plf_line_last_status(self._h, C.c_void_p(stream) if stream else None))
+
     def wait_front(self, stream):
         """make `stream` wait until the stages before region growing of the last enqueued batch are done"""
         L.check(L.lib().plf_line_wait_front(self._h, C.c_void_p(stream) if stream else None), "plf_line_wait_front")

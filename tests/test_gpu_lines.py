@@ -222,3 +222,57 @@ def test_lines_speculative_halo_rows(monkeypatch, halo):
     for seed in (12, 13):
         _check(synth_frame(seed), 100, ext=ext)
     ext.close()
+
+
+def test_lines_thousands_of_rectangles():
+    """Textures of thousands of tiny regions: the rectangle capacity is the exact bound sw*sh/min_reg_size (a 4096-rectangle cap used to fail on the
+    first image, found by tools/soak.py seed 246), and frames with more than 4096 segments sort through the global scratch row."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    # the soak's failing frame: hard-edged stripes, period ~ a few pixels, at an angle
+    rng = np.random.default_rng(77000 + 246)
+    rng.random(); rng.integers(0, 12)
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    a = rng.uniform(0, np.pi); per = rng.uniform(3, 40)
+    stripes = (127.5 + 120 * np.sign(np.sin((xx * np.cos(a) + yy * np.sin(a)) * 2 * np.pi / per))).astype(np.uint8)
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=2)
+    ref = orc.line_extract(stripes, 100)
+    kl, desc, eq = ls.ExtractLineSegment(stripes)
+    assert kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"])
+    yi, xi = np.mgrid[0:480, 0:640]
+    checker = ((((yi // 10) + (xi // 10)) & 1) * 200).astype(np.uint8)
+    res = ls.extract_batch(np.stack([checker, stripes]))                       # the same through the batched (speculative) path
+    refc = orc.line_extract(checker, 100)
+    assert res[0][0].tobytes() == refc["kl"].tobytes() and np.array_equal(res[0][1], refc["desc"])
+    assert res[1][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[1][1], ref["desc"])
+    # eight such frames: more rectangles than the batch's pooled NFA buffers -> the host-buffer call redoes the batch in halves by itself ...
+    res = ls8 = None
+    ls8 = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=8)
+    res = ls8.extract_batch(np.stack([stripes] * 8))
+    for f in range(8):
+        assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"])
+    # ... and the fully device-resident call reports it
+    import torch
+    from rgbd_pl_slam_amd import _lib as L
+    d_img = torch.from_numpy(np.stack([stripes] * 8)).cuda()
+    d_lines = torch.zeros(8 * 100 * 68, dtype=torch.uint8, device="cuda"); d_desc = torch.zeros(8 * 100 * 32, dtype=torch.uint8, device="cuda")
+    d_eq = torch.zeros(8 * 100 * 3, dtype=torch.float64, device="cuda"); d_n = torch.zeros(8, dtype=torch.int32, device="cuda")
+    ls8.extract_batch_device(d_img, 640, 480, d_lines, d_desc, d_eq, d_n, 100)
+    assert ls8.last_status() == L.PLF_E_RECTS
+    ls8.extract_batch_device(d_img[:2], 640, 480, d_lines, d_desc, d_eq, d_n, 100)
+    assert ls8.last_status() == L.PLF_OK
+    got = np.frombuffer(d_lines.cpu().numpy().tobytes(), L.KL_DTYPE)[:int(d_n[0])]
+    assert got.tobytes() == ref["kl"].tobytes()
+    ls8.close()
+    ls.close()
+    # 1280x960 checkerboard: ~10k segments -> compaction flags and sort keys in global memory; top-400 and unsorted (all kept) outputs
+    yi, xi = np.mgrid[0:960, 0:1280]
+    big = ((((yi // 10) + (xi // 10)) & 1) * 200).astype(np.uint8)
+    for nl in (400, 20000):
+        ls = LineSegment(nlines=nl, max_width=1280, max_height=960)
+        ref = orc.line_extract(big, nl)
+        kl, desc, eq = ls.ExtractLineSegment(big)
+        assert len(ref["kl"]) == (400 if nl == 400 else len(ls.segments(0))) and len(ls.segments(0)) > 8192
+        assert kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"])
+        assert np.allclose(eq, ref["eq"], rtol=0, atol=1e-9)
+        ls.close()

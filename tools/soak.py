@@ -94,7 +94,12 @@ def main():
         vga = [i for i, (im, _) in enumerate(group) if im.shape == (480, 640)]
         for i, (im, kind) in enumerate(group):
             if im.shape == (480, 640):
-                got_o.append(vga_orb(im)); got_l.append(vga_line.ExtractLineSegment(im))
+                got_o.append(vga_orb(im))
+                try:
+                    got_l.append(vga_line.ExtractLineSegment(im))
+                except Exception as ex:
+                    print("EXCEPTION", seed + i, kind, im.shape, ex, flush=True)
+                    raise
             else:
                 h, w = im.shape
                 e = ORBextractor(nfeatures=nf, max_width=w, max_height=h); got_o.append(e(im)); e.close()
