@@ -23,8 +23,11 @@ SEED0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 def make_image(seed):
     """one of a dozen texture families, size VGA two times out of three"""
     rng = np.random.default_rng(77000 + seed)
-    if rng.random() < 0.67:
+    r = rng.random()
+    if r < 0.6:
         w, h = 640, 480
+    elif r < 0.67:
+        w, h = 1280, 960
     else:
         w = int(rng.integers(8, 28)) * 32 + int(rng.choice([0, 0, 1, 7, 13, 31])); h = int(rng.integers(256, min(620, int(1.7 * (w - 40)))))   # (taller than ~2:1 the reference's octree starts with round(w/h) = 0 root nodes)
     kind = int(rng.integers(0, 12))
@@ -87,7 +90,7 @@ def main():
     while time.time() < t_end:
         group = [make_image(seed + i) for i in range(THREADS)]
         rng = np.random.default_rng(991 + seed)
-        nf = int(rng.choice([500, 1000, 2000])); nl = int(rng.choice([50, 100, 200]))
+        nf = int(rng.choice([300, 1000, 2000, 5000])); nl = int(rng.choice([50, 100, 200, 1000]))
         futs_o = [pool.submit(orc.orb_extract, im, nfeatures=(1000 if im.shape == (480, 640) else nf)) for im, _ in group]
         futs_l = [pool.submit(orc.line_extract, im, (100 if im.shape == (480, 640) else nl)) for im, _ in group]
         got_o, got_l = [], []
