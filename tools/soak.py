@@ -90,9 +90,20 @@ def main():
     while time.time() < t_end:
         group = [make_image(seed + i) for i in range(THREADS)]
         rng = np.random.default_rng(991 + seed)
-        nf = int(rng.choice([300, 1000, 2000, 5000])); nl = int(rng.choice([50, 100, 200, 1000]))
-        futs_o = [pool.submit(orc.orb_extract, im, nfeatures=(1000 if im.shape == (480, 640) else nf)) for im, _ in group]
-        futs_l = [pool.submit(orc.line_extract, im, (100 if im.shape == (480, 640) else nl)) for im, _ in group]
+        # (the octree kernel holds <= ~1900 nodes per level in LDS: plf_orb_create rejects larger per-level quotas)
+        nf = int(rng.choice([300, 1000, 2000, 3000])); nl = int(rng.choice([50, 100, 200, 1000]))
+        # frames that are not VGA also draw the other extractor parameters (every level keeps at least one 30-px FAST cell) and the LSD seed order
+        sf = float(np.float32(rng.choice([1.1, 1.2, 1.3, 1.5]))); nlev = int(rng.integers(3, 9)); ini = int(rng.integers(12, 40)); mn = int(rng.integers(3, 12))
+        so = int(rng.integers(0, 2))
+        def orb_par(im):
+            if im.shape == (480, 640):
+                return dict(nfeatures=1000)
+            k = nlev
+            while min(im.shape) / (sf ** (k - 1)) < 70:
+                k -= 1
+            return dict(nfeatures=nf, scale_factor=sf, nlevels=k, ini_th=ini, min_th=mn)
+        futs_o = [pool.submit(orc.orb_extract, im, **orb_par(im)) for im, _ in group]
+        futs_l = [pool.submit(orc.line_extract, im, (100 if im.shape == (480, 640) else nl), (0 if im.shape == (480, 640) else so)) for im, _ in group]
         got_o, got_l = [], []
         vga = [i for i, (im, _) in enumerate(group) if im.shape == (480, 640)]
         for i, (im, kind) in enumerate(group):
@@ -105,8 +116,14 @@ def main():
                     raise
             else:
                 h, w = im.shape
-                e = ORBextractor(nfeatures=nf, max_width=w, max_height=h); got_o.append(e(im)); e.close()
-                ls = LineSegment(nlines=nl, max_width=w, max_height=h); got_l.append(ls.ExtractLineSegment(im)); ls.close()
+                pr = orb_par(im)
+                try:
+                    e = ORBextractor(nfeatures=nf, scaleFactor=pr["scale_factor"], nlevels=pr["nlevels"], iniThFAST=ini, minThFAST=mn, max_width=w, max_height=h)
+                except Exception as ex:
+                    print("EXCEPTION", seed + i, kind, im.shape, pr, ini, mn, ex, flush=True)
+                    raise
+                got_o.append(e(im)); e.close()
+                ls = LineSegment(nlines=nl, max_width=w, max_height=h, seed_order=so); got_l.append(ls.ExtractLineSegment(im)); ls.close()
         # batches of the VGA frames: speculative schedule (8 frames -> 16 bands), then the serial schedule of the same frames
         batch_res = []
         for b0 in range(0, len(vga) - 7, 8):
