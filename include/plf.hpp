@@ -225,6 +225,54 @@ private:
     bool mbCheckOrientation;
 };
 
+// ORB_SLAM2::Frame members either side of the extractor / matcher path (include/Frame.h), stateless: device pointers in and out, one frame.
+// Names and roles follow the reference; the reference works on its own member vectors, these take the same data as arrays.
+struct Frame {
+    // void Frame::UndistortKeyPoints()  include/Frame.h (so@0xf8630): mvKeys -> mvKeysUn
+    static void UndistortKeyPoints(const plf_keypoint *mvKeys_dev, int N, const plf_camera &cam, plf_keypoint *mvKeysUn_dev, int device = 0,
+                                   void *stream = nullptr)
+    {
+        check(plf_frame_tail(mvKeys_dev, nullptr, N, 1, N, nullptr, 0, 0, &cam, mvKeysUn_dev, nullptr, nullptr, device, stream), "Frame::UndistortKeyPoints");
+    }
+    // void Frame::ComputeStereoFromRGBD(const cv::Mat &imDepth) (so@0xf6860): mvuRight, mvDepth (also rewrites mvKeysUn: same values)
+    static void ComputeStereoFromRGBD(const plf_keypoint *mvKeys_dev, int N, const float *imDepth_dev, int width, int height, const plf_camera &cam,
+                                      plf_keypoint *mvKeysUn_dev, float *mvuRight_dev, float *mvDepth_dev, int device = 0, void *stream = nullptr)
+    {
+        check(plf_frame_tail(mvKeys_dev, nullptr, N, 1, N, imDepth_dev, width, height, &cam, mvKeysUn_dev, mvuRight_dev, mvDepth_dev, device, stream),
+              "Frame::ComputeStereoFromRGBD");
+    }
+    // void Frame::UndistortKeyLines() include/Frame.h:267 + mvuRightLineStart/End, mvDepthLineStart/End (:208-211)
+    static void UndistortKeyLines(const plf_keyline *mvKeylines_dev, int NL, const float *imDepth_dev, int width, int height, const plf_camera &cam,
+                                  plf_keyline *mvKeylinesUn_dev, float *mvuRightLineStart_dev, float *mvuRightLineEnd_dev, float *mvDepthLineStart_dev,
+                                  float *mvDepthLineEnd_dev, int device = 0, void *stream = nullptr)
+    {
+        check(plf_frame_line_tail(mvKeylines_dev, nullptr, NL, 1, NL, imDepth_dev, width, height, &cam, mvKeylinesUn_dev, mvuRightLineStart_dev,
+                                  mvuRightLineEnd_dev, mvDepthLineStart_dev, mvDepthLineEnd_dev, device, stream), "Frame::UndistortKeyLines");
+    }
+    // bool Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit) include/Frame.h:104, for M map points at once -> the plf_mappoint_view fields
+    static void isInFrustum(const float *world_pos_dev, const float *normal_dev, const float *min_distance_dev, const float *max_distance_dev, int M,
+                            const plf_frustum_pose &pose, const plf_camera &cam, const float bounds[4], float mfLogScaleFactor, int mnScaleLevels,
+                            float viewingCosLimit, float *mTrackProjX_dev, float *mTrackProjY_dev, float *mTrackProjXR_dev, int32_t *mnTrackScaleLevel_dev,
+                            float *mTrackViewCos_dev, uint8_t *mbTrackInView_dev, int device = 0, void *stream = nullptr)
+    {
+        check(plf_frustum_points(world_pos_dev, normal_dev, min_distance_dev, max_distance_dev, M, &pose, &cam, bounds[0], bounds[1], bounds[2], bounds[3],
+                                 mfLogScaleFactor, mnScaleLevels, viewingCosLimit, mTrackProjX_dev, mTrackProjY_dev, mTrackProjXR_dev,
+                                 mnTrackScaleLevel_dev, mTrackViewCos_dev, mbTrackInView_dev, device, stream), "Frame::isInFrustum(MapPoint)");
+    }
+    // bool Frame::isInFrustum(MapLine *pML, float viewingCosLimit) include/Frame.h:107, for M map lines (world_pos6: start xyz, end xyz)
+    static void isInFrustum(const float *world_pos6_dev, const float *normal_dev, const float *min_distance_dev, const float *max_distance_dev, int M,
+                            const plf_frustum_pose &pose, const plf_camera &cam, const float bounds[4], float mfLogScaleFactor, int mnScaleLevels,
+                            float viewingCosLimit, float *mTrackProjX1_dev, float *mTrackProjY1_dev, float *mTrackProjX1R_dev, float *mTrackProjX2_dev,
+                            float *mTrackProjY2_dev, float *mTrackProjX2R_dev, int32_t *mnTrackScaleLevel_dev, float *mTrackViewCos_dev,
+                            uint8_t *mbTrackInView_dev, int device = 0, void *stream = nullptr)
+    {
+        check(plf_frustum_lines(world_pos6_dev, normal_dev, min_distance_dev, max_distance_dev, M, &pose, &cam, bounds[0], bounds[1], bounds[2], bounds[3],
+                                mfLogScaleFactor, mnScaleLevels, viewingCosLimit, mTrackProjX1_dev, mTrackProjY1_dev, mTrackProjX1R_dev, mTrackProjX2_dev,
+                                mTrackProjY2_dev, mTrackProjX2R_dev, mnTrackScaleLevel_dev, mTrackViewCos_dev, mbTrackInView_dev, device, stream),
+              "Frame::isInFrustum(MapLine)");
+    }
+};
+
 }  // namespace plf
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -87,6 +87,12 @@ int main() {
     catch (const plf::Error &e) { std::printf("error %d\\n", e.status); }
     uint8_t a[32] = {0}, b[32] = {0}; b[3] = 0x81;
     std::printf("hamming %d\\n", plf::ORBmatcher::DescriptorDistance(a, b));
+    // the Frame mirror: a null pointer must be rejected by argument checking, before any device work
+    plf_camera cam = {517.3f, 516.5f, 318.6f, 255.3f, 0.f, 0.f, 0.f, 0.f, 0.f, 40.f};
+    try { plf::Frame::UndistortKeyPoints(nullptr, 10, cam, nullptr); std::printf("accepted\\n"); }
+    catch (const plf::Error &e) { std::printf("frame error %d\\n", e.status); }
+    try { plf::Frame::UndistortKeyLines(nullptr, 10, nullptr, 0, 0, cam, nullptr, nullptr, nullptr, nullptr, nullptr); std::printf("accepted\\n"); }
+    catch (const plf::Error &e) { std::printf("frame error %d\\n", e.status); }
     return 0;
 }
 ''')
@@ -94,7 +100,7 @@ int main() {
     subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), LIB,
                            "-Wl,-rpath," + os.path.dirname(LIB), "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True, stderr=subprocess.DEVNULL)
-    assert "hamming 2" in out
+    assert "hamming 2" in out and out.count("frame error -2") == 2
     from conftest import gpu_available
     if not gpu_available():
         assert out.count("error -4") == 2
