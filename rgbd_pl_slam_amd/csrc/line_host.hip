@@ -92,7 +92,7 @@ static void line_free(plf_line *h)
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
+    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -355,7 +355,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
         // (re)allocate for lat_max frames of the current geometry
-        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
+        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
@@ -369,6 +369,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.recs, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.cnt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.seedmap, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.defmap, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl2, Fr * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.band_y, Fr * (K + 1) * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.done, Fr * K * sizeof(int)) == hipSuccess &&

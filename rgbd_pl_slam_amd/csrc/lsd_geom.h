@@ -32,6 +32,7 @@ struct SpecBufs {
     SpecRec *recs;      // [frame][band][rcap_rec]
     int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
     uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
+    uint32_t *defmap;   // [frame][bm_words]: pixels with a defined level-line angle (k_lsd_spec_bands)
     uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel
     int *band_y;        // [frame][nbands + 1]: first row of every band (shares of the frame's defined pixels)
     int *done;          // [frame][band]: set (release) when the band wave has written its log; the commit wave waits for it (acquire)

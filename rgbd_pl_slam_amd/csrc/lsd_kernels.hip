@@ -838,6 +838,15 @@ __global__ void __launch_bounds__(1024) k_lsd_spec_bands(const float *__restrict
     } else {
         for (int a = t; a < W * (H - 1); a += 1024) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) >> 3, 1023)], 1);
     }
+    // bitmap of the defined pixels (the angle words are read-only in this mode): the commit wave walks it instead of the angle map
+    {
+        uint32_t *dm = SB.defmap + (size_t)f * SB.bm_words;
+        for (int p0 = (t >> 6) * 64; p0 < SB.bm_words * 32; p0 += 1024) {
+            const int p = p0 + (t & 63);
+            const unsigned long long m = __ballot(p < W * H && ang[p] < 0x80000000u);
+            if ((t & 63) == 0) { dm[p0 >> 5] = (uint32_t)m; if ((p0 >> 5) + 1 < SB.bm_words) dm[(p0 >> 5) + 1] = (uint32_t)(m >> 32); }
+        }
+    }
     __syncthreads();
     if (t == 0) {
         int total = 0;
@@ -982,6 +991,22 @@ __device__ __forceinline__ void spec_wait_band(const SpecBufs &SB, size_t fb)
     __threadfence();
 }
 
+// 64 bits of a bitmap starting at bit p (any alignment); words past the end read as zero
+__device__ __forceinline__ unsigned long long spec_bits64(const uint32_t *__restrict__ map, int p, int words)
+{
+    const int i = p >> 5, o = p & 31;
+    const unsigned long long w0 = map[i], w1 = i + 1 < words ? map[i + 1] : 0u;
+    unsigned long long v = (w0 | (w1 << 32)) >> o;
+    if (o && i + 2 < words) v |= (unsigned long long)map[i + 2] << (64 - o);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long spec_readlane64(unsigned long long v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 template <bool SG>
 __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                  const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
@@ -1029,14 +1054,15 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
     uint32_t *tl2 = SB.tl2 + (size_t)f * 2 * g.s_stride;
     const uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
+    const uint32_t *defmap = SB.defmap + (size_t)f * SB.bm_words;
     const GrowTh th0 = grow_thresholds(g.prec);
     int nr = 0, n_commit = 0, n_redo = 0, n_fast = 0, n_slow = 0;
     long long c_redo = 0, c_val = 0, c_setup = 0;
     const long long c_t0 = clock64();
     for (int band = 0; band < SB.nbands; band++) {
-        const long long c_s0 = clock64();
         const size_t fb = (size_t)f * SB.nbands + band;
         spec_wait_band(SB, fb);
+        const long long c_s0 = clock64();
         if (stats && f == 0 && lane == 0 && band < 64) { stats[8 + 3 * band] = SB.cnt[fb * 4 + 3]; stats[8 + 3 * band + 1] = (int)(wall_clock64() & 0x7fffffff); }
         const int use_recs = SB.cnt[fb * 4 + 2] == 0;   // a band whose log overflowed is simply grown here
         const uint32_t *tl = SB.tl + fb * SB.tcap;
@@ -1058,15 +1084,31 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         CBAR();
         c_setup += clock64() - c_s0;
         int ri = 0;
-        for (int base = y0 * W; base < y1 * W; base += 64) {
+        // The band is walked in tiles of 64 chunks of 64 pixels.  Lane i first fetches the defined-pixel bits (k_lsd_spec_bands) and the record-seed
+        // bits of chunk i -- plain bitmap words, so the walk has no dependent global load per chunk -- and only chunks that hold a record or a
+        // defined pixel are visited (whether those pixels are still free is looked up in T when the chunk's turn comes).
+        const int p_hi = y1 * W;
+        for (int tile = y0 * W; tile < p_hi; tile += 64 * 64) {
+        unsigned long long defm = 0ull, recmk = 0ull;
+        {
+            const int cb = tile + lane * 64;
+            if (cb < p_hi) {
+                defm = spec_bits64(defmap, cb, SB.bm_words);
+                if (use_recs) recmk = spec_bits64(seedmap, cb, SB.bm_words);
+                if (p_hi - cb < 64) { const unsigned long long mk = (1ull << (p_hi - cb)) - 1ull; defm &= mk; recmk &= mk; }
+            }
+        }
+        unsigned long long visit = __ballot((defm | recmk) != 0ull);
+        while (visit) {
+            const int vc = __ffsll((long long)visit) - 1;
+            visit &= visit - 1;
+            const int base = tile + vc * 64;
             const int px = base + lane;
-            const bool inb = px < y1 * W;
-            const uint32_t w = inb ? C.ang[px] : 0xFFFFFFFFu;      // angle word itself (flags are in T)
-            const bool defined = w < 0x80000000u;
-            const bool isrec = use_recs && inb && ((seedmap[px >> 5] >> (px & 31)) & 1u);
-            unsigned long long todo = __ballot(isrec || (defined && !bm_get(T, px)));
+            const bool inb = px < p_hi;
+            const unsigned long long defc = spec_readlane64(defm, vc), recm = spec_readlane64(recmk, vc);
+            const bool defined = (defc >> lane) & 1ull, isrec = (recm >> lane) & 1ull;
+            unsigned long long todo = recm | __ballot(defined && !bm_get(T, px));
             if (!todo) continue;   // nothing recorded here and every defined pixel already taken
-            const unsigned long long recm = __ballot(isrec);
             // fast path: no dirty pixel in the chunk that could become a seed of its own, and every record of the chunk stays clear of the
             // dirty tiles -> all of them stand; their marks (one contiguous range of the accepted-pixel log) and rectangles are copied at once
             const bool seedless = !__ballot(inb && defined && !isrec && !bm_get(T, px) && S.get(px));   // (a dirty pixel that is used in T cannot seed anything)
@@ -1148,7 +1190,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                 const bool has_r = (recm >> j) & 1ull;
                 const int rj = ri;
                 if (has_r) ri++;
-                const bool defined_j = (__ballot(defined) >> j) & 1ull;
+                const bool defined_j = (defc >> j) & 1ull;
                 const bool true_eff = defined_j && !bm_get(T, seed);
                 if (!has_r && !true_eff) continue;   // taken by a region committed since the chunk was loaded
                 int t0 = 0, nt = 0, has_rect = 0;
@@ -1188,7 +1230,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     CBAR();
                 }
                 if (true_eff) {   // grow on the true flags
-                    const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(__uint_as_float(w)), j));
+                    const float sdeg = __uint_as_float(C.ang[seed]);
                     const float2 sc0 = C.cs0[seed];
                     LsdRect rec;
                     int tn = 0, ovf = 0;
@@ -1203,6 +1245,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                 }
             }
         }
+        }   // tiles
     }
     if (stats && f == 0 && lane == 0) stats[8 + 3 * 63 + 2] = (int)(wall_clock64() & 0x7fffffff);   // end of the commit
     if (lane == 0) {

@@ -10,4 +10,4 @@ for seed in (0, 3):
     for _ in range(2): ls.ExtractLineSegment(img)
     st = (C.c_int32 * 8)()
     L.lib().plf_line_debug_spec_stats(ls._h, st)
-    print("frame", seed, "commit %d redo %d fast_chunks %d slow_records %d | kcycles: redo %d validate %d total %d setup %d" % tuple(st))
+    print("frame", seed, "commit %d redo %d fast_chunks %d slow_records %d | kcycles: redo %d validate %d total %d per-band set-up (after the wait for the band) %d" % tuple(st))
