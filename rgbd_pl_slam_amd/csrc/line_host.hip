@@ -339,7 +339,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // measured on one MI355X (VGA, frames/s with 16 / 8 / 4 / 2 bands): 8 frames 448 / 378 / 291 / 197; 32: 1277 / 1252 / 1079 / 679; 128: 3392 / 4321 /
     // 4007 / 1511; 256: 3866 / 5713 / 6800 / 5381; 512: - / 7237 / 8352 / 8856 (serial kernel: 7220); at 1024 the batch itself hides the latency
     // of the one-wave-per-frame kernel (9.8k with 2 bands vs 11.9k)
-    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);
+    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 24 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
     const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
