@@ -1348,7 +1348,20 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
     }
     double bin_tail = term;
     const double tolerance = 0.1;
-    for (int i = k + 1; i <= n; ++i) {
+    int i = k + 1;
+    // While bin_term >= 1 (i.e. n - i + 1 >= i) the reference's loop has no exit test: such iterations are taken four at a time so that the four
+    // divisions -- independent of the running product -- overlap; the product / sum chain itself is unchanged, operation for operation.
+    while (i + 3 <= n && n - (i + 3) + 1 >= i + 3) {
+        const double b0 = (double)(n - i + 1) / (double)i, b1 = (double)(n - i) / (double)(i + 1), b2 = (double)(n - i - 1) / (double)(i + 2),
+                     b3 = (double)(n - i - 2) / (double)(i + 3);
+        const double m0 = b0 * p_term, m1 = b1 * p_term, m2 = b2 * p_term, m3 = b3 * p_term;
+        term *= m0; bin_tail += term;
+        term *= m1; bin_tail += term;
+        term *= m2; bin_tail += term;
+        term *= m3; bin_tail += term;
+        i += 4;
+    }
+    for (; i <= n; ++i) {
         const double bin_term = (double)(n - i + 1) / (double)i;
         const double mult_term = bin_term * p_term;
         term *= mult_term;
@@ -1560,7 +1573,10 @@ __global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__re
     __shared__ int hist[32];
     const bool multi = (stage == 0 || stage == 4);
     const int total = counters[stage] * (multi ? 6 : 5), t = threadIdx.x;
-    for (int c0 = blockIdx.x * EV_CHUNK; c0 < total; c0 += gridDim.x * EV_CHUNK) {
+    // items per thread: EV_PER when the grid is full; fewer when there is little work (few frames in flight), so that it spreads over more blocks
+    // and no thread evaluates several binomial tails back to back
+    const int per = min(EV_PER, max(1, (total + (int)gridDim.x * EV_T - 1) / ((int)gridDim.x * EV_T))), chunk = per * EV_T;
+    for (int c0 = blockIdx.x * chunk; c0 < total; c0 += gridDim.x * chunk) {
         if (t < 32) hist[t] = 0;
         __syncthreads();
         int bkt[EV_PER], rnk[EV_PER];
@@ -1568,7 +1584,7 @@ __global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__re
         for (int q = 0; q < EV_PER; q++) {
             const int it = c0 + q * EV_T + t;
             bkt[q] = -1; rnk[q] = 0;
-            if (it < total) {
+            if (q < per && it < total) {
                 int n = 0, k = 0;
                 double p;
                 int b = 0;
@@ -1591,7 +1607,7 @@ __global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__re
         for (int q = 0; q < EV_PER; q++)
             if (bkt[q] >= 0) order[hist[bkt[q]] + rnk[q]] = (uint16_t)(q * EV_T + t);
         __syncthreads();
-        const int cnt = min(EV_CHUNK, total - c0);
+        const int cnt = min(chunk, total - c0);
         for (int i = t; i < cnt; i += EV_T) {
             const int it = c0 + order[i];
             int n = 0, k = 0;
