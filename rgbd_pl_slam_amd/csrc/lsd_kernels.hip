@@ -1351,6 +1351,16 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
     int i = k + 1;
     // While bin_term >= 1 (i.e. n - i + 1 >= i) the reference's loop has no exit test: such iterations are taken four at a time so that the four
     // divisions -- independent of the running product -- overlap; the product / sum chain itself is unchanged, operation for operation.
+    while (i + 7 <= n && n - (i + 7) + 1 >= i + 7) {
+        double b[8], m[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) b[q] = (double)(n - i - q + 1) / (double)(i + q);
+#pragma unroll
+        for (int q = 0; q < 8; q++) m[q] = b[q] * p_term;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { term *= m[q]; bin_tail += term; }
+        i += 8;
+    }
     while (i + 3 <= n && n - (i + 3) + 1 >= i + 3) {
         const double b0 = (double)(n - i + 1) / (double)i, b1 = (double)(n - i) / (double)(i + 1), b2 = (double)(n - i - 1) / (double)(i + 2),
                      b3 = (double)(n - i - 2) / (double)(i + 3);
