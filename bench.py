@@ -200,6 +200,9 @@ def main():
     for l in lins:
         ms_, n_ = l.profile(enable=False, reset=True)
         reg_ms += ms_; reg_launches += n_
+        # the device-resident calls return before the GPU has run: a capacity overflow would make the step's outputs (and its time) meaningless
+        if l.last_status() != 0:
+            raise RuntimeError("line extractor reported status %d for the last batch" % l.last_status())
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
