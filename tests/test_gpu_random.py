@@ -195,3 +195,27 @@ def test_lines_odd_large_batch_two_frames_per_workgroup():
         assert np.array_equal(res[f][1], r["desc"])
         assert np.array_equal(res[f][0]["startPointX"].view(np.uint32), r["kl"]["startPointX"].view(np.uint32))
     ext.close()
+
+
+def test_texture_families_single_and_batched():
+    """The dozen texture families of tools/soak.py (noise, hard stripes, checkerboards, flat, saturated, quantised ...), one VGA frame each: ORB and
+    LSD+LBD through the single-frame entry points and as one 12-frame batch, byte for byte against the oracle."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment
+    from rgbd_pl_slam_amd.synth import texture_frame
+    imgs = [texture_frame(900 + k, kind=k, size=(640, 480))[0] for k in range(12)]
+    ext = ORBextractor(nfeatures=1000, max_width=640, max_height=480, max_batch=12)
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=12)
+    refs_o = [orc.orb_extract(im) for im in imgs]
+    refs_l = [orc.line_extract(im, 100) for im in imgs]
+    assert sum(len(r["kps"]) == 0 for r in refs_o) >= 1 and sum(len(r["kl"]) == 0 for r in refs_l) >= 1      # the flat frame yields nothing
+    for k, im in enumerate(imgs):
+        kps, desc = ext(im)
+        _eq_orb(kps, desc, refs_o[k])
+        kl, ld, eq = ls.ExtractLineSegment(im)
+        assert kl.tobytes() == refs_l[k]["kl"].tobytes() and np.array_equal(ld, refs_l[k]["desc"]), k
+    ro = ext.extract_batch(np.stack(imgs)); rl = ls.extract_batch(np.stack(imgs))
+    for k in range(12):
+        _eq_orb(ro[k][0], ro[k][1], refs_o[k])
+        assert rl[k][0].tobytes() == refs_l[k]["kl"].tobytes() and np.array_equal(rl[k][1], refs_l[k]["desc"]), k
+    ext.close(); ls.close()

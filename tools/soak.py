@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import orc
 from rgbd_pl_slam_amd import ORBextractor, LineSegment
-from rgbd_pl_slam_amd.synth import synth_frame
+from rgbd_pl_slam_amd.synth import synth_frame, texture_frame
 
 SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 THREADS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -21,48 +21,7 @@ SEED0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 
 
 def make_image(seed):
-    """one of a dozen texture families, size VGA two times out of three"""
-    rng = np.random.default_rng(77000 + seed)
-    r = rng.random()
-    if r < 0.6:
-        w, h = 640, 480
-    elif r < 0.67:
-        w, h = 1280, 960
-    else:
-        w = int(rng.integers(8, 28)) * 32 + int(rng.choice([0, 0, 1, 7, 13, 31])); h = int(rng.integers(256, min(620, int(1.7 * (w - 40)))))   # (taller than ~2:1 the reference's octree starts with round(w/h) = 0 root nodes)
-    kind = int(rng.integers(0, 12))
-    base = synth_frame(5000 + seed, w, h)
-    f = base.astype(np.float32)
-    if kind == 0:
-        img = base
-    elif kind == 1:      # heavy pixel noise
-        img = np.clip(f + rng.normal(0, rng.uniform(4, 25), f.shape), 0, 255).astype(np.uint8)
-    elif kind == 2:      # low contrast
-        img = np.clip(128 + (f - 128) * rng.uniform(0.08, 0.4), 0, 255).astype(np.uint8)
-    elif kind == 3:      # high contrast / saturation
-        img = np.clip(128 + (f - 128) * rng.uniform(2, 6), 0, 255).astype(np.uint8)
-    elif kind == 4:      # coarse quantisation (plateaus, many equal gradients)
-        q = int(rng.choice([8, 16, 32, 64])); img = ((base // q) * q).astype(np.uint8)
-    elif kind == 5:      # transposed / flipped scene
-        img = np.ascontiguousarray(base[::-1, ::-1]) if rng.random() < 0.5 else np.ascontiguousarray(synth_frame(5000 + seed, h, w).T)
-    elif kind == 6:      # pure noise
-        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
-    elif kind == 7:      # stripes at a random angle and period
-        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-        a = rng.uniform(0, np.pi); per = rng.uniform(3, 40)
-        img = (127.5 + 120 * np.sign(np.sin((xx * np.cos(a) + yy * np.sin(a)) * 2 * np.pi / per))).astype(np.uint8)
-    elif kind == 8:      # checkerboard
-        c = int(rng.integers(4, 48)); yy, xx = np.mgrid[0:h, 0:w]
-        img = ((((yy // c) + (xx // c)) & 1) * int(rng.integers(60, 256))).astype(np.uint8)
-    elif kind == 9:      # smooth ramps + a few sharp edges
-        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-        img = np.clip(xx * rng.uniform(0.05, 0.4) + yy * rng.uniform(0.05, 0.4) + 60 * (xx > w * rng.uniform(0.2, 0.8)) + 50 * (yy > h * rng.uniform(0.2, 0.8)), 0, 255).astype(np.uint8)
-    elif kind == 10:     # flat (nothing to find)
-        img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
-    else:                # scene with a black / white frame border and a saturated block
-        img = base.copy(); b = int(rng.integers(1, 30)); img[:b] = 0; img[-b:] = 255; img[:, :b] = 255; img[:, -b:] = 0
-        img[h // 3:h // 2, w // 3:w // 2] = 255
-    return np.ascontiguousarray(img), kind
+    return texture_frame(seed)
 
 
 def eq_orb(got, ref):
