@@ -16,6 +16,11 @@
  * (the reference asserts or returns silently: include/ORBextractor.h:58-61, so@0x76dda).
  * Threading: a handle is confined to one thread at a time; different handles are independent
  * (PL-SLAM forks run ORB and LSD extraction concurrently from two threads).
+ * Streams: the scratch buffers a handle owns are ordered by the stream its work was enqueued on.  Successive calls on one
+ * handle may name different streams: a call on another stream than the previous one first waits (host side) for that
+ * previous stream, so keep one stream per handle where overlap matters, and do not destroy a stream while it is the most
+ * recent one a live handle was called with.  Size changes (a new width / height) re-upload the handle's tables after a
+ * device-wide synchronisation.
  */
 #ifndef PLF_H
 #define PLF_H
@@ -117,7 +122,12 @@ typedef struct {
     int32_t seed_order;  /* 0 = OpenCV 3.0-3.3 raster seed order (default), 1 = published bin order */
     int32_t device;
     int32_t max_width, max_height, max_batch;
+    int32_t lbd_sobel_input; /* what BinaryDescriptor's two cv::Sobel calls read: PLF_LBD_BLURRED (0, default) = octave 0 of
+                                BinaryDescriptor::computeGaussianPyramid, i.e. cv::GaussianBlur(image, Size(5, 5), 1) -- believed to be
+                                opencv_contrib 3.3 behaviour; PLF_LBD_RAW (1) = the image as handed in.  DESIGN.md section 2 lists every
+                                such version-dependent choice. */
 } plf_line_params;
+enum { PLF_LBD_BLURRED = 0, PLF_LBD_RAW = 1 };
 
 int plf_line_create(const plf_line_params *params, plf_line **out);
 void plf_line_destroy(plf_line *h);
@@ -212,6 +222,11 @@ typedef struct {
     const float *world_pos;      /* n x 3, pMP->GetWorldPos() */
     const plf_keypoint *keys;    /* mvKeys / mvKeysUn (octave, angle) */
     const uint8_t *mp_desc;      /* n x 32, pMP->GetDescriptor() */
+    const uint8_t *obs_positive; /* pMP->Observations() > 0; NULL = all.  0 marks the temporal points of localisation mode
+                                    (Tracking::UpdateLastFrame, include/Tracking.h:152, mlpTemporalPoints :252): the reference skips a key point
+                                    only if its map point HAS observations (so@0x81e3d), so one taken by such a point is overwritten by a later
+                                    last-frame point; the return value and the rotation histogram count every assignment.  Read by
+                                    plf_match_project_lastframe only (plf_match_project_keyframe tests the pointer alone). */
 } plf_lastframe_view;
 
 typedef struct { float Rcw[9], tcw[3], Rlw[9], tlw[3]; float fx, fy, cx, cy, bf, b; } plf_pose_pair;
@@ -433,6 +448,73 @@ int plf_frustum_lines(const float *world_pos, const float *normal, const float *
                       const plf_frustum_pose *pose, const plf_camera *cam, float min_x, float min_y, float max_x, float max_y,
                       float log_scale_factor, int32_t nlevels, float viewing_cos_limit, float *x1, float *y1, float *x1r, float *x2,
                       float *y2, float *x2r, int32_t *level, float *view_cos, uint8_t *in_view, int32_t device, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch driver -- the caller loop of the reference, Examples/RGB-D/rgbd_tum.cc:84-128 (read image -> SLAM.TrackRGBD ->
+ * Tracking::GrabImageRGBD include/Tracking.h:69 -> Frame ctor -> ExtractORB / ExtractLSD), for a batch of INDEPENDENT
+ * frames in HOST memory (BASELINE configs 3-4).  Frames are cut into contiguous blocks, one block per GPU
+ * (plf_batch_shard); every GPU has one host worker thread, its own ORB / line / matcher handles and HIP streams, pinned
+ * double-buffered staging and asynchronous H2D / D2H copies, so that the upload of chunk k+1 and the download of chunk
+ * k-1 overlap the kernels of chunk k.  No collective, no peer traffic: frames are independent, the local map is a
+ * replica per GPU.  One process can drive all GPUs of a node (n_devices = 0), or one GPU per process / rank
+ * (n_devices = 1 with the rank's share of the frames from plf_batch_shard) -- same code path per device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct plf_batch plf_batch;
+
+enum { PLF_FMT_GRAY8 = 0, PLF_FMT_RGB8 = 1, PLF_FMT_BGR8 = 2 };   /* Tracking::GrabImageRGBD converts RGB / BGR to gray (so@0x522e6) */
+
+typedef struct {
+    plf_orb_params orb;        /* orb.nfeatures <= 0: no ORB extractor.  orb.device and orb.max_batch are set by the driver */
+    plf_line_params line;      /* line.nlines <= 0: no line extractor.   line.device and line.max_batch likewise */
+    int32_t n_devices;         /* 0 = every visible GPU */
+    const int32_t *devices;    /* n_devices ordinals, NULL = 0 .. n_devices-1 */
+    int32_t frames_in_flight;  /* frames per GPU and pipeline slot (the handles' max_batch); BASELINE config 3-4: 8 */
+    int32_t input_format;      /* PLF_FMT_* of the frames handed to plf_batch_extract */
+    int32_t max_mappoints;     /* > 0: a matcher per GPU; capacity of the local-map replicas (plf_batch_set_local_map) */
+    int32_t max_maplines;
+} plf_batch_params;
+
+/* Host-side outputs of one batch: n_frames x capacity entries, frame f at index f * capacity (same layout as
+ * plf_orb_extract_batch / plf_line_extract_batch with PLF_MEM_HOST).  Pointers of a disabled extractor may be NULL;
+ * the match arrays are only written when a local map is set and may be NULL otherwise.
+ * match_of_kp / match_of_line: -1 = none, >= 0 = index into the local map (ORBmatcher::SearchByProjection(Frame&, map points, th)
+ * include/ORBmatcher.h:61; LSDmatcher::SearchByProjection(Frame&, map lines, th) include/LSDmatcher.h:40). */
+typedef struct {
+    plf_keypoint *kps; uint8_t *desc; int32_t *n_kps; int32_t kp_capacity;
+    plf_keyline *lines; uint8_t *ldesc; double *line_eq; int32_t *n_lines; int32_t line_capacity;
+    int32_t *match_of_kp; int32_t *n_kp_matches;
+    int32_t *match_of_line; int32_t *n_line_matches;
+} plf_batch_outputs;
+
+/* Contiguous block partition used by the driver (and by bench.py's ranks): part `part` of `parts` owns frames
+ * [*first, *first + *count), with first = part * n / parts.  Pure host arithmetic. */
+int plf_batch_shard(int64_t n_frames, int32_t parts, int32_t part, int64_t *first, int64_t *count);
+
+int plf_batch_create(const plf_batch_params *params, plf_batch **out);
+void plf_batch_destroy(plf_batch *b);
+int plf_batch_device_count(const plf_batch *b);
+/* device ordinal of worker `i` */
+int plf_batch_device(const plf_batch *b, int32_t i);
+
+/* Replicates the tracking fields of the local map (HOST arrays of the two views; either may be NULL) on every GPU of the
+ * driver.  th / nnratio: the arguments of the two SearchByProjection calls.  m = 0 clears. */
+int plf_batch_set_local_map(plf_batch *b, const plf_mappoint_view *points, const plf_mapline_view *lines, float th, float nnratio,
+                            float min_x, float min_y, float max_x, float max_y);
+
+/* The frames of one batch, HOST memory (pageable, or pinned -- plf_host_alloc -- in which case the staging copy is
+ * skipped): frame f starts at images + f * frame_stride, rows `pitch` bytes apart, 1 (gray) or 3 (RGB / BGR) bytes per
+ * pixel.  Returns when every output is in place: PLF_OK, PLF_E_CAPACITY (some frame had more features than the caller's
+ * capacity; outputs truncated) or the first hard error of any worker. */
+int plf_batch_extract(plf_batch *b, const uint8_t *images, int64_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch,
+                      ptrdiff_t frame_stride, const plf_batch_outputs *out);
+
+/* Seconds the workers of the last plf_batch_extract spent (max over workers): [0] total, [1] staging copies into pinned
+ * memory, [2] waiting for the GPU, [3] unpacking outputs. */
+int plf_batch_last_timing(const plf_batch *b, double *out4);
+
+/* Pinned (page-locked, portable across the GPUs of the driver) host memory for frame buffers handed to plf_batch_extract */
+int plf_host_alloc(size_t bytes, void **out);
+void plf_host_free(void *p);
 
 #ifdef __cplusplus
 }

@@ -96,7 +96,7 @@ class LineSegment {
 public:
     explicit LineSegment(int nlines = 100, int maxWidth = 640, int maxHeight = 480, int maxBatch = 1, int device = 0) : nlines_(nlines)
     {
-        plf_line_params p = {nlines, 0, device, maxWidth, maxHeight, maxBatch};
+        plf_line_params p = {nlines, 0, device, maxWidth, maxHeight, maxBatch, PLF_LBD_BLURRED};
         check(plf_line_create(&p, &h_), "plf_line_create");
     }
     ~LineSegment() { plf_line_destroy(h_); }

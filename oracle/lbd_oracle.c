@@ -177,12 +177,22 @@ static void lbd_one(const int16_t *pdxImg, const int16_t *pdyImg, int realWidth,
 }
 
 /* BinaryDescriptor::compute: desc n x 32 (row = keyline order), fdesc optional n x 72 */
-void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const orc_keyline *kl, int n, uint8_t *desc,
-                     float *fdesc)
+/* sobel_input: ORC_LBD_BLURRED = BinaryDescriptor::computeGaussianPyramid's octave 0, i.e. cv::GaussianBlur(image.clone(), Size(5, 5), 1)
+ * (8U: 8-bit fixed-point separable path, taps 14 63 103 63 14) before the two cv::Sobel calls -- believed to be what opencv_contrib 3.3
+ * does (the same blur line is commented out in LSDDetector's pyramid, which is why the DETECTOR sees the raw image);
+ * ORC_LBD_RAW = Sobel on the image as handed in (round-1 behaviour of this repo). */
+void orc_lbd_compute_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const orc_keyline *kl, int n, uint8_t *desc,
+                        float *fdesc, int sobel_input)
 {
     if (n <= 0) return;
     int16_t *dxImg = (int16_t *)malloc(sizeof(int16_t) * (size_t)w * h), *dyImg = (int16_t *)malloc(sizeof(int16_t) * (size_t)w * h);
-    orc_sobel3_16s(gray, w, h, pitch, dxImg, dyImg);
+    if (sobel_input == ORC_LBD_BLURRED) {
+        uint8_t *bl = (uint8_t *)malloc((size_t)w * h);
+        orc_gaussian_blur_8u(gray, pitch, bl, w, w, h, 5, 1.0);
+        orc_sobel3_16s(bl, w, h, w, dxImg, dyImg);
+        free(bl);
+    } else
+        orc_sobel3_16s(gray, w, h, pitch, dxImg, dyImg);
     double gL[WIDTH_OF_BAND * 3], gG[NUM_OF_BANDS * WIDTH_OF_BAND];
     orc_lbd_gauss_coefs(gL, gG);
     for (int k = 0; k < n; k++) {
@@ -195,10 +205,15 @@ void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const o
     free(dxImg); free(dyImg);
 }
 
+void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const orc_keyline *kl, int n, uint8_t *desc, float *fdesc)
+{
+    orc_lbd_compute_ex(gray, w, h, pitch, kl, n, desc, fdesc, ORC_LBD_BLURRED);
+}
+
 /* LineSegment::ExtractLineSegment.  nkeep = number of lines kept (lsdNFeatures of the fork; not
  * configurable in the reference YAML -- BASELINE configs use 100/200/400).  Returns line count. */
-int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
-                     uint8_t *desc, double *lineeq, int cap, int *ndetected)
+int orc_line_extract_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
+                        uint8_t *desc, double *lineeq, int cap, int *ndetected, int sobel_input)
 {
     int segcap = 1 << 16;
     float *segs = (float *)malloc(sizeof(float) * 4 * segcap);
@@ -226,7 +241,7 @@ int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nke
         n = nkeep;
     }
     if (n > cap) n = cap;
-    orc_lbd_compute(gray, w, h, pitch, kl, n, desc, NULL);
+    orc_lbd_compute_ex(gray, w, h, pitch, kl, n, desc, NULL, sobel_input);
     for (int i = 0; i < n; i++) {
         out[i] = kl[i];
         double sx = kl[i].startPointX, sy = kl[i].startPointY, ex = kl[i].endPointX, ey = kl[i].endPointY;
@@ -236,4 +251,10 @@ int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nke
     }
     free(kl);
     return n;
+}
+
+int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
+                     uint8_t *desc, double *lineeq, int cap, int *ndetected)
+{
+    return orc_line_extract_ex(gray, w, h, pitch, nkeep, seed_order, out, desc, lineeq, cap, ndetected, ORC_LBD_BLURRED);
 }

@@ -204,7 +204,8 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
                                   int32_t *match_of_kp)
 {
     int nmatches = 0;
-    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (Cur->n > 0 ? Cur->n : 1));
+    const int HS = (Cur->n > Last->n ? Cur->n : Last->n) > 0 ? (Cur->n > Last->n ? Cur->n : Last->n) : 1;   /* one entry per ASSIGNMENT: <= Last->n */
+    int *rotHist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (size_t)HS);
     int histN[HISTO_LENGTH];
     memset(histN, 0, sizeof(histN));
     /* twc = -Rcw^T * tcw ; tlc = Rlw*twc + tlw */
@@ -243,7 +244,9 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
         for (int c = 0; c < nc; c++) {
             const int i2 = cand[c];
             const int cur = match_of_kp[i2];
-            if (cur == -2 || cur >= 0) continue; /* map points of the last frame all have observations */
+            /* CurrentFrame.mvpMapPoints[i2] && ->Observations() > 0 (so@0x81e3d): a key point given to a last-frame point WITHOUT observations
+             * earlier in this loop stays available, is overwritten, and counts (nmatches, rotation histogram) once per assignment */
+            if (cur == -2 || (cur >= 0 && (!Last->obs_positive || Last->obs_positive[cur]))) continue;
             if (Cur->uright[i2] > 0) {
                 const float ur = fmaf(-bf, invzc, u);
                 const float er = fabsf(ur - Cur->uright[i2]);
@@ -260,7 +263,7 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
                 if (rot < 0.0f) rot += 360.0f;
                 int bin = (int)roundf(rot * (1.0f / 12.0f)); /* this binary: factor = HISTO_LENGTH/360 */
                 if (bin == HISTO_LENGTH) bin = 0;
-                rotHist[bin * Cur->n + histN[bin]++] = bestIdx2;
+                rotHist[bin * HS + histN[bin]++] = bestIdx2;
             }
         }
     }
@@ -270,7 +273,7 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
         for (int bnum = 0; bnum < HISTO_LENGTH; bnum++) {
             if (bnum == i1 || bnum == i2 || bnum == i3) continue;
             for (int j = 0; j < histN[bnum]; j++) {
-                match_of_kp[rotHist[bnum * Cur->n + j]] = -1;
+                match_of_kp[rotHist[bnum * HS + j]] = -1;
                 nmatches--;
             }
         }

@@ -46,6 +46,8 @@ void orc_ic_moments(const uint8_t *img, ptrdiff_t pitch, int cx, int cy, const i
 float orc_ic_angle(const uint8_t *img, ptrdiff_t pitch, float x, float y, const int *umax);
 void orc_gauss_taps_8u(int ksize, double sigma, int *taps);
 void orc_gaussian_blur7_8u(const uint8_t *src, ptrdiff_t spitch, uint8_t *dst, ptrdiff_t dpitch, int w, int h);
+/* the same 8-bit fixed-point separable path for any odd ksize <= 33 (ksize 5, sigma 1: the LBD pre-blur) */
+void orc_gaussian_blur_8u(const uint8_t *src, ptrdiff_t spitch, uint8_t *dst, ptrdiff_t dpitch, int w, int h, int ksize, double sigma);
 void orc_brief_descriptor(const uint8_t *blur, ptrdiff_t pitch, float x, float y, float angle_deg, uint8_t *desc);
 int orc_orb_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nfeatures, float scaleFactor,
                     int nlevels, int iniTh, int minTh, orc_keypoint *kps, uint8_t *desc, int cap,
@@ -87,6 +89,8 @@ typedef struct { /* LastFrame view for the motion-model overload (8a-12) */
     const int *octave;               /* mvKeys[i].octave */
     const float *angle;              /* mvKeysUn[i].angle */
     const uint8_t *mp_desc;          /* n x 32, pMP->GetDescriptor() */
+    const uint8_t *obs_positive;     /* pMP->Observations() > 0; NULL = all.  0 = a temporal point of localisation mode (Tracking::UpdateLastFrame,
+                                        include/Tracking.h:152): a key point it was assigned to stays available to later last-frame points */
 } orc_lastframe;
 
 typedef struct { /* current frame, lines */
@@ -192,6 +196,13 @@ void orc_lbd_compute(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const o
                      float *fdesc);
 int orc_line_extract(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
                      uint8_t *desc, double *lineeq, int cap, int *ndetected);
+/* version-dependent choice: what BinaryDescriptor's Sobel reads.  The plain functions above use ORC_LBD_BLURRED. */
+#define ORC_LBD_BLURRED 0 /* GaussianBlur(5x5, sigma 1) of octave 0 first (opencv_contrib 3.3 BinaryDescriptor::computeGaussianPyramid) */
+#define ORC_LBD_RAW 1     /* the image as handed in */
+void orc_lbd_compute_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, const orc_keyline *kl, int n, uint8_t *desc,
+                        float *fdesc, int sobel_input);
+int orc_line_extract_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
+                        uint8_t *desc, double *lineeq, int cap, int *ndetected, int sobel_input);
 
 /* ---- Frame tail / ingest / frustum (frame_oracle.c) */
 void orc_rgb_to_gray(const uint8_t *rgb, int w, int h, ptrdiff_t pitch, int bgr_order, uint8_t *gray, ptrdiff_t gpitch);

@@ -978,8 +978,13 @@ int main(int argc, char **argv)
         fprintf(JL, "{\"_doc\": \"ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (so@0x80d00) executed from the reference binary on "
                     "hand-laid Frame / MapPoint objects; cv::Mat algebra (gemm) supplied by oracle/refprobe/probe.cpp. floats as uint32 bit patterns; match[k] = "
                     "last-frame index assigned to current key point k, -1 none, -2 occupied before the call\", \"cases\": [\n");
-        struct { int n; float th; int mono, check; float dz; uint64_t seed; } lc[] = {{500, 7.0f, 0, 1, 0.02f, 9401}, {400, 15.0f, 0, 1, -0.6f, 9402}, {450, 7.0f, 0, 0, 0.7f, 9403}, {350, 15.0f, 1, 1, 0.5f, 9404}};
-        const int NLC = 4;
+        // cases 5 and 6: localisation mode (Tracking::UpdateLastFrame creates temporal MapPoints with Observations() == 0, include/Tracking.h:152):
+        // `noobs` of the last-frame points have nObs = 0, and the second half of the last frame duplicates the first (same place, near-identical
+        // descriptor), so that several last-frame points compete for the same current key points and assignments get overwritten
+        struct { int n; float th; int mono, check; float dz; uint64_t seed; float noobs; int dup; } lc[] = {
+            {500, 7.0f, 0, 1, 0.02f, 9401, 0.f, 0}, {400, 15.0f, 0, 1, -0.6f, 9402, 0.f, 0}, {450, 7.0f, 0, 0, 0.7f, 9403, 0.f, 0}, {350, 15.0f, 1, 1, 0.5f, 9404, 0.f, 0},
+            {480, 15.0f, 0, 1, 0.02f, 9405, 0.5f, 1}, {420, 7.0f, 0, 0, 0.3f, 9406, 1.0f, 1}};
+        const int NLC = 6;
         for (int c = 0; c < NLC; c++) {
             rng_seed(lc[c].seed);
             auto uf = [&]() { return (float)(rng_u32() >> 8) * (1.0f / 16777216.0f); };
@@ -1000,16 +1005,28 @@ int main(int argc, char **argv)
             // last frame: key points with map points at depth z in the last camera; world = Rl^T (Xl - tl)
             std::vector<cv::KeyPoint> lk(NL);
             std::vector<float> wpos((size_t)NL * 3);
-            std::vector<int> lhas(NL), lout(NL);
+            std::vector<int> lhas(NL), lout(NL), lobs(NL, 1);
+            std::vector<float> zs(NL);
             std::vector<uint8_t> mdesc((size_t)NL * 32);
             for (int i = 0; i < NL; i++) {
                 lk[i].x = 30.f + uf() * 580.f; lk[i].y = 30.f + uf() * 420.f; lk[i].size = 31.f; lk[i].angle = uf() * 360.f; lk[i].response = 1.f;
                 lk[i].octave = (int)rng_below(8); lk[i].class_id = -1;
-                const float z = 1.0f + uf() * 5.0f;
+                float z = 1.0f + uf() * 5.0f;
+                if (lc[c].dup && i >= NL / 2) {   // a second point at (almost) the same place
+                    const int j = i - NL / 2;
+                    lk[i].x = lk[j].x + (uf() - 0.5f) * 3.f; lk[i].y = lk[j].y + (uf() - 0.5f) * 3.f; lk[i].octave = lk[j].octave; lk[i].angle = lk[j].angle;
+                    z = zs[j] * (1.f + (uf() - 0.5f) * 0.01f);
+                }
+                zs[i] = z;
                 const float Xl[3] = {(lk[i].x - cx) / fx * z, (lk[i].y - cy) / fy * z, z};
                 for (int r = 0; r < 3; r++) wpos[(size_t)i * 3 + r] = Tl[0 * 4 + r] * (Xl[0] - Tl[3]) + Tl[1 * 4 + r] * (Xl[1] - Tl[7]) + Tl[2 * 4 + r] * (Xl[2] - Tl[11]);
                 lhas[i] = uf() < 0.85f; lout[i] = uf() < 0.08f;
                 for (int b = 0; b < 32; b++) mdesc[(size_t)i * 32 + b] = (uint8_t)rng_below(256);
+                if (lc[c].dup && i >= NL / 2) {
+                    for (int b = 0; b < 32; b++) mdesc[(size_t)i * 32 + b] = mdesc[(size_t)(i - NL / 2) * 32 + b];
+                    const int flips = (int)rng_below(12);
+                    for (int q = 0; q < flips; q++) { const int bit = (int)rng_below(256); mdesc[(size_t)i * 32 + bit / 8] ^= (uint8_t)(1u << (bit & 7)); }
+                }
             }
             // current frame: noisy re-observations + clutter
             const int NC = NL + NL / 3;
@@ -1048,6 +1065,7 @@ int main(int argc, char **argv)
             for (int i = 0; i < NL; i++) {
                 char *o = mps + (size_t)i * 0x300;
                 *(int *)(o + 0x18) = 1 + (int)rng_below(3);
+                if (lc[c].noobs > 0.f && uf() < lc[c].noobs) { *(int *)(o + 0x18) = 0; lobs[i] = 0; }
                 mat_init((cv::Mat *)(o + 0xd8), (unsigned char *)&wpos[(size_t)i * 3], 3, 1, 4);
                 ((cv::Mat *)(o + 0xd8))->flags = 0x42FF0000 | 0x4000 | 5; ((cv::Mat *)(o + 0xd8))->step_buf[1] = 4;
                 mat_init((cv::Mat *)(o + 0x1c8), &mdesc[(size_t)i * 32], 1, 32, 32); ((cv::Mat *)(o + 0x1c8))->flags |= 0x4000;
@@ -1099,7 +1117,7 @@ int main(int argc, char **argv)
             J = JL;
             jarr_f("cam", cam); jarr_f("Tcw", Tcv); jarr_f("Tlw", Tlv); jarr_f("scale", scv);
             jarr_f("x", kx); jarr_f("y", ky); jarr_f("angle", ka); jarr_i("octave", ko); jarr_f("uright", cur); jarr_i("init", init);
-            jarr_f("last_angle", la); jarr_i("last_octave", lo); jarr_i("last_has_mp", lhas); jarr_i("last_outlier", lout); jarr_f("world_pos", wpos);
+            jarr_f("last_angle", la); jarr_i("last_octave", lo); jarr_i("last_has_mp", lhas); jarr_i("last_outlier", lout); jarr_i("last_obs_positive", lobs); jarr_f("world_pos", wpos);
             jarr_i("match", match);
             fprintf(JL, "\"desc\": \"");
             for (size_t b = 0; b < cdesc.size(); b++) fprintf(JL, "%02x", cdesc[b]);

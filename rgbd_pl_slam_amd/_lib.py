@@ -28,7 +28,14 @@ class OrbParams(C.Structure):
 
 class LineParams(C.Structure):
     _fields_ = [("nlines", C.c_int32), ("seed_order", C.c_int32), ("device", C.c_int32), ("max_width", C.c_int32),
-                ("max_height", C.c_int32), ("max_batch", C.c_int32)]
+                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("lbd_sobel_input", C.c_int32)]
+
+
+LBD_BLURRED, LBD_RAW = 0, 1
+
+
+def line_params(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input=LBD_BLURRED):
+    return LineParams(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input)
 
 
 class FrameView(C.Structure):
@@ -45,7 +52,7 @@ class MapPointView(C.Structure):
 
 class LastFrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("has_mappoint", C.c_void_p), ("outlier", C.c_void_p), ("world_pos", C.c_void_p),
-                ("keys", C.c_void_p), ("mp_desc", C.c_void_p)]
+                ("keys", C.c_void_p), ("mp_desc", C.c_void_p), ("obs_positive", C.c_void_p)]
 
 
 class PosePair(C.Structure):

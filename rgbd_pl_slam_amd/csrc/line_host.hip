@@ -30,6 +30,7 @@ __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
                                int, int *, unsigned long long *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
+__global__ void k_blur5_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom, int4);
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
 
 __global__ void k_lsd_spec_fused(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
@@ -46,6 +47,7 @@ struct plf_line {
     LsdGeom g;
     LsdTaps taps;
     LbdCoefs lbd;
+    int4 blur5;               // 8-bit fixed-point taps of GaussianBlur(5 x 5, sigma 1): k[0], k[1], k[2]
     int cur_w, cur_h;
     size_t alloc_full, alloc_scaled;  // elements per frame the buffers were sized for
     int alloc_rect_cap;
@@ -78,6 +80,8 @@ struct plf_line {
     int *d_xofs, *d_yofs;
     float2 *d_xa, *d_yb;
     int last_frames;
+    hipStream_t last_stream;   // stream of the most recent call
+    bool last_stream_set;
     int prof_on, prof_n;
     hipEvent_t prof_ev[2 * 512];  // (start, stop) pairs of the region kernel
     hipEvent_t ev_front;          // recorded after the front stages of the last batch (plf_line_wait_front)
@@ -183,6 +187,8 @@ static int line_configure(plf_line *h, int w, int hh)
     while (g.sort_cap < g.rect_cap) g.sort_cap <<= 1;
     g.sort_lds = g.sort_cap < 4096 ? g.sort_cap : 4096;
     g.nfa_pool = h->alloc_nfa_pool;
+    // kernels of a previous call (any stream: the caller's streams do not synchronise with the null stream) may still read the tables
+    if (h->cur_w >= 0) PLF_HIP_TRY(hipDeviceSynchronize());
     PLF_HIP_TRY(hipMemcpy(h->d_xofs, xofs.data(), sizeof(int) * g.sw, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_xa, xa.data(), sizeof(float2) * g.sw, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
@@ -201,6 +207,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     *out = nullptr;
     if (p->nlines < 1 || p->max_batch < 1 || p->max_width < 16 || p->max_height < 16) return PLF_E_BADARG;
     if (p->seed_order != 0 && p->seed_order != 1) return PLF_E_BADARG;
+    if (p->lbd_sobel_input != PLF_LBD_BLURRED && p->lbd_sobel_input != PLF_LBD_RAW) return PLF_E_BADARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fprintf(stderr, "[plf] no HIP device available: the line extractor has no CPU path\n");
@@ -223,6 +230,16 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
         for (int i = 0; i < 7; i++) { const double x = i - 3.0; h->taps.k[i] = exp(scale2X * x * x); sum += h->taps.k[i]; }
         sum = 1. / sum;
         for (int i = 0; i < 7; i++) h->taps.k[i] *= sum;
+    }
+    // cv::getGaussianKernel(5, 1, CV_32F) converted to 8-bit fixed point (createSeparableLinearFilter, 8U smoothing kernels): 14 63 103 63 14
+    {
+        float cf[5];
+        double sum = 0;
+        for (int i = 0; i < 5; i++) { const double x = i - 2.0; cf[i] = (float)exp(-0.5 * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        int k[5];
+        for (int i = 0; i < 5; i++) { cf[i] = (float)(cf[i] * sum); k[i] = (int)lrint((double)cf[i] * 256.0); }
+        h->blur5 = make_int4(k[0], k[1], k[2], 0);
     }
     // BinaryDescriptor ctor: gaussCoefL_ (21 taps, centre 10, sigma 7), gaussCoefG_ (63 taps, centre 31, sigma 31)
     {
@@ -311,7 +328,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
     hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
                        h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
-    hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
+    if (h->prm.lbd_sobel_input == PLF_LBD_RAW)
+        hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
+    else
+        hipLaunchKernelGGL(k_blur5_sobel3, dim3((g.w + 63) / 64, (g.h + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g, h->blur5);
     if (!h->ev_front) PLF_HIP_TRY(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
     PLF_HIP_TRY(hipEventRecord(h->ev_front, s));
     h->ev_front_set = true;
@@ -444,6 +464,9 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
     int rc = line_configure(h, width, height);
     if (rc != PLF_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
+    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    h->last_stream = s; h->last_stream_set = true;
     const uint8_t *d_gray = gray;
     ptrdiff_t dpitch = pitch, dfstride = frame_stride;
     if (in_mem == PLF_MEM_HOST) {
@@ -504,10 +527,20 @@ extern "C" int plf_line_last_status(plf_line *h, void *stream)
     if (!h) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
+    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    h->last_stream = s; h->last_stream_set = true;
     int status = 0;
     PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
     return (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : PLF_OK;
+}
+
+// batch driver (batch_host.hip): the status word of the batch just enqueued on `s`, copied to pinned host memory in stream order
+int plf_line_status_async(plf_line *h, int32_t *host_dst, hipStream_t s)
+{
+    PLF_HIP_TRY(hipMemcpyAsync(host_dst, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
+    return PLF_OK;
 }
 
 extern "C" int plf_line_extract(plf_line *h, const uint8_t *gray, int32_t width, int32_t height, ptrdiff_t pitch, plf_keyline *lines,

@@ -3,6 +3,7 @@
 //                   the fork's "sort by response, keep N, renumber class_id" (include/auxiliar.h:67-72) +
 //                   normalised line equations (Eigen cross product in the fork's ExtractLineSegment)
 //   k_sobel3        cv::Sobel(img, CV_16S, 1|0, 0|1, 3), BORDER_REFLECT_101 (BinaryDescriptor::computeSobel)
+//   k_blur5_sobel3  the same two Sobel calls on BinaryDescriptor::computeGaussianPyramid's octave 0 (GaussianBlur 5x5, sigma 1), fused
 //   k_lbd           BinaryDescriptor::computeLBD + binaryConversion (line_descriptor/binary_descriptor.cpp)
 // Float arithmetic follows the upstream statement order exactly (no FMA contraction); sequential float sums are
 // kept sequential per row / per band and spread over lanes only across rows / bands.
@@ -138,6 +139,64 @@ __global__ void __launch_bounds__(256) k_sobel3(const uint8_t *__restrict__ in, 
         const int gx = (r0[xp] + 2 * r1[xp] + r2[xp]) - (r0[xm] + 2 * r1[xm] + r2[xm]);
         const int gy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
         out[j] = make_short2((short)gx, (short)gy);
+    }
+}
+
+// BinaryDescriptor::computeGaussianPyramid (opencv_contrib 3.3): octave 0 = cv::GaussianBlur(image.clone(), Size(5, 5), 1), then the two
+// cv::Sobel calls read THAT image (plf_line_params.lbd_sobel_input = PLF_LBD_BLURRED).  Fused: a 256-thread block produces a 64 x 16 tile of
+// (dx, dy); the 5-tap row sums (22 x 66), the blurred bytes (18 x 66) and nothing else live in LDS -- the blurred image never reaches HBM.
+// 8U GaussianBlur = 8-bit fixed-point separable filter: taps k5 (14 63 103 63 14), row pass exact int32, column pass sum / 65536 rounded as
+// OpenCV 3.3's SymmColumnVec_32s8u does (half-to-even) for x < (w & ~3) and as its scalar tail ((s + 32768) >> 16) for the last w % 4
+// columns -- the same rule as the 7 x 7 blur of the ORB path (orb_kernels.hip); REFLECT_101 at the image edge for the blur AND for the Sobel.
+#define BS_TW 64
+#define BS_TH 16
+__global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, short2 *__restrict__ grad,
+                                                      LsdGeom g, int4 k5 /* k[0], k[1], k[2] */)
+{
+    __shared__ int rows[BS_TH + 6][BS_TW + 2];       // row sums at image (x0 - 1 + c, y0 - 3 + r)
+    __shared__ uint8_t blur[BS_TH + 2][BS_TW + 4];   // blurred bytes at image (x0 - 1 + c, y0 - 1 + r)
+    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH, f = blockIdx.z, t = threadIdx.x;
+    const int W = g.w, H = g.h;
+    const uint8_t *img = in + (size_t)f * fstride;
+    for (int i = t; i < (BS_TH + 6) * (BS_TW + 2); i += 256) {
+        const int r = i / (BS_TW + 2), c = i - r * (BS_TW + 2);
+        const int X = x0 - 1 + c, Y = y0 - 3 + r;
+        if (X < 0 || X >= W || Y < 0 || Y >= H) continue;   // only reached through reflection, which lands inside the image
+        const uint8_t *S = img + (size_t)Y * pitch;
+        int s;
+        if (X >= 2 && X + 2 < W) s = k5.x * (S[X - 2] + S[X + 2]) + k5.y * (S[X - 1] + S[X + 1]) + k5.z * S[X];
+        else s = k5.x * (S[plf_reflect101(X - 2, W)] + S[plf_reflect101(X + 2, W)]) + k5.y * (S[plf_reflect101(X - 1, W)] + S[plf_reflect101(X + 1, W)]) + k5.z * S[X];
+        rows[r][c] = s;
+    }
+    __syncthreads();
+    const int wvec = W & ~3;
+    for (int i = t; i < (BS_TH + 2) * (BS_TW + 2); i += 256) {
+        const int r = i / (BS_TW + 2), c = i - r * (BS_TW + 2);
+        const int X = x0 - 1 + c, Y = y0 - 1 + r;
+        if (X < 0 || X >= W || Y < 0 || Y >= H) continue;
+#define ROW_(yy) rows[plf_reflect101((yy), H) - (y0 - 3)][c]
+        const int s = k5.x * (ROW_(Y - 2) + ROW_(Y + 2)) + k5.y * (ROW_(Y - 1) + ROW_(Y + 1)) + k5.z * ROW_(Y);
+#undef ROW_
+        int v;
+        if (X < wvec) {
+            v = s >> 16;
+            const int rem = s & 0xFFFF;
+            if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
+        } else
+            v = (s + 32768) >> 16;
+        blur[r][c] = (uint8_t)(v > 255 ? 255 : v);
+    }
+    __syncthreads();
+    short2 *out = grad + (size_t)f * g.full_stride;
+    for (int i = t; i < BS_TH * BS_TW; i += 256) {
+        const int ry = i / BS_TW, cx = i - ry * BS_TW;
+        const int x = x0 + cx, y = y0 + ry;
+        if (x >= W || y >= H) continue;
+        const int xm = plf_reflect101(x - 1, W) - (x0 - 1), xc = cx + 1, xp = plf_reflect101(x + 1, W) - (x0 - 1);
+        const int ym = plf_reflect101(y - 1, H) - (y0 - 1), yc = ry + 1, yp = plf_reflect101(y + 1, H) - (y0 - 1);
+        const int gx = (blur[ym][xp] + 2 * blur[yc][xp] + blur[yp][xp]) - (blur[ym][xm] + 2 * blur[yc][xm] + blur[yp][xm]);
+        const int gy = (blur[yp][xm] + 2 * blur[yp][xc] + blur[yp][xp]) - (blur[ym][xm] + 2 * blur[ym][xc] + blur[ym][xp]);
+        out[(size_t)y * W + x] = make_short2((short)gx, (short)gy);
     }
 }
 

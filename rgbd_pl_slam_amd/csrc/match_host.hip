@@ -26,7 +26,7 @@ struct FrameDev {
 };
 struct MapDev { int m; const float *proj_x, *proj_y, *proj_xr; const int *level; const float *view_cos; const uint8_t *in_view, *desc, *obs_positive; };
 struct RelocDev { int on; const float *min_dist, *max_dist; float log_scale; int orb_dist; };
-struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; };
+struct LastDev { int n; const uint8_t *has_mp, *outlier; const float *xw; const plf_keypoint *keys; const uint8_t *mp_desc; const uint8_t *obs_positive; };
 struct BowDev { int n_kf, n_f; const uint8_t *kf_desc, *f_desc; const float *kf_angle, *f_angle; const uint8_t *kf_has_mp, *f_has_mp; int kf_nodes, f_nodes;
                 const uint32_t *kf_node_id, *f_node_id; const int *kf_node_start, *f_node_start; const int *kf_feat, *f_feat; };
 struct Pts3Dev { int m; const float *xw, *normal, *min_dist, *max_dist; const uint8_t *desc, *valid; };
@@ -69,7 +69,20 @@ struct plf_matcher {
     FrameDev *h_frames;      // host copy of the frame table last uploaded (skips the upload + sync when unchanged)
     LineFrameDev *h_lframes;
     int h_nframes, h_nlframes;
+    hipStream_t last_stream;   // stream of the most recent call (matcher_stream)
+    bool last_stream_set;
 };
+
+// Handle-owned scratch (frame tables, cell lists, candidate pools) is ordered by the stream the work was enqueued on.  A call on a DIFFERENT stream
+// than the previous one first waits for that stream, so successive calls on one handle may use any streams (include/plf.h, "Streams").
+static int matcher_stream(plf_matcher *h, void *stream, hipStream_t *out)
+{
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    h->last_stream = s; h->last_stream_set = true;
+    *out = s;
+    return PLF_OK;
+}
 
 static void matcher_free(plf_matcher *h)
 {
@@ -169,7 +182,8 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
     if (!h || !frames || !mp || !match_of_kp || !nmatches || n_frames < 1 || n_frames > h->max_batch || mp->m < 0 || mp->m > h->max_mp)
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     std::vector<FrameDev> fd(n_frames);
     int maxn = 1;
     for (int f = 0; f < n_frames; f++) {
@@ -213,7 +227,8 @@ static int match_bow_impl(plf_matcher *h, const plf_bow_view *pairs, int32_t n_p
 {
     if (!h || !pairs || !match || !nmatches || n_pairs < 1 || n_pairs > h->max_batch || stride < 1 || stride > h->max_kp) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     std::vector<BowDev> pd(n_pairs);
     for (int i = 0; i < n_pairs; i++) {
         const plf_bow_view &v = pairs[i];
@@ -255,7 +270,8 @@ extern "C" int plf_match_triangulation(plf_matcher *h, const plf_tri_view *v, co
         !v->level_sigma2_2)
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     BowDev d;
     memset(&d, 0, sizeof(d));
     d.n_kf = v->n1; d.n_f = v->n2; d.kf_desc = v->desc1; d.f_desc = v->desc2; d.kf_has_mp = v->has_mp1; d.f_has_mp = v->has_mp2;
@@ -290,7 +306,8 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *cur, const
         !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y) || !last->has_mappoint || (!RL.on && !last->outlier))
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     FrameDev fd;
     memset(&fd, 0, sizeof(fd));
     fd = make_frame(h, *cur, 0);
@@ -304,6 +321,7 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *cur, const
     hipLaunchKernelGGL(k_build_grid, dim3(1), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
     LastDev L;
     L.n = last->n; L.has_mp = last->has_mappoint; L.outlier = last->outlier; L.xw = last->world_pos; L.keys = last->keys; L.mp_desc = last->mp_desc;
+    L.obs_positive = RL.on ? nullptr : last->obs_positive;   // (the relocalisation overload tests the pointer only)
     const int kp_cap = ((cur->n > 0 ? cur->n : 1) + 63) & ~63;
     hipLaunchKernelGGL(k_match_lastframe, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, L, *pose, RL, th, mono, check_orientation, match_of_kp,
                        nmatches, h->d_done, h->d_proj, kp_cap);
@@ -368,7 +386,8 @@ extern "C" int plf_match_assign_grid(plf_matcher *h, const plf_frame_view *frame
 {
     if (!h || !frame || !cell_start || !cell_idx) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     FrameDev fd;
     plf_frame_view v = *frame;
     if (v.nlevels < 1) v.nlevels = 1;   // (the grid does not read the scale pyramid)
@@ -388,7 +407,8 @@ extern "C" int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const pl
     if (!h || !kf || !pose || !pts || !best_idx || !nfused || pts->m < 0 || pts->m > h->max_mp || !(pose->log_scale_factor > 0.f)) return PLF_E_BADARG;
     if (pts->m > 0 && (!pts->world_pos || !pts->normal || !pts->min_distance || !pts->max_distance || !pts->desc || !pts->valid)) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     FrameDev fd;
     const int st = stage_keyframe(h, kf, s, &fd);
     if (st != PLF_OK) return st;
@@ -437,7 +457,8 @@ extern "C" int plf_match_fuse_sim3(plf_matcher *h, const plf_frame_view *kf, con
 {
     if (!h || !best_idx || !nfused) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     FrameDev fd; ProjKf C;
     const int st = sim3_common(h, kf, Scw, intr, pts, s, &fd, &C);
     if (st != PLF_OK) return st;
@@ -453,7 +474,8 @@ extern "C" int plf_match_project_sim3(plf_matcher *h, const plf_frame_view *kf, 
 {
     if (!h || !match_of_kp || !nmatches) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     FrameDev fd; ProjKf C;
     const int st = sim3_common(h, kf, Scw, intr, pts, s, &fd, &C);
     if (st != PLF_OK) return st;
@@ -469,10 +491,12 @@ extern "C" int plf_match_sim3(plf_matcher *h, const plf_frame_view *kf1, const p
                               int32_t *match12, int32_t *nfound, void *stream)
 {
     if (!h || !kf1 || !kf2 || !pose1 || !pose2 || !R12 || !t12 || !pts1 || !pts2 || !match12 || !nfound || pts1->m != kf1->n || pts2->m != kf2->n ||
-        pts1->m > h->max_mp || pts2->m > h->max_mp || !(s12 > 0.f) || !(pose1->log_scale_factor > 0.f) || !(pose2->log_scale_factor > 0.f))
+        pts1->m > h->max_mp || pts2->m > h->max_mp || kf1->n < 0 || kf2->n < 0 || kf1->n > h->max_kp || kf2->n > h->max_kp /* vn1 / vn2 hold max_kp ints */ ||
+        !(s12 > 0.f) || !(pose1->log_scale_factor > 0.f) || !(pose2->log_scale_factor > 0.f))
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     // sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t() (scale expressions, float work type), t21 = -sR21 * t12 (gemm, alpha = -1)
     float sR12[9], sR21[9], t21[3];
     const float a21 = (float)(1.0 / (double)s12);
@@ -513,7 +537,8 @@ extern "C" int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t
 {
     if (!h || !query || !train || !out || nq < 1 || nt < 1 || nq > h->max_lines) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(128), 0, s, query, nq, train, nt, h->d_knn_idx, h->d_knn_dist);
     plf_dmatch *d_out = mem == PLF_MEM_DEVICE ? out : h->d_dm;
     hipLaunchKernelGGL(k_knn2_to_dmatch, dim3((2 * nq + 127) / 128), dim3(128), 0, s, h->d_knn_idx, h->d_knn_dist, nq, d_out);
@@ -531,7 +556,8 @@ extern "C" int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_des
     if (!h || !last_desc || !cur_desc || !last_has_mapline || !match_of_line || !nmatches || nlast > h->max_lines || ncur > h->max_lines)
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     if (nlast <= 0 || ncur < 2) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int), s)); return PLF_OK; }
     hipLaunchKernelGGL(k_knn2, dim3((nlast + 127) / 128), dim3(128), 0, s, last_desc, nlast, cur_desc, ncur, h->d_knn_idx, h->d_knn_dist);
     int P2 = 1;
@@ -548,7 +574,8 @@ extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view 
     if (!h || !frames || !ml || !match_of_line || !nmatches || n_frames < 1 || n_frames > h->max_batch || ml->m < 0 || ml->m > h->max_mp)
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
     std::vector<LineFrameDev> fd(n_frames);
     memset(fd.data(), 0, sizeof(LineFrameDev) * n_frames);
     int maxn = 1;

@@ -388,6 +388,7 @@ struct LastDev {
     const float *xw;
     const plf_keypoint *keys;
     const uint8_t *mp_desc;
+    const uint8_t *obs_positive;   // Observations() > 0 per last-frame map point; NULL = all (motion-model overload only)
 };
 
 // one block; items = key points of the last frame.  proj[i] = (u, v, invzc, radius) prepared in the first phase.
@@ -411,6 +412,10 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
         twc[i] = (float)(-((double)P.Rcw[i] * P.tcw[0] + (double)P.Rcw[3 + i] * P.tcw[1] + (double)P.Rcw[6 + i] * P.tcw[2]));
     for (int i = 0; i < 3; i++) tlc[i] = P.Rlw[i * 3] * twc[0] + P.Rlw[i * 3 + 1] * twc[1] + P.Rlw[i * 3 + 2] * twc[2] + P.tlw[i];
     const bool bForward = tlc[2] > P.b && !mono, bBackward = -tlc[2] > P.b && !mono;
+    // "CurrentFrame.mvpMapPoints[i2] && ->Observations() > 0" (so@0x81e3d): a key point taken by a last-frame point WITHOUT observations (a temporal
+    // point of localisation mode) stays available to later points and is overwritten; the relocalisation overload tests the pointer only
+    const uint8_t *obs = RL.on ? nullptr : Lf.obs_positive;
+#define KP_FREE(idx) (claim[idx] == -1 || (obs && claim[idx] >= 0 && !obs[claim[idx]]))
     for (int k = t; k < F.n; k += T) claim[k] = match[k];
     if (t < HISTO_LENGTH) hist[t] = 0;
     if (t == 0) s_acc = 0;
@@ -445,6 +450,7 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
             }
             if (act) pr = make_float4(u, v, invzc, th * F.scale_factors[RL.on ? lvl : Lf.keys[i].octave]);
         }
+        if (!act) pr.x = __int_as_float(-1);   // finished items keep their assignment (key point index, -1 none) in .x
         proj[i] = pr;
         done[i] = act ? (uint8_t)(lvl << 1) : 1;   // bit 0: finished, bits 1..: predicted level (relocalisation)
     }
@@ -459,7 +465,7 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
             const int oct = RL.on ? (done[i] >> 1) : Lf.keys[i].octave;
             const int minL = RL.on ? oct - 1 : (bForward ? oct : (bBackward ? 0 : oct - 1)), maxL = RL.on ? oct + 1 : (bForward ? -1 : (bBackward ? oct : oct + 1));
             const CellWin w = cell_window(F, pr.x, pr.y, pr.w);
-            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (claim[idx] == -1) atomicMin(&owner[idx], i); })
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (KP_FREE(idx)) atomicMin(&owner[idx], i); })
         }
         __syncthreads();
         for (int i = t; i < Lf.n; i += T) {
@@ -469,12 +475,12 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
             const int minL = RL.on ? oct - 1 : (bForward ? oct : (bBackward ? 0 : oct - 1)), maxL = RL.on ? oct + 1 : (bForward ? -1 : (bBackward ? oct : oct + 1));
             const CellWin w = cell_window(F, pr.x, pr.y, pr.w);
             bool safe = true;
-            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (claim[idx] == -1 && owner[idx] != i) safe = false; })
+            if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, { if (KP_FREE(idx) && owner[idx] != i) safe = false; })
             if (!safe) { atomicAdd(&s_left, 1); continue; }
             int bestDist = 256, bestIdx2 = -1;
             const uint8_t *d = Lf.mp_desc + 32 * (size_t)i;
             if (w.ok) FOR_EACH_CANDIDATE(F, w, pr.x, pr.y, pr.w, minL, maxL, idx, {
-                if (claim[idx] != -1) continue;
+                if (!KP_FREE(idx)) continue;
                 if (F.uright && !RL.on) {
                     const float urr = F.uright[idx];
                     if (urr > 0) { const float ur = fmaf(-P.bf, pr.z, pr.x); const float er = fabsf(ur - urr); if (er > pr.w) continue; }
@@ -483,8 +489,10 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
                 if (dist < bestDist) { bestDist = dist; bestIdx2 = idx; }
             })
             done[i] |= 1;
+            proj[i].x = __int_as_float(-1);   // the item's projection is no longer needed: the slot records its assignment
             if (bestDist <= (RL.on ? RL.orb_dist : TH_HIGH)) {
                 claim[bestIdx2] = i;
+                proj[i].x = __int_as_float(bestIdx2);
                 atomicAdd(&s_acc, 1);
                 if (check_ori) {
                     float rot = Lf.keys[i].angle - F.keys[bestIdx2].angle;
@@ -513,9 +521,11 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
             keepbin[0] = i1; keepbin[1] = i2; keepbin[2] = i3;
         }
         __syncthreads();
-        for (int k = t; k < F.n; k += T) {
-            const int i = claim[k];
-            if (i < 0 || match[k] >= 0) continue;  // only matches made by this call sit in the histogram
+        // the reference culls per ASSIGNMENT (rotHist entries): an overwritten key point whose earlier or later assignment falls in a dropped bin
+        // ends up NULL, and nmatches is decremented once per dropped assignment
+        for (int i = t; i < Lf.n; i += T) {
+            const int k = __float_as_int(proj[i].x);
+            if (k < 0 || k >= F.n) continue;
             float rot = Lf.keys[i].angle - F.keys[k].angle;
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * (1.0f / 12.0f));
@@ -526,6 +536,7 @@ __global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf,
     }
     for (int k = t; k < F.n; k += T) match[k] = claim[k];
     if (t == 0) *nmatches = s_acc;
+#undef KP_FREE
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,6 +46,8 @@ struct plf_orb {
     int *d_nout;
     size_t in_cap;
     int last_frames;
+    hipStream_t last_stream;   // stream of the most recent call
+    bool last_stream_set;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
@@ -211,6 +213,8 @@ static int orb_configure(plf_orb *h, int w, int hh)
     for (int l = 0; l < g.nlevels; l++) { tx += g.lv[l].w; ty += g.lv[l].h; }
     if (tx > h->alloc_tx || ty > h->alloc_ty) return PLF_E_BADARG;
     xofs.resize(tx); xa.resize(tx); yofs.resize(ty); yb.resize(ty);
+    // kernels of a previous call (any stream: the caller's streams do not synchronise with the null stream) may still read the tables
+    if (h->cur_w >= 0) PLF_HIP_TRY(hipDeviceSynchronize());
     for (int l = 1; l < g.nlevels; l++)
         resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, &xofs[g.lv[l].tabx_off], &xa[g.lv[l].tabx_off],
                       &yofs[g.lv[l].taby_off], &yb[g.lv[l].taby_off]);
@@ -384,6 +388,9 @@ extern "C" int plf_orb_extract_batch(plf_orb *h, const uint8_t *gray, int32_t in
     int rc = orb_configure(h, width, height);
     if (rc != PLF_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
+    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    h->last_stream = s; h->last_stream_set = true;
     const uint8_t *d_gray = gray;
     ptrdiff_t dpitch = pitch, dfstride = frame_stride;
     if (in_mem == PLF_MEM_HOST) {
@@ -425,6 +432,13 @@ extern "C" int plf_orb_extract_batch(plf_orb *h, const uint8_t *gray, int32_t in
     }
     PLF_HIP_TRY(hipStreamSynchronize(s));
     return (status & 5) ? PLF_E_HIP : ((status & 2) ? PLF_E_CAPACITY : PLF_OK);
+}
+
+// batch driver (batch_host.hip): the status word of the batch just enqueued on `s`, copied to pinned host memory in stream order
+int plf_orb_status_async(plf_orb *h, int32_t *host_dst, hipStream_t s)
+{
+    PLF_HIP_TRY(hipMemcpyAsync(host_dst, h->d_counters + 3 * (size_t)h->prm.max_batch * h->g.nlevels, sizeof(int), hipMemcpyDeviceToHost, s));
+    return PLF_OK;
 }
 
 extern "C" int plf_orb_extract(plf_orb *h, const uint8_t *gray, int32_t width, int32_t height, ptrdiff_t pitch, plf_keypoint *kps,

@@ -10,9 +10,9 @@ class LineSegment:
     """ExtractLineSegment(img, keylines, ldesc, lineFunctions, scale=1.2, numOctaves=1) -- include/ExtractLineSegment.h:38.
     `nlines` is the number of lines kept after the response sort (compile-time constant in the fork)."""
 
-    def __init__(self, nlines=100, max_width=640, max_height=480, max_batch=1, device=0, seed_order=0):
+    def __init__(self, nlines=100, max_width=640, max_height=480, max_batch=1, device=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED):
         self._h = C.c_void_p()
-        p = L.LineParams(nlines, seed_order, device, max_width, max_height, max_batch)
+        p = L.line_params(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input)
         L.check(L.lib().plf_line_create(C.byref(p), C.byref(self._h)), "plf_line_create")
         self.nlines, self.max_batch = nlines, max_batch
 

@@ -59,6 +59,7 @@ class Matcher:
         lv.n = int(last["mp_desc"].shape[0])
         lv.has_mappoint = L.vp(last["has_mappoint"]).value; lv.outlier = L.vp(last["outlier"]).value
         lv.world_pos = L.vp(last["world_pos"]).value; lv.keys = L.vp(last["keys"]).value; lv.mp_desc = L.vp(last["mp_desc"]).value
+        lv.obs_positive = L.vp(last["obs_positive"]).value if last.get("obs_positive") is not None else None
         pp = L.PosePair()
         for name in ("Rcw", "tcw", "Rlw", "tlw"):
             a = np.asarray(pose[name], np.float32).ravel()

@@ -43,7 +43,7 @@ class MapPoints(C.Structure):
 
 class LastFrame(C.Structure):
     _fields_ = [("n", C.c_int), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("xw", C.c_void_p), ("octave", C.c_void_p),
-                ("angle", C.c_void_p), ("mp_desc", C.c_void_p)]
+                ("angle", C.c_void_p), ("mp_desc", C.c_void_p), ("obs_positive", C.c_void_p)]
 
 
 class Points3D(C.Structure):
@@ -150,15 +150,18 @@ def lsd_detect(gray, seed_order=0, maps=False):
     return res
 
 
-def line_extract(gray, nkeep=100, seed_order=0):
+LBD_BLURRED, LBD_RAW = 0, 1   # what BinaryDescriptor's Sobel reads (plf_line_params.lbd_sobel_input)
+
+
+def line_extract(gray, nkeep=100, seed_order=0, lbd_sobel_input=LBD_BLURRED):
     L = lib()
     gray = np.ascontiguousarray(gray, np.uint8)
     h, w = gray.shape
     cap = nkeep
     kl = np.zeros(cap, KL_DTYPE); desc = np.zeros((cap, 32), np.uint8); eq = np.zeros((cap, 3), np.float64)
     nd = C.c_int(0)
-    n = L.orc_line_extract(p(gray), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(nkeep), C.c_int(seed_order), p(kl), p(desc),
-                           p(eq), C.c_int(cap), C.byref(nd))
+    n = L.orc_line_extract_ex(p(gray), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(nkeep), C.c_int(seed_order), p(kl), p(desc),
+                              p(eq), C.c_int(cap), C.byref(nd), C.c_int(lbd_sobel_input))
     return dict(kl=kl[:n].copy(), desc=desc[:n].copy(), eq=eq[:n].copy(), ndetected=nd.value)
 
 
@@ -200,6 +203,8 @@ def search_by_projection_last(kps, desc, uright, scale, bounds, last, pose, th, 
     Lf = LastFrame()
     Lf.n = len(lk); Lf.has_mp = p(arrs["has_mappoint"]).value; Lf.outlier = p(arrs["outlier"]).value; Lf.xw = p(arrs["world_pos"]).value
     Lf.octave = p(oc).value; Lf.angle = p(ang).value; Lf.mp_desc = p(arrs["mp_desc"]).value
+    obs = np.ascontiguousarray(last["obs_positive"], np.uint8) if last.get("obs_positive") is not None else None
+    Lf.obs_positive = p(obs).value if obs is not None else None
     R = {k: np.ascontiguousarray(np.asarray(pose[k], np.float32).ravel()) for k in ("Rcw", "tcw", "Rlw", "tlw")}
     match = np.ascontiguousarray(match_init, np.int32).copy()
     n = L.orc_search_by_projection_last(C.byref(F), C.byref(Lf), p(R["Rcw"]), p(R["tcw"]), p(R["Rlw"]), p(R["tlw"]), C.c_float(pose["fx"]),

@@ -121,7 +121,8 @@ def load_search_last_cases(path):
         lk["angle"] = f32(c["last_angle"]); lk["octave"] = np.array(c["last_octave"], np.int32)
         cam = f32(c["cam"]); Tc = f32(c["Tcw"]).reshape(4, 4); Tl = f32(c["Tlw"]).reshape(4, 4)
         last = dict(keys=lk, has_mappoint=np.array(c["last_has_mp"], np.uint8), outlier=np.array(c["last_outlier"], np.uint8),
-                    world_pos=f32(c["world_pos"]).reshape(NL, 3).copy(), mp_desc=np.frombuffer(bytes.fromhex(c["mp_desc"]), np.uint8).reshape(NL, 32).copy())
+                    world_pos=f32(c["world_pos"]).reshape(NL, 3).copy(), mp_desc=np.frombuffer(bytes.fromhex(c["mp_desc"]), np.uint8).reshape(NL, 32).copy(),
+                    obs_positive=np.array(c["last_obs_positive"], np.uint8))   # Observations() > 0 of the last frame's map points (0: temporal points)
         pose = dict(Rcw=Tc[:3, :3].copy(), tcw=Tc[:3, 3].copy(), Rlw=Tl[:3, :3].copy(), tlw=Tl[:3, 3].copy(), fx=float(cam[0]), fy=float(cam[1]),
                     cx=float(cam[2]), cy=float(cam[3]), bf=float(cam[4]), b=float(cam[5]))
         match = np.array(c["match"], np.int32)

@@ -55,7 +55,7 @@ def test_no_cpu_fallback_without_gpu(lib):
     h = C.c_void_p()
     p = L.OrbParams(1000, 1.2, 8, 20, 7, 0, 640, 480, 1)
     assert lib.plf_orb_create(C.byref(p), C.byref(h)) == L.PLF_E_HIP and not h.value
-    lp = L.LineParams(100, 0, 0, 640, 480, 1)
+    lp = L.line_params(100, 0, 0, 640, 480, 1)
     assert lib.plf_line_create(C.byref(lp), C.byref(h)) == L.PLF_E_HIP and not h.value
     assert lib.plf_matcher_create(0, 1000, 5000, 100, 1, C.byref(h)) == L.PLF_E_HIP and not h.value
     assert lib.plf_device_count() == 0

@@ -1,0 +1,145 @@
+"""GPU parity of the multi-GPU batch driver (plf_batch_*, rgbd_pl_slam_amd/csrc/batch_host.hip): host frames in, features (and matches
+against a replicated local map) out, through per-GPU worker threads with pinned double-buffered staging.  Every frame must equal the CPU
+oracle's output for that frame, whatever chunk / slot / GPU it went through.  BASELINE configs 3 and 4 run here as specified."""
+import numpy as np
+import pytest
+
+import matchgen
+import orc
+from conftest import gpu_available
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not gpu_available():
+        pytest.fail("no GPU visible: the -m gpu tests need a real MI355X")
+
+
+def _same_orb(got, ref, tag):
+    assert len(got["kps"]) == len(ref["kps"]), "%s: %d vs %d key points" % (tag, len(got["kps"]), len(ref["kps"]))
+    for name in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(got["kps"][name].view(np.uint32), ref["kps"][name].view(np.uint32)), "%s: key point field %s" % (tag, name)
+    assert np.array_equal(got["desc"], ref["desc"]), "%s: ORB descriptors" % tag
+
+
+def _same_lines(got, ref, tag):
+    assert len(got["lines"]) == len(ref["kl"]), "%s: %d vs %d lines" % (tag, len(got["lines"]), len(ref["kl"]))
+    for name in got["lines"].dtype.names:
+        assert np.array_equal(got["lines"][name].view(np.uint32), ref["kl"][name].view(np.uint32)), "%s: KeyLine field %s" % (tag, name)
+    assert np.array_equal(got["ldesc"], ref["desc"]), "%s: LBD descriptors" % tag
+    assert np.allclose(got["line_eq"], ref["eq"], rtol=0, atol=1e-4), "%s: line equations" % tag
+
+
+def test_config4_batch_of_8_1280x960_4000_400():
+    """BASELINE configs[3] as one GPU of the 8 sees it: 8 frames of 1280x960 in flight, 4000 ORB features + 400 lines."""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd.synth import synth_frame
+    imgs = np.stack([synth_frame(900 + i, 1280, 960) for i in range(8)])
+    bx = BatchExtractor(nfeatures=4000, nlines=400, width=1280, height=960, frames_in_flight=8, devices=[0])
+    res = bx.extract(imgs)
+    for f in range(8):
+        _same_orb(res[f], orc.orb_extract(imgs[f], nfeatures=4000), "frame %d" % f)
+        _same_lines(res[f], orc.line_extract(imgs[f], 400), "frame %d" % f)
+        assert len(res[f]["kps"]) >= 3900 and len(res[f]["lines"]) == 400
+    bx.close()
+
+
+def test_config3_batch_vga_2000_200_with_local_map_and_ragged_chunks():
+    """BASELINE configs[2]: VGA, 2000 + 200, 8 frames in flight; 21 frames = two full chunks + a ragged one, so both pipeline slots are
+    reused; matches against a replicated local map (SearchByProjection for points and lines) ride along."""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd.synth import synth_frame
+    n = 21
+    imgs = np.stack([synth_frame(300 + i) for i in range(n)])
+    r0 = orc.orb_extract(imgs[0], nfeatures=2000); l0 = orc.line_extract(imgs[0], 200)
+    mp = matchgen.make_local_map(r0["kps"], r0["desc"], 3000, 5)
+    ml = matchgen.make_map_lines(l0["kl"], l0["desc"], 400, 6)
+    scale = orc.orb_tables(2000, 1.2, 8)["scale"]
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    bx = BatchExtractor(nfeatures=2000, nlines=200, width=640, height=480, frames_in_flight=8, devices=[0], max_mappoints=4096, max_maplines=512)
+    bx.set_local_map(mp, ml, th=3.0, nnratio=0.8, bounds=bounds)
+    for rep in range(2):   # second call: slots and handles reused across calls
+        res = bx.extract(imgs)
+        for f in range(n):
+            ro = orc.orb_extract(imgs[f], nfeatures=2000); rl = orc.line_extract(imgs[f], 200)
+            _same_orb(res[f], ro, "frame %d" % f); _same_lines(res[f], rl, "frame %d" % f)
+            rm, rn = orc.search_by_projection_map(ro["kps"], ro["desc"], None, scale, bounds, mp, 3.0, 0.8, np.full(len(ro["kps"]), -1, np.int32))
+            assert res[f]["n_kp_matches"] == rn and np.array_equal(res[f]["match_of_kp"], rm), "frame %d: point matches" % f
+            lm, ln = orc.search_lines_by_projection(rl["kl"], rl["desc"], scale, ml, 3.0, 0.8, np.full(len(rl["kl"]), -1, np.int32))
+            assert res[f]["n_line_matches"] == ln and np.array_equal(res[f]["match_of_line"], lm), "frame %d: line matches" % f
+            if f == 0:
+                assert rn > 100 and ln > 10
+    t = bx.last_timing()
+    assert t["total"] > 0
+    bx.close()
+
+
+def test_padded_pinned_and_rgb_inputs():
+    """row pitch > width, frame stride > pitch * height, pinned caller memory (no staging copy) and RGB / BGR frames
+    (Tracking::GrabImageRGBD colour conversion on the device) all give the features of the plain gray frames"""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor, FMT_RGB8, FMT_BGR8, pinned_array, free_pinned
+    from rgbd_pl_slam_amd.synth import synth_frame
+    n, w, h = 5, 320, 240
+    gray = np.stack([synth_frame(40 + i, w, h) for i in range(n)])
+    ref = [(orc.orb_extract(g, nfeatures=500), orc.line_extract(g, 60)) for g in gray]
+    bx = BatchExtractor(nfeatures=500, nlines=60, width=w, height=h, frames_in_flight=2, devices=[0])
+    padded = np.zeros((n, h + 3, w + 24), np.uint8); padded[:, :h, :w] = gray
+    for tag, arr in (("padded", padded[:, :h, :w]), ("tight", gray)):
+        res = bx.extract(arr)
+        for f in range(n):
+            _same_orb(res[f], ref[f][0], tag); _same_lines(res[f], ref[f][1], tag)
+    pin = pinned_array((n, h, w)); pin[:] = gray
+    res = bx.extract(pin)
+    for f in range(n):
+        _same_orb(res[f], ref[f][0], "pinned"); _same_lines(res[f], ref[f][1], "pinned")
+    free_pinned(pin)
+    bx.close()
+    rng = np.random.default_rng(7)
+    rgb = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    rgb[..., 1] = gray    # structured green channel so that features exist
+    for fmt, bgr in ((FMT_RGB8, 0), (FMT_BGR8, 1)):
+        bc = BatchExtractor(nfeatures=500, nlines=60, width=w, height=h, frames_in_flight=2, devices=[0], input_format=fmt)
+        res = bc.extract(rgb)
+        for f in range(n):
+            g = orc.rgb_to_gray(rgb[f], bgr)
+            _same_orb(res[f], orc.orb_extract(g, nfeatures=500), "rgb"); _same_lines(res[f], orc.line_extract(g, 60), "rgb")
+        bc.close()
+
+
+def test_all_visible_gpus_share_one_batch():
+    """n_devices = 0: every visible GPU gets a contiguous block (plf_batch_shard); on the 1-GPU test box this is one worker, on an
+    8-GPU node the same call exercises eight -- the per-frame outputs do not depend on the partition"""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor, shard
+    from rgbd_pl_slam_amd.synth import synth_frame
+    n = 11
+    imgs = np.stack([synth_frame(70 + i, 320, 240) for i in range(n)])
+    bx = BatchExtractor(nfeatures=500, nlines=50, width=320, height=240, frames_in_flight=4)
+    assert bx.n_devices >= 1 and bx.devices == list(range(bx.n_devices))
+    blocks = [shard(n, bx.n_devices, d) for d in range(bx.n_devices)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    res = bx.extract(imgs)
+    for f in range(n):
+        _same_orb(res[f], orc.orb_extract(imgs[f], nfeatures=500), "frame %d" % f)
+        _same_lines(res[f], orc.line_extract(imgs[f], 50), "frame %d" % f)
+    bx.close()
+
+
+def test_empty_and_bad_arguments():
+    _need_gpu()
+    import ctypes as C
+    from rgbd_pl_slam_amd import _lib as L
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    bx = BatchExtractor(nfeatures=500, nlines=50, width=320, height=240, frames_in_flight=4, devices=[0])
+    out = bx.alloc_outputs(1)
+    img = np.zeros((1, 240, 320), np.uint8)
+    assert bx.extract_into(img, out) == 0 and out["n_kps"][0] == 0 and out["n_lines"][0] == 0     # flat image: no features, no error
+    big = np.zeros((1, 480, 640), np.uint8)
+    with pytest.raises(L.PlfError) as e:
+        bx.extract_into(big, bx.alloc_outputs(1))
+    assert e.value.status == L.PLF_E_BADARG
+    bx.close()

@@ -18,16 +18,16 @@ def _need_gpu():
         pytest.fail("no GPU visible: the -m gpu tests need a real MI355X")
 
 
-def _check(img, nlines, ext=None):
+def _check(img, nlines, ext=None, lbd_sobel_input=0):
     from rgbd_pl_slam_amd import LineSegment
     h, w = img.shape
     own = ext is None
     if own:
-        ext = LineSegment(nlines=nlines, max_width=w, max_height=h)
+        ext = LineSegment(nlines=nlines, max_width=w, max_height=h, lbd_sobel_input=lbd_sobel_input)
     kl, desc, eq = ext.ExtractLineSegment(img)
     segs = ext.segments(0)
     ref_seg = orc.lsd_detect(img)["lines"]
-    ref = orc.line_extract(img, nlines)
+    ref = orc.line_extract(img, nlines, lbd_sobel_input=lbd_sobel_input)
     assert len(segs) == len(ref_seg), "segment count %d vs %d" % (len(segs), len(ref_seg))
     assert np.allclose(segs, ref_seg, rtol=0, atol=TOL)
     nbits = int((segs.view(np.uint32) != ref_seg.view(np.uint32)).sum())
@@ -52,6 +52,22 @@ def test_lines_vga_synthetic():
     from rgbd_pl_slam_amd.synth import synth_frame
     for seed in (0, 1):
         _check(synth_frame(seed), 100)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (322, 243), (641, 479), (1280, 960)])
+def test_lbd_sobel_input_switch_both_settings(w, h):
+    """plf_line_params.lbd_sobel_input: BinaryDescriptor's Sobel on octave 0 of its Gaussian pyramid (GaussianBlur 5x5 sigma 1, the default,
+    believed opencv_contrib 3.3 behaviour) or on the raw image -- both bit-exact against the oracle, and they really differ.  Widths with
+    w % 4 != 0 exercise the scalar tail rounding of the column filter, odd heights the REFLECT_101 border of blur and Sobel."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    img = synth_frame(11, w, h)
+    _check(img, 100, lbd_sobel_input=orc.LBD_BLURRED)
+    _check(img, 100, lbd_sobel_input=orc.LBD_RAW)
+    a = orc.line_extract(img, 100, lbd_sobel_input=orc.LBD_BLURRED); b = orc.line_extract(img, 100, lbd_sobel_input=orc.LBD_RAW)
+    assert np.array_equal(a["kl"], b["kl"])                 # detection does not depend on the switch
+    assert (a["desc"] != b["desc"]).any(1).mean() > 0.5     # the descriptors do
 
 
 def test_lines_fewer_than_requested_and_200():

@@ -155,6 +155,68 @@ def test_line_matchers():
     m.close()
 
 
+LINE_SCENES = [
+    # frames a / b, lines kept, how many of a's lines reappear, bit flips, share of last-frame lines with a MapLine, map lines, th, nnratio
+    dict(sa=0, sb=1, n=100, keep=70, flips=25, has=0.8, M=500, th=3.0, nn=0.8),
+    dict(sa=2, sb=3, n=200, keep=150, flips=10, has=1.0, M=800, th=1.0, nn=0.9),    # th == 1: radius not scaled; every line tracked
+    dict(sa=4, sb=5, n=400, keep=100, flips=60, has=0.5, M=2000, th=5.0, nn=0.6),   # heavy noise: MAD threshold bites, more map lines than lines
+    dict(sa=6, sb=7, n=50, keep=50, flips=0, has=0.9, M=64, th=3.0, nn=0.8),        # exact copies: distance 0, ties in the kNN
+    dict(sa=8, sb=9, n=30, keep=3, flips=5, has=0.3, M=10, th=3.0, nn=0.8),         # few lines, tiny map
+    dict(sa=10, sb=11, n=100, keep=0, flips=0, has=0.8, M=300, th=3.0, nn=0.8),     # nothing in common
+    dict(sa=12, sb=13, n=120, keep=120, flips=3, has=0.0, M=300, th=3.0, nn=0.8),   # no last-frame line holds a MapLine: zero matches
+]
+
+
+@pytest.mark.parametrize("sc", LINE_SCENES, ids=lambda sc: "a%d_n%d_keep%d_flips%d" % (sc["sa"], sc["n"], sc["keep"], sc["flips"]))
+def test_line_matcher_scenes(sc):
+    """rows 13 / 14 (LSDmatcher::SearchByProjection x3, include/LSDmatcher.h:32,35,40): BF kNN + MAD rule and the projection search on scenes
+    that differ in size, noise, occupancy and thresholds"""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    from rgbd_pl_slam_amd.synth import synth_frame
+    a = orc.line_extract(synth_frame(sc["sa"]), sc["n"]); b = orc.line_extract(synth_frame(sc["sb"]), sc["n"])
+    rng = np.random.default_rng(100 + sc["sa"])
+    keep = min(sc["keep"], len(a["desc"]))
+    cur_desc = np.concatenate([matchgen.flip_bits(a["desc"][:keep], rng, sc["flips"]), b["desc"][:max(len(b["desc"]) - keep, 2)]])
+    cur_desc = np.ascontiguousarray(cur_desc[rng.permutation(len(cur_desc))])
+    m = Matcher(max_lines=1024, max_mappoints=4096)
+    idx, dist = orc.knn2(a["desc"], cur_desc)
+    dm = m.knnMatch(_dev(a["desc"]), _dev(cur_desc))
+    assert np.array_equal(dm["trainIdx"], idx) and np.array_equal(dm["distance"], dist.astype(np.float32))
+    has_ml = (rng.uniform(0, 1, len(a["desc"])) < sc["has"]).astype(np.uint8)
+    ref_match, ref_n = orc.match_lines_knn(a["desc"], cur_desc, has_ml)
+    match = torch.full((len(cur_desc),), -1, dtype=torch.int32, device="cuda"); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_last, d_cur, d_has = _dev(a["desc"]), _dev(cur_desc), _dev(has_ml)
+    m.SearchLinesLastFrame(d_last, d_cur, d_has, match, nm)
+    torch.cuda.synchronize()
+    assert int(nm[0]) == ref_n and np.array_equal(match.cpu().numpy(), ref_match)
+    if sc["has"] == 0.0:
+        assert ref_n == 0
+    # the keyframe overload (LSDmatcher.h:35) is the same rule with the keyframe's descriptors on the query side: swap the roles
+    has_kf = (rng.uniform(0, 1, len(cur_desc)) < 0.7).astype(np.uint8)
+    ref_match2, ref_n2 = orc.match_lines_knn(cur_desc, a["desc"], has_kf)
+    match2 = torch.full((len(a["desc"]),), -1, dtype=torch.int32, device="cuda")
+    d_has2 = _dev(has_kf)
+    m.SearchLinesLastFrame(d_cur, d_last, d_has2, match2, nm)
+    torch.cuda.synchronize()
+    assert int(nm[0]) == ref_n2 and np.array_equal(match2.cpu().numpy(), ref_match2)
+    # projection search against map lines
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    ml = matchgen.make_map_lines(a["kl"], a["desc"], sc["M"], 3 + sc["sa"])
+    init = np.full(len(a["kl"]), -1, np.int32); init[::7] = -2
+    ref_match, ref_n = orc.search_lines_by_projection(a["kl"], a["desc"], scale, ml, sc["th"], sc["nn"], init)
+    dkl = torch.from_numpy(np.frombuffer(np.ascontiguousarray(a["kl"]).tobytes(), np.uint8).copy()).cuda()
+    dld = _dev(a["desc"]); dsc = _dev(scale)
+    view = Matcher.lineframe_view(len(a["kl"]), dkl, dld, dsc)
+    dml = {k: _dev(v) for k, v in ml.items()}
+    match = _dev(init); nm2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    m.SearchLinesByProjection([view], dml, sc["th"], sc["nn"], match, len(a["kl"]), nm2)
+    torch.cuda.synchronize()
+    assert int(nm2[0]) == ref_n and np.array_equal(match.cpu().numpy(), ref_match)
+    m.close()
+
+
 def test_descriptor_distance_and_matrix():
     _need_gpu()
     import ctypes as C
@@ -265,7 +327,7 @@ def test_gpu_equals_reference_search_by_projection_lastframe_fixture():
         cur = Matcher.frame_view(N, dk, dd, ds, (0.0, 0.0, 640.0, 480.0), du)
         last = c["last"]
         dl = dict(keys=_kp_tensor(last["keys"]), has_mappoint=_dev(last["has_mappoint"]), outlier=_dev(last["outlier"]), world_pos=_dev(last["world_pos"]),
-                  mp_desc=_dev(last["mp_desc"]))
+                  mp_desc=_dev(last["mp_desc"]), obs_positive=_dev(last["obs_positive"]))   # cases 5-6: points without observations (localisation mode)
         match = _dev(c["init"]); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
         m.SearchByProjectionLastFrame(cur, dl, c["pose"], c["th"], c["mono"], c["check"], match, nm)
         torch.cuda.synchronize()

@@ -126,3 +126,31 @@ def test_gpu_equals_reference_operator_fixture():
         assert np.array_equal(kps["octave"], np.array(c["octave"], np.int32)), c["w"]
         assert np.array_equal(desc, np.frombuffer(bytes.fromhex(c["desc"]), np.uint8).reshape(-1, 32)), c["w"]
 
+
+def test_get_tables_equals_reference_ctor_fixture():
+    """a1: plf_orb_get_tables (C ABI, HIP library) against the tables the reference constructor itself produced
+    (ORBextractor::ORBextractor so@0x73050 executed by oracle/refprobe -> tests/golden/ref_orb_tables.json), bit patterns compared"""
+    _need_gpu()
+    import json
+    import os
+    import struct
+    from rgbd_pl_slam_amd import ORBextractor, PlfError
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_orb_tables.json")))["cases"]
+    done = 0
+    for c in cases:
+        nl = int(c["nlevels"])
+        sf = struct.unpack("f", struct.pack("I", c["scaleFactor_bits"]))[0]
+        try:
+            ext = ORBextractor(nfeatures=int(c["nfeatures"]), scaleFactor=sf, nlevels=nl, max_width=1280, max_height=960)
+        except PlfError:
+            continue    # parameter sets outside the handle's geometry limits (levels, quota) are covered by the oracle test
+        bits = lambda a: np.asarray(a, np.float32).view(np.uint32).tolist()
+        assert ext.GetLevels() == nl
+        assert bits(ext.GetScaleFactors()) == c["scale"]
+        assert bits(ext.GetInverseScaleFactors()) == c["inv"]
+        assert bits(ext.GetScaleSigmaSquares()) == c["sigma2"]
+        assert bits(ext.GetInverseScaleSigmaSquares()) == c["invsigma2"]
+        assert ext.GetFeaturesPerLevel().tolist() == c["perLevel"]
+        ext.close()
+        done += 1
+    assert done >= 3, "only %d of %d reference parameter sets fit a handle" % (done, len(cases))
