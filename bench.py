@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- RGB-D frames/sec through the MI355X feature front-end (ORB + LSD/LBD extract + Hamming match).
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run,
-one rank per GPU).  One "step" = one pass of the whole hot path over one batch of synthetic 640x480 frames that are
-already resident in HBM: ORBextractor::operator() (1000 features, 8 levels) + LineSegment::ExtractLineSegment
-(100 lines) + ORBmatcher::SearchByProjection against a 5000-point local map + LSDmatcher::SearchByProjection against
-500 map lines, i.e. BASELINE.json configs[1] with the config-5 matching load.  Frames are independent, so ranks
-shard the stream with no collective (weak scaling: every rank processes its own batch).
-Prints ONE JSON line on rank 0.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU).
+One "step" = one pass of the whole hot path over one batch of synthetic frames already resident in HBM:
+  ORBextractor::operator()  +  LineSegment::ExtractLineSegment  +  the four tracking matchers of the metric --
+  ORBmatcher::SearchByProjection(Frame, local map)   (5000-point local map, config-5 load)
+  ORBmatcher::SearchByProjection(Cur, Last)          (motion-model search against the last frame)
+  LSDmatcher::SearchByProjection(Frame, map lines)   (500 map lines)
+  LSDmatcher::SearchByProjection(Cur, Last)          (the brute-force Hamming kNN (k = 2) of the LBD descriptors + MAD rule)
+Workloads (--config, numbering = BASELINE.json configs[] counted from 1):
+  2 (default)  configs[1]: 640x480, 1000 ORB + 100 lines, the headline metric; --batch frames in flight per GPU (default 4096)
+  3            configs[2]: 640x480, 2000 ORB + 200 lines, 8 frames in flight on one GPU
+  4            configs[3]: 1280x960, 4000 ORB + 400 lines, batch 64 sharded over 8 GPUs = 8 frames in flight per GPU
+Frames are independent, so ranks shard the job with no collective (rgbd_pl_slam_amd.batch.shard = plf_batch_shard; weak scaling:
+every rank processes its own frames_in_flight).  Prints ONE JSON line on rank 0; at N = 1 the default config also carries the
+secondary figures (config 3 as specified, single-frame latency, PCIe-inclusive rate through the product's batch driver, CPU baseline).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,28 +27,244 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W_IMG, H_IMG, NFEAT, NLINES, M_POINTS, M_LINES = 640, 480, 1000, 100, 5000, 500
-# algorithmic bytes per VGA frame (1000 ORB + 100 lines, Lambda = 8000) and of the region-growing stage
-BYTES_PER_FRAME = 5_742_474 + 8_590_192
-P_S = int(0.64 * W_IMG * H_IMG)
-REGION_BYTES_PER_FRAME = 6 * P_S  # "6 * P_s [region grow: angle + used read, used write]"
+M_POINTS, M_LINES = 5000, 500
+CONFIGS = {   # --config -> (width, height, ORB features, lines, frames in flight per GPU, label)
+    2: (640, 480, 1000, 100, 4096, "BASELINE configs[1]: VGA, 1000 ORB feats (8 levels) + 100 lines"),
+    3: (640, 480, 2000, 200, 8, "BASELINE configs[2]: VGA, 2000 ORB + 200 lines, 8 frames in flight"),
+    4: (1280, 960, 4000, 400, 8, "BASELINE configs[3]: 1280x960, 4000 ORB + 400 lines, batch 64 over 8 GPUs = 8 frames in flight per GPU"),
+}
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(seconds_target, threads):
-    """The CPU oracle (a port of the reference algorithm, kind="port") timed on this host: the whole per-frame
-    front-end, one frame per OpenMP thread (oracle/bench_oracle.c).  The sample is sized for ~seconds_target."""
+def algorithmic_bytes(w, h, nfeat, nlines, lam_per_line=80):
+    """algorithmic bytes per frame of ORB and of the line pipeline, and of the region-growing stage alone"""
+    lw, lh, sp, p0, plast = w, h, 0, w * h, 0
+    scale = 1.0
+    import numpy as np
+    sf = np.float32(1.0)
+    for l in range(8):
+        if l:
+            sf = np.float32(np.float64(sf) * np.float64(np.float32(1.2)))
+        inv = np.float32(1.0) / sf
+        lw, lh = int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))
+        sp += lw * lh
+        plast = lw * lh
+    K = nfeat
+    b_orb = (sp - plast) + (sp - p0) + sp + 2 * sp + 749 * K + 512 * K + 32 * K + 28 * K
+    ps = int(0.64 * p0)
+    lam = lam_per_line * nlines
+    b_line = (p0 + ps) + 9 * ps + 8 * ps + 6 * ps + 5 * p0 + 252 * lam + 124 * nlines
+    return b_orb, b_line, 6 * ps
+
+
+class Pipeline:
+    """the device-resident step: both extractors + the four matchers for B frames in flight on one GPU"""
+
+    def __init__(self, w, h, nfeat, nlines, B, device, seed_base, serial=False, line_handles=1, front_wait=True):
+        import numpy as np
+        import torch
+        import matchgen
+        from rgbd_pl_slam_amd import ORBextractor, LineSegment, Matcher
+        from rgbd_pl_slam_amd._lib import KP_DTYPE, KL_DTYPE
+        from rgbd_pl_slam_amd.synth import synth_frame
+        self.torch, self.B, self.w, self.h, self.nlines = torch, B, w, h, nlines
+        self.serial, self.front_wait = serial, front_wait
+        ndist = min(B, 32)
+        self.ndist = ndist
+        imgs = np.stack([synth_frame(seed_base + i, w, h) for i in range(ndist)])
+        imgs = np.concatenate([imgs] * ((B + ndist - 1) // ndist))[:B]
+        self.d_img = torch.from_numpy(imgs).cuda()
+        self.orb = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, max_batch=B, device=device)
+        # (line_handles 2: two handles used alternately so that the NFA / descriptor tail of batch k overlaps the region growing of batch k+1)
+        self.lins = [LineSegment(nlines=nlines, max_width=w, max_height=h, max_batch=B, device=device) for _ in range(max(1, min(2, line_handles)))]
+        cap = self.cap = self.orb.capacity
+
+        def bufset():
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+            neg = lambda shape: torch.full(shape, -1, dtype=torch.int32, device="cuda")
+            return dict(kps=z((B, cap, 7), torch.float32), desc=z((B, cap, 32), torch.uint8), nk=z(B, torch.int32),
+                        lines=z((B, nlines, 17), torch.float32), ldesc=z((B, nlines, 32), torch.uint8), leq=z((B, nlines, 3), torch.float64), nl=z(B, torch.int32),
+                        match_kp=neg((B, cap)), nm_kp=z(B, torch.int32), match_kp_last=neg((B, cap)), nm_kp_last=z(B, torch.int32),
+                        match_ln=neg((B, nlines)), nm_ln=z(B, torch.int32), match_ln_last=neg((B, nlines)), nm_ln_last=z(B, torch.int32))
+        # feature / match buffers are double-buffered so that the extraction of step k+1 overlaps the matching of step k
+        self.bufs = [bufset(), bufset()]
+        self.scale = torch.from_numpy(np.ascontiguousarray(self.orb.GetScaleFactors())).cuda()
+        # HIP streams: LSD/LBD on a high-priority stream per line handle (region growing is a serial chain per frame and the long pole), ORB on sA,
+        # the matchers on sM.  The two extractors are independent, as the two threads of the PL-SLAM Frame constructor are.
+        self.sA = torch.cuda.Stream(priority=0)
+        self.sBs = [torch.cuda.Stream(priority=-1) for _ in self.lins]
+        if serial:
+            self.sBs = [self.sA for _ in self.lins]
+        self.sM = self.sA if serial else torch.cuda.Stream(priority=0)
+        # local map / last frame built from the features of frame 0 (so that real matches exist); replicas per GPU (SURVEY 8e)
+        b0 = self.bufs[0]
+        torch.cuda.synchronize()
+        self.orb.extract_batch_device(self.d_img, w, h, b0["kps"], b0["desc"], b0["nk"], cap, self.sA.cuda_stream)
+        self.lins[0].extract_batch_device(self.d_img, w, h, b0["lines"], b0["ldesc"], b0["leq"], b0["nl"], nlines, self.sBs[0].cuda_stream)
+        torch.cuda.synchronize()
+        n0 = int(b0["nk"][0]); k0 = np.frombuffer(b0["kps"][0, :n0].cpu().numpy().tobytes(), KP_DTYPE)
+        d0 = b0["desc"][0, :n0].cpu().numpy()
+        l0n = int(b0["nl"][0]); l0 = np.frombuffer(b0["lines"][0, :l0n].cpu().numpy().tobytes(), KL_DTYPE)
+        ld0 = b0["ldesc"][0, :l0n].cpu().numpy()
+        dev = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
+        self.mp = dev(matchgen.make_local_map(k0, d0, M_POINTS, 1, w=w, h=h))
+        self.ml = dev(matchgen.make_map_lines(l0, ld0, M_LINES, 2))
+        last, pose = matchgen.make_last_frame(k0, d0, 3, cx=w / 2 - 0.5, cy=h / 2 - 0.5)
+        last["keys"] = np.frombuffer(np.ascontiguousarray(last["keys"]).tobytes(), np.uint8).copy()
+        self.last = dev(last)
+        self.last_ldesc = torch.from_numpy(matchgen.flip_bits(ld0, np.random.default_rng(4), 15)).cuda()
+        self.last_has_ml = torch.from_numpy((np.random.default_rng(5).uniform(0, 1, l0n) < 0.8).astype(np.uint8)).cuda()
+        bounds = (0.0, 0.0, float(w), float(h))
+        self.mats = [Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=max(nlines, 2), max_batch=B, device=device) for _ in range(2)]
+        self.last_view = Matcher.last_view(self.last)
+        from rgbd_pl_slam_amd import _lib as L
+        self.poses = (L.PosePair * B)(*[Matcher.pose_pair(pose)] * B)
+        for bs in self.bufs:
+            bs["fviews"] = Matcher.view_array([Matcher.frame_view(cap, bs["kps"].data_ptr() + f * cap * 28, bs["desc"].data_ptr() + f * cap * 32, self.scale, bounds,
+                                                                  None, bs["nk"].data_ptr() + 4 * f) for f in range(B)])
+            bs["lviews"] = Matcher.view_array([Matcher.lineframe_view(nlines, bs["lines"].data_ptr() + f * nlines * 68, bs["ldesc"].data_ptr() + f * nlines * 32,
+                                                                      self.scale, bs["nl"].data_ptr() + 4 * f) for f in range(B)])
+            bs["match_done"] = None
+        self.k = 0
+
+    def step(self):
+        torch = self.torch
+        k = self.k; self.k += 1
+        bs = self.bufs[k & 1]
+        li = k % len(self.lins)
+        sA, sBk, sM, w, h = self.sA, self.sBs[li], self.sM, self.w, self.h
+        if bs["match_done"] is not None:           # the matchers of step k-2 read this buffer set
+            sA.wait_event(bs["match_done"]); sBk.wait_event(bs["match_done"])
+        self.lins[li].extract_batch_device(self.d_img, w, h, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], self.nlines, sBk.cuda_stream)
+        ev_lines = torch.cuda.Event(); ev_lines.record(sBk)
+        # ORB starts when the line extractor reaches region growing: that kernel is a latency-bound chain that leaves issue slots idle,
+        # whereas the line front stages (blur / resize / gradient / Sobel) are throughput-bound like ORB
+        if self.front_wait and not self.serial:
+            self.lins[li].wait_front(sA.cuda_stream)
+        self.orb.extract_batch_device(self.d_img, w, h, bs["kps"], bs["desc"], bs["nk"], self.cap, sA.cuda_stream)
+        ev_orb = torch.cuda.Event(); ev_orb.record(sA)
+        sM.wait_event(ev_orb)
+        with torch.cuda.stream(sM):
+            bs["match_kp"].fill_(-1); bs["match_kp_last"].fill_(-1); bs["match_ln"].fill_(-1); bs["match_ln_last"].fill_(-1)
+        mat = self.mats[k & 1]
+        mat.SearchByProjection(bs["fviews"], self.mp, 3.0, 0.8, bs["match_kp"], self.cap, bs["nm_kp"], sM.cuda_stream)
+        mat.SearchByProjectionLastFrameBatch(bs["fviews"], self.last_view, self.poses, 7.0, 0, 1, bs["match_kp_last"], self.cap, bs["nm_kp_last"], sM.cuda_stream)
+        sM.wait_event(ev_lines)
+        mat.SearchLinesByProjection(bs["lviews"], self.ml, 3.0, 0.8, bs["match_ln"], self.nlines, bs["nm_ln"], sM.cuda_stream)
+        mat.SearchLinesLastFrameBatch(self.last_ldesc, self.last_has_ml, bs["lviews"], bs["match_ln_last"], self.nlines, bs["nm_ln_last"], sM.cuda_stream)
+        bs["match_done"] = torch.cuda.Event(); bs["match_done"].record(sM)
+
+    def check(self):
+        # the device-resident calls return before the GPU has run: a capacity overflow would make the step's outputs (and its time) meaningless
+        for l in self.lins:
+            if l.last_status() != 0:
+                raise RuntimeError("line extractor reported status %d for the last batch" % l.last_status())
+
+    def matches_frame0(self):
+        b = self.bufs[0]
+        return {"points_map": int(b["nm_kp"][0]), "points_last_frame": int(b["nm_kp_last"][0]), "lines_map": int(b["nm_ln"][0]),
+                "lines_last_frame_knn": int(b["nm_ln_last"][0]), "keypoints": int(b["nk"][0]), "lines": int(b["nl"][0])}
+
+    def close(self):
+        for o in [self.orb] + self.lins + self.mats:
+            o.close()
+
+
+def timed(pipe, steps, warmup, dist=None):
+    torch = pipe.torch
+    for _ in range(warmup):
+        pipe.step()
+    torch.cuda.synchronize()
+    for l in pipe.lins:
+        l.profile(enable=True, reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    reg_ms, reg_launches = 0.0, 0
+    for l in pipe.lins:
+        ms_, n_ = l.profile(enable=False, reset=True)
+        reg_ms += ms_; reg_launches += n_
+    pipe.check()
+    return elapsed, reg_ms, reg_launches
+
+
+def single_frame_latency(device, w, h, nfeat, nlines, reps=20):
+    """one frame at a time through the host-memory entry points (ORBextractor::operator(), LineSegment::ExtractLineSegment): what a live
+    SLAM loop sees"""
+    import numpy as np
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    orb = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, device=device)
+    lin = LineSegment(nlines=nlines, max_width=w, max_height=h, device=device)
+    imgs = [synth_frame(7000 + i, w, h) for i in range(4)]
+    to, tl = [], []
+    for i in range(reps + 3):
+        t0 = time.perf_counter(); orb(imgs[i % 4]); t1 = time.perf_counter(); lin.ExtractLineSegment(imgs[i % 4]); t2 = time.perf_counter()
+        if i >= 3:
+            to.append(t1 - t0); tl.append(t2 - t1)
+    orb.close(); lin.close()
+    return {"orb_ms_median": round(1e3 * float(np.median(to)), 3), "lsd_lbd_ms_median": round(1e3 * float(np.median(tl)), 3), "frames": reps,
+            "what": "one %dx%d frame, host memory in and out, nothing else in flight" % (w, h)}
+
+
+def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml):
+    """host frames in, host features + matches out through the product's batch driver (plf_batch_*): pinned caller buffer, double-buffered
+    async H2D / D2H, one worker thread per GPU"""
+    import numpy as np
+    from rgbd_pl_slam_amd.batch import BatchExtractor, pinned_array, free_pinned
+    from rgbd_pl_slam_amd.synth import synth_frame
+    bx = BatchExtractor(nfeatures=nfeat, nlines=nlines, width=w, height=h, frames_in_flight=in_flight, devices=[device], max_mappoints=M_POINTS,
+                        max_maplines=M_LINES)
+    bx.set_local_map({k: v.cpu().numpy() for k, v in mp.items()}, {k: v.cpu().numpy() for k, v in ml.items()}, bounds=(0.0, 0.0, float(w), float(h)))
+    pin = pinned_array((n_frames, h, w))
+    distinct = np.stack([synth_frame(8000 + i, w, h) for i in range(16)])
+    for i in range(n_frames):
+        pin[i] = distinct[i % 16]
+    out = bx.alloc_outputs(n_frames)
+    bx.extract_into(pin[:min(n_frames, 2 * in_flight)], {k: v[:min(n_frames, 2 * in_flight)] for k, v in out.items()})   # warm-up (allocations, tables)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        bx.extract_into(pin, out)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    tm = bx.last_timing()
+    bx.close(); free_pinned(pin)
+    mb = n_frames * w * h / 1e6
+    return {"value": round(n_frames / best, 1), "unit": "frames/s", "frames": n_frames, "frames_in_flight": in_flight,
+            "h2d_MBps": round(mb / best, 1), "worker_seconds": {k: round(v, 4) for k, v in tm.items()},
+            "what": "plf_batch_extract: %d host frames (pinned) -> key points, descriptors, lines and local-map matches in host memory, 1 GPU" % n_frames}
+
+
+def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
+    """The CPU oracle (a port of the reference algorithm, kind="port") timed on this host, built HERE with the reference's flags
+    (-O3 -march=native, /root/reference CMakeLists.txt:14): (a) one frame at a time on one thread, as Examples/RGB-D/rgbd_tum.cc:98-116 times
+    it -- median / p95 and the per-stage split; (a2) ORB and LSD on two threads (PL-SLAM family); (b) one frame per thread on all cores."""
     import ctypes as C
     import numpy as np
     import orc
     import matchgen
     from rgbd_pl_slam_amd.synth import synth_frame
-    L = orc.lib()
+    flags = "-O3 -march=native"
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "-B", "native"])
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_native.so"))
+    except Exception:
+        L = orc.lib(); flags = "-O2 (the -O3 -march=native build failed on this host)"
     L.orc_frontend_throughput.restype = C.c_double
-    frames = np.stack([synth_frame(5000 + i) for i in range(16)])
-    r0 = orc.orb_extract(frames[0], nfeatures=NFEAT)
-    l0 = orc.line_extract(frames[0], NLINES)
-    mp = {k: np.ascontiguousarray(v) for k, v in matchgen.make_local_map(r0["kps"], r0["desc"], M_POINTS, 1).items()}
+    L.orc_frontend_latency.restype = C.c_long
+    frames = np.stack([synth_frame(5000 + i, w, h) for i in range(16)])
+    r0 = orc.orb_extract(frames[0], nfeatures=nfeat)
+    l0 = orc.line_extract(frames[0], nlines)
+    mp = {k: np.ascontiguousarray(v) for k, v in matchgen.make_local_map(r0["kps"], r0["desc"], M_POINTS, 1, w=w, h=h).items()}
     ml = {k: np.ascontiguousarray(v) for k, v in matchgen.make_map_lines(l0["kl"], l0["desc"], M_LINES, 2).items()}
     MP = orc.MapPoints(); MP.m = M_POINTS
     for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos", "in_view", "desc", "obs_positive"):
@@ -48,28 +272,41 @@ def cpu_baseline(seconds_target, threads):
     ML = orc.MapLines(); ML.m = M_LINES
     for k in ("x1", "y1", "x2", "y2", "level", "view_cos", "in_view", "desc"):
         setattr(ML, k, orc.p(ml[k]).value)
+    common = (C.c_int(nfeat), C.c_int(nlines), C.byref(MP), C.byref(ML), C.c_float(3.0), C.c_float(0.8))
 
-    def run(n):
+    def latency(n, warm, two):
+        per = np.zeros(n, np.float64); st = np.zeros(16, np.float64)
+        chk = L.orc_frontend_latency(orc.p(frames), C.c_int(16), C.c_int(w), C.c_int(h), C.c_int(n), C.c_int(warm), *common, C.c_int(two), orc.p(per), orc.p(st))
+        return per, st, chk
+    # (a) single thread: a probe frame sizes the sample to ~45 % of the budget
+    per, _, _ = latency(2, 1, 0)
+    n1 = int(max(10, min(200, 0.45 * seconds_target / max(float(np.median(per)), 1e-3))))
+    per1, st1, chk1 = latency(n1, 3, 0)
+    n2 = max(6, n1 // 4)
+    per2, _, _ = latency(n2, 2, 1)
+    names = ["pyramid", "fast", "octree", "orient", "blur", "brief", "lsd", "lbd", "match_points", "match_lines"]
+    single = {"ms_median": round(1e3 * float(np.median(per1)), 2), "ms_p95": round(1e3 * float(np.percentile(per1, 95)), 2),
+              "ms_mean": round(1e3 * float(per1.mean()), 2), "frames_per_s": round(1.0 / float(np.median(per1)), 2), "frames": n1, "warmup": 3,
+              "stage_ms_per_frame": {nm: round(1e3 * float(st1[i]) / n1, 3) for i, nm in enumerate(names)},
+              "orb_lsd_on_two_threads_ms_median": round(1e3 * float(np.median(per2)), 2), "two_thread_frames": n2}
+
+    def run(n, t):
         chk = C.c_long(0)
-        return L.orc_frontend_throughput(orc.p(frames), C.c_int(16), C.c_int(W_IMG), C.c_int(H_IMG), C.c_int(n), C.c_int(threads), C.c_int(NFEAT),
-                                         C.c_int(NLINES), C.byref(MP), C.byref(ML), C.c_float(3.0), C.c_float(0.8), C.byref(chk))
-    # the visible CPU count can exceed what the container may really use: pick the thread count with the best
-    # measured throughput on a short probe, then grow the sample until it lasts about seconds_target
+        return L.orc_frontend_throughput(orc.p(frames), C.c_int(16), C.c_int(w), C.c_int(h), C.c_int(n), C.c_int(t), *common, C.byref(chk))
+    # (b) the visible CPU count can exceed what the container may really use: pick the thread count with the best measured throughput on a
+    # short probe, then size the sample to the rest of the budget
     best_t, best_v = threads, 0.0
-    for t in sorted({threads, max(1, threads // 2), max(1, threads // 4), min(threads, 64), min(threads, 32), min(threads, 16)}):
-        threads = t
-        d = run(2 * t)
+    for t in sorted({threads, max(1, threads // 2), min(threads, 64), min(threads, 32)}):
+        d = run(2 * t, t)
         if 2 * t / d > best_v:
             best_v, best_t = 2 * t / d, t
     threads = best_t
-    n = 4 * threads
-    dt = run(n)
-    for _ in range(4):
-        if dt >= 0.6 * seconds_target:
-            break
-        n = max(n + threads, int(n * seconds_target / max(dt, 1e-3)))
-        dt = run(n)
-    return n / dt, dt, n, threads
+    n = max(2 * threads, int(best_v * 0.35 * seconds_target))
+    dt = run(n, threads)
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port", "flags": flags,
+            "sample": "%d synthetic %dx%d frames (16 distinct), same workload incl. map matching, one frame per OpenMP thread on %d threads, %.1f s; "
+                      "single-thread figures: %d frames one at a time" % (n, w, h, threads, dt, n1),
+            "per_core": round(n / dt / threads, 3), "single_thread": single}
 
 
 def main():
@@ -77,14 +314,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="frames in flight per GPU and step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample (0: skip)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] entry, counted from 1 (2 = the headline metric)")
+    ap.add_argument("--batch", type=int, default=0, help="frames in flight per GPU and step (0: the config's own value)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (config 3 as specified, latency, PCIe-inclusive rate)")
     ap.add_argument("--line-handles", type=int, default=1, help="line extractor handles used alternately (1 or 2)")
     ap.add_argument("--no-front-wait", action="store_true", help="diagnostic: let ORB start together with the line front stages")
     ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
@@ -96,113 +334,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    import matchgen
-    from rgbd_pl_slam_amd import ORBextractor, LineSegment, Matcher
-    from rgbd_pl_slam_amd.synth import synth_frame
-
-    B = args.batch
-    ndist = min(B, 32)
-    imgs = np.stack([synth_frame(10_000 * rank + i) for i in range(ndist)])
-    imgs = np.concatenate([imgs] * ((B + ndist - 1) // ndist))[:B]
-    d_img = torch.from_numpy(imgs).cuda()
-
-    orb = ORBextractor(nfeatures=NFEAT, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank)
-    # (--line-handles 2: two handles used alternately so that the NFA / descriptor tail of batch k overlaps the region
-    # growing of batch k+1; at >= 3072 frames per batch the GPU is already saturated and one handle is as fast)
-    lins = [LineSegment(nlines=NLINES, max_width=W_IMG, max_height=H_IMG, max_batch=B, device=local_rank) for _ in range(max(1, min(2, args.line_handles)))]
-    lin = lins[0]
-    cap = orb.capacity
-    mat = Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)
-    # feature / match buffers are double-buffered so that the extraction of step k+1 overlaps the matching of step k
-    def bufset():
-        return dict(
-            kps=torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
-            nk=torch.zeros(B, dtype=torch.int32, device="cuda"),
-            lines=torch.zeros((B, NLINES, 17), dtype=torch.float32, device="cuda"), ldesc=torch.zeros((B, NLINES, 32), dtype=torch.uint8, device="cuda"),
-            leq=torch.zeros((B, NLINES, 3), dtype=torch.float64, device="cuda"), nl=torch.zeros(B, dtype=torch.int32, device="cuda"),
-            match_kp=torch.full((B, cap), -1, dtype=torch.int32, device="cuda"), nm_kp=torch.zeros(B, dtype=torch.int32, device="cuda"),
-            match_ln=torch.full((B, NLINES), -1, dtype=torch.int32, device="cuda"), nm_ln=torch.zeros(B, dtype=torch.int32, device="cuda"))
-    bufs = [bufset(), bufset()]
-    scale = torch.from_numpy(np.ascontiguousarray(orb.GetScaleFactors())).cuda()
-    # HIP streams: LSD/LBD on a high-priority stream per line handle (its region growing is a serial chain per frame and
-    # the long pole), ORB on sA, the matchers on sM.  The two extractors are independent, as the two threads of the
-    # PL-SLAM Frame constructor are; the matchers of step k wait for both extractors of step k.
-    sA = torch.cuda.Stream(priority=0)
-    sBs = [torch.cuda.Stream(priority=-1) for _ in lins]   # one stream per line handle (a handle's scratch buffers are stream-ordered)
-    if args.serial:
-        sBs = [sA for _ in lins]
-    sB = sBs[0]
-    stream, stream_b = sA.cuda_stream, sB.cuda_stream
-
-    # local map built from the features of frame 0 (so that real matches exist); replicated per GPU
-    b0 = bufs[0]
-    torch.cuda.synchronize()
-    orb.extract_batch_device(d_img, W_IMG, H_IMG, b0["kps"], b0["desc"], b0["nk"], cap, stream)
-    lin.extract_batch_device(d_img, W_IMG, H_IMG, b0["lines"], b0["ldesc"], b0["leq"], b0["nl"], NLINES, stream_b)
-    torch.cuda.synchronize()
-    from rgbd_pl_slam_amd._lib import KP_DTYPE, KL_DTYPE
-    n0 = int(b0["nk"][0]); k0 = np.frombuffer(b0["kps"][0, :n0].cpu().numpy().tobytes(), KP_DTYPE)
-    l0n = int(b0["nl"][0]); l0 = np.frombuffer(b0["lines"][0, :l0n].cpu().numpy().tobytes(), KL_DTYPE)
-    mp = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in matchgen.make_local_map(k0, b0["desc"][0, :n0].cpu().numpy(), M_POINTS, 1).items()}
-    ml = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in matchgen.make_map_lines(l0, b0["ldesc"][0, :l0n].cpu().numpy(), M_LINES, 2).items()}
-    bounds = (0.0, 0.0, float(W_IMG), float(H_IMG))
-    for bs in bufs:
-        bs["fviews"] = [Matcher.frame_view(cap, bs["kps"].data_ptr() + f * cap * 28, bs["desc"].data_ptr() + f * cap * 32, scale, bounds, None,
-                                           bs["nk"].data_ptr() + 4 * f) for f in range(B)]
-        bs["lviews"] = [Matcher.lineframe_view(NLINES, bs["lines"].data_ptr() + f * NLINES * 68, bs["ldesc"].data_ptr() + f * NLINES * 32, scale,
-                                               bs["nl"].data_ptr() + 4 * f) for f in range(B)]
-        bs["match_done"] = None
-    mats = [mat, Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=NLINES, max_batch=B, device=local_rank)]
-    state = {"k": 0}
-
-    sM = sA if args.serial else torch.cuda.Stream(priority=0)   # matchers: their own stream, so that ORB of step k+1 need not wait for lines of step k
-
-    def step():
-        k = state["k"]; state["k"] += 1
-        bs = bufs[k & 1]
-        li = k % len(lins)
-        sBk = sBs[li]
-        if bs["match_done"] is not None:           # the matchers of step k-2 read this buffer set
-            sA.wait_event(bs["match_done"]); sBk.wait_event(bs["match_done"])
-        lins[li].extract_batch_device(d_img, W_IMG, H_IMG, bs["lines"], bs["ldesc"], bs["leq"], bs["nl"], NLINES, sBk.cuda_stream)
-        ev_lines = torch.cuda.Event(); ev_lines.record(sBk)
-        # ORB starts when the line extractor reaches region growing: that kernel is a latency-bound chain that leaves
-        # issue slots idle, whereas the line front stages (blur/resize/gradient/Sobel) are throughput-bound like ORB
-        if not (args.no_front_wait or args.serial):
-            lins[li].wait_front(stream)
-        orb.extract_batch_device(d_img, W_IMG, H_IMG, bs["kps"], bs["desc"], bs["nk"], cap, stream)
-        ev_orb = torch.cuda.Event(); ev_orb.record(sA)
-        sM.wait_event(ev_orb)
-        with torch.cuda.stream(sM):
-            bs["match_kp"].fill_(-1); bs["match_ln"].fill_(-1)
-        mats[k & 1].SearchByProjection(bs["fviews"], mp, 3.0, 0.8, bs["match_kp"], cap, bs["nm_kp"], sM.cuda_stream)
-        sM.wait_event(ev_lines)
-        mats[k & 1].SearchLinesByProjection(bs["lviews"], ml, 3.0, 0.8, bs["match_ln"], NLINES, bs["nm_ln"], sM.cuda_stream)
-        bs["match_done"] = torch.cuda.Event(); bs["match_done"].record(sM)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    for l in lins:
-        l.profile(enable=True, reset=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    reg_ms, reg_launches = 0.0, 0
-    for l in lins:
-        ms_, n_ = l.profile(enable=False, reset=True)
-        reg_ms += ms_; reg_launches += n_
-        # the device-resident calls return before the GPU has run: a capacity overflow would make the step's outputs (and its time) meaningless
-        if l.last_status() != 0:
-            raise RuntimeError("line extractor reported status %d for the last batch" % l.last_status())
+    from rgbd_pl_slam_amd.batch import shard
+    W, H, NFEAT, NLINES, B0, label = CONFIGS[args.config]
+    B = args.batch if args.batch > 0 else B0
+    # the job = world * B frames per step; this rank's block of it (contiguous, plf_batch_shard) -- always B frames: weak scaling
+    lo, hi = shard(world * B, world, rank)
+    assert hi - lo == B
+    pipe = Pipeline(W, H, NFEAT, NLINES, B, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait)
+    elapsed, reg_ms, reg_launches = timed(pipe, args.steps, args.warmup, dist)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,40 +350,52 @@ def main():
     fps = frames / elapsed
 
     if rank == 0:
+        b_orb, b_line, b_region = algorithmic_bytes(W, H, NFEAT, NLINES)
         reg_avg_s = (reg_ms / max(reg_launches, 1)) * 1e-3
-        # HBM traffic of the dominant kernel from PMC counters (collected offline with rocprofv3 --pmc in separate
-        # passes on this very command; profiles/r01_pmc_traffic.json), scaled to this batch size
-        traffic = None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected with rocprofv3 --pmc in
+        # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
+        traffic, traffic_source = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            src = os.path.join("profiles", "r02_pmc_traffic.json")
+            with open(os.path.join(ROOT, src)) as fh:
                 pmc = json.load(fh)
-            traffic = int(pmc["k_lsd_regions2"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
+            if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):
+                traffic = int(pmc["region_kernel"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
+                traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command at %d frames per launch, scaled to %d)" % (src, pmc["frames_per_launch"], B)
         except Exception:
             traffic = None
-        achieved = (REGION_BYTES_PER_FRAME * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
+        achieved = (b_region * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
         out = {
-            "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at 640x480",
+            "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d" % (W, H),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/f64", "data": "synthetic (%d distinct seeded 640x480 frames per GPU tiled to the batch, resident in HBM)" % ndist,
-            "config": {"workload": "BASELINE configs[1]: VGA, 1000 ORB feats (8 levels) + 100 lines, plus config-5 matching "
-                                   "(SearchByProjection vs 5000-point local map, line projection search vs 500 map lines)",
-                       "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), no collective" % world},
-            "matches_frame0": {"points": int(bufs[0]["nm_kp"][0]), "lines": int(bufs[0]["nm_ln"][0])},
-            "pipeline_algorithmic_GBps": round(fps * BYTES_PER_FRAME / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": "k_lsd_regions2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches,
-                         "algorithmic_bytes_per_launch": REGION_BYTES_PER_FRAME * B},
+            "dtype": "u8/f64", "data": "synthetic (%d distinct seeded %dx%d frames per GPU tiled to the batch, resident in HBM)" % (pipe.ndist, W, H),
+            "config": {"workload": label + "; matching per frame: SearchByProjection vs a %d-point local map + vs the last frame, line projection search vs %d map "
+                                           "lines + brute-force Hamming kNN (k = 2) of the LBD descriptors vs the last frame's lines" % (M_POINTS, M_LINES),
+                       "baseline_config": args.config, "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
+            "matches_frame0": pipe.matches_frame0(),
+            "pipeline_algorithmic_GBps": round(fps * (b_orb + b_line) / 1e9, 2),
+            "roofline": {"bound": "hbm", "kernel": "LSD region growing (k_lsd_regions2 / k_lsd_spec_* for few frames in flight)", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                         "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches, "algorithmic_bytes_per_launch": b_region * B},
         }
+        mp, ml = pipe.mp, pipe.ml
+        pipe.close(); del pipe
+        if world == 1 and args.config == 2 and not args.no_extras and not args.serial:
+            # secondary figures, driver-timed in the same run
+            p3 = Pipeline(*CONFIGS[3][:5], local_rank, 20_000)
+            e3, r3, n3 = timed(p3, 30, 5)
+            out["config3_as_specified"] = {"value": round(8 * 30 / e3, 1), "unit": "frames/s", "ms_per_step": round(1e3 * e3 / 30, 3), "what": CONFIGS[3][5],
+                                           "region_stage_ms": round(r3 / max(n3, 1), 3)}
+            p3.close(); del p3
+            out["single_frame_latency"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES)
+            out["pcie_inclusive"] = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, 8192, 2048, mp, ml)
         if world == 1 and args.cpu_seconds > 0:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            v, dt, nfr, cores = cpu_baseline(float(args.cpu_seconds), cores)
-            out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-                                   "sample": "%d synthetic VGA frames (16 distinct), same workload incl. matching, one frame per OpenMP thread on %d threads, %.1f s"
-                                             % (nfr, cores, dt),
-                                   "per_core": round(v / cores, 3)}
+            out["cpu_baseline"] = cpu_baseline(float(args.cpu_seconds), cores, W, H, NFEAT, NLINES)
         print(json.dumps(out))
+    else:
+        pipe.close()
     if dist is not None:
         dist.destroy_process_group()
 

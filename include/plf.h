@@ -237,6 +237,13 @@ int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const
                                 const plf_pose_pair *pose, float th, int32_t mono, int32_t check_orientation,
                                 int32_t *match_of_kp, int32_t *nmatches, void *stream);
 
+/* The same overload for a batch of independent current frames against ONE last frame (a replica, like the local map of
+ * plf_match_project_points): frame f uses poses[f] (HOST array of n_frames), its assignments go to match_of_kp + f * kp_stride and its
+ * return value to nmatches[f]. */
+int plf_match_project_lastframe_batch(plf_matcher *h, const plf_frame_view *frames, int32_t n_frames, const plf_lastframe_view *last,
+                                      const plf_pose_pair *poses, float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp,
+                                      int32_t kp_stride, int32_t *nmatches, void *stream);
+
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint*> &sAlreadyFound,
  *                                    const float th, const int ORBdist)   include/ORBmatcher.h:82 (so@0x7e8c0, relocalisation).
  * kf: the keyframe's features -- has_mappoint[i] = pKF->GetMapPointMatches()[i] != NULL && !isBad() && !sAlreadyFound.count(pMP),
@@ -378,7 +385,7 @@ int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_desc, int32_t 
                               int32_t ncur, const uint8_t *last_has_mapline, int32_t *match_of_line, int32_t *nmatches,
                               void *stream);
 
-/* Frame members read by the line projection search (include/Frame.h:201-214); device memory */
+/* Frame members read by the line matchers (include/Frame.h:201-214); device memory */
 typedef struct {
     int32_t n;                   /* number of lines (upper bound when n_device is given) */
     const int32_t *n_device;     /* optional: count in device memory (output of plf_line_extract_batch) */
@@ -386,6 +393,13 @@ typedef struct {
     const uint8_t *desc;         /* mLdesc */
     const float *scale_factors;
 } plf_lineframe_view;
+
+/* LSDmatcher::SearchByProjection(Cur, Last) for a batch of independent current frames against ONE last frame (BF kNN k = 2 on the LBD
+ * descriptors + the lineDescriptorMAD rule per frame): frames[f].desc / n / n_device are read; frame f writes match_of_line + f * line_stride
+ * (pre-set to -1 by the caller) and nmatches[f]. */
+int plf_match_lines_lastframe_batch(plf_matcher *h, const uint8_t *last_desc, int32_t nlast, const uint8_t *last_has_mapline,
+                                    const plf_lineframe_view *frames, int32_t n_frames, int32_t *match_of_line, int32_t line_stride,
+                                    int32_t *nmatches, void *stream);
 
 /* MapLine tracking fields include/MapLine.h:113-129 */
 typedef struct {

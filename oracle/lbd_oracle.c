@@ -217,7 +217,9 @@ int orc_line_extract_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
 {
     int segcap = 1 << 16;
     float *segs = (float *)malloc(sizeof(float) * 4 * segcap);
+    ORC_T0(t_lsd);
     int ns = orc_lsd_detect(gray, w, h, pitch, seed_order, segs, segcap, NULL);
+    ORC_T1(t_lsd, ORC_ST_LSD);
     if (ns > segcap) ns = segcap;
     if (ndetected) *ndetected = ns;
     orc_keyline *kl = (orc_keyline *)malloc(sizeof(orc_keyline) * (ns > 0 ? ns : 1));
@@ -241,7 +243,9 @@ int orc_line_extract_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
         n = nkeep;
     }
     if (n > cap) n = cap;
+    ORC_T0(t_lbd);
     orc_lbd_compute_ex(gray, w, h, pitch, kl, n, desc, NULL, sobel_input);
+    ORC_T1(t_lbd, ORC_ST_LBD);
     for (int i = 0; i < n; i++) {
         out[i] = kl[i];
         double sx = kl[i].startPointX, sy = kl[i].startPointY, ex = kl[i].endPointX, ey = kl[i].endPointY;

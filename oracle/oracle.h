@@ -204,6 +204,16 @@ void orc_lbd_compute_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, cons
 int orc_line_extract_ex(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nkeep, int seed_order, orc_keyline *out,
                         uint8_t *desc, double *lineeq, int cap, int *ndetected, int sobel_input);
 
+/* ---- per-stage wall-clock split of the CPU baseline (bench_oracle.c).  Thread-local accumulators, filled only
+ * while orc_stage_timing is non-zero; the timed functions are otherwise untouched. */
+enum { ORC_ST_PYRAMID = 0, ORC_ST_FAST, ORC_ST_OCTREE, ORC_ST_ORIENT, ORC_ST_BLUR, ORC_ST_BRIEF, ORC_ST_LSD, ORC_ST_LBD, ORC_ST_MATCH_POINTS,
+       ORC_ST_MATCH_LINES, ORC_NSTAGES };
+extern int orc_stage_timing;
+extern __thread double orc_stage_s[ORC_NSTAGES];
+double orc_now_s(void);
+#define ORC_T0(var) const double var = orc_stage_timing ? orc_now_s() : 0.0
+#define ORC_T1(var, stage) do { if (orc_stage_timing) orc_stage_s[stage] += orc_now_s() - (var); } while (0)
+
 /* ---- Frame tail / ingest / frustum (frame_oracle.c) */
 void orc_rgb_to_gray(const uint8_t *rgb, int w, int h, ptrdiff_t pitch, int bgr_order, uint8_t *gray, ptrdiff_t gpitch);
 void orc_depth_to_float(const uint16_t *d, int w, int h, ptrdiff_t pitch_elems, float factor, float *out);

@@ -40,13 +40,14 @@ __global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, 
 struct TriDev { const plf_keypoint *keys1, *keys2; const float *uright1, *uright2, *scale2, *sigma2_2; float F[9]; float ex, ey; int only_stereo; };
 __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *, TriDev);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
-__global__ void k_match_lastframe(FrameDev, LastDev, plf_pose_pair, RelocDev, float, int, int, int *, int *, uint8_t *, float4 *, int);
+__global__ void k_match_lastframe(const FrameDev *, LastDev, const plf_pose_pair *, RelocDev, float, int, int, int *, int, int *, uint8_t *, float4 *, int, int);
 __global__ void k_project_kf(FrameDev, Pts3Dev, ProjKf, float, int *, int *, int *);
 __global__ void k_sim3_agree(const int *, int, const int *, int, int *, int *);
 __global__ void k_project_kf_greedy(FrameDev, Pts3Dev, ProjKf, float, int *, int *, uint8_t *, float4 *, int);
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
+__global__ void k_knn2_batch(const uint8_t *, int, const LineFrameDev *, int *, int *, int);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
-__global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int);
+__global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int, int, int, const LineFrameDev *);
 __global__ void k_match_project_lines(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
 __global__ void k_hamming_matrix(const uint8_t *, int, const uint8_t *, int, int *);
 
@@ -69,6 +70,8 @@ struct plf_matcher {
     FrameDev *h_frames;      // host copy of the frame table last uploaded (skips the upload + sync when unchanged)
     LineFrameDev *h_lframes;
     int h_nframes, h_nlframes;
+    plf_pose_pair *d_poses, *h_poses;   // per-frame poses of the batched last-frame search (device table + the host copy last uploaded)
+    int h_nposes;
     hipStream_t last_stream;   // stream of the most recent call (matcher_stream)
     bool last_stream_set;
 };
@@ -86,10 +89,10 @@ static int matcher_stream(plf_matcher *h, void *stream, hipStream_t *out)
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used, h->d_poses};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    free(h->h_frames); free(h->h_lframes);
+    free(h->h_frames); free(h->h_lframes); free(h->h_poses);
 }
 
 extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t max_mappoints, int32_t max_lines, int32_t max_batch,
@@ -126,9 +129,13 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     ALLOC(h->d_bow_fnode, B * (size_t)max_keypoints * sizeof(int));
     ALLOC(h->d_bow_used, B * (size_t)max_keypoints * sizeof(int));
     ALLOC(h->d_done, B * items);
-    ALLOC(h->d_proj, (size_t)(max_keypoints > max_mappoints ? max_keypoints : max_mappoints) * sizeof(float4));
-    ALLOC(h->d_knn_idx, 2 * (size_t)max_lines * sizeof(int));
-    ALLOC(h->d_knn_dist, 2 * (size_t)max_lines * sizeof(int));
+    {   // one row per map point (greedy Sim3 search, one frame) or max_keypoints entries per frame of a batched last-frame search
+        const size_t one = (size_t)(max_keypoints > max_mappoints ? max_keypoints : max_mappoints), batch = B * (size_t)max_keypoints;
+        ALLOC(h->d_proj, (one > batch ? one : batch) * sizeof(float4));
+    }
+    ALLOC(h->d_knn_idx, B * 2 * (size_t)max_lines * sizeof(int));
+    ALLOC(h->d_knn_dist, B * 2 * (size_t)max_lines * sizeof(int));
+    ALLOC(h->d_poses, B * sizeof(plf_pose_pair));
     ALLOC(h->d_dm, 2 * (size_t)max_lines * sizeof(plf_dmatch));
     // average of 64 cached candidates per map point; denser frames use the fallback kernel (PLF_MATCH_CAND_AVG: test hook)
     const char *avg_env = getenv("PLF_MATCH_CAND_AVG");
@@ -140,7 +147,8 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
 #undef ALLOC
     h->h_frames = (FrameDev *)calloc(B, sizeof(FrameDev));
     h->h_lframes = (LineFrameDev *)calloc(B, sizeof(LineFrameDev));
-    if (!h->h_frames || !h->h_lframes) { matcher_free(h); free(h); return PLF_E_NOMEM; }
+    h->h_poses = (plf_pose_pair *)calloc(B, sizeof(plf_pose_pair));
+    if (!h->h_frames || !h->h_lframes || !h->h_poses) { matcher_free(h); free(h); return PLF_E_NOMEM; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { matcher_free(h); free(h); return PLF_E_HIP; }
     (void)hipFuncSetAttribute((const void *)k_mp_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_points_slow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -159,6 +167,9 @@ extern "C" void plf_matcher_destroy(plf_matcher *h)
     matcher_free(h);
     free(h);
 }
+
+static int upload_frames(plf_matcher *h, const std::vector<FrameDev> &fd, hipStream_t s);
+static int upload_lframes(plf_matcher *h, const std::vector<LineFrameDev> &fd, hipStream_t s);
 
 static FrameDev make_frame(const plf_matcher *h, const plf_frame_view &v, int f)
 {
@@ -193,13 +204,7 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
         fd[f] = make_frame(h, frames[f], f);
         if (frames[f].n > maxn) maxn = frames[f].n;
     }
-    if (h->h_nframes != n_frames || memcmp(h->h_frames, fd.data(), sizeof(FrameDev) * n_frames) != 0) {
-        PLF_HIP_TRY(hipStreamSynchronize(s));  // a previous launch may still read the old table
-        memcpy(h->h_frames, fd.data(), sizeof(FrameDev) * n_frames);
-        h->h_nframes = n_frames;
-        PLF_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_frames, sizeof(FrameDev) * n_frames, hipMemcpyHostToDevice, s));
-        PLF_HIP_TRY(hipStreamSynchronize(s));
-    }
+    { const int urc = upload_frames(h, fd, s); if (urc != PLF_OK) return urc; }
     hipLaunchKernelGGL(k_build_grid, dim3(n_frames), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
     MapDev M;
     M.m = mp->m; M.proj_x = mp->proj_x; M.proj_y = mp->proj_y; M.proj_xr = mp->proj_xr; M.level = mp->level; M.view_cos = mp->view_cos;
@@ -299,32 +304,70 @@ extern "C" int plf_match_triangulation(plf_matcher *h, const plf_tri_view *v, co
     return PLF_OK;
 }
 
-static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last, const plf_pose_pair *pose, RelocDev RL,
-                                float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp, int32_t *nmatches, void *stream)
+// the frame table of the point matchers: uploaded only when it changed (the sync protects a launch that may still read the old one)
+static int upload_frames(plf_matcher *h, const std::vector<FrameDev> &fd, hipStream_t s)
 {
-    if (!h || !cur || !last || !pose || !match_of_kp || !nmatches || cur->n < 0 || cur->n > h->max_kp || last->n < 0 || last->n > h->max_kp ||
-        !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y) || !last->has_mappoint || (!RL.on && !last->outlier))
+    const int n = (int)fd.size();
+    if (h->h_nframes != n || memcmp(h->h_frames, fd.data(), sizeof(FrameDev) * n) != 0) {
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(h->h_frames, fd.data(), sizeof(FrameDev) * n);
+        h->h_nframes = n;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_frames, sizeof(FrameDev) * n, hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return PLF_OK;
+}
+
+static int upload_lframes(plf_matcher *h, const std::vector<LineFrameDev> &fd, hipStream_t s)
+{
+    const int n = (int)fd.size();
+    if (h->h_nlframes != n || memcmp(h->h_lframes, fd.data(), sizeof(LineFrameDev) * n) != 0) {
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(h->h_lframes, fd.data(), sizeof(LineFrameDev) * n);
+        h->h_nlframes = n;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_lframes, h->h_lframes, sizeof(LineFrameDev) * n, hipMemcpyHostToDevice, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return PLF_OK;
+}
+
+// n_frames current frames against ONE last frame / keyframe, every frame with its own pose (poses: host array, pose_step 0 = one shared pose)
+static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *frames, int32_t n_frames, const plf_lastframe_view *last, const plf_pose_pair *poses,
+                                int pose_step, RelocDev RL, float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp, int32_t kp_stride,
+                                int32_t *nmatches, void *stream)
+{
+    if (!h || !frames || !last || !poses || !match_of_kp || !nmatches || n_frames < 1 || n_frames > h->max_batch || last->n < 0 || last->n > h->max_kp ||
+        !last->has_mappoint || (!RL.on && !last->outlier))
         return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
-    FrameDev fd;
-    memset(&fd, 0, sizeof(fd));
-    fd = make_frame(h, *cur, 0);
-    if (h->h_nframes != 1 || memcmp(h->h_frames, &fd, sizeof(FrameDev)) != 0) {
+    std::vector<FrameDev> fd(n_frames);
+    int maxn = 1;
+    for (int f = 0; f < n_frames; f++) {
+        const plf_frame_view &v = frames[f];
+        if (v.n < 0 || v.n > h->max_kp || (n_frames > 1 && v.n > kp_stride) || !(v.max_x > v.min_x) || !(v.max_y > v.min_y)) return PLF_E_BADARG;
+        fd[f] = make_frame(h, v, f);
+        if (v.n > maxn) maxn = v.n;
+    }
+    int rc = upload_frames(h, fd, s);
+    if (rc != PLF_OK) return rc;
+    bool same = h->h_nposes == n_frames;
+    for (int f = 0; f < n_frames && same; f++) same = memcmp(&h->h_poses[f], &poses[(size_t)f * pose_step], sizeof(plf_pose_pair)) == 0;
+    if (!same) {
         PLF_HIP_TRY(hipStreamSynchronize(s));
-        memcpy(h->h_frames, &fd, sizeof(FrameDev));
-        h->h_nframes = 1;
-        PLF_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_frames, sizeof(FrameDev), hipMemcpyHostToDevice, s));
+        for (int f = 0; f < n_frames; f++) h->h_poses[f] = poses[(size_t)f * pose_step];
+        h->h_nposes = n_frames;
+        PLF_HIP_TRY(hipMemcpyAsync(h->d_poses, h->h_poses, sizeof(plf_pose_pair) * n_frames, hipMemcpyHostToDevice, s));
         PLF_HIP_TRY(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(k_build_grid, dim3(1), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
+    hipLaunchKernelGGL(k_build_grid, dim3(n_frames), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
     LastDev L;
     L.n = last->n; L.has_mp = last->has_mappoint; L.outlier = last->outlier; L.xw = last->world_pos; L.keys = last->keys; L.mp_desc = last->mp_desc;
     L.obs_positive = RL.on ? nullptr : last->obs_positive;   // (the relocalisation overload tests the pointer only)
-    const int kp_cap = ((cur->n > 0 ? cur->n : 1) + 63) & ~63;
-    hipLaunchKernelGGL(k_match_lastframe, dim3(1), dim3(256), (size_t)kp_cap * 8, s, fd, L, *pose, RL, th, mono, check_orientation, match_of_kp,
-                       nmatches, h->d_done, h->d_proj, kp_cap);
+    const int kp_cap = (maxn + 63) & ~63;
+    hipLaunchKernelGGL(k_match_lastframe, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, L, h->d_poses, RL, th, mono, check_orientation, match_of_kp,
+                       kp_stride, nmatches, h->d_done, h->d_proj, kp_cap, h->max_kp);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }
@@ -335,7 +378,16 @@ extern "C" int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view 
 {
     RelocDev RL;
     memset(&RL, 0, sizeof(RL));
-    return match_lastframe_impl(h, cur, last, pose, RL, th, mono, check_orientation, match_of_kp, nmatches, stream);
+    return match_lastframe_impl(h, cur, 1, last, pose, 0, RL, th, mono, check_orientation, match_of_kp, cur ? cur->n : 0, nmatches, stream);
+}
+
+extern "C" int plf_match_project_lastframe_batch(plf_matcher *h, const plf_frame_view *frames, int32_t n_frames, const plf_lastframe_view *last,
+                                                 const plf_pose_pair *poses, float th, int32_t mono, int32_t check_orientation, int32_t *match_of_kp,
+                                                 int32_t kp_stride, int32_t *nmatches, void *stream)
+{
+    RelocDev RL;
+    memset(&RL, 0, sizeof(RL));
+    return match_lastframe_impl(h, frames, n_frames, last, poses, 1, RL, th, mono, check_orientation, match_of_kp, kp_stride, nmatches, stream);
 }
 
 extern "C" int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *kf, const float *min_distance,
@@ -345,7 +397,7 @@ extern "C" int plf_match_project_keyframe(plf_matcher *h, const plf_frame_view *
     if (!min_distance || !max_distance || !(log_scale_factor > 0.f) || !cur || cur->nlevels < 1 || cur->nlevels > 64) return PLF_E_BADARG;
     RelocDev RL;
     RL.on = 1; RL.min_dist = min_distance; RL.max_dist = max_distance; RL.log_scale = log_scale_factor; RL.orb_dist = orb_dist;
-    return match_lastframe_impl(h, cur, kf, pose, RL, th, 1, check_orientation, match_of_kp, nmatches, stream);
+    return match_lastframe_impl(h, cur, 1, kf, pose, 0, RL, th, 1, check_orientation, match_of_kp, cur->n, nmatches, stream);
 }
 
 // upload the keyframe's view as frame 0 of the handle's table and build its cell CSR
@@ -563,7 +615,35 @@ extern "C" int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_des
     int P2 = 1;
     while (P2 < nlast) P2 <<= 1;
     hipLaunchKernelGGL(k_lines_lastframe, dim3(1), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_idx, h->d_knn_dist, nlast,
-                       last_has_mapline, match_of_line, nmatches, P2);
+                       last_has_mapline, match_of_line, nmatches, P2, 0, 0, (const LineFrameDev *)nullptr);
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_lines_lastframe_batch(plf_matcher *h, const uint8_t *last_desc, int32_t nlast, const uint8_t *last_has_mapline,
+                                               const plf_lineframe_view *frames, int32_t n_frames, int32_t *match_of_line, int32_t line_stride,
+                                               int32_t *nmatches, void *stream)
+{
+    if (!h || !last_desc || !last_has_mapline || !frames || !match_of_line || !nmatches || nlast > h->max_lines || n_frames < 1 || n_frames > h->max_batch)
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    if (nlast <= 0) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int) * n_frames, s)); return PLF_OK; }
+    std::vector<LineFrameDev> fd(n_frames);
+    memset(fd.data(), 0, sizeof(LineFrameDev) * n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        if (frames[f].n < 0 || frames[f].n > h->max_lines || frames[f].n > line_stride || !frames[f].desc) return PLF_E_BADARG;
+        fd[f].n = frames[f].n; fd[f].n_dev = frames[f].n_device; fd[f].lines = frames[f].lines_un; fd[f].desc = frames[f].desc; fd[f].scale_factors = frames[f].scale_factors;
+    }
+    const int rc = upload_lframes(h, fd, s);
+    if (rc != PLF_OK) return rc;
+    const int stride = 2 * h->max_lines;
+    hipLaunchKernelGGL(k_knn2_batch, dim3((nlast + 127) / 128, n_frames), dim3(128), 0, s, last_desc, nlast, h->d_lframes, h->d_knn_idx, h->d_knn_dist, stride);
+    int P2 = 1;
+    while (P2 < nlast) P2 <<= 1;
+    hipLaunchKernelGGL(k_lines_lastframe, dim3(n_frames), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_idx, h->d_knn_dist, nlast, last_has_mapline,
+                       match_of_line, nmatches, P2, stride, line_stride, h->d_lframes);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }
@@ -584,13 +664,7 @@ extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view 
         fd[f].n = frames[f].n; fd[f].n_dev = frames[f].n_device; fd[f].lines = frames[f].lines_un; fd[f].desc = frames[f].desc; fd[f].scale_factors = frames[f].scale_factors;
         if (frames[f].n > maxn) maxn = frames[f].n;
     }
-    if (h->h_nlframes != n_frames || memcmp(h->h_lframes, fd.data(), sizeof(LineFrameDev) * n_frames) != 0) {
-        PLF_HIP_TRY(hipStreamSynchronize(s));
-        memcpy(h->h_lframes, fd.data(), sizeof(LineFrameDev) * n_frames);
-        h->h_nlframes = n_frames;
-        PLF_HIP_TRY(hipMemcpyAsync(h->d_lframes, h->h_lframes, sizeof(LineFrameDev) * n_frames, hipMemcpyHostToDevice, s));
-        PLF_HIP_TRY(hipStreamSynchronize(s));
-    }
+    { const int urc = upload_lframes(h, fd, s); if (urc != PLF_OK) return urc; }
     MapLineDev M;
     M.m = ml->m; M.x1 = ml->x1; M.y1 = ml->y1; M.x2 = ml->x2; M.y2 = ml->y2; M.level = ml->level; M.view_cos = ml->view_cos;
     M.in_view = ml->in_view; M.desc = ml->desc;

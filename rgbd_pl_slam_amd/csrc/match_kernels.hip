@@ -397,10 +397,17 @@ struct LastDev {
 // and no uRight test, level window from MapPoint::PredictScale (so@0x8fc20), acceptance threshold ORBdist.
 struct RelocDev { int on; const float *min_dist, *max_dist; float log_scale; int orb_dist; };
 
-__global__ void __launch_bounds__(256) k_match_lastframe(FrameDev F, LastDev Lf, plf_pose_pair P, RelocDev RL, float th, int mono, int check_ori,
-                                                         int *__restrict__ match, int *__restrict__ nmatches, uint8_t *__restrict__ done,
-                                                         float4 *__restrict__ proj, int kp_cap)
+__global__ void __launch_bounds__(256) k_match_lastframe(const FrameDev *__restrict__ frames, LastDev Lf, const plf_pose_pair *__restrict__ poses, RelocDev RL,
+                                                         float th, int mono, int check_ori, int *__restrict__ match_all, int kp_stride,
+                                                         int *__restrict__ nmatches_all, uint8_t *__restrict__ done_all, float4 *__restrict__ proj_all, int kp_cap,
+                                                         int item_stride)
 {
+    // one block per current frame (blockIdx.x); every frame is matched against the same last frame / keyframe with its own pose
+    FrameDev F = frames[blockIdx.x];
+    const plf_pose_pair P = poses[blockIdx.x];
+    int *match = match_all + (size_t)blockIdx.x * kp_stride, *nmatches = nmatches_all + blockIdx.x;
+    uint8_t *done = done_all + (size_t)blockIdx.x * item_stride;
+    float4 *proj = proj_all + (size_t)blockIdx.x * item_stride;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *claim = (int *)smem, *owner = claim + kp_cap;
     __shared__ int s_left, s_acc, hist[HISTO_LENGTH], keepbin[3];
@@ -916,6 +923,46 @@ __global__ void __launch_bounds__(128) k_knn2(const uint8_t *__restrict__ q, int
     dist[2 * i] = d0; dist[2 * i + 1] = d1;
 }
 
+// the same brute-force 2-NN for a batch of current frames against ONE query set (the last frame's line descriptors): blockIdx.y = frame, the
+// frame's descriptors are staged through LDS in tiles of 128 so that every thread (= query) reads them as broadcasts
+struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const uint8_t *desc; const float *scale_factors; };
+__global__ void __launch_bounds__(128) k_knn2_batch(const uint8_t *__restrict__ q, int nq, const LineFrameDev *__restrict__ frames, int *__restrict__ idx_all,
+                                                    int *__restrict__ dist_all, int stride)
+{
+    __shared__ uint32_t tile[128][9];   // (+1: conflict-free fill)
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, t = threadIdx.x;
+    const uint8_t *tr = frames[f].desc;
+    int nt = frames[f].n;
+    if (frames[f].n_dev) nt = min(nt, *frames[f].n_dev);
+    uint32_t qd[8];
+    if (i < nq) {
+        const uint4 *qp = reinterpret_cast<const uint4 *>(q + 32 * (size_t)i);
+        const uint4 a = qp[0], b = qp[1];
+        qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+    }
+    int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1, i1 = -1;
+    for (int j0 = 0; j0 < nt; j0 += 128) {
+        const int m = min(128, nt - j0);
+        __syncthreads();
+        for (int k = t; k < m * 8; k += 128) tile[k >> 3][k & 7] = reinterpret_cast<const uint32_t *>(tr + 32 * (size_t)j0)[k];
+        __syncthreads();
+        if (i < nq)
+            for (int j = 0; j < m; j++) {
+                int d = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) d += __popc(qd[k] ^ tile[j][k]);
+                if (d < d1) {
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j0 + j; }
+                    else { d1 = d; i1 = j0 + j; }
+                }
+            }
+    }
+    if (i >= nq) return;
+    int *idx = idx_all + (size_t)f * stride, *dist = dist_all + (size_t)f * stride;
+    idx[2 * i] = i0; idx[2 * i + 1] = i1;
+    dist[2 * i] = d0; dist[2 * i + 1] = d1;
+}
+
 __global__ void __launch_bounds__(128) k_knn2_to_dmatch(const int *__restrict__ idx, const int *__restrict__ dist, int nq, plf_dmatch *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -944,10 +991,19 @@ __device__ void block_sort_floats(float *v, int n, int P2)
 }
 
 // Frame::lineDescriptorMAD + LSDmatcher::SearchByProjection(CurrentFrame, LastFrame); one block, nlast <= cap (power of two >= nlast)
-__global__ void __launch_bounds__(256) k_lines_lastframe(const int *__restrict__ idx, const int *__restrict__ dist, int nlast,
-                                                         const uint8_t *__restrict__ last_has_mapline, int *__restrict__ match_of_line,
-                                                         int *__restrict__ nmatches, int P2)
+__global__ void __launch_bounds__(256) k_lines_lastframe(const int *__restrict__ idx_all, const int *__restrict__ dist_all, int nlast,
+                                                         const uint8_t *__restrict__ last_has_mapline, int *__restrict__ match_all,
+                                                         int *__restrict__ nmatches_all, int P2, int knn_stride, int line_stride,
+                                                         const LineFrameDev *__restrict__ frames)
 {
+    // blockIdx.x = current frame of the batch (one frame: strides unused, ncur_* NULL)
+    const int *idx = idx_all + (size_t)blockIdx.x * knn_stride, *dist = dist_all + (size_t)blockIdx.x * knn_stride;
+    int *match_of_line = match_all + (size_t)blockIdx.x * line_stride, *nmatches = nmatches_all + blockIdx.x;
+    if (frames) {   // fewer than two current lines: knnMatch(k = 2) has no second neighbour, nothing is matched
+        int nc = frames[blockIdx.x].n;
+        if (frames[blockIdx.x].n_dev) nc = min(nc, *frames[blockIdx.x].n_dev);
+        if (nc < 2) { if (threadIdx.x == 0) *nmatches = 0; return; }
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *v = (float *)smem;
     __shared__ int s_cnt;
@@ -977,7 +1033,6 @@ __global__ void __launch_bounds__(256) k_lines_lastframe(const int *__restrict__
     if (t == 0) *nmatches = s_cnt;
 }
 
-struct LineFrameDev { int n; const int *n_dev; const plf_keyline *lines; const uint8_t *desc; const float *scale_factors; };
 struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };
 
 // Frame::GetLinesInArea test for line i

@@ -42,15 +42,58 @@ class Matcher:
         v.scale_factors = L.vp(scale_factors).value; v.nlevels = int(scale_factors.shape[0])
         return v
 
+    @staticmethod
+    def view_array(views, ctype=None):
+        """a list of views as one ctypes array (build it once and pass it to the batched calls instead of the list)"""
+        if isinstance(views, C.Array):
+            return views
+        ctype = ctype or type(views[0])
+        return (ctype * len(views))(*views)
+
+    @staticmethod
+    def last_view(last):
+        lv = L.LastFrameView()
+        lv.n = int(last["mp_desc"].shape[0])
+        lv.has_mappoint = L.vp(last["has_mappoint"]).value; lv.outlier = L.vp(last["outlier"]).value
+        lv.world_pos = L.vp(last["world_pos"]).value; lv.keys = L.vp(last["keys"]).value; lv.mp_desc = L.vp(last["mp_desc"]).value
+        lv.obs_positive = L.vp(last["obs_positive"]).value if last.get("obs_positive") is not None else None
+        return lv
+
+    @staticmethod
+    def pose_pair(pose):
+        pp = L.PosePair()
+        for name in ("Rcw", "tcw", "Rlw", "tlw"):
+            getattr(pp, name)[:] = np.asarray(pose[name], np.float32).ravel().tolist()
+        for name in ("fx", "fy", "cx", "cy", "bf", "b"):
+            setattr(pp, name, float(pose[name]))
+        return pp
+
+    def SearchByProjectionLastFrameBatch(self, frames, last, poses, th, mono, check_ori, match_of_kp, kp_stride, nmatches, stream=None):
+        """ORBmatcher::SearchByProjection(Cur, Last, th, bMono) for a batch of current frames (list / array of FrameView) against one last frame;
+        poses: list of pose dicts, or a prebuilt (PosePair * n) array"""
+        arr = self.view_array(frames, L.FrameView)
+        pa = poses if isinstance(poses, C.Array) else (L.PosePair * len(poses))(*[self.pose_pair(p) for p in poses])
+        lv = last if isinstance(last, L.LastFrameView) else self.last_view(last)
+        L.check(L.lib().plf_match_project_lastframe_batch(self._h, arr, len(arr), C.byref(lv), pa, C.c_float(th), int(mono), int(check_ori),
+                                                          L.vp(match_of_kp), int(kp_stride), L.vp(nmatches), C.c_void_p(stream) if stream else None),
+                "plf_match_project_lastframe_batch")
+
+    def SearchLinesLastFrameBatch(self, last_desc, last_has_mapline, frames, match_of_line, line_stride, nmatches, stream=None):
+        """LSDmatcher::SearchByProjection(Cur, Last) (BF kNN + MAD rule) for a batch of current frames (LineFrameView list / array)"""
+        arr = self.view_array(frames, L.LineFrameView)
+        L.check(L.lib().plf_match_lines_lastframe_batch(self._h, L.vp(last_desc), int(last_desc.shape[0]), L.vp(last_has_mapline), arr, len(arr),
+                                                        L.vp(match_of_line), int(line_stride), L.vp(nmatches), C.c_void_p(stream) if stream else None),
+                "plf_match_lines_lastframe_batch")
+
     def SearchByProjection(self, frames, mp, th, nnratio, match_of_kp, kp_stride, nmatches, stream=None):
         """frames: list of FrameView; mp: dict of device tensors (proj_x, proj_y, proj_xr, level, view_cos, in_view, desc[, obs_positive])"""
-        arr = (L.FrameView * len(frames))(*frames)
+        arr = self.view_array(frames, L.FrameView)
         m = L.MapPointView()
         m.m = int(mp["desc"].shape[0])
         for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos", "in_view", "desc"):
             setattr(m, k, L.vp(mp[k]).value)
         m.obs_positive = L.vp(mp["obs_positive"]).value if mp.get("obs_positive") is not None else None
-        L.check(L.lib().plf_match_project_points(self._h, arr, len(frames), C.byref(m), C.c_float(th), C.c_float(nnratio), L.vp(match_of_kp),
+        L.check(L.lib().plf_match_project_points(self._h, arr, len(arr), C.byref(m), C.c_float(th), C.c_float(nnratio), L.vp(match_of_kp),
                                                  int(kp_stride), L.vp(nmatches), C.c_void_p(stream) if stream else None),
                 "plf_match_project_points")
 
@@ -211,11 +254,11 @@ class Matcher:
                                          L.vp(nmatches), C.c_void_p(stream) if stream else None), "plf_match_bow_kf")
 
     def SearchLinesByProjection(self, frames, ml, th, nnratio, match_of_line, line_stride, nmatches, stream=None):
-        arr = (L.LineFrameView * len(frames))(*frames)
+        arr = self.view_array(frames, L.LineFrameView)
         m = L.MapLineView()
         m.m = int(ml["desc"].shape[0])
         for k in ("x1", "y1", "x2", "y2", "level", "view_cos", "in_view", "desc"):
             setattr(m, k, L.vp(ml[k]).value)
-        L.check(L.lib().plf_match_project_lines(self._h, arr, len(frames), C.byref(m), C.c_float(th), C.c_float(nnratio), L.vp(match_of_line),
+        L.check(L.lib().plf_match_project_lines(self._h, arr, len(arr), C.byref(m), C.c_float(th), C.c_float(nnratio), L.vp(match_of_line),
                                                 int(line_stride), L.vp(nmatches), C.c_void_p(stream) if stream else None),
                 "plf_match_project_lines")

@@ -47,3 +47,18 @@ def make_map_lines(kl, ldesc, M, seed, nlevels=8):
     d[~real] = rng.integers(0, 256, (int((~real).sum()), 32), dtype=np.uint8)
     return dict(x1=x1, y1=y1, x2=x2, y2=y2, level=rng.integers(0, 2, M).astype(np.int32), view_cos=rng.uniform(0.99, 1.0, M).astype(np.float32),
                 in_view=(rng.uniform(0, 1, M) < 0.9).astype(np.uint8), desc=d)
+
+
+def make_last_frame(kps, desc, seed, fx=525.0, fy=525.0, cx=319.5, cy=239.5, bf=40.0):
+    """a "last frame" whose map points reproject close to the key points `kps` under a small forward motion: the input of
+    ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono).  Returns (last dict of numpy arrays, pose dict)."""
+    rng = np.random.default_rng(seed)
+    n = len(kps)
+    z = rng.uniform(0.8, 4.0, n).astype(np.float32)
+    # last camera at the origin; current camera moved 2 cm forward and 1 cm sideways
+    xw = np.stack([(kps["x"] - cx) * z / fx, (kps["y"] - cy) * z / fy, z], 1).astype(np.float32)
+    pose = dict(Rcw=np.eye(3, dtype=np.float32), tcw=np.array([0.01, -0.005, -0.02], np.float32), Rlw=np.eye(3, dtype=np.float32),
+                tlw=np.zeros(3, np.float32), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, b=bf / fx)
+    last = dict(keys=kps.copy(), has_mappoint=(rng.uniform(0, 1, n) < 0.8).astype(np.uint8), outlier=(rng.uniform(0, 1, n) < 0.05).astype(np.uint8),
+                world_pos=xw, mp_desc=flip_bits(desc, rng, 20), obs_positive=np.ones(n, np.uint8))
+    return last, pose

@@ -5,7 +5,7 @@ Counter units: KB (rocprofv3 derived metrics).  See /opt/skills/guides/MI355X_MI
 import csv, glob, json, os, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-bargs = sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
+bargs = sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extras"]
 out = {"_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) of `python bench.py %s` on one MI355X; "
                "KB per launch as reported by rocprofv3.  MI355X_MICROARCH.md: FETCH_SIZE under-counts wide (16 B/lane) streaming reads by 2x on "
                "gfx950; k_lsd_regions2 issues 4-16-byte gathers, so no correction is applied to it; WRITE_SIZE is uncalibrated." % " ".join(bargs),
@@ -30,8 +30,12 @@ for i, a in enumerate(bargs):
     if a == "--batch":
         B = int(bargs[i + 1])
 out["frames_per_launch"] = B
-f = out["counters"]["FETCH_SIZE"].get("k_lsd_regions2", {}).get("per_launch_KB", 0.0)
-w = out["counters"]["WRITE_SIZE"].get("k_lsd_regions2", {}).get("per_launch_KB", 0.0)
-out["k_lsd_regions2"] = {"hbm_bytes_per_launch": int((f + w) * 1024), "fetch_KB": f, "write_KB": w}
+out["width"], out["height"] = 640, 480   # (bench.py --config 2)
+rk = [k for k in out["counters"]["FETCH_SIZE"] if k.startswith("k_lsd_regions")]
+rk = rk[0] if rk else "k_lsd_regions2"
+f = out["counters"]["FETCH_SIZE"].get(rk, {}).get("per_launch_KB", 0.0)
+w = out["counters"]["WRITE_SIZE"].get(rk, {}).get("per_launch_KB", 0.0)
+out["region_kernel"] = {"name": rk, "hbm_bytes_per_launch": int((f + w) * 1024), "fetch_KB": f, "write_KB": w}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "%s_pmc_traffic.json" % tag), "w"), indent=1)
-print(json.dumps(out["k_lsd_regions2"]))
+print(json.dumps(out["region_kernel"]))
