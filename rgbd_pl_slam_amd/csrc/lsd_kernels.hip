@@ -128,8 +128,11 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
         ang[o] = deg;
         const double ad = (double)deg * DEG2RAD_D;
         const double af = (double)(float)ad;
-        cs[o] = make_double2(cos(af), sin(af));
-        cs0[o] = make_float2((float)cos(ad), (float)sin(ad));
+        double sf, cf, sd, cd;   // (sincos: one argument reduction for the pair)
+        sincos(af, &sf, &cf);
+        sincos(ad, &sd, &cd);
+        cs[o] = make_double2(cf, sf);
+        cs0[o] = make_float2((float)cd, (float)sd);
     }
 }
 
@@ -227,10 +230,13 @@ __device__ __forceinline__ uint32_t ang_load(const RegCtx &C, int a)
     return __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float ang_value(uint32_t w) { return __uint_as_float(w & 0x7FFFFFFFu); }   // of a defined pixel
-__device__ __forceinline__ void used_set(RegCtx &C, int a)
+// w = the pixel's angle word as this wave last read it (sign clear: it was a candidate).  The wave that owns the frame is the only writer of its
+// map, so "set the sign bit" is a plain 4-byte store of the known word -- no read-modify-write at the L2 -- and per-location program order keeps
+// its own later loads coherent with it (relaxed device-scope store / loads).
+__device__ __forceinline__ void used_set(RegCtx &C, int a, uint32_t w)
 {
     if (C.use_bm) { __hip_atomic_fetch_or(&C.bm[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
-    __hip_atomic_fetch_or(&C.ang[a], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&C.ang[a], w | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void used_clr(RegCtx &C, int a)
 {
@@ -327,7 +333,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     float sumdx = cs0.x, sumdy = cs0.y;   // float(cos(reg_angle)), float(sin(reg_angle))
     if (lane == 0) {
         rxy_put(C, 0, (uint32_t)sx | ((uint32_t)sy << 16));
-        used_set(C, sy * C.W + sx);
+        used_set(C, sy * C.W + sx, __float_as_uint(deg0));
     }
     CBAR();
     int n = 1, i = 0;
@@ -387,7 +393,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             if (k < 0) break;
             CNT(9, 1);
             if (lane == k) {
-                used_set(C, cur.a);
+                used_set(C, cur.a, cur.w);
                 rxy_put(C, n, cur.xy);
             }
             const double cc = readlane_d(cur.csx, k), ss = readlane_d(cur.csy, k);

@@ -40,7 +40,9 @@ __global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, 
 struct TriDev { const plf_keypoint *keys1, *keys2; const float *uright1, *uright2, *scale2, *sigma2_2; float F[9]; float ex, ey; int only_stereo; };
 __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *, TriDev);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
-__global__ void k_match_lastframe(const FrameDev *, LastDev, const plf_pose_pair *, RelocDev, float, int, int, int *, int, int *, uint8_t *, float4 *, int, int);
+__global__ void k_match_lastframe(const FrameDev *, LastDev, const plf_pose_pair *, RelocDev, float, int, int, int *, int, int *, uint8_t *, float4 *, int, int, const int *);
+__global__ void k_lf_candidates(const FrameDev *, LastDev, const plf_pose_pair *, float, int, const int *, int, uint8_t *, uint32_t *, int2 *, int, int, int *, int *);
+__global__ void k_lf_rounds(const FrameDev *, LastDev, int, int *, int, int *, const uint8_t *, int, int, const uint32_t *, const int2 *, int, int, const int *);
 __global__ void k_project_kf(FrameDev, Pts3Dev, ProjKf, float, int *, int *, int *);
 __global__ void k_sim3_agree(const int *, int, const int *, int, int *, int *);
 __global__ void k_project_kf_greedy(FrameDev, Pts3Dev, ProjKf, float, int *, int *, uint8_t *, float4 *, int);
@@ -153,6 +155,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     (void)hipFuncSetAttribute((const void *)k_mp_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_points_slow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lf_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();  // the attribute call is advisory; never leave a sticky error behind for other HIP users
     *out = h;
@@ -366,8 +369,20 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *frames, in
     L.n = last->n; L.has_mp = last->has_mappoint; L.outlier = last->outlier; L.xw = last->world_pos; L.keys = last->keys; L.mp_desc = last->mp_desc;
     L.obs_positive = RL.on ? nullptr : last->obs_positive;   // (the relocalisation overload tests the pointer only)
     const int kp_cap = (maxn + 63) & ~63;
+    // batches of the motion-model overload: cached candidate lists + conflict-free rounds (k_lf_*); key point / last-frame indices must fit 16 bits,
+    // the span table one row per last-frame point, the lists the LDS.  Frames that overflow the pool, and everything else, use k_match_lastframe.
+    const int item_cap = (last->n + 1) & ~1;
+    const size_t lds_fast = (size_t)kp_cap * 8 + 3 * (size_t)item_cap * sizeof(uint16_t);
+    const bool fast = !RL.on && n_frames > 1 && maxn <= 65535 && last->n <= 65534 && last->n <= h->max_mp && last->n > 0 && lds_fast <= 150 * 1024;
+    if (fast) {
+        PLF_HIP_TRY(hipMemsetAsync(h->d_overflow, 0, 2 * (size_t)h->max_batch * sizeof(int), s));
+        hipLaunchKernelGGL(k_lf_candidates, dim3((last->n + 255) / 256, n_frames), dim3(256), 0, s, h->d_frames, L, h->d_poses, th, mono, match_of_kp, kp_stride,
+                           h->d_done, h->d_cand, (int2 *)h->d_cand_off, h->cand_cap, h->max_mp, h->d_overflow, h->d_overflow + h->max_batch);
+        hipLaunchKernelGGL(k_lf_rounds, dim3(n_frames), dim3(256), lds_fast, s, h->d_frames, L, check_orientation, match_of_kp, kp_stride, nmatches, h->d_done,
+                           kp_cap, item_cap, h->d_cand, (const int2 *)h->d_cand_off, h->cand_cap, h->max_mp, h->d_overflow);
+    }
     hipLaunchKernelGGL(k_match_lastframe, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, L, h->d_poses, RL, th, mono, check_orientation, match_of_kp,
-                       kp_stride, nmatches, h->d_done, h->d_proj, kp_cap, h->max_kp);
+                       kp_stride, nmatches, h->d_done, h->d_proj, kp_cap, h->max_kp, fast ? h->d_overflow : (const int *)nullptr);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

@@ -400,9 +400,10 @@ struct RelocDev { int on; const float *min_dist, *max_dist; float log_scale; int
 __global__ void __launch_bounds__(256) k_match_lastframe(const FrameDev *__restrict__ frames, LastDev Lf, const plf_pose_pair *__restrict__ poses, RelocDev RL,
                                                          float th, int mono, int check_ori, int *__restrict__ match_all, int kp_stride,
                                                          int *__restrict__ nmatches_all, uint8_t *__restrict__ done_all, float4 *__restrict__ proj_all, int kp_cap,
-                                                         int item_stride)
+                                                         int item_stride, const int *__restrict__ overflow)
 {
     // one block per current frame (blockIdx.x); every frame is matched against the same last frame / keyframe with its own pose
+    if (overflow && !overflow[blockIdx.x]) return;   // batched calls: this kernel is the fallback for frames k_lf_candidates could not cache
     FrameDev F = frames[blockIdx.x];
     const plf_pose_pair P = poses[blockIdx.x];
     int *match = match_all + (size_t)blockIdx.x * kp_stride, *nmatches = nmatches_all + blockIdx.x;
@@ -544,6 +545,216 @@ __global__ void __launch_bounds__(256) k_match_lastframe(const FrameDev *__restr
     for (int k = t; k < F.n; k += T) match[k] = claim[k];
     if (t == 0) *nmatches = s_acc;
 #undef KP_FREE
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path of the motion-model search for batches (plf_match_project_lastframe_batch): the scheme of k_mp_candidates / k_mp_rounds.
+//   k_lf_candidates   one thread per (frame, last-frame point): projection with the frame's pose, cell window, level window, uRight test and the
+//                     Hamming distance of every admissible key point, cached as (index | distance << 16) in the reference's candidate order
+//   k_lf_rounds       one block per frame: the greedy loop in conflict-free rounds on the cached lists.  This overload keeps the BEST distance only
+//                     (no ratio test), so a point's outcome is decided by its best still-available candidate alone: it is final as soon as no
+//                     unfinished EARLIER point lists that key point (owner[best] == i).  Then the rotation histogram and its per-assignment cull.
+// Frames whose lists overflow the pool are left to k_match_lastframe (gate: overflow[f]).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lf_candidates(const FrameDev *__restrict__ frames, LastDev Lf, const plf_pose_pair *__restrict__ poses, float th, int mono,
+                                                       const int *__restrict__ match_all, int kp_stride, uint8_t *__restrict__ done_all,
+                                                       uint32_t *__restrict__ cand_all, int2 *__restrict__ span_all, int cand_cap, int item_stride,
+                                                       int *__restrict__ overflow, int *__restrict__ total)
+{
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    FrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    const plf_pose_pair P = poses[f];
+    const int *claim = match_all + (size_t)f * kp_stride;   // occupancy before this call
+    uint32_t *cand = cand_all + (size_t)f * cand_cap;
+    float twc[3], tlc[3];
+    for (int k = 0; k < 3; k++)
+        twc[k] = (float)(-((double)P.Rcw[k] * P.tcw[0] + (double)P.Rcw[3 + k] * P.tcw[1] + (double)P.Rcw[6 + k] * P.tcw[2]));
+    for (int k = 0; k < 3; k++) tlc[k] = P.Rlw[k * 3] * twc[0] + P.Rlw[k * 3 + 1] * twc[1] + P.Rlw[k * 3 + 2] * twc[2] + P.tlw[k];
+    const bool bForward = tlc[2] > P.b && !mono, bBackward = -tlc[2] > P.b && !mono;
+    const bool in = i < Lf.n;
+    bool act = in && Lf.has_mp[i] && !Lf.outlier[i];
+    float u = 0.f, v = 0.f, invzc = 0.f, rad = 0.f;
+    int oct = 0, ub = 0;
+    CellWin w;
+    w.ok = false;
+    if (act) {
+        const float *xw = Lf.xw + 3 * (size_t)i;
+        const float xc = P.Rcw[0] * xw[0] + P.Rcw[1] * xw[1] + P.Rcw[2] * xw[2] + P.tcw[0];
+        const float yc = P.Rcw[3] * xw[0] + P.Rcw[4] * xw[1] + P.Rcw[5] * xw[2] + P.tcw[1];
+        const float zc = P.Rcw[6] * xw[0] + P.Rcw[7] * xw[1] + P.Rcw[8] * xw[2] + P.tcw[2];
+        invzc = (float)(1.0 / (double)zc);
+        if (invzc < 0) act = false;
+        u = fmaf(P.fx * xc, invzc, P.cx); v = fmaf(P.fy * yc, invzc, P.cy);   // FMA contractions of the binary: so@0x81cba, so@0x81cd9
+        if (u < F.min_x || u > F.max_x) act = false;
+        if (v < F.min_y || v > F.max_y) act = false;
+        if (act) {
+            oct = Lf.keys[i].octave;
+            rad = th * F.scale_factors[oct];
+            w = cell_window(F, u, v, rad);
+            if (w.ok)
+                for (int ix = w.x0; ix <= w.x1; ix++) ub += F.cell_start[ix * GRID_ROWS + w.y1 + 1] - F.cell_start[ix * GRID_ROWS + w.y0];
+        }
+    }
+    const int excl = plf_wave_excl_scan(ub), wsum = plf_wave_sum(ub);
+    int base = 0;
+    if (wsum > 0) {
+        if (plf_lane() == 0) base = atomicAdd(&total[f], wsum);
+        base = __shfl(base, 0, 64);
+    }
+    const bool fits = base + wsum <= cand_cap;
+    if (!fits && plf_lane() == 0) overflow[f] = 1;
+    if (!in) return;
+    const int o0 = base + excl;
+    int o = o0;
+    if (ub > 0 && fits) {
+        const int minL = bForward ? oct : (bBackward ? 0 : oct - 1), maxL = bForward ? -1 : (bBackward ? oct : oct + 1);
+        const bool chk = (minL > 0) || (maxL >= 0);
+        const uint4 *dp = reinterpret_cast<const uint4 *>(Lf.mp_desc + (size_t)i * 32);
+        const uint4 d0 = dp[0], d1 = dp[1];
+        const float ur = fmaf(-P.bf, invzc, u);   // so@0x81eb5
+        for (int ix = w.x0; ix <= w.x1; ix++) {
+            const int j1 = F.cell_start[ix * GRID_ROWS + w.y1 + 1];
+            for (int j = F.cell_start[ix * GRID_ROWS + w.y0]; j < j1; j++) {
+                const float4 e = F.cell_kp[j];
+                const int ko = __float_as_int(e.z), idx = __float_as_int(e.w);
+                if (chk) {
+                    if (ko < minL) continue;
+                    if (maxL >= 0 && ko > maxL) continue;
+                }
+                if (!(fabsf(e.x - u) < rad && fabsf(e.y - v) < rad)) continue;
+                if (blocked(claim, idx, Lf.obs_positive)) continue;
+                if (F.uright) { const float urr = F.uright[idx]; if (urr > 0 && fabsf(ur - urr) > rad) continue; }
+                const uint4 *kp = reinterpret_cast<const uint4 *>(F.desc + (size_t)idx * 32);
+                const uint4 k0 = kp[0], k1 = kp[1];
+                const int dist = __popc(d0.x ^ k0.x) + __popc(d0.y ^ k0.y) + __popc(d0.z ^ k0.z) + __popc(d0.w ^ k0.w) + __popc(d1.x ^ k1.x) +
+                                 __popc(d1.y ^ k1.y) + __popc(d1.z ^ k1.z) + __popc(d1.w ^ k1.w);
+                cand[o++] = (uint32_t)idx | ((uint32_t)dist << 16);
+            }
+        }
+    }
+    span_all[(size_t)f * item_stride + i] = make_int2(o0, o - o0);
+    done_all[(size_t)f * item_stride + i] = (o > o0) ? 0 : 1;
+}
+
+// LDS: claim[kp_cap], owner[kp_cap] (int); la, lb (unfinished points) and assign (key point of a finished point, 0xFFFF none): uint16[item_cap] each
+__global__ void __launch_bounds__(256) k_lf_rounds(const FrameDev *__restrict__ frames, LastDev Lf, int check_ori, int *__restrict__ match_all, int kp_stride,
+                                                   int *__restrict__ nmatches, const uint8_t *__restrict__ done_all, int kp_cap, int item_cap,
+                                                   const uint32_t *__restrict__ cand_all, const int2 *__restrict__ span_all, int cand_cap, int item_stride,
+                                                   const int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + kp_cap;
+    uint16_t *la = (uint16_t *)(owner + kp_cap), *lb = la + item_cap, *assign = lb + item_cap;
+    __shared__ int s_n[2], s_acc, hist[HISTO_LENGTH], keepbin[3];
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x, lane = plf_lane();
+    if (overflow[f]) return;
+    FrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int *match = match_all + (size_t)f * kp_stride;
+    const uint8_t *done = done_all + (size_t)f * item_stride;
+    const uint32_t *cand = cand_all + (size_t)f * cand_cap;
+    const int2 *span = span_all + (size_t)f * item_stride;
+    const uint8_t *obs = Lf.obs_positive;
+    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int i = t; i < Lf.n; i += T) assign[i] = 0xFFFFu;
+    if (t < HISTO_LENGTH) hist[t] = 0;
+    if (t == 0) { s_acc = 0; s_n[0] = 0; s_n[1] = 0; }
+    __syncthreads();
+    for (int m0 = 0; m0 < Lf.n; m0 += T) {
+        const int m = m0 + t;
+        const bool un = m < Lf.n && !done[m];
+        const unsigned long long mask = __ballot(un);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&s_n[0], __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (un) la[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)m;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round <= Lf.n; round++) {
+        const int nact = s_n[cur];
+        if (nact == 0) break;
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        __syncthreads();
+        for (int q = t; q < nact; q += T) {
+            const int i = la[q];
+            const int2 sp = span[i];
+            for (int j = sp.x; j < sp.x + sp.y; j++) {
+                const int idx = (int)(cand[j] & 0xFFFF);
+                if (!blocked(claim, idx, obs)) atomicMin(&owner[idx], i);
+            }
+        }
+        __syncthreads();
+        for (int q0 = 0; q0 < nact; q0 += T) {
+            const int q = q0 + t;
+            bool keep = false;
+            int i = 0;
+            if (q < nact) {
+                i = la[q];
+                const int2 sp = span[i];
+                int bestDist = 256, bestIdx = -1;
+                for (int j = sp.x; j < sp.x + sp.y; j++) {
+                    const uint32_t e = cand[j];
+                    const int idx = (int)(e & 0xFFFF);
+                    if (blocked(claim, idx, obs)) continue;
+                    const int dist = (int)(e >> 16);
+                    if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+                }
+                const bool safe = bestIdx < 0 || owner[bestIdx] == i;
+                keep = !safe;
+                if (safe && bestDist <= TH_HIGH) {
+                    claim[bestIdx] = i;   // only this point can touch bestIdx in this round
+                    assign[i] = (uint16_t)bestIdx;
+                    atomicAdd(&s_acc, 1);
+                    if (check_ori) {
+                        float rot = Lf.keys[i].angle - F.keys[bestIdx].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * (1.0f / 12.0f));  // this binary: HISTO_LENGTH / 360 (so@0x829b5)
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        atomicAdd(&hist[bin], 1);
+                    }
+                }
+            }
+            const unsigned long long mask = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&s_n[cur ^ 1], __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (keep) lb[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
+        __syncthreads();
+        if (t == 0) s_n[cur] = 0;
+        uint16_t *tmp = la; la = lb; lb = tmp;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (check_ori) {
+        if (t == 0) {  // ComputeThreeMaxima (so@0x823eb)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int b = 0; b < HISTO_LENGTH; b++) {
+                const int sz = hist[b];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = b; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = b; }
+                else if (sz > max3) { max3 = sz; i3 = b; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            keepbin[0] = i1; keepbin[1] = i2; keepbin[2] = i3;
+        }
+        __syncthreads();
+        for (int i = t; i < Lf.n; i += T) {   // per ASSIGNMENT, as the reference's rotHist entries
+            const int k = assign[i];
+            if (k == 0xFFFF) continue;
+            float rot = Lf.keys[i].angle - F.keys[k].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / 12.0f));
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { claim[k] = -1; atomicSub(&s_acc, 1); }
+        }
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) nmatches[f] = s_acc;
 }
 
 // ------------------------------------------------------------------------------------------------
