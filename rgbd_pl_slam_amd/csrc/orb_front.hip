@@ -1,0 +1,389 @@
+// orb_front.hip -- the fused ORB front pass for gfx950: ONE tiled kernel per pyramid level does what the reference spreads over
+//   ORBextractor::ComputePyramid          (include/ORBextractor.h:89, so@0x70430: cv::resize INTER_LINEAR from the previous level + copyMakeBorder)
+//   the 815 cv::FAST cell calls of ComputeKeyPointsOctTree (:90, so@0x75fa0: score, per-cell threshold / retry, 3x3 NMS)
+//   GaussianBlur(7x7, sigma 2) of operator() (so@0x77487)
+// A 256-thread workgroup owns a tile of 2 x 2 FAST cells of one level of one frame.  The level pixels of the tile (+ 3-pixel halo) are produced
+// ONCE into LDS -- resized from the previous level's plane (itself staged through LDS with coalesced loads) or copied from the input for level 0 --
+// and everything else is computed from that LDS tile before it leaves the CU:
+//   * the tile's part of the padded pyramid plane (mvImagePyramid layout, REFLECT_101 border included) -- the only copy the later stages need
+//     (IC_Angle reads it, the next level is resized from it);
+//   * the 7x7 blur (8-bit fixed-point separable path, exact integer sums, OpenCV 3.3's column rounding), row sums as uint16 in LDS;
+//   * the FAST-9/16 score, in two phases: a cheap necessary test on every pixel (two ADJACENT compass points of the ring must both be brighter
+//     or both darker by the minimum threshold: every 9-arc contains such a pair), survivors compacted with wave ballots into an LDS list, and the
+//     full cornerScore only for them, densely packed over the lanes;
+//   * per cell (one wave each): threshold iniThFAST, retry with minThFAST when the cell stays empty, strict 3x3 non-maximum suppression inside
+//     the cell's computed region, raster-ordered emission into the level's candidate pool -- exactly what k_fast_cells did on the score plane.
+// The score never reaches HBM, the pyramid is written once and read once (by the next level), the blurred plane is written once.
+// Cell geometry: cell (cx, cy) of a level has the sub-image x0 = 16 + cx * wCell, width min(x0 + wCell + 6, w - 16) - x0; cv::FAST computes
+// the sub-image minus a 3-pixel frame, so the computed regions of neighbouring cells abut: [19 + cx * wCell, 19 + (cx + 1) * wCell).
+#include "plf_common.h"
+#include "orb_geom.h"
+
+typedef uint32_t __attribute__((aligned(1))) plf_u32u;
+
+// cornerScore<16> of cv::FAST (largest threshold for which the pixel is still a corner) minus 1, clamped at 0; d[k] = I_p - I_ring[k]
+__device__ __forceinline__ int orb_fast_score(const int d[16], int t)
+{
+    bool br = true, dk = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        br = br && (d[k] > t || d[k + 8] > t);
+        dk = dk && (d[k] < -t || d[k + 8] < -t);
+    }
+    if (!br && !dk) return 0;
+    int m3[16], M3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        m3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
+        M3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+    }
+    int sb = -256, sd = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        sb = max(sb, min(m3[k], min(m3[(k + 3) & 15], m3[(k + 6) & 15])));
+        sd = min(sd, max(M3[k], max(M3[(k + 3) & 15], M3[(k + 6) & 15])));
+    }
+    const int s = max(sb, -sd) - 1;
+    return s < 0 ? 0 : s;
+}
+
+struct __attribute__((aligned(8))) OrbColTab { uint32_t sel, coef; };   // one tile column of the resize: v_perm selector of its two source bytes inside
+                                                                         // the group's 8-byte window (bytes 0 and 2; 1 and 3 = zero), coefficients as short2
+struct __attribute__((aligned(8))) OrbRowTab { short off, nxt, c0, c1; };   // one tile row: the two source rows inside the staged tile, coefficients
+typedef short plf_s2v __attribute__((ext_vector_type(2)));
+
+// byte k (0..11) of the 12 bytes held in three dwords
+#define OF_BYTE(A, B, C, k) ((int)((((k) < 4 ? (A) : (k) < 8 ? (B) : (C)) >> (8 * ((k) & 3))) & 0xFFu))
+
+// Thread layout of the pixel phases: 8 rows x 32 groups of 4 tile columns per pass (tid >> 5, tid & 31): no integer division, LDS accessed as
+// aligned dwords.  Tile column c <-> level x = ex0 + c with ex0 = 4 * floor(xs / 4) - 4, so groups of 4 columns are 4-aligned in the level image
+// too (aligned stores to the blurred plane).
+#define OF_NT 512   // threads per tile
+__global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__ in, ptrdiff_t in_pitch, ptrdiff_t in_fstride, uint8_t *__restrict__ pyr,
+                                                   uint8_t *__restrict__ blur, int l, const int *__restrict__ xofs, const short2 *__restrict__ xa,
+                                                   const int *__restrict__ yofs, const short2 *__restrict__ yb, const int4 *__restrict__ cells,
+                                                   int2 *__restrict__ cellinfo, uint2 *__restrict__ pool, int *__restrict__ poolcnt,
+                                                   int *__restrict__ status, OrbGeom g, int4 taps)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_nlist;
+    __shared__ unsigned long long s_mask[4][64][2];   // per cell of the tile, per row of its computed region: NMS maxima >= iniTh / >= minTh
+    const OrbLevel &L = g.lv[l];
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const int trow = tid >> 5, tc4 = (tid & 31) * 4;
+    constexpr int NR = OF_NT / 32;   // tile rows per pass of the pixel phases
+    const int tx = (int)blockIdx.x % L.tcx, ty = (int)blockIdx.x / L.tcx;
+    const int W = L.w, H = L.h;
+    // ---- tile geometry
+    const int cx0 = 2 * tx, cx1 = min(cx0 + 2, L.ncx), cy0 = 2 * ty, cy1 = min(cy0 + 2, L.ncy);
+    const int rx0 = PLF_EDGE + cx0 * L.wCell, rx1 = cx1 == L.ncx ? L.rex : PLF_EDGE + cx1 * L.wCell;   // bounding box of the cells' computed regions
+    const int ry0 = PLF_EDGE + cy0 * L.hCell, ry1 = cy1 == L.ncy ? L.rey : PLF_EDGE + cy1 * L.hCell;
+    const int xm = cx1 - cx0 == 2 ? rx0 + L.wCell : rx1, ym = cy1 - cy0 == 2 ? ry0 + L.hCell : ry1;   // where the second cell column / row starts
+    const int xs = tx == 0 ? 0 : rx0, xe = tx == L.tcx - 1 ? W : rx1;                                   // owned part of the level image
+    const int ys = ty == 0 ? 0 : ry0, ye = ty == L.tcy - 1 ? H : ry1;
+    const int ex0 = (xs & ~3) - 4, EW = ((xe - 1) & ~3) + 8 - ex0;                                     // tile columns: owned + halo, 4-aligned
+    const int ey0 = ys - 3, EH = ye - ys + 6;                                                          // tile rows: owned + 3-row halo
+    const int PW = g.lds_pw;
+    uint8_t *P = smem;
+    uint8_t *SRC = smem + g.lds_off_a;
+    uint16_t *LIST = reinterpret_cast<uint16_t *>(smem + g.lds_off_a);   // FAST survivors (the staged source is dead by then)
+    uint8_t *S = smem + g.lds_off_s;
+    OrbColTab *XT = reinterpret_cast<OrbColTab *>(smem + g.lds_off_tab);
+    OrbRowTab *YT = reinterpret_cast<OrbRowTab *>(XT + PW);
+    short *GM = reinterpret_cast<short *>(YT + g.lds_eh);   // per column group: first source byte of its window (negative: -1 - first, window wider than 8)
+    if (tid == 0) s_nlist = 0;
+    for (int i = tid; i < 4 * 64 * 2; i += OF_NT) (&s_mask[0][0][0])[i] = 0ull;
+    // ---- 1. the level pixels of the tile
+    if (l == 0) {
+        const uint8_t *img = in + (size_t)f * in_fstride;
+        for (int ey = trow; ey < EH; ey += NR) {
+            const uint8_t *row = img + (size_t)plf_reflect101(ey0 + ey, H) * in_pitch;
+            for (int c4 = tc4; c4 < EW; c4 += 128) {
+                const int x = ex0 + c4;
+                uint32_t v;
+                if (x >= 0 && x + 3 < W) v = *(const plf_u32u *)(row + x);
+                else {
+                    v = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v |= (uint32_t)row[plf_reflect101(x + j, W)] << (8 * j);
+                }
+                *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = v;
+            }
+        }
+    } else {
+        const OrbLevel &SL = g.lv[l - 1];
+        const int SPW = g.lds_spw;
+        // level coordinates the tile needs (mirrored halo coordinates fall inside this range), and the source rectangle behind them
+        const int lx_lo = max(ex0, 0), lx_hi = min(ex0 + EW - 1, W - 1), ly_lo = max(ey0, 0), ly_hi = min(ey0 + EH - 1, H - 1);
+        const int sx_lo = xofs[L.tabx_off + lx_lo] & ~3, sx_hi = min(xofs[L.tabx_off + lx_hi] + 1, SL.w - 1);
+        const int sy_lo = min(max(yofs[L.taby_off + ly_lo], 0), SL.h - 1), sy_hi = min(max(yofs[L.taby_off + ly_hi] + 1, 0), SL.h - 1);
+        const int SWt = sx_hi - sx_lo + 1, SHt = sy_hi - sy_lo + 1;
+        const uint8_t *src = pyr + (size_t)f * g.pyr_stride + SL.plane_off + (size_t)PLF_EDGE * SL.ppitch + PLF_EDGE;
+        for (int r = trow; r < SHt; r += NR)
+            for (int c4 = tc4; c4 < SWt + 8; c4 += 128)   // (+8: the 12-byte windows below may read past the last needed byte; the padded plane has them)
+                *reinterpret_cast<uint32_t *>(SRC + r * SPW + c4) = *(const plf_u32u *)(src + (size_t)(sy_lo + r) * SL.ppitch + sx_lo + c4);
+        const int ngrp = EW >> 2;
+        for (int i = tid; i < ngrp + EH; i += OF_NT) {
+            if (i < ngrp) {   // one column group: its 4 table entries relative to the group's first source byte
+                int off[4], nxt[4];
+                uint32_t cf[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int X = plf_reflect101(ex0 + 4 * i + j, W);
+                    const int sx = xofs[L.tabx_off + X];
+                    const short2 a = xa[L.tabx_off + X];
+                    off[j] = sx - sx_lo; nxt[j] = min(sx + 1, SL.w - 1) - sx_lo;
+                    cf[j] = (uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16);
+                }
+                const int mn = min(min(off[0], off[1]), min(off[2], off[3])), mx = max(max(nxt[0], nxt[1]), max(nxt[2], nxt[3]));
+                const bool wide = mx - mn > 7;
+                GM[i] = (short)(wide ? -1 - mn : mn);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    OrbColTab t;
+                    t.coef = cf[j];
+                    t.sel = wide ? ((uint32_t)off[j] | ((uint32_t)nxt[j] << 16)) : ((uint32_t)(off[j] - mn) | 0x0C000C00u | ((uint32_t)(nxt[j] - mn) << 16));
+                    XT[4 * i + j] = t;
+                }
+            } else {
+                const int Y = plf_reflect101(ey0 + (i - ngrp), H);
+                const int sy = yofs[L.taby_off + Y];
+                const short2 b = yb[L.taby_off + Y];
+                OrbRowTab t;
+                t.off = (short)(min(max(sy, 0), SL.h - 1) - sy_lo); t.nxt = (short)(min(max(sy + 1, 0), SL.h - 1) - sy_lo); t.c0 = b.x; t.c1 = b.y;
+                YT[i - ngrp] = t;
+            }
+        }
+        __syncthreads();
+        // cv::resize INTER_LINEAR 8UC1 (OpenCV 3.3): dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2, 11-bit coefficients.
+        // 4 outputs per thread: per source row one 8-byte window (three aligned LDS dwords, v_alignbyte), per output v_perm picks its two
+        // bytes as int16 lanes and v_dot2 multiplies them with the (a0, a1) pair
+        for (int ey = trow; ey < EH; ey += NR) {
+            const OrbRowTab ty_ = YT[ey];
+            const uint8_t *r0 = SRC + ty_.off * SPW, *r1 = SRC + ty_.nxt * SPW;
+            for (int c4 = tc4; c4 < EW; c4 += 128) {
+                OrbColTab t[4];
+                *reinterpret_cast<uint4 *>(&t[0]) = *reinterpret_cast<const uint4 *>(&XT[c4]);
+                *reinterpret_cast<uint4 *>(&t[2]) = *reinterpret_cast<const uint4 *>(&XT[c4 + 2]);
+                const int gm = GM[c4 >> 2];
+                uint32_t out = 0;
+                if (gm >= 0) {
+                    const int base = gm & ~3, sh = gm & 3;
+                    const uint32_t a0 = *reinterpret_cast<const uint32_t *>(r0 + base), a1 = *reinterpret_cast<const uint32_t *>(r0 + base + 4),
+                                   a2 = *reinterpret_cast<const uint32_t *>(r0 + base + 8);
+                    const uint32_t b0 = *reinterpret_cast<const uint32_t *>(r1 + base), b1 = *reinterpret_cast<const uint32_t *>(r1 + base + 4),
+                                   b2 = *reinterpret_cast<const uint32_t *>(r1 + base + 8);
+                    const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, sh), ahi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+                    const uint32_t blo = __builtin_amdgcn_alignbyte(b1, b0, sh), bhi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const plf_s2v cf = __builtin_bit_cast(plf_s2v, t[j].coef);
+                        const int s0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm(ahi, alo, t[j].sel)), cf, 0, false);
+                        const int s1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm(bhi, blo, t[j].sel)), cf, 0, false);
+                        out |= (uint32_t)(((((ty_.c0 * (s0 >> 4)) >> 16) + ((ty_.c1 * (s1 >> 4)) >> 16) + 2) >> 2) & 0xFF) << (8 * j);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int o0 = (int)(t[j].sel & 0xFFFF), o1 = (int)(t[j].sel >> 16), c0 = (short)(t[j].coef & 0xFFFF), c1 = (short)(t[j].coef >> 16);
+                        const int s0 = r0[o0] * c0 + r0[o1] * c1;
+                        const int s1 = r1[o0] * c0 + r1[o1] * c1;
+                        out |= (uint32_t)(((((ty_.c0 * (s0 >> 4)) >> 16) + ((ty_.c1 * (s1 >> 4)) >> 16) + 2) >> 2) & 0xFF) << (8 * j);
+                    }
+                }
+                *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = out;
+            }
+        }
+    }
+    __syncthreads();
+#if defined(OF_STOP) && OF_STOP <= 1
+    return;
+#endif
+    // ---- 2. this tile's part of the padded plane (interior + REFLECT_101 border)
+    {
+        const int pxs = tx == 0 ? 0 : xs + PLF_EDGE, pxe = tx == L.tcx - 1 ? L.ppitch : xe + PLF_EDGE;
+        const int pys = ty == 0 ? 0 : ys + PLF_EDGE, pye = ty == L.tcy - 1 ? H + 2 * PLF_EDGE : ye + PLF_EDGE;
+        uint8_t *plane = pyr + (size_t)f * g.pyr_stride + L.plane_off;
+        // groups of 4 level columns x4 = 4-aligned, from the one holding plane column pxs to the one holding pxe - 1
+        const int xg0 = (pxs - PLF_EDGE) & ~3;
+        for (int py = pys + trow; py < pye; py += NR) {
+            const uint8_t *prow = P + (plf_reflect101(py - PLF_EDGE, H) - ey0) * PW - ex0;   // indexed by level x
+            uint8_t *drow = plane + (size_t)py * L.ppitch + PLF_EDGE;                        // indexed by level x
+            for (int x4 = xg0 + tc4; x4 + PLF_EDGE < pxe; x4 += 128) {
+                if (x4 >= 0 && x4 + 3 < W && x4 + PLF_EDGE >= pxs && x4 + 3 + PLF_EDGE < pxe)
+                    *(plf_u32u *)(drow + x4) = *reinterpret_cast<const uint32_t *>(prow + x4);
+                else
+                    for (int j = 0; j < 4; j++)
+                        if (x4 + j + PLF_EDGE >= pxs && x4 + j + PLF_EDGE < pxe) drow[x4 + j] = prow[plf_reflect101(x4 + j, W)];
+            }
+        }
+    }
+#if defined(OF_STOP) && OF_STOP <= 2
+    return;
+#endif
+    // ---- 3. GaussianBlur 7x7.  A thread owns one group of 4 columns for a segment of 8 output rows and walks down the 14 tile rows behind
+    // them: row sums by two byte dot products per pixel (taps 18 34 49 55 fit a byte; v_alignbyte lines the 4-byte windows up), the 7 live
+    // rows of sums stay in registers (fully unrolled: no window shifting), exact int32 column sums, rounded as OpenCV 3.3's column filter does
+    {
+        const uint32_t K0123 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
+        const uint32_t K210 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
+        const int k0 = taps.x, k1 = taps.y, k2 = taps.z, k3 = taps.w;
+        const int OH = ye - ys, ngb = (EW >> 2) - 2, nseg = (OH + 7) >> 3, wvec = W & ~3;
+        uint8_t *bp = blur + (size_t)f * g.blur_stride + L.blur_off;
+        for (int it = tid; it < ngb * nseg; it += OF_NT) {
+            const int seg = it / ngb, c4 = 4 + 4 * (it - seg * ngb), oy0 = seg * 8, x4 = ex0 + c4;
+            int hs[14][4];
+#pragma unroll
+            for (int r = 0; r < 14; r++) {
+                const int ey = min(oy0 + r, EH - 1);   // (rows past the tile only feed outputs that are not stored)
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(P + ey * PW + c4 - 4);
+                const uint32_t A = p[0], B = p[1], C = p[2];   // level x - 4 .. x + 7 of the group's first pixel x
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t lo4 = j == 3 ? B : __builtin_amdgcn_alignbyte(B, A, j + 1);   // bytes x + j - 3 .. x + j
+                    const uint32_t hi4 = j == 3 ? C : __builtin_amdgcn_alignbyte(C, B, j + 1);   // bytes x + j + 1 .. x + j + 4 (the last has tap 0)
+                    hs[r][j] = (int)__builtin_amdgcn_udot4(hi4, K210, __builtin_amdgcn_udot4(lo4, K0123, 0u, false), false);
+                }
+                if (r < 6) continue;
+                const int oy = oy0 + r - 6;
+                if (oy >= OH) continue;
+                uint32_t bw = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sm = k0 * (hs[r - 6][j] + hs[r][j]) + k1 * (hs[r - 5][j] + hs[r - 1][j]) + k2 * (hs[r - 4][j] + hs[r - 2][j]) + k3 * hs[r - 3][j];
+                    // SymmColumnVec_32s8u: sum / 65536 rounded half to even for x < (w & ~3); its scalar tail ((sum + 32768) >> 16) for the last w % 4 columns
+                    const int v = x4 + j < wvec ? (sm + 0x7FFF + ((sm >> 16) & 1)) >> 16 : (sm + 32768) >> 16;
+                    bw |= (uint32_t)min(v, 255) << (8 * j);
+                }
+                uint8_t *bo = bp + (size_t)(ys + oy) * L.bpitch + x4;
+                if (x4 >= xs && x4 + 3 < xe) *reinterpret_cast<uint32_t *>(bo) = bw;
+                else
+                    for (int j = 0; j < 4; j++)
+                        if (x4 + j >= xs && x4 + j < xe) bo[j] = (uint8_t)(bw >> (8 * j));
+            }
+        }
+    }
+#if defined(OF_STOP) && OF_STOP <= 3
+    return;
+#endif
+    // ---- 4. FAST score of the cells' computed regions (score tile S: rows ry0.., columns = tile columns)
+    const int RH = ry1 - ry0;
+    for (int i = tid; i < ((PW * RH + 3) >> 2); i += OF_NT) reinterpret_cast<uint32_t *>(S)[i] = 0u;
+    __syncthreads();   // (every thread is done with the staged source: LIST aliases it)
+    const int tmin = g.minTh;
+    {
+        const int cA = (rx0 - ex0) & ~3, cB = (rx1 - 1 - ex0) & ~3;
+        for (int ry = trow; ry < ((RH + NR - 1) / NR) * NR; ry += NR)   // (uniform trip count: the ballots below need every lane)
+            for (int c4 = cA + tc4; c4 - tc4 <= cB; c4 += 128) {
+                uint32_t poss = 0;
+                if (ry < RH && c4 <= cB) {
+                    const uint8_t *prow = P + (ry0 + ry - ey0) * PW + c4;
+                    const uint32_t Lw = *reinterpret_cast<const uint32_t *>(prow - 4), C = *reinterpret_cast<const uint32_t *>(prow),
+                                   Rw = *reinterpret_cast<const uint32_t *>(prow + 4), N = *reinterpret_cast<const uint32_t *>(prow + 3 * PW),
+                                   Sd = *reinterpret_cast<const uint32_t *>(prow - 3 * PW);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int x = ex0 + c4 + j;
+                        const int v = OF_BYTE(Lw, C, Rw, 4 + j), hi = v + tmin, lo = v - tmin;
+                        const int n = (int)((N >> (8 * j)) & 0xFF), s = (int)((Sd >> (8 * j)) & 0xFF);     // ring points 0 and 8
+                        const int e = OF_BYTE(Lw, C, Rw, 7 + j), w_ = OF_BYTE(Lw, C, Rw, 1 + j);             // ring points 4 and 12
+                        const bool bn = n > hi, be = e > hi, bs = s > hi, bw = w_ > hi, dn = n < lo, de = e < lo, ds = s < lo, dw = w_ < lo;
+                        const bool ps = (bn && be) || (be && bs) || (bs && bw) || (bw && bn) || (dn && de) || (de && ds) || (ds && dw) || (dw && dn);
+                        if (ps && x >= rx0 && x < rx1) poss |= 1u << j;
+                    }
+                }
+                const unsigned long long m0 = __ballot(poss & 1u), m1 = __ballot(poss & 2u), m2 = __ballot(poss & 4u), m3 = __ballot(poss & 8u);
+                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                int base = 0;
+                if (plf_lane() == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(&s_nlist, n0 + n1 + n2 + n3);
+                base = __shfl(base, 0, 64);
+                const unsigned long long below = (1ull << plf_lane()) - 1ull;
+                const uint16_t e0 = (uint16_t)(c4 | (ry << 8));
+                if (poss & 1u) LIST[base + __popcll(m0 & below)] = e0;
+                if (poss & 2u) LIST[base + n0 + __popcll(m1 & below)] = (uint16_t)(e0 + 1);
+                if (poss & 4u) LIST[base + n0 + n1 + __popcll(m2 & below)] = (uint16_t)(e0 + 2);
+                if (poss & 8u) LIST[base + n0 + n1 + n2 + __popcll(m3 & below)] = (uint16_t)(e0 + 3);
+            }
+    }
+    __syncthreads();
+#if defined(OF_STOP) && OF_STOP <= 4
+    return;
+#endif
+    const int nl = s_nlist;
+    for (int k = tid; k < nl; k += OF_NT) {
+        const int q = LIST[k], c = q & 255, ry = q >> 8;
+        const uint8_t *p = P + (ry0 + ry - ey0) * PW + c;
+        const int v = p[0];
+        int d[16];
+        d[0] = v - p[3 * PW];       d[1] = v - p[3 * PW + 1];   d[2] = v - p[2 * PW + 2];   d[3] = v - p[PW + 3];
+        d[4] = v - p[3];            d[5] = v - p[-PW + 3];      d[6] = v - p[-2 * PW + 2];  d[7] = v - p[-3 * PW + 1];
+        d[8] = v - p[-3 * PW];      d[9] = v - p[-3 * PW - 1];  d[10] = v - p[-2 * PW - 2]; d[11] = v - p[-PW - 3];
+        d[12] = v - p[-3];          d[13] = v - p[PW - 3];      d[14] = v - p[2 * PW - 2];  d[15] = v - p[3 * PW - 1];
+        S[ry * PW + c] = (uint8_t)orb_fast_score(d, tmin);
+    }
+    __syncthreads();
+#if defined(OF_STOP) && OF_STOP <= 5
+    return;
+#endif
+    // ---- 5. 3x3 non-maximum suppression inside each cell's computed region (neighbours outside it count as 0), per survivor; the maxima are
+    // recorded as one bit per (cell, row, column) for the two thresholds
+    for (int k = tid; k < nl; k += OF_NT) {
+        const int q = LIST[k], c = q & 255, ry = q >> 8;
+        const uint8_t *sp = S + ry * PW + c;
+        const int sc = sp[0];
+        if (sc < tmin) continue;
+        const int x = ex0 + c, y = ry0 + ry;
+        const int ccol = x >= xm, crow = y >= ym;
+        const int xl = ccol ? xm : rx0, xr = ccol ? rx1 : xm, yt = crow ? ym : ry0, yb_ = crow ? ry1 : ym;   // the cell's computed region
+        const bool okl = x > xl, okr = x + 1 < xr, oku = y > yt, okd = y + 1 < yb_;
+        int nb = 0;
+        if (okl) nb = max(nb, (int)sp[-1]);
+        if (okr) nb = max(nb, (int)sp[1]);
+        if (oku) { nb = max(nb, (int)sp[-PW]); if (okl) nb = max(nb, (int)sp[-PW - 1]); if (okr) nb = max(nb, (int)sp[-PW + 1]); }
+        if (okd) { nb = max(nb, (int)sp[PW]); if (okl) nb = max(nb, (int)sp[PW - 1]); if (okr) nb = max(nb, (int)sp[PW + 1]); }
+        if (sc > nb) {
+            const int ci = ccol + 2 * crow;
+            const unsigned long long bit = 1ull << (x - xl);
+            atomicOr(&s_mask[ci][y - yt][1], bit);
+            if (sc >= g.iniTh) atomicOr(&s_mask[ci][y - yt][0], bit);
+        }
+    }
+    __syncthreads();
+    // ---- 6. per cell (one wave each): iniThFAST, or minThFAST when that leaves the cell empty; raster-ordered emission
+    {
+        const int wv = tid >> 6, lane = tid & 63;
+        const int cx = cx0 + (wv & 1), cy = cy0 + (wv >> 1);
+        if (cx >= cx1 || cy >= cy1) return;
+        const int cell = L.cell_base + cy * L.ncx + cx;
+        const int4 rc = cells[cell];                 // x0, y0, w, h of the sub-image (level interior coordinates)
+        const int ch = rc.w - 6;                     // rows of the computed region
+        const uint8_t *sp = S + (rc.y + 3 - ry0) * PW + (rc.x + 3 - ex0);
+        const unsigned long long my20 = lane < ch ? s_mask[wv][lane][0] : 0ull, my7 = lane < ch ? s_mask[wv][lane][1] : 0ull;   // lane r = row r
+        const int n20 = plf_wave_sum(__popcll(my20));
+        const unsigned long long mine = n20 > 0 ? my20 : my7;
+        const int cnt = __popcll(mine);
+        const int total = plf_wave_sum(cnt);
+        const int excl = plf_wave_excl_scan(cnt);
+        int base = 0;
+        if (lane == 0 && total > 0) base = atomicAdd(&poolcnt[f * g.nlevels + l], total);
+        base = __shfl(base, 0, 64);
+        if (lane == 0) cellinfo[(size_t)f * g.cells_total + cell] = make_int2(base, total);
+        if (total == 0) return;
+        if (base + total > (int)L.pool_cap) {  // cannot happen (pool sized for the densest possible NMS output)
+            if (lane == 0) atomicOr(status, 1);
+            return;
+        }
+        uint2 *out = pool + (size_t)f * g.pool_stride + L.pool_off + base + excl;
+        unsigned long long mm = mine;
+        const int gy = rc.y + 3 + lane;
+        int k = 0;
+        while (mm) {
+            const int c = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int x = rc.x + 3 + c;
+            const int resp = sp[lane * PW + c];
+            // coordinates relative to (minBorderX, minBorderY) as DistributeOctTree expects
+            out[k++] = make_uint2((uint32_t)(x - PLF_MINB) | ((uint32_t)(gy - PLF_MINB) << 16), (uint32_t)resp);
+        }
+    }
+}

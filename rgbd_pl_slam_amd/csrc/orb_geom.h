@@ -25,6 +25,9 @@ struct OrbLevel {
     uint32_t sel_off;    // selected keypoints: first entry inside one frame's sel block
     uint32_t sel_cap;    // quota + 8
     uint32_t tabx_off, taby_off;  // resize coefficient tables (levels >= 1)
+    // k_orb_level: the effective cell grid (cells skipped by the reference's loop are at the row / column ends), tiles of 2 x 2 cells, and the
+    // end of the last cell's computed region (cell sub-image minus its 3-pixel frame; the regions of neighbouring cells abut)
+    int ncx, ncy, tcx, tcy, rex, rey;
 };
 
 struct OrbGeom {
@@ -37,5 +40,7 @@ struct OrbGeom {
     uint32_t blur_stride;  // bytes per frame
     uint32_t pool_stride;  // entries per frame
     uint32_t sel_stride;   // entries per frame
+    // LDS layout of k_orb_level (bytes; maxima over the levels): pixel tile pitch, source tile pitch, score tile pitch, byte offsets
+    int lds_pw, lds_spw, lds_sp, lds_eh, lds_off_a, lds_off_s, lds_off_list, lds_off_tab, lds_total;
     OrbLevel lv[PLF_MAX_LEVELS];
 };

@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "plf_common.h"
 #include "orb_geom.h"
@@ -14,6 +15,8 @@ __global__ void k_pyr_level0(const uint8_t *, ptrdiff_t, ptrdiff_t, uint8_t *, O
 __global__ void k_pyr_resize(uint8_t *, OrbGeom, int, const int *, const short2 *, const int *, const short2 *);
 __global__ void k_fast_cells(const uint8_t *, const int4 *, int2 *, uint2 *, int *, int *, OrbGeom);
 __global__ void k_score_blur(const uint8_t *, uint8_t *, uint8_t *, OrbGeom, int4);
+__global__ void k_orb_level(const uint8_t *, ptrdiff_t, ptrdiff_t, uint8_t *, uint8_t *, int, const int *, const short2 *, const int *, const short2 *, const int4 *,
+                            int2 *, uint2 *, int *, int *, OrbGeom, int4);
 __global__ void k_octree(const int2 *, const uint2 *, int *, uint2 *, int *, uint8_t *, uint2 *, int *, int *, int *, OrbGeom, int, int);
 __global__ void k_orient_brief(const uint8_t *, const uint8_t *, const uint2 *, const int *, plf_keypoint *, uint8_t *, int *, int,
                                int *, OrbGeom);
@@ -145,6 +148,19 @@ static int orb_geometry(plf_orb *h, int w, int h_, OrbGeom *g, std::vector<int4>
         }
         L.ncells = nc;
         cellbase += nc;
+        // effective cell grid (the loop above skips cells only at the row / column ends) and the end of the last computed region
+        L.ncx = 0; L.ncy = 0;
+        for (int j = 0; j < nCols; j++) if (!((float)(minB + j * L.wCell) >= maxBX - 6)) L.ncx++;
+        for (int i = 0; i < nRows; i++) if (!((float)(minB + i * L.hCell) >= maxBY - 3)) L.ncy++;
+        if (L.ncx < 1 || L.ncy < 1 || L.ncx * L.ncy != nc) return PLF_E_BADARG;
+        {
+            float mx = (float)(minB + (L.ncx - 1) * L.wCell) + L.wCell + 6, my = (float)(minB + (L.ncy - 1) * L.hCell) + L.hCell + 6;
+            if (mx > maxBX) mx = (float)maxBX;
+            if (my > maxBY) my = (float)maxBY;
+            L.rex = (int)mx - 3; L.rey = (int)my - 3;
+        }
+        L.tcx = (L.ncx + 1) / 2; L.tcy = (L.ncy + 1) / 2;
+        if (2 * L.wCell > 250 || 2 * L.hCell > 250) return PLF_E_BADARG;   // tile-relative coordinates are packed in 8 bits
         L.quota = h->per_level[l];
         L.scale = h->scale[l];
         L.size_i = (int)(PLF_PATCH * h->scale[l]);
@@ -223,6 +239,46 @@ static int orb_configure(plf_orb *h, int w, int hh)
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * ty, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(short2) * ty, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), sizeof(int4) * cells.size(), hipMemcpyHostToDevice));
+    // LDS layout of k_orb_level: maxima over all tiles of all levels
+    {
+        int maxEW = 0, maxEH = 0, maxSW = 0, maxSH = 0, maxRW = 0, maxRH = 0, maxOW = 0;
+        for (int l = 0; l < g.nlevels; l++) {
+            const OrbLevel &L = g.lv[l];
+            for (int ty = 0; ty < L.tcy; ty++)
+                for (int txi = 0; txi < L.tcx; txi++) {
+                    const int cx0 = 2 * txi, cx1 = std::min(cx0 + 2, L.ncx), cy0 = 2 * ty, cy1 = std::min(cy0 + 2, L.ncy);
+                    const int rx0 = PLF_EDGE + cx0 * L.wCell, rx1 = cx1 == L.ncx ? L.rex : PLF_EDGE + cx1 * L.wCell;
+                    const int ry0 = PLF_EDGE + cy0 * L.hCell, ry1 = cy1 == L.ncy ? L.rey : PLF_EDGE + cy1 * L.hCell;
+                    const int xs = txi == 0 ? 0 : rx0, xe = txi == L.tcx - 1 ? L.w : rx1, ys = ty == 0 ? 0 : ry0, ye = ty == L.tcy - 1 ? L.h : ry1;
+                    const int ex0 = (xs & ~3) - 4, EW = ((xe - 1) & ~3) + 8 - ex0, EH = ye - ys + 6;
+                    if (rx1 <= rx0 || ry1 <= ry0 || xe - xs < 4 || ye - ys < 4) return PLF_E_BADARG;
+                    maxEW = std::max(maxEW, EW); maxEH = std::max(maxEH, EH); maxOW = std::max(maxOW, xe - xs);
+                    maxRW = std::max(maxRW, rx1 - rx0); maxRH = std::max(maxRH, ry1 - ry0);
+                    if (l > 0) {
+                        const OrbLevel &S = g.lv[l - 1];
+                        const int lx_lo = std::max(ex0, 0), lx_hi = std::min(ex0 + EW - 1, L.w - 1), ly_lo = std::max(ys - 3, 0), ly_hi = std::min(ys - 3 + EH - 1, L.h - 1);
+                        const int sx_lo = xofs[L.tabx_off + lx_lo] & ~3, sx_hi = std::min(xofs[L.tabx_off + lx_hi] + 1, S.w - 1);
+                        const int sy_lo = std::min(std::max(yofs[L.taby_off + ly_lo], 0), S.h - 1), sy_hi = std::min(std::max(yofs[L.taby_off + ly_hi] + 1, 0), S.h - 1);
+                        maxSW = std::max(maxSW, sx_hi - sx_lo + 1); maxSH = std::max(maxSH, sy_hi - sy_lo + 1);
+                    }
+                }
+        }
+        if (maxEW > 255 || maxRH > 255) return PLF_E_BADARG;   // survivors are packed as (tile column | row << 8)
+        g.lds_pw = (maxEW + 3) & ~3;
+        g.lds_spw = ((maxSW + 8 + 3) & ~3) + 4;
+        g.lds_sp = g.lds_pw;
+        g.lds_eh = maxEH;
+        const size_t sz_p = (size_t)g.lds_pw * (maxEH + 1) + 16;
+        const size_t sz_a = std::max((size_t)g.lds_spw * (maxSH + 1), (size_t)maxRW * maxRH * 2) + 16;   // staged source tile, later the FAST survivor list
+        const size_t sz_s = (size_t)g.lds_pw * maxRH + 16, sz_t = (size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16;
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        g.lds_off_a = (int)up16(sz_p);
+        g.lds_off_s = g.lds_off_a + (int)up16(sz_a);
+        g.lds_off_list = g.lds_off_a;
+        g.lds_off_tab = g.lds_off_s + (int)up16(sz_s);
+        g.lds_total = g.lds_off_tab + (int)up16(sz_t);
+        if (g.lds_total > 150 * 1024) return PLF_E_BADARG;
+    }
     // keep the per-frame strides of the allocation (max size) so that buffer sizes stay valid
     g.pyr_stride = big.pyr_stride; g.blur_stride = big.blur_stride; g.pool_stride = big.pool_stride; g.sel_stride = big.sel_stride;
     const int cells_alloc = big.cells_total;
@@ -301,6 +357,7 @@ extern "C" int plf_orb_create(const plf_orb_params *p, plf_orb **out)
     (void)hipMemset(h->d_score, 0, B * g.blur_stride);
     plf_orb_upload_constants(h->umax);
     (void)hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_lds);
+    (void)hipFuncSetAttribute((const void *)k_orb_level, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();
     h->cur_w = -1; h->cur_h = -1;
     rc = orb_configure(h, p->max_width, p->max_height);
@@ -346,23 +403,13 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
     int *poolcnt = h->d_counters, *selcnt = h->d_counters + (size_t)h->prm.max_batch * nl,
         *ncand = h->d_counters + 2 * (size_t)h->prm.max_batch * nl, *status = h->d_counters + 3 * (size_t)h->prm.max_batch * nl;
     PLF_HIP_TRY(hipMemsetAsync(h->d_counters, 0, (3 * (size_t)h->prm.max_batch * nl + 16) * sizeof(int), s));
-    {
-        const OrbLevel &L = g.lv[0];
-        dim3 grid((((L.ppitch + 3) / 4) * (L.h + 2 * PLF_EDGE) + 255) / 256, 1, B);
-        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_gray, pitch, fstride, h->d_pyr, g);
-    }
-    for (int l = 1; l < nl; l++) {
+    // one fused launch per level (k_orb_level: pyramid plane + blur + FAST score / NMS / cell candidates from one LDS tile); level l is
+    // resized from level l-1, so the launches are stream-ordered
+    for (int l = 0; l < nl; l++) {
         const OrbLevel &L = g.lv[l];
-        dim3 grid((((L.ppitch + 3) / 4) * (L.h + 2 * PLF_EDGE) + 255) / 256, 1, B);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, h->d_pyr, g, l, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
+        hipLaunchKernelGGL(k_orb_level, dim3(L.tcx * L.tcy, B), dim3(512), (size_t)g.lds_total, s, d_gray, pitch, fstride, h->d_pyr, h->d_blur, l, h->d_xofs, h->d_xa,
+                           h->d_yofs, h->d_yb, h->d_cells, h->d_cellinfo, h->d_pool, poolcnt, status, g, h->taps);
     }
-    {
-        int sb_tiles = 0;   // waves of k_score_blur: 64 strips of 4 x 16 (SB_RS) pixels each, per level
-        for (int l = 0; l < nl; l++) sb_tiles += (((g.lv[l].w + 3) / 4) * ((g.lv[l].h + 15) / 16) + 63) / 64;
-        hipLaunchKernelGGL(k_score_blur, dim3(sb_tiles, B), dim3(64), 0, s, h->d_pyr, h->d_score, h->d_blur, g, h->taps);
-    }
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.cells_total, B), dim3(64), 0, s, h->d_score, h->d_cells, h->d_cellinfo, h->d_pool, poolcnt,
-                       status, g);
     hipLaunchKernelGGL(k_octree, dim3(nl, B), dim3(256), h->octree_lds, s, h->d_cellinfo, h->d_pool, h->d_celloff, h->d_keys,
                        h->d_nodeof, h->d_quad, h->d_sel, selcnt, ncand, status, g, h->cap_nodes, h->cap_sort);
     int slots = 0;   // at most sum of the per-level selection caps, and never more than the caller can take
