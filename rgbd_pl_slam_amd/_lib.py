@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplf_hip.so")
+LIB_PATH = os.environ.get("PLF_LIB_PATH") or os.path.join(_HERE, "libplf_hip.so")   # (PLF_LIB_PATH: A/B measurements of scratch builds)
 
 PLF_OK, PLF_E_EMPTY, PLF_E_BADARG, PLF_E_CAPACITY, PLF_E_HIP, PLF_E_NOMEM, PLF_E_RECTS = 0, -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -109,30 +109,57 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
         s_sc[i] = r0 * (double)b.x + r1 * (double)b.y;
     }
     __syncthreads();
+    // ll_angle for the tile; the pixels with a defined angle are compacted (wave ballots) into an LDS list so that the double-precision sincos
+    // below runs on full waves (about a quarter of the pixels have a gradient above the threshold)
+    __shared__ int s_ndef;
+    float2 *s_list = reinterpret_cast<float2 *>(s_blur);   // (offset inside the frame, angle in degrees); the blurred tile is dead after the resize
+    if (tid == 0) s_ndef = 0;
+    __syncthreads();
     const int tx = tid & 63;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int ty = (tid >> 6) + 4 * k;
         const int x = dx0 + tx, y = dy0 + ty;
-        if (x >= g.sw || y >= g.sh) continue;
+        bool def = false;
+        float deg = 0.f;
         const size_t o = (size_t)f * g.s_stride + (size_t)y * g.sw + x;
-        if (x == g.sw - 1 || y == g.sh - 1) { ang[o] = NOTDEF_F; modgrad[o] = 0.0; continue; }
-        const double *im = s_sc + ty * (PRE_TW + 1) + tx;
-        const double DA = im[PRE_TW + 2] - im[0];
-        const double BC = im[1] - im[PRE_TW + 1];
-        const double gx = DA + BC, gy = DA - BC;
-        const double norm = sqrt((gx * gx + gy * gy) / 4);
-        modgrad[o] = norm;
-        if (norm <= g.rho) { ang[o] = NOTDEF_F; continue; }
-        const float deg = plf_fast_atan2((float)gx, (float)-gy);
-        ang[o] = deg;
-        const double ad = (double)deg * DEG2RAD_D;
+        if (x < g.sw && y < g.sh) {
+            if (x == g.sw - 1 || y == g.sh - 1) { ang[o] = NOTDEF_F; modgrad[o] = 0.0; }
+            else {
+                const double *im = s_sc + ty * (PRE_TW + 1) + tx;
+                const double DA = im[PRE_TW + 2] - im[0];
+                const double BC = im[1] - im[PRE_TW + 1];
+                const double gx = DA + BC, gy = DA - BC;
+                const double norm = sqrt((gx * gx + gy * gy) / 4);
+                modgrad[o] = norm;
+                if (norm <= g.rho) ang[o] = NOTDEF_F;
+                else {
+                    deg = plf_fast_atan2((float)gx, (float)-gy);
+                    ang[o] = deg;
+                    def = true;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(def);
+        int base = 0;
+        if (plf_lane() == 0 && m) base = atomicAdd(&s_ndef, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (def) s_list[base + __popcll(m & ((1ull << plf_lane()) - 1ull))] = make_float2(__int_as_float(y * g.sw + x), deg);
+    }
+    __syncthreads();
+    const int ndef = s_ndef;
+    for (int i = tid; i < ndef; i += 256) {
+        const float2 e = s_list[i];
+        const size_t o = (size_t)f * g.s_stride + (size_t)__float_as_int(e.x);
+        const double ad = (double)e.y * DEG2RAD_D;
         const double af = (double)(float)ad;
-        double sf, cf, sd, cd;   // (sincos: one argument reduction for the pair)
-        sincos(af, &sf, &cf);
-        sincos(ad, &sd, &cd);
+        double sf, cf;
+        sincos(af, &sf, &cf);   // cs: cos / sin of the FLOAT-rounded angle, the increments region_grow adds
         cs[o] = make_double2(cf, sf);
-        cs0[o] = make_float2((float)cd, (float)sd);
+        // cs0: float(cos(ad)), float(sin(ad)) of the un-rounded angle.  ad = af + eps with |eps| <= 2^-25 |ad|: the second-order expansion around af is
+        // within ~2 ulp (double) of cos / sin (ad), i.e. as close to the correctly rounded value as a second libm call is, at a twentieth of its cost
+        const double eps = ad - af, h = 0.5 * eps * eps;
+        cs0[o] = make_float2((float)(cf - eps * sf - h * cf), (float)(sf + eps * cf - h * sf));
     }
 }
 
@@ -268,7 +295,10 @@ __device__ __forceinline__ double readlane_d(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// Thresholds of the cheap alignment pre-test of region_grow (see there): tan(prec -/+ delta), delta = 0.05 degrees.
+// Thresholds of the cheap alignment pre-test of region_grow (see there): t1 <= tan(prec - delta), t2 >= tan(prec + delta), delta = 0.05 degrees.
+// The pre-test only sorts candidates into "surely aligned", "surely not" and "border" (decided by the reference's own test), so ANY t1 below and
+// t2 above those tangents is sound: single-precision tanf with a 1e-4 relative safety factor (its error is ~1e-7; the band is ~2.5e-3 wide) keeps
+// the double-precision tan -- a double-double routine that alone costs ~40 VGPRs -- out of this kernel.
 // t1 < 0 switches the pre-test off (every decision is then taken by the exact test).
 struct GrowTh { float t1, t2; };
 __device__ __forceinline__ GrowTh grow_thresholds(double prec)
@@ -277,8 +307,8 @@ __device__ __forceinline__ GrowTh grow_thresholds(double prec)
     GrowTh t;
     t.t1 = -1.f; t.t2 = 0.f;
     if (prec - delta > 0.0 && prec + delta < 1.55) {
-        t.t1 = (float)tan(prec - delta) * (1.0f - 1.0e-6f);
-        t.t2 = (float)tan(prec + delta) * (1.0f + 1.0e-6f);
+        t.t1 = tanf((float)(prec - delta)) * (1.0f - 1.0e-4f);
+        t.t2 = tanf((float)(prec + delta)) * (1.0f + 1.0e-4f);
     }
     return t;
 }

@@ -12,7 +12,7 @@
 //     or both darker by the minimum threshold: every 9-arc contains such a pair), survivors compacted with wave ballots into an LDS list, and the
 //     full cornerScore only for them, densely packed over the lanes;
 //   * per cell (one wave each): threshold iniThFAST, retry with minThFAST when the cell stays empty, strict 3x3 non-maximum suppression inside
-//     the cell's computed region, raster-ordered emission into the level's candidate pool -- exactly what k_fast_cells did on the score plane.
+//     the cell's computed region, raster-ordered emission into the level's candidate pool.
 // The score never reaches HBM, the pyramid is written once and read once (by the next level), the blurred plane is written once.
 // Cell geometry: cell (cx, cy) of a level has the sub-image x0 = 16 + cx * wCell, width min(x0 + wCell + 6, w - 16) - x0; cv::FAST computes
 // the sub-image minus a 3-pixel frame, so the computed regions of neighbouring cells abut: [19 + cx * wCell, 19 + (cx + 1) * wCell).
@@ -52,13 +52,19 @@ struct __attribute__((aligned(8))) OrbColTab { uint32_t sel, coef; };   // one t
 struct __attribute__((aligned(8))) OrbRowTab { short off, nxt, c0, c1; };   // one tile row: the two source rows inside the staged tile, coefficients
 typedef short plf_s2v __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ plf_s2v of_min(plf_s2v a, plf_s2v b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ plf_s2v of_max(plf_s2v a, plf_s2v b) { return __builtin_elementwise_max(a, b); }
+// bytes k and k + 1 (0 <= k <= 10) of the 12 bytes (A, B, C) as two zero-extended int16 (one v_perm_b32); bytes k, k + 1 (k <= 2) of one dword
+#define OF_PAIR(A, B, C, k) __builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm((k) < 4 ? (B) : (C), (k) < 4 ? (A) : (k) < 8 ? (B) : (C), \
+                                                                              (uint32_t)((k) & 3) | 0x0C000C00u | ((uint32_t)(((k) & 3) + 1) << 16)))
+#define OF_PAIR1(A, k) __builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm(0u, (A), (uint32_t)(k) | 0x0C000C00u | ((uint32_t)((k) + 1) << 16)))
 // byte k (0..11) of the 12 bytes held in three dwords
 #define OF_BYTE(A, B, C, k) ((int)((((k) < 4 ? (A) : (k) < 8 ? (B) : (C)) >> (8 * ((k) & 3))) & 0xFFu))
 
 // Thread layout of the pixel phases: 8 rows x 32 groups of 4 tile columns per pass (tid >> 5, tid & 31): no integer division, LDS accessed as
 // aligned dwords.  Tile column c <-> level x = ex0 + c with ex0 = 4 * floor(xs / 4) - 4, so groups of 4 columns are 4-aligned in the level image
 // too (aligned stores to the blurred plane).
-#define OF_NT 512   // threads per tile
+#define OF_NT PLF_ORB_LEVEL_THREADS   // threads per tile
 __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__ in, ptrdiff_t in_pitch, ptrdiff_t in_fstride, uint8_t *__restrict__ pyr,
                                                    uint8_t *__restrict__ blur, int l, const int *__restrict__ xofs, const short2 *__restrict__ xa,
                                                    const int *__restrict__ yofs, const short2 *__restrict__ yb, const int4 *__restrict__ cells,
@@ -158,10 +164,12 @@ __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__
         // cv::resize INTER_LINEAR 8UC1 (OpenCV 3.3): dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2, 11-bit coefficients.
         // 4 outputs per thread: per source row one 8-byte window (three aligned LDS dwords, v_alignbyte), per output v_perm picks its two
         // bytes as int16 lanes and v_dot2 multiplies them with the (a0, a1) pair
-        for (int ey = trow; ey < EH; ey += NR) {
+        const uint32_t rcp_g = 0xFFFFFFFFu / (uint32_t)ngrp + 1u;   // i / ngrp = umulhi(i, rcp_g) for i < 65536
+        for (int i = tid; i < ngrp * EH; i += OF_NT) {
+            const int ey = (int)__umulhi((uint32_t)i, rcp_g), c4 = (i - ey * ngrp) * 4;
             const OrbRowTab ty_ = YT[ey];
             const uint8_t *r0 = SRC + ty_.off * SPW, *r1 = SRC + ty_.nxt * SPW;
-            for (int c4 = tc4; c4 < EW; c4 += 128) {
+            {
                 OrbColTab t[4];
                 *reinterpret_cast<uint4 *>(&t[0]) = *reinterpret_cast<const uint4 *>(&XT[c4]);
                 *reinterpret_cast<uint4 *>(&t[2]) = *reinterpret_cast<const uint4 *>(&XT[c4 + 2]);
@@ -272,25 +280,34 @@ __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__
     __syncthreads();   // (every thread is done with the staged source: LIST aliases it)
     const int tmin = g.minTh;
     {
-        const int cA = (rx0 - ex0) & ~3, cB = (rx1 - 1 - ex0) & ~3;
-        for (int ry = trow; ry < ((RH + NR - 1) / NR) * NR; ry += NR)   // (uniform trip count: the ballots below need every lane)
-            for (int c4 = cA + tc4; c4 - tc4 <= cB; c4 += 128) {
+        const int cA = (rx0 - ex0) & ~3, cB = (rx1 - 1 - ex0) & ~3, ngr = ((cB - cA) >> 2) + 1, nit = ngr * RH;
+        const uint32_t rcp_r = 0xFFFFFFFFu / (uint32_t)ngr + 1u;
+        for (int i0 = 0; i0 < nit; i0 += OF_NT) {   // (uniform trip count: the ballots below need every lane)
+            {
+                const int i = i0 + tid;
+                const int ry = (int)__umulhi((uint32_t)i, rcp_r), c4 = cA + (i - ry * ngr) * 4;
                 uint32_t poss = 0;
-                if (ry < RH && c4 <= cB) {
+                if (i < nit) {
                     const uint8_t *prow = P + (ry0 + ry - ey0) * PW + c4;
                     const uint32_t Lw = *reinterpret_cast<const uint32_t *>(prow - 4), C = *reinterpret_cast<const uint32_t *>(prow),
                                    Rw = *reinterpret_cast<const uint32_t *>(prow + 4), N = *reinterpret_cast<const uint32_t *>(prow + 3 * PW),
                                    Sd = *reinterpret_cast<const uint32_t *>(prow - 3 * PW);
+                    // two pixels per instruction in packed int16 lanes: d = ring - centre for the compass points 0 (row + 3), 4 (x + 3), 8 (row - 3),
+                    // 12 (x - 3); a bright 9-arc needs two ADJACENT compass points with d > t, a dark one two with d < -t
+                    const plf_s2v tt = {(short)tmin, (short)tmin};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int x = ex0 + c4 + j;
-                        const int v = OF_BYTE(Lw, C, Rw, 4 + j), hi = v + tmin, lo = v - tmin;
-                        const int n = (int)((N >> (8 * j)) & 0xFF), s = (int)((Sd >> (8 * j)) & 0xFF);     // ring points 0 and 8
-                        const int e = OF_BYTE(Lw, C, Rw, 7 + j), w_ = OF_BYTE(Lw, C, Rw, 1 + j);             // ring points 4 and 12
-                        const bool bn = n > hi, be = e > hi, bs = s > hi, bw = w_ > hi, dn = n < lo, de = e < lo, ds = s < lo, dw = w_ < lo;
-                        const bool ps = (bn && be) || (be && bs) || (bs && bw) || (bw && bn) || (dn && de) || (de && ds) || (ds && dw) || (dw && dn);
-                        if (ps && x >= rx0 && x < rx1) poss |= 1u << j;
+                    for (int j = 0; j < 4; j += 2) {
+                        const plf_s2v v = OF_PAIR(Lw, C, Rw, 4 + j);
+                        const plf_s2v dn = OF_PAIR1(N, j) - v, de = OF_PAIR(Lw, C, Rw, 7 + j) - v, ds = OF_PAIR1(Sd, j) - v, dw = OF_PAIR(Lw, C, Rw, 1 + j) - v;
+                        const plf_s2v br = of_max(of_max(of_min(dn, de), of_min(de, ds)), of_max(of_min(ds, dw), of_min(dw, dn)));
+                        const plf_s2v dk = of_min(of_min(of_max(dn, de), of_max(de, ds)), of_min(of_max(ds, dw), of_max(dw, dn)));
+                        const plf_s2v m = of_max(br, -dk) - tt;   // > 0: possible corner
+                        if (m.x > 0) poss |= 1u << j;
+                        if (m.y > 0) poss |= 2u << j;
                     }
+                    // pixels of the group outside the computed regions
+                    const int lo = rx0 - (ex0 + c4), hi = rx1 - (ex0 + c4);
+                    poss &= (hi >= 4 ? 15u : (1u << max(hi, 0)) - 1u) & ~((1u << min(max(lo, 0), 4)) - 1u);
                 }
                 const unsigned long long m0 = __ballot(poss & 1u), m1 = __ballot(poss & 2u), m2 = __ballot(poss & 4u), m3 = __ballot(poss & 8u);
                 const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
@@ -304,6 +321,7 @@ __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__
                 if (poss & 4u) LIST[base + n0 + n1 + __popcll(m2 & below)] = (uint16_t)(e0 + 2);
                 if (poss & 8u) LIST[base + n0 + n1 + n2 + __popcll(m3 & below)] = (uint16_t)(e0 + 3);
             }
+        }
     }
     __syncthreads();
 #if defined(OF_STOP) && OF_STOP <= 4

@@ -7,6 +7,9 @@
 #define PLF_MINB 16        // minBorderX/Y
 #define PLF_HALF_PATCH 15
 #define PLF_PATCH 31
+#ifndef PLF_ORB_LEVEL_THREADS
+#define PLF_ORB_LEVEL_THREADS 256   // workgroup size of k_orb_level (one tile of 2 x 2 cells): 4 waves x 72 VGPRs still fit a CU next to 16 region-growing waves
+#endif
 
 struct OrbLevel {
     int w, h;            // level image (interior) size

@@ -11,10 +11,6 @@
 
 // kernels (orb_kernels.hip, orb_octree.hip)
 void plf_orb_upload_constants(const int *umax16);
-__global__ void k_pyr_level0(const uint8_t *, ptrdiff_t, ptrdiff_t, uint8_t *, OrbGeom);
-__global__ void k_pyr_resize(uint8_t *, OrbGeom, int, const int *, const short2 *, const int *, const short2 *);
-__global__ void k_fast_cells(const uint8_t *, const int4 *, int2 *, uint2 *, int *, int *, OrbGeom);
-__global__ void k_score_blur(const uint8_t *, uint8_t *, uint8_t *, OrbGeom, int4);
 __global__ void k_orb_level(const uint8_t *, ptrdiff_t, ptrdiff_t, uint8_t *, uint8_t *, int, const int *, const short2 *, const int *, const short2 *, const int4 *,
                             int2 *, uint2 *, int *, int *, OrbGeom, int4);
 __global__ void k_octree(const int2 *, const uint2 *, int *, uint2 *, int *, uint8_t *, uint2 *, int *, int *, int *, OrbGeom, int, int);
@@ -37,7 +33,7 @@ struct plf_orb {
     int4 taps;
     hipStream_t stream;
     // device buffers
-    uint8_t *d_pyr, *d_blur, *d_score, *d_quad, *d_in;
+    uint8_t *d_pyr, *d_blur, *d_quad, *d_in;
     uint2 *d_pool, *d_keys, *d_sel;
     int *d_nodeof, *d_celloff, *d_counters;  // counters: poolcnt[B*nl], selcnt[B*nl], ncand[B*nl], status[1]
     int2 *d_cellinfo;
@@ -204,7 +200,7 @@ static void resize_tables(int sw, int sh, int dw, int dh, int *xofs, short2 *xa,
 
 static void orb_free(plf_orb *h)
 {
-    void *ptrs[] = {h->d_pyr, h->d_blur, h->d_score, h->d_quad, h->d_in, h->d_pool, h->d_keys, h->d_sel, h->d_nodeof, h->d_celloff,
+    void *ptrs[] = {h->d_pyr, h->d_blur, h->d_quad, h->d_in, h->d_pool, h->d_keys, h->d_sel, h->d_nodeof, h->d_celloff,
                     h->d_counters, h->d_cellinfo, h->d_cells, h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_kps, h->d_desc, h->d_nout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -265,7 +261,7 @@ static int orb_configure(plf_orb *h, int w, int hh)
         }
         if (maxEW > 255 || maxRH > 255) return PLF_E_BADARG;   // survivors are packed as (tile column | row << 8)
         g.lds_pw = (maxEW + 3) & ~3;
-        g.lds_spw = ((maxSW + 8 + 3) & ~3) + 4;
+        g.lds_spw = ((maxSW + 8 + 15) & ~15) + 16;   // (rows are filled 16 bytes at a time)
         g.lds_sp = g.lds_pw;
         g.lds_eh = maxEH;
         const size_t sz_p = (size_t)g.lds_pw * (maxEH + 1) + 16;
@@ -334,7 +330,6 @@ extern "C" int plf_orb_create(const plf_orb_params *p, plf_orb **out)
     } while (0)
     ALLOC(h->d_pyr, B * g.pyr_stride);
     ALLOC(h->d_blur, B * g.blur_stride);
-    ALLOC(h->d_score, B * g.blur_stride);
     ALLOC(h->d_pool, B * g.pool_stride * sizeof(uint2));
     ALLOC(h->d_keys, B * g.pool_stride * sizeof(uint2));
     ALLOC(h->d_nodeof, B * g.pool_stride * sizeof(int));
@@ -353,8 +348,6 @@ extern "C" int plf_orb_create(const plf_orb_params *p, plf_orb **out)
     ALLOC(h->d_in, h->in_cap);
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { orb_free(h); free(h); return PLF_E_HIP; }
-    // the score plane is only written inside [19, w-19) x [19, h-19); everything else must read as 0
-    (void)hipMemset(h->d_score, 0, B * g.blur_stride);
     plf_orb_upload_constants(h->umax);
     (void)hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_lds);
     (void)hipFuncSetAttribute((const void *)k_orb_level, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -407,7 +400,7 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
     // resized from level l-1, so the launches are stream-ordered
     for (int l = 0; l < nl; l++) {
         const OrbLevel &L = g.lv[l];
-        hipLaunchKernelGGL(k_orb_level, dim3(L.tcx * L.tcy, B), dim3(512), (size_t)g.lds_total, s, d_gray, pitch, fstride, h->d_pyr, h->d_blur, l, h->d_xofs, h->d_xa,
+        hipLaunchKernelGGL(k_orb_level, dim3(L.tcx * L.tcy, B), dim3(PLF_ORB_LEVEL_THREADS), (size_t)g.lds_total, s, d_gray, pitch, fstride, h->d_pyr, h->d_blur, l, h->d_xofs, h->d_xa,
                            h->d_yofs, h->d_yb, h->d_cells, h->d_cellinfo, h->d_pool, poolcnt, status, g, h->taps);
     }
     hipLaunchKernelGGL(k_octree, dim3(nl, B), dim3(256), h->octree_lds, s, h->d_cellinfo, h->d_pool, h->d_celloff, h->d_keys,
