@@ -401,6 +401,25 @@ int plf_match_lines_lastframe_batch(plf_matcher *h, const uint8_t *last_desc, in
                                     const plf_lineframe_view *frames, int32_t n_frames, int32_t *match_of_line, int32_t line_stride,
                                     int32_t *nmatches, void *stream);
 
+/* int LSDmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo)
+ * include/LSDmatcher.h:54 (LocalMapping::CreateNewMapLines; body absent from the snapshot -- PL-SLAM family rule, "parity unpinned"): brute-force
+ * Hamming kNN (k = 2) of pKF1->mLineDescriptors against pKF2->mLineDescriptors, KeyFrame::lineDescriptorMAD (include/KeyFrame.h:159), a pair is
+ * kept when d2 - d1 > mad_factor * nn12_mad (upstream 0.1) and neither line holds a MapLine (has_ml1 / has_ml2 = GetMapLine(i) != NULL); with
+ * bOnlyStereo both lines also need stereo data (stereo1 / stereo2; may be NULL otherwise).  All arrays DEVICE memory.
+ * match12 (n1 int32, overwritten): keyframe-2 line paired with keyframe-1 line q, -1 = none -- vMatchedPairs = {(q, match12[q])} in ascending q.
+ * nmatches (device int32) = the return value. */
+int plf_match_lines_triangulation(plf_matcher *h, const uint8_t *desc1, int32_t n1, const uint8_t *desc2, int32_t n2, const uint8_t *has_ml1,
+                                  const uint8_t *has_ml2, const uint8_t *stereo1, const uint8_t *stereo2, int32_t only_stereo, float mad_factor,
+                                  int32_t *match12, int32_t *nmatches, void *stream);
+
+/* int LSDmatcher::Fuse(KeyFrame *pKF, const vector<MapLine*> &vpMapLines)   include/LSDmatcher.h:58 (LocalMapping::SearchInNeighbors; body absent --
+ * PL-SLAM family rule, "parity unpinned") -- the search half: for every map line with valid[i] (non-NULL, !isBad(), !IsInKeyFrame(pKF)) the
+ * keyframe line nearest in Hamming distance over ALL of pKF->mLineDescriptors (first minimum), fused when the distance is <= TH_LOW (50).
+ * best_idx (device, m int32): keyframe line index or -1; nfused (device int32) = the return value.  As for ORBmatcher::Fuse the map mutation
+ * (Replace / AddObservation / AddMapLine, decided by pKF->GetMapLine(best_idx[i])) is applied by the caller in list order. */
+int plf_match_lines_fuse(plf_matcher *h, const uint8_t *kf_desc, int32_t n_kf, const uint8_t *ml_desc, const uint8_t *valid, int32_t m,
+                         int32_t *best_idx, int32_t *nfused, void *stream);
+
 /* MapLine tracking fields include/MapLine.h:113-129 */
 typedef struct {
     int32_t m;
@@ -525,6 +544,16 @@ int plf_batch_extract(plf_batch *b, const uint8_t *images, int64_t n_frames, int
 /* Seconds the workers of the last plf_batch_extract spent (max over workers): [0] total, [1] staging copies into pinned
  * memory, [2] waiting for the GPU, [3] unpacking outputs. */
 int plf_batch_last_timing(const plf_batch *b, double *out4);
+
+/* Device memory helpers for host code above this ABI that does not link the HIP runtime itself (the exact-signature adapters of include/plf.hpp
+ * stage the Frame / MapPoint / MapLine members the matchers read with them).  With a stream: plf_upload / plf_fill enqueue on it, plf_download
+ * enqueues and waits for it.  stream == NULL means synchronous: uploads and fills are complete on return, a download first waits for ALL work
+ * of the device (the handles run on their own non-blocking streams, which the null stream does not order with). */
+int plf_device_alloc(int32_t device, size_t bytes, void **out);
+void plf_device_free(void *p);
+int plf_upload(void *dst_device, const void *src_host, size_t bytes, void *stream);
+int plf_download(void *dst_host, const void *src_device, size_t bytes, void *stream);
+int plf_fill(void *dst_device, int32_t byte_value, size_t bytes, void *stream);
 
 /* Pinned (page-locked, portable across the GPUs of the driver) host memory for frame buffers handed to plf_batch_extract */
 int plf_host_alloc(size_t bytes, void **out);

@@ -219,10 +219,52 @@ public:
         check(plf_match_project_lines(m_, &F, 1, &vpMapLines, th, mfNNratio, match_of_line_dev, F.n, nmatches_dev, stream), "LSDmatcher::SearchByProjection");
     }
 
+    // int SearchByProjection(KeyFrame *pKF, Frame &F, vector<MapLine*> &vpMapLineMatches): the same rule, the keyframe's lines on the query side
+    void SearchByProjection(const uint8_t *kf_desc_dev, int nkf, const uint8_t *f_desc_dev, int nf, const uint8_t *kf_has_mapline_dev, int32_t *match_of_line_dev,
+                            int32_t *nmatches_dev, bool /*keyframe*/, void *stream = nullptr)
+    {
+        check(plf_match_lines_lastframe(m_, kf_desc_dev, nkf, f_desc_dev, nf, kf_has_mapline_dev, match_of_line_dev, nmatches_dev, stream),
+              "LSDmatcher::SearchByProjection(keyframe)");
+    }
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo)
+    void SearchForTriangulation(const uint8_t *desc1_dev, int n1, const uint8_t *desc2_dev, int n2, const uint8_t *has_ml1_dev, const uint8_t *has_ml2_dev,
+                                const uint8_t *stereo1_dev, const uint8_t *stereo2_dev, bool bOnlyStereo, int32_t *match12_dev, int32_t *nmatches_dev,
+                                float mad_factor = 0.1f, void *stream = nullptr)
+    {
+        check(plf_match_lines_triangulation(m_, desc1_dev, n1, desc2_dev, n2, has_ml1_dev, has_ml2_dev, stereo1_dev, stereo2_dev, bOnlyStereo, mad_factor,
+                                            match12_dev, nmatches_dev, stream), "LSDmatcher::SearchForTriangulation");
+    }
+    // int Fuse(KeyFrame *pKF, const vector<MapLine*> &vpMapLines)   (search half; the caller applies Replace / AddObservation / AddMapLine)
+    void Fuse(const uint8_t *kf_desc_dev, int nkf, const uint8_t *ml_desc_dev, const uint8_t *valid_dev, int m, int32_t *best_idx_dev, int32_t *nfused_dev,
+              void *stream = nullptr)
+    {
+        check(plf_match_lines_fuse(m_, kf_desc_dev, nkf, ml_desc_dev, valid_dev, m, best_idx_dev, nfused_dev, stream), "LSDmatcher::Fuse");
+    }
+
 private:
     plf_matcher *m_;
     float mfNNratio;
     bool mbCheckOrientation;
+};
+
+// RAII device array for host code that stages data for the matchers (plf_device_alloc / plf_upload / plf_download)
+template <class T> class DeviceArray {
+public:
+    DeviceArray() = default;
+    DeviceArray(size_t n, int device = 0) { reset(n, device); }
+    template <class U> DeviceArray(const std::vector<U> &host, int device = 0) { static_assert(sizeof(U) == sizeof(T), "element size"); reset(host.size(), device); upload(host.data(), host.size()); }
+    ~DeviceArray() { plf_device_free(p_); }
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    void reset(size_t n, int device = 0) { plf_device_free(p_); p_ = nullptr; n_ = n; void *q = nullptr; check(plf_device_alloc(device, n * sizeof(T), &q), "plf_device_alloc"); p_ = (T *)q; }
+    void upload(const void *host, size_t n) { check(plf_upload(p_, host, n * sizeof(T), nullptr), "plf_upload"); }
+    void fill(int byte) { check(plf_fill(p_, byte, n_ * sizeof(T), nullptr), "plf_fill"); }
+    std::vector<T> download() const { std::vector<T> v(n_); check(plf_download(v.data(), p_, n_ * sizeof(T), nullptr), "plf_download"); return v; }
+    T *get() const { return p_; }
+    size_t size() const { return n_; }
+private:
+    T *p_ = nullptr;
+    size_t n_ = 0;
 };
 
 // ORB_SLAM2::Frame members either side of the extractor / matcher path (include/Frame.h), stateless: device pointers in and out, one frame.
@@ -276,17 +318,27 @@ struct Frame {
 }  // namespace plf
 
 // ---------------------------------------------------------------------------------------------------------------
-// Drop-in adapters with the EXACT reference signatures; compiled only where OpenCV (+ contrib line_descriptor) exists.
+// Drop-in adapters with the EXACT reference signatures; compiled only where OpenCV (+ contrib line_descriptor) headers exist
+// (tests/mock/ holds a minimal stand-in so that tests/test_abi.py can at least compile them in this image).
+// The matcher adapters are templates over the reference's own Frame / KeyFrame / MapPoint / MapLine classes (include/Frame.h,
+// KeyFrame.h, MapPoint.h, MapLine.h): they read exactly the members the reference bodies read, flatten them into the plf_*_view
+// structs, run the device search and write the result back into mvpMapPoints / mvpMapLines -- the state the reference loop leaves.
 // ---------------------------------------------------------------------------------------------------------------
 #if defined(PLF_WITH_OPENCV) && defined(__has_include)
 #if __has_include(<opencv2/core.hpp>)
+#include <cstring>
+#include <utility>
 #include <opencv2/core.hpp>
 #include <opencv2/features2d.hpp>
+#include <opencv2/line_descriptor/descriptor.hpp>
 namespace ORB_SLAM2_PLF {
 static_assert(sizeof(cv::KeyPoint) == sizeof(plf_keypoint), "cv::KeyPoint must be 28 bytes");
+static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(plf_keyline), "cv::line_descriptor::KeyLine must be 68 bytes");
+
 class ORBextractor : public plf::ORBextractor {
 public:
     using plf::ORBextractor::ORBextractor;
+    using plf::ORBextractor::operator();
     // include/ORBextractor.h:59-61
     void operator()(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors)
     {
@@ -302,6 +354,272 @@ public:
         descriptors.create((int)k.size(), 32, CV_8U);
         memcpy(descriptors.getMat().data, d.data(), d.size());
     }
+};
+
+// include/ExtractLineSegment.h:29-57.  Vector3dT = Eigen::Vector3d in the reference (any type with operator()(int) or [] assignable from double works).
+class LineSegment : public plf::LineSegment {
+public:
+    using plf::LineSegment::LineSegment;
+    using plf::LineSegment::ExtractLineSegment;
+    // void ExtractLineSegment(const Mat &img, vector<KeyLine> &keylines, Mat &ldesc, vector<Vector3d> &keylineFunctions, int scale = 1.2, int numOctaves = 1)
+    template <class Vector3dT>
+    void ExtractLineSegment(const cv::Mat &img, std::vector<cv::line_descriptor::KeyLine> &keylines, cv::Mat &ldesc, std::vector<Vector3dT> &keylineFunctions,
+                            int scale = 1.2, int numOctaves = 1)
+    {
+        keylines.clear(); keylineFunctions.clear();
+        if (img.empty()) { ldesc.release(); return; }
+        CV_Assert(img.type() == CV_8UC1);
+        std::vector<plf_keyline> kl;
+        std::vector<uint8_t> d;
+        std::vector<plf::Vector3d> eq;
+        plf::LineSegment::ExtractLineSegment(img.data, img.cols, img.rows, (ptrdiff_t)img.step, kl, d, eq, scale, numOctaves);
+        keylines.resize(kl.size());
+        if (!kl.empty()) memcpy((void *)keylines.data(), kl.data(), kl.size() * sizeof(plf_keyline));
+        if (kl.empty()) { ldesc.release(); return; }
+        ldesc.create((int)kl.size(), 32, CV_8U);
+        memcpy(ldesc.data, d.data(), d.size());
+        keylineFunctions.resize(eq.size());
+        for (size_t i = 0; i < eq.size(); i++) { keylineFunctions[i][0] = eq[i].v[0]; keylineFunctions[i][1] = eq[i].v[1]; keylineFunctions[i][2] = eq[i].v[2]; }
+    }
+};
+
+namespace detail {
+inline std::vector<uint8_t> rows32(const cv::Mat &m)   // n x 32 CV_8U, rows possibly strided -> packed
+{
+    std::vector<uint8_t> out((size_t)m.rows * 32);
+    for (int r = 0; r < m.rows; r++) memcpy(&out[(size_t)r * 32], m.data + (size_t)r * m.step, 32);
+    return out;
+}
+inline void pose34(const cv::Mat &Tcw, float *R, float *t)   // 4x4 CV_32F
+{
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = Tcw.at<float>(r, c); t[r] = Tcw.at<float>(r, 3); }
+}
+}  // namespace detail
+
+// include/ORBmatcher.h:36-140, the two tracking overloads with their reference signatures
+class ORBmatcher {
+public:
+    static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0, int maxKeypoints = 8192, int maxMapPoints = 65535)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device)
+    {
+        plf::check(plf_matcher_create(device, maxKeypoints, maxMapPoints, 1024, 1, &m_), "plf_matcher_create");
+    }
+    ~ORBmatcher() { plf_matcher_destroy(m_); }
+    ORBmatcher(const ORBmatcher &) = delete;
+    ORBmatcher &operator=(const ORBmatcher &) = delete;
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return plf_hamming256(a.data, b.data); }   // include/ORBmatcher.h:44
+
+    // int SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th = 3)   include/ORBmatcher.h:61
+    template <class FrameT, class MapPointT> int SearchByProjection(FrameT &F, const std::vector<MapPointT *> &vpMapPoints, const float th = 3)
+    {
+        const int N = (int)F.mvKeysUn.size(), M = (int)vpMapPoints.size();
+        if (N == 0 || M == 0) return 0;
+        std::vector<float> px(M), py(M), pxr(M), vc(M);
+        std::vector<int32_t> lvl(M);
+        std::vector<uint8_t> inview(M), obs(M), desc((size_t)M * 32);
+        for (int i = 0; i < M; i++) {
+            MapPointT *p = vpMapPoints[i];
+            inview[i] = p && p->mbTrackInView && !p->isBad();
+            if (!inview[i]) continue;
+            px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR; lvl[i] = p->mnTrackScaleLevel; vc[i] = p->mTrackViewCos;
+            obs[i] = p->Observations() > 0;
+            const cv::Mat d = p->GetDescriptor();
+            memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        std::vector<int32_t> init(N, -1);
+        for (int k = 0; k < N; k++)
+            if (F.mvpMapPoints[k] && F.mvpMapPoints[k]->Observations() > 0) init[k] = -2;
+        plf::DeviceArray<plf_keypoint> dk(N, device_); dk.upload(F.mvKeysUn.data(), N);
+        plf::DeviceArray<float> dur(F.mvuRight, device_), dsc(F.mvScaleFactors, device_);
+        plf::DeviceArray<uint8_t> dd(detail::rows32(F.mDescriptors), device_), dmd(desc, device_), div(inview, device_), dob(obs, device_);
+        plf::DeviceArray<float> dpx(px, device_), dpy(py, device_), dpxr(pxr, device_), dvc(vc, device_);
+        plf::DeviceArray<int32_t> dl(lvl, device_), dm(init, device_), dn(1, device_);
+        plf_frame_view fv = {N, nullptr, dk.get(), dur.get(), dd.get(), FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY, dsc.get(),
+                             (int32_t)F.mvScaleFactors.size()};
+        plf_mappoint_view mv = {M, dpx.get(), dpy.get(), dpxr.get(), dl.get(), dvc.get(), div.get(), dmd.get(), dob.get()};
+        plf::check(plf_match_project_points(m_, &fv, 1, &mv, th, mfNNratio, dm.get(), N, dn.get(), nullptr), "ORBmatcher::SearchByProjection");
+        const std::vector<int32_t> match = dm.download();
+        for (int k = 0; k < N; k++)
+            if (match[k] >= 0) F.mvpMapPoints[k] = vpMapPoints[match[k]];
+        return dn.download()[0];
+    }
+
+    // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)   include/ORBmatcher.h:78
+    template <class FrameT> int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono)
+    {
+        const int N = (int)CurrentFrame.mvKeysUn.size(), NLst = (int)LastFrame.mvKeys.size();
+        if (N == 0 || NLst == 0) return 0;
+        std::vector<uint8_t> has(NLst), outl(NLst), obs(NLst), desc((size_t)NLst * 32);
+        std::vector<float> xw((size_t)NLst * 3);
+        for (int i = 0; i < NLst; i++) {
+            auto *p = LastFrame.mvpMapPoints[i];
+            has[i] = p != nullptr; outl[i] = LastFrame.mvbOutlier[i];
+            if (!p) continue;
+            obs[i] = p->Observations() > 0;
+            const cv::Mat w = p->GetWorldPos();
+            for (int c = 0; c < 3; c++) xw[(size_t)i * 3 + c] = w.template at<float>(c);
+            const cv::Mat d = p->GetDescriptor();
+            memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        std::vector<int32_t> init(N, -1);
+        for (int k = 0; k < N; k++)
+            if (CurrentFrame.mvpMapPoints[k] && CurrentFrame.mvpMapPoints[k]->Observations() > 0) init[k] = -2;
+        plf_pose_pair P;
+        detail::pose34(CurrentFrame.mTcw, P.Rcw, P.tcw); detail::pose34(LastFrame.mTcw, P.Rlw, P.tlw);
+        P.fx = FrameT::fx; P.fy = FrameT::fy; P.cx = FrameT::cx; P.cy = FrameT::cy; P.bf = CurrentFrame.mbf; P.b = CurrentFrame.mb;
+        plf::DeviceArray<plf_keypoint> dk(N, device_), dlk(NLst, device_);
+        dk.upload(CurrentFrame.mvKeysUn.data(), N); dlk.upload(LastFrame.mvKeysUn.data(), NLst);
+        plf::DeviceArray<float> dur(CurrentFrame.mvuRight, device_), dsc(CurrentFrame.mvScaleFactors, device_), dxw(xw, device_);
+        plf::DeviceArray<uint8_t> dd(detail::rows32(CurrentFrame.mDescriptors), device_), dh(has, device_), dou(outl, device_), dob(obs, device_), dmd(desc, device_);
+        plf::DeviceArray<int32_t> dm(init, device_), dn(1, device_);
+        plf_frame_view fv = {N, nullptr, dk.get(), dur.get(), dd.get(), FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY, dsc.get(),
+                             (int32_t)CurrentFrame.mvScaleFactors.size()};
+        plf_lastframe_view lv = {NLst, dh.get(), dou.get(), dxw.get(), dlk.get(), dmd.get(), dob.get()};
+        plf::check(plf_match_project_lastframe(m_, &fv, &lv, &P, th, bMono, mbCheckOrientation, dm.get(), dn.get(), nullptr), "ORBmatcher::SearchByProjection(last frame)");
+        const std::vector<int32_t> match = dm.download();
+        for (int k = 0; k < N; k++)
+            if (match[k] >= 0) CurrentFrame.mvpMapPoints[k] = LastFrame.mvpMapPoints[match[k]];
+        // (a key point whose assignment the rotation-consistency check removed ends as NULL in the reference; it was NULL or held a point
+        // without observations before -- the latter is the one state this adapter leaves as it was)
+        return dn.download()[0];
+    }
+    plf_matcher *handle() { return m_; }
+
+private:
+    plf_matcher *m_ = nullptr;
+    float mfNNratio;
+    bool mbCheckOrientation;
+    int device_;
+};
+
+// include/LSDmatcher.h:27-78, the three SearchByProjection overloads with their reference signatures (+ SearchForTriangulation / Fuse)
+class LSDmatcher {
+public:
+    static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+    LSDmatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0, int maxLines = 4096, int maxMapLines = 65535)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device)
+    {
+        plf::check(plf_matcher_create(device, 1, maxMapLines, maxLines, 1, &m_), "plf_matcher_create");
+    }
+    ~LSDmatcher() { plf_matcher_destroy(m_); }
+    LSDmatcher(const LSDmatcher &) = delete;
+    LSDmatcher &operator=(const LSDmatcher &) = delete;
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return plf_hamming256(a.data, b.data); }   // include/LSDmatcher.h:43
+
+    // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th = 3, const bool bMono = false)   include/LSDmatcher.h:32
+    template <class FrameT> int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float /*th*/ = 3, const bool /*bMono*/ = false)
+    {
+        return knn_assign(LastFrame.mLdesc, LastFrame.mvpMapLines, CurrentFrame.mLdesc, CurrentFrame.mvpMapLines);
+    }
+    // int SearchByProjection(KeyFrame *pKF, Frame &F, std::vector<MapLine*> &vpMapLineMatches)   include/LSDmatcher.h:35
+    template <class KeyFrameT, class FrameT, class MapLineT> int SearchByProjection(KeyFrameT *pKF, FrameT &F, std::vector<MapLineT *> &vpMapLineMatches)
+    {
+        vpMapLineMatches.assign((size_t)F.mLdesc.rows, nullptr);
+        const std::vector<MapLineT *> kfLines = pKF->GetMapLineMatches();
+        return knn_assign(pKF->mLineDescriptors, kfLines, F.mLdesc, vpMapLineMatches);
+    }
+    // int SearchByProjection(Frame &F, const std::vector<MapLine*> &vpMapLines, const float th = 3)   include/LSDmatcher.h:40
+    template <class FrameT, class MapLineT> int SearchByProjection(FrameT &F, const std::vector<MapLineT *> &vpMapLines, const float th = 3)
+    {
+        const int NL = (int)F.mvKeylinesUn.size(), M = (int)vpMapLines.size();
+        if (NL == 0 || M == 0) return 0;
+        std::vector<float> x1(M), y1(M), x2(M), y2(M), vc(M);
+        std::vector<int32_t> lvl(M);
+        std::vector<uint8_t> inview(M), desc((size_t)M * 32);
+        for (int i = 0; i < M; i++) {
+            MapLineT *p = vpMapLines[i];
+            inview[i] = p && p->mbTrackInView && !p->isBad();
+            if (!inview[i]) continue;
+            x1[i] = p->mTrackProjX1; y1[i] = p->mTrackProjY1; x2[i] = p->mTrackProjX2; y2[i] = p->mTrackProjY2; lvl[i] = p->mnTrackScaleLevel; vc[i] = p->mTrackViewCos;
+            const cv::Mat d = p->GetDescriptor();
+            memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        std::vector<int32_t> init(NL, -1);
+        for (int k = 0; k < NL; k++)
+            if (F.mvpMapLines[k] && F.mvpMapLines[k]->Observations() > 0) init[k] = -2;
+        plf::DeviceArray<plf_keyline> dkl(NL, device_); dkl.upload(F.mvKeylinesUn.data(), NL);
+        plf::DeviceArray<float> dsc(F.mvScaleFactors, device_), dx1(x1, device_), dy1(y1, device_), dx2(x2, device_), dy2(y2, device_), dvc(vc, device_);
+        plf::DeviceArray<uint8_t> dd(detail::rows32(F.mLdesc), device_), dmd(desc, device_), div(inview, device_);
+        plf::DeviceArray<int32_t> dl(lvl, device_), dm(init, device_), dn(1, device_);
+        plf_lineframe_view fv = {NL, nullptr, dkl.get(), dd.get(), dsc.get()};
+        plf_mapline_view mv = {M, dx1.get(), dy1.get(), dx2.get(), dy2.get(), dl.get(), dvc.get(), div.get(), dmd.get()};
+        plf::check(plf_match_project_lines(m_, &fv, 1, &mv, th, mfNNratio, dm.get(), NL, dn.get(), nullptr), "LSDmatcher::SearchByProjection");
+        const std::vector<int32_t> match = dm.download();
+        for (int k = 0; k < NL; k++)
+            if (match[k] >= 0) F.mvpMapLines[k] = vpMapLines[match[k]];
+        return dn.download()[0];
+    }
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo)   include/LSDmatcher.h:54
+    template <class KeyFrameT> int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo)
+    {
+        vMatchedPairs.clear();
+        const int n1 = pKF1->mLineDescriptors.rows, n2 = pKF2->mLineDescriptors.rows;
+        if (n1 == 0 || n2 < 2) return 0;
+        std::vector<uint8_t> h1(n1), h2(n2), s1(n1), s2(n2);
+        for (int i = 0; i < n1; i++) { h1[i] = pKF1->GetMapLine(i) != nullptr; s1[i] = pKF1->mvuRightLineStart[i] >= 0 && pKF1->mvuRightLineEnd[i] >= 0; }
+        for (int i = 0; i < n2; i++) { h2[i] = pKF2->GetMapLine(i) != nullptr; s2[i] = pKF2->mvuRightLineStart[i] >= 0 && pKF2->mvuRightLineEnd[i] >= 0; }
+        plf::DeviceArray<uint8_t> d1(detail::rows32(pKF1->mLineDescriptors), device_), d2(detail::rows32(pKF2->mLineDescriptors), device_), dh1(h1, device_),
+            dh2(h2, device_), ds1(s1, device_), ds2(s2, device_);
+        plf::DeviceArray<int32_t> dm(n1, device_), dn(1, device_);
+        plf::check(plf_match_lines_triangulation(m_, d1.get(), n1, d2.get(), n2, dh1.get(), dh2.get(), ds1.get(), ds2.get(), bOnlyStereo, 0.1f, dm.get(), dn.get(), nullptr),
+                   "LSDmatcher::SearchForTriangulation");
+        const std::vector<int32_t> match = dm.download();
+        for (int q = 0; q < n1; q++)
+            if (match[q] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)q, (size_t)match[q]));
+        return (int)vMatchedPairs.size();
+    }
+    // int Fuse(KeyFrame *pKF, const vector<MapLine*> &vpMapLines)   include/LSDmatcher.h:58: the device search, then the reference's map mutation in list order
+    template <class KeyFrameT, class MapLineT> int Fuse(KeyFrameT *pKF, const std::vector<MapLineT *> &vpMapLines)
+    {
+        const int nkf = pKF->mLineDescriptors.rows, M = (int)vpMapLines.size();
+        if (M == 0) return 0;
+        std::vector<uint8_t> valid(M), desc((size_t)M * 32);
+        for (int i = 0; i < M; i++) {
+            MapLineT *p = vpMapLines[i];
+            valid[i] = p && !p->isBad() && !p->IsInKeyFrame(pKF);
+            if (!valid[i]) continue;
+            const cv::Mat d = p->GetDescriptor();
+            memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        plf::DeviceArray<uint8_t> dk(detail::rows32(pKF->mLineDescriptors), device_), dmd(desc, device_), dv(valid, device_);
+        plf::DeviceArray<int32_t> db(M, device_), dn(1, device_);
+        plf::check(plf_match_lines_fuse(m_, dk.get(), nkf, dmd.get(), dv.get(), M, db.get(), dn.get(), nullptr), "LSDmatcher::Fuse");
+        const std::vector<int32_t> best = db.download();
+        int nFused = 0;
+        for (int i = 0; i < M; i++) {
+            if (best[i] < 0) continue;
+            MapLineT *pML = vpMapLines[i], *pMLinKF = pKF->GetMapLine((size_t)best[i]);
+            if (pMLinKF) {
+                if (!pMLinKF->isBad()) { if (pMLinKF->Observations() > pML->Observations()) pML->Replace(pMLinKF); else pMLinKF->Replace(pML); }
+            } else { pML->AddObservation(pKF, (size_t)best[i]); pKF->AddMapLine(pML, (size_t)best[i]); }
+            nFused++;
+        }
+        return nFused;
+    }
+    plf_matcher *handle() { return m_; }
+
+private:
+    // the brute-force kNN + MAD rule shared by the two frame / keyframe overloads: query = the side that holds MapLines, train = the frame being filled
+    template <class VecQ, class VecT> int knn_assign(const cv::Mat &qdesc, const VecQ &qlines, const cv::Mat &tdesc, VecT &tlines)
+    {
+        const int nq = qdesc.rows, nt = tdesc.rows;
+        if (nq == 0 || nt < 2) return 0;
+        std::vector<uint8_t> has(nq);
+        for (int q = 0; q < nq; q++) has[q] = qlines[q] != nullptr;
+        plf::DeviceArray<uint8_t> dq(detail::rows32(qdesc), device_), dt(detail::rows32(tdesc), device_), dh(has, device_);
+        plf::DeviceArray<int32_t> dm(nt, device_), dn(1, device_);
+        dm.fill(0xFF);
+        plf::check(plf_match_lines_lastframe(m_, dq.get(), nq, dt.get(), nt, dh.get(), dm.get(), dn.get(), nullptr), "LSDmatcher::SearchByProjection(kNN)");
+        const std::vector<int32_t> match = dm.download();
+        for (int t = 0; t < nt; t++)
+            if (match[t] >= 0) tlines[t] = qlines[match[t]];
+        return dn.download()[0];
+    }
+    plf_matcher *m_ = nullptr;
+    float mfNNratio;
+    bool mbCheckOrientation;
+    int device_;
 };
 }  // namespace ORB_SLAM2_PLF
 #endif

@@ -937,6 +937,58 @@ int orc_match_lines_knn(const uint8_t *last_desc, int nlast, const uint8_t *cur_
     return n;
 }
 
+/* ---------------------------------------------------------------- the two remaining LSDmatcher overloads (bodies absent: PARITY UNPINNED)
+ * int LSDmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo)
+ * include/LSDmatcher.h:54 (LocalMapping::CreateNewMapLines).  Restated from the PL-SLAM family this fork derives from -- the same brute-force rule
+ * as LSDmatcher::SearchByProjection(Cur, Last): BinaryDescriptorMatcher::knnMatch(pKF1->mLineDescriptors, pKF2->mLineDescriptors, k = 2),
+ * KeyFrame::lineDescriptorMAD (include/KeyFrame.h:159), nn12 threshold = mad_factor * nn12_mad (0.1 upstream), matches walked in queryIdx order,
+ * a pair (q, t) kept when d2 - d1 exceeds the threshold and NEITHER line holds a MapLine yet (the point overload: both pMP1 and pMP2 must be
+ * NULL, ORBmatcher.h:111); bOnlyStereo -- this fork's added argument -- applies the point overload's rule to lines: both lines need stereo data
+ * (end-point depths, Frame.h:208-211).  match12[q] = t or -1; returns the number of pairs. */
+int orc_lines_search_for_triangulation(const uint8_t *desc1, int n1, const uint8_t *desc2, int n2, const uint8_t *has_ml1, const uint8_t *has_ml2,
+                                       const uint8_t *stereo1, const uint8_t *stereo2, int only_stereo, double mad_factor, int32_t *match12)
+{
+    for (int q = 0; q < n1; q++) match12[q] = -1;
+    if (n1 <= 0 || n2 < 2) return 0;
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * 2 * n1), *dist = (int32_t *)malloc(sizeof(int32_t) * 2 * n1);
+    orc_knn2_hamming(desc1, n1, desc2, n2, idx, dist);
+    double nn_mad, nn12_mad;
+    orc_line_mad(dist, n1, &nn_mad, &nn12_mad);
+    const double th12 = nn12_mad * mad_factor;
+    int n = 0;
+    for (int q = 0; q < n1; q++) {
+        const int t = idx[2 * q];
+        const double d12 = (double)((float)dist[2 * q + 1] - (float)dist[2 * q]);
+        if (!(d12 > th12)) continue;
+        if (has_ml1[q] || has_ml2[t]) continue;
+        if (only_stereo && (!stereo1[q] || !stereo2[t])) continue;
+        match12[q] = t; n++;
+    }
+    free(idx); free(dist);
+    return n;
+}
+
+/* int LSDmatcher::Fuse(KeyFrame *pKF, const vector<MapLine*> &vpMapLines)   include/LSDmatcher.h:58 (LocalMapping::SearchInNeighbors) -- the search
+ * half.  PL-SLAM family: no projection (the signature has no th); for every map line that is non-NULL, not bad and not already in the keyframe
+ * (valid[i]) the keyframe line with the smallest Hamming distance to MapLine::mLDescriptor over ALL of pKF->mLineDescriptors (first minimum),
+ * fused when that distance is <= TH_LOW.  best_idx[i] = keyframe line or -1; returns the number fused.  The map mutation (Replace / AddObservation /
+ * AddMapLine, decided by pKF->GetMapLine(best_idx)) is the caller's, in list order, as for ORBmatcher::Fuse. */
+int orc_lines_fuse(const uint8_t *kf_desc, int n_kf, const uint8_t *ml_desc, const uint8_t *valid, int m, int32_t *best_idx)
+{
+    int nfused = 0;
+    for (int i = 0; i < m; i++) {
+        best_idx[i] = -1;
+        if (!valid[i]) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int j = 0; j < n_kf; j++) {
+            const int d = orc_hamming256(ml_desc + 32 * (size_t)i, kf_desc + 32 * (size_t)j);
+            if (d < bestDist) { bestDist = d; bestIdx = j; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nfused++; }
+    }
+    return nfused;
+}
+
 /* Frame::GetLinesInArea [UPSTREAM] */
 int orc_lines_in_area(const orc_lineframe *F, float x1, float y1, float x2, float y2, float r, int minLevel,
                       int maxLevel, int *out, int cap)

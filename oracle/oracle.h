@@ -127,6 +127,9 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
 void orc_line_mad(const int32_t *dist, int n, double *nn_mad, double *nn12_mad);
 int orc_match_lines_knn(const uint8_t *last_desc, int nlast, const uint8_t *cur_desc, int ncur,
                         const uint8_t *last_has_mapline, int32_t *match_of_line);
+int orc_lines_search_for_triangulation(const uint8_t *desc1, int n1, const uint8_t *desc2, int n2, const uint8_t *has_ml1, const uint8_t *has_ml2,
+                                       const uint8_t *stereo1, const uint8_t *stereo2, int only_stereo, double mad_factor, int32_t *match12);
+int orc_lines_fuse(const uint8_t *kf_desc, int n_kf, const uint8_t *ml_desc, const uint8_t *valid, int m, int32_t *best_idx);
 int orc_lines_in_area(const orc_lineframe *F, float x1, float y1, float x2, float y2, float r, int minLevel,
                       int maxLevel, int *out, int cap);
 int orc_search_by_projection_lines(const orc_lineframe *F, const orc_maplines *ML, float th, float nnratio,

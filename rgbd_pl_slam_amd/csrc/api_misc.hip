@@ -38,3 +38,53 @@ extern "C" int plf_hamming256(const uint8_t *a, const uint8_t *b)
     }
     return d;
 }
+
+// ---- device memory helpers for host code that does not link the HIP runtime itself (the C++ adapters of include/plf.hpp move the
+// Frame / MapPoint members the matchers read into HBM with these).  Plain wrappers: no state, no fallback.
+extern "C" int plf_device_alloc(int32_t device, size_t bytes, void **out)
+{
+    if (!out) return PLF_E_BADARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return PLF_E_HIP; }
+    if (device < 0 || device >= n) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(device));
+    if (hipMalloc(out, bytes ? bytes : 256) != hipSuccess) { (void)hipGetLastError(); return PLF_E_NOMEM; }
+    return PLF_OK;
+}
+
+extern "C" void plf_device_free(void *p) { if (p) (void)hipFree(p); }
+
+// stream == NULL means "synchronous": the handles run on their own NON-BLOCKING streams, which the legacy null stream does not order with, so a
+// null-stream upload must be complete before the next enqueue and a null-stream download must wait for everything the device is still running.
+extern "C" int plf_upload(void *dst_device, const void *src_host, size_t bytes, void *stream)
+{
+    if (bytes == 0) return PLF_OK;
+    if (!dst_device || !src_host) return PLF_E_BADARG;
+    if (!stream) { PLF_HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice)); return PLF_OK; }
+    PLF_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return PLF_OK;
+}
+
+extern "C" int plf_download(void *dst_host, const void *src_device, size_t bytes, void *stream)
+{
+    if (bytes == 0) return PLF_OK;
+    if (!dst_host || !src_device) return PLF_E_BADARG;
+    if (!stream) {
+        PLF_HIP_TRY(hipDeviceSynchronize());
+        PLF_HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+        return PLF_OK;
+    }
+    PLF_HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PLF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return PLF_OK;
+}
+
+extern "C" int plf_fill(void *dst_device, int32_t byte_value, size_t bytes, void *stream)
+{
+    if (bytes == 0) return PLF_OK;
+    if (!dst_device) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipMemsetAsync(dst_device, byte_value, bytes, (hipStream_t)stream));
+    if (!stream) PLF_HIP_TRY(hipStreamSynchronize(nullptr));
+    return PLF_OK;
+}

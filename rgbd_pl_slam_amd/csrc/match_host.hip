@@ -49,7 +49,9 @@ __global__ void k_project_kf_greedy(FrameDev, Pts3Dev, ProjKf, float, int *, int
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_batch(const uint8_t *, int, const LineFrameDev *, int *, int *, int);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
-__global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int, int, int, const LineFrameDev *);
+struct LineTriDev { const uint8_t *has_ml1, *has_ml2, *stereo1, *stereo2; int only_stereo; };
+__global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int, int, int, const LineFrameDev *, double, LineTriDev);
+__global__ void k_lines_fuse_pick(const int *, const int *, const uint8_t *, int, int *, int *);
 __global__ void k_match_project_lines(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
 __global__ void k_hamming_matrix(const uint8_t *, int, const uint8_t *, int, int *);
 
@@ -630,7 +632,7 @@ extern "C" int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_des
     int P2 = 1;
     while (P2 < nlast) P2 <<= 1;
     hipLaunchKernelGGL(k_lines_lastframe, dim3(1), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_idx, h->d_knn_dist, nlast,
-                       last_has_mapline, match_of_line, nmatches, P2, 0, 0, (const LineFrameDev *)nullptr);
+                       last_has_mapline, match_of_line, nmatches, P2, 0, 0, (const LineFrameDev *)nullptr, 0.5, LineTriDev{nullptr, nullptr, nullptr, nullptr, 0});
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }
@@ -658,7 +660,44 @@ extern "C" int plf_match_lines_lastframe_batch(plf_matcher *h, const uint8_t *la
     int P2 = 1;
     while (P2 < nlast) P2 <<= 1;
     hipLaunchKernelGGL(k_lines_lastframe, dim3(n_frames), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_idx, h->d_knn_dist, nlast, last_has_mapline,
-                       match_of_line, nmatches, P2, stride, line_stride, h->d_lframes);
+                       match_of_line, nmatches, P2, stride, line_stride, h->d_lframes, 0.5, LineTriDev{nullptr, nullptr, nullptr, nullptr, 0});
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_lines_triangulation(plf_matcher *h, const uint8_t *desc1, int32_t n1, const uint8_t *desc2, int32_t n2, const uint8_t *has_ml1,
+                                             const uint8_t *has_ml2, const uint8_t *stereo1, const uint8_t *stereo2, int32_t only_stereo, float mad_factor,
+                                             int32_t *match12, int32_t *nmatches, void *stream)
+{
+    if (!h || !desc1 || !desc2 || !has_ml1 || !has_ml2 || !match12 || !nmatches || n1 < 0 || n2 < 0 || n1 > h->max_lines || n2 > h->max_lines ||
+        (only_stereo && (!stereo1 || !stereo2)) || !(mad_factor >= 0.f))
+        return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    if (n1 > 0) PLF_HIP_TRY(hipMemsetAsync(match12, 0xFF, sizeof(int32_t) * (size_t)n1, s));
+    if (n1 <= 0 || n2 < 2) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int), s)); return PLF_OK; }
+    hipLaunchKernelGGL(k_knn2, dim3((n1 + 127) / 128), dim3(128), 0, s, desc1, n1, desc2, n2, h->d_knn_idx, h->d_knn_dist);
+    int P2 = 1;
+    while (P2 < n1) P2 <<= 1;
+    hipLaunchKernelGGL(k_lines_lastframe, dim3(1), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_idx, h->d_knn_dist, n1, (const uint8_t *)nullptr, match12,
+                       nmatches, P2, 0, 0, (const LineFrameDev *)nullptr, (double)mad_factor, LineTriDev{has_ml1, has_ml2, stereo1, stereo2, only_stereo ? 1 : 0});
+    PLF_HIP_TRY(hipGetLastError());
+    return PLF_OK;
+}
+
+extern "C" int plf_match_lines_fuse(plf_matcher *h, const uint8_t *kf_desc, int32_t n_kf, const uint8_t *ml_desc, const uint8_t *valid, int32_t m,
+                                    int32_t *best_idx, int32_t *nfused, void *stream)
+{
+    if (!h || !kf_desc || !ml_desc || !valid || !best_idx || !nfused || n_kf < 0 || m < 0 || n_kf > h->max_lines || m > h->max_lines) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PLF_HIP_TRY(hipMemsetAsync(nfused, 0, sizeof(int), s));
+    if (m == 0) return PLF_OK;
+    // brute force over ALL keyframe lines: the 2-NN table of (map lines -> keyframe lines); n_kf == 0 leaves idx = -1
+    hipLaunchKernelGGL(k_knn2, dim3((m + 127) / 128), dim3(128), 0, s, ml_desc, m, kf_desc, n_kf, h->d_knn_idx, h->d_knn_dist);
+    hipLaunchKernelGGL(k_lines_fuse_pick, dim3((m + 255) / 256), dim3(256), 0, s, h->d_knn_idx, h->d_knn_dist, valid, m, best_idx, nfused);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

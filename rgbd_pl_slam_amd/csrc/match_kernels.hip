@@ -1201,13 +1201,16 @@ __device__ void block_sort_floats(float *v, int n, int P2)
     (void)n;
 }
 
-// Frame::lineDescriptorMAD + LSDmatcher::SearchByProjection(CurrentFrame, LastFrame); one block, nlast <= cap (power of two >= nlast)
+// Frame::lineDescriptorMAD + LSDmatcher::SearchByProjection(CurrentFrame, LastFrame); one block per current frame, nlast <= P2 (power of two)
+// tri != NULL: LSDmatcher::SearchForTriangulation (include/LSDmatcher.h:54) on the same 2-NN table -- queries = keyframe-1 lines, a pair (q, t) is kept
+// when neither line holds a MapLine (and, with only_stereo, both have stereo data); match_all[q] = t.
+struct LineTriDev { const uint8_t *has_ml1, *has_ml2, *stereo1, *stereo2; int only_stereo; };
 __global__ void __launch_bounds__(256) k_lines_lastframe(const int *__restrict__ idx_all, const int *__restrict__ dist_all, int nlast,
                                                          const uint8_t *__restrict__ last_has_mapline, int *__restrict__ match_all,
                                                          int *__restrict__ nmatches_all, int P2, int knn_stride, int line_stride,
-                                                         const LineFrameDev *__restrict__ frames)
+                                                         const LineFrameDev *__restrict__ frames, double mad_factor, LineTriDev tri)
 {
-    // blockIdx.x = current frame of the batch (one frame: strides unused, ncur_* NULL)
+    // blockIdx.x = current frame of the batch (one frame: strides unused, frames NULL)
     const int *idx = idx_all + (size_t)blockIdx.x * knn_stride, *dist = dist_all + (size_t)blockIdx.x * knn_stride;
     int *match_of_line = match_all + (size_t)blockIdx.x * line_stride, *nmatches = nmatches_all + blockIdx.x;
     if (frames) {   // fewer than two current lines: knnMatch(k = 2) has no second neighbour, nothing is matched
@@ -1231,17 +1234,39 @@ __global__ void __launch_bounds__(256) k_lines_lastframe(const int *__restrict__
         v[i] = i < nlast ? fabsf((float)((double)((float)dist[2 * i + 1] - (float)dist[2 * i]) - med)) : INF;
     __syncthreads();
     block_sort_floats(v, nlast, P2);
-    const double th12 = 1.4826 * (double)v[nlast / 2] * 0.5;
+    const double th12 = 1.4826 * (double)v[nlast / 2] * mad_factor;
     __syncthreads();
     for (int q = t; q < nlast; q += T) {
         const double d12 = (double)((float)dist[2 * q + 1] - (float)dist[2 * q]);
-        if (d12 > th12 && last_has_mapline[q]) {
-            atomicMax(&match_of_line[idx[2 * q]], q);  // queries are visited in increasing order: the last one wins
+        if (!(d12 > th12)) continue;
+        const int tr = idx[2 * q];
+        if (tri.has_ml1) {
+            if (tri.has_ml1[q] || tri.has_ml2[tr]) continue;
+            if (tri.only_stereo && (!tri.stereo1[q] || !tri.stereo2[tr])) continue;
+            match_of_line[q] = tr;
+            atomicAdd(&s_cnt, 1);
+        } else if (last_has_mapline[q]) {
+            atomicMax(&match_of_line[tr], q);  // queries are visited in increasing order: the last one wins
             atomicAdd(&s_cnt, 1);
         }
     }
     __syncthreads();
     if (t == 0) *nmatches = s_cnt;
+}
+
+// LSDmatcher::Fuse (include/LSDmatcher.h:58), search half: best[i] = nearest keyframe line of map line i (first minimum of the brute-force scan:
+// idx[2i] of the 2-NN table) when the map line is valid and that distance is <= TH_LOW
+__global__ void __launch_bounds__(256) k_lines_fuse_pick(const int *__restrict__ idx, const int *__restrict__ dist, const uint8_t *__restrict__ valid, int m,
+                                                         int *__restrict__ best, int *__restrict__ nfused)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    if (i < m) {
+        ok = valid[i] && idx[2 * i] >= 0 && dist[2 * i] <= TH_LOW;
+        best[i] = ok ? idx[2 * i] : -1;
+    }
+    const unsigned long long mk = __ballot(ok);
+    if (plf_lane() == 0 && mk) atomicAdd(nfused, __popcll(mk));
 }
 
 struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; const float *view_cos; const uint8_t *in_view; const uint8_t *desc; };

@@ -221,6 +221,17 @@ class Matcher:
                                                   L.vp(last_has_mapline), L.vp(match_of_line), L.vp(nmatches),
                                                   C.c_void_p(stream) if stream else None), "plf_match_lines_lastframe")
 
+    def SearchLinesForTriangulation(self, desc1, desc2, has_ml1, has_ml2, stereo1, stereo2, only_stereo, match12, nmatches, mad_factor=0.1, stream=None):
+        """LSDmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo); device tensors; match12[q] = keyframe-2 line or -1"""
+        L.check(L.lib().plf_match_lines_triangulation(self._h, L.vp(desc1), int(desc1.shape[0]), L.vp(desc2), int(desc2.shape[0]), L.vp(has_ml1), L.vp(has_ml2),
+                                                      L.vp(stereo1), L.vp(stereo2), int(bool(only_stereo)), C.c_float(mad_factor), L.vp(match12), L.vp(nmatches),
+                                                      C.c_void_p(stream) if stream else None), "plf_match_lines_triangulation")
+
+    def FuseLines(self, kf_desc, ml_desc, valid, best_idx, nfused, stream=None):
+        """LSDmatcher::Fuse(pKF, vpMapLines), search half: best_idx[i] = keyframe line fused with map line i, -1 none"""
+        L.check(L.lib().plf_match_lines_fuse(self._h, L.vp(kf_desc), int(kf_desc.shape[0]), L.vp(ml_desc), L.vp(valid), int(ml_desc.shape[0]), L.vp(best_idx),
+                                             L.vp(nfused), C.c_void_p(stream) if stream else None), "plf_match_lines_fuse")
+
     @staticmethod
     def lineframe_view(n, lines_un, desc, scale_factors, n_device=None):
         v = L.LineFrameView()

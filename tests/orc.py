@@ -221,6 +221,23 @@ def knn2(q, t):
     return idx, dist
 
 
+def lines_search_for_triangulation(desc1, desc2, has_ml1, has_ml2, stereo1, stereo2, only_stereo, mad_factor=0.1):
+    L = lib()
+    a = [np.ascontiguousarray(x, np.uint8) for x in (desc1, desc2, has_ml1, has_ml2, stereo1, stereo2)]
+    match = np.full(len(desc1), -1, np.int32)
+    n = L.orc_lines_search_for_triangulation(p(a[0]), C.c_int(len(desc1)), p(a[1]), C.c_int(len(desc2)), p(a[2]), p(a[3]), p(a[4]), p(a[5]),
+                                             C.c_int(int(only_stereo)), C.c_double(mad_factor), p(match))
+    return match, n
+
+
+def lines_fuse(kf_desc, ml_desc, valid):
+    L = lib()
+    a = [np.ascontiguousarray(x, np.uint8) for x in (kf_desc, ml_desc, valid)]
+    best = np.full(len(ml_desc), -1, np.int32)
+    n = L.orc_lines_fuse(p(a[0]), C.c_int(len(kf_desc)), p(a[1]), p(a[2]), C.c_int(len(ml_desc)), p(best))
+    return best, n
+
+
 def match_lines_knn(last_desc, cur_desc, has_ml):
     L = lib()
     a = np.ascontiguousarray(last_desc); b = np.ascontiguousarray(cur_desc); hm = np.ascontiguousarray(has_ml, np.uint8)

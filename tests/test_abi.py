@@ -104,3 +104,15 @@ int main() {
     from conftest import gpu_available
     if not gpu_available():
         assert out.count("error -4") == 2
+
+
+def test_exact_signature_adapters_compile_against_the_mock_headers(tmp_path):
+    """include/plf.hpp under PLF_WITH_OPENCV: ORBextractor::operator()(InputArray, ...), LineSegment::ExtractLineSegment(Mat, ...),
+    ORBmatcher::SearchByProjection x2, LSDmatcher::SearchByProjection x3 / SearchForTriangulation / Fuse with the reference's signatures, instantiated
+    over mock Frame / KeyFrame / MapPoint / MapLine classes that carry the reference's member names (tests/mock/) -- compiled and linked here (no GPU:
+    the driver is only built, tests/test_gpu_cpp_mirror.py runs it)."""
+    exe = tmp_path / "mirror_driver"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror=return-type", "-DPLF_WITH_OPENCV", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "tests", "mock"), os.path.join(ROOT, "tests", "cpp", "mirror_driver.cpp"), "-o", str(exe), LIB,
+                           "-Wl,-rpath," + os.path.dirname(LIB), "-Wl,-rpath,/opt/rocm/lib"])
+    assert exe.exists()

@@ -290,6 +290,59 @@ def test_line_matcher_scenes(sc):
     m.close()
 
 
+LINE_KF_SCENES = [
+    # lines in keyframe 1 / 2, how many of keyframe 1's lines reappear in keyframe 2, bit flips, share with a MapLine (kf1, kf2), share with stereo, bOnlyStereo, MAD factor
+    dict(s1=30, s2=31, n=120, keep=90, flips=12, ml1=0.3, ml2=0.3, st=0.7, only=0, f=0.1),
+    dict(s1=32, s2=33, n=200, keep=60, flips=40, ml1=0.0, ml2=0.0, st=0.5, only=1, f=0.1),
+    dict(s1=34, s2=35, n=60, keep=60, flips=0, ml1=0.5, ml2=0.1, st=1.0, only=1, f=0.5),     # exact copies: distance 0 and ties
+    dict(s1=36, s2=37, n=40, keep=1, flips=3, ml1=1.0, ml2=0.0, st=0.0, only=0, f=0.1),      # every keyframe-1 line already has a MapLine: nothing to pair
+    dict(s1=38, s2=39, n=150, keep=100, flips=25, ml1=0.2, ml2=0.6, st=0.0, only=1, f=0.0),  # no stereo data at all with bOnlyStereo: nothing; factor 0
+]
+
+
+@pytest.mark.parametrize("sc", LINE_KF_SCENES, ids=lambda sc: "kf%d_n%d_keep%d_only%d" % (sc["s1"], sc["n"], sc["keep"], sc["only"]))
+def test_line_triangulation_and_fuse(sc):
+    """SURVEY 8f rank 3, the two remaining LSDmatcher overloads (include/LSDmatcher.h:54,58): SearchForTriangulation (kNN + MAD, unmatched lines only,
+    bOnlyStereo) and Fuse (nearest keyframe line over all of them, TH_LOW) -- bit-equal to the oracle; "parity unpinned" like rows 13 / 14"""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    from rgbd_pl_slam_amd.synth import synth_frame
+    a = orc.line_extract(synth_frame(sc["s1"]), sc["n"]); b = orc.line_extract(synth_frame(sc["s2"]), sc["n"])
+    rng = np.random.default_rng(200 + sc["s1"])
+    keep = min(sc["keep"], len(a["desc"]))
+    d1 = a["desc"]
+    d2 = np.concatenate([matchgen.flip_bits(d1[:keep], rng, sc["flips"]), b["desc"][:max(len(b["desc"]) - keep, 2)]])
+    d2 = np.ascontiguousarray(d2[rng.permutation(len(d2))])
+    ml1 = (rng.uniform(0, 1, len(d1)) < sc["ml1"]).astype(np.uint8); ml2 = (rng.uniform(0, 1, len(d2)) < sc["ml2"]).astype(np.uint8)
+    st1 = (rng.uniform(0, 1, len(d1)) < sc["st"]).astype(np.uint8); st2 = (rng.uniform(0, 1, len(d2)) < sc["st"]).astype(np.uint8)
+    ref, rn = orc.lines_search_for_triangulation(d1, d2, ml1, ml2, st1, st2, sc["only"], sc["f"])
+    m = Matcher(max_lines=1024, max_mappoints=64)
+    match = torch.zeros(len(d1), dtype=torch.int32, device="cuda"); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    t = [_dev(x) for x in (d1, d2, ml1, ml2, st1, st2)]
+    m.SearchLinesForTriangulation(t[0], t[1], t[2], t[3], t[4], t[5], sc["only"], match, nm, mad_factor=sc["f"])
+    torch.cuda.synchronize()
+    assert int(nm[0]) == rn and np.array_equal(match.cpu().numpy(), ref)
+    if sc["ml1"] == 1.0 or (sc["only"] and sc["st"] == 0.0):
+        assert rn == 0
+    # fewer than two keyframe-2 lines: knnMatch(k = 2) has no second neighbour
+    m.SearchLinesForTriangulation(t[0], t[1][:1], t[2], t[3][:1], t[4], t[5][:1], 0, match, nm)
+    torch.cuda.synchronize()
+    assert int(nm[0]) == 0 and (match.cpu().numpy() == -1).all()
+    # Fuse: the keyframe's lines = d2, map lines = descriptors of keyframe 1's lines with a few flips (true duplicates) + unrelated ones
+    mld = np.concatenate([matchgen.flip_bits(d1[:keep], rng, 2 * sc["flips"]), rng.integers(0, 256, (25, 32), dtype=np.uint8)])
+    valid = (rng.uniform(0, 1, len(mld)) < 0.85).astype(np.uint8)
+    fb, fn = orc.lines_fuse(d2, mld, valid)
+    best = torch.zeros(len(mld), dtype=torch.int32, device="cuda"); nf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dk, dm, dv = _dev(d2), _dev(mld), _dev(valid)
+    m.FuseLines(dk, dm, dv, best, nf)
+    torch.cuda.synchronize()
+    assert int(nf[0]) == fn and np.array_equal(best.cpu().numpy(), fb)
+    if keep > 10 and sc["flips"] <= 12:
+        assert fn > 5
+    m.close()
+
+
 def test_descriptor_distance_and_matrix():
     _need_gpu()
     import ctypes as C

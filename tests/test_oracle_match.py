@@ -40,3 +40,27 @@ def test_knn2_against_bruteforce():
     D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
     order = np.argsort(D, axis=1, kind="stable")
     assert np.array_equal(idx, order[:, :2]) and np.array_equal(dist, np.take_along_axis(D, order[:, :2], 1))
+
+
+def test_line_keyframe_overloads_properties():
+    """LSDmatcher::SearchForTriangulation / Fuse restatements (parity unpinned): structural properties of the rules"""
+    rng = np.random.default_rng(5)
+    d1 = rng.integers(0, 256, (80, 32), dtype=np.uint8)
+    d2 = np.concatenate([d1[:50][::-1].copy(), rng.integers(0, 256, (30, 32), dtype=np.uint8)])   # 50 exact duplicates, reversed
+    none = np.zeros(80, np.uint8); yes = np.ones(80, np.uint8)
+    m, n = orc.lines_search_for_triangulation(d1, d2, none, none, yes, yes, 0, 0.1)
+    assert n == int((m >= 0).sum()) and n >= 50
+    assert np.array_equal(m[:50], np.arange(49, -1, -1))                     # the duplicate is the nearest neighbour with distance 0
+    m2, n2 = orc.lines_search_for_triangulation(d1, d2, yes, none, yes, yes, 0, 0.1)
+    assert n2 == 0 and (m2 == -1).all()                                      # keyframe-1 lines that hold a MapLine are never paired
+    st1 = np.zeros(80, np.uint8); st1[::2] = 1
+    m3, n3 = orc.lines_search_for_triangulation(d1, d2, none, none, st1, yes, 1, 0.1)
+    assert (m3[1::2] == -1).all() and np.array_equal(m3[::2], m[::2])         # bOnlyStereo drops the lines without stereo data, nothing else changes
+    assert orc.lines_search_for_triangulation(d1, d2[:1], none, none[:1], yes, yes[:1], 0, 0.1)[1] == 0
+    best, nf = orc.lines_fuse(d2, d1, yes)
+    assert np.array_equal(best[:50], np.arange(49, -1, -1)) and nf >= 50
+    valid = yes.copy(); valid[:10] = 0
+    best2, nf2 = orc.lines_fuse(d2, d1, valid)
+    assert (best2[:10] == -1).all() and np.array_equal(best2[10:], best[10:]) and nf2 == nf - 10
+    far = orc.lines_fuse(d2[50:], d1[:50], yes[:50])                         # random 256-bit descriptors are ~128 bits apart: above TH_LOW
+    assert far[1] == 0
