@@ -154,6 +154,16 @@ class Pipeline:
         mat.SearchLinesLastFrameBatch(self.last_ldesc, self.last_has_ml, bs["lviews"], bs["match_ln_last"], self.nlines, bs["nm_ln_last"], sM.cuda_stream)
         bs["match_done"] = torch.cuda.Event(); bs["match_done"].record(sM)
 
+    def match_step(self):
+        """BASELINE configs[4]: only the matchers, on the features the last step() left in buffer set 0"""
+        bs = self.bufs[0]; sM = self.sM; mat = self.mats[0]
+        with self.torch.cuda.stream(sM):
+            bs["match_kp"].fill_(-1); bs["match_kp_last"].fill_(-1); bs["match_ln"].fill_(-1); bs["match_ln_last"].fill_(-1)
+        mat.SearchByProjection(bs["fviews"], self.mp, 3.0, 0.8, bs["match_kp"], self.cap, bs["nm_kp"], sM.cuda_stream)
+        mat.SearchByProjectionLastFrameBatch(bs["fviews"], self.last_view, self.poses, 7.0, 0, 1, bs["match_kp_last"], self.cap, bs["nm_kp_last"], sM.cuda_stream)
+        mat.SearchLinesByProjection(bs["lviews"], self.ml, 3.0, 0.8, bs["match_ln"], self.nlines, bs["nm_ln"], sM.cuda_stream)
+        mat.SearchLinesLastFrameBatch(self.last_ldesc, self.last_has_ml, bs["lviews"], bs["match_ln_last"], self.nlines, bs["nm_ln_last"], sM.cuda_stream)
+
     def check(self):
         # the device-resident calls return before the GPU has run: a capacity overflow would make the step's outputs (and its time) meaningless
         for l in self.lins:

@@ -410,6 +410,7 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
         }
     }
     if (w->line) {
+        if (s.h_status[1] & 4) return PLF_E_HIP;
         if (s.h_status[1] & 1) {
             // pooled NFA buffers exceeded by this chunk (pathological textures): redo it through the host-memory entry point, which
             // halves the batch until it fits (line_host.hip).  Stream-ordered after everything queued on the line stream.

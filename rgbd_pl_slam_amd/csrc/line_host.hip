@@ -42,6 +42,7 @@ struct plf_line {
     plf_line_params prm;
     SpecBufs spec;            // banded speculative region growing (few frames in flight); allocated on first use
     int spec_frames;          // frames the buffers were sized for (0: not allocated, -1: allocation failed / disabled)
+    size_t fused_lds, fused_capacity;   // k_lsd_spec_fused: workgroups of that LDS size the GPU can hold at once (occupancy query)
     int *d_spec_stats;
     int device;
     LsdGeom g;
@@ -406,7 +407,17 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
         // finish, and the bands are staggered for that; otherwise two launches with equal bands
-        const bool fused = (size_t)B * (spec_bands + 1) <= 448 && !getenv("PLF_LSD_SPEC_NOFUSE");
+        // ... and only while EVERY workgroup of the launch can be resident at the same time: the commit workgroups wait for band workgroups of the
+        // same launch, and HIP does not promise a dispatch order (occupancy query per launch configuration, cached)
+        if (h->fused_lds != lds_commit) {
+            int per_cu = 0, cus = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_lsd_spec_fused, 256, lds_commit) != hipSuccess ||
+                hipGetDeviceProperties(&prop, h->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; cus = 0; }
+            else cus = prop.multiProcessorCount;
+            h->fused_lds = lds_commit; h->fused_capacity = (size_t)per_cu * (size_t)cus;
+        }
+        const bool fused = (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !getenv("PLF_LSD_SPEC_NOFUSE");
         h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(1024), 0, s, h->d_ang, g, h->spec);
         if (fused) {
@@ -504,6 +515,7 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
         }
     }
     PLF_HIP_TRY(hipStreamSynchronize(s));
+    if (status & 4) return PLF_E_HIP;   // the fused speculative launch gave up waiting for a band wave (never seen; see spec_wait_band)
     if (status & 1) {
         // The batch as a whole produced more rectangles than the pooled NFA buffers hold (thousands per frame on average: synthetic textures).
         // One frame always fits, so the batch is redone in halves.
@@ -533,7 +545,7 @@ extern "C" int plf_line_last_status(plf_line *h, void *stream)
     int status = 0;
     PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
-    return (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : PLF_OK;
+    return (status & 4) ? PLF_E_HIP : (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : PLF_OK;
 }
 
 // batch driver (batch_host.hip): the status word of the batch just enqueued on `s`, copied to pinned host memory in stream order

@@ -1021,10 +1021,18 @@ template <bool SG> struct SpecS {
     }
 };
 
-__device__ __forceinline__ void spec_wait_band(const SpecBufs &SB, size_t fb)
+// The one-launch schedule makes the commit wave of a frame wait for the band waves of the same launch.  The host only uses it when ALL workgroups of
+// the launch can be resident at once (occupancy query), so every band wave is dispatched whatever the dispatch order; the spin is bounded all the
+// same (~2^21 x 3 us): a scheduling surprise then surfaces as status bit 4 -> PLF_E_HIP for the batch instead of a hung GPU.
+__device__ __forceinline__ bool spec_wait_band(const SpecBufs &SB, size_t fb, int *status)
 {
-    while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(127);
+    int spins = 0;
+    while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(127);
+        if (++spins > (1 << 21)) { atomicOr(status, 4); return false; }
+    }
     __threadfence();
+    return true;
 }
 
 // 64 bits of a bitmap starting at bit p (any alignment); words past the end read as zero
@@ -1058,7 +1066,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         const uint32_t *sm = SB.seedmap + (size_t)f * SB.bm_words;
         for (int b = 0; b < SB.nbands; b++) {
             const size_t fb = (size_t)f * SB.nbands + b;
-            spec_wait_band(SB, fb);
+            if (!spec_wait_band(SB, fb, status)) return;
             const int nrec = SB.cnt[fb * 4 + 0], tn = SB.cnt[fb * 4 + 1];
             const uint32_t *r = reinterpret_cast<const uint32_t *>(SB.recs + fb * SB.rcap_rec);
             for (int i = t * 32; i < nrec * (int)(sizeof(SpecRec) / 4); i += 192 * 32) acc ^= r[i];
@@ -1097,7 +1105,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     const long long c_t0 = clock64();
     for (int band = 0; band < SB.nbands; band++) {
         const size_t fb = (size_t)f * SB.nbands + band;
-        spec_wait_band(SB, fb);
+        if (!spec_wait_band(SB, fb, status)) return;
         const long long c_s0 = clock64();
         if (stats && f == 0 && lane == 0 && band < 64) { stats[8 + 3 * band] = SB.cnt[fb * 4 + 3]; stats[8 + 3 * band + 1] = (int)(wall_clock64() & 0x7fffffff); }
         const int use_recs = SB.cnt[fb * 4 + 2] == 0;   // a band whose log overflowed is simply grown here

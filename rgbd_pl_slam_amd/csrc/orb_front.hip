@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__
     const int cx0 = 2 * tx, cx1 = min(cx0 + 2, L.ncx), cy0 = 2 * ty, cy1 = min(cy0 + 2, L.ncy);
     const int rx0 = PLF_EDGE + cx0 * L.wCell, rx1 = cx1 == L.ncx ? L.rex : PLF_EDGE + cx1 * L.wCell;   // bounding box of the cells' computed regions
     const int ry0 = PLF_EDGE + cy0 * L.hCell, ry1 = cy1 == L.ncy ? L.rey : PLF_EDGE + cy1 * L.hCell;
-    const int xm = cx1 - cx0 == 2 ? rx0 + L.wCell : rx1, ym = cy1 - cy0 == 2 ? ry0 + L.hCell : ry1;   // where the second cell column / row starts
+    // where the second cell column / row of the tile starts -- clamped: the LAST cell's sub-image is cut at the level border (maxBorder), which can leave
+    // the cell before it a shorter computed region than wCell / hCell and the last one none at all
+    const int xm = cx1 - cx0 == 2 ? min(rx0 + L.wCell, rx1) : rx1, ym = cy1 - cy0 == 2 ? min(ry0 + L.hCell, ry1) : ry1;
     const int xs = tx == 0 ? 0 : rx0, xe = tx == L.tcx - 1 ? W : rx1;                                   // owned part of the level image
     const int ys = ty == 0 ? 0 : ry0, ye = ty == L.tcy - 1 ? H : ry1;
     const int ex0 = (xs & ~3) - 4, EW = ((xe - 1) & ~3) + 8 - ex0;                                     // tile columns: owned + halo, 4-aligned
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__
         // bytes as int16 lanes and v_dot2 multiplies them with the (a0, a1) pair
         const uint32_t rcp_g = 0xFFFFFFFFu / (uint32_t)ngrp + 1u;   // i / ngrp = umulhi(i, rcp_g) for i < 65536
         for (int i = tid; i < ngrp * EH; i += OF_NT) {
-            const int ey = (int)__umulhi((uint32_t)i, rcp_g), c4 = (i - ey * ngrp) * 4;
+            const int ey = ngrp > 1 ? (int)__umulhi((uint32_t)i, rcp_g) : i, c4 = (i - ey * ngrp) * 4;
             const OrbRowTab ty_ = YT[ey];
             const uint8_t *r0 = SRC + ty_.off * SPW, *r1 = SRC + ty_.nxt * SPW;
             {
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__
         for (int i0 = 0; i0 < nit; i0 += OF_NT) {   // (uniform trip count: the ballots below need every lane)
             {
                 const int i = i0 + tid;
-                const int ry = (int)__umulhi((uint32_t)i, rcp_r), c4 = cA + (i - ry * ngr) * 4;
+                const int ry = ngr > 1 ? (int)__umulhi((uint32_t)i, rcp_r) : i, c4 = cA + (i - ry * ngr) * 4;   // (ngr == 1: the reciprocal does not fit 32 bits)
                 uint32_t poss = 0;
                 if (i < nit) {
                     const uint8_t *prow = P + (ry0 + ry - ey0) * PW + c4;

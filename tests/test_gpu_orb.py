@@ -154,3 +154,23 @@ def test_get_tables_equals_reference_ctor_fixture():
         ext.close()
         done += 1
     assert done >= 3, "only %d of %d reference parameter sets fit a handle" % (done, len(cases))
+
+
+@pytest.mark.parametrize("w,h,sf,nlev,ini,mn,nf", [(1280, 960, 1.1, 8, 26, 5, 2000), (1280, 960, 1.1, 3, 38, 6, 3000), (723, 542, 1.3, 5, 20, 7, 800)])
+def test_level_geometries_with_clamped_last_cells(w, h, sf, nlev, ini, mn, nf):
+    """regressions found by tools/soak.py in the fused level kernel: a level whose LAST cell row / column is cut at the border so that the cell
+    before it has a shorter computed region than hCell / wCell (and the last one none), and a last tile that is a single 4-column group wide
+    (e.g. the 1164x873 and 723x542 levels of a 1280x960 pyramid at scale 1.1); every level compared stage by stage"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import ORBextractor
+    from rgbd_pl_slam_amd.synth import synth_frame
+    img = synth_frame(31, w, h)
+    ref = orc.orb_extract(img, nfeatures=nf, scale_factor=sf, nlevels=nlev, ini_th=ini, min_th=mn, debug=True)
+    e = ORBextractor(nfeatures=nf, scaleFactor=sf, nlevels=nlev, iniThFAST=ini, minThFAST=mn, max_width=w, max_height=h)
+    kps, desc = e(img)
+    for l in range(nlev):
+        assert np.array_equal(e.pyramid_level(0, l), ref["pyr"][l]), "pyramid level %d" % l
+        assert np.array_equal(e.blurred_level(0, l), ref["blur"][l]), "blurred level %d" % l
+        assert len(e.candidates(0, l)) == ref["ncand"][l], "FAST candidates of level %d" % l
+    assert kps.tobytes() == ref["kps"].tobytes() and np.array_equal(desc, ref["desc"])
+    e.close()
