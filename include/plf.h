@@ -505,6 +505,7 @@ typedef struct {
     int32_t input_format;      /* PLF_FMT_* of the frames handed to plf_batch_extract */
     int32_t max_mappoints;     /* > 0: a matcher per GPU; capacity of the local-map replicas (plf_batch_set_local_map) */
     int32_t max_maplines;
+    int32_t rgbd;              /* 1: also allocate the depth / Frame-tail buffers of plf_batch_extract_rgbd */
 } plf_batch_params;
 
 /* Host-side outputs of one batch: n_frames x capacity entries, frame f at index f * capacity (same layout as
@@ -540,6 +541,25 @@ int plf_batch_set_local_map(plf_batch *b, const plf_mappoint_view *points, const
  * capacity; outputs truncated) or the first hard error of any worker. */
 int plf_batch_extract(plf_batch *b, const uint8_t *images, int64_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch,
                       ptrdiff_t frame_stride, const plf_batch_outputs *out);
+
+/* RGB-D frames: the whole RGB-D Frame constructor (include/Frame.h:60; called by Tracking::GrabImageRGBD include/Tracking.h:69, which first
+ * converts the colour image to gray, so@0x522e6, and the depth image with mDepthMapFactor, so@0x5206d, include/Tracking.h:233) for a batch of
+ * independent frames: ExtractORB + ExtractLSD, then UndistortKeyPoints (so@0xf8630), ComputeStereoFromRGBD (so@0xf6860) and the line half
+ * (UndistortKeyLines include/Frame.h:267, end-point depths :208-211) on the device, i.e. plf_frame_tail / plf_frame_line_tail applied to every
+ * frame of the batch before anything is copied back.  With a local map set, SearchByProjection then reads mvKeysUn / mvuRight / mvKeylinesUn as
+ * the reference does (without this call it sees the distorted key points and uright = none).  Requires plf_batch_params.rgbd = 1.
+ * depth: n_frames images of uint16 (the TUM png files; depth_factor = 1 / DepthMapFactor, Examples/RGB-D/TUM1.yaml:35: 5000), HOST memory, rows
+ * depth_pitch_elems apart; NULL = no depth (uright = -1, depths = -1: the monocular rule of the same functions).
+ * Outputs use kp_capacity / line_capacity of `out`; any pointer may be NULL. */
+typedef struct {
+    plf_camera cam;
+    float depth_factor;
+    const uint16_t *depth; ptrdiff_t depth_pitch_elems, depth_frame_stride_elems;
+    plf_keypoint *kps_un; float *uright; float *kp_depth;                                   /* mvKeysUn, mvuRight, mvDepth */
+    plf_keyline *lines_un; float *uright_start, *uright_end, *depth_start, *depth_end;     /* mvKeylinesUn, mvuRightLineStart/End, mvDepthLineStart/End */
+} plf_batch_rgbd;
+int plf_batch_extract_rgbd(plf_batch *b, const uint8_t *images, int64_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch,
+                           ptrdiff_t frame_stride, const plf_batch_outputs *out, const plf_batch_rgbd *rgbd);
 
 /* Seconds the workers of the last plf_batch_extract spent (max over workers): [0] total, [1] staging copies into pinned
  * memory, [2] waiting for the GPU, [3] unpacking outputs. */

@@ -7,19 +7,27 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
+from .frame import Camera
 
 FMT_GRAY8, FMT_RGB8, FMT_BGR8 = 0, 1, 2
 
 
 class BatchParams(C.Structure):
     _fields_ = [("orb", L.OrbParams), ("line", L.LineParams), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)),
-                ("frames_in_flight", C.c_int32), ("input_format", C.c_int32), ("max_mappoints", C.c_int32), ("max_maplines", C.c_int32)]
+                ("frames_in_flight", C.c_int32), ("input_format", C.c_int32), ("max_mappoints", C.c_int32), ("max_maplines", C.c_int32), ("rgbd", C.c_int32)]
 
 
 class BatchOutputs(C.Structure):
     _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("n_kps", C.c_void_p), ("kp_capacity", C.c_int32),
                 ("lines", C.c_void_p), ("ldesc", C.c_void_p), ("line_eq", C.c_void_p), ("n_lines", C.c_void_p), ("line_capacity", C.c_int32),
                 ("match_of_kp", C.c_void_p), ("n_kp_matches", C.c_void_p), ("match_of_line", C.c_void_p), ("n_line_matches", C.c_void_p)]
+
+
+class BatchRgbd(C.Structure):
+    _fields_ = [("cam", Camera), ("depth_factor", C.c_float), ("depth", C.c_void_p), ("depth_pitch_elems", C.c_ssize_t),
+                ("depth_frame_stride_elems", C.c_ssize_t), ("kps_un", C.c_void_p), ("uright", C.c_void_p), ("kp_depth", C.c_void_p),
+                ("lines_un", C.c_void_p), ("uright_start", C.c_void_p), ("uright_end", C.c_void_p), ("depth_start", C.c_void_p),
+                ("depth_end", C.c_void_p)]
 
 
 def shard(n_frames, parts, part):
@@ -55,7 +63,7 @@ class BatchExtractor:
     the local map set with set_local_map)."""
 
     def __init__(self, nfeatures=1000, nlines=100, width=640, height=480, frames_in_flight=8, devices=None, scaleFactor=1.2, nlevels=8,
-                 iniThFAST=20, minThFAST=7, input_format=FMT_GRAY8, max_mappoints=0, max_maplines=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED):
+                 iniThFAST=20, minThFAST=7, input_format=FMT_GRAY8, max_mappoints=0, max_maplines=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED, rgbd=False):
         p = BatchParams()
         p.orb = L.OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, 0, width, height, 1)
         p.line = L.line_params(nlines, seed_order, 0, width, height, 1, lbd_sobel_input)
@@ -64,10 +72,12 @@ class BatchExtractor:
             self._devs = (C.c_int32 * len(devices))(*devices)
             p.n_devices = len(devices); p.devices = self._devs
         p.frames_in_flight = frames_in_flight; p.input_format = input_format
-        p.max_mappoints = max_mappoints; p.max_maplines = max_maplines
+        p.max_mappoints = max_mappoints; p.max_maplines = max_maplines; p.rgbd = int(bool(rgbd))
+        self.rgbd = bool(rgbd)
         self._h = C.c_void_p()
         lib = L.lib()
         lib.plf_batch_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_ssize_t, C.c_ssize_t, C.c_void_p]
+        lib.plf_batch_extract_rgbd.argtypes = lib.plf_batch_extract.argtypes + [C.c_void_p]
         L.check(lib.plf_batch_create(C.byref(p), C.byref(self._h)), "plf_batch_create")
         self.n_devices = lib.plf_batch_device_count(self._h)
         self.devices = [lib.plf_batch_device(self._h, i) for i in range(self.n_devices)]
@@ -119,9 +129,21 @@ class BatchExtractor:
             o["match_of_line"] = np.full((n, self.nlines), -1, np.int32); o["n_line_matches"] = np.zeros(n, np.int32)
         return o
 
-    def extract_into(self, images, out):
+    def alloc_rgbd_outputs(self, n):
+        o = {}
+        if self.nfeatures > 0:
+            o["kps_un"] = np.zeros((n, self.kp_capacity), L.KP_DTYPE)
+            o["uright"] = np.zeros((n, self.kp_capacity), np.float32); o["kp_depth"] = np.zeros((n, self.kp_capacity), np.float32)
+        if self.nlines > 0:
+            o["lines_un"] = np.zeros((n, self.nlines), L.KL_DTYPE)
+            for k in ("uright_start", "uright_end", "depth_start", "depth_end"):
+                o[k] = np.zeros((n, self.nlines), np.float32)
+        return o
+
+    def extract_into(self, images, out, depth=None, cam=None, depth_factor=1.0 / 5000.0, rgbd_out=None):
         """images: (n, H, W) uint8 (gray) or (n, H, W, 3); row / frame strides may be padded.  out: alloc_outputs(n).  Returns the status
-        (0 or PLF_E_CAPACITY)."""
+        (0 or PLF_E_CAPACITY).  With cam (a frame.Camera) the RGB-D Frame tail runs too (plf_batch_extract_rgbd): depth = (n, H, W) uint16 or
+        None, rgbd_out = alloc_rgbd_outputs(n)."""
         n, h, w = images.shape[:3]
         if images.dtype != np.uint8 or images.strides[2] != self.bpp or (self.bpp == 3 and (images.ndim != 4 or images.strides[3] != 1)):
             raise ValueError("uint8 frames with %d byte(s) per pixel expected" % self.bpp)
@@ -130,16 +152,30 @@ class BatchExtractor:
             if k in out:
                 setattr(O, k, out[k].ctypes.data)
         O.kp_capacity = self.kp_capacity; O.line_capacity = self.nlines
-        st = L.lib().plf_batch_extract(self._h, images.ctypes.data, n, w, h, images.strides[1], images.strides[0], C.byref(O))
+        if cam is None:
+            st = L.lib().plf_batch_extract(self._h, images.ctypes.data, n, w, h, images.strides[1], images.strides[0], C.byref(O))
+        else:
+            R = BatchRgbd()
+            R.cam = cam; R.depth_factor = depth_factor
+            if depth is not None:
+                if depth.dtype != np.uint16 or depth.shape[:3] != (n, h, w) or depth.strides[2] != 2:
+                    raise ValueError("depth: (n, H, W) uint16 expected")
+                R.depth = depth.ctypes.data; R.depth_pitch_elems = depth.strides[1] // 2; R.depth_frame_stride_elems = depth.strides[0] // 2
+            for k in ("kps_un", "uright", "kp_depth", "lines_un", "uright_start", "uright_end", "depth_start", "depth_end"):
+                if rgbd_out is not None and k in rgbd_out:
+                    setattr(R, k, rgbd_out[k].ctypes.data)
+            st = L.lib().plf_batch_extract_rgbd(self._h, images.ctypes.data, n, w, h, images.strides[1], images.strides[0], C.byref(O), C.byref(R))
         if st not in (L.PLF_OK, L.PLF_E_CAPACITY):
             L.check(st, "plf_batch_extract")
         return st
 
-    def extract(self, images):
-        """-> list of per-frame dicts (kps, desc, lines, ldesc, line_eq[, match_of_kp, n_kp_matches, match_of_line, n_line_matches])"""
+    def extract(self, images, depth=None, cam=None, depth_factor=1.0 / 5000.0):
+        """-> list of per-frame dicts (kps, desc, lines, ldesc, line_eq[, match_of_kp, n_kp_matches, match_of_line, n_line_matches]); with cam:
+        the RGB-D Frame constructor -- also kps_un, uright, kp_depth, lines_un, uright_start / _end, depth_start / _end"""
         images = np.asarray(images)
         out = self.alloc_outputs(images.shape[0])
-        self.extract_into(images, out)
+        ro = self.alloc_rgbd_outputs(images.shape[0]) if cam is not None else None
+        self.extract_into(images, out, depth, cam, depth_factor, ro)
         res = []
         for f in range(images.shape[0]):
             d = {}
@@ -147,11 +183,17 @@ class BatchExtractor:
                 k = int(out["n_kps"][f]); d["kps"] = out["kps"][f, :k].copy(); d["desc"] = out["desc"][f, :k].copy()
                 if self._has_map:
                     d["match_of_kp"] = out["match_of_kp"][f, :k].copy(); d["n_kp_matches"] = int(out["n_kp_matches"][f])
+                if ro is not None:
+                    for q in ("kps_un", "uright", "kp_depth"):
+                        d[q] = ro[q][f, :k].copy()
             if self.nlines > 0:
                 k = int(out["n_lines"][f]); d["lines"] = out["lines"][f, :k].copy(); d["ldesc"] = out["ldesc"][f, :k].copy()
                 d["line_eq"] = out["line_eq"][f, :k].copy()
                 if self._has_map:
                     d["match_of_line"] = out["match_of_line"][f, :k].copy(); d["n_line_matches"] = int(out["n_line_matches"][f])
+                if ro is not None:
+                    for q in ("lines_un", "uright_start", "uright_end", "depth_start", "depth_end"):
+                        d[q] = ro[q][f, :k].copy()
             res.append(d)
         return res
 

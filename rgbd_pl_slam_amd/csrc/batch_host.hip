@@ -38,6 +38,13 @@ struct Slot {
     int32_t *d_nl = nullptr, *h_nl = nullptr;
     int32_t *d_mkp = nullptr, *h_mkp = nullptr, *d_nmkp = nullptr, *h_nmkp = nullptr;
     int32_t *d_mln = nullptr, *h_mln = nullptr, *d_nmln = nullptr, *h_nmln = nullptr;
+    // RGB-D Frame tail (plf_batch_params.rgbd): depth staging / device images, mvKeysUn, mvuRight, mvDepth and the line-side members
+    uint16_t *h_dep = nullptr, *d_dep16 = nullptr;
+    float *d_depf = nullptr;
+    plf_keypoint *d_kun = nullptr, *h_kun = nullptr;
+    float *d_ur = nullptr, *h_ur = nullptr, *d_kd = nullptr, *h_kd = nullptr;
+    plf_keyline *d_lun = nullptr, *h_lun = nullptr;
+    float *d_le[4] = {nullptr, nullptr, nullptr, nullptr}, *h_le[4] = {nullptr, nullptr, nullptr, nullptr};   // uright start / end, depth start / end
     int32_t *h_status = nullptr;   // [0] ORB status word, [1] line status word
     hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_line = nullptr, ev_out = nullptr;
     plf_matcher *mat = nullptr;
@@ -57,6 +64,8 @@ struct LocalMap {   // device replica
 struct Job {
     const uint8_t *images; int64_t first, count; int w, h; ptrdiff_t pitch, fstride;
     plf_batch_outputs out;
+    bool rgbd = false;
+    plf_batch_rgbd R;
 };
 
 struct Worker {
@@ -175,6 +184,21 @@ static int worker_init(Worker *w)
         W_RC(dev_alloc(w, &s.d_in, C * w->in_bytes_per_frame));
         if (bpp == 3) W_RC(dev_alloc(w, &s.d_gray, C * (size_t)mw * mh));
         W_RC(pin_alloc(w, &s.h_status, 4));
+        if (P.rgbd) {
+            const size_t px = C * (size_t)mw * mh;
+            W_RC(pin_alloc(w, &s.h_dep, px)); W_RC(dev_alloc(w, &s.d_dep16, px)); W_RC(dev_alloc(w, &s.d_depf, px));
+            if (w->orb) {
+                const size_t K = C * (size_t)w->orb_cap;
+                W_RC(dev_alloc(w, &s.d_kun, K)); W_RC(pin_alloc(w, &s.h_kun, K));
+                W_RC(dev_alloc(w, &s.d_ur, K)); W_RC(pin_alloc(w, &s.h_ur, K));
+                W_RC(dev_alloc(w, &s.d_kd, K)); W_RC(pin_alloc(w, &s.h_kd, K));
+            }
+            if (w->line) {
+                const size_t K = C * (size_t)w->line_cap;
+                W_RC(dev_alloc(w, &s.d_lun, K)); W_RC(pin_alloc(w, &s.h_lun, K));
+                for (int q = 0; q < 4; q++) { W_RC(dev_alloc(w, &s.d_le[q], K)); W_RC(pin_alloc(w, &s.h_le[q], K)); }
+            }
+        }
         if (w->orb) {
             const size_t K = C * (size_t)w->orb_cap;
             W_RC(dev_alloc(w, &s.d_kps, K)); W_RC(pin_alloc(w, &s.h_kps, K));
@@ -222,9 +246,11 @@ static void worker_shutdown(Worker *w)
     (void)hipDeviceSynchronize();
     worker_free_map(w);
     for (Slot &s : w->slot) {
-        void *dev[] = {s.d_in, s.d_gray, s.d_kps, s.d_desc, s.d_nk, s.d_lines, s.d_ldesc, s.d_eq, s.d_nl, s.d_mkp, s.d_nmkp, s.d_mln, s.d_nmln};
+        void *dev[] = {s.d_in, s.d_gray, s.d_kps, s.d_desc, s.d_nk, s.d_lines, s.d_ldesc, s.d_eq, s.d_nl, s.d_mkp, s.d_nmkp, s.d_mln, s.d_nmln,
+                       s.d_dep16, s.d_depf, s.d_kun, s.d_ur, s.d_kd, s.d_lun, s.d_le[0], s.d_le[1], s.d_le[2], s.d_le[3]};
         for (void *p : dev) if (p) (void)hipFree(p);
-        void *pin[] = {s.h_in, s.h_kps, s.h_desc, s.h_nk, s.h_lines, s.h_ldesc, s.h_eq, s.h_nl, s.h_mkp, s.h_nmkp, s.h_mln, s.h_nmln, s.h_status};
+        void *pin[] = {s.h_in, s.h_kps, s.h_desc, s.h_nk, s.h_lines, s.h_ldesc, s.h_eq, s.h_nl, s.h_mkp, s.h_nmkp, s.h_mln, s.h_nmln, s.h_status,
+                       s.h_dep, s.h_kun, s.h_ur, s.h_kd, s.h_lun, s.h_le[0], s.h_le[1], s.h_le[2], s.h_le[3]};
         for (void *p : pin) if (p) (void)hipHostFree(p);
         hipEvent_t ev[] = {s.ev_in, s.ev_orb, s.ev_line, s.ev_out};
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -288,7 +314,22 @@ static bool is_pinned(const void *p)
 }
 
 // stage + upload + enqueue the kernels and the output copies of one chunk
-static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, bool src_pinned)
+// the line half of the Frame tail for the chunk in slot s (lines in s.d_lines / s.d_nl), enqueued on `st`
+static int line_tail_submit(Worker *w, Slot &s, const Job &J, int n, hipStream_t st)
+{
+    return plf_frame_line_tail(s.d_lines, s.d_nl, 0, n, w->line_cap, J.R.depth ? s.d_depf : nullptr, J.w, J.h, &J.R.cam, s.d_lun, s.d_le[0], s.d_le[1],
+                               s.d_le[2], s.d_le[3], w->device, st);
+}
+
+static int line_tail_download(Worker *w, Slot &s, int n, hipStream_t st)
+{
+    const size_t K = (size_t)n * w->line_cap;
+    W_TRY(hipMemcpyAsync(s.h_lun, s.d_lun, K * sizeof(plf_keyline), hipMemcpyDeviceToHost, st));
+    for (int q = 0; q < 4; q++) W_TRY(hipMemcpyAsync(s.h_le[q], s.d_le[q], K * sizeof(float), hipMemcpyDeviceToHost, st));
+    return PLF_OK;
+}
+
+static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, bool src_pinned, bool depth_pinned)
 {
     const plf_batch_params &P = w->owner->prm;
     const int bpp = P.input_format == PLF_FMT_GRAY8 ? 1 : 3;
@@ -309,6 +350,23 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         }
         up_src = s.h_in;
     }
+    const uint16_t *up_dep = nullptr;
+    const size_t dpx = (size_t)J.w * J.h;
+    if (J.rgbd && J.R.depth) {
+        const uint16_t *dsrc = J.R.depth + (size_t)first * J.R.depth_frame_stride_elems;
+        const bool dtight = J.R.depth_pitch_elems == (ptrdiff_t)J.w && J.R.depth_frame_stride_elems == (ptrdiff_t)dpx;
+        up_dep = dsrc;
+        if (!(depth_pinned && dtight)) {
+            W_TRY(hipEventSynchronize(s.ev_in));
+            for (int f = 0; f < n; f++) {
+                const uint16_t *fs = dsrc + (size_t)f * J.R.depth_frame_stride_elems;
+                uint16_t *fd = s.h_dep + (size_t)f * dpx;
+                if (J.R.depth_pitch_elems == (ptrdiff_t)J.w) memcpy(fd, fs, dpx * 2);
+                else for (int y = 0; y < J.h; y++) memcpy(fd + (size_t)y * J.w, fs + (size_t)y * J.R.depth_pitch_elems, (size_t)J.w * 2);
+            }
+            up_dep = s.h_dep;
+        }
+    }
     w->t_stage += secs(t0, clk::now());
     W_TRY(hipStreamWaitEvent(w->s_in, s.ev_orb, 0));
     W_TRY(hipStreamWaitEvent(w->s_in, s.ev_line, 0));
@@ -319,6 +377,10 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
                              w->device, w->s_in));
         d_gray = s.d_gray;
     }
+    if (up_dep) {   // imDepth.convertTo(CV_32F, mDepthMapFactor)
+        W_TRY(hipMemcpyAsync(s.d_dep16, up_dep, (size_t)n * dpx * 2, hipMemcpyHostToDevice, w->s_in));
+        W_RC(plf_depth_to_float(s.d_dep16, n, J.w, J.h, J.w, (ptrdiff_t)dpx, J.R.depth_factor, s.d_depf, w->device, w->s_in));
+    }
     W_TRY(hipEventRecord(s.ev_in, w->s_in));
     const bool match_pts = w->map.has_pts && s.mat, match_lns = w->map.has_lns && s.mat;
     if (w->line) {
@@ -327,6 +389,7 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         W_RC(plf_line_extract_batch(w->line, d_gray, PLF_MEM_DEVICE, n, J.w, J.h, J.w, (ptrdiff_t)J.w * J.h, s.d_lines, s.d_ldesc, s.d_eq, s.d_nl,
                                     PLF_MEM_DEVICE, w->line_cap, w->s_line));
         W_RC(plf_line_status_async(w->line, &s.h_status[1], w->s_line));
+        if (J.rgbd) W_RC(line_tail_submit(w, s, J, n, w->s_line));
         W_TRY(hipEventRecord(s.ev_line, w->s_line));
     }
     if (w->orb) {
@@ -335,6 +398,8 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         W_RC(plf_orb_extract_batch(w->orb, d_gray, PLF_MEM_DEVICE, n, J.w, J.h, J.w, (ptrdiff_t)J.w * J.h, s.d_kps, s.d_desc, s.d_nk, PLF_MEM_DEVICE,
                                    w->orb_cap, w->s_orb));
         W_RC(plf_orb_status_async(w->orb, &s.h_status[0], w->s_orb));
+        if (J.rgbd)   // Frame::UndistortKeyPoints + Frame::ComputeStereoFromRGBD
+            W_RC(plf_frame_tail(s.d_kps, s.d_nk, 0, n, w->orb_cap, up_dep ? s.d_depf : nullptr, J.w, J.h, &J.R.cam, s.d_kun, s.d_ur, s.d_kd, w->device, w->s_orb));
         W_TRY(hipEventRecord(s.ev_orb, w->s_orb));
     }
     // matchers + downloads on the output stream
@@ -345,7 +410,8 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
             W_TRY(hipMemsetAsync(s.d_mkp, 0xFF, K * sizeof(int32_t), w->s_out));
             for (int f = 0; f < n; f++) {
                 plf_frame_view &v = s.fviews[f];
-                v.n = w->orb_cap; v.n_device = s.d_nk + f; v.keys_un = s.d_kps + (size_t)f * w->orb_cap; v.uright = nullptr;
+                v.n = w->orb_cap; v.n_device = s.d_nk + f; v.keys_un = (J.rgbd ? s.d_kun : s.d_kps) + (size_t)f * w->orb_cap;
+                v.uright = (J.rgbd && up_dep) ? s.d_ur + (size_t)f * w->orb_cap : nullptr;
                 v.desc = s.d_desc + (size_t)f * w->orb_cap * 32;
                 v.min_x = w->owner->bounds[0]; v.min_y = w->owner->bounds[1]; v.max_x = w->owner->bounds[2]; v.max_y = w->owner->bounds[3];
                 v.scale_factors = w->d_scale; v.nlevels = w->nlevels;
@@ -357,6 +423,11 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         W_TRY(hipMemcpyAsync(s.h_nk, s.d_nk, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, w->s_out));
         W_TRY(hipMemcpyAsync(s.h_kps, s.d_kps, K * sizeof(plf_keypoint), hipMemcpyDeviceToHost, w->s_out));
         W_TRY(hipMemcpyAsync(s.h_desc, s.d_desc, K * 32, hipMemcpyDeviceToHost, w->s_out));
+        if (J.rgbd) {
+            W_TRY(hipMemcpyAsync(s.h_kun, s.d_kun, K * sizeof(plf_keypoint), hipMemcpyDeviceToHost, w->s_out));
+            W_TRY(hipMemcpyAsync(s.h_ur, s.d_ur, K * sizeof(float), hipMemcpyDeviceToHost, w->s_out));
+            W_TRY(hipMemcpyAsync(s.h_kd, s.d_kd, K * sizeof(float), hipMemcpyDeviceToHost, w->s_out));
+        }
     }
     if (w->line) {
         W_TRY(hipStreamWaitEvent(w->s_out, s.ev_line, 0));
@@ -365,7 +436,8 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
             W_TRY(hipMemsetAsync(s.d_mln, 0xFF, K * sizeof(int32_t), w->s_out));
             for (int f = 0; f < n; f++) {
                 plf_lineframe_view &v = s.lviews[f];
-                v.n = w->line_cap; v.n_device = s.d_nl + f; v.lines_un = s.d_lines + (size_t)f * w->line_cap; v.desc = s.d_ldesc + (size_t)f * w->line_cap * 32;
+                v.n = w->line_cap; v.n_device = s.d_nl + f; v.lines_un = (J.rgbd ? s.d_lun : s.d_lines) + (size_t)f * w->line_cap;
+                v.desc = s.d_ldesc + (size_t)f * w->line_cap * 32;
                 v.scale_factors = w->d_scale;
             }
             W_RC(plf_match_project_lines(s.mat, s.lviews.data(), n, &w->map.lns, w->owner->th, w->owner->nnratio, s.d_mln, w->line_cap, s.d_nmln, w->s_out));
@@ -376,6 +448,7 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         W_TRY(hipMemcpyAsync(s.h_lines, s.d_lines, K * sizeof(plf_keyline), hipMemcpyDeviceToHost, w->s_out));
         W_TRY(hipMemcpyAsync(s.h_ldesc, s.d_ldesc, K * 32, hipMemcpyDeviceToHost, w->s_out));
         W_TRY(hipMemcpyAsync(s.h_eq, s.d_eq, K * 3 * sizeof(double), hipMemcpyDeviceToHost, w->s_out));
+        if (J.rgbd) W_RC(line_tail_download(w, s, n, w->s_out));
     }
     W_TRY(hipEventRecord(s.ev_out, w->s_out));
     s.src = src;
@@ -407,6 +480,12 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
                 else for (int i = 0; i < n; i++) O.match_of_kp[g * O.kp_capacity + i] = -1;
             }
             if (O.n_kp_matches) O.n_kp_matches[g] = match_pts ? s.h_nmkp[f] : 0;
+            if (J.rgbd) {
+                const plf_batch_rgbd &R = J.R;
+                if (R.kps_un) memcpy(R.kps_un + g * O.kp_capacity, s.h_kun + (size_t)f * w->orb_cap, sizeof(plf_keypoint) * n);
+                if (R.uright) memcpy(R.uright + g * O.kp_capacity, s.h_ur + (size_t)f * w->orb_cap, sizeof(float) * n);
+                if (R.kp_depth) memcpy(R.kp_depth + g * O.kp_capacity, s.h_kd + (size_t)f * w->orb_cap, sizeof(float) * n);
+            }
         }
     }
     if (w->line) {
@@ -422,17 +501,21 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
                                             PLF_MEM_HOST, w->line_cap, w->s_line);
             if (rc != PLF_OK && rc != PLF_E_CAPACITY) return rc;
             for (int f = 0; f < s.n; f++) s.h_nl[f] = nl[f];
-            if (match_lns) {   // the matches of the failed pass are meaningless: redo them on the fresh lines
+            if (match_lns || J.rgbd) {   // the Frame tail / matches of the failed pass are meaningless: redo them on the fresh lines
                 const size_t K = (size_t)s.n * w->line_cap;
                 W_TRY(hipMemcpyAsync(s.d_lines, s.h_lines, K * sizeof(plf_keyline), hipMemcpyHostToDevice, w->s_out));
                 W_TRY(hipMemcpyAsync(s.d_ldesc, s.h_ldesc, K * 32, hipMemcpyHostToDevice, w->s_out));
                 W_TRY(hipMemcpyAsync(s.d_nl, s.h_nl, (size_t)s.n * sizeof(int32_t), hipMemcpyHostToDevice, w->s_out));
+                if (J.rgbd) { W_RC(line_tail_submit(w, s, J, s.n, w->s_out)); W_RC(line_tail_download(w, s, s.n, w->s_out)); }
+            }
+            if (match_lns) {
+                const size_t K = (size_t)s.n * w->line_cap;
                 W_TRY(hipMemsetAsync(s.d_mln, 0xFF, K * sizeof(int32_t), w->s_out));
                 W_RC(plf_match_project_lines(s.mat, s.lviews.data(), s.n, &w->map.lns, w->owner->th, w->owner->nnratio, s.d_mln, w->line_cap, s.d_nmln, w->s_out));
                 W_TRY(hipMemcpyAsync(s.h_mln, s.d_mln, K * sizeof(int32_t), hipMemcpyDeviceToHost, w->s_out));
                 W_TRY(hipMemcpyAsync(s.h_nmln, s.d_nmln, (size_t)s.n * sizeof(int32_t), hipMemcpyDeviceToHost, w->s_out));
-                W_TRY(hipStreamSynchronize(w->s_out));
             }
+            W_TRY(hipStreamSynchronize(w->s_out));
         }
         for (int f = 0; f < s.n; f++) {
             const size_t g = (size_t)(s.first + f);
@@ -448,6 +531,13 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
                 else for (int i = 0; i < n; i++) O.match_of_line[g * O.line_capacity + i] = -1;
             }
             if (O.n_line_matches) O.n_line_matches[g] = match_lns ? s.h_nmln[f] : 0;
+            if (J.rgbd) {
+                const plf_batch_rgbd &R = J.R;
+                float *dst[4] = {R.uright_start, R.uright_end, R.depth_start, R.depth_end};
+                if (R.lines_un) memcpy(R.lines_un + g * O.line_capacity, s.h_lun + (size_t)f * w->line_cap, sizeof(plf_keyline) * n);
+                for (int q = 0; q < 4; q++)
+                    if (dst[q]) memcpy(dst[q] + g * O.line_capacity, s.h_le[q] + (size_t)f * w->line_cap, sizeof(float) * n);
+            }
         }
     }
     w->t_unpack += secs(t1, clk::now());
@@ -464,13 +554,14 @@ static int worker_extract(Worker *w)
     W_TRY(hipSetDevice(w->device));
     const int C = w->owner->prm.frames_in_flight;
     const bool pinned = is_pinned(J.images + (size_t)J.first * J.fstride);
+    const bool dpinned = J.rgbd && J.R.depth && is_pinned(J.R.depth + (size_t)J.first * J.R.depth_frame_stride_elems);
     int soft = PLF_OK, k = 0;
     for (int64_t done = 0; done < J.count; done += C, k++) {
         Slot &s = w->slot[k & 1];
         int rc = chunk_retire(w, s, J, &soft);   // chunk k-2 (normally retired already)
         if (rc != PLF_OK) return rc;
         const int n = (int)(J.count - done < C ? J.count - done : C);
-        rc = chunk_submit(w, s, J, J.first + done, n, pinned);
+        rc = chunk_submit(w, s, J, J.first + done, n, pinned, dpinned);
         if (rc != PLF_OK) return rc;
         rc = chunk_retire(w, w->slot[(k & 1) ^ 1], J, &soft);   // chunk k-1 while chunk k runs
         if (rc != PLF_OK) return rc;
@@ -622,7 +713,19 @@ extern "C" int plf_batch_set_local_map(plf_batch *b, const plf_mappoint_view *po
 extern "C" int plf_batch_extract(plf_batch *b, const uint8_t *images, int64_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch,
                                  ptrdiff_t frame_stride, const plf_batch_outputs *out)
 {
+    return plf_batch_extract_rgbd(b, images, n_frames, width, height, pitch, frame_stride, out, nullptr);
+}
+
+extern "C" int plf_batch_extract_rgbd(plf_batch *b, const uint8_t *images, int64_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch,
+                                      ptrdiff_t frame_stride, const plf_batch_outputs *out, const plf_batch_rgbd *rgbd)
+{
     if (!b || !out) return PLF_E_BADARG;
+    if (rgbd) {
+        if (!b->prm.rgbd) return PLF_E_BADARG;
+        if (rgbd->depth && (rgbd->depth_pitch_elems < (ptrdiff_t)width ||
+                            rgbd->depth_frame_stride_elems < rgbd->depth_pitch_elems * (ptrdiff_t)(height - 1) + (ptrdiff_t)width))
+            return PLF_E_BADARG;
+    }
     if (!images || n_frames <= 0 || width <= 0 || height <= 0) return PLF_E_EMPTY;   // reference: silent return on an empty image, so@0x76dda
     const plf_batch_params &P = b->prm;
     const int bpp = P.input_format == PLF_FMT_GRAY8 ? 1 : 3;
@@ -635,6 +738,8 @@ extern "C" int plf_batch_extract(plf_batch *b, const uint8_t *images, int64_t n_
     for (int i = 0; i < nw; i++) {
         Job &J = b->workers[i]->job;
         J.images = images; J.w = width; J.h = height; J.pitch = pitch; J.fstride = frame_stride; J.out = *out;
+        J.rgbd = rgbd != nullptr;
+        if (rgbd) J.R = *rgbd; else memset(&J.R, 0, sizeof(J.R));
         (void)plf_batch_shard(n_frames, nw, i, &J.first, &J.count);
     }
     return run_all(b, 1);

@@ -11,6 +11,9 @@
 #include "plf_common.h"
 #include "lsd_geom.h"
 
+#ifndef PRE_NT
+#define PRE_NT 256   // threads per k_lsd_pre tile (lsd_kernels.hip)
+#endif
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *);
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
@@ -327,7 +330,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail_unused = h->d_counters + 3 * MB + 16;
     (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
-    hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
+    hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(PRE_NT), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
                        h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     if (h->prm.lbd_sobel_input == PLF_LBD_RAW)
         hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);

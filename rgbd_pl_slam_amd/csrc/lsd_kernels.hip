@@ -46,7 +46,10 @@ typedef unsigned long long __attribute__((aligned(1))) plf_u64u;   // 8-byte acc
 #define PRE_TH 16
 #define PRE_SC 88
 #define PRE_SR 26
-__global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, float *__restrict__ ang,
+#ifndef PRE_NT
+#define PRE_NT 256   // threads per tile
+#endif
+__global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, float *__restrict__ ang,
                                                  double *__restrict__ modgrad, double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g,
                                                  LsdTaps t, const int *__restrict__ xofs, const float2 *__restrict__ xa,
                                                  const int *__restrict__ yofs, const float2 *__restrict__ yb)
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
     const int r_lo = min(max(yofs[dy0], 0), g.h - 1), r_hi = min(max(yofs[dy1] + 1, 0), g.h - 1);
     const int nc = c_hi - c_lo + 1, nr = r_hi - r_lo + 1;
     const uint8_t *img = in + (size_t)f * fstride;
-    for (int i = tid; i < (nr + 6) * PRE_SC; i += 256) {
+    for (int i = tid; i < (nr + 6) * PRE_SC; i += PRE_NT) {
         const int r = i / PRE_SC, c = i - r * PRE_SC;
         if (c >= nc) continue;
         const uint8_t *row = img + (size_t)plf_reflect101(r_lo - 3 + r, g.h) * pitch;
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
         s_tmp[i] = s;
     }
     __syncthreads();
-    for (int i = tid; i < nr * PRE_SC; i += 256) {
+    for (int i = tid; i < nr * PRE_SC; i += PRE_NT) {
         const int r = i / PRE_SC, c = i - r * PRE_SC;
         if (c >= nc) continue;
         const double *p = s_tmp + (r + 3) * PRE_SC + c;
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
     }
     __syncthreads();
     const int ncs = dx1 - dx0 + 1, nrs = dy1 - dy0 + 1;
-    for (int i = tid; i < nrs * (PRE_TW + 1); i += 256) {
+    for (int i = tid; i < nrs * (PRE_TW + 1); i += PRE_NT) {
         const int ry = i / (PRE_TW + 1), rx = i - ry * (PRE_TW + 1);
         if (rx >= ncs) continue;
         const int dx = dx0 + rx, dy = dy0 + ry;
@@ -117,8 +120,8 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
     __syncthreads();
     const int tx = tid & 63;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ty = (tid >> 6) + 4 * k;
+    for (int k = 0; k < PRE_TH / (PRE_NT / 64); k++) {
+        const int ty = (tid >> 6) + (PRE_NT / 64) * k;
         const int x = dx0 + tx, y = dy0 + ty;
         bool def = false;
         float deg = 0.f;
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) k_lsd_pre(const uint8_t *__restrict__ in,
     }
     __syncthreads();
     const int ndef = s_ndef;
-    for (int i = tid; i < ndef; i += 256) {
+    for (int i = tid; i < ndef; i += PRE_NT) {
         const float2 e = s_list[i];
         const size_t o = (size_t)f * g.s_stride + (size_t)__float_as_int(e.x);
         const double ad = (double)e.y * DEG2RAD_D;
@@ -764,7 +767,12 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
 }
 
 #define PLF_LSD_FPW2_LDS 6400
-__global__ void __launch_bounds__(128) k_lsd_regions2(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+#ifdef PLF_REGIONS_WPE   // experiment switch (tools/variant_build.sh): cap the VGPRs of the large-batch region kernel for N waves per SIMD
+#define PLF_REGIONS_OCC __attribute__((amdgpu_waves_per_eu(PLF_REGIONS_WPE, PLF_REGIONS_WPE)))
+#else
+#define PLF_REGIONS_OCC
+#endif
+__global__ void PLF_REGIONS_OCC __launch_bounds__(128) k_lsd_regions2(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                       const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                       uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                       int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)

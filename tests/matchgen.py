@@ -13,8 +13,9 @@ def flip_bits(desc, rng, maxflips):
     return out
 
 
-def make_local_map(kps, desc, M, seed, w=640, h=480, nlevels=8, with_uright=False):
-    """kps: structured keypoints of the current frame (x, y, octave); returns dict of numpy arrays describing M map points"""
+def make_local_map(kps, desc, M, seed, w=640, h=480, nlevels=8, with_uright=False, uright=None):
+    """kps: structured keypoints of the current frame (x, y, octave); returns dict of numpy arrays describing M map points.
+    uright (the frame's mvuRight): map points derived from a key point with stereo data get a consistent mTrackProjXR"""
     rng = np.random.default_rng(seed)
     N = len(kps)
     src = rng.integers(0, N, M)
@@ -29,6 +30,9 @@ def make_local_map(kps, desc, M, seed, w=640, h=480, nlevels=8, with_uright=Fals
     in_view = (rng.uniform(0, 1, M) < 0.9).astype(np.uint8)
     proj_xr = (px - rng.uniform(2, 30, M)).astype(np.float32)
     obs_positive = (rng.uniform(0, 1, M) < 0.97).astype(np.uint8)
+    if uright is not None:
+        ur = np.asarray(uright, np.float32)[src]
+        proj_xr = np.where(real & (ur > 0), ur + rng.normal(0, 1.0, M), proj_xr).astype(np.float32)
     return dict(proj_x=px, proj_y=py, proj_xr=proj_xr, level=lvl, view_cos=view_cos, in_view=in_view, desc=d, obs_positive=obs_positive)
 
 

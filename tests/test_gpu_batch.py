@@ -110,6 +110,75 @@ def test_padded_pinned_and_rgb_inputs():
         bc.close()
 
 
+def test_rgbd_frame_constructor_batch():
+    """plf_batch_extract_rgbd = the RGB-D Frame constructor (include/Frame.h:60) for a batch of host frames: colour -> gray, uint16 depth ->
+    float, ExtractORB / ExtractLSD, UndistortKeyPoints, ComputeStereoFromRGBD and the line-side members, then SearchByProjection on mvKeysUn /
+    mvuRight / mvKeylinesUn.  7 frames with 3 in flight (ragged last chunk), padded depth pitch; also without depth (monocular rule)."""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor, FMT_BGR8
+    from rgbd_pl_slam_amd.frame import camera, TUM1
+    from rgbd_pl_slam_amd.synth import synth_frame
+    n, w, h = 7, 640, 480
+    rng = np.random.default_rng(11)
+    gray = np.stack([synth_frame(500 + i, w, h) for i in range(n)])
+    bgr = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8); bgr[..., 1] = gray
+    dpad = np.zeros((n, h + 2, w + 10), np.uint16)
+    dpad[:, :h, :w] = rng.integers(2000, 30000, (n, h, w), dtype=np.uint16)
+    dpad[:, :h, :w][rng.uniform(0, 1, (n, h, w)) < 0.15] = 0          # holes: no depth
+    d16 = dpad[:, :h, :w]
+    cam = camera(**TUM1)
+    c9 = np.array([TUM1[k] for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")], np.float32)
+    factor = np.float32(1.0 / 5000.0)
+    g0 = orc.rgb_to_gray(bgr[0], 1)
+    r0 = orc.orb_extract(g0, nfeatures=1000); l0 = orc.line_extract(g0, 100)
+    un0, ur0, _ = orc.frame_tail(r0["kps"], orc.depth_to_float(np.ascontiguousarray(d16[0]), factor), c9, TUM1["bf"])
+    mp = matchgen.make_local_map(un0, r0["desc"], 3000, 5, uright=ur0)
+    lun0 = orc.line_tail(l0["kl"], None, c9, TUM1["bf"])[0]
+    ml = matchgen.make_map_lines(lun0, l0["desc"], 400, 6)
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    bounds = (-10.0, -12.0, 655.0, 490.0)      # Frame::ComputeImageBounds of a distorted camera reach outside the image
+    bx = BatchExtractor(nfeatures=1000, nlines=100, width=w, height=h, frames_in_flight=3, devices=[0], input_format=FMT_BGR8,
+                        max_mappoints=4096, max_maplines=512, rgbd=True)
+    bx.set_local_map(mp, ml, th=3.0, nnratio=0.8, bounds=bounds)
+    for with_depth in (True, False):
+        res = bx.extract(bgr, depth=d16 if with_depth else None, cam=cam, depth_factor=float(factor))
+        for f in range(n):
+            g = orc.rgb_to_gray(bgr[f], 1)
+            ro = orc.orb_extract(g, nfeatures=1000); rl = orc.line_extract(g, 100)
+            _same_orb(res[f], ro, "frame %d" % f); _same_lines(res[f], rl, "frame %d" % f)
+            tag = "frame %d depth %d" % (f, with_depth)
+            if with_depth:
+                df = orc.depth_to_float(np.ascontiguousarray(d16[f]), factor)
+                un, ur, kd = orc.frame_tail(ro["kps"], df, c9, TUM1["bf"])
+                assert np.array_equal(res[f]["uright"].view(np.uint32), ur.view(np.uint32)), tag
+                assert np.array_equal(res[f]["kp_depth"].view(np.uint32), kd.view(np.uint32)), tag
+                assert (ur > 0).sum() > 500
+            else:
+                df = None
+                un = orc.frame_tail(ro["kps"], np.zeros((h, w), np.float32), c9, TUM1["bf"])[0]
+                ur = None
+                assert np.all(res[f]["uright"] == -1) and np.all(res[f]["kp_depth"] == -1), tag
+            for name in un.dtype.names:
+                assert np.array_equal(res[f]["kps_un"][name].view(np.uint32), un[name].view(np.uint32)), "%s: mvKeysUn.%s" % (tag, name)
+            lun, urs, ure, ds, de = orc.line_tail(rl["kl"], df, c9, TUM1["bf"])
+            for name in lun.dtype.names:
+                assert np.array_equal(res[f]["lines_un"][name].view(np.uint32), lun[name].view(np.uint32)), "%s: mvKeylinesUn.%s" % (tag, name)
+            for got, exp in ((res[f]["uright_start"], urs), (res[f]["uright_end"], ure), (res[f]["depth_start"], ds), (res[f]["depth_end"], de)):
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), tag
+            rm, rn = orc.search_by_projection_map(un, ro["desc"], ur, scale, bounds, mp, 3.0, 0.8, np.full(len(un), -1, np.int32))
+            assert res[f]["n_kp_matches"] == rn and np.array_equal(res[f]["match_of_kp"], rm), "%s: point matches" % tag
+            lm, ln = orc.search_lines_by_projection(lun, rl["desc"], scale, ml, 3.0, 0.8, np.full(len(lun), -1, np.int32))
+            assert res[f]["n_line_matches"] == ln and np.array_equal(res[f]["match_of_line"], lm), "%s: line matches" % tag
+            if f == 0:
+                assert rn > 100 and ln > 10
+    # the RGB-D entry needs the buffers of plf_batch_params.rgbd
+    plain = BatchExtractor(nfeatures=500, nlines=50, width=w, height=h, frames_in_flight=2, devices=[0])
+    with pytest.raises(RuntimeError):
+        plain.extract(gray[:1], cam=cam)
+    plain.close()
+    bx.close()
+
+
 def test_all_visible_gpus_share_one_batch():
     """n_devices = 0: every visible GPU gets a contiguous block (plf_batch_shard); on the 1-GPU test box this is one worker, on an
     8-GPU node the same call exercises eight -- the per-frame outputs do not depend on the partition"""
