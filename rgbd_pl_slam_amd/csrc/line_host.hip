@@ -12,7 +12,7 @@
 #include "lsd_geom.h"
 
 #ifndef PRE_NT
-#define PRE_NT 256   // threads per k_lsd_pre tile (lsd_kernels.hip)
+#define PRE_NT 512   // threads per k_lsd_pre tile (lsd_kernels.hip)
 #endif
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *);
@@ -34,7 +34,7 @@ __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, flo
                                int, int *, unsigned long long *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
 __global__ void k_blur5_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom, int4);
-__global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, LbdCoefs);
+__global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, const LbdCoefs *);
 
 __global__ void k_lsd_spec_fused(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
 __global__ void k_lsd_spec_bands(const float *, LsdGeom, SpecBufs);
@@ -51,6 +51,7 @@ struct plf_line {
     LsdGeom g;
     LsdTaps taps;
     LbdCoefs lbd;
+    LbdCoefs *d_lbd;   // the same, in device memory (k_lbd indexes it per lane)
     int4 blur5;               // 8-bit fixed-point taps of GaussianBlur(5 x 5, sigma 1): k[0], k[1], k[2]
     int cur_w, cur_h;
     size_t alloc_full, alloc_scaled;  // elements per frame the buffers were sized for
@@ -98,7 +99,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
     for (void *p : sp) if (p) (void)hipFree(p);
@@ -277,6 +278,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
     ALLOC(h->d_counters, (4 * B + 16) * sizeof(int));
     ALLOC(h->d_lgam, 65536 * sizeof(double));
+    ALLOC(h->d_lbd, sizeof(LbdCoefs));
     ALLOC(h->d_ent[0], NP * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], NP * 5 * sizeof(NfaEntry));
     ALLOC(h->d_st[0], NP * sizeof(NfaState)); ALLOC(h->d_st[1], NP * sizeof(NfaState));
     ALLOC(h->d_cnt, NP * 5 * sizeof(NfaCounts));
@@ -305,6 +307,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
+    if (hipMemcpy(h->d_lbd, &h->lbd, sizeof(LbdCoefs), hipMemcpyHostToDevice) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
     h->cur_w = -1; h->cur_h = -1;
     rc = line_configure(h, p->max_width, p->max_height);
     if (rc != PLF_OK) { line_free(h); free(h); return rc; }
@@ -458,8 +461,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
                        d_lines, d_eq, d_nout, capacity, status, h->d_sort_scratch, g);
-    hipLaunchKernelGGL(k_lbd, dim3(capacity < g.nkeep ? capacity : g.nkeep, B), dim3(128), 0, s, h->d_grad, d_lines, d_nout, d_ldesc, capacity, g,
-                       h->lbd);
+    hipLaunchKernelGGL(k_lbd, dim3(capacity < g.nkeep ? capacity : g.nkeep, B), dim3(64), 0, s, h->d_grad, d_lines, d_nout, d_ldesc, capacity, g,
+                       h->d_lbd);
     PLF_HIP_TRY(hipGetLastError());
     h->last_frames = B;
     return PLF_OK;

@@ -203,10 +203,24 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
 __constant__ int c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3, 2, 4, 2, 5, 2, 6, 2, 7,
                                    2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6, 4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
 
-// one 128-thread block per (line, frame): threads 0..62 = rows of the 63-row line support region,
-// threads 0..71 = (band, statistic) accumulators, threads 0..31 = output bytes.
-__global__ void __launch_bounds__(128) k_lbd(const short2 *__restrict__ grad_all, const plf_keyline *__restrict__ lines,
-                                             const int *__restrict__ n_out, uint8_t *__restrict__ desc, int capacity, LsdGeom g, LbdCoefs cf)
+// BinaryDescriptor::computeLBD for one line: ONE WAVE per (line, frame).  Lanes 0..62 = the rows of the 63-row line support region (sequential
+// float sums along the row, in the reference's order; the gradient gathers of 4 consecutive steps are issued together -- the coordinates are a float
+// recurrence that does not depend on the loaded data -- so a row waits for one memory round trip per 4 pixels instead of per pixel); then the 72
+// (band, statistic) sums, two passes of the wave; the descriptor statistics (mean / stddev per band), each lane its own entry; the three norm sums are
+// ORDERED float sums over 36 / 36 / 72 entries: every lane runs the same chain on values broadcast with v_readlane (no private array: the 72-float
+// scratch copy of round 1 cost 140 VGPRs); finally 32 lanes pack the bytes.  cf: the Gaussian weights in device memory (indexed per lane).
+#ifdef PLF_LBD_WPE   // experiment switch (tools/variant_build.sh)
+#define PLF_LBD_OCC __attribute__((amdgpu_waves_per_eu(PLF_LBD_WPE, PLF_LBD_WPE)))
+#else
+#define PLF_LBD_OCC
+#endif
+__device__ __forceinline__ float lbd_bcast(float lo, float hi, int j)   // entry j (0..71) of a 72-vector held as lane j of lo (j < 64) / lane j - 64 of hi
+{
+    return __int_as_float(j < 64 ? __builtin_amdgcn_readlane(__float_as_int(lo), j) : __builtin_amdgcn_readlane(__float_as_int(hi), j - 64));
+}
+__global__ void PLF_LBD_OCC __launch_bounds__(64) k_lbd(const short2 *__restrict__ grad_all, const plf_keyline *__restrict__ lines,
+                                                        const int *__restrict__ n_out, uint8_t *__restrict__ desc, int capacity, LsdGeom g,
+                                                        const LbdCoefs *__restrict__ cf)
 {
     __shared__ float rowsum[8][64];
     __shared__ float dv[72];
@@ -224,85 +238,96 @@ __global__ void __launch_bounds__(128) k_lbd(const short2 *__restrict__ grad_all
     const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
     const float dO0 = -dL1, dO1 = dL0;
     if (t < 63) {
-        float sCorX0 = -dL0 * (float)halfWidth + dL1 * (float)halfHeight + lineMiddlePointX;
-        float sCorY0 = -dL1 * (float)halfWidth - dL0 * (float)halfHeight + lineMiddlePointY;
-        for (int h = 0; h < t; h++) { sCorX0 -= dL1; sCorY0 += dL0; }
-        float sCorX = sCorX0, sCorY = sCorY0;
+        float sCorX = -dL0 * (float)halfWidth + dL1 * (float)halfHeight + lineMiddlePointX;
+        float sCorY = -dL1 * (float)halfWidth - dL0 * (float)halfHeight + lineMiddlePointY;
+        for (int h = 0; h < t; h++) { sCorX -= dL1; sCorY += dL0; }
         float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
-        for (short wID = 0; wID < lengthOfLSP; wID++) {
-            short tempCor = (short)(int)roundf(sCorX);
-            const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
-            tempCor = (short)(int)roundf(sCorY);
-            const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
-            const short2 d = grad[(int)yCor * realWidth + (int)xCor];
-            const float gDL = (float)d.x * dL0 + (float)d.y * dL1;
-            const float gDO = (float)d.x * dO0 + (float)d.y * dO1;
-            if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
-            if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
-            sCorX += dL0;
-            sCorY += dL1;
+        const int len = lengthOfLSP;
+        for (int w0 = 0; w0 < len; w0 += 4) {
+            short2 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                short tempCor = (short)(int)roundf(sCorX);
+                const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+                tempCor = (short)(int)roundf(sCorY);
+                const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+                d[q] = grad[(int)yCor * realWidth + (int)xCor];   // (steps past the end of the row read a clamped, valid address and are not accumulated)
+                sCorX += dL0;
+                sCorY += dL1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (w0 + q < len) {
+                    const float gDL = (float)d[q].x * dL0 + (float)d[q].y * dL1;
+                    const float gDO = (float)d[q].x * dO0 + (float)d[q].y * dO1;
+                    if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
+                    if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
+                }
+            }
         }
-        const float cg = cf.gG[t];
+        const float cg = cf->gG[t];
         pgdL = cg * pgdL; ngdL = cg * ngdL; pgdO = cg * pgdO; ngdO = cg * ngdO;
         rowsum[0][t] = pgdL; rowsum[1][t] = ngdL; rowsum[2][t] = pgdL * pgdL; rowsum[3][t] = ngdL * ngdL;
         rowsum[4][t] = pgdO; rowsum[5][t] = ngdO; rowsum[6][t] = pgdO * pgdO; rowsum[7][t] = ngdO * ngdO;
     }
     __syncthreads();
-    if (t < 72) {
+    for (int e = t; e < 72; e += 64) {
         // band sums: band b receives, in row order, the rows of bands b-1, b, b+1 with the local Gaussian weights
-        const int b = t >> 3, st = t & 7;
+        const int b = e >> 3, st = e & 7;
         const bool sq = (st & 2) != 0;  // statistics 2,3,6,7 are the squared sums
         float acc = 0;
         const int h0 = max(0, 7 * (b - 1)), h1 = min(62, 7 * (b + 2) - 1);
         for (int hID = h0; hID <= h1; hID++) {
             const int rb = hID / 7;
             const int ci = (rb == b) ? (hID % 7 + 7) : (rb == b + 1 ? hID % 7 + 14 : hID % 7);
-            const float c = cf.gL[ci];
+            const float c = cf->gL[ci];
             const float v = rowsum[st][hID];
             acc += sq ? (c * c * v) : (c * v);
         }
-        dv[t] = acc;  // staged as [band][stat: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2]
+        dv[e] = acc;  // staged as [band][stat: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2]
     }
     __syncthreads();
-    if (t == 0) {
-        float des[72];
-        const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
-        for (int b = 0; b < 9; b++) {
+    // descriptor entry j = 8 b + k: k < 4 the band means (of pgdL, ngdL, pgdO, ngdO), k >= 4 their standard deviations.  des_lo = entry t, des_hi = entry 64 + t
+    const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
+    float des_lo = 0.f, des_hi = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int j = t + 64 * pass;
+        if (j < 72) {
+            const int b = j >> 3, k = j & 7, m = k & 3;
             const float invN = (b == 0 || b == 8) ? invN2 : invN3;
-            const float *a = &dv[b * 8];
-            float temp = a[0] * invN;
-            des[b * 8] = temp;
-            des[b * 8 + 4] = sqrtf(a[2] * invN - temp * temp);
-            temp = a[1] * invN;
-            des[b * 8 + 1] = temp;
-            des[b * 8 + 5] = sqrtf(a[3] * invN - temp * temp);
-            temp = a[4] * invN;
-            des[b * 8 + 2] = temp;
-            des[b * 8 + 6] = sqrtf(a[6] * invN - temp * temp);
-            temp = a[5] * invN;
-            des[b * 8 + 3] = temp;
-            des[b * 8 + 7] = sqrtf(a[7] * invN - temp * temp);
+            const int sm = (m < 2) ? m : m + 2;         // slot of the sum: 0, 1, 4, 5
+            const float temp = dv[b * 8 + sm] * invN;
+            float v = temp;
+            if (k >= 4) v = sqrtf(dv[b * 8 + sm + 2] * invN - temp * temp);
+            if (pass == 0) des_lo = v; else des_hi = v;
         }
-        float tempM = 0, tempS = 0;
-        for (int b = 0; b < 9; b++) {
-            const float *d = des + 8 * b;
-            tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
-            tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
-        }
-        tempM = 1 / sqrtf(tempM);
-        tempS = 1 / sqrtf(tempS);
-        for (int b = 0; b < 9; b++) {
-            float *d = des + 8 * b;
-            d[0] = d[0] * tempM; d[1] = d[1] * tempM; d[2] = d[2] * tempM; d[3] = d[3] * tempM;
-            d[4] = d[4] * tempS; d[5] = d[5] * tempS; d[6] = d[6] * tempS; d[7] = d[7] * tempS;
-        }
-        for (int i = 0; i < 72; i++)
-            if ((double)des[i] > 0.4) des[i] = (float)0.4;
-        float temp = 0;
-        for (int i = 0; i < 72; i++) temp += des[i] * des[i];
-        temp = 1 / sqrtf(temp);
-        for (int i = 0; i < 72; i++) dv[i] = des[i] * temp;
     }
+    // tempM / tempS: ordered sums of squares over the 36 means / 36 deviations (band by band, k ascending)
+    float tempM = 0, tempS = 0;
+#pragma unroll
+    for (int b = 0; b < 9; b++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const float d = lbd_bcast(des_lo, des_hi, 8 * b + k); tempM += d * d; }
+#pragma unroll
+        for (int k = 4; k < 8; k++) { const float d = lbd_bcast(des_lo, des_hi, 8 * b + k); tempS += d * d; }
+    }
+    tempM = 1 / sqrtf(tempM);
+    tempS = 1 / sqrtf(tempS);
+    {
+        const bool mean_lo = (t & 7) < 4;   // (entry 64 + t has the same k as entry t)
+        des_lo = des_lo * (mean_lo ? tempM : tempS);
+        des_hi = des_hi * (mean_lo ? tempM : tempS);
+        if ((double)des_lo > 0.4) des_lo = (float)0.4;
+        if ((double)des_hi > 0.4) des_hi = (float)0.4;
+    }
+    float temp = 0;
+#pragma unroll
+    for (int i = 0; i < 72; i++) { const float d = lbd_bcast(des_lo, des_hi, i); temp += d * d; }
+    temp = 1 / sqrtf(temp);
+    __syncthreads();   // every lane has read dv
+    dv[t] = des_lo * temp;
+    if (t < 8) dv[64 + t] = des_hi * temp;
     __syncthreads();
     if (t < 32) {
         const float *f1 = &dv[8 * c_lbd_comb[2 * t]], *f2 = &dv[8 * c_lbd_comb[2 * t + 1]];

@@ -83,7 +83,10 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     const int tid = threadIdx.x, f = blockIdx.y;
     const int trow = tid >> 5, tc4 = (tid & 31) * 4;
     constexpr int NR = OF_NT / 32;   // tile rows per pass of the pixel phases
-    const int tx = (int)blockIdx.x % L.tcx, ty = (int)blockIdx.x / L.tcx;
+    // (An XCD-aware order -- giving each of the 8 XCDs a contiguous run of the frame's tiles so that neighbours share halo reads and merge their
+    // 60-byte row segments in one L2 -- was measured: 3 % SLOWER solo, 30.8 vs 29.8 ms per 4096 frames; the plain raster order stays.)
+    const int tile = (int)blockIdx.x;
+    const int tx = tile % L.tcx, ty = tile / L.tcx;
     const int W = L.w, H = L.h;
     // ---- tile geometry
     const int cx0 = 2 * tx, cx1 = min(cx0 + 2, L.ncx), cy0 = 2 * ty, cy1 = min(cy0 + 2, L.ncy);
