@@ -28,6 +28,7 @@ struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
 __global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, NfaState *, int *, int *, LsdGeom);
 __global__ void k_nfa_clamp(int *, int *, LsdGeom);
 __global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
+__global__ void k_nfa_count1(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_eval(int, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
@@ -452,8 +453,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const int count_waves = 256 * 16, math_blocks = 1024;
     for (int stage = 0; stage <= 4; stage++) {
         const int in = stage & 1, out = in ^ 1;
-        hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage,
-                           (stage >= 1 && stage <= 3) ? 5 : 1, h->d_cnt, g);
+        if (stage >= 1 && stage <= 3)
+            hipLaunchKernelGGL(k_nfa_count1, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 5, h->d_cnt, g);
+        else
+            hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 1, h->d_cnt, g);
         hipLaunchKernelGGL(k_nfa_eval, dim3(2 * math_blocks), dim3(256), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
                            h->d_vals, g);
         hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],

@@ -1456,7 +1456,10 @@ struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
 
 // pixel count of one rectangle by a group of 16 lanes (4 rectangles per wave: most candidate rectangles span
 // only a few rows, so a full wave per rectangle would idle)
-__device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, int nprec, NfaCounts &out)
+// NP = 6: the counts for rec.prec and the five halved precisions of the same geometry (stages 0 and 4); NP = 1: rec.prec only (the candidate
+// rectangles of stages 1..3 -- most of the pixel visits; the five unused comparisons per pixel were 37 % of the loop body)
+template <int NP>
+__device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, NfaCounts &out)
 {
     const int lane = plf_lane() & 15;
     const double half_width = rec.width / 2.0;
@@ -1504,13 +1507,16 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
     // After visiting row y' the walk adds (y' >= lf.y ? slstep : flstep); all terms are integers, so the span of
     // row y is exact in closed form.
     const int y_lo = max(mn.y, 0), y_hi = min(mx.y, H - 1);
-    double precs[6];
+    double precs[NP];
     precs[0] = rec.prec;
-    {
+    if (NP > 1) {
         double pp = rec.p;
-        for (int k = 1; k < 6; k++) { pp /= 2; precs[k] = pp * PI_D; }
+#pragma unroll
+        for (int k = 1; k < NP; k++) { pp /= 2; precs[k] = pp * PI_D; }
     }
-    int total = 0, alg[6] = {0, 0, 0, 0, 0, 0};
+    int total = 0, alg[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) alg[k] = 0;
     // 16 lanes = ry_n rows x rx_n interleaved columns: rectangles along the x axis have few, long rows
     int ry_n = 16;
     while (ry_n > 1 && ry_n > y_hi - y_lo + 1) ry_n >>= 1;
@@ -1533,18 +1539,18 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
                 if (n_theta < 0) n_theta = -n_theta;
             }
 #pragma unroll
-            for (int k = 0; k < 6; k++) if (k < nprec && n_theta <= precs[k]) ++alg[k];
+            for (int k = 0; k < NP; k++) if (n_theta <= precs[k]) ++alg[k];
         }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {  // butterfly inside the 16-lane group
         total += __shfl_xor(total, o, 64);
 #pragma unroll
-        for (int k = 0; k < 6; k++) alg[k] += __shfl_xor(alg[k], o, 64);
+        for (int k = 0; k < NP; k++) alg[k] += __shfl_xor(alg[k], o, 64);
     }
     out.total = total;
 #pragma unroll
-    for (int k = 0; k < 6; k++) out.alg[k] = alg[k];
+    for (int k = 0; k < 6; k++) out.alg[k] = k < NP ? alg[k < NP ? k : 0] : 0;
 }
 
 __device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
@@ -1578,9 +1584,11 @@ __global__ void k_nfa_clamp(int *__restrict__ counters, int *__restrict__ status
     if (counters[0] > g.nfa_pool) { counters[0] = g.nfa_pool; atomicOr(status, 1); }
 }
 
-// persistent waves: entry e -> counts[e];  n = counters[cidx] * mult
-__global__ void __launch_bounds__(64) k_nfa_count(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
-                                                  const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
+// persistent waves: entry e -> counts[e];  n = counters[cidx] * mult.  k_nfa_count: stages 0 and 4 (entries carry nprec 6 or 0), k_nfa_count1:
+// stages 1..3 (nprec 1 or 0)
+template <int NP>
+__device__ __forceinline__ void nfa_count_body(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
+                                               int cidx, int mult, NfaCounts *__restrict__ counts, const LsdGeom &g)
 {
     const int n = counters[cidx] * mult;
     const int grp = threadIdx.x >> 4;
@@ -1590,9 +1598,21 @@ __global__ void __launch_bounds__(64) k_nfa_count(const float *__restrict__ ang_
         const NfaEntry en = entries[e];
         if (en.nprec == 0) continue;
         NfaCounts c;
-        rect_count(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, en.nprec, c);
+        if (en.nprec == NP) rect_count<NP>(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, c);
+        else if (NP == 1) rect_count<6>(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, c);   // (not produced by k_nfa_math; kept for safety)
+        else rect_count<1>(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, c);
         if ((threadIdx.x & 15) == 0) counts[e] = c;
     }
+}
+__global__ void __launch_bounds__(64) k_nfa_count(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
+                                                  const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
+{
+    nfa_count_body<6>(ang_all, entries, counters, cidx, mult, counts, g);
+}
+__global__ void __launch_bounds__(64) k_nfa_count1(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
+                                                   const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
+{
+    nfa_count_body<1>(ang_all, entries, counters, cidx, mult, counts, g);
 }
 
 __device__ __forceinline__ void nfa_finish(const NfaState &st, float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, const LsdGeom &g)
