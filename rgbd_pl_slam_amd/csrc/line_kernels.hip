@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(256) k_lsd_finalize(const float4 *__restrict__
     if (t == 0) n_out[f] = nout;
 }
 
-typedef unsigned long long __attribute__((aligned(1))) plf_u64u;   // 8-byte access at byte alignment (legal on gfx950 global memory)
+typedef unsigned long long __attribute__((aligned(1))) plf_u64u;
+typedef uint32_t __attribute__((aligned(1))) plf_u32u;            // dword access at byte alignment   // 8-byte access at byte alignment (legal on gfx950 global memory)
 struct __attribute__((aligned(4))) plf_short8 { short2 a, b, c, d; };
 
 // A thread produces 4 consecutive pixels: 3 x 8 source bytes (one unaligned 8-byte load per row) instead of 32 byte
@@ -148,55 +149,118 @@ __global__ void __launch_bounds__(256) k_sobel3(const uint8_t *__restrict__ in, 
 // 8U GaussianBlur = 8-bit fixed-point separable filter: taps k5 (14 63 103 63 14), row pass exact int32, column pass sum / 65536 rounded as
 // OpenCV 3.3's SymmColumnVec_32s8u does (half-to-even) for x < (w & ~3) and as its scalar tail ((s + 32768) >> 16) for the last w % 4
 // columns -- the same rule as the 7 x 7 blur of the ORB path (orb_kernels.hip); REFLECT_101 at the image edge for the blur AND for the Sobel.
+// Every phase works on groups of 4 pixels: the raw bytes of the tile are staged in LDS with dword loads (396 per tile; round 1 of this kernel issued
+// 7260 single-byte global loads per tile and ran at 1 TB/s), the 5-tap row sums are one v_dot4_u32_u8 + one multiply-add per pixel on byte windows
+// cut out with v_alignbyte, the column pass reads int4 row-sum vectors, the Sobel reads two dwords per row for 4 pixels.  The staged bytes are already
+// mirrored (REFLECT_101) at the image border, so the row pass has no border case.
 #define BS_TW 64
 #define BS_TH 16
+#define BS_RAWW 80   // staged bytes per row: image x0 - 4 .. x0 + 75
+#define BS_RSW 68    // row sums per row:    image x0 - 1 .. x0 + 66 (66 used)
+#define BS_BLW 72    // blurred bytes per row: image x0 - 1 .. (68 written, 66 used)
 __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, short2 *__restrict__ grad,
                                                       LsdGeom g, int4 k5 /* k[0], k[1], k[2] */)
 {
-    __shared__ int rows[BS_TH + 6][BS_TW + 2];       // row sums at image (x0 - 1 + c, y0 - 3 + r)
-    __shared__ uint8_t blur[BS_TH + 2][BS_TW + 4];   // blurred bytes at image (x0 - 1 + c, y0 - 1 + r)
+    __shared__ __attribute__((aligned(16))) uint8_t raw[BS_TH + 6][BS_RAWW];   // image (x0 - 4 + i, y0 - 3 + r)
+    __shared__ __attribute__((aligned(16))) int rows[BS_TH + 6][BS_RSW];       // row sums at image (x0 - 1 + c, y0 - 3 + r)
+    __shared__ __attribute__((aligned(16))) uint8_t blur[BS_TH + 2][BS_BLW];   // blurred bytes at image (x0 - 1 + c, y0 - 1 + r)
     const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH, f = blockIdx.z, t = threadIdx.x;
     const int W = g.w, H = g.h;
     const uint8_t *img = in + (size_t)f * fstride;
-    for (int i = t; i < (BS_TH + 6) * (BS_TW + 2); i += 256) {
-        const int r = i / (BS_TW + 2), c = i - r * (BS_TW + 2);
-        const int X = x0 - 1 + c, Y = y0 - 3 + r;
-        if (X < 0 || X >= W || Y < 0 || Y >= H) continue;   // only reached through reflection, which lands inside the image
+    // ---- 0. raw bytes, mirrored in x
+    for (int i = t; i < (BS_TH + 6) * (BS_RAWW / 4); i += 256) {
+        const int r = i / (BS_RAWW / 4), i4 = i - r * (BS_RAWW / 4);
+        const int Y = y0 - 3 + r, X4 = x0 - 4 + 4 * i4;
+        if (Y < 0 || Y >= H) continue;   // only reached through reflection, which lands inside the image
         const uint8_t *S = img + (size_t)Y * pitch;
-        int s;
-        if (X >= 2 && X + 2 < W) s = k5.x * (S[X - 2] + S[X + 2]) + k5.y * (S[X - 1] + S[X + 1]) + k5.z * S[X];
-        else s = k5.x * (S[plf_reflect101(X - 2, W)] + S[plf_reflect101(X + 2, W)]) + k5.y * (S[plf_reflect101(X - 1, W)] + S[plf_reflect101(X + 1, W)]) + k5.z * S[X];
-        rows[r][c] = s;
+        uint32_t v;
+        if (X4 >= 0 && X4 + 3 < W) v = *(const plf_u32u *)(S + X4);
+        else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)S[plf_reflect101(X4 + j, W)] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(&raw[r][4 * i4]) = v;
     }
     __syncthreads();
-    const int wvec = W & ~3;
-    for (int i = t; i < (BS_TH + 2) * (BS_TW + 2); i += 256) {
-        const int r = i / (BS_TW + 2), c = i - r * (BS_TW + 2);
-        const int X = x0 - 1 + c, Y = y0 - 1 + r;
-        if (X < 0 || X >= W || Y < 0 || Y >= H) continue;
-#define ROW_(yy) rows[plf_reflect101((yy), H) - (y0 - 3)][c]
-        const int s = k5.x * (ROW_(Y - 2) + ROW_(Y + 2)) + k5.y * (ROW_(Y - 1) + ROW_(Y + 1)) + k5.z * ROW_(Y);
+    // ---- 1. row sums s(X) = k0 (S[X-2] + S[X+2]) + k1 (S[X-1] + S[X+1]) + k2 S[X], 4 per item: X = x0 - 1 + c has its taps at staged columns c + 1 .. c + 5
+    {
+        const uint32_t K = (uint32_t)k5.x | ((uint32_t)k5.y << 8) | ((uint32_t)k5.z << 16) | ((uint32_t)k5.y << 24);
+        for (int i = t; i < (BS_TH + 6) * (BS_RSW / 4); i += 256) {
+            const int r = i / (BS_RSW / 4), g4 = i - r * (BS_RSW / 4);
+            const int Y = y0 - 3 + r;
+            if (Y < 0 || Y >= H) continue;
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(&raw[r][4 * g4]);
+            const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
+            int4 o;
+            o.x = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K, (uint32_t)k5.x * ((w1 >> 8) & 0xFFu), false);
+            o.y = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K, (uint32_t)k5.x * ((w1 >> 16) & 0xFFu), false);
+            o.z = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K, (uint32_t)k5.x * (w1 >> 24), false);
+            o.w = (int)__builtin_amdgcn_udot4(w1, K, (uint32_t)k5.x * (w2 & 0xFFu), false);
+            *reinterpret_cast<int4 *>(&rows[r][4 * g4]) = o;
+        }
+    }
+    __syncthreads();
+    // ---- 2. column pass + OpenCV's rounding, 4 per item
+    {
+        const int wvec = W & ~3;
+        for (int i = t; i < (BS_TH + 2) * (BS_RSW / 4); i += 256) {
+            const int r = i / (BS_RSW / 4), g4 = i - r * (BS_RSW / 4);
+            const int Y = y0 - 1 + r;
+            if (Y < 0 || Y >= H) continue;
+#define ROW_(yy) (*reinterpret_cast<const int4 *>(&rows[plf_reflect101((yy), H) - (y0 - 3)][4 * g4]))
+            const int4 a = ROW_(Y - 2), b = ROW_(Y - 1), c = ROW_(Y), d = ROW_(Y + 1), e = ROW_(Y + 2);
 #undef ROW_
-        int v;
-        if (X < wvec) {
-            v = s >> 16;
-            const int rem = s & 0xFFFF;
-            if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
-        } else
-            v = (s + 32768) >> 16;
-        blur[r][c] = (uint8_t)(v > 255 ? 255 : v);
+            const int sv[4] = {k5.x * (a.x + e.x) + k5.y * (b.x + d.x) + k5.z * c.x, k5.x * (a.y + e.y) + k5.y * (b.y + d.y) + k5.z * c.y,
+                               k5.x * (a.z + e.z) + k5.y * (b.z + d.z) + k5.z * c.z, k5.x * (a.w + e.w) + k5.y * (b.w + d.w) + k5.z * c.w};
+            uint32_t out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int X = x0 - 1 + 4 * g4 + j, s_ = sv[j];
+                int v;
+                if (X < wvec) {
+                    v = s_ >> 16;
+                    const int rem = s_ & 0xFFFF;
+                    if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
+                } else
+                    v = (s_ + 32768) >> 16;
+                out |= (uint32_t)(v > 255 ? 255 : v) << (8 * j);
+            }
+            *reinterpret_cast<uint32_t *>(&blur[r][4 * g4]) = out;
+        }
     }
     __syncthreads();
-    short2 *out = grad + (size_t)f * g.full_stride;
-    for (int i = t; i < BS_TH * BS_TW; i += 256) {
-        const int ry = i / BS_TW, cx = i - ry * BS_TW;
+    // ---- 3. the two 3 x 3 Sobel derivatives of the blurred image, 4 pixels per thread (16 rows x 16 groups = one item each)
+    {
+        const int ry = t >> 4, cx = (t & 15) * 4;
         const int x = x0 + cx, y = y0 + ry;
-        if (x >= W || y >= H) continue;
-        const int xm = plf_reflect101(x - 1, W) - (x0 - 1), xc = cx + 1, xp = plf_reflect101(x + 1, W) - (x0 - 1);
+        if (x >= W || y >= H) return;
         const int ym = plf_reflect101(y - 1, H) - (y0 - 1), yc = ry + 1, yp = plf_reflect101(y + 1, H) - (y0 - 1);
-        const int gx = (blur[ym][xp] + 2 * blur[yc][xp] + blur[yp][xp]) - (blur[ym][xm] + 2 * blur[yc][xm] + blur[yp][xm]);
-        const int gy = (blur[yp][xm] + 2 * blur[yp][xc] + blur[yp][xp]) - (blur[ym][xm] + 2 * blur[ym][xc] + blur[ym][xp]);
-        out[(size_t)y * W + x] = make_short2((short)gx, (short)gy);
+        short2 *out = grad + (size_t)f * g.full_stride + (size_t)y * W + x;
+        if (x >= 1 && x + 4 < W) {   // blurred columns x - 1 .. x + 4 exist: blur[][cx .. cx + 5]
+#define LD8_(row) ((unsigned long long)*reinterpret_cast<const uint32_t *>(&blur[row][cx]) | ((unsigned long long)*reinterpret_cast<const uint32_t *>(&blur[row][cx + 4]) << 32))
+            const unsigned long long a0 = LD8_(ym), a1 = LD8_(yc), a2 = LD8_(yp);
+#undef LD8_
+            short2 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#define B_(A, k) ((int)(((A) >> (8 * (k))) & 0xFF))
+                const int gx = (B_(a0, j + 2) + 2 * B_(a1, j + 2) + B_(a2, j + 2)) - (B_(a0, j) + 2 * B_(a1, j) + B_(a2, j));
+                const int gy = (B_(a2, j) + 2 * B_(a2, j + 1) + B_(a2, j + 2)) - (B_(a0, j) + 2 * B_(a0, j + 1) + B_(a0, j + 2));
+#undef B_
+                o[j] = make_short2((short)gx, (short)gy);
+            }
+            plf_short8 v; v.a = o[0]; v.b = o[1]; v.c = o[2]; v.d = o[3];
+            *(plf_short8 *)out = v;
+            return;
+        }
+        for (int j = 0; j < 4 && x + j < W; j++) {
+            const int xx = x + j;
+            const int xm = plf_reflect101(xx - 1, W) - (x0 - 1), xc = cx + j + 1, xp = plf_reflect101(xx + 1, W) - (x0 - 1);
+            const int gx = (blur[ym][xp] + 2 * blur[yc][xp] + blur[yp][xp]) - (blur[ym][xm] + 2 * blur[yc][xm] + blur[yp][xm]);
+            const int gy = (blur[yp][xm] + 2 * blur[yp][xc] + blur[yp][xp]) - (blur[ym][xm] + 2 * blur[ym][xc] + blur[ym][xp]);
+            out[j] = make_short2((short)gx, (short)gy);
+        }
     }
 }
 
