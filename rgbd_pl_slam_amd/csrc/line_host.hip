@@ -450,7 +450,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
                        h->d_nfa_counters, status, g);
     hipLaunchKernelGGL(k_nfa_clamp, dim3(1), dim3(1), 0, s, h->d_nfa_counters, status, g);
-    const int count_waves = 256 * 16, math_blocks = 1024;
+#ifndef PLF_NFA_COUNT_WAVES
+#define PLF_NFA_COUNT_WAVES (256 * 64)   // persistent waves of k_nfa_count: 16 per SIMD offered (occupancy by VGPRs: 8); the kernel is HBM-latency bound
+#endif
+    const int count_waves = PLF_NFA_COUNT_WAVES, math_blocks = 1024;
     for (int stage = 0; stage <= 4; stage++) {
         const int in = stage & 1, out = in ^ 1;
         if (stage >= 1 && stage <= 3)
