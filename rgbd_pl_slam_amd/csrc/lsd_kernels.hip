@@ -54,9 +54,12 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
                                                  LsdTaps t, const int *__restrict__ xofs, const float2 *__restrict__ xa,
                                                  const int *__restrict__ yofs, const float2 *__restrict__ yb)
 {
+    // LDS: the row-pass tile (22.5 KB; the column pass overwrites it IN PLACE with the blurred tile -- every thread first reads the 14 rows behind its
+    // 8 outputs into registers, one barrier, then writes -- and the list of defined pixels reuses it at the end) + the scaled tile (8.8 KB): 31 KB per
+    // workgroup, 4 resident tiles of 8 waves per CU (a separate 18 KB blurred tile made it 40 KB / 3 tiles)
     __shared__ double s_tmp[(PRE_SR + 6) * PRE_SC];
-    __shared__ double s_blur[PRE_SR * PRE_SC];
-    double *s_sc = s_tmp;   // the scaled tile reuses the row-pass buffer
+    __shared__ double s_sc[(PRE_TH + 1) * (PRE_TW + 1)];
+    double *s_blur = s_tmp;   // blurred row r at s_tmp row r (after the column pass)
     const int f = blockIdx.z, tid = threadIdx.x;
     const int dx0 = blockIdx.x * PRE_TW, dy0 = blockIdx.y * PRE_TH;
     const int dx1 = min(dx0 + PRE_TW, g.sw - 1), dy1 = min(dy0 + PRE_TH, g.sh - 1);
@@ -83,14 +86,28 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         s_tmp[i] = s;
     }
     __syncthreads();
-    for (int i = tid; i < nr * PRE_SC; i += PRE_NT) {
-        const int r = i / PRE_SC, c = i - r * PRE_SC;
-        if (c >= nc) continue;
-        const double *p = s_tmp + (r + 3) * PRE_SC + c;
-        double s = t.k[3] * p[0] + 0.0;
+    {
+        // column pass, one item = (column c, band of 8 blurred rows): at most 4 bands x 88 columns <= PRE_NT items, so one round
+        static_assert(((PRE_SR + 7) / 8) * PRE_SC <= PRE_NT, "one column-pass item per thread");
+        const int cb = tid / PRE_SC, cc = tid - cb * PRE_SC, rb0 = 8 * cb;
+        const bool item = cc < nc && rb0 < nr;
+        double v[14];
+        if (item) {
 #pragma unroll
-        for (int q = 1; q <= 3; q++) s += t.k[3 + q] * (p[q * PRE_SC] + p[-q * PRE_SC]);
-        s_blur[i] = s;
+            for (int j = 0; j < 14; j++) v[j] = (rb0 + j < nr + 6) ? s_tmp[(rb0 + j) * PRE_SC + cc] : 0.0;
+        }
+        __syncthreads();
+        if (item) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (rb0 + j < nr) {
+                    double s_ = t.k[3] * v[j + 3] + 0.0;
+#pragma unroll
+                    for (int q = 1; q <= 3; q++) s_ += t.k[3 + q] * (v[j + 3 + q] + v[j + 3 - q]);
+                    s_blur[(rb0 + j) * PRE_SC + cc] = s_;
+                }
+            }
+        }
     }
     __syncthreads();
     const int ncs = dx1 - dx0 + 1, nrs = dy1 - dy0 + 1;
@@ -115,7 +132,7 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     // ll_angle for the tile; the pixels with a defined angle are compacted (wave ballots) into an LDS list so that the double-precision sincos
     // below runs on full waves (about a quarter of the pixels have a gradient above the threshold)
     __shared__ int s_ndef;
-    float2 *s_list = reinterpret_cast<float2 *>(s_blur);   // (offset inside the frame, angle in degrees); the blurred tile is dead after the resize
+    float2 *s_list = reinterpret_cast<float2 *>(s_tmp);   // (offset inside the frame, angle in degrees); the blurred tile is dead after the resize
     if (tid == 0) s_ndef = 0;
     __syncthreads();
     const int tx = tid & 63;
