@@ -228,7 +228,8 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             const uint8_t *prow = P + (plf_reflect101(py - PLF_EDGE, H) - ey0) * PW - ex0;   // indexed by level x
             uint8_t *drow = plane + (size_t)py * L.ppitch + PLF_EDGE;                        // indexed by level x
             // (measured alternatives: 16-byte stores at byte alignment 29.8 -> 41.9 ms per 4096 frames; a plane layout that makes these dword stores
-            // aligned -- pitch rounded to 64, one pad byte in front of every row -- changes nothing: 29.8 ms)
+            // aligned -- pitch rounded to 64, one pad byte in front of every row -- changes nothing: 29.8 ms; writing the mirrored border columns as byte-swapped
+            // dwords instead of single bytes: 30.4 ms.  The cost of this phase is not its instruction count)
             for (int x4 = xg0 + tc4; x4 + PLF_EDGE < pxe; x4 += 128) {
                 if (x4 >= 0 && x4 + 3 < W && x4 + PLF_EDGE >= pxs && x4 + 3 + PLF_EDGE < pxe)
                     *(plf_u32u *)(drow + x4) = *reinterpret_cast<const uint32_t *>(prow + x4);
