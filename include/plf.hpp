@@ -12,6 +12,7 @@
 // see INTEGRATION.md.  Error behaviour: the reference returns silently on an empty image and asserts on a wrong
 // type; here empty -> outputs cleared, everything else -> plf::Error (never a silent fallback).
 #pragma once
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <algorithm>
@@ -313,6 +314,106 @@ struct Frame {
                                 mTrackProjY2_dev, mTrackProjX2R_dev, mnTrackScaleLevel_dev, mTrackViewCos_dev, mbTrackInView_dev, device, stream),
               "Frame::isInFrustum(MapLine)");
     }
+};
+
+// ------------------------------------------------------------------ batches of independent host frames on all GPUs of the node
+// The caller loop of the reference (Examples/RGB-D/rgbd_tum.cc:84-128 -> System::TrackRGBD -> Tracking::GrabImageRGBD -> RGB-D Frame::Frame,
+// include/Frame.h:60) for N frames at once: plf_batch_* shards the frames over the GPUs in contiguous blocks (no collective), stages them through
+// pinned double buffers and returns every Frame member the front-end produces.  Frames are independent: this is the offline / dataset-replay /
+// multi-camera mode (BASELINE configs 3-4); the live loop uses ORBextractor / LineSegment above.
+struct BatchFrames {   // outputs of one call: frame f at [f * kp_capacity, ...) / [f * line_capacity, ...)
+    int n = 0, kp_capacity = 0, line_capacity = 0;
+    std::vector<plf_keypoint> mvKeys, mvKeysUn; std::vector<uint8_t> mDescriptors; std::vector<int32_t> N;
+    std::vector<float> mvuRight, mvDepth;
+    std::vector<plf_keyline> mvKeylines, mvKeylinesUn; std::vector<uint8_t> mLdesc; std::vector<double> mvKeyLineFunctions; std::vector<int32_t> NL;
+    std::vector<float> mvuRightLineStart, mvuRightLineEnd, mvDepthLineStart, mvDepthLineEnd;
+    std::vector<int32_t> match_of_kp, n_kp_matches, match_of_line, n_line_matches;   // against the local map of set_local_map (-1 = none)
+};
+
+class BatchExtractor {
+public:
+    // devices empty = every visible GPU.  rgbd = the Frame-tail buffers of extract_rgbd.
+    BatchExtractor(int nfeatures, int nlines, int width, int height, int frames_in_flight = 8, const std::vector<int> &devices = {},
+                   int input_format = PLF_FMT_GRAY8, int max_mappoints = 0, int max_maplines = 0, bool rgbd = false, float scaleFactor = 1.2f, int nlevels = 8,
+                   int iniThFAST = 20, int minThFAST = 7)
+        : nfeatures_(nfeatures), nlines_(nlines), kp_cap_(nfeatures > 0 ? nfeatures + 4 * nlevels : 0)
+    {
+        plf_batch_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.orb.nfeatures = nfeatures; p.orb.scale_factor = scaleFactor; p.orb.nlevels = nlevels; p.orb.ini_th_fast = iniThFAST; p.orb.min_th_fast = minThFAST;
+        p.orb.max_width = width; p.orb.max_height = height; p.orb.max_batch = 1;
+        p.line.nlines = nlines; p.line.max_width = width; p.line.max_height = height; p.line.max_batch = 1; p.line.lbd_sobel_input = PLF_LBD_BLURRED;
+        std::vector<int32_t> dv(devices.begin(), devices.end());
+        p.n_devices = (int32_t)dv.size(); p.devices = dv.empty() ? nullptr : dv.data();
+        p.frames_in_flight = frames_in_flight; p.input_format = input_format; p.max_mappoints = max_mappoints; p.max_maplines = max_maplines; p.rgbd = rgbd ? 1 : 0;
+        check(plf_batch_create(&p, &b_), "plf_batch_create");
+    }
+    ~BatchExtractor() { plf_batch_destroy(b_); }
+    BatchExtractor(const BatchExtractor &) = delete;
+    BatchExtractor &operator=(const BatchExtractor &) = delete;
+
+    int device_count() const { return plf_batch_device_count(b_); }
+    // host arrays of the tracking fields of the local map; replicated on every GPU (Tracking::SearchLocalPoints / SearchLocalLines feed)
+    void set_local_map(const plf_mappoint_view *points, const plf_mapline_view *lines, float th, float nnratio, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY)
+    {
+        check(plf_batch_set_local_map(b_, points, lines, th, nnratio, mnMinX, mnMinY, mnMaxX, mnMaxY), "plf_batch_set_local_map");
+        has_map_ = (points && points->m > 0) || (lines && lines->m > 0);
+    }
+    // gray / RGB / BGR frames (the format given to the constructor); returns PLF_OK or PLF_E_CAPACITY (outputs truncated), throws otherwise
+    int extract(const uint8_t *images, int64_t n_frames, int width, int height, ptrdiff_t pitch, ptrdiff_t frame_stride, BatchFrames &out)
+    {
+        return run(images, n_frames, width, height, pitch, frame_stride, nullptr, nullptr, 0, 0, 0.f, out);
+    }
+    // RGB-D Frame constructor per frame: depth = uint16 images (NULL: none), mDepthMapFactor = 1 / DepthMapFactor of the settings file
+    int extract_rgbd(const uint8_t *images, const uint16_t *depth, int64_t n_frames, int width, int height, ptrdiff_t pitch, ptrdiff_t frame_stride,
+                     ptrdiff_t depth_pitch_elems, ptrdiff_t depth_frame_stride_elems, const plf_camera &cam, float mDepthMapFactor, BatchFrames &out)
+    {
+        return run(images, n_frames, width, height, pitch, frame_stride, &cam, depth, depth_pitch_elems, depth_frame_stride_elems, mDepthMapFactor, out);
+    }
+    plf_batch *handle() { return b_; }
+
+private:
+    int run(const uint8_t *images, int64_t n, int width, int height, ptrdiff_t pitch, ptrdiff_t frame_stride, const plf_camera *cam, const uint16_t *depth,
+            ptrdiff_t dpitch, ptrdiff_t dstride, float factor, BatchFrames &o)
+    {
+        const size_t K = (size_t)n * kp_cap_, Lc = (size_t)n * nlines_;
+        o.n = (int)n; o.kp_capacity = kp_cap_; o.line_capacity = nlines_;
+        plf_batch_outputs O;
+        std::memset(&O, 0, sizeof(O));
+        if (nfeatures_ > 0) {
+            o.mvKeys.assign(K, plf_keypoint()); o.mDescriptors.assign(K * 32, 0); o.N.assign(n, 0);
+            O.kps = o.mvKeys.data(); O.desc = o.mDescriptors.data(); O.n_kps = o.N.data(); O.kp_capacity = kp_cap_;
+            if (has_map_) { o.match_of_kp.assign(K, -1); o.n_kp_matches.assign(n, 0); O.match_of_kp = o.match_of_kp.data(); O.n_kp_matches = o.n_kp_matches.data(); }
+        }
+        if (nlines_ > 0) {
+            o.mvKeylines.assign(Lc, plf_keyline()); o.mLdesc.assign(Lc * 32, 0); o.mvKeyLineFunctions.assign(Lc * 3, 0.0); o.NL.assign(n, 0);
+            O.lines = o.mvKeylines.data(); O.ldesc = o.mLdesc.data(); O.line_eq = o.mvKeyLineFunctions.data(); O.n_lines = o.NL.data(); O.line_capacity = nlines_;
+            if (has_map_) { o.match_of_line.assign(Lc, -1); o.n_line_matches.assign(n, 0); O.match_of_line = o.match_of_line.data(); O.n_line_matches = o.n_line_matches.data(); }
+        }
+        int st;
+        if (!cam) st = plf_batch_extract(b_, images, n, width, height, pitch, frame_stride, &O);
+        else {
+            plf_batch_rgbd R;
+            std::memset(&R, 0, sizeof(R));
+            R.cam = *cam; R.depth_factor = factor; R.depth = depth; R.depth_pitch_elems = dpitch; R.depth_frame_stride_elems = dstride;
+            if (nfeatures_ > 0) {
+                o.mvKeysUn.assign(K, plf_keypoint()); o.mvuRight.assign(K, -1.f); o.mvDepth.assign(K, -1.f);
+                R.kps_un = o.mvKeysUn.data(); R.uright = o.mvuRight.data(); R.kp_depth = o.mvDepth.data();
+            }
+            if (nlines_ > 0) {
+                o.mvKeylinesUn.assign(Lc, plf_keyline());
+                o.mvuRightLineStart.assign(Lc, -1.f); o.mvuRightLineEnd.assign(Lc, -1.f); o.mvDepthLineStart.assign(Lc, -1.f); o.mvDepthLineEnd.assign(Lc, -1.f);
+                R.lines_un = o.mvKeylinesUn.data(); R.uright_start = o.mvuRightLineStart.data(); R.uright_end = o.mvuRightLineEnd.data();
+                R.depth_start = o.mvDepthLineStart.data(); R.depth_end = o.mvDepthLineEnd.data();
+            }
+            st = plf_batch_extract_rgbd(b_, images, n, width, height, pitch, frame_stride, &O, &R);
+        }
+        if (st != PLF_OK && st != PLF_E_CAPACITY && st != PLF_E_EMPTY) check(st, "plf_batch_extract");
+        return st;
+    }
+    plf_batch *b_ = nullptr;
+    int nfeatures_, nlines_, kp_cap_;
+    bool has_map_ = false;
 };
 
 }  // namespace plf

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <cstring>
 #include "plf.hpp"
 #include <ORB_SLAM2/mock_slam.h>
 
@@ -210,6 +211,26 @@ int main(int argc, char **argv)
         STAGE("outputs written");
     }
     STAGE("end of LSD block");
+    // ---- plf::BatchExtractor: three RGB-D frames (the same image, shifted depth) through the product-side batch driver, 2 in flight
+    {
+        STAGE("BatchExtractor");
+        const int nb = 3;
+        std::vector<uint8_t> imgs((size_t)nb * w * h);
+        for (int f = 0; f < nb; f++) std::memcpy(imgs.data() + (size_t)f * w * h, img.data(), (size_t)w * h);
+        const std::vector<uint16_t> depth = rd<uint16_t>("batch_depth.u16");   // nb x h x w
+        const std::vector<float> camv = rd<float>("batch_cam.f32");             // fx fy cx cy k1 k2 p1 p2 k3 bf
+        plf_camera cam = {camv[0], camv[1], camv[2], camv[3], camv[4], camv[5], camv[6], camv[7], camv[8], camv[9]};
+        plf::BatchExtractor bx(dims[2], dims[3], w, h, 2, {0}, PLF_FMT_GRAY8, 0, 0, true);
+        plf::BatchFrames F;
+        const int st = bx.extract_rgbd(imgs.data(), depth.data(), nb, w, h, w, (ptrdiff_t)w * h, w, (ptrdiff_t)w * h, cam, 1.0f / 5000.0f, F);
+        if (st != PLF_OK || F.n != nb) { fprintf(stderr, "batch status %d\n", st); return 3; }
+        wr("out_b_n.i32", F.N.data(), F.N.size()); wr("out_b_nl.i32", F.NL.data(), F.NL.size());
+        wr("out_b_kps.bin", F.mvKeys.data(), F.mvKeys.size()); wr("out_b_kun.bin", F.mvKeysUn.data(), F.mvKeysUn.size());
+        wr("out_b_ur.f32", F.mvuRight.data(), F.mvuRight.size()); wr("out_b_kd.f32", F.mvDepth.data(), F.mvDepth.size());
+        wr("out_b_lun.bin", F.mvKeylinesUn.data(), F.mvKeylinesUn.size()); wr("out_b_lds.f32", F.mvDepthLineStart.data(), F.mvDepthLineStart.size());
+        const int32_t caps[2] = {F.kp_capacity, F.line_capacity};
+        wr("out_b_caps.i32", caps, 2);
+    }
     printf("mirror driver ok: %zu key points, %zu lines\n", kps.size(), kl.size());
     return 0;
 }

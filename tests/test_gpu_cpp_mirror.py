@@ -53,6 +53,12 @@ def test_full_path_through_the_cpp_adapters(tmp_path):
     put("tri_stereo1.u8", st1); put("tri_stereo2.u8", st2)
     kfh = (rng.uniform(0, 1, len(kl)) < 0.5).astype(np.uint8)
     put("fuse_kf_has.u8", kfh)
+    # plf::BatchExtractor::extract_rgbd: 3 frames of the same image with different depth maps
+    from rgbd_pl_slam_amd.frame import TUM1
+    nb = 3
+    d16 = rng.integers(2000, 30000, (nb, h, w), dtype=np.uint16); d16[rng.uniform(0, 1, (nb, h, w)) < 0.1] = 0
+    camv = np.array([TUM1[k] for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")], np.float32)
+    put("batch_depth.u16", d16); put("batch_cam.f32", camv)
     run = subprocess.run([str(exe), d], text=True, capture_output=True)
     assert run.returncode == 0 and "mirror driver ok" in run.stdout, "driver failed (rc %d)\n%s\n%s" % (run.returncode, run.stdout, run.stderr[-2000:])
     get = lambda name, dt: np.fromfile(os.path.join(d, name), dt)
@@ -111,3 +117,19 @@ def test_full_path_through_the_cpp_adapters(tmp_path):
         else:
             nobs[("ml", i)] += 1; exp_added[i] = k; slot[k] = ("ml", i)
     assert np.array_equal(g[0:-1:2], exp_added) and np.array_equal(g[1:-1:2], exp_rep) and np.array_equal(held_rep, exp_held)
+    # ---- plf::BatchExtractor (RGB-D Frame constructor per frame)
+    caps = get("out_b_caps.i32", np.int32); kc, lc = int(caps[0]), int(caps[1])
+    bn = get("out_b_n.i32", np.int32); bnl = get("out_b_nl.i32", np.int32)
+    assert list(bn) == [len(kps)] * nb and list(bnl) == [len(kl)] * nb
+    bk = get("out_b_kps.bin", KP_DTYPE).reshape(nb, kc); bun = get("out_b_kun.bin", KP_DTYPE).reshape(nb, kc)
+    bur = get("out_b_ur.f32", np.float32).reshape(nb, kc); bkd = get("out_b_kd.f32", np.float32).reshape(nb, kc)
+    blun = get("out_b_lun.bin", KL_DTYPE).reshape(nb, lc); blds = get("out_b_lds.f32", np.float32).reshape(nb, lc)
+    for f in range(nb):
+        df = orc.depth_to_float(np.ascontiguousarray(d16[f]), np.float32(1.0 / 5000.0))
+        un, ur, kd = orc.frame_tail(kps, df, camv[:9], float(camv[9]))
+        assert all(np.array_equal(bk[f, :len(kps)][n].view(np.uint32), kps[n].view(np.uint32)) for n in KP_DTYPE.names)
+        assert all(np.array_equal(bun[f, :len(kps)][n].view(np.uint32), un[n].view(np.uint32)) for n in KP_DTYPE.names)
+        assert np.array_equal(bur[f, :len(kps)].view(np.uint32), ur.view(np.uint32)) and np.array_equal(bkd[f, :len(kps)].view(np.uint32), kd.view(np.uint32))
+        lun, urs, ure, ds, de = orc.line_tail(kl, df, camv[:9], float(camv[9]))
+        assert all(np.array_equal(blun[f, :len(kl)][n].view(np.uint32), lun[n].view(np.uint32)) for n in KL_DTYPE.names)
+        assert np.array_equal(blds[f, :len(kl)].view(np.uint32), ds.view(np.uint32))
