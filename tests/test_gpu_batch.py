@@ -179,6 +179,48 @@ def test_rgbd_frame_constructor_batch():
     bx.close()
 
 
+def test_chunk_redo_when_the_rectangle_pool_overflows():
+    """Eight frames of hard-edged stripes hold more LSD rectangles than the pooled NFA buffers of an 8-frame batch (PLF_E_RECTS): the worker redoes
+    the chunk through the splitting entry point and repeats the Frame tail and the line matching on the fresh lines; a normal chunk follows in the
+    same call (slot reuse after a redo)."""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd.frame import camera, TUM1
+    from rgbd_pl_slam_amd.synth import synth_frame
+    rng = np.random.default_rng(77000 + 246)
+    rng.random(); rng.integers(0, 12)
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    a = rng.uniform(0, np.pi); per = rng.uniform(3, 40)
+    stripes = (127.5 + 120 * np.sign(np.sin((xx * np.cos(a) + yy * np.sin(a)) * 2 * np.pi / per))).astype(np.uint8)
+    imgs = np.stack([stripes] * 8 + [synth_frame(600 + i) for i in range(3)])
+    n = len(imgs)
+    d16 = np.random.default_rng(5).integers(2000, 30000, (n, 480, 640), dtype=np.uint16)
+    cam = camera(**TUM1)
+    c9 = np.array([TUM1[k] for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")], np.float32)
+    refs = {}
+    for f in (0, 8, 9, 10):
+        refs[f] = orc.line_extract(imgs[f], 100)
+    for f in range(1, 8):
+        refs[f] = refs[0]
+    lun0 = orc.line_tail(refs[8]["kl"], None, c9, TUM1["bf"])[0]
+    ml = matchgen.make_map_lines(lun0, refs[8]["desc"], 300, 6)
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    bx = BatchExtractor(nfeatures=1000, nlines=100, width=640, height=480, frames_in_flight=8, devices=[0], max_mappoints=16, max_maplines=512, rgbd=True)
+    bx.set_local_map(None, ml, th=3.0, nnratio=0.8, bounds=(0.0, 0.0, 640.0, 480.0))
+    res = bx.extract(imgs, depth=d16, cam=cam)
+    for f in range(n):
+        _same_lines(res[f], refs[f], "frame %d" % f)
+        df = orc.depth_to_float(np.ascontiguousarray(d16[f]), np.float32(1.0 / 5000.0))
+        lun, urs, ure, ds, de = orc.line_tail(refs[f]["kl"], df, c9, TUM1["bf"])
+        for name in lun.dtype.names:
+            assert np.array_equal(res[f]["lines_un"][name].view(np.uint32), lun[name].view(np.uint32)), "frame %d: mvKeylinesUn.%s" % (f, name)
+        assert np.array_equal(res[f]["depth_end"].view(np.uint32), de.view(np.uint32)), "frame %d" % f
+        lm, ln = orc.search_lines_by_projection(lun, refs[f]["desc"], scale, ml, 3.0, 0.8, np.full(len(lun), -1, np.int32))
+        assert res[f]["n_line_matches"] == ln and np.array_equal(res[f]["match_of_line"], lm), "frame %d: line matches" % f
+    assert res[8]["n_line_matches"] > 10
+    bx.close()
+
+
 def test_all_visible_gpus_share_one_batch():
     """n_devices = 0: every visible GPU gets a contiguous block (plf_batch_shard); on the 1-GPU test box this is one worker, on an
     8-GPU node the same call exercises eight -- the per-frame outputs do not depend on the partition"""
