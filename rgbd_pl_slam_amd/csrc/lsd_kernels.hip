@@ -414,11 +414,13 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                 mA = candm & pos & __ballot(acr <= th.t1 * dot);
                 mB = candm & ~mA & pos & ~__ballot(acr >= th.t2 * dot);
             }
-            int k = -1;
-            while (mA | mB) {
-                const int j = __ffsll((long long)(mA | mB)) - 1;
-                if (!((mB >> j) & 1ull)) { k = j; break; }   // surely aligned
-                // border lane: the reference's own test
+            // the first remaining candidate that is not surely misaligned; border lanes are rare (the cone pre-test decides ~99.8 % of the candidates), so the
+            // loop is flat: one rarely taken branch for the reference's own test instead of an inner loop over the masks.  A candidate the exact test rejects
+            // is decided for good -- it precedes every lane that can still be accepted, and a later accept drops the lanes before it anyway.
+            const unsigned long long mAB = mA | mB;
+            if (!mAB) break;
+            const int k = __ffsll((long long)mAB) - 1;
+            if ((mB >> k) & 1ull) {
                 if (!theta_valid) {
                     // (the empty asm pins the fastAtan2 -- two IEEE divisions -- inside this rarely taken branch; the
                     // compiler would otherwise evaluate it speculatively on every accept step)
@@ -428,7 +430,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                     theta_valid = true;
                 }
                 bool al = false;
-                if (lane == j) {
+                if (lane == k) {
                     double n_theta = reg_angle - (double)__uint_as_float(cur.w) * DEG2RAD_D;
                     if (n_theta < 0) n_theta = -n_theta;
                     if (n_theta > M_3_2_PI_D) {
@@ -437,10 +439,8 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                     }
                     al = n_theta <= prec;
                 }
-                if (__ballot(al)) { k = j; break; }
-                mB &= ~(1ull << j);   // not aligned; the sums did not change, the other masks stay valid
+                if (!__ballot(al)) { candm &= ~(1ull << k); continue; }   // not aligned: the sums did not change
             }
-            if (k < 0) break;
             CNT(9, 1);
             if (lane == k) {
                 used_set(C, cur.a, cur.w);
