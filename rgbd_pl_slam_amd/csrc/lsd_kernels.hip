@@ -727,11 +727,12 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     for (int base = 0; base < NP; base += 64) {
         int px = base + lane;
         if (seeds) px = px < NP ? (int)(seeds[px] & 0xFFFFFu) : NP;
+        // (the seed sums are fetched with the angle words, not after them: one round trip per chunk of 64 seeds instead of two dependent ones)
+        float2 c0 = make_float2(0.f, 0.f);
+        if (px < NP) c0 = C.cs0[px];
         uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
         const float deg = __uint_as_float(w);
-        float2 c0 = make_float2(0.f, 0.f);
-        if (ok) c0 = C.cs0[px];
         C.cbase = seeds ? -0x40000000 : base;   // (list order: the chunk is not contiguous, flags are re-read after every region)
         C.cused = 0ull;
         unsigned long long mask = __ballot(ok);
