@@ -248,7 +248,6 @@ struct RegCtx {
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
     int gcap;                  // entries of rxy_g (scratch beyond the list: reduce_region_radius)
-    int eager;                 // few frames in flight (latency mode): fetch the cos/sin increment together with the angle word
     int use_bm;                // speculative mode: the USED flags live in an LDS bitmap (bm), the angle words are read-only
     LDS_PTR(uint32_t) bm;
     int regrow_n;              // size of the list refine() regrew (-1: it did not regrow)
@@ -335,6 +334,9 @@ __device__ __forceinline__ GrowTh grow_thresholds(double prec)
 
 // 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order
 struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle word (candidate iff < 0x80000000)
+// The cos/sin increment is fetched together with the angle word (fetching it only for candidates, after the word has arrived, saves HBM traffic but puts a
+// second dependent round trip -- and an s_waitcnt that also stalls the group being processed -- into every step of the chain: 77.2 -> 71.4 ms per 4096
+// frames).  (A single-predicate, single-branch form of this function was measured too: 3 VGPRs more and 2.6 % slower.)
 __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, int lane, int slot, int kx, int ky)
 {
     Grp G;
@@ -345,17 +347,9 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
         if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
             G.a = yy * C.W + xx;
             G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            if (C.eager) {   // latency mode: one round trip instead of two dependent ones
-                const double2 c = C.cs[G.a];
-                G.w = ang_load(C, G.a);
-                G.csx = c.x; G.csy = c.y;
-            } else {
-                G.w = ang_load(C, G.a);
-                if (G.w < 0x80000000u) {   // only candidates can be accepted: no 16-byte increment fetch for NOTDEF / used pixels
-                    const double2 c = C.cs[G.a];
-                    G.csx = c.x; G.csy = c.y;
-                }
-            }
+            const double2 c = C.cs[G.a];
+            G.w = ang_load(C, G.a);
+            G.csx = c.x; G.csy = c.y;
         }
     }
     return G;
@@ -695,7 +689,7 @@ template <int LDSOFF, int FPW>
 __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                              const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                              uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                             int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int eager, int nframes)
+                                             int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int nframes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_base[];
     // FPW = 2 (k_lsd_regions2): two frames per workgroup, one wave each, every wave instantiated with ITS constant LDS offset
@@ -713,7 +707,6 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.rxy_l = (LDS_PTR(uint32_t))smem;
     C.rcap = g.rcap;
     C.gcap = (int)g.s_stride;
-    C.eager = eager;
     C.use_bm = 0; C.bm = (LDS_PTR(uint32_t))smem; C.regrow_n = -1;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
     // This wave is one long dependent chain; waves of other kernels sharing its SIMD only ever delay it.
@@ -781,7 +774,7 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
                                                     uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                     int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
 {
-    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 1, 0);
+    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
 }
 
 #define PLF_LSD_FPW2_LDS 6400
@@ -795,14 +788,8 @@ __global__ void PLF_REGIONS_OCC __launch_bounds__(128) k_lsd_regions2(float *__r
                                                       uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                       int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
 {
-    // eager = 1: the cos/sin increment of every inspected pixel is fetched together with its angle word.  Fetching it only for candidates (after the word
-    // has arrived) saves HBM traffic but puts a second dependent round trip -- and an s_waitcnt that also stalls the group being processed -- into every
-    // iteration of the chain: 77.2 -> 71.4 ms per 4096 frames
-#ifndef PLF_REGIONS2_EAGER
-#define PLF_REGIONS2_EAGER 1
-#endif
-    if (threadIdx.x < 64) regions_body<0, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, PLF_REGIONS2_EAGER, nframes);
-    else regions_body<PLF_LSD_FPW2_LDS, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, PLF_REGIONS2_EAGER, nframes);
+    if (threadIdx.x < 64) regions_body<0, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
+    else regions_body<PLF_LSD_FPW2_LDS, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
 }
 
 // Latency mode (a handful of frames in flight, e.g. the live SLAM loop): the chain of one frame is all there is to run, so its memory round
@@ -828,7 +815,7 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
         if (acc == 0x9E3779B9u) *sink = (int)acc;   // keeps the loads alive
         return;
     }
-    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 1, 0);
+    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +869,7 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
     C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
-    C.eager = 1; C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
+    C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
     C.cbase = -0x40000000; C.cused = 0ull;
 }
 
