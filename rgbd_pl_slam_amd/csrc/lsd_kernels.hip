@@ -384,7 +384,19 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     const int slot = lane / 9, k9 = lane - slot * 9;
     const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;
     int cur_n = 1;
-    Grp cur = load_group(C, 0, 1, lane, slot, kx, ky);
+    // (the first group is the seed itself: its neighbourhood is addressed from (sx, sy) directly, not through the list entry lane 0 has just written)
+    Grp cur;
+    cur.w = 0xFFFFFFFFu; cur.csx = 0.0; cur.csy = 0.0; cur.a = -1; cur.xy = 0u;
+    if (lane < 9) {
+        const int xx = sx + kx, yy = sy + ky;
+        if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
+            cur.a = yy * C.W + xx;
+            cur.xy = (uint32_t)xx | ((uint32_t)yy << 16);
+            const double2 c = C.cs[cur.a];
+            cur.w = ang_load(C, cur.a);
+            cur.csx = c.x; cur.csy = c.y;
+        }
+    }
     unsigned long long cur_stale = 0ull;   // lanes whose pixel was accepted after its word was loaded
     // All per-lane predicates of the accept loop are kept as wave-uniform 64-bit masks (the compares write them
     // directly), so the loop control is scalar and nothing bounces between VGPR booleans and masks.
