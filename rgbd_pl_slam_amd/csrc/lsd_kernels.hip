@@ -504,11 +504,15 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
             wx = (double)(int)(q & 0xFFFF) * w;
             wy = (double)(int)(q >> 16) * w;
         }
+        // (in list order, 8 points per loop trip; the lanes past the end hold +0.0, which leaves these non-negative sums unchanged bit for bit)
         const int cnt = min(64, n - base);
-        for (int k = 0; k < cnt; k++) {
-            x += readlane_d(wx, k);
-            y += readlane_d(wy, k);
-            sum += readlane_d(w, k);
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                x += readlane_d(wx, k0 + q);
+                y += readlane_d(wy, k0 + q);
+                sum += readlane_d(w, k0 + q);
+            }
         }
     }
     x /= sum;
@@ -526,10 +530,13 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
             txy = dx * dy * w;
         }
         const int cnt = min(64, n - base);
-        for (int k = 0; k < cnt; k++) {
-            Ixx += readlane_d(txx, k);
-            Iyy += readlane_d(tyy, k);
-            Ixy -= readlane_d(txy, k);
+        for (int k0 = 0; k0 < cnt; k0 += 8) {   // (Ixy - (+0.0) = Ixy as well: a running sum is never -0.0)
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                Ixx += readlane_d(txx, k0 + q);
+                Iyy += readlane_d(tyy, k0 + q);
+                Ixy -= readlane_d(txy, k0 + q);
+            }
         }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
