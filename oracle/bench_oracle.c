@@ -11,14 +11,7 @@
 #include <omp.h>
 #include "oracle.h"
 
-int orc_stage_timing = 0;
-__thread double orc_stage_s[ORC_NSTAGES];
-double orc_now_s(void)
-{
-    struct timespec t;
-    clock_gettime(CLOCK_MONOTONIC, &t);
-    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
-}
+/* (the stage timers orc_stage_timing / orc_stage_s / orc_now_s live in timing.c: orb_oracle.c is also linked alone into the reference probe) */
 
 /* one frame through the whole front-end on the calling thread (two_threads: ORB and LSD/LBD extraction on two OpenMP threads, as the
  * PL-SLAM family's Frame constructor does); returns the checksum contribution */

@@ -67,8 +67,10 @@ def main():
         os.path.join(ROOT, "oracle/orb_oracle.c"), "-o", os.path.join(OUT, "orb_oracle_probe.o")])
     sh(["gcc", "-c", "-O2", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "oracle"),
         os.path.join(ROOT, "oracle/frame_oracle.c"), "-o", os.path.join(OUT, "frame_oracle_probe.o")])
+    sh(["gcc", "-c", "-O2", "-fPIC", "-I", os.path.join(ROOT, "oracle"),
+        os.path.join(ROOT, "oracle/timing.c"), "-o", os.path.join(OUT, "timing_probe.o")])
     sh(["g++", "-rdynamic", os.path.join(OUT, "probe.o"),
-        os.path.join(OUT, "orb_oracle_probe.o"), os.path.join(OUT, "frame_oracle_probe.o"), "-o", probe, "-L/root/reference/lib", "-l:libORB_SLAM2.so",
+        os.path.join(OUT, "orb_oracle_probe.o"), os.path.join(OUT, "frame_oracle_probe.o"), os.path.join(OUT, "timing_probe.o"), "-o", probe, "-L/root/reference/lib", "-l:libORB_SLAM2.so",
         "-L" + STUBS, "-Wl,--allow-shlib-undefined", "-Wl,-rpath-link," + STUBS, "-ldl", "-lm"])
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = STUBS + ":/root/reference/lib:" + env.get("LD_LIBRARY_PATH", "")
