@@ -65,11 +65,13 @@ __device__ __forceinline__ plf_s2v of_max(plf_s2v a, plf_s2v b) { return __built
 // aligned dwords.  Tile column c <-> level x = ex0 + c with ex0 = 4 * floor(xs / 4) - 4, so groups of 4 columns are 4-aligned in the level image
 // too (aligned stores to the blurred plane).
 #define OF_NT PLF_ORB_LEVEL_THREADS   // threads per tile
-#ifdef PLF_ORB_LEVEL_WPE   // experiment switch (tools/variant_build.sh): cap the VGPRs for N waves per SIMD
-#define OF_OCC __attribute__((amdgpu_waves_per_eu(PLF_ORB_LEVEL_WPE, PLF_ORB_LEVEL_WPE)))
-#else
-#define OF_OCC
+// Register budget: 8 waves per SIMD = at most 64 VGPRs (the compiler lands on 51 without spilling a vector register; 73 uncapped).  Not for this
+// kernel's own occupancy (LDS allows 6 workgroups per CU) but for co-residency: four region-growing waves hold 416 of a SIMD's 512 VGPRs for 80 ms, and
+// in the 96 that are left a 56-register ORB wave fits TOGETHER with a matcher wave (40-48), an 80-register one alone: +2.5 % for the pipeline.
+#ifndef PLF_ORB_LEVEL_WPE
+#define PLF_ORB_LEVEL_WPE 8
 #endif
+#define OF_OCC __attribute__((amdgpu_waves_per_eu(PLF_ORB_LEVEL_WPE, PLF_ORB_LEVEL_WPE)))
 __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__ in, ptrdiff_t in_pitch, ptrdiff_t in_fstride, uint8_t *__restrict__ pyr,
                                                    uint8_t *__restrict__ blur, int l, const int *__restrict__ xofs, const short2 *__restrict__ xa,
                                                    const int *__restrict__ yofs, const short2 *__restrict__ yb, const int4 *__restrict__ cells,
