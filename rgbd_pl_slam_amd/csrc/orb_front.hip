@@ -132,14 +132,11 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         const OrbLevel &SL = g.lv[l - 1];
         const int SPW = g.lds_spw;
         // level coordinates the tile needs (mirrored halo coordinates fall inside this range), and the source rectangle behind them
-        const int lx_lo = max(ex0, 0), lx_hi = min(ex0 + EW - 1, W - 1), ly_lo = max(ey0, 0), ly_hi = min(ey0 + EH - 1, H - 1);
+        const int lx_lo = max(ex0, 0), lx_hi = min(ex0 + EW - 1, W - 1), ly_lo = max(ey0, 0);
         const int sx_lo = xofs[L.tabx_off + lx_lo] & ~3, sx_hi = min(xofs[L.tabx_off + lx_hi] + 1, SL.w - 1);
-        const int sy_lo = min(max(yofs[L.taby_off + ly_lo], 0), SL.h - 1), sy_hi = min(max(yofs[L.taby_off + ly_hi] + 1, 0), SL.h - 1);
-        const int SWt = sx_hi - sx_lo + 1, SHt = sy_hi - sy_lo + 1;
+        const int sy_lo = min(max(yofs[L.taby_off + ly_lo], 0), SL.h - 1);   // row origin of the row table below
+        const int SWt = sx_hi - sx_lo + 1;
         const uint8_t *src = pyr + (size_t)f * g.pyr_stride + SL.plane_off + (size_t)PLF_EDGE * SL.ppitch + PLF_EDGE;
-        for (int r = trow; r < SHt; r += NR)
-            for (int c4 = tc4; c4 < SWt + 8; c4 += 128)   // (+8: the 12-byte windows below may read past the last needed byte; the padded plane has them)
-                *reinterpret_cast<uint32_t *>(SRC + r * SPW + c4) = *(const plf_u32u *)(src + (size_t)(sy_lo + r) * SL.ppitch + sx_lo + c4);
         const int ngrp = EW >> 2;
         for (int i = tid; i < ngrp + EH; i += OF_NT) {
             if (i < ngrp) {   // one column group: its 4 table entries relative to the group's first source byte
@@ -172,15 +169,25 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 YT[i - ngrp] = t;
             }
         }
-        __syncthreads();
         // cv::resize INTER_LINEAR 8UC1 (OpenCV 3.3): dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2, 11-bit coefficients.
         // 4 outputs per thread: per source row one 8-byte window (three aligned LDS dwords, v_alignbyte), per output v_perm picks its two
-        // bytes as int16 lanes and v_dot2 multiplies them with the (a0, a1) pair
+        // bytes as int16 lanes and v_dot2 multiplies them with the (a0, a1) pair.
+        // The source rows are staged in g.lds_parts passes (the rows of the tile split evenly; orb_part_rows is the host's arithmetic): the staging buffer is
+        // what decides how many tiles a CU holds, and the kernel's run time is inversely proportional to that number.
         const uint32_t rcp_g = 0xFFFFFFFFu / (uint32_t)ngrp + 1u;   // i / ngrp = umulhi(i, rcp_g) for i < 65536
-        for (int i = tid; i < ngrp * EH; i += OF_NT) {
+        for (int part = 0; part < g.lds_parts; part++) {
+        int ps_lo, ps_hi;
+        orb_part_rows(ey0, EH, g.lds_parts, part, H, SL.h, yofs + L.taby_off, &ps_lo, &ps_hi);
+        const int e0 = part * EH / g.lds_parts, e1 = (part + 1) * EH / g.lds_parts, SHt = ps_hi - ps_lo + 1;
+        if (part > 0) __syncthreads();   // the previous part's rows have been consumed
+        for (int r = trow; r < SHt; r += NR)
+            for (int c4 = tc4; c4 < SWt + 8; c4 += 128)   // (+8: the 12-byte windows below may read past the last needed byte; the padded plane has them)
+                *reinterpret_cast<uint32_t *>(SRC + r * SPW + c4) = *(const plf_u32u *)(src + (size_t)(ps_lo + r) * SL.ppitch + sx_lo + c4);
+        __syncthreads();                 // (first part: the tables above as well)
+        for (int i = tid + e0 * ngrp; i < ngrp * e1; i += OF_NT) {
             const int ey = ngrp > 1 ? (int)__umulhi((uint32_t)i, rcp_g) : i, c4 = (i - ey * ngrp) * 4;
             const OrbRowTab ty_ = YT[ey];
-            const uint8_t *r0 = SRC + ty_.off * SPW, *r1 = SRC + ty_.nxt * SPW;
+            const uint8_t *r0 = SRC + (ty_.off + sy_lo - ps_lo) * SPW, *r1 = SRC + (ty_.nxt + sy_lo - ps_lo) * SPW;
             {
                 OrbColTab t[4];
                 *reinterpret_cast<uint4 *>(&t[0]) = *reinterpret_cast<const uint4 *>(&XT[c4]);
@@ -213,6 +220,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 }
                 *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = out;
             }
+        }
         }
     }
     __syncthreads();
@@ -291,7 +299,8 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
 #endif
     // ---- 4. FAST score of the cells' computed regions (score tile S: rows ry0.., columns = tile columns)
     const int RH = ry1 - ry0;
-    for (int i = tid; i < ((PW * RH + 3) >> 2); i += OF_NT) reinterpret_cast<uint32_t *>(S)[i] = 0u;
+    const int SP = g.lds_sp, cS0 = (rx0 - ex0) & ~3;   // score tile: pitch and first tile column (the computed regions only)
+    for (int i = tid; i < ((SP * RH + 3) >> 2); i += OF_NT) reinterpret_cast<uint32_t *>(S)[i] = 0u;
     __syncthreads();   // (every thread is done with the staged source: LIST aliases it)
     const int tmin = g.minTh;
     {
@@ -352,7 +361,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         d[4] = v - p[3];            d[5] = v - p[-PW + 3];      d[6] = v - p[-2 * PW + 2];  d[7] = v - p[-3 * PW + 1];
         d[8] = v - p[-3 * PW];      d[9] = v - p[-3 * PW - 1];  d[10] = v - p[-2 * PW - 2]; d[11] = v - p[-PW - 3];
         d[12] = v - p[-3];          d[13] = v - p[PW - 3];      d[14] = v - p[2 * PW - 2];  d[15] = v - p[3 * PW - 1];
-        S[ry * PW + c] = (uint8_t)orb_fast_score(d, tmin);
+        S[ry * SP + c - cS0] = (uint8_t)orb_fast_score(d, tmin);
     }
     __syncthreads();
 #if defined(OF_STOP) && OF_STOP <= 5
@@ -362,7 +371,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     // recorded as one bit per (cell, row, column) for the two thresholds
     for (int k = tid; k < nl; k += OF_NT) {
         const int q = LIST[k], c = q & 255, ry = q >> 8;
-        const uint8_t *sp = S + ry * PW + c;
+        const uint8_t *sp = S + ry * SP + c - cS0;
         const int sc = sp[0];
         if (sc < tmin) continue;
         const int x = ex0 + c, y = ry0 + ry;
@@ -372,8 +381,8 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         int nb = 0;
         if (okl) nb = max(nb, (int)sp[-1]);
         if (okr) nb = max(nb, (int)sp[1]);
-        if (oku) { nb = max(nb, (int)sp[-PW]); if (okl) nb = max(nb, (int)sp[-PW - 1]); if (okr) nb = max(nb, (int)sp[-PW + 1]); }
-        if (okd) { nb = max(nb, (int)sp[PW]); if (okl) nb = max(nb, (int)sp[PW - 1]); if (okr) nb = max(nb, (int)sp[PW + 1]); }
+        if (oku) { nb = max(nb, (int)sp[-SP]); if (okl) nb = max(nb, (int)sp[-SP - 1]); if (okr) nb = max(nb, (int)sp[-SP + 1]); }
+        if (okd) { nb = max(nb, (int)sp[SP]); if (okl) nb = max(nb, (int)sp[SP - 1]); if (okr) nb = max(nb, (int)sp[SP + 1]); }
         if (sc > nb) {
             const int ci = ccol + 2 * crow;
             const unsigned long long bit = 1ull << (x - xl);
@@ -390,7 +399,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         const int cell = L.cell_base + cy * L.ncx + cx;
         const int4 rc = cells[cell];                 // x0, y0, w, h of the sub-image (level interior coordinates)
         const int ch = rc.w - 6;                     // rows of the computed region
-        const uint8_t *sp = S + (rc.y + 3 - ry0) * PW + (rc.x + 3 - ex0);
+        const uint8_t *sp = S + (rc.y + 3 - ry0) * SP + (rc.x + 3 - ex0 - cS0);
         const unsigned long long my20 = lane < ch ? s_mask[wv][lane][0] : 0ull, my7 = lane < ch ? s_mask[wv][lane][1] : 0ull;   // lane r = row r
         const int n20 = plf_wave_sum(__popcll(my20));
         const unsigned long long mine = n20 > 0 ? my20 : my7;
@@ -414,7 +423,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             const int c = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
             const int x = rc.x + 3 + c;
-            const int resp = sp[lane * PW + c];
+            const int resp = sp[lane * SP + c];
             // coordinates relative to (minBorderX, minBorderY) as DistributeOctTree expects
             out[k++] = make_uint2((uint32_t)(x - PLF_MINB) | ((uint32_t)(gy - PLF_MINB) << 16), (uint32_t)resp);
         }

@@ -45,5 +45,26 @@ struct OrbGeom {
     uint32_t sel_stride;   // entries per frame
     // LDS layout of k_orb_level (bytes; maxima over the levels): pixel tile pitch, source tile pitch, score tile pitch, byte offsets
     int lds_pw, lds_spw, lds_sp, lds_eh, lds_off_a, lds_off_s, lds_off_list, lds_off_tab, lds_total;
+    int lds_parts;       // the source rows of a tile are staged in this many passes (rows of the tile split evenly): bounds the staging buffer
     OrbLevel lv[PLF_MAX_LEVELS];
 };
+
+// Source rows (of level l - 1) behind part `pi` of `parts` of a tile's rows [ey0, ey0 + EH) of level l: rows of the tile are split evenly, rows outside
+// the level are REFLECT_101 mirrors (they fall inside the part's clamped range: a tile keeps >= 4 rows inside).  yofs: the level's row table.
+// Used by the host (LDS sizing) and by k_orb_level (staging) -- the same arithmetic on both sides.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline void orb_part_rows(int ey0, int EH, int parts, int pi, int H, int srcH, const int *yofs, int *s_lo, int *s_hi)
+{
+    const int e0 = pi * EH / parts, e1 = (pi + 1) * EH / parts;
+    const int a = ey0 + e0, b = ey0 + e1 - 1;
+    const int ra = a < 0 ? -a : (a >= H ? 2 * (H - 1) - a : a), rb = b < 0 ? -b : (b >= H ? 2 * (H - 1) - b : b);
+    int lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
+    if (a < 0 && b >= 0) lo = 0;
+    if (a <= H - 1 && b > H - 1) hi = H - 1;
+    int sl = yofs[lo], sh = yofs[hi] + 1;
+    sl = sl < 0 ? 0 : (sl > srcH - 1 ? srcH - 1 : sl);
+    sh = sh < 0 ? 0 : (sh > srcH - 1 ? srcH - 1 : sh);
+    *s_lo = sl; *s_hi = sh;
+}

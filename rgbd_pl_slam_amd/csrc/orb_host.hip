@@ -1,6 +1,9 @@
 // orb_host.hip -- host side of the ORB extractor: handle, geometry, tables, launch sequence, C ABI.
 // Mirrors ORB_SLAM2::ORBextractor (include/ORBextractor.h:44-112): ctor tables (so@0x73050),
 // ComputePyramid geometry (so@0x70430), cell tiling of ComputeKeyPointsOctTree (so@0x75fa0).
+#ifndef PLF_ORB_LDS_PAD
+#define PLF_ORB_LDS_PAD 0   // experiment: extra dynamic LDS per tile (occupancy sensitivity)
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -235,9 +238,12 @@ static int orb_configure(plf_orb *h, int w, int hh)
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * ty, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(short2) * ty, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), sizeof(int4) * cells.size(), hipMemcpyHostToDevice));
-    // LDS layout of k_orb_level: maxima over all tiles of all levels
+    // LDS layout of k_orb_level: maxima over all tiles of all levels.  The kernel is latency-bound per tile, so its run time is inversely
+    // proportional to the tiles a CU holds (measured: 52 / 37 / 30 ms per 4096 frames for 2 / 3 / 4 resident tiles): the source rows of a tile are
+    // staged in `parts` passes and the score tile only spans the cells' computed columns, so that 5 tiles fit (38.5 -> 30.8 KB at VGA).
     {
-        int maxEW = 0, maxEH = 0, maxSW = 0, maxSH = 0, maxRW = 0, maxRH = 0, maxOW = 0;
+        int maxEW = 0, maxEH = 0, maxSW = 0, maxRW = 0, maxRH = 0, maxOW = 0;
+        int maxSHp[5] = {0, 0, 0, 0, 0};   // [parts]: tallest staged source block when the tile rows are split into 1..4 parts
         for (int l = 0; l < g.nlevels; l++) {
             const OrbLevel &L = g.lv[l];
             for (int ty = 0; ty < L.tcy; ty++)
@@ -246,34 +252,48 @@ static int orb_configure(plf_orb *h, int w, int hh)
                     const int rx0 = PLF_EDGE + cx0 * L.wCell, rx1 = cx1 == L.ncx ? L.rex : PLF_EDGE + cx1 * L.wCell;
                     const int ry0 = PLF_EDGE + cy0 * L.hCell, ry1 = cy1 == L.ncy ? L.rey : PLF_EDGE + cy1 * L.hCell;
                     const int xs = txi == 0 ? 0 : rx0, xe = txi == L.tcx - 1 ? L.w : rx1, ys = ty == 0 ? 0 : ry0, ye = ty == L.tcy - 1 ? L.h : ry1;
-                    const int ex0 = (xs & ~3) - 4, EW = ((xe - 1) & ~3) + 8 - ex0, EH = ye - ys + 6;
+                    const int ex0 = (xs & ~3) - 4, EW = ((xe - 1) & ~3) + 8 - ex0, EH = ye - ys + 6, ey0 = ys - 3;
                     if (rx1 <= rx0 || ry1 <= ry0 || xe - xs < 4 || ye - ys < 4) return PLF_E_BADARG;
                     maxEW = std::max(maxEW, EW); maxEH = std::max(maxEH, EH); maxOW = std::max(maxOW, xe - xs);
                     maxRW = std::max(maxRW, rx1 - rx0); maxRH = std::max(maxRH, ry1 - ry0);
                     if (l > 0) {
                         const OrbLevel &S = g.lv[l - 1];
-                        const int lx_lo = std::max(ex0, 0), lx_hi = std::min(ex0 + EW - 1, L.w - 1), ly_lo = std::max(ys - 3, 0), ly_hi = std::min(ys - 3 + EH - 1, L.h - 1);
+                        const int lx_lo = std::max(ex0, 0), lx_hi = std::min(ex0 + EW - 1, L.w - 1);
                         const int sx_lo = xofs[L.tabx_off + lx_lo] & ~3, sx_hi = std::min(xofs[L.tabx_off + lx_hi] + 1, S.w - 1);
-                        const int sy_lo = std::min(std::max(yofs[L.taby_off + ly_lo], 0), S.h - 1), sy_hi = std::min(std::max(yofs[L.taby_off + ly_hi] + 1, 0), S.h - 1);
-                        maxSW = std::max(maxSW, sx_hi - sx_lo + 1); maxSH = std::max(maxSH, sy_hi - sy_lo + 1);
+                        maxSW = std::max(maxSW, sx_hi - sx_lo + 1);
+                        for (int parts = 1; parts <= 4; parts++)
+                            for (int pi = 0; pi < parts; pi++) {
+                                int s_lo, s_hi;
+                                orb_part_rows(ey0, EH, parts, pi, L.h, S.h, &yofs[L.taby_off], &s_lo, &s_hi);
+                                maxSHp[parts] = std::max(maxSHp[parts], s_hi - s_lo + 1);
+                            }
                     }
                 }
         }
         if (maxEW > 255 || maxRH > 255) return PLF_E_BADARG;   // survivors are packed as (tile column | row << 8)
         g.lds_pw = (maxEW + 3) & ~3;
         g.lds_spw = ((maxSW + 8 + 15) & ~15) + 16;   // (rows are filled 16 bytes at a time)
-        g.lds_sp = g.lds_pw;
+        g.lds_sp = (maxRW + 6 + 3) & ~3;              // score tile: columns (rx0 - ex0) & ~3 .. of the tile, i.e. the computed regions + alignment slack
         g.lds_eh = maxEH;
-        const size_t sz_p = (size_t)g.lds_pw * (maxEH + 1) + 16;
-        const size_t sz_a = std::max((size_t)g.lds_spw * (maxSH + 1), (size_t)maxRW * maxRH * 2) + 16;   // staged source tile, later the FAST survivor list
-        const size_t sz_s = (size_t)g.lds_pw * maxRH + 16, sz_t = (size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16;
         auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t sz_p = (size_t)g.lds_pw * (maxEH + 1) + 16;
+        const size_t sz_s = (size_t)g.lds_sp * maxRH + 16, sz_t = (size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16;
+        const size_t sz_list = (size_t)maxRW * maxRH * 2 + 16;   // FAST survivor list (aliases the staged source)
+        size_t sz_a = 0;
+        for (g.lds_parts = 1; g.lds_parts <= 4; g.lds_parts++) {
+            sz_a = std::max((size_t)g.lds_spw * (maxSHp[g.lds_parts] + 1) + 16, sz_list);
+            // five tiles per CU: 160 KB / 5 minus the 4112 static bytes; stop splitting when the survivor list is what is left
+            if (up16(sz_p) + up16(sz_a) + up16(sz_s) + up16(sz_t) <= 160 * 1024 / 5 - 4112 - 64 || sz_a == sz_list || g.lds_parts == 4) break;
+        }
         g.lds_off_a = (int)up16(sz_p);
         g.lds_off_s = g.lds_off_a + (int)up16(sz_a);
         g.lds_off_list = g.lds_off_a;
         g.lds_off_tab = g.lds_off_s + (int)up16(sz_s);
         g.lds_total = g.lds_off_tab + (int)up16(sz_t);
         if (g.lds_total > 150 * 1024) return PLF_E_BADARG;
+        if (getenv("PLF_ORB_DEBUG_LDS"))
+            fprintf(stderr, "[plf] k_orb_level LDS: P %zu, SRC/LIST %zu (%d parts), S %zu, tables %zu -> %d dynamic + 4112 static (pw %d, spw %d, sp %d, eh %d, maxRW %d, maxRH %d)\n",
+                    sz_p, sz_a, g.lds_parts, sz_s, sz_t, g.lds_total, g.lds_pw, g.lds_spw, g.lds_sp, g.lds_eh, maxRW, maxRH);
     }
     // keep the per-frame strides of the allocation (max size) so that buffer sizes stay valid
     g.pyr_stride = big.pyr_stride; g.blur_stride = big.blur_stride; g.pool_stride = big.pool_stride; g.sel_stride = big.sel_stride;
@@ -400,7 +420,7 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
     // resized from level l-1, so the launches are stream-ordered
     for (int l = 0; l < nl; l++) {
         const OrbLevel &L = g.lv[l];
-        hipLaunchKernelGGL(k_orb_level, dim3(L.tcx * L.tcy, B), dim3(PLF_ORB_LEVEL_THREADS), (size_t)g.lds_total, s, d_gray, pitch, fstride, h->d_pyr, h->d_blur, l, h->d_xofs, h->d_xa,
+        hipLaunchKernelGGL(k_orb_level, dim3(L.tcx * L.tcy, B), dim3(PLF_ORB_LEVEL_THREADS), (size_t)g.lds_total + PLF_ORB_LDS_PAD, s, d_gray, pitch, fstride, h->d_pyr, h->d_blur, l, h->d_xofs, h->d_xa,
                            h->d_yofs, h->d_yb, h->d_cells, h->d_cellinfo, h->d_pool, poolcnt, status, g, h->taps);
     }
 // k_octree is a chain of LDS sweeps and barriers over <= 250 nodes: latency-bound per workgroup.  128 threads: twice as many independent workgroups per wave slot
