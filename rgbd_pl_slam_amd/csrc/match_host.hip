@@ -217,7 +217,7 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
     const int kp_cap = (maxn + 63) & ~63;
     if (maxn > 65535) return PLF_E_BADARG;  // candidate cache packs key point indices in 16 bits
     // fast path needs 16-bit map point indices and its lists in LDS; otherwise every frame takes the fallback kernel
-    const size_t lds_fast = (size_t)kp_cap * 8 + 2 * (size_t)((M.m + 1) & ~1) * sizeof(uint16_t);
+    const size_t lds_fast = (size_t)kp_cap * 8 + (size_t)((M.m + 1) & ~1) * sizeof(uint16_t);
     const bool fast = M.m <= 65535 && lds_fast <= 150 * 1024;
     PLF_HIP_TRY(hipMemsetAsync(h->d_overflow, fast ? 0 : 1, 2 * (size_t)h->max_batch * sizeof(int), s));
     if (fast && M.m > 0) {

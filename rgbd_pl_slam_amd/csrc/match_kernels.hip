@@ -297,7 +297,8 @@ __global__ void __launch_bounds__(256) k_mp_candidates(const FrameDev *__restric
     done_all[(size_t)f * MP.m + m] = (o > o0) ? 0 : 1;
 }
 
-// LDS: claim[kp_cap], owner[kp_cap] (int), two lists of unfinished map points (uint16, MP.m <= 65535 each)
+// LDS: claim[kp_cap], owner[kp_cap] (int), ONE list of unfinished map points (uint16, MP.m <= 65535), compacted in place after every round -- a second
+// list made the block 28 KB at 5000 map points (5 blocks per CU, and no room next to an ORB tile in the shadow of the region-growing kernel)
 __global__ void __launch_bounds__(256) k_mp_rounds(const FrameDev *__restrict__ frames, MapDev MP, float nnratio, int *__restrict__ match_all,
                                                    int kp_stride, int *__restrict__ nmatches, const uint8_t *__restrict__ done_all, int kp_cap,
                                                    const uint32_t *__restrict__ cand_all, const int2 *__restrict__ span_all, int cand_cap,
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(256) k_mp_rounds(const FrameDev *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *claim = (int *)smem, *owner = claim + kp_cap;
-    uint16_t *la = (uint16_t *)(owner + kp_cap), *lb = la + ((MP.m + 1) & ~1);
+    uint16_t *la = (uint16_t *)(owner + kp_cap);
     __shared__ int s_n[2], s_acc;
     const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x, lane = plf_lane();
     if (overflow[f]) return;
@@ -366,15 +367,16 @@ __global__ void __launch_bounds__(256) k_mp_rounds(const FrameDev *__restrict__ 
                     atomicAdd(&s_acc, 1);
                 }
             }
+            // in place: the kept items of chunks 0 .. i0 / T land below i0 + T; every thread of the block has read its entry of THIS chunk before any is written
+            __syncthreads();
             const unsigned long long mask = __ballot(keep);
             int base = 0;
             if (lane == 0 && mask) base = atomicAdd(&s_n[cur ^ 1], __popcll(mask));
             base = __shfl(base, 0, 64);
-            if (keep) lb[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)m;
+            if (keep) la[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)m;
         }
         __syncthreads();
         if (t == 0) s_n[cur] = 0;
-        uint16_t *tmp = la; la = lb; lb = tmp;
         cur ^= 1;
         __syncthreads();
     }
