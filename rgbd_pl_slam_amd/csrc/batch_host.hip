@@ -53,6 +53,7 @@ struct Slot {
     int64_t first = 0;   // first frame (call-relative) of the chunk in the slot
     int n = 0;           // frames of that chunk; 0 = slot free
     const uint8_t *src = nullptr;
+    bool has_depth = false;   // the chunk in the slot came with depth images (mvuRight is valid)
 };
 
 struct LocalMap {   // device replica
@@ -382,7 +383,6 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         W_RC(plf_depth_to_float(s.d_dep16, n, J.w, J.h, J.w, (ptrdiff_t)dpx, J.R.depth_factor, s.d_depf, w->device, w->s_in));
     }
     W_TRY(hipEventRecord(s.ev_in, w->s_in));
-    const bool match_pts = w->map.has_pts && s.mat, match_lns = w->map.has_lns && s.mat;
     if (w->line) {
         W_TRY(hipStreamWaitEvent(w->s_line, s.ev_in, 0));
         W_TRY(hipStreamWaitEvent(w->s_line, s.ev_out, 0));
@@ -395,6 +395,9 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
     if (w->orb) {
         W_TRY(hipStreamWaitEvent(w->s_orb, s.ev_in, 0));
         W_TRY(hipStreamWaitEvent(w->s_orb, s.ev_out, 0));
+        // ORB starts when the line extractor reaches region growing (a latency-bound chain that leaves room on every CU) instead of competing with its
+        // throughput-bound front stages -- the schedule bench.py measures as the better one
+        if (w->line) W_RC(plf_line_wait_front(w->line, w->s_orb));
         W_RC(plf_orb_extract_batch(w->orb, d_gray, PLF_MEM_DEVICE, n, J.w, J.h, J.w, (ptrdiff_t)J.w * J.h, s.d_kps, s.d_desc, s.d_nk, PLF_MEM_DEVICE,
                                    w->orb_cap, w->s_orb));
         W_RC(plf_orb_status_async(w->orb, &s.h_status[0], w->s_orb));
@@ -402,7 +405,19 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
             W_RC(plf_frame_tail(s.d_kps, s.d_nk, 0, n, w->orb_cap, up_dep ? s.d_depf : nullptr, J.w, J.h, &J.R.cam, s.d_kun, s.d_ur, s.d_kd, w->device, w->s_orb));
         W_TRY(hipEventRecord(s.ev_orb, w->s_orb));
     }
-    // matchers + downloads on the output stream
+    s.has_depth = up_dep != nullptr;
+    s.src = src;
+    return PLF_OK;
+}
+
+// matchers + downloads of the chunk in slot s on the output stream.  behind_front: the NEXT chunk's extraction has been enqueued; these light kernels are
+// released when its line extractor reaches region growing, i.e. they run in that kernel's shadow instead of colliding with the next front stages
+static int chunk_outputs(Worker *w, Slot &s, const Job &J, bool behind_front)
+{
+    const int n = s.n;
+    if (n == 0) return PLF_OK;
+    const bool match_pts = w->map.has_pts && s.mat, match_lns = w->map.has_lns && s.mat;
+    if (behind_front && w->line) W_RC(plf_line_wait_front(w->line, w->s_out));
     if (w->orb) {
         W_TRY(hipStreamWaitEvent(w->s_out, s.ev_orb, 0));
         const size_t K = (size_t)n * w->orb_cap;
@@ -411,7 +426,7 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
             for (int f = 0; f < n; f++) {
                 plf_frame_view &v = s.fviews[f];
                 v.n = w->orb_cap; v.n_device = s.d_nk + f; v.keys_un = (J.rgbd ? s.d_kun : s.d_kps) + (size_t)f * w->orb_cap;
-                v.uright = (J.rgbd && up_dep) ? s.d_ur + (size_t)f * w->orb_cap : nullptr;
+                v.uright = (J.rgbd && s.has_depth) ? s.d_ur + (size_t)f * w->orb_cap : nullptr;
                 v.desc = s.d_desc + (size_t)f * w->orb_cap * 32;
                 v.min_x = w->owner->bounds[0]; v.min_y = w->owner->bounds[1]; v.max_x = w->owner->bounds[2]; v.max_y = w->owner->bounds[3];
                 v.scale_factors = w->d_scale; v.nlevels = w->nlevels;
@@ -451,7 +466,6 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         if (J.rgbd) W_RC(line_tail_download(w, s, n, w->s_out));
     }
     W_TRY(hipEventRecord(s.ev_out, w->s_out));
-    s.src = src;
     return PLF_OK;
 }
 
@@ -556,6 +570,7 @@ static int worker_extract(Worker *w)
     const bool pinned = is_pinned(J.images + (size_t)J.first * J.fstride);
     const bool dpinned = J.rgbd && J.R.depth && is_pinned(J.R.depth + (size_t)J.first * J.R.depth_frame_stride_elems);
     int soft = PLF_OK, k = 0;
+    Slot *pending = nullptr;   // extraction enqueued, matchers / downloads not yet
     for (int64_t done = 0; done < J.count; done += C, k++) {
         Slot &s = w->slot[k & 1];
         int rc = chunk_retire(w, s, J, &soft);   // chunk k-2 (normally retired already)
@@ -563,7 +578,16 @@ static int worker_extract(Worker *w)
         const int n = (int)(J.count - done < C ? J.count - done : C);
         rc = chunk_submit(w, s, J, J.first + done, n, pinned, dpinned);
         if (rc != PLF_OK) return rc;
+        if (pending) {
+            rc = chunk_outputs(w, *pending, J, true);   // chunk k-1, behind the front stages of chunk k
+            if (rc != PLF_OK) return rc;
+        }
+        pending = &s;
         rc = chunk_retire(w, w->slot[(k & 1) ^ 1], J, &soft);   // chunk k-1 while chunk k runs
+        if (rc != PLF_OK) return rc;
+    }
+    if (pending) {
+        const int rc = chunk_outputs(w, *pending, J, false);
         if (rc != PLF_OK) return rc;
     }
     for (int i = 0; i < 2; i++) {
