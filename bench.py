@@ -424,7 +424,7 @@ def main():
                                            "region_stage_ms": round(r3 / max(n3, 1), 3)}
             p3.close(); del p3
             out["single_frame_latency"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES)
-            out["pcie_inclusive"] = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, 8192, 2048, mp, ml)
+            out["pcie_inclusive"] = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, 16384, 4096, mp, ml)
         if world == 1 and args.cpu_seconds > 0:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(float(args.cpu_seconds), cores, W, H, NFEAT, NLINES)
