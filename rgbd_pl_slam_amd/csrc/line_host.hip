@@ -438,9 +438,11 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else if (B <= lat_max)
         hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
-    else if (!getenv("PLF_LSD_FPW1") && h->regions_lds <= 6400)   // two frames per workgroup: half the workgroup slots per CU, +2 % whole-pipeline throughput (co-running kernels get slots)
-        hipLaunchKernelGGL(k_lsd_regions2, dim3((B + 1) / 2), dim3(128), 2 * 6400, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+    else if (h->regions_lds <= 6400) {   // 8 frames per workgroup (one wave each): see k_lsd_regions2
+        const int wpg = getenv("PLF_LSD_WPG") ? max(1, min(16, atoi(getenv("PLF_LSD_WPG")))) : 8;
+        hipLaunchKernelGGL(k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * 6400, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B);
+    }
     else
         hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds);

@@ -704,6 +704,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     return true;
 }
 
+#define PLF_LSD_FPW2_LDS 6400
 template <int LDSOFF, int FPW>
 __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                              const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
@@ -711,10 +712,12 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
                                              int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int nframes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_base[];
-    // FPW = 2 (k_lsd_regions2): two frames per workgroup, one wave each, every wave instantiated with ITS constant LDS offset
-    const int f = FPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * FPW + (LDSOFF ? 1 : 0), lane = FPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    if (FPW > 1 && f >= nframes) return;
-    LDS_PTR(char) smem = (LDS_PTR(char))smem_base + LDSOFF;
+    // LDSOFF < 0 (k_lsd_regions2): blockDim.x / 64 frames per workgroup, one wave each, the LDS offset of a wave is a run-time scalar
+    const int wv = LDSOFF < 0 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (LDSOFF ? 1 : 0);
+    const int fpw = LDSOFF < 0 ? (int)(blockDim.x >> 6) : FPW;
+    const int f = FPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * fpw + wv, lane = FPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    if (FPW != 1 && f >= nframes) return;
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_base + (LDSOFF < 0 ? wv * PLF_LSD_FPW2_LDS : LDSOFF);
     const uint32_t *seeds = seeds_all ? seeds_all + (size_t)f * g.s_stride : nullptr;   // sorted keys (seed_order 1) or raster
     const int W = g.sw, H = g.sh, NP = W * H;
     RegCtx C;
@@ -796,19 +799,21 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
     regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
 }
 
-#define PLF_LSD_FPW2_LDS 6400
 #ifdef PLF_REGIONS_WPE   // experiment switch (tools/variant_build.sh): cap the VGPRs of the large-batch region kernel for N waves per SIMD
 #define PLF_REGIONS_OCC __attribute__((amdgpu_waves_per_eu(PLF_REGIONS_WPE, PLF_REGIONS_WPE)))
 #else
 #define PLF_REGIONS_OCC
 #endif
-__global__ void PLF_REGIONS_OCC __launch_bounds__(128) k_lsd_regions2(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+// Large batches: blockDim.x / 64 frames per workgroup (the host launches 8), one wave each; a wave finds its 6400 bytes of LDS at a run-time
+// scalar offset.  (Round 2 had two frames per workgroup with a constant offset per wave, i.e. two copies of the body in one kernel: 97 spilled
+// SGPRs instead of 38, 71.8 instead of 69.5 ms per 4096 frames.  Frames per workgroup, whole step at 4096 in flight: 2: 136.4, 4: 135.2,
+// 8: 135.0, 16: 136.0 ms.)
+__global__ void PLF_REGIONS_OCC __launch_bounds__(1024) k_lsd_regions2(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                       const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                       uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                       int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
 {
-    if (threadIdx.x < 64) regions_body<0, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
-    else regions_body<PLF_LSD_FPW2_LDS, 2>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
+    regions_body<-1, 0>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
 }
 
 // Latency mode (a handful of frames in flight, e.g. the live SLAM loop): the chain of one frame is all there is to run, so its memory round
