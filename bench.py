@@ -93,11 +93,12 @@ class Pipeline:
         self.scale = torch.from_numpy(np.ascontiguousarray(self.orb.GetScaleFactors())).cuda()
         # HIP streams: LSD/LBD on a high-priority stream per line handle (region growing is a serial chain per frame and the long pole), ORB on sA,
         # the matchers on sM.  The two extractors are independent, as the two threads of the PL-SLAM Frame constructor are.
-        self.sA = torch.cuda.Stream(priority=0)
-        self.sBs = [torch.cuda.Stream(priority=-1) for _ in self.lins]
+        pa, pb, pm = [int(x) for x in os.environ.get("PLF_BENCH_PRIO", "0,-1,0").split(",")]
+        self.sA = torch.cuda.Stream(priority=pa)
+        self.sBs = [torch.cuda.Stream(priority=pb) for _ in self.lins]
         if serial:
             self.sBs = [self.sA for _ in self.lins]
-        self.sM = self.sA if serial else torch.cuda.Stream(priority=0)
+        self.sM = self.sA if serial else torch.cuda.Stream(priority=pm)
         # local map / last frame built from the features of frame 0 (so that real matches exist); replicas per GPU
         b0 = self.bufs[0]
         torch.cuda.synchronize()

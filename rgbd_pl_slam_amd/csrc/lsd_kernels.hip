@@ -705,6 +705,9 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
 }
 
 #define PLF_LSD_FPW2_LDS 6400
+#ifndef PLF_REGIONS_PRIO
+#define PLF_REGIONS_PRIO 3
+#endif
 template <int LDSOFF, int FPW>
 __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                              const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
@@ -733,7 +736,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
     // This wave is one long dependent chain; waves of other kernels sharing its SIMD only ever delay it.
     // Raise its issue priority so that co-running throughput kernels (ORB, matchers, NFA) fill the idle slots instead.
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(PLF_REGIONS_PRIO);
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
     int nr = 0;
     const double prec = g.prec, p = g.p;

@@ -72,12 +72,18 @@ __device__ __forceinline__ plf_s2v of_max(plf_s2v a, plf_s2v b) { return __built
 #define PLF_ORB_LEVEL_WPE 8
 #endif
 #define OF_OCC __attribute__((amdgpu_waves_per_eu(PLF_ORB_LEVEL_WPE, PLF_ORB_LEVEL_WPE)))
+#ifndef PLF_ORB_PRIO
+#define PLF_ORB_PRIO 2
+#endif
 __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__restrict__ in, ptrdiff_t in_pitch, ptrdiff_t in_fstride, uint8_t *__restrict__ pyr,
                                                    uint8_t *__restrict__ blur, int l, const int *__restrict__ xofs, const short2 *__restrict__ xa,
                                                    const int *__restrict__ yofs, const short2 *__restrict__ yb, const int4 *__restrict__ cells,
                                                    int2 *__restrict__ cellinfo, uint2 *__restrict__ pool, int *__restrict__ poolcnt,
                                                    int *__restrict__ status, OrbGeom g, int4 taps)
 {
+    // issue priority above the other throughput kernels (matchers, k_lsd_pre, NFA stages: 0), below the region chain (3): the tile kernel is the longest
+    // of the co-runners and latency-bound per tile; 0 -> 2: 134.5 -> 131.8 ms per 4096-frame step (3: the same; above the region waves: 132.8)
+    __builtin_amdgcn_s_setprio(PLF_ORB_PRIO);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_nlist;
     __shared__ unsigned long long s_mask[4][64][2];   // per cell of the tile, per row of its computed region: NMS maxima >= iniTh / >= minTh

@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
                                                      plf_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                      int *__restrict__ n_out, int capacity, int *__restrict__ status, OrbGeom g)
 {
+#ifdef PLF_ORB_PRIO2
+    __builtin_amdgcn_s_setprio(PLF_ORB_PRIO2);
+#endif
     // one wave per OUTPUT slot o of the frame (level-major order); its level follows from the per-level counts
     const int o = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const int *cnt = selcnt + f * g.nlevels;
