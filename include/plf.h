@@ -375,6 +375,19 @@ int plf_match_bow_kf(plf_matcher *h, const plf_bow_view *pairs, int32_t n_pairs,
 int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t nq, const uint8_t *train, int32_t nt,
                         plf_dmatch *out, int32_t mem, void *stream);
 
+/* void LineSegment::LineSegmentMathch(Mat &ldesc1, Mat &ldesc2) + void LineSegment::LineDescriptorMAD()  include/ExtractLineSegment.h:41,44
+ * (the same statistic as Frame::lineDescriptorMAD(vector<vector<DMatch>>, double &nn_mad, double &nn12_mad)  include/Frame.h:75): the 2-NN table of
+ * ldesc1 (n1 x 32) against ldesc2 (n2 x 32, n2 >= 2) and its two robust spreads, mad[0] = nn_mad = 1.4826 * median |d1 - median d1|,
+ * mad[1] = nn12_mad = the same on d2 - d1.  knn (optional, n1 x 2 plf_dmatch = mvlineMatches) and mad (2 doubles) both live in `mem`. */
+int plf_line_descriptor_mad(plf_matcher *h, const uint8_t *ldesc1, int32_t n1, const uint8_t *ldesc2, int32_t n2, plf_dmatch *knn,
+                            double *mad, int32_t mem, void *stream);
+
+/* double LineSegment::LineSegmentOverlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj)  include/ExtractLineSegment.h:47
+ * (declared without a body in the snapshot; restated from the PL-SLAM family's lineSegmentOverlap, PARITY UNPINNED): overlap of the observed
+ * interval [min, max](spl_obs, epl_obs) with the projected one, divided by length = max(obs) - min(proj); 0 when the intervals are disjoint or
+ * length <= 0.01.  A host scalar (no device work), exported so that every binding shares one definition. */
+double plf_line_segment_overlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj);
+
 /* int LSDmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  include/LSDmatcher.h:32
  * with Frame::lineDescriptorMAD include/Frame.h:75.  last_has_mapline[q] = LastFrame.mvpMapLines[q] != NULL.
  * match_of_line (device, ncur int32, pre-set to -1): last-frame line index assigned to each current line.

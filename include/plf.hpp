@@ -117,7 +117,38 @@ public:
         else check(st, "plf_line_extract");
         vkeyLines.resize(n); ldesc.resize((size_t)n * 32); vkeylineFunctions.resize(n);
     }
+    // void LineSegmentMathch(Mat &ldesc1, Mat &ldesc2)   include/ExtractLineSegment.h:41   (host descriptor rows, n x 32; knnMatch k = 2 into mvlineMatches)
+    // void LineDescriptorMAD()                             include/ExtractLineSegment.h:44   (mnnMad, mnn12Mad of those matches; computed in the same device pass)
+    void LineSegmentMathch(const uint8_t *ldesc1, int n1, const uint8_t *ldesc2, int n2, int device = 0)
+    {
+        mvlineMatches.clear(); mnnMad = mnn12Mad = 0.0;
+        if (n1 < 1 || n2 < 2) return;
+        plf_matcher *m = nullptr;
+        check(plf_matcher_create(device, 64, 64, n1 > n2 ? n1 : n2, 1, &m), "plf_matcher_create");
+        void *d1 = nullptr, *d2 = nullptr;
+        int st = plf_device_alloc(device, (size_t)n1 * 32, &d1);
+        if (st == PLF_OK) st = plf_device_alloc(device, (size_t)n2 * 32, &d2);
+        if (st == PLF_OK) st = plf_upload(d1, ldesc1, (size_t)n1 * 32, nullptr);
+        if (st == PLF_OK) st = plf_upload(d2, ldesc2, (size_t)n2 * 32, nullptr);
+        std::vector<plf_dmatch> knn((size_t)n1 * 2);
+        double mad[2] = {0.0, 0.0};
+        if (st == PLF_OK) st = plf_line_descriptor_mad(m, (const uint8_t *)d1, n1, (const uint8_t *)d2, n2, knn.data(), mad, PLF_MEM_HOST, nullptr);
+        plf_device_free(d1); plf_device_free(d2); plf_matcher_destroy(m);
+        check(st, "plf_line_descriptor_mad");
+        mvlineMatches.resize(n1);
+        for (int q = 0; q < n1; q++) mvlineMatches[q] = {knn[2 * q], knn[2 * q + 1]};
+        mnnMad = mad[0]; mnn12Mad = mad[1];
+    }
+    void LineDescriptorMAD(double &nn_mad, double &nn12_mad) const { nn_mad = mnnMad; nn12_mad = mnn12Mad; }
+    // double LineSegmentOverlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj)   include/ExtractLineSegment.h:47
+    static double LineSegmentOverlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj)
+    {
+        return plf_line_segment_overlap(spl_obs, epl_obs, spl_proj, epl_proj);
+    }
     plf_line *handle() { return h_; }
+
+    std::vector<std::vector<plf_dmatch>> mvlineMatches;   // include/ExtractLineSegment.h:51
+    double mnnMad = 0.0, mnn12Mad = 0.0;                    // include/ExtractLineSegment.h:52
 
 private:
     plf_line *h_ = nullptr;

@@ -917,6 +917,26 @@ void orc_line_mad(const int32_t *dist /*n x 2*/, int n, double *nn_mad, double *
     free(v);
 }
 
+/* double LineSegment::LineSegmentOverlap(spl_obs, epl_obs, spl_proj, epl_proj)  include/ExtractLineSegment.h:47 -- declared without a body in the
+ * snapshot; restated from the PL-SLAM family's lineSegmentOverlap (PARITY UNPINNED): both intervals ordered, length = max(obs) - min(proj),
+ * overlap = 0 when disjoint, the observed extent when the projection covers it, else min(ends) - max(starts); divided by length when
+ * length > 0.01f, else 0. */
+double orc_line_segment_overlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj)
+{
+    double sln = fmin(spl_obs, epl_obs), eln = fmax(spl_obs, epl_obs);
+    double spn = fmin(spl_proj, epl_proj), epn = fmax(spl_proj, epl_proj);
+    double length = eln - spn;
+    double overlap;
+    if ((epn < sln) || (spn > eln)) overlap = 0.f;
+    else {
+        if ((epn > eln) && (spn < sln)) overlap = eln - sln;
+        else overlap = fmin(eln, epn) - fmax(sln, spn);
+    }
+    if (length > 0.01f) overlap = overlap / length;
+    else overlap = 0.f;
+    return overlap;
+}
+
 /* LSDmatcher::SearchByProjection(CurrentFrame, LastFrame): query = last-frame lines, train = current.
  * last_has_mapline[q] says whether LastFrame.mvpMapLines[q] != NULL.  match_of_line[t] = q written. */
 int orc_match_lines_knn(const uint8_t *last_desc, int nlast, const uint8_t *cur_desc, int ncur,

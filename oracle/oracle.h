@@ -125,6 +125,7 @@ int orc_search_by_projection_last(const orc_frame *Cur, const orc_lastframe *Las
                                   float cx, float cy, float bf, float b, float th, int bMono, int checkOri,
                                   int32_t *match_of_kp);
 void orc_line_mad(const int32_t *dist, int n, double *nn_mad, double *nn12_mad);
+double orc_line_segment_overlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj);   /* LineSegment::LineSegmentOverlap, include/ExtractLineSegment.h:47 */
 int orc_match_lines_knn(const uint8_t *last_desc, int nlast, const uint8_t *cur_desc, int ncur,
                         const uint8_t *last_has_mapline, int32_t *match_of_line);
 int orc_lines_search_for_triangulation(const uint8_t *desc1, int n1, const uint8_t *desc2, int n2, const uint8_t *has_ml1, const uint8_t *has_ml2,

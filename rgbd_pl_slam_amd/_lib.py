@@ -108,6 +108,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libplf_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                                "there is no CPU fallback" % LIB_PATH)
+        # torch (the Python mirror's device-memory plumbing) ships its own copy of the HIP runtime: it has to be in the process BEFORE this library's
+        # dependency on libamdhip64 is resolved, otherwise a later `import torch` brings a second runtime and neither sees the GPU any more
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.plf_version.restype = C.c_char_p
         _lib.plf_status_string.restype = C.c_char_p

@@ -49,6 +49,7 @@ __global__ void k_project_kf_greedy(FrameDev, Pts3Dev, ProjKf, float, int *, int
 __global__ void k_knn2(const uint8_t *, int, const uint8_t *, int, int *, int *);
 __global__ void k_knn2_batch(const uint8_t *, int, const LineFrameDev *, int *, int *, int);
 __global__ void k_knn2_to_dmatch(const int *, const int *, int, plf_dmatch *);
+__global__ void k_line_mad(const int *, int, int, double *);
 struct LineTriDev { const uint8_t *has_ml1, *has_ml2, *stereo1, *stereo2; int only_stereo; };
 __global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int, int, int, const LineFrameDev *, double, LineTriDev);
 __global__ void k_lines_fuse_pick(const int *, const int *, const uint8_t *, int, int *, int *);
@@ -68,6 +69,7 @@ struct plf_matcher {
     uint8_t *d_done;
     float4 *d_proj;
     plf_dmatch *d_dm;
+    double *d_mad;
     uint32_t *d_cand;        // cached candidate lists of the projection matcher
     int *d_cand_off, *d_overflow;
     int cand_cap;
@@ -93,7 +95,7 @@ static int matcher_stream(plf_matcher *h, void *stream, hipStream_t *out)
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used, h->d_poses};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_mad, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used, h->d_poses};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     free(h->h_frames); free(h->h_lframes); free(h->h_poses);
@@ -141,6 +143,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     ALLOC(h->d_knn_dist, B * 2 * (size_t)max_lines * sizeof(int));
     ALLOC(h->d_poses, B * sizeof(plf_pose_pair));
     ALLOC(h->d_dm, 2 * (size_t)max_lines * sizeof(plf_dmatch));
+    ALLOC(h->d_mad, 2 * sizeof(double));
     // average of 64 cached candidates per map point; denser frames use the fallback kernel (PLF_MATCH_CAND_AVG: test hook)
     const char *avg_env = getenv("PLF_MATCH_CAND_AVG");
     const int cand_avg = (avg_env && atoi(avg_env) > 0) ? atoi(avg_env) : 64;
@@ -614,6 +617,41 @@ extern "C" int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t
     PLF_HIP_TRY(hipGetLastError());
     if (mem != PLF_MEM_DEVICE) {
         PLF_HIP_TRY(hipMemcpyAsync(out, h->d_dm, sizeof(plf_dmatch) * 2 * nq, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return PLF_OK;
+}
+
+extern "C" double plf_line_segment_overlap(double spl_obs, double epl_obs, double spl_proj, double epl_proj)
+{
+    const double sln = spl_obs < epl_obs ? spl_obs : epl_obs, eln = spl_obs < epl_obs ? epl_obs : spl_obs;
+    const double spn = spl_proj < epl_proj ? spl_proj : epl_proj, epn = spl_proj < epl_proj ? epl_proj : spl_proj;
+    const double length = eln - spn;
+    double overlap;
+    if (epn < sln || spn > eln) overlap = 0.0;
+    else if (epn > eln && spn < sln) overlap = eln - sln;
+    else overlap = (eln < epn ? eln : epn) - (sln > spn ? sln : spn);
+    return length > (double)0.01f ? overlap / length : 0.0;
+}
+
+extern "C" int plf_line_descriptor_mad(plf_matcher *h, const uint8_t *ldesc1, int32_t n1, const uint8_t *ldesc2, int32_t n2, plf_dmatch *knn,
+                                       double *mad, int32_t mem, void *stream)
+{
+    if (!h || !ldesc1 || !ldesc2 || !mad || n1 < 1 || n2 < 2 || n1 > h->max_lines) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s;
+    { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    hipLaunchKernelGGL(k_knn2, dim3((n1 + 127) / 128), dim3(128), 0, s, ldesc1, n1, ldesc2, n2, h->d_knn_idx, h->d_knn_dist);
+    int P2 = 1;
+    while (P2 < n1) P2 <<= 1;
+    double *d_mad = mem == PLF_MEM_DEVICE ? mad : h->d_mad;
+    hipLaunchKernelGGL(k_line_mad, dim3(1), dim3(256), (size_t)P2 * sizeof(float), s, h->d_knn_dist, n1, P2, d_mad);
+    plf_dmatch *d_out = mem == PLF_MEM_DEVICE ? knn : h->d_dm;
+    if (knn) hipLaunchKernelGGL(k_knn2_to_dmatch, dim3((2 * n1 + 127) / 128), dim3(128), 0, s, h->d_knn_idx, h->d_knn_dist, n1, d_out);
+    PLF_HIP_TRY(hipGetLastError());
+    if (mem != PLF_MEM_DEVICE) {
+        if (knn) PLF_HIP_TRY(hipMemcpyAsync(knn, h->d_dm, sizeof(plf_dmatch) * 2 * n1, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipMemcpyAsync(mad, h->d_mad, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         PLF_HIP_TRY(hipStreamSynchronize(s));
     }
     return PLF_OK;

@@ -1203,6 +1203,30 @@ __device__ void block_sort_floats(float *v, int n, int P2)
     (void)n;
 }
 
+// Frame::lineDescriptorMAD (include/Frame.h:75) / LineSegment::LineDescriptorMAD (include/ExtractLineSegment.h:44) on a 2-NN table of n queries:
+// mad[0] = nn_mad = 1.4826 * median |d1 - median(d1)|, mad[1] = nn12_mad the same on d2 - d1 (float distances, double medians: oracle orc_line_mad).
+// One block, n <= P2 (power of two) floats of LDS.
+__global__ void __launch_bounds__(256) k_line_mad(const int *__restrict__ dist, int n, int P2, double *__restrict__ mad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *v = (float *)smem;
+    const int t = threadIdx.x, T = blockDim.x;
+    const float INF = 3.0e38f;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = t; i < P2; i += T) v[i] = i < n ? (pass ? (float)dist[2 * i + 1] - (float)dist[2 * i] : (float)dist[2 * i]) : INF;
+        __syncthreads();
+        block_sort_floats(v, n, P2);
+        const double med = v[n / 2];
+        __syncthreads();
+        for (int i = t; i < P2; i += T)
+            v[i] = i < n ? fabsf((float)((double)(pass ? (float)dist[2 * i + 1] - (float)dist[2 * i] : (float)dist[2 * i]) - med)) : INF;
+        __syncthreads();
+        block_sort_floats(v, n, P2);
+        if (t == 0) mad[pass] = 1.4826 * (double)v[n / 2];
+        __syncthreads();
+    }
+}
+
 // Frame::lineDescriptorMAD + LSDmatcher::SearchByProjection(CurrentFrame, LastFrame); one block per current frame, nlast <= P2 (power of two)
 // tri != NULL: LSDmatcher::SearchForTriangulation (include/LSDmatcher.h:54) on the same 2-NN table -- queries = keyframe-1 lines, a pair (q, t) is kept
 // when neither line holds a MapLine (and, with only_stereo, both have stereo data); match_all[q] = t.

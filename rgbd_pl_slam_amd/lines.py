@@ -44,6 +44,30 @@ class LineSegment:
         L.check(st, "plf_line_extract")
         return kl[:n.value].copy(), desc[:n.value].copy(), eq[:n.value].copy()
 
+    def LineSegmentMathch(self, ldesc1, ldesc2):
+        """void LineSegmentMathch(Mat &ldesc1, Mat &ldesc2) -- include/ExtractLineSegment.h:41: BFMatcher(NORM_HAMMING).knnMatch(k = 2) of two host
+        descriptor matrices into mvlineMatches; the spreads LineDescriptorMAD() reports come from the same device pass"""
+        import torch
+        from .matcher import Matcher
+        d1 = torch.from_numpy(np.ascontiguousarray(ldesc1, np.uint8)).cuda(); d2 = torch.from_numpy(np.ascontiguousarray(ldesc2, np.uint8)).cuda()
+        m = Matcher(max_keypoints=64, max_mappoints=64, max_lines=max(int(d1.shape[0]), int(d2.shape[0]), 2), device=d1.device.index or 0)
+        try:
+            self.mvlineMatches, self.mnnMad, self.mnn12Mad = m.LineDescriptorMAD(d1, d2)
+        finally:
+            m.close()
+        return self.mvlineMatches
+
+    def LineDescriptorMAD(self):
+        """void LineDescriptorMAD() -- include/ExtractLineSegment.h:44: (mnnMad, mnn12Mad) of the last LineSegmentMathch"""
+        return self.mnnMad, self.mnn12Mad
+
+    @staticmethod
+    def LineSegmentOverlap(spl_obs, epl_obs, spl_proj, epl_proj):
+        """double LineSegmentOverlap(spl_obs, epl_obs, spl_proj, epl_proj) -- include/ExtractLineSegment.h:47 (host scalar, see plf.h)"""
+        f = L.lib().plf_line_segment_overlap
+        f.restype = C.c_double; f.argtypes = [C.c_double] * 4
+        return f(spl_obs, epl_obs, spl_proj, epl_proj)
+
     def extract_batch(self, images):
         images = np.ascontiguousarray(images, np.uint8)
         B, h, w = images.shape

@@ -216,6 +216,16 @@ class Matcher:
         L.check(L.lib().plf_match_lines_knn(self._h, L.vp(query), nq, L.vp(train), nt, L.vp(out), L.MEM_HOST, None), "plf_match_lines_knn")
         return out
 
+    def LineDescriptorMAD(self, ldesc1, ldesc2, want_knn=True):
+        """LineSegment::LineSegmentMathch + LineDescriptorMAD (include/ExtractLineSegment.h:41,44; Frame::lineDescriptorMAD include/Frame.h:75):
+        device descriptor tensors in; (knn (n1,2) DMATCH array or None, nn_mad, nn12_mad) on the host"""
+        n1, n2 = int(ldesc1.shape[0]), int(ldesc2.shape[0])
+        knn = np.zeros((n1, 2), L.DMATCH_DTYPE) if want_knn else None
+        mad = np.zeros(2, np.float64)
+        L.check(L.lib().plf_line_descriptor_mad(self._h, L.vp(ldesc1), n1, L.vp(ldesc2), n2, L.vp(knn) if want_knn else None, L.vp(mad), L.MEM_HOST, None),
+                "plf_line_descriptor_mad")
+        return knn, float(mad[0]), float(mad[1])
+
     def SearchLinesLastFrame(self, last_desc, cur_desc, last_has_mapline, match_of_line, nmatches, stream=None):
         L.check(L.lib().plf_match_lines_lastframe(self._h, L.vp(last_desc), int(last_desc.shape[0]), L.vp(cur_desc), int(cur_desc.shape[0]),
                                                   L.vp(last_has_mapline), L.vp(match_of_line), L.vp(nmatches),

@@ -151,6 +151,16 @@ int main(int argc, char **argv)
         std::vector<uint8_t> ld = rd<uint8_t>("lastl_desc.u8");
         const std::vector<uint8_t> lh = rd<uint8_t>("lastl_has.u8");
         const int nl = (int)lh.size();
+        {   // LineSegment::LineSegmentMathch / LineDescriptorMAD / LineSegmentOverlap (include/ExtractLineSegment.h:41-47)
+            ls.LineSegmentMathch(ld.data(), nl, ldesc.data, ldesc.rows);
+            std::vector<int32_t> mm((size_t)nl * 4);
+            for (int q = 0; q < nl; q++) for (int k = 0; k < 2; k++) { mm[4 * q + 2 * k] = ls.mvlineMatches[q][k].trainIdx; mm[4 * q + 2 * k + 1] = (int32_t)ls.mvlineMatches[q][k].distance; }
+            wr("out_lsmatch.i32", mm.data(), mm.size());
+            double mad[3];
+            ls.LineDescriptorMAD(mad[0], mad[1]);
+            mad[2] = ORB_SLAM2_PLF::LineSegment::LineSegmentOverlap(2.0, 10.0, 4.0, 7.0);
+            wr("out_lsmad.f64", mad, 3);
+        }
         Frame Last;
         Last.mLdesc = cv::Mat(nl, 32, CV_8U, ld.data());
         std::vector<MapLine> lml(nl);

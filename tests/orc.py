@@ -221,6 +221,21 @@ def knn2(q, t):
     return idx, dist
 
 
+def line_mad(dist):
+    """Frame::lineDescriptorMAD on an (n, 2) int32 distance table: (nn_mad, nn12_mad)"""
+    L = lib()
+    dist = np.ascontiguousarray(dist, np.int32)
+    a = C.c_double(0); b = C.c_double(0)
+    L.orc_line_mad(p(dist), C.c_int(len(dist)), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def line_segment_overlap(a, b, c, d):
+    L = lib()
+    L.orc_line_segment_overlap.restype = C.c_double
+    return L.orc_line_segment_overlap(C.c_double(a), C.c_double(b), C.c_double(c), C.c_double(d))
+
+
 def lines_search_for_triangulation(desc1, desc2, has_ml1, has_ml2, stereo1, stereo2, only_stereo, mad_factor=0.1):
     L = lib()
     a = [np.ascontiguousarray(x, np.uint8) for x in (desc1, desc2, has_ml1, has_ml2, stereo1, stereo2)]

@@ -86,6 +86,12 @@ def test_full_path_through_the_cpp_adapters(tmp_path):
     for name in ("out_lmatch_last.i32", "out_lmatch_kf.i32"):     # the Frame / Frame and the KeyFrame / Frame overloads are the same rule
         g = get(name, np.int32)
         assert g[-1] == rn and np.array_equal(g[:-1], rm) and rn > 10
+    # ---- the remaining LineSegment members (include/ExtractLineSegment.h:41-47)
+    kidx, kdist = orc.knn2(lastl, ldesc)
+    g = get("out_lsmatch.i32", np.int32).reshape(-1, 2, 2)
+    assert np.array_equal(g[:, :, 0], kidx) and np.array_equal(g[:, :, 1], kdist)
+    gm = get("out_lsmad.f64", np.float64)
+    assert (gm[0], gm[1]) == orc.line_mad(kdist) and gm[2] == orc.line_segment_overlap(2.0, 10.0, 4.0, 7.0) == 0.5
     hml1 = lhas                                                     # keyframe 1 = the "last" lines with their MapLines; keyframe 2 holds none
     rm, rn = orc.lines_search_for_triangulation(lastl, ldesc, hml1, np.zeros(len(kl), np.uint8), st1, st2, 1, 0.1)
     g = get("out_ltri.i32", np.int32)

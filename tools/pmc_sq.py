@@ -20,5 +20,5 @@ for gi, g in enumerate(groups):
             acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
     for (k, c), v in acc.items():
         res[k][c] = v[1] / v[0]
-for k in sorted(res, key=lambda k: -res[k].get("SQ_BUSY_CYCLES", 0))[:10]:
+for k in sorted(res, key=lambda k: -res[k].get("SQ_BUSY_CYCLES", 0))[:16]:
     print(k, " ".join("%s=%.3g" % (c, v) for c, v in sorted(res[k].items())))
