@@ -126,7 +126,7 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     // LDS of k_lsd_regions = the first rcap entries of the region list (+1 mailbox word); longer regions spill to HBM.
     // The USED flags live in the angle map, so a workgroup needs ~6 KB and a CU hosts as many frames as it has wave
     // slots: the kernel is a latency-bound serial chain per frame and its throughput is the number of frames in flight.
-    g->rcap = 1535;
+    g->rcap = 1279;   // (1535 until the large-batch kernel parked its seed chunk in LDS: no measurable difference, 68.8 vs 68.8 ms per 4096 frames)
     if (const char *e = getenv("PLF_LSD_RCAP")) { if (atoi(e) >= 63 && atoi(e) <= 16384) g->rcap = atoi(e); }
     // Rectangles per frame: regions are disjoint and one that yields a rectangle owns >= min_reg_size pixels, so sw * sh / min_reg_size bounds
     // their number for ANY image (13107 at VGA, 46k at 1280x960; real frames produce 500-1500): no frame can overflow its rows.  Only the NFA
@@ -438,9 +438,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else if (B <= lat_max)
         hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
-    else if (h->regions_lds <= 6400) {   // 8 frames per workgroup (one wave each): see k_lsd_regions2
+    else if ((size_t)(g.rcap + 1) * 4 <= 5120) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
         const int wpg = getenv("PLF_LSD_WPG") ? max(1, min(16, atoi(getenv("PLF_LSD_WPG")))) : 8;
-        hipLaunchKernelGGL(k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * 6400, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+        const size_t wave_lds = 5120 + 1024;
+        hipLaunchKernelGGL(k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B);
     }
     else

@@ -704,7 +704,9 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     return true;
 }
 
-#define PLF_LSD_FPW2_LDS 6400
+// LDS of one wave of the large-batch region kernel: the first 1280 words of the region list (rcap <= 1279 + the mailbox word) and 1 KB for the parked seed chunk
+#define PLF_LSD_WAVE_LIST 5120
+#define PLF_LSD_WAVE_LDS (PLF_LSD_WAVE_LIST + 1024)
 #ifndef PLF_REGIONS_PRIO
 #define PLF_REGIONS_PRIO 3
 #endif
@@ -720,7 +722,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     const int fpw = LDSOFF < 0 ? (int)(blockDim.x >> 6) : FPW;
     const int f = FPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * fpw + wv, lane = FPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     if (FPW != 1 && f >= nframes) return;
-    LDS_PTR(char) smem = (LDS_PTR(char))smem_base + (LDSOFF < 0 ? wv * PLF_LSD_FPW2_LDS : LDSOFF);
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_base + (LDSOFF < 0 ? wv * PLF_LSD_WAVE_LDS : LDSOFF);
     const uint32_t *seeds = seeds_all ? seeds_all + (size_t)f * g.s_stride : nullptr;   // sorted keys (seed_order 1) or raster
     const int W = g.sw, H = g.sh, NP = W * H;
     RegCtx C;
@@ -742,6 +744,68 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     const double prec = g.prec, p = g.p;
     const GrowTh th0 = grow_thresholds(prec);
     TIC(tall);
+    if (LDSOFF < 0) {
+    // Large-batch kernel: the per-lane state of the seed chunk (pixel, angle word, seed sums) is parked in 1 KB of LDS behind the list instead of in
+    // 4 VGPRs that live across the whole per-seed pipeline: 96 instead of 99 VGPRs, i.e. 128 instead of 96 registers per SIMD left next to the four region
+    // waves -- with the list cut to 1280 entries (6144 bytes of LDS per wave, 64 KB per CU left) a second k_orb_level tile fits beside them.
+    // One 16-byte broadcast read per seed replaces four readlanes; the kernel's own time is unchanged (69.5 vs 69.0 ms per 4096 frames), the step
+    // goes from 131.7 to 129.3 ms.  (With two-wave workgroups this build lost: a fifth workgroup pair per CU became possible and the 2048 workgroups
+    // of a launch were placed unevenly; an 8-wave workgroup cannot be placed a third time on a CU.)
+    typedef uint32_t park_t __attribute__((ext_vector_type(4)));
+    LDS_PTR(park_t) park = (LDS_PTR(park_t))(smem + PLF_LSD_WAVE_LIST);
+    for (int base = 0; base < NP; base += 64) {
+        unsigned long long mask;
+        {
+            int px = base + lane;
+            if (seeds) px = px < NP ? (int)(seeds[px] & 0xFFFFFu) : NP;
+            float2 c0 = make_float2(0.f, 0.f);
+            if (px < NP) c0 = C.cs0[px];
+            const uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
+            park[lane] = park_t{(uint32_t)px, w, __float_as_uint(c0.x), __float_as_uint(c0.y)};
+            mask = __ballot(w < 0x80000000u);
+        }
+        CBAR();
+        C.cbase = seeds ? -0x40000000 : base;
+        C.cused = 0ull;
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            const park_t sv = park[j];
+            const int seed = __builtin_amdgcn_readfirstlane((int)sv.x);
+            const float sdeg = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sv.y));
+            const float2 sc0 = make_float2(__uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sv.z)),
+                                           __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sv.w)));
+            double reg_angle;
+            TIC(t0);
+            int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
+            TOC(0, t0); CNT(4, 1); CNT(5, n);
+            const bool big = n >= g.min_reg_size;
+            if (big) {
+                LsdRect rec;
+                TIC(t1);
+                region2rect(C, n, reg_angle, prec, p, rec);
+                TOC(1, t1); CNT(6, 1);
+                TIC(t2);
+                const bool okr = refine(C, n, reg_angle, prec, p, rec, 0.7);
+                TOC(2, t2);
+                if (okr) {
+                    if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
+                    else if (lane == 0) atomicOr(status, 1);
+                    nr++;
+                }
+            }
+            CBAR();
+            mask &= ~((2ull << j) - 1ull);
+            if (big || seeds) {   // refine / reduce may have released pixels again: take the flags from memory
+                const int px = (int)park[lane].x;
+                const uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
+                C.cused = 0ull;
+                mask &= __ballot(w < 0x80000000u);
+            } else {
+                mask &= ~C.cused;
+            }
+        }
+    }
+    } else
     for (int base = 0; base < NP; base += 64) {
         int px = base + lane;
         if (seeds) px = px < NP ? (int)(seeds[px] & 0xFFFFFu) : NP;
