@@ -48,7 +48,7 @@ typedef uint32_t __attribute__((aligned(1))) plf_u32u_pre;
 #define PRE_SC 88
 #define PRE_SR 26
 #ifndef PRE_NT
-#define PRE_NT 512   // threads per tile: 8 waves share the 40 KB of LDS (3 tiles per CU = 6 waves per SIMD); 256 -> 512: 16.3 -> 13.9 ms per 4096 frames, 1024: 18.9
+#define PRE_NT 512   // threads per tile: 8 waves share the 31 KB of LDS (4 tiles per CU = 8 waves per SIMD); 256 / 384 / 448 / 512 / 1024: 16.3 / 14.7 / 15.1 / 13.5 / 18.9 ms per 4096 frames
 #endif
 __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, float *__restrict__ ang,
                                                  double *__restrict__ modgrad, double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g,
@@ -154,8 +154,9 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     __syncthreads();
     const int tx = tid & 63;
 #pragma unroll
-    for (int k = 0; k < PRE_TH / (PRE_NT / 64); k++) {
-        const int ty = (tid >> 6) + (PRE_NT / 64) * k;
+    for (int k = 0; k < (PRE_TH + PRE_NT / 64 - 1) / (PRE_NT / 64); k++) {
+        const int ty = (tid >> 6) + (PRE_NT / 64) * k;   // (wave-uniform)
+        if (PRE_TH % (PRE_NT / 64) != 0 && ty >= PRE_TH) break;
         const int x = dx0 + tx, y = dy0 + ty;
         bool def = false;
         float deg = 0.f;
