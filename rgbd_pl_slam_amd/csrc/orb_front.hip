@@ -240,20 +240,34 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         uint8_t *plane = pyr + (size_t)f * g.pyr_stride + L.plane_off;
         // groups of 4 level columns x4 = 4-aligned, from the one holding plane column pxs to the one holding pxe - 1
         const int xg0 = (pxs - PLF_EDGE) & ~3;
-        for (int py = pys + trow; py < pye; py += NR) {
-            const uint8_t *prow = P + (plf_reflect101(py - PLF_EDGE, H) - ey0) * PW - ex0;   // indexed by level x
-            uint8_t *drow = plane + (size_t)py * L.ppitch + PLF_EDGE;                        // indexed by level x
-            // (upper bound of what a branch-free border would buy, measured with the fast path forced: 27.4 -> 27.0 ms per 4096 frames for this loop,
-            // 27.4 -> 27.2 for the level-0 load above: not pursued)
-            // (measured alternatives: 16-byte stores at byte alignment 29.8 -> 41.9 ms per 4096 frames; a plane layout that makes these dword stores
-            // aligned -- pitch rounded to 64, one pad byte in front of every row -- changes nothing: 29.8 ms; writing the mirrored border columns as byte-swapped
-            // dwords instead of single bytes: 30.4 ms.  The cost of this phase is not its instruction count)
-            for (int x4 = xg0 + tc4; x4 + PLF_EDGE < pxe; x4 += 128) {
-                if (x4 >= 0 && x4 + 3 < W && x4 + PLF_EDGE >= pxs && x4 + 3 + PLF_EDGE < pxe)
-                    *(plf_u32u *)(drow + x4) = *reinterpret_cast<const uint32_t *>(prow + x4);
-                else
+        // A thread owns one group of 4 columns and walks down the rows: what depends on the column only -- whether the group is a plain dword or
+        // a partial / mirrored one, the 4 source columns and their validity -- is settled once, a row costs one LDS read, one store and the two
+        // pointer steps.  (With the rows outside, every thread redid the column tests and the 64-bit row arithmetic per dword: 45 instructions per
+        // stored dword; this phase issued as many VALU instructions as the resize or the blur -- SQ_INSTS_VALU of cut builds, 71 M of 416 M per
+        // launch.)
+        // (measured alternatives for the stores themselves: 16-byte stores at byte alignment 29.8 -> 41.9 ms per 4096 frames; a plane layout that
+        // makes these dword stores aligned -- pitch rounded to 64, one pad byte in front of every row -- changes nothing: 29.8 ms; writing the mirrored
+        // border columns as byte-swapped dwords instead of single bytes: 30.4 ms)
+        for (int x4 = xg0 + tc4; x4 + PLF_EDGE < pxe; x4 += 128) {
+            const bool full = x4 >= 0 && x4 + 3 < W && x4 + PLF_EDGE >= pxs && x4 + 3 + PLF_EDGE < pxe;
+            int sc[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ok[j] = x4 + j + PLF_EDGE >= pxs && x4 + j + PLF_EDGE < pxe;
+                sc[j] = plf_reflect101(x4 + j, W) - ex0;
+            }
+            uint8_t *dcol = plane + PLF_EDGE + x4;
+            for (int py = pys + trow; py < pye; py += NR) {
+                const int ly = py - PLF_EDGE;
+                const uint8_t *prow = P + (((unsigned)ly < (unsigned)H ? ly : plf_reflect101(ly, H)) - ey0) * PW;
+                uint8_t *d = dcol + (size_t)py * L.ppitch;
+                if (full) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow + (x4 - ex0));
+                else {
+#pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (x4 + j + PLF_EDGE >= pxs && x4 + j + PLF_EDGE < pxe) drow[x4 + j] = prow[plf_reflect101(x4 + j, W)];
+                        if (ok[j]) d[j] = prow[sc[j]];
+                }
             }
         }
     }
