@@ -106,6 +106,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     const int xs = tx == 0 ? 0 : rx0, xe = tx == L.tcx - 1 ? W : rx1;                                   // owned part of the level image
     const int ys = ty == 0 ? 0 : ry0, ye = ty == L.tcy - 1 ? H : ry1;
     const int ex0 = (xs & ~3) - 4, EW = ((xe - 1) & ~3) + 8 - ex0;                                     // tile columns: owned + halo, 4-aligned
+    const int xs4 = xs & ~3, xe4 = tx == L.tcx - 1 ? xe : xe & ~3;                                     // the columns this tile WRITES (plane, blur): inner boundaries 4-aligned
     const int ey0 = ys - 3, EH = ye - ys + 6;                                                          // tile rows: owned + 3-row halo
     const int PW = g.lds_pw;
     uint8_t *P = smem;
@@ -235,7 +236,9 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
 #endif
     // ---- 2. this tile's part of the padded plane (interior + REFLECT_101 border)
     {
-        const int pxs = tx == 0 ? 0 : xs + PLF_EDGE, pxe = tx == L.tcx - 1 ? L.ppitch : xe + PLF_EDGE;
+        // columns written by this tile: its owned range with the inner boundaries rounded DOWN to multiples of 4 (the tile holds those level
+        // pixels in its halo, the left neighbour stops there as well), so that every group of an inner tile is a whole dword
+        const int pxs = tx == 0 ? 0 : xs4 + PLF_EDGE, pxe = tx == L.tcx - 1 ? L.ppitch : xe4 + PLF_EDGE;
         const int pys = ty == 0 ? 0 : ys + PLF_EDGE, pye = ty == L.tcy - 1 ? H + 2 * PLF_EDGE : ye + PLF_EDGE;
         uint8_t *plane = pyr + (size_t)f * g.pyr_stride + L.plane_off;
         // groups of 4 level columns x4 = 4-aligned, from the one holding plane column pxs to the one holding pxe - 1
@@ -309,10 +312,10 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                     bw |= (uint32_t)min(v, 255) << (8 * j);
                 }
                 uint8_t *bo = bp + (size_t)(ys + oy) * L.bpitch + x4;
-                if (x4 >= xs && x4 + 3 < xe) *reinterpret_cast<uint32_t *>(bo) = bw;
+                if (x4 >= xs4 && x4 + 3 < xe4) *reinterpret_cast<uint32_t *>(bo) = bw;
                 else
                     for (int j = 0; j < 4; j++)
-                        if (x4 + j >= xs && x4 + j < xe) bo[j] = (uint8_t)(bw >> (8 * j));
+                        if (x4 + j >= xs4 && x4 + j < xe4) bo[j] = (uint8_t)(bw >> (8 * j));
             }
         }
     }
