@@ -409,6 +409,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     if (spec) {
         h->spec.s_global = s_global ? 1 : 0;
+        h->spec.spin_bound = 1 << 21;
+        if (const char *e = getenv("PLF_LSD_SPEC_SPINS")) { if (atoi(e) >= 64) h->spec.spin_bound = atoi(e); }   // test hook: a short bound must still let slow band waves finish (heartbeat)
         h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : 16;
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
         PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));

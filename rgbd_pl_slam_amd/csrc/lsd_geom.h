@@ -30,7 +30,8 @@ struct SpecBufs {
     uint32_t *rxy;      // [frame][band][s_stride] list overflow of the band waves
     uint32_t *tl;       // [frame][band][tcap] accepted pixels (bit 30: still marked at the end of the seed)
     SpecRec *recs;      // [frame][band][rcap_rec]
-    int *cnt;           // [frame][band][4]: records, accepted pixels, overflow
+    int *cnt;           // [frame][band][4]: records, accepted pixels, overflow, heartbeat / end time stamp
+    int spin_bound;     // polls (~3.4 us each) the commit wave waits for a band wave WITHOUT a heartbeat before it gives up (status bit 4)
     uint32_t *seedmap;  // [frame][bm_words]: seeds that own a record
     uint32_t *defmap;   // [frame][bm_words]: pixels with a defined level-line angle (k_lsd_spec_bands)
     uint32_t *tl2;      // [frame][2 * s_stride]: accepted pixels of a seed regrown by the commit kernel

@@ -1093,6 +1093,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             LsdRect rec;
             const int t0 = tn;
+            if (lane == 0) __hip_atomic_store(&SB.cnt[fb * 4 + 3], seed + 1 + (phase << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // heartbeat (spec_wait_band)
             const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf);
             if (!record) { tn = 0; ovf = 0; }
             if (record && nrec >= SB.rcap_rec) ovf = 1;
@@ -1170,13 +1171,18 @@ template <bool SG> struct SpecS {
 
 // The one-launch schedule makes the commit wave of a frame wait for the band waves of the same launch.  The host only uses it when ALL workgroups of
 // the launch can be resident at once (occupancy query), so every band wave is dispatched whatever the dispatch order; the spin is bounded all the
-// same (~2^21 x 3 us): a scheduling surprise then surfaces as status bit 4 -> PLF_E_HIP for the batch instead of a hung GPU.
+// same (~2^21 x 3 us WITHOUT a heartbeat of the awaited band wave -- it bumps cnt[3] once per seed): a scheduling surprise then surfaces as status
+// bit 4 -> PLF_E_HIP for the batch instead of a hung GPU.
 __device__ __forceinline__ bool spec_wait_band(const SpecBufs &SB, size_t fb, int *status)
 {
-    int spins = 0;
+    int spins = 0, beat = 0;
     while (__hip_atomic_load(&SB.done[fb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(127);
-        if (++spins > (1 << 21)) { atomicOr(status, 4); return false; }
+        if (++spins > SB.spin_bound) { atomicOr(status, 4); return false; }
+        if ((spins & (SB.spin_bound >= 4096 ? 1023 : 15)) == 0) {   // a band wave that is still retiring seeds is slow, not missing (quantised images take tens of seconds per frame)
+            const int b = __hip_atomic_load(&SB.cnt[fb * 4 + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b != beat) { beat = b; spins = 0; }
+        }
     }
     __threadfence();
     return true;

@@ -202,6 +202,22 @@ def test_lines_speculative_overflow_falls_back(monkeypatch):
     ext.close()
 
 
+def test_lines_speculative_slow_band_is_not_a_timeout(monkeypatch):
+    """The commit wave of the one-launch schedule gives up (PLF_E_HIP) after a bounded number of polls WITHOUT a heartbeat of the band wave it waits for.
+    With the bound cut to 7 ms a two-band VGA frame (each band wave works for far longer than that) still has to come out equal to the oracle: a band
+    wave that keeps retiring seeds is slow, not missing.  (tools/soak.py seed 51591, a 3-level quantised checkerboard that takes 42 s per frame on the GPU
+    and 2.4 s in the oracle, ran into the unconditional 7 s bound with 2 and 4 bands.)"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    monkeypatch.setenv("PLF_LSD_SPEC_SPINS", "2048")
+    monkeypatch.setenv("PLF_LSD_SPEC_BANDS", "2")
+    ext = LineSegment(nlines=100, max_width=640, max_height=480)
+    for seed in (9, 21):
+        _check(synth_frame(seed), 100, ext=ext)
+    ext.close()
+
+
 def test_lines_speculative_odd_widths():
     """scaled widths that are not multiples of 8 / 32 (752 -> 602, 600 -> 480, 333 -> 266) through the speculative path"""
     _need_gpu()
