@@ -121,17 +121,19 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     // ---- 1. the level pixels of the tile
     if (l == 0) {
         const uint8_t *img = in + (size_t)f * in_fstride;
-        for (int ey = trow; ey < EH; ey += NR) {
-            const uint8_t *row = img + (size_t)plf_reflect101(ey0 + ey, H) * in_pitch;
-            for (int c4 = tc4; c4 < EW; c4 += 128) {
-                const int x = ex0 + c4;
-                uint32_t v;
-                if (x >= 0 && x + 3 < W) v = *(const plf_u32u *)(row + x);
-                else {
-                    v = 0;
+        // (a thread owns a column group and walks down the rows, as in the plane write below: the column test and the mirrored columns are settled once)
+        for (int c4 = tc4; c4 < EW; c4 += 128) {
+            const int x = ex0 + c4;
+            const bool whole = x >= 0 && x + 3 < W;
+            int mx[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v |= (uint32_t)row[plf_reflect101(x + j, W)] << (8 * j);
-                }
+            for (int j = 0; j < 4; j++) mx[j] = plf_reflect101(x + j, W);
+            for (int ey = trow; ey < EH; ey += NR) {
+                const int y = ey0 + ey;
+                const uint8_t *row = img + (size_t)((unsigned)y < (unsigned)H ? y : plf_reflect101(y, H)) * in_pitch;
+                uint32_t v;
+                if (whole) v = *(const plf_u32u *)(row + x);
+                else v = (uint32_t)row[mx[0]] | ((uint32_t)row[mx[1]] << 8) | ((uint32_t)row[mx[2]] << 16) | ((uint32_t)row[mx[3]] << 24);
                 *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = v;
             }
         }
