@@ -140,6 +140,28 @@ def test_lines_published_seed_order():
     ext.close()
 
 
+@pytest.mark.parametrize("seed_order", [0, 1])
+def test_lines_large_batch_kernel_on_a_small_batch(monkeypatch, seed_order):
+    """k_lsd_regions2 (the throughput launch: 8 frames per workgroup, seed chunk parked in LDS) normally needs > 640 frames in flight (seed_order 0)
+    or > 8 (seed_order 1, which has no speculative schedule); with the speculative schedule switched off it runs for 21 frames -- a count that leaves
+    the last workgroup partly empty -- of mixed textures, each compared with the oracle run with the same seed order"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import texture_frame
+    monkeypatch.setenv("PLF_LSD_SPEC_MAX", "0")
+    imgs = []
+    s = 400
+    while len(imgs) < 21:
+        im, _ = texture_frame(s, size=(640, 480)); s += 1
+        imgs.append(im)
+    ext = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=21, seed_order=seed_order)
+    res = ext.extract_batch(np.stack(imgs))
+    for f in range(21):
+        ref = orc.line_extract(imgs[f], 100, seed_order=seed_order)
+        assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"]), "frame %d" % f
+    ext.close()
+
+
 def test_line_and_matcher_errors():
     """argument errors come back as PLF_E_BADARG (never a crash, never a silent wrong answer); an empty image is the
     reference's silent return (PLF_E_EMPTY, outputs untouched)"""
