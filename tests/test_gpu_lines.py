@@ -162,6 +162,21 @@ def test_lines_large_batch_kernel_on_a_small_batch(monkeypatch, seed_order):
     ext.close()
 
 
+@pytest.mark.parametrize("w,h", [(12, 40), (40, 12), (15, 15), (16, 16), (17, 33), (19, 64), (64, 19)])
+def test_lines_tiny_images(w, h):
+    """images narrower than the 16-byte border window of k_lsd_pre's row pass (per-tap fallback) and images where EVERY 4-column group is a border group"""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (((xx // 5 + yy // 7) & 1) * 180 + 30 + rng.integers(0, 8, (h, w))).astype(np.uint8)
+    ls = LineSegment(nlines=20, max_width=max(w, 16), max_height=max(h, 16))
+    kl, desc, eq = ls.ExtractLineSegment(img)
+    ref = orc.line_extract(img, 20)
+    assert len(kl) == len(ref["kl"]) > 0 and kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"])
+    ls.close()
+
+
 def test_line_and_matcher_errors():
     """argument errors come back as PLF_E_BADARG (never a crash, never a silent wrong answer); an empty image is the
     reference's silent return (PLF_E_EMPTY, outputs untouched)"""
