@@ -48,7 +48,18 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
     __builtin_amdgcn_s_setprio(PLF_ORB_PRIO2);
 #endif
     // one wave per OUTPUT slot o of the frame (level-major order); its level follows from the per-level counts
-    const int o = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    // XCD-aware order: workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), so with (slot, frame) = (blockIdx.x, blockIdx.y)
+    // the key points of ONE frame are spread over all 8 L2s and every L2 pulls most of that frame's planes from HBM (FETCH_SIZE 2.9x the
+    // algorithmic bytes).  Remapped: 8 consecutive workgroups take the same slot of 8 different frames, i.e. XCD x works through frame 8 G + x.
+    const int lane = threadIdx.x;
+    int o, f;
+    {
+        const int S = (int)gridDim.x, B = (int)gridDim.y;
+        const int Lid = (int)blockIdx.x + S * (int)blockIdx.y;
+        const int G = Lid / (8 * S), r = Lid - G * 8 * S, nf = min(8, B - 8 * G);
+        f = 8 * G + r % nf;
+        o = r / nf;
+    }
     const int *cnt = selcnt + f * g.nlevels;
     int offset = 0, total = 0, l = -1;
     for (int i = 0; i < g.nlevels; i++) {
