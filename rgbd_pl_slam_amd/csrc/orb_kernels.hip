@@ -44,9 +44,6 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
                                                      plf_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                      int *__restrict__ n_out, int capacity, int *__restrict__ status, OrbGeom g)
 {
-#ifdef PLF_ORB_PRIO2
-    __builtin_amdgcn_s_setprio(PLF_ORB_PRIO2);
-#endif
     // one wave per OUTPUT slot o of the frame (level-major order); its level follows from the per-level counts
     // XCD-aware order: workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), so with (slot, frame) = (blockIdx.x, blockIdx.y)
     // the key points of ONE frame are spread over all 8 L2s and every L2 pulls most of that frame's planes from HBM (FETCH_SIZE 2.9x the

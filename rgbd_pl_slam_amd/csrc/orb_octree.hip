@@ -165,9 +165,6 @@ __global__ void __launch_bounds__(256) k_octree(const int2 *__restrict__ cellinf
                                                 uint2 *__restrict__ sel, int *__restrict__ selcnt, int *__restrict__ ncand_dbg,
                                                 int *__restrict__ status, OrbGeom g, int cap_nodes, int cap_sort)
 {
-#ifdef PLF_ORB_PRIO2
-    __builtin_amdgcn_s_setprio(PLF_ORB_PRIO2);
-#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int l = blockIdx.x, f = blockIdx.y, T = blockDim.x, t = threadIdx.x;
     const OrbLevel &L = g.lv[l];
