@@ -22,6 +22,7 @@
 typedef uint32_t __attribute__((aligned(1))) plf_u32u;
 
 // cornerScore<16> of cv::FAST (largest threshold for which the pixel is still a corner) minus 1, clamped at 0; d[k] = I_p - I_ring[k]
+// (scalar form: the definition; the kernel runs the packed form orb_fast_score_pk below)
 __device__ __forceinline__ int orb_fast_score(const int d[16], int t)
 {
     bool br = true, dk = true;
@@ -54,6 +55,47 @@ typedef short plf_s2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ plf_s2v of_min(plf_s2v a, plf_s2v b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ plf_s2v of_max(plf_s2v a, plf_s2v b) { return __builtin_elementwise_max(a, b); }
+// cornerScore<16> as above on packed int16 pairs: P[k] = (d[k], d[k + 8]), k = 0..7 (|d| <= 255, t <= 255: exact in 16 bits).  With E[j] = P[j] for j < 8 and
+// the half-swapped P[j - 8] for j >= 8, lane x of an expression over E[k], E[k + 1], ... is the scalar expression at ring index k and lane y the one at
+// k + 8 -- half the min / max instructions of the scalar form.
+__device__ __forceinline__ plf_s2v of_swap(plf_s2v a)
+{
+    const uint32_t u = __builtin_bit_cast(uint32_t, a);
+    return __builtin_bit_cast(plf_s2v, __builtin_amdgcn_alignbit(u, u, 16));
+}
+__device__ __forceinline__ int orb_fast_score_pk(const plf_s2v P[8], int t)
+{
+    plf_s2v E[10];
+#pragma unroll
+    for (int k = 0; k < 8; k++) E[k] = P[k];
+    plf_s2v SW[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) SW[k] = of_swap(P[k]);
+    E[8] = SW[0]; E[9] = SW[1];
+    // necessary condition: of every opposite pair one pixel is brighter than t (or one darker than -t)
+    plf_s2v brm = of_max(P[0], SW[0]), dkm = of_min(P[0], SW[0]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) { brm = of_min(brm, of_max(P[k], SW[k])); dkm = of_max(dkm, of_min(P[k], SW[k])); }
+    if (!((int)brm.x > t) && !((int)dkm.x < -t)) return 0;
+    plf_s2v m3[14], M3[14];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        m3[k] = of_min(E[k], of_min(E[k + 1], E[k + 2]));
+        M3[k] = of_max(E[k], of_max(E[k + 1], E[k + 2]));
+    }
+#pragma unroll
+    for (int k = 8; k < 14; k++) { m3[k] = of_swap(m3[k - 8]); M3[k] = of_swap(M3[k - 8]); }
+    plf_s2v sb = of_min(m3[0], of_min(m3[3], m3[6])), sd = of_max(M3[0], of_max(M3[3], M3[6]));
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        sb = of_max(sb, of_min(m3[k], of_min(m3[k + 3], m3[k + 6])));
+        sd = of_min(sd, of_max(M3[k], of_max(M3[k + 3], M3[k + 6])));
+    }
+    const int sbs = max((int)sb.x, (int)sb.y), sds = min((int)sd.x, (int)sd.y);
+    const int s_ = max(sbs, -sds) - 1;
+    return s_ < 0 ? 0 : s_;
+}
+
 // bytes k and k + 1 (0 <= k <= 10) of the 12 bytes (A, B, C) as two zero-extended int16 (one v_perm_b32); bytes k, k + 1 (k <= 2) of one dword
 #define OF_PAIR(A, B, C, k) __builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm((k) < 4 ? (B) : (C), (k) < 4 ? (A) : (k) < 8 ? (B) : (C), \
                                                                               (uint32_t)((k) & 3) | 0x0C000C00u | ((uint32_t)(((k) & 3) + 1) << 16)))
@@ -383,12 +425,16 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         const int q = LIST[k], c = q & 255, ry = q >> 8;
         const uint8_t *p = P + (ry0 + ry - ey0) * PW + c;
         const int v = p[0];
-        int d[16];
-        d[0] = v - p[3 * PW];       d[1] = v - p[3 * PW + 1];   d[2] = v - p[2 * PW + 2];   d[3] = v - p[PW + 3];
-        d[4] = v - p[3];            d[5] = v - p[-PW + 3];      d[6] = v - p[-2 * PW + 2];  d[7] = v - p[-3 * PW + 1];
-        d[8] = v - p[-3 * PW];      d[9] = v - p[-3 * PW - 1];  d[10] = v - p[-2 * PW - 2]; d[11] = v - p[-PW - 3];
-        d[12] = v - p[-3];          d[13] = v - p[PW - 3];      d[14] = v - p[2 * PW - 2];  d[15] = v - p[3 * PW - 1];
-        S[ry * SP + c - cS0] = (uint8_t)orb_fast_score(d, tmin);
+        // ring pixel k and k + 8 packed as (low, high) int16, subtracted from (v, v) by one v_pk_sub_i16
+        const plf_s2v vv = {(short)v, (short)v};
+#define OF_RP_(a, b) (vv - __builtin_bit_cast(plf_s2v, (uint32_t)(a) | ((uint32_t)(b) << 16)))
+        plf_s2v Pk[8];
+        Pk[0] = OF_RP_(p[3 * PW], p[-3 * PW]);          Pk[1] = OF_RP_(p[3 * PW + 1], p[-3 * PW - 1]);
+        Pk[2] = OF_RP_(p[2 * PW + 2], p[-2 * PW - 2]);  Pk[3] = OF_RP_(p[PW + 3], p[-PW - 3]);
+        Pk[4] = OF_RP_(p[3], p[-3]);                    Pk[5] = OF_RP_(p[-PW + 3], p[PW - 3]);
+        Pk[6] = OF_RP_(p[-2 * PW + 2], p[2 * PW - 2]);  Pk[7] = OF_RP_(p[-3 * PW + 1], p[3 * PW - 1]);
+#undef OF_RP_
+        S[ry * SP + c - cS0] = (uint8_t)orb_fast_score_pk(Pk, tmin);
     }
     __syncthreads();
 #if defined(OF_STOP) && OF_STOP <= 5
