@@ -25,7 +25,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 M_POINTS, M_LINES = 5000, 500
 CONFIGS = {   # --config -> (width, height, ORB features, lines, frames in flight per GPU, label)
@@ -63,8 +62,7 @@ class Pipeline:
     def __init__(self, w, h, nfeat, nlines, B, device, seed_base, serial=False, line_handles=1, front_wait=True, defer_match=True):
         import numpy as np
         import torch
-        import matchgen
-        from rgbd_pl_slam_amd import ORBextractor, LineSegment, Matcher
+        from rgbd_pl_slam_amd import ORBextractor, LineSegment, Matcher, matchgen
         from rgbd_pl_slam_amd._lib import KP_DTYPE, KL_DTYPE
         from rgbd_pl_slam_amd.synth import synth_frame
         self.torch, self.B, self.w, self.h, self.nlines = torch, B, w, h, nlines
@@ -284,8 +282,9 @@ def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
     it -- median / p95 and the per-stage split; (a2) ORB and LSD on two threads (PL-SLAM family); (b) one frame per thread on all cores."""
     import ctypes as C
     import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))   # tests/orc.py = the ctypes wrapper of the CPU oracle (the checker; only this leg uses it)
     import orc
-    import matchgen
+    from rgbd_pl_slam_amd import matchgen
     from rgbd_pl_slam_amd.synth import synth_frame
     flags = "-O3 -march=native"
     try:

@@ -169,10 +169,25 @@ static int worker_init(Worker *w)
         op.device = w->device; op.max_batch = (int32_t)C;
         W_RC(plf_orb_create(&op, &w->orb));
         w->orb_cap = plf_orb_capacity(w->orb);
+    }
+    {   // mvScaleFactors (ORBextractor ctor, include/ORBextractor.h:51-52: float(double(previous) * scaleFactor)): the line matcher reads them too, so the
+        // table exists whether or not this worker extracts ORB features (a lines-only batch with map lines silently matched nothing)
         float sc[PLF_MAX_LEVELS];
-        W_RC(plf_orb_get_tables(w->orb, &w->nlevels, sc, nullptr, nullptr, nullptr, nullptr));
-        W_RC(dev_alloc(w, &w->d_scale, PLF_MAX_LEVELS));
-        W_TRY(hipMemcpy(w->d_scale, sc, sizeof(float) * w->nlevels, hipMemcpyHostToDevice));
+        if (w->orb) W_RC(plf_orb_get_tables(w->orb, &w->nlevels, sc, nullptr, nullptr, nullptr, nullptr));
+        else if (P.max_maplines > 0) {
+            const int nl = P.orb.nlevels;
+            if (nl < 1 || nl > PLF_MAX_LEVELS || !(P.orb.scale_factor > 1.0f)) {
+                fprintf(stderr, "[plf] plf_batch_create: max_maplines > 0 needs orb.scale_factor / orb.nlevels (mvScaleFactors) even with orb.nfeatures <= 0\n");
+                return PLF_E_BADARG;
+            }
+            w->nlevels = nl;
+            sc[0] = 1.0f;
+            for (int i = 1; i < nl; i++) sc[i] = (float)((double)sc[i - 1] * (double)P.orb.scale_factor);
+        }
+        if (w->nlevels > 0) {
+            W_RC(dev_alloc(w, &w->d_scale, PLF_MAX_LEVELS));
+            W_TRY(hipMemcpy(w->d_scale, sc, sizeof(float) * w->nlevels, hipMemcpyHostToDevice));
+        }
     }
     if (P.line.nlines > 0) {
         plf_line_params lp = P.line;
@@ -514,6 +529,7 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
             int rc = plf_line_extract_batch(w->line, d_gray, PLF_MEM_DEVICE, s.n, J.w, J.h, J.w, (ptrdiff_t)J.w * J.h, s.h_lines, s.h_ldesc, s.h_eq, nl.data(),
                                             PLF_MEM_HOST, w->line_cap, w->s_line);
             if (rc != PLF_OK && rc != PLF_E_CAPACITY) return rc;
+            if (rc == PLF_E_CAPACITY) *soft = PLF_E_CAPACITY;
             for (int f = 0; f < s.n; f++) s.h_nl[f] = nl[f];
             if (match_lns || J.rgbd) {   // the Frame tail / matches of the failed pass are meaningless: redo them on the fresh lines
                 const size_t K = (size_t)s.n * w->line_cap;

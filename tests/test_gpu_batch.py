@@ -240,6 +240,102 @@ def test_all_visible_gpus_share_one_batch():
     bx.close()
 
 
+def _check_frames(res, imgs, nfeat, nlines, frames=None, local_map=None, tag=""):
+    for f in (range(len(imgs)) if frames is None else frames):
+        ro = orc.orb_extract(imgs[f], nfeatures=nfeat); rl = orc.line_extract(imgs[f], nlines)
+        _same_orb(res[f], ro, "%sframe %d" % (tag, f)); _same_lines(res[f], rl, "%sframe %d" % (tag, f))
+        if local_map is not None:
+            mp, ml, scale, bounds = local_map
+            rm, rn = orc.search_by_projection_map(ro["kps"], ro["desc"], None, scale, bounds, mp, 3.0, 0.8, np.full(len(ro["kps"]), -1, np.int32))
+            assert res[f]["n_kp_matches"] == rn and np.array_equal(res[f]["match_of_kp"], rm), "%sframe %d: point matches" % (tag, f)
+            lm, ln = orc.search_lines_by_projection(rl["kl"], rl["desc"], scale, ml, 3.0, 0.8, np.full(len(rl["kl"]), -1, np.int32))
+            assert res[f]["n_line_matches"] == ln and np.array_equal(res[f]["match_of_line"], lm), "%sframe %d: line matches" % (tag, f)
+
+
+def test_two_workers_on_one_gpu_37_vga_frames_with_local_map():
+    """More than one worker for real: devices = [0, 0] gives two worker threads -- each with its own handles, streams, pinned slots and
+    local-map replica -- sharing the one GPU of the test box, exactly the code an 8-GPU node runs with eight.  37 VGA frames = blocks of 18 and 19
+    (plf_batch_shard), 8 in flight: each worker runs two full chunks and a ragged one while the other is active; both write into ONE set of caller
+    arrays.  Two calls in a row (hand-off post / wait_done twice, slots reused).  Every frame equals the oracle."""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor, shard
+    from rgbd_pl_slam_amd.synth import synth_frame
+    n = 37
+    imgs = np.stack([synth_frame(1300 + i) for i in range(n)])
+    r0 = orc.orb_extract(imgs[0], nfeatures=1000); l0 = orc.line_extract(imgs[0], 100)
+    mp = matchgen.make_local_map(r0["kps"], r0["desc"], 3000, 5)
+    ml = matchgen.make_map_lines(l0["kl"], l0["desc"], 400, 6)
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    bx = BatchExtractor(nfeatures=1000, nlines=100, width=640, height=480, frames_in_flight=8, devices=[0, 0], max_mappoints=4096, max_maplines=512)
+    assert bx.n_devices == 2 and bx.devices == [0, 0]
+    assert [shard(n, 2, g) for g in range(2)] == [(0, 18), (18, 37)]
+    bx.set_local_map(mp, ml, th=3.0, nnratio=0.8, bounds=bounds)
+    for rep in range(2):
+        res = bx.extract(imgs)
+        _check_frames(res, imgs, 1000, 100, local_map=(mp, ml, scale, bounds), tag="call %d " % rep)
+    # a new local map replaces the replicas of BOTH workers
+    mp2 = matchgen.make_local_map(r0["kps"], r0["desc"], 2000, 15)
+    bx.set_local_map(mp2, ml, th=3.0, nnratio=0.8, bounds=bounds)
+    res = bx.extract(imgs)
+    _check_frames(res, imgs, 1000, 100, frames=(0, 17, 18, 36), local_map=(mp2, ml, scale, bounds), tag="new map ")
+    bx.close()
+
+
+def test_four_workers_on_one_gpu_config4_shape():
+    """BASELINE configs[3] shape (1280x960, 4000 ORB + 400 lines) on FOUR workers (devices = [0, 0, 0, 0]): 16 frames = 4 per worker, 2 in flight, so every
+    worker pipelines two chunks through both slots while three others compete for the GPU"""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd.synth import synth_frame
+    n = 16
+    imgs = np.stack([synth_frame(2100 + i, 1280, 960) for i in range(n)])
+    bx = BatchExtractor(nfeatures=4000, nlines=400, width=1280, height=960, frames_in_flight=2, devices=[0, 0, 0, 0])
+    assert bx.n_devices == 4
+    for rep in range(2):
+        res = bx.extract(imgs)
+        _check_frames(res, imgs, 4000, 400, frames=None if rep == 0 else (0, 3, 4, 8, 15), tag="call %d " % rep)
+    # fewer frames than workers: blocks of 0 / 1 frames (an idle worker must not touch the outputs or block the call)
+    res = bx.extract(imgs[:3])
+    _check_frames(res, imgs[:3], 4000, 400, tag="3 frames ")
+    bx.close()
+
+
+def test_rectangle_pool_redo_in_one_worker_while_the_other_runs():
+    """PLF_E_RECTS redo (host-memory re-extraction in halves + line matching on the fresh lines) inside worker 0 while worker 1 processes normal frames on the
+    same GPU; lines-only batch with map lines -- the mvScaleFactors table no longer depends on an ORB handle"""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd.synth import synth_frame
+    rng = np.random.default_rng(77000 + 246)
+    rng.random(); rng.integers(0, 12)
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    a = rng.uniform(0, np.pi); per = rng.uniform(3, 40)
+    stripes = (127.5 + 120 * np.sign(np.sin((xx * np.cos(a) + yy * np.sin(a)) * 2 * np.pi / per))).astype(np.uint8)
+    normal = [synth_frame(2600 + i) for i in range(11)]
+    imgs = np.stack([stripes] * 8 + normal[:1] + normal)          # worker 0: frames 0-9 (8 stripes + 2 normal), worker 1: frames 10-19
+    n = len(imgs)
+    assert n == 20
+    refs = {}
+    for f in range(n):
+        refs[f] = refs[0] if 0 < f < 8 else orc.line_extract(imgs[f], 100)
+    ml = matchgen.make_map_lines(refs[8]["kl"], refs[8]["desc"], 300, 6)
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    for nfeat in (1000, 0):
+        bx = BatchExtractor(nfeatures=nfeat, nlines=100, width=640, height=480, frames_in_flight=8, devices=[0, 0], max_mappoints=16, max_maplines=512)
+        bx.set_local_map(None, ml, th=3.0, nnratio=0.8, bounds=(0.0, 0.0, 640.0, 480.0))
+        res = bx.extract(imgs)
+        for f in range(n):
+            _same_lines(res[f], refs[f], "nfeatures %d frame %d" % (nfeat, f))
+            lm, ln = orc.search_lines_by_projection(refs[f]["kl"], refs[f]["desc"], scale, ml, 3.0, 0.8, np.full(len(refs[f]["kl"]), -1, np.int32))
+            assert res[f]["n_line_matches"] == ln and np.array_equal(res[f]["match_of_line"], lm), "nfeatures %d frame %d: line matches" % (nfeat, f)
+        assert res[8]["n_line_matches"] > 10
+        if nfeat:
+            for f in (8, 19):
+                _same_orb(res[f], orc.orb_extract(imgs[f], nfeatures=nfeat), "frame %d" % f)
+        bx.close()
+
+
 def test_empty_and_bad_arguments():
     _need_gpu()
     import ctypes as C
