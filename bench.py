@@ -59,21 +59,23 @@ def algorithmic_bytes(w, h, nfeat, nlines, lam_per_line=80):
 class Pipeline:
     """the device-resident step: both extractors + the four matchers for B frames in flight on one GPU"""
 
-    def __init__(self, w, h, nfeat, nlines, B, device, seed_base, serial=False, line_handles=1, front_wait=True, defer_match=True):
+    def __init__(self, w, h, nfeat, nlines, B, device, seed_base, serial=False, line_handles=1, front_wait=True, defer_match=True, distinct=1024):
         import numpy as np
         import torch
         from rgbd_pl_slam_amd import ORBextractor, LineSegment, Matcher, matchgen
         from rgbd_pl_slam_amd._lib import KP_DTYPE, KL_DTYPE
-        from rgbd_pl_slam_amd.synth import synth_frame
+        from rgbd_pl_slam_amd.synth import synth_batch_parallel
         self.torch, self.B, self.w, self.h, self.nlines = torch, B, w, h, nlines
         self.serial, self.front_wait = serial, front_wait
         self.defer_match = defer_match and not serial
         self.pending = None
-        ndist = min(B, 32)
+        # `distinct` independently seeded frames tiled to the batch (VERDICT r02: a region-growing launch lasts as long as its slowest chain, so 32
+        # distinct images tiled 128 times understate the tail of a diverse stream)
+        ndist = min(B, max(1, distinct))
         self.ndist = ndist
-        imgs = np.stack([synth_frame(seed_base + i, w, h) for i in range(ndist)])
-        imgs = np.concatenate([imgs] * ((B + ndist - 1) // ndist))[:B]
-        self.d_img = torch.from_numpy(imgs).cuda()
+        self.h_distinct = synth_batch_parallel(seed_base, ndist, w, h)
+        self.d_img = torch.empty((B, h, w), dtype=torch.uint8, device="cuda")
+        self.load_images(ndist)
         self.orb = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, max_batch=B, device=device)
         # (line_handles 2: two handles used alternately so that the NFA / descriptor tail of batch k overlaps the region growing of batch k+1)
         self.lins = [LineSegment(nlines=nlines, max_width=w, max_height=h, max_batch=B, device=device) for _ in range(max(1, min(2, line_handles)))]
@@ -119,7 +121,17 @@ class Pipeline:
         self.mats = [Matcher(max_keypoints=cap, max_mappoints=M_POINTS, max_lines=max(nlines, 2), max_batch=B, device=device) for _ in range(2)]
         self.last_view = Matcher.last_view(self.last)
         from rgbd_pl_slam_amd import _lib as L
-        self.poses = (L.PosePair * B)(*[Matcher.pose_pair(pose)] * B)
+        # every frame of the batch has its own pose (the motion-model prediction differs per frame) and the poses change from step to step, as in a
+        # tracking loop: the pose upload is part of every timed step (one constant array always hit the handle's cache)
+        prng = np.random.default_rng(6)
+        self.poses = []
+        for _ in range(3):
+            arr = (L.PosePair * B)()
+            jit = prng.normal(0.0, 0.002, (B, 3)).astype(np.float32)
+            for f in range(B):
+                pf = dict(pose); pf["tcw"] = pose["tcw"] + jit[f]
+                arr[f] = Matcher.pose_pair(pf)
+            self.poses.append(arr)
         for bs in self.bufs:
             bs["fviews"] = Matcher.view_array([Matcher.frame_view(cap, bs["kps"].data_ptr() + f * cap * 28, bs["desc"].data_ptr() + f * cap * 32, self.scale, bounds,
                                                                   None, bs["nk"].data_ptr() + 4 * f) for f in range(B)])
@@ -127,6 +139,17 @@ class Pipeline:
                                                                       self.scale, bs["nl"].data_ptr() + 4 * f) for f in range(B)])
             bs["match_done"] = None
         self.k = 0
+
+    def load_images(self, ndist):
+        """fill the resident batch with the first ndist distinct frames, tiled"""
+        import numpy as np
+        torch, B = self.torch, self.B
+        src = torch.from_numpy(self.h_distinct[:ndist]).cuda()
+        for lo in range(0, B, ndist):
+            n = min(ndist, B - lo)
+            self.d_img[lo:lo + n].copy_(src[:n])
+        torch.cuda.synchronize()
+        self.ndist_loaded = ndist
 
     def step(self):
         torch = self.torch
@@ -168,7 +191,7 @@ class Pipeline:
             bs["match_kp"].fill_(-1); bs["match_kp_last"].fill_(-1); bs["match_ln"].fill_(-1); bs["match_ln_last"].fill_(-1)
         mat = self.mats[k & 1]
         mat.SearchByProjection(bs["fviews"], self.mp, 3.0, 0.8, bs["match_kp"], self.cap, bs["nm_kp"], sM.cuda_stream)
-        mat.SearchByProjectionLastFrameBatch(bs["fviews"], self.last_view, self.poses, 7.0, 0, 1, bs["match_kp_last"], self.cap, bs["nm_kp_last"], sM.cuda_stream)
+        mat.SearchByProjectionLastFrameBatch(bs["fviews"], self.last_view, self.poses[k % 3], 7.0, 0, 1, bs["match_kp_last"], self.cap, bs["nm_kp_last"], sM.cuda_stream)
         sM.wait_event(ev_lines)
         mat.SearchLinesByProjection(bs["lviews"], self.ml, 3.0, 0.8, bs["match_ln"], self.nlines, bs["nm_ln"], sM.cuda_stream)
         mat.SearchLinesLastFrameBatch(self.last_ldesc, self.last_has_ml, bs["lviews"], bs["match_ln_last"], self.nlines, bs["nm_ln_last"], sM.cuda_stream)
@@ -180,7 +203,8 @@ class Pipeline:
         with self.torch.cuda.stream(sM):
             bs["match_kp"].fill_(-1); bs["match_kp_last"].fill_(-1); bs["match_ln"].fill_(-1); bs["match_ln_last"].fill_(-1)
         mat.SearchByProjection(bs["fviews"], self.mp, 3.0, 0.8, bs["match_kp"], self.cap, bs["nm_kp"], sM.cuda_stream)
-        mat.SearchByProjectionLastFrameBatch(bs["fviews"], self.last_view, self.poses, 7.0, 0, 1, bs["match_kp_last"], self.cap, bs["nm_kp_last"], sM.cuda_stream)
+        self.mk = getattr(self, "mk", 0) + 1
+        mat.SearchByProjectionLastFrameBatch(bs["fviews"], self.last_view, self.poses[self.mk % 3], 7.0, 0, 1, bs["match_kp_last"], self.cap, bs["nm_kp_last"], sM.cuda_stream)
         mat.SearchLinesByProjection(bs["lviews"], self.ml, 3.0, 0.8, bs["match_ln"], self.nlines, bs["nm_ln"], sM.cuda_stream)
         mat.SearchLinesLastFrameBatch(self.last_ldesc, self.last_has_ml, bs["lviews"], bs["match_ln_last"], self.nlines, bs["nm_ln_last"], sM.cuda_stream)
 
@@ -194,6 +218,13 @@ class Pipeline:
         b = self.bufs[0]
         return {"points_map": int(b["nm_kp"][0]), "points_last_frame": int(b["nm_kp_last"][0]), "lines_map": int(b["nm_ln"][0]),
                 "lines_last_frame_knn": int(b["nm_ln_last"][0]), "keypoints": int(b["nk"][0]), "lines": int(b["nl"][0])}
+
+    def chain_stats(self):
+        """min / median / max length of the frames' region-growing chains in the last batch (pixels left marked USED; 0 if it took the speculative schedule)"""
+        import numpy as np
+        c = self.lins[(self.k - 1) % len(self.lins)].chain_lengths(self.B)
+        return {"min": int(c.min()), "median": int(np.median(c)), "max": int(c.max()), "mean": round(float(c.mean()), 1),
+                "what": "pixels left USED per frame by LSD region growing = length of the frame's serial chain; the one-wave-per-frame launch lasts as long as the longest"}
 
     def close(self):
         for o in [self.orb] + self.lins + self.mats:
@@ -252,14 +283,15 @@ def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml):
     async H2D / D2H, one worker thread per GPU"""
     import numpy as np
     from rgbd_pl_slam_amd.batch import BatchExtractor, pinned_array, free_pinned
-    from rgbd_pl_slam_amd.synth import synth_frame
+    from rgbd_pl_slam_amd.synth import synth_batch_parallel
     bx = BatchExtractor(nfeatures=nfeat, nlines=nlines, width=w, height=h, frames_in_flight=in_flight, devices=[device], max_mappoints=M_POINTS,
                         max_maplines=M_LINES)
     bx.set_local_map({k: v.cpu().numpy() for k, v in mp.items()}, {k: v.cpu().numpy() for k, v in ml.items()}, bounds=(0.0, 0.0, float(w), float(h)))
     pin = pinned_array((n_frames, h, w))
-    distinct = np.stack([synth_frame(8000 + i, w, h) for i in range(16)])
+    nd = min(n_frames, 256)
+    distinct = synth_batch_parallel(8000, nd, w, h)
     for i in range(n_frames):
-        pin[i] = distinct[i % 16]
+        pin[i] = distinct[i % nd]
     out = bx.alloc_outputs(n_frames)
     bx.extract_into(pin[:min(n_frames, 2 * in_flight)], {k: v[:min(n_frames, 2 * in_flight)] for k, v in out.items()})   # warm-up (allocations, tables)
     best = None
@@ -273,7 +305,7 @@ def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml):
     mb = n_frames * w * h / 1e6
     return {"value": round(n_frames / best, 1), "unit": "frames/s", "frames": n_frames, "frames_in_flight": in_flight,
             "h2d_MBps": round(mb / best, 1), "worker_seconds": {k: round(v, 4) for k, v in tm.items()},
-            "what": "plf_batch_extract: %d host frames (pinned) -> key points, descriptors, lines and local-map matches in host memory, 1 GPU" % n_frames}
+            "what": "plf_batch_extract: %d host frames (pinned, %d distinct) -> key points, descriptors, lines and local-map matches in host memory, 1 GPU" % (n_frames, nd)}
 
 
 def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
@@ -349,6 +381,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] entry, counted from 1 (2 = the headline metric)")
     ap.add_argument("--batch", type=int, default=0, help="frames in flight per GPU and step (0: the config's own value)")
+    ap.add_argument("--distinct", type=int, default=1024, help="independently seeded frames per GPU, tiled to the batch (the extra key tiled32 repeats the run with 32)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (config 3 as specified, latency, PCIe-inclusive rate)")
     ap.add_argument("--line-handles", type=int, default=1, help="line extractor handles used alternately (1 or 2)")
@@ -375,7 +408,8 @@ def main():
     # the job = world * B frames per step; this rank's block of it (contiguous, plf_batch_shard) -- always B frames: weak scaling
     lo, hi = shard(world * B, world, rank)
     assert hi - lo == B
-    pipe = Pipeline(W, H, NFEAT, NLINES, B, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait, defer_match=not args.no_defer_match)
+    pipe = Pipeline(W, H, NFEAT, NLINES, B, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait, defer_match=not args.no_defer_match,
+                    distinct=args.distinct)
     elapsed, reg_ms, reg_launches = timed(pipe, args.steps, args.warmup, dist)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -404,7 +438,7 @@ def main():
             "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d" % (W, H),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/f64", "data": "synthetic (%d distinct seeded %dx%d frames per GPU tiled to the batch, resident in HBM)" % (pipe.ndist, W, H),
+            "dtype": "u8/f64", "data": "synthetic (%d independently seeded %dx%d frames per GPU tiled to the batch, resident in HBM; per-frame poses change every step)" % (pipe.ndist, W, H),
             "config": {"workload": label + "; matching per frame: SearchByProjection vs a %d-point local map + vs the last frame, line projection search vs %d map "
                                            "lines + brute-force Hamming kNN (k = 2) of the LBD descriptors vs the last frame's lines" % (M_POINTS, M_LINES),
                        "baseline_config": args.config, "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
@@ -414,6 +448,14 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches, "algorithmic_bytes_per_launch": b_region * B},
         }
+        out["region_chain_length"] = pipe.chain_stats()
+        if world == 1 and args.config == 2 and not args.no_extras and not args.serial and pipe.ndist > 32:
+            # the round-2 workload (32 distinct frames tiled to the batch), same pipeline object, same run: how much input diversity costs
+            pipe.load_images(32)
+            e32, r32, n32 = timed(pipe, args.steps, 1)
+            out["tiled32"] = {"value": round(B * args.steps / e32, 2), "unit": "frames/s", "ms_per_step": round(1e3 * e32 / args.steps, 3),
+                              "region_kernel_ms": round(r32 / max(n32, 1), 3), "region_chain_length": pipe.chain_stats(),
+                              "what": "the same step on 32 distinct frames tiled to the batch (the round-1/2 workload)"}
         mp, ml = pipe.mp, pipe.ml
         pipe.close(); del pipe
         if world == 1 and args.config == 2 and not args.no_extras and not args.serial:

@@ -41,6 +41,8 @@ typedef enum {
     PLF_E_RECTS = -6     /* line extractor, fully device-resident batches only: the batch produced more LSD rectangles than the pooled NFA buffers
                             hold (thousands per frame on average); its outputs are invalid -- redo it in smaller batches (calls that hand
                             host buffers in or out do that themselves) */
+    , PLF_W_TRUNCATED = 1 /* not an error (plf_line_last_status only): at least one frame of the batch spent its plf_line_params.max_ms and was finished
+                            with the line segments found so far; extraction calls themselves return PLF_OK for such a batch */
 } plf_status;
 
 enum { PLF_MEM_HOST = 0, PLF_MEM_DEVICE = 1 };
@@ -126,6 +128,12 @@ typedef struct {
                                 BinaryDescriptor::computeGaussianPyramid, i.e. cv::GaussianBlur(image, Size(5, 5), 1) -- believed to be
                                 opencv_contrib 3.3 behaviour; PLF_LBD_RAW (1) = the image as handed in.  DESIGN.md section 2 lists every
                                 such version-dependent choice. */
+    float max_ms;        /* time budget of LSD region growing per call, milliseconds; 0 (default) = unlimited, the reference's behaviour.  The reference has
+                            no bound: a pathological image (e.g. a coarse checkerboard: net-like regions of 10^4-10^5 pixels) keeps one frame's serial chain
+                            busy for seconds -- on the CPU as on the GPU.  With max_ms > 0 every frame of a call stops seeding regions once the budget is
+                            spent and is finished with the rectangles found so far (NFA validation, top-N, LBD as usual): a DELIBERATE, opt-in deviation
+                            from the reference -- the lines of a truncated frame are a prefix-like subset of the reference's, not bit-equal.  Reported
+                            as PLF_W_TRUNCATED by plf_line_last_status and per frame by plf_line_truncated; frames that finish in time are bit-exact. */
 } plf_line_params;
 enum { PLF_LBD_BLURRED = 0, PLF_LBD_RAW = 1 };
 
@@ -149,13 +157,21 @@ int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t in_mem, int
  * the front stages.  No-op if no batch was enqueued yet. */
 int plf_line_wait_front(plf_line *h, void *stream);
 /* Status of the last batch enqueued with device-resident inputs AND outputs (that call returns before the GPU has run): waits for `stream`
- * (NULL: the handle's stream), then PLF_OK, PLF_E_CAPACITY (a frame had more lines than `capacity`) or PLF_E_RECTS. */
+ * (NULL: the handle's stream), then PLF_OK, PLF_E_CAPACITY (a frame had more lines than `capacity`), PLF_E_RECTS, or PLF_W_TRUNCATED (> 0: a frame ran
+ * out of plf_line_params.max_ms; valid after host-memory calls too). */
 int plf_line_last_status(plf_line *h, void *stream);
+/* flags[f] = 1 if frame f of the last batch ran out of plf_line_params.max_ms (waits for the stream of that call) */
+int plf_line_truncated(plf_line *h, int32_t *flags, int32_t n);
 
 /* Diagnostics of the banded speculative region growing used for <= 640 frames in flight, frame 0 of the last batch:
  * out8 = {regions committed from the speculation, regions grown by the commit wave, chunks committed in one step, records checked pixel by pixel,
  * kilo-cycles spent regrowing, validating, in total, in per-band setup}.  PLF_E_BADARG if the path has not run on this handle. */
 int plf_line_debug_spec_stats(plf_line *h, int32_t *out8);
+
+/* Diagnostics (bench.py): out[f] = length of frame f's region-growing chain in the last batch = pixels left marked USED (accept steps minus the pixels
+ * refine released again), n <= frames of that batch.  The launch of the one-wave-per-frame kernel lasts as long as its longest chain.  Zero for batches
+ * that took the speculative schedule (its flags live in LDS).  Synchronises the device. */
+int plf_line_chain_lengths(plf_line *h, int32_t *out, int32_t n);
 
 /* Measurement hook (bench.py roofline): when enabled, every launch of the region-growing kernel -- the dominant
  * kernel of the whole front-end -- is bracketed by HIP events on the stream it is launched on.  The call
@@ -573,6 +589,10 @@ typedef struct {
 } plf_batch_rgbd;
 int plf_batch_extract_rgbd(plf_batch *b, const uint8_t *images, int64_t n_frames, int32_t width, int32_t height, ptrdiff_t pitch,
                            ptrdiff_t frame_stride, const plf_batch_outputs *out, const plf_batch_rgbd *rgbd);
+
+/* Frames of the last plf_batch_extract* call whose LSD region growing ran out of plf_batch_params.line.max_ms and were finished with the segments found
+ * until then (0 without a budget; a deliberate opt-in deviation, see plf_line_params.max_ms). */
+int64_t plf_batch_truncated_frames(const plf_batch *b);
 
 /* Seconds the workers of the last plf_batch_extract spent (max over workers): [0] total, [1] staging copies into pinned
  * memory, [2] waiting for the GPU, [3] unpacking outputs. */

@@ -95,9 +95,10 @@ struct Vector3d { double v[3]; double operator()(int i) const { return v[i]; } }
 
 class LineSegment {
 public:
-    explicit LineSegment(int nlines = 100, int maxWidth = 640, int maxHeight = 480, int maxBatch = 1, int device = 0) : nlines_(nlines)
+    // maxMs > 0: opt-in time budget of LSD region growing per call (plf_line_params.max_ms; the reference has none)
+    explicit LineSegment(int nlines = 100, int maxWidth = 640, int maxHeight = 480, int maxBatch = 1, int device = 0, float maxMs = 0.f) : nlines_(nlines)
     {
-        plf_line_params p = {nlines, 0, device, maxWidth, maxHeight, maxBatch, PLF_LBD_BLURRED};
+        plf_line_params p = {nlines, 0, device, maxWidth, maxHeight, maxBatch, PLF_LBD_BLURRED, maxMs};
         check(plf_line_create(&p, &h_), "plf_line_create");
     }
     ~LineSegment() { plf_line_destroy(h_); }

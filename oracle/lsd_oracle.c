@@ -21,6 +21,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
@@ -770,6 +771,222 @@ int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch,
     for (int b = 0; b < nbands; b++) { free(recs[b]); free(tl[b]); free(halo[b]); }
     free(halo);
     free(recs); free(nrecs); free(tl); free(priv); free(T); free(S); free(D); free(rects_par); free(rects_serial); free(used_serial);
+    free(reg); free(touched); free(L.img); free(L.angles); free(L.modgrad);
+    return (int)stats[6];
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Model of the round-3 scheme, "banded speculation with PARALLEL validation rounds" (DESIGN.md section 5): phase 1 as above but WITHOUT halo
+ * rows (every band speculates against an empty map, so it does no extra work); the serial commit wave is replaced by rounds in which EVERY band
+ * validates itself, all bands at once: band b takes E'_b = the union of what the bands before it mark according to their CURRENT logs, compares it
+ * with E_b (the union its log was last made consistent with) and, where they differ, walks its records exactly like phase 2 above (stands / regrown
+ * on the true flags / new seeds), which leaves a log that is the serial processing of the band's seeds from E'_b.  Band 0 never changes, so after
+ * round r the bands 0..r are final: at most nbands rounds; the rounds stop when no band's marks changed.  The fixpoint is the serial result
+ * (induction over the bands).  Not part of any parity path.
+ * stats[0] serial accepts, [1] max over bands of speculative accepts (phase 1 critical path), [2] sum over rounds of (max over bands of accepts
+ * redone in the round) = critical path of the rounds, [3] total accepts redone, [4] rounds until nothing changed (the last round only confirms),
+ * [5] band validations that had to walk their records, [6] 1 if identical to the serial result, [7] regions redone or new, summed */
+typedef struct { band_rec *recs; int nrecs, cap; int *tl; size_t tn, tcap; uint8_t *out, *E; rect_t *rects; int nrect; } band_log;
+
+static void band_log_push(band_log *B, int seed, int has_rect, const rect_t *rec, const int *touched, int nt, const uint8_t *used)
+{
+    if (B->nrecs == B->cap) { B->cap = B->cap ? 2 * B->cap : 1024; B->recs = (band_rec *)realloc(B->recs, sizeof(band_rec) * B->cap); }
+    if (B->tn + (size_t)nt > B->tcap) { B->tcap = 2 * (B->tn + nt) + 1024; B->tl = (int *)realloc(B->tl, sizeof(int) * B->tcap); }
+    band_rec *r = &B->recs[B->nrecs++];
+    r->seed = seed; r->has_rect = has_rect; r->t0 = (int)B->tn; r->nt = nt;
+    if (has_rect) r->rec = *rec;
+    for (int i = 0; i < nt; i++) B->tl[B->tn++] = touched[i] | (used[touched[i]] == USED ? (int)0x40000000 : 0);
+}
+
+static int g_rounds_mode = 0, g_rounds_refined = 0;
+void orc_lsd_band_rounds_refined(int m) { g_rounds_refined = m; }
+void orc_lsd_band_rounds_mode(int m) { g_rounds_mode = m; }
+
+int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats)
+{
+    const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5;
+    lsd_t L;
+    const double prec = CV_PI_ * ANG_TH / 180, p = ANG_TH / 180, rho = QUANT / sin(prec);
+    double *img = (double *)malloc(sizeof(double) * (size_t)w * h);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) img[(size_t)y * w + x] = (double)gray[(size_t)y * pitch + x];
+    const double sigma = SIGMA_SCALE / SCALE;
+    const int ksize = 1 + 2 * (int)(unsigned)ceil(sigma * sqrt(2 * 3 * log(10.0)));
+    double kern[64];
+    orc_gauss_kernel_f64(ksize, sigma, kern);
+    double *blur = (double *)malloc(sizeof(double) * (size_t)w * h);
+    gaussian_blur_f64(img, blur, w, h, kern, ksize);
+    L.w = (int)lrint(w * SCALE); L.h = (int)lrint(h * SCALE);
+    L.img = (double *)malloc(sizeof(double) * (size_t)L.w * L.h);
+    resize_linear_f64(blur, w, h, L.img, L.w, L.h, SCALE, SCALE);
+    free(img); free(blur);
+    const int W = L.w, H = L.h;
+    const size_t NP = (size_t)W * H;
+    L.angles = (double *)malloc(sizeof(double) * NP);
+    L.modgrad = (double *)calloc(NP, sizeof(double));
+    for (int x = 0; x < W; x++) L.angles[(size_t)(H - 1) * W + x] = NOTDEF;
+    for (int y = 0; y < H; y++) L.angles[(size_t)y * W + (W - 1)] = NOTDEF;
+    for (int y = 0; y < H - 1; ++y)
+        for (int x = 0; x < W - 1; ++x) {
+            size_t a = (size_t)y * W + x;
+            double DA = L.img[a + W + 1] - L.img[a], BC = L.img[a + 1] - L.img[a + W];
+            double gx = DA + BC, gy = DA - BC, norm = sqrt((gx * gx + gy * gy) / 4);
+            L.modgrad[a] = norm;
+            L.angles[a] = norm <= rho ? NOTDEF : (double)orc_fast_atan2((float)gx, (float)-gy) * DEG_TO_RADS;
+        }
+    L.LOG_NT = 5 * (log10((double)W) + log10((double)H)) / 2 + log10(11.0);
+    const int min_reg_size = (int)(-L.LOG_NT / log10(p));
+    regpt *reg = (regpt *)malloc(sizeof(regpt) * NP);
+    int *touched = (int *)malloc(sizeof(int) * 2 * NP);
+    memset(stats, 0, sizeof(long) * 8);
+    /* ---- serial run */
+    uint8_t *used_serial = (uint8_t *)calloc(NP, 1);
+    rect_t *rects_serial = (rect_t *)malloc(sizeof(rect_t) * NP / 4);
+    int nrect_serial = 0;
+    L.used = used_serial;
+    for (int y = 0; y < H - 1; ++y)
+        for (int x = 0; x < W - 1; ++x) {
+            const int adx = y * W + x;
+            if (L.used[adx] != NOTUSED || L.angles[adx] == NOTDEF) continue;
+            int nt; rect_t rec;
+            if (run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &stats[0])) rects_serial[nrect_serial++] = rec;
+        }
+    /* ---- bands: equal shares of the defined pixels, boundaries on multiples of 8 rows (as k_lsd_spec_bands) */
+    const int rows = H - 1, units = (rows + 7) / 8;
+    if (nbands < 1) nbands = 1;
+    if (nbands > units) nbands = units;
+    int *by = (int *)calloc(nbands + 1, sizeof(int));
+    {
+        long *cnt = (long *)calloc(units, sizeof(long)), total = 0;
+        for (int y = 0; y < rows; y++) for (int x = 0; x < W - 1; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) { cnt[y >> 3]++; total++; }
+        long acc = 0; int u = 0;
+        for (int b = 1; b < nbands; b++) {
+            const long target = total * b / nbands;
+            while (u < units && acc + cnt[u] / 2 < target) acc += cnt[u++];
+            int uu = u, umin = (by[b - 1] >> 3) + 1;
+            if (uu < umin) uu = umin;
+            if (uu > units - (nbands - b)) uu = units - (nbands - b);
+            by[b] = uu * 8 < rows ? uu * 8 : rows;
+        }
+        by[nbands] = rows;
+        free(cnt);
+    }
+    /* ---- phase 1: every band against an empty map */
+    band_log *B = (band_log *)calloc(nbands, sizeof(band_log)), *B2 = (band_log *)calloc(nbands, sizeof(band_log));
+    uint8_t *priv = (uint8_t *)malloc(NP);
+    for (int b = 0; b < nbands; b++) {
+        memset(priv, 0, NP);
+        /* initial guess of what the earlier bands mark: nothing (mode 0), or every defined pixel above the band (mode 1) -- in the serial run a defined
+         * pixel above the current seed is free only if refine / reduce_region_radius released it again */
+        if (g_rounds_mode == 1) for (int y = 0; y < by[b]; y++) for (int x = 0; x < W; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) priv[(size_t)y * W + x] = USED;
+        B[b].E = (uint8_t *)malloc(NP); memcpy(B[b].E, priv, NP);
+        L.used = priv;
+        long acc = 0;
+        B[b].rects = (rect_t *)malloc(sizeof(rect_t) * NP / 4);
+        for (int y = by[b]; y < by[b + 1]; ++y)
+            for (int x = 0; x < W - 1; ++x) {
+                const int adx = y * W + x;
+                if (L.used[adx] != NOTUSED || L.angles[adx] == NOTDEF) continue;
+                int nt; rect_t rec;
+                const int ok = run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &acc);
+                band_log_push(&B[b], adx, ok, &rec, touched, nt, L.used);
+                if (ok) B[b].rects[B[b].nrect++] = rec;
+            }
+        B[b].out = (uint8_t *)malloc(NP);
+        for (size_t i = 0; i < NP; i++) B[b].out[i] = (priv[i] == USED && B[b].E[i] != USED) ? USED : NOTUSED;
+        if (getenv("ORC_ROUNDS_VERBOSE")) fprintf(stderr, "  band %d rows %d-%d: %ld accepts, %d records\n", b, by[b], by[b + 1], acc, B[b].nrecs);
+        if (acc > stats[1]) stats[1] = acc;
+    }
+    /* ---- rounds */
+    uint8_t *T = (uint8_t *)malloc(NP), *S = (uint8_t *)malloc(NP), *D = (uint8_t *)malloc(NP), *En = (uint8_t *)malloc(NP);
+    uint8_t **newout = (uint8_t **)calloc(nbands, sizeof(uint8_t *));
+    int rounds = 0;
+    for (;;) {
+        int changed = 0;
+        long round_max = 0;
+        rounds++;
+        memset(En, 0, NP);   /* running union of the outs of the bands before b, all taken from the state BEFORE this round (Jacobi) */
+        for (int b = 0; b < nbands; b++) {
+            newout[b] = NULL;
+            if (b > 0) for (size_t i = 0; i < NP; i++) En[i] |= B[b - 1].out[i];
+            if (memcmp(En, B[b].E, NP) == 0) continue;   /* consistent already */
+            stats[5]++;
+            memcpy(T, En, NP); memcpy(S, B[b].E, NP);
+            for (size_t i = 0; i < NP; i++) D[i] = S[i] != T[i];
+            band_log N; memset(&N, 0, sizeof(N));
+            N.rects = (rect_t *)malloc(sizeof(rect_t) * NP / 4);
+            long redo = 0;
+            int ri = 0;
+            for (int y = by[b]; y < by[b + 1]; ++y)
+                for (int x = 0; x < W - 1; ++x) {
+                    const int adx = y * W + x;
+                    const band_rec *r = (ri < B[b].nrecs && B[b].recs[ri].seed == adx) ? &B[b].recs[ri] : NULL;
+                    if (r) ri++;
+                    const int true_eff = T[adx] == NOTUSED && L.angles[adx] != NOTDEF;
+                    if (!r && !true_eff) continue;
+                    int valid = r && true_eff;
+                    if (valid)
+                        for (int i = 0; i < r->nt && valid; i++) {
+                            const int q = B[b].tl[r->t0 + i] & 0x3FFFFFFF, qx = q % W, qy = q / W;
+                            for (int dy = -1; dy <= 1 && valid; dy++)
+                                for (int dx = -1; dx <= 1; dx++) {
+                                    const int xx = qx + dx, yy = qy + dy;
+                                    if (xx < 0 || yy < 0 || xx >= W || yy >= H) continue;
+                                    const size_t a = (size_t)yy * W + xx;
+                                    if (!D[a]) continue;
+                                    /* refined rule (g_rounds_refined): a neighbour the speculation saw FREE and that is truly USED changes nothing unless the
+                                     * record ACCEPTED it (a free neighbour it rejected for its angle is skipped in the true run: same outcome) */
+                                    if (g_rounds_refined && T[a] == USED && !(dx == 0 && dy == 0)) continue;
+                                    valid = 0; break;
+                                }
+                        }
+                    if (valid) {
+                        for (int i = 0; i < r->nt; i++) { const int e = B[b].tl[r->t0 + i]; if (e & 0x40000000) { T[e & 0x3FFFFFFF] = USED; S[e & 0x3FFFFFFF] = USED; } }
+                        /* the record moves to the new log unchanged */
+                        for (int i = 0; i < r->nt; i++) touched[i] = B[b].tl[r->t0 + i] & 0x3FFFFFFF;
+                        band_log_push(&N, adx, r->has_rect, &r->rec, touched, r->nt, T);
+                        /* (marks: the pixels flagged in the old log are exactly those now USED in T among the touched ones) */
+                        if (r->has_rect) N.rects[N.nrect++] = r->rec;
+                        continue;
+                    }
+                    if (r)
+                        for (int i = 0; i < r->nt; i++) { const int e = B[b].tl[r->t0 + i]; if (e & 0x40000000) { const int q = e & 0x3FFFFFFF; S[q] = USED; D[q] = S[q] != T[q]; } }
+                    if (true_eff) {
+                        int nt; rect_t rec;
+                        L.used = T;
+                        stats[7]++;
+                        const int ok = run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &redo);
+                        band_log_push(&N, adx, ok, &rec, touched, nt, T);
+                        if (ok) N.rects[N.nrect++] = rec;
+                        for (int i = 0; i < nt; i++) D[touched[i]] = S[touched[i]] != T[touched[i]];
+                    }
+                }
+            /* what the band marks = T minus what the earlier bands mark */
+            N.out = (uint8_t *)malloc(NP);
+            for (size_t i = 0; i < NP; i++) N.out[i] = (T[i] == USED && En[i] != USED) ? USED : NOTUSED;
+            N.E = (uint8_t *)malloc(NP); memcpy(N.E, En, NP);
+            if (memcmp(N.out, B[b].out, NP) != 0) changed = 1;
+            B2[b] = N; newout[b] = N.out;
+            stats[3] += redo;
+            if (redo > round_max) round_max = redo;
+        }
+        for (int b = 0; b < nbands; b++)
+            if (newout[b]) { free(B[b].recs); free(B[b].tl); free(B[b].out); free(B[b].E); free(B[b].rects); B[b] = B2[b]; }
+        stats[2] += round_max;
+        if (getenv("ORC_ROUNDS_VERBOSE")) fprintf(stderr, "  round %d: max redo %ld, changed %d\n", rounds, round_max, changed);
+        if (!changed || rounds > nbands + 1) break;
+    }
+    stats[4] = rounds;
+    /* ---- result: the bands' rectangles in band order, the union of their marks */
+    int nrect_par = 0, same = 1;
+    memset(T, 0, NP);
+    for (int b = 0; b < nbands; b++) {
+        for (int i = 0; i < B[b].nrect; i++, nrect_par++)
+            if (nrect_par >= nrect_serial || memcmp(&B[b].rects[i], &rects_serial[nrect_par], sizeof(rect_t)) != 0) same = 0;
+        for (size_t i = 0; i < NP; i++) T[i] |= B[b].out[i];
+    }
+    stats[6] = same && nrect_par == nrect_serial && memcmp(T, used_serial, NP) == 0;
+    for (int b = 0; b < nbands; b++) { free(B[b].recs); free(B[b].tl); free(B[b].out); free(B[b].E); free(B[b].rects); }
+    free(B); free(B2); free(newout); free(by); free(priv); free(T); free(S); free(D); free(En); free(rects_serial); free(used_serial);
     free(reg); free(touched); free(L.img); free(L.angles); free(L.modgrad);
     return (int)stats[6];
 }

@@ -193,6 +193,7 @@ int orc_lsd_detect(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int seed_
                    orc_lsd_debug *dbg);
 void orc_lsd_band_speculation_halo(int rows);
 int orc_lsd_band_speculation(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats /*8*/);
+int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats /*8*/);
 int orc_keylines_from_segments(const float *lines, int n, int w, int h, orc_keyline *out);
 void orc_sobel3_16s(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int16_t *dxImg, int16_t *dyImg);
 void orc_lbd_gauss_coefs(double *gaussCoefL, double *gaussCoefG);

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLF_LIB_PATH") or os.path.join(_HERE, "libplf_hip.so")   # (PLF_LIB_PATH: A/B measurements of scratch builds)
 
 PLF_OK, PLF_E_EMPTY, PLF_E_BADARG, PLF_E_CAPACITY, PLF_E_HIP, PLF_E_NOMEM, PLF_E_RECTS = 0, -1, -2, -3, -4, -5, -6
+PLF_W_TRUNCATED = 1
 MEM_HOST, MEM_DEVICE = 0, 1
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -28,14 +29,14 @@ class OrbParams(C.Structure):
 
 class LineParams(C.Structure):
     _fields_ = [("nlines", C.c_int32), ("seed_order", C.c_int32), ("device", C.c_int32), ("max_width", C.c_int32),
-                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("lbd_sobel_input", C.c_int32)]
+                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("lbd_sobel_input", C.c_int32), ("max_ms", C.c_float)]
 
 
 LBD_BLURRED, LBD_RAW = 0, 1
 
 
-def line_params(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input=LBD_BLURRED):
-    return LineParams(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input)
+def line_params(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input=LBD_BLURRED, max_ms=0.0):
+    return LineParams(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input, max_ms)
 
 
 class FrameView(C.Structure):

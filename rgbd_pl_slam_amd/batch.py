@@ -63,10 +63,10 @@ class BatchExtractor:
     the local map set with set_local_map)."""
 
     def __init__(self, nfeatures=1000, nlines=100, width=640, height=480, frames_in_flight=8, devices=None, scaleFactor=1.2, nlevels=8,
-                 iniThFAST=20, minThFAST=7, input_format=FMT_GRAY8, max_mappoints=0, max_maplines=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED, rgbd=False):
+                 iniThFAST=20, minThFAST=7, input_format=FMT_GRAY8, max_mappoints=0, max_maplines=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED, rgbd=False, max_ms=0.0):
         p = BatchParams()
         p.orb = L.OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, 0, width, height, 1)
-        p.line = L.line_params(nlines, seed_order, 0, width, height, 1, lbd_sobel_input)
+        p.line = L.line_params(nlines, seed_order, 0, width, height, 1, lbd_sobel_input, max_ms)
         self._devs = None
         if devices is not None:
             self._devs = (C.c_int32 * len(devices))(*devices)
@@ -196,6 +196,12 @@ class BatchExtractor:
                         d[q] = ro[q][f, :k].copy()
             res.append(d)
         return res
+
+    def truncated_frames(self):
+        """frames of the last extract whose line extraction ran out of max_ms"""
+        f = L.lib().plf_batch_truncated_frames
+        f.restype = C.c_int64
+        return int(f(self._h))
 
     def last_timing(self):
         t = (C.c_double * 4)()

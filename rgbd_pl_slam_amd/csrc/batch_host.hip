@@ -20,7 +20,7 @@
 
 // status words of the extractor handles, copied asynchronously on `s` (orb_host.hip / line_host.hip)
 int plf_orb_status_async(plf_orb *h, int32_t *host_dst, hipStream_t s);
-int plf_line_status_async(plf_line *h, int32_t *host_dst, hipStream_t s);
+int plf_line_status_async(plf_line *h, int32_t *host_dst, int32_t *host_flags, int n, hipStream_t s);
 
 namespace {
 
@@ -46,6 +46,7 @@ struct Slot {
     plf_keyline *d_lun = nullptr, *h_lun = nullptr;
     float *d_le[4] = {nullptr, nullptr, nullptr, nullptr}, *h_le[4] = {nullptr, nullptr, nullptr, nullptr};   // uright start / end, depth start / end
     int32_t *h_status = nullptr;   // [0] ORB status word, [1] line status word
+    int32_t *h_trunc = nullptr;    // per frame of the chunk: the line extractor ran out of plf_line_params.max_ms
     hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_line = nullptr, ev_out = nullptr;
     plf_matcher *mat = nullptr;
     std::vector<plf_frame_view> fviews;
@@ -89,6 +90,7 @@ struct Worker {
     int orb_cap = 0, line_cap = 0, nlevels = 0;
     size_t in_bytes_per_frame = 0;
     double t_total = 0, t_stage = 0, t_wait = 0, t_unpack = 0;
+    int64_t n_trunc = 0;   // frames of the last call whose line extraction ran out of its time budget
 };
 
 }  // namespace
@@ -200,6 +202,8 @@ static int worker_init(Worker *w)
         W_RC(dev_alloc(w, &s.d_in, C * w->in_bytes_per_frame));
         if (bpp == 3) W_RC(dev_alloc(w, &s.d_gray, C * (size_t)mw * mh));
         W_RC(pin_alloc(w, &s.h_status, 4));
+        W_RC(pin_alloc(w, &s.h_trunc, C));
+        memset(s.h_trunc, 0, C * sizeof(int32_t));
         if (P.rgbd) {
             const size_t px = C * (size_t)mw * mh;
             W_RC(pin_alloc(w, &s.h_dep, px)); W_RC(dev_alloc(w, &s.d_dep16, px)); W_RC(dev_alloc(w, &s.d_depf, px));
@@ -265,7 +269,7 @@ static void worker_shutdown(Worker *w)
         void *dev[] = {s.d_in, s.d_gray, s.d_kps, s.d_desc, s.d_nk, s.d_lines, s.d_ldesc, s.d_eq, s.d_nl, s.d_mkp, s.d_nmkp, s.d_mln, s.d_nmln,
                        s.d_dep16, s.d_depf, s.d_kun, s.d_ur, s.d_kd, s.d_lun, s.d_le[0], s.d_le[1], s.d_le[2], s.d_le[3]};
         for (void *p : dev) if (p) (void)hipFree(p);
-        void *pin[] = {s.h_in, s.h_kps, s.h_desc, s.h_nk, s.h_lines, s.h_ldesc, s.h_eq, s.h_nl, s.h_mkp, s.h_nmkp, s.h_mln, s.h_nmln, s.h_status,
+        void *pin[] = {s.h_in, s.h_kps, s.h_desc, s.h_nk, s.h_lines, s.h_ldesc, s.h_eq, s.h_nl, s.h_mkp, s.h_nmkp, s.h_mln, s.h_nmln, s.h_status, s.h_trunc,
                        s.h_dep, s.h_kun, s.h_ur, s.h_kd, s.h_lun, s.h_le[0], s.h_le[1], s.h_le[2], s.h_le[3]};
         for (void *p : pin) if (p) (void)hipHostFree(p);
         hipEvent_t ev[] = {s.ev_in, s.ev_orb, s.ev_line, s.ev_out};
@@ -403,7 +407,7 @@ static int chunk_submit(Worker *w, Slot &s, const Job &J, int64_t first, int n, 
         W_TRY(hipStreamWaitEvent(w->s_line, s.ev_out, 0));
         W_RC(plf_line_extract_batch(w->line, d_gray, PLF_MEM_DEVICE, n, J.w, J.h, J.w, (ptrdiff_t)J.w * J.h, s.d_lines, s.d_ldesc, s.d_eq, s.d_nl,
                                     PLF_MEM_DEVICE, w->line_cap, w->s_line));
-        W_RC(plf_line_status_async(w->line, &s.h_status[1], w->s_line));
+        W_RC(plf_line_status_async(w->line, &s.h_status[1], s.h_trunc, n, w->s_line));
         if (J.rgbd) W_RC(line_tail_submit(w, s, J, n, w->s_line));
         W_TRY(hipEventRecord(s.ev_line, w->s_line));
     }
@@ -561,6 +565,7 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
                 else for (int i = 0; i < n; i++) O.match_of_line[g * O.line_capacity + i] = -1;
             }
             if (O.n_line_matches) O.n_line_matches[g] = match_lns ? s.h_nmln[f] : 0;
+            if ((s.h_status[1] & 8) && s.h_trunc[f]) w->n_trunc++;
             if (J.rgbd) {
                 const plf_batch_rgbd &R = J.R;
                 float *dst[4] = {R.uright_start, R.uright_end, R.depth_start, R.depth_end};
@@ -579,6 +584,7 @@ static int worker_extract(Worker *w)
 {
     const Job &J = w->job;
     w->t_total = w->t_stage = w->t_wait = w->t_unpack = 0;
+    w->n_trunc = 0;
     if (J.count <= 0) return PLF_OK;
     const auto t0 = clk::now();
     W_TRY(hipSetDevice(w->device));
@@ -783,6 +789,15 @@ extern "C" int plf_batch_extract_rgbd(plf_batch *b, const uint8_t *images, int64
         (void)plf_batch_shard(n_frames, nw, i, &J.first, &J.count);
     }
     return run_all(b, 1);
+}
+
+// frames of the last plf_batch_extract* call whose LSD region growing ran out of plf_line_params.max_ms (0 without a budget)
+extern "C" int64_t plf_batch_truncated_frames(const plf_batch *b)
+{
+    if (!b) return PLF_E_BADARG;
+    int64_t n = 0;
+    for (const Worker *w : b->workers) n += w->n_trunc;
+    return n;
 }
 
 extern "C" int plf_batch_last_timing(const plf_batch *b, double *out4)

@@ -19,9 +19,17 @@ __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
 __global__ void k_lsd_regions2(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int);
 __global__ void k_lsd_regions_lat(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
+// the same kernels with the time budget of plf_line_params.max_ms compiled in (separate instances: the default ones read no clock)
+__global__ void k_lsd_regions_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
+__global__ void k_lsd_regions2_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int);
+__global__ void k_lsd_regions_lat_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
+__global__ void k_lsd_spec_fused_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
+__global__ void k_lsd_spec_grow_budget(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
+__global__ void k_lsd_spec_commit_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
 __global__ void k_lsd_maxgrad(const float *, const double *, double *, LsdGeom);
 __global__ void k_lsd_seedkeys(const double *, const double *, uint32_t *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
+__global__ void k_lsd_count_used(const float *, int *, LsdGeom);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
 struct NfaCounts { int total, alg[6], pad; };
 struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
@@ -139,6 +147,9 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     while (g->sort_cap < rc) g->sort_cap <<= 1;
     g->sort_lds = g->sort_cap < 4096 ? g->sort_cap : 4096;
     g->nkeep = h->prm.nlines;
+    // time budget of the region stage (opt-in; the reference has none): milliseconds -> ticks of the 100 MHz wall clock the kernels read
+    g->budget_ticks = h->prm.max_ms > 0.f ? (unsigned)std::min((double)h->prm.max_ms * 1.0e5, 4.0e9) : 0u;
+    if (h->prm.max_ms > 0.f && g->budget_ticks == 0u) g->budget_ticks = 1u;
     return PLF_OK;
 }
 
@@ -214,6 +225,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     if (p->nlines < 1 || p->max_batch < 1 || p->max_width < 16 || p->max_height < 16) return PLF_E_BADARG;
     if (p->seed_order != 0 && p->seed_order != 1) return PLF_E_BADARG;
     if (p->lbd_sobel_input != PLF_LBD_BLURRED && p->lbd_sobel_input != PLF_LBD_RAW) return PLF_E_BADARG;
+    if (!(p->max_ms >= 0.f)) return PLF_E_BADARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fprintf(stderr, "[plf] no HIP device available: the line extractor has no CPU path\n");
@@ -277,7 +289,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lines, B * (size_t)cap * sizeof(plf_keyline));
     ALLOC(h->d_ldesc, B * (size_t)cap * 32);
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
-    ALLOC(h->d_counters, (4 * B + 16) * sizeof(int));
+    ALLOC(h->d_counters, (5 * B + 16) * sizeof(int));   // nrect[B], nseg[B], nout[B], status[16] + truncated[B], chain lengths[B]
     ALLOC(h->d_lgam, 65536 * sizeof(double));
     ALLOC(h->d_lbd, sizeof(LbdCoefs));
     ALLOC(h->d_ent[0], NP * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], NP * 5 * sizeof(NfaEntry));
@@ -306,6 +318,11 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_regions_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_grow_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_fused_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_lsd_lgamma_table, dim3(65536 / 256), dim3(256), 0, h->stream, h->d_lgam);
     if (hipMemcpy(h->d_lbd, &h->lbd, sizeof(LbdCoefs), hipMemcpyHostToDevice) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
@@ -348,6 +365,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (!h->prof_ev[2 * h->prof_n]) { (void)hipEventCreate(&h->prof_ev[2 * h->prof_n]); (void)hipEventCreate(&h->prof_ev[2 * h->prof_n + 1]); }
         (void)hipEventRecord(h->prof_ev[2 * h->prof_n], s);
     }
+    const bool budget = g.budget_ticks != 0u;
     const uint32_t *seeds = nullptr;
     if (h->prm.seed_order == 1) {   // published LSD order: bins descending, raster inside a bin
         std::vector<int> off(2 * (size_t)B);
@@ -430,24 +448,24 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(1024), 0, s, h->d_ang, g, h->spec);
         if (fused) {
-            hipLaunchKernelGGL(k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
+            hipLaunchKernelGGL(budget ? k_lsd_spec_fused_budget : k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
                                status, g, h->spec, h->d_spec_stats, B);
         } else {
-        hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
-        hipLaunchKernelGGL(k_lsd_spec_commit, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
+        hipLaunchKernelGGL(budget ? k_lsd_spec_grow_budget : k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
+        hipLaunchKernelGGL(budget ? k_lsd_spec_commit_budget : k_lsd_spec_commit, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
                            h->spec, h->d_spec_stats);
         }
     } else if (B <= lat_max)
-        hipLaunchKernelGGL(k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+        hipLaunchKernelGGL(budget ? k_lsd_regions_lat_budget : k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
     else if ((size_t)(g.rcap + 1) * 4 <= 5120) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
         const int wpg = getenv("PLF_LSD_WPG") ? max(1, min(16, atoi(getenv("PLF_LSD_WPG")))) : 8;
         const size_t wave_lds = 5120 + 1024;
-        hipLaunchKernelGGL(k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+        hipLaunchKernelGGL(budget ? k_lsd_regions2_budget : k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B);
     }
     else
-        hipLaunchKernelGGL(k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
+        hipLaunchKernelGGL(budget ? k_lsd_regions_budget : k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)
@@ -562,13 +580,27 @@ extern "C" int plf_line_last_status(plf_line *h, void *stream)
     int status = 0;
     PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
-    return (status & 4) ? PLF_E_HIP : (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : PLF_OK;
+    return (status & 4) ? PLF_E_HIP : (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : (status & 8) ? PLF_W_TRUNCATED : PLF_OK;
+}
+
+// which frames of the last batch ran out of their time budget (plf_line_params.max_ms): flags[f] = 1 / 0
+extern "C" int plf_line_truncated(plf_line *h, int32_t *flags, int32_t n)
+{
+    if (!h || !flags || n < 1 || n > h->last_frames) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->last_stream_set ? h->last_stream : h->stream;
+    PLF_HIP_TRY(hipMemcpyAsync(flags, h->d_counters + 3 * (size_t)h->prm.max_batch + 16, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    PLF_HIP_TRY(hipStreamSynchronize(s));
+    return PLF_OK;
 }
 
 // batch driver (batch_host.hip): the status word of the batch just enqueued on `s`, copied to pinned host memory in stream order
-int plf_line_status_async(plf_line *h, int32_t *host_dst, hipStream_t s)
+// (host_flags: per-frame "ran out of max_ms" flags of the same batch, n of them; only fetched for handles with a time budget)
+int plf_line_status_async(plf_line *h, int32_t *host_dst, int32_t *host_flags, int n, hipStream_t s)
 {
     PLF_HIP_TRY(hipMemcpyAsync(host_dst, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (host_flags && n > 0 && h->g.budget_ticks)
+        PLF_HIP_TRY(hipMemcpyAsync(host_flags, h->d_counters + 3 * (size_t)h->prm.max_batch + 16, sizeof(int) * n, hipMemcpyDeviceToHost, s));
     return PLF_OK;
 }
 
@@ -604,6 +636,20 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
         for (int b = 0; b < h->spec.nbands && b < 63; b++) fprintf(stderr, " b%d grow_end %d commit_start %d |", b, (tl[3 * b] - t0) / 100, (tl[3 * b + 1] - t0) / 100);
         fprintf(stderr, " commit_end %d\n", (tl[3 * 63 + 2] - t0) / 100);
     }
+    return PLF_OK;
+}
+
+// diagnostics (bench.py): length of each frame's region-growing chain in the last batch = pixels left marked USED (k_lsd_count_used; serial-chain
+// schedules only: the speculative schedule keeps its flags in LDS and reports 0)
+extern "C" int plf_line_chain_lengths(plf_line *h, int32_t *out, int32_t n)
+{
+    if (!h || !out || n < 1 || n > h->last_frames) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    int *d_out = h->d_counters + 4 * (size_t)h->prm.max_batch + 16;
+    hipLaunchKernelGGL(k_lsd_count_used, dim3(n), dim3(256), 0, h->stream, h->d_ang, d_out, h->g);
+    PLF_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    PLF_HIP_TRY(hipStreamSynchronize(h->stream));
     return PLF_OK;
 }
 

@@ -22,6 +22,7 @@ struct LsdGeom {
     int sort_cap;         // power of two >= rect_cap
     int sort_lds;         // sort keys k_lsd_finalize keeps in LDS (frames with more segments sort in a global scratch row)
     int nfa_pool;         // rectangles of the whole batch the NFA stage buffers hold (entries are compacted over the batch)
+    unsigned budget_ticks; // plf_line_params.max_ms in ticks of the 100 MHz wall clock (k_*_budget kernels only)
 };
 
 // banded speculative region growing: one record per effective seed of a band wave, and the buffers of both phases

@@ -261,6 +261,21 @@ __global__ void __launch_bounds__(256) k_lsd_seedkeys(const double *__restrict__
     keys_all[(size_t)f * g.s_stride + a] = ((uint32_t)(1023 - b) << 20) | (uint32_t)a;
 }
 
+// diagnostics (plf_line_chain_lengths): pixels of a frame that region growing left marked USED (sign bit of the angle word of a defined pixel) = the accept
+// steps of the frame's chain minus what refine / reduce_region_radius released again.  Counted after the fact so that the chain kernel carries no counter.
+__global__ void __launch_bounds__(256) k_lsd_count_used(const float *__restrict__ ang_all, int *__restrict__ out, LsdGeom g)
+{
+    __shared__ int red[256];
+    const int f = blockIdx.x, t = threadIdx.x, NP = g.sw * g.sh;
+    const uint32_t *ang = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
+    int c = 0;
+    for (int a = t; a < NP; a += 256) { const uint32_t w = ang[a]; c += (w >= 0x80000000u && w != __float_as_uint(NOTDEF_F)) ? 1 : 0; }
+    red[t] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    if (t == 0) out[f] = red[0];
+}
+
 // ------------------------------------------------------------------------------------------------
 // region growing (one wave per frame)
 // ------------------------------------------------------------------------------------------------
@@ -288,6 +303,8 @@ struct RegCtx {
     int use_bm;                // speculative mode: the USED flags live in an LDS bitmap (bm), the angle words are read-only
     LDS_PTR(uint32_t) bm;
     int regrow_n;              // size of the list refine() regrew (-1: it did not regrow)
+    unsigned long long t_dead; // time budget (plf_line_params.max_ms): wall_clock64() value after which the frame stops; 0 = no budget (a constant in every
+                               // kernel without the budget, so the test folds away)
 };
 
 #ifdef PLF_LSD_TIMING
@@ -618,6 +635,7 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
     const double radSq1 = distsq_d(xc, yc, rec.x1, rec.y1), radSq2 = distsq_d(xc, yc, rec.x2, rec.y2);
     double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
     while (density < density_th) {
+        if (C.t_dead && wall_clock64() > C.t_dead) return false;   // budgeted frames only: a pathological region can spend seconds in this loop
         radSq *= 0.75 * 0.75;
         const int m = n;
         if (m + (m >> 1) + 64 <= C.gcap) {
@@ -747,7 +765,9 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
 #ifndef PLF_REGIONS_PRIO
 #define PLF_REGIONS_PRIO 3
 #endif
-template <int LDSOFF, int FPW>
+// BUDGET (plf_line_params.max_ms > 0; separate kernel instances, the default ones carry no clock reads): the wave reads the 100 MHz clock before every seed
+// and, past the deadline, leaves the frame with the rectangles found so far -- status bit 8 (PLF_W_TRUNCATED), per-frame flag in status[16 + f]
+template <int LDSOFF, int FPW, bool BUDGET>
 __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                              const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                              uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
@@ -772,6 +792,8 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.rcap = g.rcap;
     C.gcap = (int)g.s_stride;
     C.use_bm = 0; C.bm = (LDS_PTR(uint32_t))smem; C.regrow_n = -1;
+    C.t_dead = BUDGET ? wall_clock64() + g.budget_ticks : 0ull;
+    bool truncated = false;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
     // This wave is one long dependent chain; waves of other kernels sharing its SIMD only ever delay it.
     // Raise its issue priority so that co-running throughput kernels (ORB, matchers, NFA) fill the idle slots instead.
@@ -805,6 +827,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
         C.cbase = seeds ? -0x40000000 : base;
         C.cused = 0ull;
         while (mask) {
+            if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
             const park_t sv = park[j];
             const int seed = __builtin_amdgcn_readfirstlane((int)sv.x);
@@ -841,6 +864,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
                 mask &= ~C.cused;
             }
         }
+        if (BUDGET && truncated) break;
     }
     } else
     for (int base = 0; base < NP; base += 64) {
@@ -856,6 +880,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
         C.cused = 0ull;
         unsigned long long mask = __ballot(ok);
         while (mask) {
+            if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
             const int seed = __builtin_amdgcn_readlane(px, j);
             const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(deg), j));
@@ -890,9 +915,11 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             }
             mask = __ballot(ok);
         }
+        if (BUDGET && truncated) break;
     }
     TOC(3, tall);
     if (lane == 0) nrect[f] = min(nr, g.rect_cap);
+    if (BUDGET && truncated && lane == 0) { atomicOr(status, 8); status[16 + f] = 1; }
 }
 
 __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
@@ -900,7 +927,14 @@ __global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all,
                                                     uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                     int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
 {
-    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
+    regions_body<0, 1, false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
+}
+__global__ void __launch_bounds__(64) k_lsd_regions_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                           const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
+                                                           uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
+                                                           int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
+{
+    regions_body<0, 1, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
 }
 
 #ifdef PLF_REGIONS_WPE   // experiment switch (tools/variant_build.sh): cap the VGPRs of the large-batch region kernel for N waves per SIMD
@@ -917,13 +951,21 @@ __global__ void PLF_REGIONS_OCC __launch_bounds__(1024) k_lsd_regions2(float *__
                                                       uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                       int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
 {
-    regions_body<-1, 0>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
+    regions_body<-1, 0, false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
+}
+__global__ void __launch_bounds__(1024) k_lsd_regions2_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                      const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
+                                                      uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
+                                                      int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
+{
+    regions_body<-1, 0, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
 }
 
 // Latency mode (a handful of frames in flight, e.g. the live SLAM loop): the chain of one frame is all there is to run, so its memory round
 // trips are the run time.  Wave 0 is the region wave (cos/sin fetched eagerly); waves 1..3 of the workgroup only pull the frame's angle and
 // increment maps into this XCD's L2 (they were written by k_lsd_pre on all XCDs, i.e. they sit in HBM / Infinity Cache), then leave.
-__global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+template <bool BUDGET>
+__device__ __forceinline__ void regions_lat_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                          const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                          uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
                                                          int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int *__restrict__ sink)
@@ -943,7 +985,22 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang
         if (acc == 0x9E3779B9u) *sink = (int)acc;   // keeps the loads alive
         return;
     }
-    regions_body<0, 1>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
+    regions_body<0, 1, BUDGET>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
+}
+
+__global__ void __launch_bounds__(256) k_lsd_regions_lat(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                         const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
+                                                         uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
+                                                         int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int *__restrict__ sink)
+{
+    regions_lat_body<false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, sink);
+}
+__global__ void __launch_bounds__(256) k_lsd_regions_lat_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
+                                                         const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
+                                                         uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
+                                                         int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int *__restrict__ sink)
+{
+    regions_lat_body<true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, sink);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -999,6 +1056,7 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
     C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
     C.cbase = -0x40000000; C.cused = 0ull;
+    C.t_dead = 0ull;
 }
 
 // rows of the bands: equal shares of the frame's defined pixels (the work of a band is roughly its number of accepted pixels),
@@ -1051,6 +1109,7 @@ __global__ void __launch_bounds__(1024) k_lsd_spec_bands(const float *__restrict
     }
 }
 
+template <bool BUDGET>
 __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                const float2 *__restrict__ cs0_all, const LsdGeom &g, const SpecBufs &SB)
 {
@@ -1064,6 +1123,8 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     const size_t fb = (size_t)f * SB.nbands + band;
     RegCtx C;
     spec_ctx(C, g, f, ang_all, modgrad_all, cs_all, cs0_all, SB.rxy + fb * g.s_stride, list, bm);
+    if (BUDGET) C.t_dead = wall_clock64() + g.budget_ticks;   // past it the band wave stops; what it has not grown is left to the commit wave, which stops as well
+    bool truncated = false;
     __builtin_amdgcn_s_setprio(3);
     uint32_t *tl = SB.tl + fb * SB.tcap;
     SpecRec *recs = SB.recs + fb * SB.rcap_rec;
@@ -1086,6 +1147,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
         if (ok) c0 = C.cs0[px];
         unsigned long long mask = __ballot(ok);
         while (mask) {
+            if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
             const int seed = base + j;
             const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(__uint_as_float(w)), j));
@@ -1123,7 +1185,9 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
             ok = ok && lane > j && w < 0x80000000u;
             mask = __ballot(ok);
         }
+        if (BUDGET && truncated) break;
     }
+    if (BUDGET && truncated) break;
     }
     if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; SB.cnt[fb * 4 + 3] = (int)(wall_clock64() & 0x7fffffff); }   // ([3]: 100 MHz timestamp, diagnostics)
     __threadfence();   // every lane's log entries are visible device-wide before the flag
@@ -1133,7 +1197,12 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
 __global__ void __launch_bounds__(64) k_lsd_spec_grow(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                       const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB)
 {
-    spec_grow_body(blockIdx.x, blockIdx.y, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
+    spec_grow_body<false>(blockIdx.x, blockIdx.y, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
+}
+__global__ void __launch_bounds__(64) k_lsd_spec_grow_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                             const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB)
+{
+    spec_grow_body<true>(blockIdx.x, blockIdx.y, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
 }
 
 __device__ __forceinline__ bool bm_get(LDS_PTR(uint32_t) b, int a) { return (b[a >> 5] >> (a & 31)) & 1u; }
@@ -1204,7 +1273,7 @@ __device__ __forceinline__ unsigned long long spec_readlane64(unsigned long long
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <bool SG>
+template <bool SG, bool BUDGET>
 __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                  const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
                                                  int *__restrict__ nrect, int *__restrict__ status, const LsdGeom &g, const SpecBufs &SB, int *__restrict__ stats)
@@ -1247,6 +1316,8 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     CBAR();
     RegCtx C;
     spec_ctx(C, g, f, ang_all, modgrad_all, cs_all, cs0_all, rxy_all + (size_t)f * g.s_stride, list, T);
+    if (BUDGET) C.t_dead = wall_clock64() + g.budget_ticks;
+    bool truncated = false;
     __builtin_amdgcn_s_setprio(3);
     LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
     uint32_t *tl2 = SB.tl2 + (size_t)f * 2 * g.s_stride;
@@ -1297,6 +1368,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         }
         unsigned long long visit = __ballot((defm | recmk) != 0ull);
         while (visit) {
+            if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int vc = __ffsll((long long)visit) - 1;
             visit &= visit - 1;
             const int base = tile + vc * 64;
@@ -1381,6 +1453,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                 todo &= ~((1ull << pos) - 1ull);
             }
             while (todo) {
+                if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const int seed = base + j;
@@ -1441,9 +1514,13 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     n_redo++;
                 }
             }
+            if (BUDGET && truncated) break;
         }
+        if (BUDGET && truncated) break;
         }   // tiles
+        if (BUDGET && truncated) break;
     }
+    if (BUDGET && truncated && lane == 0) { atomicOr(status, 8); status[16 + f] = 1; }
     if (stats && f == 0 && lane == 0) stats[8 + 3 * 63 + 2] = (int)(wall_clock64() & 0x7fffffff);   // end of the commit
     if (lane == 0) {
         nrect[f] = min(nr, g.rect_cap);
@@ -1458,25 +1535,46 @@ __global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang
                                                         const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
                                                         int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
 {
-    if (SB.s_global) spec_commit_body<true>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
-    else spec_commit_body<false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+    if (SB.s_global) spec_commit_body<true, false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+    else spec_commit_body<false, false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+}
+__global__ void __launch_bounds__(256) k_lsd_spec_commit_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                        const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                        int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
+{
+    if (SB.s_global) spec_commit_body<true, true>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+    else spec_commit_body<false, true>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
 }
 
 // Both phases in one launch (few frames): workgroups [0, B * nbands) are the band waves, the last B the commit waves.  Workgroups are dispatched in
 // index order, so every band wave is resident or finished before a commit wave starts waiting for it; the commit wave then follows the
 // bands as they finish (band 0 is the smallest, see k_lsd_spec_bands).
-__global__ void __launch_bounds__(256) k_lsd_spec_fused(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+template <bool BUDGET>
+__device__ __forceinline__ void spec_fused_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                        const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
                                                        int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats, int B)
 {
     const int L = blockIdx.x, nb = B * SB.nbands;
     if (L < nb) {
         if (threadIdx.x >= 64) return;
-        spec_grow_body(L % SB.nbands, L / SB.nbands, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
+        spec_grow_body<BUDGET>(L % SB.nbands, L / SB.nbands, ang_all, modgrad_all, cs_all, cs0_all, g, SB);
     } else {
-        if (SB.s_global) spec_commit_body<true>(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
-        else spec_commit_body<false>(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+        if (SB.s_global) spec_commit_body<true, BUDGET>(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
+        else spec_commit_body<false, BUDGET>(L - nb, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
     }
+}
+
+__global__ void __launch_bounds__(256) k_lsd_spec_fused(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                       const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                       int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats, int B)
+{
+    spec_fused_body<false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats, B);
+}
+__global__ void __launch_bounds__(256) k_lsd_spec_fused_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                       const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                       int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats, int B)
+{
+    spec_fused_body<true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats, B);
 }
 
 #ifdef PLF_LSD_TIMING

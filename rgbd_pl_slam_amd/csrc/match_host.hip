@@ -76,8 +76,11 @@ struct plf_matcher {
     FrameDev *h_frames;      // host copy of the frame table last uploaded (skips the upload + sync when unchanged)
     LineFrameDev *h_lframes;
     int h_nframes, h_nlframes;
-    plf_pose_pair *d_poses, *h_poses;   // per-frame poses of the batched last-frame search (device table + the host copy last uploaded)
-    int h_nposes;
+    // per-frame poses of the last-frame / keyframe searches: a ring of (pinned staging, device table, "kernels done" event) slots, so that a call whose
+    // poses changed -- every call of a tracking loop -- uploads them asynchronously on the caller's stream and never blocks the host (the
+    // single device table of round 2 needed two hipStreamSynchronize per change)
+    struct PoseSlot { plf_pose_pair *d, *h; hipEvent_t ev; bool used; } pose_ring[4];
+    int pose_next;
     hipStream_t last_stream;   // stream of the most recent call (matcher_stream)
     bool last_stream_set;
 };
@@ -95,10 +98,11 @@ static int matcher_stream(plf_matcher *h, void *stream, hipStream_t *out)
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_mad, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used, h->d_poses};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_mad, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &ps : h->pose_ring) { if (ps.d) (void)hipFree(ps.d); if (ps.h) (void)hipHostFree(ps.h); if (ps.ev) (void)hipEventDestroy(ps.ev); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    free(h->h_frames); free(h->h_lframes); free(h->h_poses);
+    free(h->h_frames); free(h->h_lframes);
 }
 
 extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t max_mappoints, int32_t max_lines, int32_t max_batch,
@@ -141,7 +145,11 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     }
     ALLOC(h->d_knn_idx, B * 2 * (size_t)max_lines * sizeof(int));
     ALLOC(h->d_knn_dist, B * 2 * (size_t)max_lines * sizeof(int));
-    ALLOC(h->d_poses, B * sizeof(plf_pose_pair));
+    for (auto &ps : h->pose_ring) {
+        ALLOC(ps.d, B * sizeof(plf_pose_pair));
+        if (hipHostMalloc((void **)&ps.h, B * sizeof(plf_pose_pair), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); matcher_free(h); free(h); return PLF_E_NOMEM; }
+    }
     ALLOC(h->d_dm, 2 * (size_t)max_lines * sizeof(plf_dmatch));
     ALLOC(h->d_mad, 2 * sizeof(double));
     // average of 64 cached candidates per map point; denser frames use the fallback kernel (PLF_MATCH_CAND_AVG: test hook)
@@ -154,8 +162,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
 #undef ALLOC
     h->h_frames = (FrameDev *)calloc(B, sizeof(FrameDev));
     h->h_lframes = (LineFrameDev *)calloc(B, sizeof(LineFrameDev));
-    h->h_poses = (plf_pose_pair *)calloc(B, sizeof(plf_pose_pair));
-    if (!h->h_frames || !h->h_lframes || !h->h_poses) { matcher_free(h); free(h); return PLF_E_NOMEM; }
+    if (!h->h_frames || !h->h_lframes) { matcher_free(h); free(h); return PLF_E_NOMEM; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { matcher_free(h); free(h); return PLF_E_HIP; }
     (void)hipFuncSetAttribute((const void *)k_mp_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_points_slow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -360,15 +367,14 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *frames, in
     }
     int rc = upload_frames(h, fd, s);
     if (rc != PLF_OK) return rc;
-    bool same = h->h_nposes == n_frames;
-    for (int f = 0; f < n_frames && same; f++) same = memcmp(&h->h_poses[f], &poses[(size_t)f * pose_step], sizeof(plf_pose_pair)) == 0;
-    if (!same) {
-        PLF_HIP_TRY(hipStreamSynchronize(s));
-        for (int f = 0; f < n_frames; f++) h->h_poses[f] = poses[(size_t)f * pose_step];
-        h->h_nposes = n_frames;
-        PLF_HIP_TRY(hipMemcpyAsync(h->d_poses, h->h_poses, sizeof(plf_pose_pair) * n_frames, hipMemcpyHostToDevice, s));
-        PLF_HIP_TRY(hipStreamSynchronize(s));
-    }
+    // poses: next slot of the ring (its previous user finished long ago in steady state: the wait is a formality), staged in pinned memory, uploaded in
+    // stream order -- the host does not wait
+    plf_matcher::PoseSlot &ps = h->pose_ring[h->pose_next];
+    h->pose_next = (h->pose_next + 1) % 4;
+    if (ps.used) PLF_HIP_TRY(hipEventSynchronize(ps.ev));
+    for (int f = 0; f < n_frames; f++) ps.h[f] = poses[(size_t)f * pose_step];
+    PLF_HIP_TRY(hipMemcpyAsync(ps.d, ps.h, sizeof(plf_pose_pair) * n_frames, hipMemcpyHostToDevice, s));
+    const plf_pose_pair *d_poses = ps.d;
     hipLaunchKernelGGL(k_build_grid, dim3(n_frames), dim3(256), 0, s, h->d_frames, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->max_kp);
     LastDev L;
     L.n = last->n; L.has_mp = last->has_mappoint; L.outlier = last->outlier; L.xw = last->world_pos; L.keys = last->keys; L.mp_desc = last->mp_desc;
@@ -381,13 +387,15 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *frames, in
     const bool fast = !RL.on && n_frames > 1 && maxn <= 65535 && last->n <= 65534 && last->n <= h->max_mp && last->n > 0 && lds_fast <= 150 * 1024;
     if (fast) {
         PLF_HIP_TRY(hipMemsetAsync(h->d_overflow, 0, 2 * (size_t)h->max_batch * sizeof(int), s));
-        hipLaunchKernelGGL(k_lf_candidates, dim3((last->n + 255) / 256, n_frames), dim3(256), 0, s, h->d_frames, L, h->d_poses, th, mono, match_of_kp, kp_stride,
+        hipLaunchKernelGGL(k_lf_candidates, dim3((last->n + 255) / 256, n_frames), dim3(256), 0, s, h->d_frames, L, d_poses, th, mono, match_of_kp, kp_stride,
                            h->d_done, h->d_cand, (int2 *)h->d_cand_off, h->cand_cap, h->max_mp, h->d_overflow, h->d_overflow + h->max_batch);
         hipLaunchKernelGGL(k_lf_rounds, dim3(n_frames), dim3(256), lds_fast, s, h->d_frames, L, check_orientation, match_of_kp, kp_stride, nmatches, h->d_done,
                            kp_cap, item_cap, h->d_cand, (const int2 *)h->d_cand_off, h->cand_cap, h->max_mp, h->d_overflow);
     }
-    hipLaunchKernelGGL(k_match_lastframe, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, L, h->d_poses, RL, th, mono, check_orientation, match_of_kp,
+    hipLaunchKernelGGL(k_match_lastframe, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, L, d_poses, RL, th, mono, check_orientation, match_of_kp,
                        kp_stride, nmatches, h->d_done, h->d_proj, kp_cap, h->max_kp, fast ? h->d_overflow : (const int *)nullptr);
+    PLF_HIP_TRY(hipEventRecord(ps.ev, s));
+    ps.used = true;
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

@@ -10,9 +10,10 @@ class LineSegment:
     """ExtractLineSegment(img, keylines, ldesc, lineFunctions, scale=1.2, numOctaves=1) -- include/ExtractLineSegment.h:38.
     `nlines` is the number of lines kept after the response sort (compile-time constant in the fork)."""
 
-    def __init__(self, nlines=100, max_width=640, max_height=480, max_batch=1, device=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED):
+    def __init__(self, nlines=100, max_width=640, max_height=480, max_batch=1, device=0, seed_order=0, lbd_sobel_input=L.LBD_BLURRED, max_ms=0.0):
+        """max_ms > 0: time budget of LSD region growing per call (plf_line_params.max_ms; an opt-in deviation from the reference, see include/plf.h)"""
         self._h = C.c_void_p()
-        p = L.line_params(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input)
+        p = L.line_params(nlines, seed_order, device, max_width, max_height, max_batch, lbd_sobel_input, max_ms)
         L.check(L.lib().plf_line_create(C.byref(p), C.byref(self._h)), "plf_line_create")
         self.nlines, self.max_batch = nlines, max_batch
 
@@ -87,6 +88,12 @@ class LineSegment:
         """status of the last extract_batch_device call (waits for the stream): 0, PLF_E_CAPACITY or PLF_E_RECTS"""
         return int(L.lib().plf_line_last_status(self._h, C.c_void_p(stream) if stream else None))
 
+    def truncated(self, n=1):
+        """flags of the first n frames of the last batch: 1 = the frame ran out of max_ms and holds only the segments found until then"""
+        out = np.zeros(n, np.int32)
+        L.check(L.lib().plf_line_truncated(self._h, L.vp(out), n), "plf_line_truncated")
+        return out
+
     def wait_front(self, stream):
         """make `stream` wait until the stages before region growing of the last enqueued batch are done"""
         L.check(L.lib().plf_line_wait_front(self._h, C.c_void_p(stream) if stream else None), "plf_line_wait_front")
@@ -96,6 +103,12 @@ class LineSegment:
         ms = C.c_double(0); n = C.c_int32(0)
         L.check(L.lib().plf_line_profile(self._h, int(enable), int(reset), C.byref(ms), C.byref(n)), "plf_line_profile")
         return ms.value, n.value
+
+    def chain_lengths(self, n):
+        """accept steps of the region-growing chain of the first n frames of the last batch (plf_line_chain_lengths)"""
+        out = np.zeros(n, np.int32)
+        L.check(L.lib().plf_line_chain_lengths(self._h, L.vp(out), n), "plf_line_chain_lengths")
+        return out
 
     def segments(self, frame=0):
         """test hook: all LSD segments of the last call in detection order"""

@@ -65,6 +65,29 @@ def synth_batch(seed0, n, w=640, h=480):
     return np.stack([synth_frame(seed0 + i, w, h) for i in range(n)])
 
 
+def _synth_job(args):
+    seed, w, h = args
+    return synth_frame(seed, w, h)
+
+
+def synth_batch_parallel(seed0, n, w=640, h=480, workers=0):
+    """synth_batch on a pool of worker processes (a VGA frame costs ~70 ms of numpy: a thousand distinct frames for bench.py would take a
+    minute on one core).  'spawn' start method: safe after the parent initialised HIP; falls back to the serial loop for small n."""
+    import os
+    if workers <= 0:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        workers = max(1, min(48, cores // 2, n // 8))
+    if workers <= 1 or n < 16:
+        return synth_batch(seed0, n, w, h)
+    import multiprocessing as mp
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            frames = pool.map(_synth_job, [(seed0 + i, w, h) for i in range(n)], chunksize=max(1, n // (4 * workers)))
+    except Exception:          # (no process pool available: sandboxed hosts)
+        return synth_batch(seed0, n, w, h)
+    return np.stack(frames)
+
+
 def texture_frame(seed, kind=None, size=None):
     """One of a dozen texture families for parity soaks (tools/soak.py) and tests: synthetic scene, + heavy noise, low / saturated contrast, coarse
     quantisation, flipped / transposed, pure noise, hard stripes, checkerboard, ramps with step edges, flat, framed scene.  `kind` (0..11) and

@@ -345,3 +345,62 @@ def test_lines_thousands_of_rectangles():
         assert kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"])
         assert np.allclose(eq, ref["eq"], rtol=0, atol=1e-9)
         ls.close()
+
+
+def _is_prefix(segs, ref_seg):
+    return len(segs) <= len(ref_seg) and np.array_equal(segs.view(np.uint32), ref_seg[:len(segs)].view(np.uint32))
+
+
+def test_time_budget_on_the_pathological_soak_frame():
+    """plf_line_params.max_ms (opt-in; the reference has no bound).  tools/soak.py seed 51591 -- hard three-level stripes -- keeps the serial LSD chain of ONE
+    VGA frame busy for ~40 s on the GPU (2.4-5 s in the CPU oracle): with a 30 ms budget the call returns at once, reports PLF_W_TRUNCATED, and what it
+    found is a prefix of the reference's segment list.  Without a budget the result is exact (checked on the same texture at 320x240 to keep the suite short)."""
+    _need_gpu()
+    import time
+    from rgbd_pl_slam_amd import LineSegment, _lib as L
+    from rgbd_pl_slam_amd.synth import texture_frame
+    img, _ = texture_frame(51591)
+    assert img.shape == (480, 640)
+    ls = LineSegment(nlines=100, max_ms=30.0)
+    ls.ExtractLineSegment(img)                       # first call: allocations of the speculative schedule
+    t0 = time.perf_counter()
+    kl, desc, eq = ls.ExtractLineSegment(img)
+    dt = time.perf_counter() - t0
+    assert dt < 1.5, "a 30 ms budget took %.2f s" % dt
+    assert ls.last_status() == L.PLF_W_TRUNCATED and int(ls.truncated(1)[0]) == 1
+    assert _is_prefix(ls.segments(0), orc.lsd_detect(img)["lines"])
+    ls.close()
+    small, _ = texture_frame(51591, size=(320, 240))
+    _check(small, 100)                               # no budget: exact, however long it takes
+
+
+def test_time_budget_leaves_a_prefix_and_is_invisible_when_not_spent():
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment, _lib as L
+    from rgbd_pl_slam_amd.synth import synth_frame
+    imgs = np.stack([synth_frame(9100 + i) for i in range(6)])
+    refs = [orc.lsd_detect(im)["lines"] for im in imgs]
+    # generous budget: nothing changes, nothing is reported
+    ls = LineSegment(nlines=100, max_ms=20000.0)
+    _check(imgs[0], 100, ext=ls)
+    assert ls.last_status() == 0 and int(ls.truncated(1)[0]) == 0
+    ls.close()
+    # one frame (speculative schedule, one launch): 1 ms is a fraction of its region stage
+    ls = LineSegment(nlines=100, max_ms=1.0)
+    ls.ExtractLineSegment(imgs[0]); ls.ExtractLineSegment(imgs[0])
+    segs = ls.segments(0)
+    assert ls.last_status() == L.PLF_W_TRUNCATED and _is_prefix(segs, refs[0]) and len(segs) < len(refs[0])
+    ls.close()
+    # batches: 40 frames (speculative schedule, band waves and commit waves stop on their own clocks) and 700 (one wave per frame)
+    for B, ms in ((40, 1.0), (700, 8.0)):
+        ls = LineSegment(nlines=100, max_batch=B, max_ms=ms)
+        batch = np.stack([imgs[i % 6] for i in range(B)])
+        ls.extract_batch(batch); res = ls.extract_batch(batch)
+        flags = ls.truncated(B)
+        assert ls.last_status() == L.PLF_W_TRUNCATED and flags.sum() > 0
+        for f in (0, 1, 5, B - 1):
+            segs = ls.segments(f)
+            assert _is_prefix(segs, refs[f % 6]), "batch %d frame %d" % (B, f)
+            if not flags[f]:
+                assert len(segs) == len(refs[f % 6])
+        ls.close()
