@@ -388,7 +388,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 24 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
     const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
-    const int coarse_words = (((g.sw + 7) >> 3) * ((g.sh + 7) >> 3) + 31) >> 5;
+    const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
     // commit wave: T and S in LDS when they fit, otherwise S in global memory
     const bool s_global = (size_t)(list_words + 2 * bm_words + coarse_words) * 4 + 64 > 150 * 1024;
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words) * 4 + 64;

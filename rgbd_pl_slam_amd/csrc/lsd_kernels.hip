@@ -1059,25 +1059,53 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.t_dead = 0ull;
 }
 
-// rows of the bands: equal shares of the frame's defined pixels (the work of a band is roughly its number of accepted pixels),
-// boundaries on multiples of 8 rows so that a coarse dirty tile belongs to one band
+// Rows of the bands.  A band wave grows its own rows AND the halo rows above them (unrecorded warm-up), so its run time follows the defined pixels of
+// [y0 - halo_rows, y1): the boundaries (any row, since round 3 -- multiples of 8 rows until then, which left bands of 8, 16 or 24 rows next to each other
+// when 24 bands share 383 rows: the slowest band wave, i.e. the whole launch, took up to 1.6x the mean) minimise the largest weighted band cost
+//     cost(b) = defined pixels in rows [max(0, y0_b - halo_rows), y1_b)   against the weight   w_b = 1 + stagger * b
+// (late bands may be longer: the commit wave reaches them later).  The minimum is found by bisection on the cost bound: the 64 lanes of wave 0 try 64 bounds
+// at once with a greedy sweep (binary searches in the prefix sums), twice.
+__device__ __forceinline__ int spec_band_sweep(const int *__restrict__ P, int rows, int nb, int halo, float stagger, float C, int *__restrict__ by_out)
+{
+    int a = 0;
+    for (int b = 0; b < nb; b++) {
+        const int base = b > 0 ? P[max(0, a - halo)] : 0;
+        const float lim = C * (1.f + stagger * (float)b) + (float)base;
+        const int emax = rows - (nb - 1 - b);          // every later band keeps at least one row
+        int lo = a + 1, hi = emax;                     // the band takes at least one row, whatever it costs
+        if (b == nb - 1) lo = hi = rows;
+        while (lo < hi) {                              // largest e in [lo, hi] with P[e] <= lim (P is non-decreasing); lo if none
+            const int mid = (lo + hi + 1) >> 1;
+            if ((float)P[mid] <= lim) lo = mid; else hi = mid - 1;
+        }
+        if (b == nb - 1 && (float)P[rows] > lim) return 0;   // the last band cannot absorb the rest within the bound
+        a = lo;
+        if (by_out) by_out[b + 1] = a;
+    }
+    return 1;
+}
+
 __global__ void __launch_bounds__(1024) k_lsd_spec_bands(const float *__restrict__ ang_all, LsdGeom g, SpecBufs SB)
 {
-    __shared__ int cnt[1024];
+    __shared__ int cnt[1024 + 1];
+    __shared__ int scan[2][1024];
     const int f = blockIdx.x, t = threadIdx.x, W = g.sw, H = g.sh;
     const uint32_t *ang = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
-    const int units = (H - 1 + 7) >> 3;   // 8-row units
-    for (int u = t; u < 1024; u += 1024) cnt[u] = 0;
+    const int rows = H - 1;
+    const int ru = (rows + 1023) / 1024;      // rows per counting unit: 1 up to 1024 rows
+    const int units = (rows + ru - 1) / ru;
+    cnt[t] = 0;
+    if (t == 0) cnt[1024] = 0;
     __syncthreads();
     if ((W & 3) == 0 && (g.s_stride & 3) == 0) {   // four pixels of one row per load, one LDS atomic per thread and step
         const uint4 *a4 = reinterpret_cast<const uint4 *>(ang);
-        for (int q = t; q < (W >> 2) * (H - 1); q += 1024) {
+        for (int q = t; q < (W >> 2) * rows; q += 1024) {
             const uint4 v = a4[q];
             const int c = (v.x < 0x80000000u) + (v.y < 0x80000000u) + (v.z < 0x80000000u) + (v.w < 0x80000000u);
-            if (c) atomicAdd(&cnt[min((q / (W >> 2)) >> 3, 1023)], c);
+            if (c) atomicAdd(&cnt[min((q / (W >> 2)) / ru, 1023)], c);
         }
     } else {
-        for (int a = t; a < W * (H - 1); a += 1024) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) >> 3, 1023)], 1);
+        for (int a = t; a < W * rows; a += 1024) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) / ru, 1023)], 1);
     }
     // bitmap of the defined pixels (the angle words are read-only in this mode): the commit wave walks it instead of the angle map
     {
@@ -1089,23 +1117,46 @@ __global__ void __launch_bounds__(1024) k_lsd_spec_bands(const float *__restrict
         }
     }
     __syncthreads();
+    // exclusive prefix sums over the units: P[u] = defined pixels in units [0, u)
+    int v = cnt[t];
+    scan[0][t] = v;
+    __syncthreads();
+    int cur = 0;
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int x = scan[cur][t] + (t >= o ? scan[cur][t - o] : 0);
+        scan[cur ^ 1][t] = x;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const int incl = scan[cur][t];
+    __syncthreads();
+    cnt[t + 1] = incl;        // cnt[] becomes P[0 .. 1024]
+    if (t == 0) cnt[0] = 0;
+    __syncthreads();
+    if (t >= 64) return;
+    const int nb = SB.nbands, halo_u = (SB.halo_rows + ru - 1) / ru;
+    const int total = cnt[units];
+    int *by = SB.band_y + f * (nb + 1);
+    // bound on the cost per unit weight: between 0 and the whole frame (plus halos) on the lightest band
+    float lo = 0.f, hi = (float)total + 1.f;
+    for (int pass = 0; pass < 2; pass++) {
+        const float C = lo + (hi - lo) * (float)(t + 1) / 64.f;
+        const int ok = units >= nb ? spec_band_sweep(cnt, units, nb, halo_u, SB.stagger, C, nullptr) : 0;
+        const unsigned long long m = __ballot(ok != 0);
+        if (!m) break;                                  // (cannot happen for hi = total + 1 with units >= nb)
+        const int first = __ffsll((long long)m) - 1;    // smallest feasible bound of this pass
+        const float nlo = lo + (hi - lo) * (float)first / 64.f, nhi = lo + (hi - lo) * (float)(first + 1) / 64.f;
+        lo = nlo; hi = nhi;
+    }
     if (t == 0) {
-        int total = 0;
-        for (int u = 0; u < units; u++) total += cnt[u];
-        int *by = SB.band_y + f * (SB.nbands + 1);
         by[0] = 0;
-        int acc = 0, u = 0;
-        for (int b = 1; b < SB.nbands; b++) {
-            // cumulative share of bands 0..b-1 with weights 1 + stagger * i
-            const float K = (float)SB.nbands, wsum = K + SB.stagger * K * (K - 1.f) * 0.5f, wcum = (float)b + SB.stagger * (float)b * (float)(b - 1) * 0.5f;
-            const long long target = (long long)((double)total * (double)(wcum / wsum));
-            while (u < units && acc + cnt[u] / 2 < target) acc += cnt[u++];
-            const int umin = (by[b - 1] >> 3) + 1;          // every band owns at least one unit
-            const int uu = min(max(u, umin), units - (SB.nbands - b));
-            by[b] = min(uu * 8, H - 1);
+        if (units >= nb && spec_band_sweep(cnt, units, nb, halo_u, SB.stagger, hi, by)) {
+            for (int b = 1; b <= nb; b++) by[b] = min(by[b] * ru, rows);
+        } else {   // fewer units than bands (the host excludes it) -- equal rows
+            for (int b = 1; b <= nb; b++) by[b] = (int)((long long)rows * b / nb);
         }
-        by[SB.nbands] = H - 1;
-        for (int b = 1; b <= SB.nbands; b++) by[b] = max(by[b], by[b - 1]);
+        by[nb] = rows;
+        for (int b = 1; b <= nb; b++) by[b] = max(by[b], by[b - 1]);
     }
 }
 
@@ -1310,7 +1361,9 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     // a pixel of the tile turns dirty, rebuilt per band).
     SpecS<SG> S;
     S.l = T + SB.bm_words; S.g = SB.sglob + (size_t)f * SB.bm_words;
-    const int ctx = (W + 7) >> 3, cty = (H + 7) >> 3, cwords = (ctx * cty + 31) >> 5;
+    // (a row of tiles starts on a word boundary: a record's bounding box is tested one tile ROW at a time -- one or two masked words -- instead of tile by
+    // tile; the dependent LDS reads of that test were most of the commit wave's "walking" time: a 200 x 100 pixel box is 325 tiles but 13 rows)
+    const int ctx = (((W + 7) >> 3) + 31) & ~31, cty = (H + 7) >> 3, cwords = (ctx >> 5) * cty;
     LDS_PTR(uint32_t) Dc = T + (SG ? 1 : 2) * SB.bm_words;
     for (int i = lane; i < SB.bm_words; i += 64) T[i] = 0u;
     CBAR();
@@ -1393,8 +1446,17 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     const SpecRec *r = &recs[ri + lane];
                     h_t0 = r->t0; h_nt = r->nt; h_rect = r->has_rect;
                     const int tx0 = r->bx0 >> 3, tx1 = r->bx1 >> 3, ty0 = r->by0 >> 3, ty1 = r->by1 >> 3;
-                    for (int ty = ty0; ty <= ty1 && clean; ty++)
-                        for (int tx = tx0; tx <= tx1; tx++) { const int t = ty * ctx + tx; if ((Dc[t >> 5] >> (t & 31)) & 1u) { clean = false; break; } }
+                    const int w0 = tx0 >> 5, w1 = tx1 >> 5;
+                    const uint32_t m0 = 0xFFFFFFFFu << (tx0 & 31), m1 = 0xFFFFFFFFu >> (31 - (tx1 & 31));
+                    for (int ty = ty0; ty <= ty1 && clean; ty++) {
+                        LDS_PTR(uint32_t) row = Dc + ty * (ctx >> 5);
+                        for (int wq = w0; wq <= w1; wq++) {
+                            uint32_t bits = row[wq];
+                            if (wq == w0) bits &= m0;
+                            if (wq == w1) bits &= m1;
+                            if (bits) { clean = false; break; }
+                        }
+                    }
                 }
                 const unsigned long long dirtym = __ballot(!clean);
                 const int t_begin = __builtin_amdgcn_readlane(h_t0, 0);

@@ -1,0 +1,36 @@
+"""single-frame LSD+LBD latency and the speculation timeline for a few band / halo settings (env hooks are read per call)
+    python tools/spec_probe.py"""
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import rgbd_pl_slam_amd._lib as L
+from rgbd_pl_slam_amd import LineSegment
+from rgbd_pl_slam_amd.synth import synth_frame
+imgs = [synth_frame(200 + i) for i in range(6)]
+
+
+def lat(ls, reps=3):
+    ts = []
+    for im in imgs:
+        ls.ExtractLineSegment(im)
+        t = time.perf_counter()
+        for _ in range(reps): ls.ExtractLineSegment(im)
+        ts.append((time.perf_counter() - t) / reps * 1e3)
+    return np.mean(ts), min(ts), max(ts)
+
+
+for bands, halo in ((24, 16), (24, 8), (24, 0), (32, 16), (32, 8), (48, 8), (48, 0), (16, 16), (12, 16)):
+    os.environ["PLF_LSD_SPEC_BANDS"] = str(bands); os.environ["PLF_LSD_SPEC_HALO"] = str(halo)
+    ls = LineSegment(nlines=100)
+    m = lat(ls)
+    st = (C.c_int32 * 8)()
+    L.lib().plf_line_debug_spec_stats(ls._h, st)
+    print("bands %2d halo %2d: %.2f ms (min %.2f max %.2f) | last frame: commit %d redo %d fast %d slow %d kcyc redo %d val %d total %d setup %d" % ((bands, halo) + m + tuple(st)), flush=True)
+    ls.close()
+os.environ["PLF_LSD_SPEC_BANDS"] = "24"; os.environ["PLF_LSD_SPEC_HALO"] = "16"; os.environ["PLF_LSD_SPEC_TIMELINE"] = "1"
+ls = LineSegment(nlines=100)
+for im in imgs[:2]:
+    ls.ExtractLineSegment(im); ls.ExtractLineSegment(im)
+    st = (C.c_int32 * 8)()
+    L.lib().plf_line_debug_spec_stats(ls._h, st)
+ls.close()

@@ -57,6 +57,82 @@ K32(k_cndmask_b32, A_CNDMASK)
 K32(k_lshl_add_u32, A_LSHLADD)
 K32(k_sad_u8, A_SAD)
 
+#define A_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define A_LSHL(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define A_MIN(i) "v_min_u32 %" #i ", %" #i ", %8\n"
+#define A_MUL24(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
+#define A_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define A_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define A_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 3, 9\n"
+#define A_MOV(i) "v_mov_b32 %" #i ", %8\n"
+#define A_ADDF(i) "v_add_f32 %" #i ", %" #i ", %8\n"
+#define A_MULF(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define A_EXPF(i) "v_exp_f32 %" #i ", %" #i "\n"
+#define A_RCPF(i) "v_rcp_f32 %" #i ", %" #i "\n"
+#define A_CVTFU(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+#define A_CMP(i) "v_cmp_lt_u32 vcc, %" #i ", %8\n"
+K32(k_and_b32, A_AND)
+K32(k_lshlrev_b32, A_LSHL)
+K32(k_min_u32, A_MIN)
+K32(k_mul_u32_u24, A_MUL24)
+K32(k_mad_u32_u24, A_MAD24)
+K32(k_add3_u32, A_ADD3)
+K32(k_bfe_u32, A_BFE)
+K32(k_mov_b32, A_MOV)
+K32(k_add_f32, A_ADDF)
+K32(k_mul_f32, A_MULF)
+K32(k_exp_f32, A_EXPF)
+K32(k_rcp_f32, A_RCPF)
+K32(k_cvt_f32_u32, A_CVTFU)
+K32(k_cmp_lt_u32, A_CMP)
+
+// VALU instructions with a SCALAR source (the compiler feeds wave-uniform values to VALU instructions this way all the time) and the select on a mask
+#define KS32(NAME, ASM)                                                                                    \
+    __global__ void __launch_bounds__(1024) NAME(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk) \
+    {                                                                                                      \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        unsigned long long m = __ballot((threadIdx.x & 1) != 0);                                           \
+        const unsigned long long t0 = clock64(), w0 = wall_clock64();                                      \
+        for (int i = 0; i < iters; i++) {                                                                  \
+            asm volatile(BODY64(ASM) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "s"(m), "v"(c) : "vcc"); \
+        }                                                                                                  \
+        const unsigned long long t1 = clock64(), w1 = wall_clock64();                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }                   \
+        if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = a0;                              \
+    }
+#define A_ADD_S(i) "v_add_u32 %" #i ", %8, %" #i "\n"
+#define A_XOR_S(i) "v_xor_b32 %" #i ", %8, %" #i "\n"
+#define A_FMA_S(i) "v_fma_f32 %" #i ", %" #i ", %8, %10\n"
+#define A_CND_S(i) "v_cndmask_b32 %" #i ", %" #i ", %10, %9\n"
+#define A_CND_VCC(i) "v_cndmask_b32 %" #i ", %" #i ", %10, vcc\n"
+#define A_RDL(i) "v_readlane_b32 s20, %" #i ", 3\n"
+KS32(k_add_u32_sgpr, A_ADD_S)
+KS32(k_xor_b32_sgpr, A_XOR_S)
+KS32(k_fma_f32_sgpr, A_FMA_S)
+KS32(k_cndmask_sgprmask, A_CND_S)
+__global__ void __launch_bounds__(1024) k_cndmask_vcc_init(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; i++) {
+        asm volatile("s_mov_b64 vcc, 0x5555\n" BODY64(A_CND_VCC) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "s"(b), "v"(c) : "vcc");
+    }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = a0;
+}
+__global__ void __launch_bounds__(1024) k_readlane_b32(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; i++) {
+        asm volatile(BODY64(A_RDL) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "s"(b), "v"(c) : "s20");
+    }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = a0;
+}
+
 // 64-bit classes: accumulators are VGPR pairs
 #define K64(NAME, ASM)                                                                                     \
     __global__ void __launch_bounds__(1024) NAME(uint32_t *out, int iters, double b, double c, unsigned long long *clk)     \
@@ -77,6 +153,13 @@ K64(k_add_f64, A_ADD64)
 K64(k_fma_f64, A_FMA64)
 K64(k_mul_f64, A_MUL64)
 K64(k_pk_fma_f32, A_PKFMA32)
+#define A_ADD64S(i) "v_add_f64 %" #i ", %" #i ", 1.0\n"
+#define A_RCP64(i) "v_rcp_f64 %" #i ", %" #i "\n"
+#define A_SQRT64(i) "v_sqrt_f64 %" #i ", %" #i "\n"
+#define A_CVT64(i) "v_cvt_f32_f64 %" #i ", %" #i "\n"
+K64(k_add_f64_const, A_ADD64S)
+K64(k_rcp_f64, A_RCP64)
+K64(k_sqrt_f64, A_SQRT64)
 
 // scalar ALU for comparison (the region chain is ~45 % SALU): 8 independent SGPR accumulators
 __global__ void __launch_bounds__(1024) k_s_add_u32(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk)
@@ -109,6 +192,15 @@ int main()
         {"v_dot4_u32_u8", (void *)k_dot4_u32_u8, false}, {"v_sad_u8", (void *)k_sad_u8, false}, {"v_mul_lo_u32", (void *)k_mul_lo_u32, false},
         {"v_fma_f32", (void *)k_fma_f32, false}, {"v_pk_fma_f32", (void *)k_pk_fma_f32, true}, {"v_add_f64", (void *)k_add_f64, true},
         {"v_mul_f64", (void *)k_mul_f64, true}, {"v_fma_f64", (void *)k_fma_f64, true}, {"s_add_u32", (void *)k_s_add_u32, false},
+        {"v_and_b32", (void *)k_and_b32, false}, {"v_lshlrev_b32", (void *)k_lshlrev_b32, false}, {"v_min_u32", (void *)k_min_u32, false},
+        {"v_mul_u32_u24", (void *)k_mul_u32_u24, false}, {"v_mad_u32_u24", (void *)k_mad_u32_u24, false}, {"v_add3_u32", (void *)k_add3_u32, false},
+        {"v_bfe_u32", (void *)k_bfe_u32, false}, {"v_mov_b32", (void *)k_mov_b32, false}, {"v_add_f32", (void *)k_add_f32, false},
+        {"v_mul_f32", (void *)k_mul_f32, false}, {"v_exp_f32", (void *)k_exp_f32, false}, {"v_rcp_f32", (void *)k_rcp_f32, false},
+        {"v_cvt_f32_u32", (void *)k_cvt_f32_u32, false}, {"v_cmp_lt_u32 (vcc)", (void *)k_cmp_lt_u32, false},
+        {"v_add_u32 (sgpr src)", (void *)k_add_u32_sgpr, false}, {"v_xor_b32 (sgpr src)", (void *)k_xor_b32_sgpr, false},
+        {"v_fma_f32 (sgpr src)", (void *)k_fma_f32_sgpr, false}, {"v_cndmask_b32 (sgpr-pair mask)", (void *)k_cndmask_sgprmask, false},
+        {"v_cndmask_b32 (vcc set once per 64)", (void *)k_cndmask_vcc_init, false}, {"v_readlane_b32", (void *)k_readlane_b32, false},
+        {"v_add_f64 (inline const)", (void *)k_add_f64_const, true}, {"v_rcp_f64", (void *)k_rcp_f64, true}, {"v_sqrt_f64", (void *)k_sqrt_f64, true},
     };
     const int waves_per_simd[] = {1, 2, 4, 8};
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"simds\": %d, \"clock_rate_khz\": %d,\n", P.name, P.gcnArchName, cus, simds, P.clockRate);
