@@ -390,8 +390,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
     // commit wave: T and S in LDS when they fit, otherwise S in global memory
-    const bool s_global = (size_t)(list_words + 2 * bm_words + coarse_words) * 4 + 64 > 150 * 1024;
-    const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words) * 4 + 64;
+    const bool s_global = (size_t)(list_words + 2 * bm_words + coarse_words + 5 * 512 + 512 / 32 + 1024 + 33) * 4 + 64 > 150 * 1024;
+    const int commit_extra = 5 * 512 + 512 / 32 + 1024 + 1 + 16 + 16;   // SPEC_COMMIT_EXTRA_WORDS of lsd_kernels.hip (+ the 16-word alignment of the tile map): record headers, SUSPECT mask, "defined, no record" bits
+    const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words + commit_extra) * 4 + 64;
     bool spec = !seeds && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     if (spec) {   // scratch of the speculation: ~23 MB per VGA frame, ~65 MB per 1280x960 frame; keep it below 8 GiB
         size_t Fr = 8;

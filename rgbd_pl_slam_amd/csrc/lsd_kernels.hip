@@ -1324,6 +1324,9 @@ __device__ __forceinline__ unsigned long long spec_readlane64(unsigned long long
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#define SPEC_HCAP 512    // record headers of a commit segment held in LDS
+#define SPEC_NRW 1024    // words (32 pixels each) of a commit segment
+#define SPEC_COMMIT_EXTRA_WORDS (5 * SPEC_HCAP + SPEC_HCAP / 32 + SPEC_NRW + 1 + 16)   // line_host.hip sizes the dynamic LDS with the same expression
 template <bool SG, bool BUDGET>
 __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                  const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
@@ -1365,6 +1368,15 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     // tile; the dependent LDS reads of that test were most of the commit wave's "walking" time: a 200 x 100 pixel box is 325 tiles but 13 rows)
     const int ctx = (((W + 7) >> 3) + 31) & ~31, cty = (H + 7) >> 3, cwords = (ctx >> 5) * cty;
     LDS_PTR(uint32_t) Dc = T + (SG ? 1 : 2) * SB.bm_words;
+    // record headers of the segment being committed (seed, first log entry, log entries | has_rect << 31, dilated bounding box), its SUSPECT mask, and the
+    // "defined, no record" bits of the segment's pixels
+    LDS_PTR(uint32_t) Hseed = Dc + ((cwords + 15) & ~15);
+    LDS_PTR(uint32_t) Ht0 = Hseed + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hnt = Ht0 + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hb0 = Hnt + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hb1 = Hb0 + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hsus = Hb1 + SPEC_HCAP;
+    LDS_PTR(uint32_t) NR = Hsus + SPEC_HCAP / 32;
     for (int i = lane; i < SB.bm_words; i += 64) T[i] = 0u;
     CBAR();
     RegCtx C;
@@ -1404,133 +1416,146 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         }
         CBAR();
         c_setup += clock64() - c_s0;
-        int ri = 0;
-        // The band is walked in tiles of 64 chunks of 64 pixels.  Lane i first fetches the defined-pixel bits (k_lsd_spec_bands) and the record-seed
-        // bits of chunk i -- plain bitmap words, so the walk has no dependent global load per chunk -- and only chunks that hold a record or a
-        // defined pixel are visited (whether those pixels are still free is looked up in T when the chunk's turn comes).
-        const int p_hi = y1 * W;
-        for (int tile = y0 * W; tile < p_hi; tile += 64 * 64) {
-        unsigned long long defm = 0ull, recmk = 0ull;
-        {
-            const int cb = tile + lane * 64;
-            if (cb < p_hi) {
-                defm = spec_bits64(defmap, cb, SB.bm_words);
-                if (use_recs) recmk = spec_bits64(seedmap, cb, SB.bm_words);
-                if (p_hi - cb < 64) { const unsigned long long mk = (1ull << (p_hi - cb)) - 1ull; defm &= mk; recmk &= mk; }
+        // ---- The band's records are committed EVENT BY EVENT, not pixel by pixel (round 3; the chunk walk of round 2 paid two or three dependent
+        // global round trips -- record headers, accepted-pixel log, rectangle -- for each of ~1800 chunks of a frame: ~4 ms, more than the band waves take).
+        // A segment = up to SPEC_HCAP consecutive records and SPEC_NRW words of pixels.  Its record headers are loaded into LDS at once.  A record
+        // whose dilated bounding box is clear of dirty tiles is CLEAN: every flag it read had the true value, it stands (the tile map only grows inside
+        // a band, and every change is followed by a re-scan of the records still to come).  Runs of CLEAN records are committed in bulk: their marks are
+        // one contiguous range of the accepted-pixel log, streamed with independent loads.  Only three things are events, handled in raster order:
+        //   * a SUSPECT record (box touches a dirty tile): checked pixel by pixel; it stands, or its marks stay in S only and its seed -- if free in T --
+        //     is regrown on T;
+        //   * a CANDIDATE pixel: defined, no record, marked in S, free in T -- speculation skipped it because something it believed in took it; it is
+        //     grown on T once every record before it is committed and it is still free;
+        //   * (a band whose log overflowed has no records: every defined pixel that is free in T when its turn comes is a candidate.)
+        // The result is the walk's, statement for statement: same validity rule, same order of rectangles.
+        const int p_end = y1 * W;
+        const int nrec_band = use_recs ? SB.cnt[fb * 4 + 0] : 0;
+        int r_lo = 0, p_lo = y0 * W;
+        while (p_lo < p_end) {
+            // ---- segment [p_lo, p_hi) x records [r_lo, r_hi)
+            const int nh = min(SPEC_HCAP, nrec_band - r_lo);
+            for (int i = lane; i < nh; i += 64) {
+                const int4 *hp = reinterpret_cast<const int4 *>(&recs[r_lo + i]);
+                const int4 h0 = hp[0], h1 = hp[1];     // seed, t0, nt, has_rect | bx0, by0, bx1, by1
+                Hseed[i] = (uint32_t)h0.x; Ht0[i] = (uint32_t)h0.y; Hnt[i] = (uint32_t)h0.z | (h0.w ? 0x80000000u : 0u);
+                Hb0[i] = (uint32_t)h1.x | ((uint32_t)h1.y << 16); Hb1[i] = (uint32_t)h1.z | ((uint32_t)h1.w << 16);
             }
-        }
-        unsigned long long visit = __ballot((defm | recmk) != 0ull);
-        while (visit) {
-            if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
-            const int vc = __ffsll((long long)visit) - 1;
-            visit &= visit - 1;
-            const int base = tile + vc * 64;
-            const int px = base + lane;
-            const bool inb = px < p_hi;
-            const unsigned long long defc = spec_readlane64(defm, vc), recm = spec_readlane64(recmk, vc);
-            const bool defined = (defc >> lane) & 1ull, isrec = (recm >> lane) & 1ull;
-            unsigned long long todo = recm | __ballot(defined && !bm_get(T, px));
-            if (!todo) continue;   // nothing recorded here and every defined pixel already taken
-            // fast path: no dirty pixel in the chunk that could become a seed of its own, and every record of the chunk stays clear of the
-            // dirty tiles -> all of them stand; their marks (one contiguous range of the accepted-pixel log) and rectangles are copied at once
-            const bool seedless = !__ballot(inb && defined && !isrec && !bm_get(T, px) && S.get(px));   // (a dirty pixel that is used in T cannot seed anything)
-            // Chunk-at-a-time path (no dirty pixel of the chunk can become a seed of its own): lane i holds the header of the chunk's i-th record.
-            // Records clear of the dirty tiles stand as they are; the others are checked pixel by pixel, all at once (their accepted-pixel logs are
-            // one contiguous range).  Everything before the first record that fails is committed in bulk; the rest of the chunk goes through the
-            // one-at-a-time loop below.
-            if (recm && seedless) {
-                const int cnt = __popcll(recm);
-                bool clean = true;
-                int h_t0 = 0, h_nt = 0, h_rect = 0;
-                if (lane < cnt) {
-                    const SpecRec *r = &recs[ri + lane];
-                    h_t0 = r->t0; h_nt = r->nt; h_rect = r->has_rect;
-                    const int tx0 = r->bx0 >> 3, tx1 = r->bx1 >> 3, ty0 = r->by0 >> 3, ty1 = r->by1 >> 3;
-                    const int w0 = tx0 >> 5, w1 = tx1 >> 5;
-                    const uint32_t m0 = 0xFFFFFFFFu << (tx0 & 31), m1 = 0xFFFFFFFFu >> (31 - (tx1 & 31));
-                    for (int ty = ty0; ty <= ty1 && clean; ty++) {
-                        LDS_PTR(uint32_t) row = Dc + ty * (ctx >> 5);
-                        for (int wq = w0; wq <= w1; wq++) {
-                            uint32_t bits = row[wq];
-                            if (wq == w0) bits &= m0;
-                            if (wq == w1) bits &= m1;
-                            if (bits) { clean = false; break; }
-                        }
-                    }
-                }
-                const unsigned long long dirtym = __ballot(!clean);
-                const int t_begin = __builtin_amdgcn_readlane(h_t0, 0);
-                const int t_end = __builtin_amdgcn_readlane(h_t0, cnt - 1) + __builtin_amdgcn_readlane(h_nt, cnt - 1);
-                int first_bad = cnt;
-                if (dirtym) {
-                    const long long c_v0 = clock64();
-                    const int kd = __ffsll((long long)dirtym) - 1;
-                    for (int i0 = __builtin_amdgcn_readlane(h_t0, kd); i0 < t_end && first_bad == cnt; i0 += 64) {
-                        const int i = i0 + lane;
-                        int myk = 64;
-                        if (i < t_end) {
-                            int k = 0;
-                            for (int c = 1; c < cnt; c++) k += (i >= __builtin_amdgcn_readlane(h_t0, c)) ? 1 : 0;
-                            if ((dirtym >> k) & 1ull) {
-                                const int q = (int)(tl[i] & 0x3FFFFFFFu), qx = q % W, qy = q / W;
-                                bool hit = false;
-                                for (int dy = -1; dy <= 1; dy++) {
-                                    const int yy = qy + dy;
-                                    if (yy < 0 || yy >= H) continue;
-                                    for (int dx = -1; dx <= 1; dx++) {
-                                        const int xx = qx + dx;
-                                        if (xx < 0 || xx >= W) continue;
-                                        hit |= bm_get(T, yy * W + xx) != S.get(yy * W + xx);
-                                    }
-                                }
-                                if (hit) myk = k;
+            int p_hi = min(p_end, ((p_lo >> 5) + SPEC_NRW) << 5);
+            if (r_lo + nh < nrec_band) p_hi = min(p_hi, recs[r_lo + nh].seed);      // the first record that did not fit bounds the segment
+            CBAR();
+            int nseg = nh;                                    // records of the segment: those with seed < p_hi
+            for (int base = 0; base < nh; base += 64) {
+                const unsigned long long m = __ballot(base + lane < nh && (int)Hseed[base + lane] >= p_hi);
+                if (m) { nseg = base + __ffsll((long long)m) - 1; break; }
+            }
+            const int w_lo = p_lo >> 5, nw = ((p_hi + 31) >> 5) - w_lo;
+            for (int i = lane; i < nw; i += 64) NR[i] = defmap[w_lo + i] & ~(use_recs ? seedmap[w_lo + i] : 0u);
+            for (int i = lane; i < SPEC_HCAP / 32; i += 64) Hsus[i] = 0u;
+            CBAR();
+            bool rescan = true;                               // classify the records against the tile map
+            int cur = 0, pos = p_lo;                          // next record of the segment, next pixel position
+            for (;;) {
+                if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
+                if (rescan) {
+                    for (int i = cur + lane; i < nseg; i += 64) {
+                        const uint32_t b0 = Hb0[i], b1 = Hb1[i];
+                        const int tx0 = (int)(b0 & 0xFFFFu) >> 3, ty0 = (int)(b0 >> 16) >> 3, tx1 = (int)(b1 & 0xFFFFu) >> 3, ty1 = (int)(b1 >> 16) >> 3;
+                        const int w0 = tx0 >> 5, w1 = tx1 >> 5;
+                        const uint32_t m0 = 0xFFFFFFFFu << (tx0 & 31), m1 = 0xFFFFFFFFu >> (31 - (tx1 & 31));
+                        bool clean = true;
+                        for (int ty = ty0; ty <= ty1 && clean; ty++) {
+                            LDS_PTR(uint32_t) row = Dc + ty * (ctx >> 5);
+                            for (int wq = w0; wq <= w1; wq++) {
+                                uint32_t bits = row[wq];
+                                if (wq == w0) bits &= m0;
+                                if (wq == w1) bits &= m1;
+                                if (bits) { clean = false; break; }
                             }
                         }
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) myk = min(myk, __shfl_xor(myk, o, 64));
-                        if (myk < 64) first_bad = myk;
+                        if (!clean) __hip_atomic_fetch_or(&Hsus[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    c_val += clock64() - c_v0;
-                    n_slow += __popcll(dirtym);
+                    CBAR();
+                    rescan = false;
                 }
-                if (first_bad > 0) {
-                    const int t_stop = first_bad < cnt ? __builtin_amdgcn_readlane(h_t0, first_bad) : t_end;
-                    for (int i = t_begin + lane; i < t_stop; i += 64) { const uint32_t e = tl[i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); } }
-                    const unsigned long long rm = __ballot(h_rect != 0 && lane < first_bad);
-                    if (h_rect && lane < first_bad) {
-                        const int slot = nr + __popcll(rm & ((1ull << lane) - 1ull));
-                        if (slot < g.rect_cap) rects[slot] = recs[ri + lane].rec; else atomicOr(status, 1);
+                // next SUSPECT record at or after cur
+                int rs = nseg;
+                {
+                    uint32_t wv = 0u;
+                    if (lane < SPEC_HCAP / 32 && lane >= (cur >> 5)) { wv = Hsus[lane]; if (lane == (cur >> 5)) wv &= 0xFFFFFFFFu << (cur & 31); }
+                    const unsigned long long m = __ballot(wv != 0u);
+                    if (m) {
+                        const int l0 = __ffsll((long long)m) - 1;
+                        rs = min(nseg, l0 * 32 + __ffs((int)__builtin_amdgcn_readlane((int)wv, l0)) - 1);
                     }
-                    nr += __popcll(rm);
-                    n_commit += first_bad;
-                    n_fast++;
-                    ri += first_bad;
+                }
+                const int ps = rs < nseg ? (int)Hseed[rs] : p_hi;
+                // first CANDIDATE pixel in [pos, ps)
+                int pc = -1;
+                for (int wb = (pos >> 5); wb <= ((ps - 1) >> 5) && pos < ps; wb += 64) {
+                    const int wq = wb + lane;
+                    uint32_t bits = 0u;
+                    if (wq <= ((ps - 1) >> 5)) {
+                        bits = NR[wq - w_lo] & ~T[wq];
+                        if (use_recs) bits &= S.word(wq);
+                        if (wq == (pos >> 5)) bits &= 0xFFFFFFFFu << (pos & 31);
+                        if (wq == ((ps - 1) >> 5) && (ps & 31)) bits &= 0xFFFFFFFFu >> (32 - (ps & 31));
+                    }
+                    const unsigned long long m = __ballot(bits != 0u);
+                    if (m) {
+                        const int l0 = __ffsll((long long)m) - 1;
+                        pc = (wb + l0) * 32 + __ffs((int)__builtin_amdgcn_readlane((int)bits, l0)) - 1;
+                        break;
+                    }
+                }
+                // the CLEAN records before the event stand: commit them in bulk
+                int rk = rs;                                  // first record NOT committed now
+                if (pc >= 0) {
+                    rk = cur;
+                    for (int base = cur; base < rs; base += 64) {
+                        const unsigned long long m = __ballot(base + lane >= rs || (int)Hseed[min(base + lane, SPEC_HCAP - 1)] > pc);
+                        if (m) { rk = min(rs, base + __ffsll((long long)m) - 1); break; }
+                        rk = min(rs, base + 64);
+                    }
+                }
+                if (rk > cur) {
+                    const int t_begin = (int)Ht0[cur], t_stop = (int)Ht0[rk - 1] + (int)(Hnt[rk - 1] & 0x7FFFFFFFu);
+                    for (int i0 = t_begin; i0 < t_stop; i0 += 256) {          // four independent loads per lane in flight
+                        uint32_t e[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int i = i0 + u * 64 + lane; e[u] = i < t_stop ? tl[i] : 0u; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (e[u] & 0x40000000u) { bm_set(T, (int)(e[u] & 0x3FFFFFFFu)); S.set((int)(e[u] & 0x3FFFFFFFu)); }
+                    }
+                    for (int base = cur; base < rk; base += 64) {
+                        const int i = base + lane;
+                        const bool hr = i < rk && (Hnt[min(i, SPEC_HCAP - 1)] & 0x80000000u);
+                        const unsigned long long rm = __ballot(hr);
+                        if (hr) {
+                            const int slot = nr + __popcll(rm & ((1ull << lane) - 1ull));
+                            if (slot < g.rect_cap) rects[slot] = recs[r_lo + i].rec; else atomicOr(status, 1);
+                        }
+                        nr += __popcll(rm);
+                    }
+                    n_commit += rk - cur; n_fast++;
+                    cur = rk;
                     CBAR();
                 }
-                if (first_bad == cnt) continue;
-                // the rest of the chunk, from the seed of the failing record on, one seed at a time
-                unsigned long long mm = recm;
-                for (int c = 0; c < first_bad; c++) mm &= mm - 1;
-                const int pos = __ffsll((long long)mm) - 1;
-                todo &= ~((1ull << pos) - 1ull);
-            }
-            while (todo) {
-                if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int seed = base + j;
-                const bool has_r = (recm >> j) & 1ull;
-                const int rj = ri;
-                if (has_r) ri++;
-                const bool defined_j = (defc >> j) & 1ull;
-                const bool true_eff = defined_j && !bm_get(T, seed);
-                if (!has_r && !true_eff) continue;   // taken by a region committed since the chunk was loaded
-                int t0 = 0, nt = 0, has_rect = 0;
-                if (has_r) { t0 = recs[rj].t0; nt = recs[rj].nt; has_rect = recs[rj].has_rect; }
-                bool valid = has_r && true_eff;
-                const long long c_v0 = clock64();
-                if (has_r) n_slow++;
-                if (valid) {
+                int gseed = -1;                               // pixel to grow on the true flags, if the event calls for it
+                if (pc >= 0) {
+                    // candidate pixel: every record before it is committed; is it still free?
+                    pos = pc + 1;
+                    if (bm_get(T, pc)) continue;
+                    gseed = pc;
+                } else {
+                if (rs >= nseg) break;                        // no event left in the segment
+                // SUSPECT record rs: the walk's pixel-by-pixel test
+                {
+                    const int seed = (int)Hseed[rs], t0 = (int)Ht0[rs], nt = (int)(Hnt[rs] & 0x7FFFFFFFu);
+                    const bool has_rect = (Hnt[rs] & 0x80000000u) != 0u;
+                    const bool true_eff = !bm_get(T, seed);
+                    bool valid = true_eff;
+                    const long long c_v0 = clock64();
+                    n_slow++;
                     for (int i0 = 0; i0 < nt && valid; i0 += 64) {
                         const int i = i0 + lane;
                         bool hit = false;
@@ -1548,38 +1573,41 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                         }
                         if (__ballot(hit)) valid = false;
                     }
-                }
-                c_val += clock64() - c_v0;
-                if (valid) {   // every flag the speculative run read was the true one: take its marks and its rectangle
-                    for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); } }
-                    if (has_rect) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = recs[rj].rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
-                    n_commit++;
-                    CBAR();
-                    continue;
-                }
-                if (has_r) {   // the speculative timeline keeps its own marks
+                    c_val += clock64() - c_v0;
+                    cur = rs + 1; pos = seed + 1;
+                    if (valid) {   // every flag the speculative run read was the true one: take its marks and its rectangle
+                        for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); } }
+                        if (has_rect) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = recs[r_lo + rs].rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
+                        n_commit++;
+                        CBAR();
+                        continue;
+                    }
+                    // the speculative timeline keeps its own marks
                     for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); S.set(q); if (!bm_get(T, q)) dc_mark(Dc, q, W, ctx); } }
                     CBAR();
+                    if (true_eff) gseed = seed;
+                    rescan = true;
                 }
-                if (true_eff) {   // grow on the true flags
-                    const float sdeg = __uint_as_float(C.ang[seed]);
-                    const float2 sc0 = C.cs0[seed];
+                }
+                if (gseed >= 0) {   // grow on the true flags
+                    const float sdeg = __uint_as_float(C.ang[gseed]);
+                    const float2 sc0 = C.cs0[gseed];
                     LsdRect rec;
                     int tn = 0, ovf = 0;
                     const long long c_r0 = clock64();
-                    const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl2, tn, 2 * (int)g.s_stride, ovf);
+                    const bool okr = spec_seed(C, g, th0, gseed, sdeg, sc0, rec, tl2, tn, 2 * (int)g.s_stride, ovf);
                     c_redo += clock64() - c_r0;
                     if (okr) { if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; } else if (lane == 0) atomicOr(status, 1); nr++; }
                     CBAR();
                     for (int i = lane; i < tn; i += 64) { const int q = (int)tl2[i]; if (S.get(q) != bm_get(T, q)) dc_mark(Dc, q, W, ctx); }
                     CBAR();
                     n_redo++;
+                    rescan = true;
                 }
             }
             if (BUDGET && truncated) break;
+            r_lo += nseg; p_lo = p_hi;
         }
-        if (BUDGET && truncated) break;
-        }   // tiles
         if (BUDGET && truncated) break;
     }
     if (BUDGET && truncated && lane == 0) { atomicOr(status, 8); status[16 + f] = 1; }

@@ -110,6 +110,31 @@ KS32(k_add_u32_sgpr, A_ADD_S)
 KS32(k_xor_b32_sgpr, A_XOR_S)
 KS32(k_fma_f32_sgpr, A_FMA_S)
 KS32(k_cndmask_sgprmask, A_CND_S)
+#define A_CND_E64VCC(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %10, vcc\n"
+#define A_CMPCND_VCC(i) "v_cmp_lt_u32_e32 vcc, %10, %" #i "\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\n"
+#define A_CMPCND_SGPR(i) "v_cmp_lt_u32_e64 s[20:21], %10, %" #i "\nv_cndmask_b32_e64 %" #i ", %" #i ", %10, s[20:21]\n"
+#define A_ADDCO(i) "v_add_co_u32_e32 %" #i ", vcc, %10, %" #i "\n"
+#define A_ADDC(i) "v_addc_co_u32_e32 %" #i ", vcc, %10, %" #i ", vcc\n"
+#define A_ADDCO_SGPR(i) "v_add_co_u32_e64 %" #i ", s[20:21], %10, %" #i "\n"
+#define KSX(NAME, ASM)                                                                                     \
+    __global__ void __launch_bounds__(1024) NAME(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk) \
+    {                                                                                                      \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        unsigned long long m = __ballot((threadIdx.x & 1) != 0);                                           \
+        const unsigned long long t0 = clock64(), w0 = wall_clock64();                                      \
+        for (int i = 0; i < iters; i++) {                                                                  \
+            asm volatile(BODY64(ASM) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "s"(m), "v"(c) : "vcc", "s20", "s21"); \
+        }                                                                                                  \
+        const unsigned long long t1 = clock64(), w1 = wall_clock64();                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }                   \
+        if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = a0;                              \
+    }
+KSX(k_cnd_e64_vcc, A_CND_E64VCC)
+KSX(k_cmpcnd_vcc, A_CMPCND_VCC)
+KSX(k_cmpcnd_sgpr, A_CMPCND_SGPR)
+KSX(k_addco_vcc, A_ADDCO)
+KSX(k_addc_vcc, A_ADDC)
+KSX(k_addco_sgpr, A_ADDCO_SGPR)
 __global__ void __launch_bounds__(1024) k_cndmask_vcc_init(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk)
 {
     uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
@@ -200,6 +225,11 @@ int main()
         {"v_add_u32 (sgpr src)", (void *)k_add_u32_sgpr, false}, {"v_xor_b32 (sgpr src)", (void *)k_xor_b32_sgpr, false},
         {"v_fma_f32 (sgpr src)", (void *)k_fma_f32_sgpr, false}, {"v_cndmask_b32 (sgpr-pair mask)", (void *)k_cndmask_sgprmask, false},
         {"v_cndmask_b32 (vcc set once per 64)", (void *)k_cndmask_vcc_init, false}, {"v_readlane_b32", (void *)k_readlane_b32, false},
+        {"v_cndmask_b32_e64 (vcc as explicit operand)", (void *)k_cnd_e64_vcc, false},
+        {"PAIR v_cmp_lt_u32_e32 vcc + v_cndmask_b32_e32 vcc (per pair)", (void *)k_cmpcnd_vcc, false},
+        {"PAIR v_cmp_lt_u32_e64 s[20:21] + v_cndmask_b32_e64 s[20:21] (per pair)", (void *)k_cmpcnd_sgpr, false},
+        {"v_add_co_u32_e32 (writes vcc)", (void *)k_addco_vcc, false}, {"v_addc_co_u32_e32 (reads + writes vcc)", (void *)k_addc_vcc, false},
+        {"v_add_co_u32_e64 (writes s[20:21])", (void *)k_addco_sgpr, false},
         {"v_add_f64 (inline const)", (void *)k_add_f64_const, true}, {"v_rcp_f64", (void *)k_rcp_f64, true}, {"v_sqrt_f64", (void *)k_sqrt_f64, true},
     };
     const int waves_per_simd[] = {1, 2, 4, 8};
