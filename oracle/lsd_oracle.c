@@ -878,9 +878,19 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
         /* initial guess of what the earlier bands mark: nothing (mode 0), or every defined pixel above the band (mode 1) -- in the serial run a defined
          * pixel above the current seed is free only if refine / reduce_region_radius released it again */
         if (g_rounds_mode == 1) for (int y = 0; y < by[b]; y++) for (int x = 0; x < W; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) priv[(size_t)y * W + x] = USED;
-        B[b].E = (uint8_t *)malloc(NP); memcpy(B[b].E, priv, NP);
         L.used = priv;
         long acc = 0;
+        if (g_rounds_mode == 2 && b > 0) {   /* the GPU's halo warm-up: the g_band_halo rows above the band grown first, unrecorded, on an empty map */
+            const int yh = by[b] - g_band_halo > 0 ? by[b] - g_band_halo : 0;
+            for (int y = yh; y < by[b]; ++y)
+                for (int x = 0; x < W - 1; ++x) {
+                    const int adx = y * W + x;
+                    if (L.used[adx] != NOTUSED || L.angles[adx] == NOTDEF) continue;
+                    int nt; rect_t rec;
+                    run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &acc);
+                }
+        }
+        B[b].E = (uint8_t *)malloc(NP); memcpy(B[b].E, priv, NP);
         B[b].rects = (rect_t *)malloc(sizeof(rect_t) * NP / 4);
         for (int y = by[b]; y < by[b + 1]; ++y)
             for (int x = 0; x < W - 1; ++x) {

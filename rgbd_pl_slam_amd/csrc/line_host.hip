@@ -632,6 +632,7 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
     if (getenv("PLF_LSD_SPEC_TIMELINE")) {   // per band: grow end, commit start (100 MHz ticks); last: commit end
         int tl[200];
         PLF_HIP_TRY(hipMemcpy(tl, h->d_spec_stats + 8, 200 * sizeof(int), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[plf] commit wave of frame 0, kilo-cycles: bulk commits %d, event scans %d, re-classification %d, segment set-up %d\n", tl[193], tl[194], tl[195], tl[196]);
         const int t0 = tl[1];
         fprintf(stderr, "[plf] speculation timeline (us after the commit of band 0 started):");
         for (int b = 0; b < h->spec.nbands && b < 63; b++) fprintf(stderr, " b%d grow_end %d commit_start %d |", b, (tl[3 * b] - t0) / 100, (tl[3 * b + 1] - t0) / 100);

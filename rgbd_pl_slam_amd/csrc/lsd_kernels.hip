@@ -1281,7 +1281,16 @@ template <bool SG> struct SpecS {
     __device__ __forceinline__ uint32_t word(int i) const { return SG ? __hip_atomic_load(&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : l[i]; }
     __device__ __forceinline__ void load_from(const uint32_t *__restrict__ src, int words, int lane) const
     {
-        for (int i = lane; i < words; i += 64) { const uint32_t v = src[i]; if (SG) __hip_atomic_store(&g[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else l[i] = v; }
+        for (int i0 = lane; i0 < words; i0 += 512) {   // eight independent loads per lane in flight (one per iteration cost a round trip each: 6144 words = 96 trips per band)
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = i0 + 64 * u < words ? src[i0 + 64 * u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 64 * u;
+                if (i < words) { if (SG) __hip_atomic_store(&g[i], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else l[i] = v[u]; }
+            }
+        }
     }
     __device__ __forceinline__ void clear_all(int words, int lane) const
     {
@@ -1390,7 +1399,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
     const uint32_t *defmap = SB.defmap + (size_t)f * SB.bm_words;
     const GrowTh th0 = grow_thresholds(g.prec);
     int nr = 0, n_commit = 0, n_redo = 0, n_fast = 0, n_slow = 0;
-    long long c_redo = 0, c_val = 0, c_setup = 0;
+    long long c_redo = 0, c_val = 0, c_setup = 0, c_bulk = 0, c_scan = 0, c_rescan = 0, c_seg = 0;
     const long long c_t0 = clock64();
     for (int band = 0; band < SB.nbands; band++) {
         const size_t fb = (size_t)f * SB.nbands + band;
@@ -1433,6 +1442,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         int r_lo = 0, p_lo = y0 * W;
         while (p_lo < p_end) {
             // ---- segment [p_lo, p_hi) x records [r_lo, r_hi)
+            const long long c_g0 = clock64();
             const int nh = min(SPEC_HCAP, nrec_band - r_lo);
             for (int i = lane; i < nh; i += 64) {
                 const int4 *hp = reinterpret_cast<const int4 *>(&recs[r_lo + i]);
@@ -1454,8 +1464,10 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
             CBAR();
             bool rescan = true;                               // classify the records against the tile map
             int cur = 0, pos = p_lo;                          // next record of the segment, next pixel position
+            c_seg += clock64() - c_g0;
             for (;;) {
                 if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
+                const long long c_e0 = clock64();
                 if (rescan) {
                     for (int i = cur + lane; i < nseg; i += 64) {
                         const uint32_t b0 = Hb0[i], b1 = Hb1[i];
@@ -1477,6 +1489,8 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     CBAR();
                     rescan = false;
                 }
+                const long long c_e1 = clock64();
+                c_rescan += c_e1 - c_e0;
                 // next SUSPECT record at or after cur
                 int rs = nseg;
                 {
@@ -1508,6 +1522,8 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     }
                 }
                 // the CLEAN records before the event stand: commit them in bulk
+                const long long c_e2 = clock64();
+                c_scan += c_e2 - c_e1;
                 int rk = rs;                                  // first record NOT committed now
                 if (pc >= 0) {
                     rk = cur;
@@ -1540,6 +1556,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                     cur = rk;
                     CBAR();
                 }
+                c_bulk += clock64() - c_e2;
                 int gseed = -1;                               // pixel to grow on the true flags, if the event calls for it
                 if (pc >= 0) {
                     // candidate pixel: every record before it is committed; is it still free?
@@ -1617,6 +1634,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         if (stats) {
             int *st = stats + 8 * f;
             st[0] = n_commit; st[1] = n_redo; st[2] = n_fast; st[3] = n_slow; st[4] = (int)(c_redo >> 10); st[5] = (int)(c_val >> 10); st[6] = (int)((clock64() - c_t0) >> 10); st[7] = (int)(c_setup >> 10);
+            if (f == 0) { stats[201] = (int)(c_bulk >> 10); stats[202] = (int)(c_scan >> 10); stats[203] = (int)(c_rescan >> 10); stats[204] = (int)(c_seg >> 10); }   // (kilo-cycles: bulk commits, event scans, re-classification, segment set-up)
         }
     }
 }
