@@ -49,6 +49,11 @@ __global__ void k_lsd_spec_fused(float *, const double *, const double2 *, const
 __global__ void k_lsd_spec_bands(const float *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_commit(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
+__global__ void k_lsd_spec_commit_rest(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
+__global__ void k_lsd_spec_prefix(SpecBufs, int);
+__global__ void k_lsd_spec_round_begin(SpecBufs, int, int);
+__global__ void k_lsd_spec_validate(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs, int);
+__global__ void k_lsd_spec_assemble(LsdRect *, int *, int *, LsdGeom, SpecBufs, int);
 
 struct plf_line {
     plf_line_params prm;
@@ -110,7 +115,8 @@ static void line_free(plf_line *h)
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
+    void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
+                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -317,6 +323,8 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_grow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_validate, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit_rest, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_regions_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -394,15 +402,22 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const int commit_extra = 5 * 512 + 512 / 32 + 1024 + 1 + 16 + 16;   // SPEC_COMMIT_EXTRA_WORDS of lsd_kernels.hip (+ the 16-word alignment of the tile map): record headers, SUSPECT mask, "defined, no record" bits
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words + commit_extra) * 4 + 64;
     bool spec = !seeds && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
-    if (spec) {   // scratch of the speculation: ~23 MB per VGA frame, ~65 MB per 1280x960 frame; keep it below 8 GiB
+    // validation rounds instead of the serial commit wave (k_lsd_spec_validate): up to PLF_LSD_SPEC_Z frames in flight (16), never with a time budget
+    const int zmax = getenv("PLF_LSD_SPEC_Z") ? atoi(getenv("PLF_LSD_SPEC_Z")) : 16;
+    bool zmode = spec && !budget && B <= zmax;
+    if (spec) {   // scratch of the speculation: ~23 MB per VGA frame, ~65 MB per 1280x960 frame (x 2.5 with the buffers of the validation rounds); keep it below 32 GiB
         size_t Fr = 8;
         while (Fr < (size_t)B) Fr <<= 1;
         const size_t per_frame = ((size_t)2 * spec_bands + 3) * g.s_stride * sizeof(uint32_t) + (size_t)spec_bands * 8192 * sizeof(SpecRec);
+        const size_t per_frame_z = (size_t)spec_bands * (3 * g.s_stride * sizeof(uint32_t) + 8192 * sizeof(SpecRec) + 3 * (size_t)bm_words * sizeof(uint32_t));
         if (Fr * per_frame > ((size_t)8 << 30)) spec = false;
+        if (zmode && Fr * (per_frame + per_frame_z) > ((size_t)32 << 30)) zmode = false;
+        if (!spec) zmode = false;
     }
-    if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride)) {
+    if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out))) {
         // (re)allocate for lat_max frames of the current geometry
-        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats};
+        void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
+                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
@@ -420,10 +435,21 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.tl2, Fr * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.band_y, Fr * (K + 1) * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.done, Fr * K * sizeof(int)) == hipSuccess &&
-                  hipMalloc((void **)&h->spec.sglob, Fr * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.sglob, Fr * (zmode ? K : 1) * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&   // (one per band for the validation rounds)
+                  hipMalloc((void **)&h->spec.side, Fr * K * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.halo, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->d_spec_stats, (Fr * 8 + 200) * sizeof(int)) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; }
+        if (ok && zmode) {
+            ok = hipMalloc((void **)&h->spec.out, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.pre, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.tl_alt, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.recs_alt, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.cnt_alt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.nrects, Fr * K * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.round_state, Fr * 4 * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.tl2b, Fr * K * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess;
+        }
+        if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; zmode = false; }
         else h->spec_frames = (int)Fr;
     }
     if (spec) {
@@ -445,16 +471,34 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             else cus = prop.multiProcessorCount;
             h->fused_lds = lds_commit; h->fused_capacity = (size_t)per_cu * (size_t)cus;
         }
-        const bool fused = (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !getenv("PLF_LSD_SPEC_NOFUSE");
+        zmode = zmode && h->spec.out != nullptr;
+        const bool fused = !zmode && (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !getenv("PLF_LSD_SPEC_NOFUSE");
         h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
+        PLF_HIP_TRY(hipMemsetAsync(h->spec.side, 0, (size_t)B * spec_bands * sizeof(int), s));
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(1024), 0, s, h->d_ang, g, h->spec);
-        if (fused) {
+        SpecBufs SBn = h->spec; SBn.out = nullptr; SBn.round_state = nullptr;   // (schedules without validation rounds: the band waves skip their part of them)
+        if (zmode) {
+            // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;
+            // rectangles assembled from the bands' logs; frames that did not reach the fixpoint within the rounds are committed serially (exact either way)
+            const int rounds = getenv("PLF_LSD_SPEC_ROUNDS") ? max(1, min(64, atoi(getenv("PLF_LSD_SPEC_ROUNDS")))) : 6;
+            PLF_HIP_TRY(hipMemsetAsync(h->spec.round_state, 0, (size_t)B * 4 * sizeof(int), s));
+            const SpecBufs SBz = h->spec;
+            hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);
+            for (int r = 1; r <= rounds; r++) {
+                hipLaunchKernelGGL(k_lsd_spec_round_begin, dim3((B + 63) / 64), dim3(64), 0, s, SBz, B, r);
+                hipLaunchKernelGGL(k_lsd_spec_prefix, dim3((bm_words + 255) / 256, B), dim3(256), 0, s, SBz, r);
+                hipLaunchKernelGGL(k_lsd_spec_validate, dim3(spec_bands, B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz, r);
+            }
+            hipLaunchKernelGGL(k_lsd_spec_assemble, dim3(spec_bands, B), dim3(64), 0, s, h->d_rects, nrect, status, g, SBz, rounds);
+            hipLaunchKernelGGL(k_lsd_spec_commit_rest, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
+                               SBz, h->d_spec_stats, rounds);
+        } else if (fused) {
             hipLaunchKernelGGL(budget ? k_lsd_spec_fused_budget : k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
-                               status, g, h->spec, h->d_spec_stats, B);
+                               status, g, SBn, h->d_spec_stats, B);
         } else {
-        hipLaunchKernelGGL(budget ? k_lsd_spec_grow_budget : k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, h->spec);
+        hipLaunchKernelGGL(budget ? k_lsd_spec_grow_budget : k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBn);
         hipLaunchKernelGGL(budget ? k_lsd_spec_commit_budget : k_lsd_spec_commit, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
-                           h->spec, h->d_spec_stats);
+                           SBn, h->d_spec_stats);
         }
     } else if (B <= lat_max)
         hipLaunchKernelGGL(budget ? k_lsd_regions_lat_budget : k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,

@@ -44,5 +44,15 @@ struct SpecBufs {
     int halo_rows;      // rows above a band that its wave grows first, unrecorded (model: orc_lsd_band_speculation_halo)
     int s_global;
     int tcap, rcap_rec, nbands, bm_words;
+    // parallel validation rounds (k_lsd_spec_prefix / _validate / _assemble): every band keeps its log consistent with what the bands before it mark
+    uint32_t *out;      // [frame][band][bm_words]: pixels marked by the band's own records (current log)
+    uint32_t *pre;      // [frame][band][bm_words]: union of out[] of the bands before it
+    uint32_t *tl_alt;   // second side of the logs: a validation reads one side and writes the other
+    SpecRec *recs_alt;
+    int *cnt_alt;
+    int *side;          // [frame][band]: side that holds the band's current log (0: tl / recs / cnt)
+    int *nrects;        // [frame][band]: rectangles in the band's current log
+    int *round_state;   // [frame][4]: bands whose marks changed in the even / odd rounds, converged, fall back to the serial commit
+    uint32_t *tl2b;     // [frame][band][2 * s_stride]: accepted pixels of a seed regrown by a validation
 };
 

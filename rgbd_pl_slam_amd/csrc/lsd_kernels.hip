@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
     const GrowTh th0 = grow_thresholds(g.prec);
     const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
-    int nrec = 0, tn = 0, ovf = 0;
+    int nrec = 0, tn = 0, ovf = 0, nrect_band = 0;
     // phase 0 (bands > 0): the rows just above the band, unrecorded -- what they mark (regions poking into the band) is the state the band's
     // speculation starts from, handed to the commit wave as the initial S; phase 1: the band itself, recorded
     uint32_t *halo = SB.halo + fb * SB.bm_words;
@@ -1210,6 +1210,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
             const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf);
             if (!record) { tn = 0; ovf = 0; }
             if (record && nrec >= SB.rcap_rec) ovf = 1;
+            if (record && okr) nrect_band++;
             if (record && !ovf) {
                 int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
                 for (int i = t0 + lane; i < tn; i += 64) {
@@ -1240,7 +1241,14 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     }
     if (BUDGET && truncated) break;
     }
+    if (SB.out) {   // validation rounds follow: what the band's own records mark (its flags minus the state its warm-up rows left) and its rectangle count
+        uint32_t *outb = SB.out + fb * SB.bm_words;
+        const bool had_halo = band > 0 && SB.halo_rows > 0;
+        for (int i = lane; i < SB.bm_words; i += 64) outb[i] = bm[i] & ~(had_halo ? halo[i] : 0u);
+        if (lane == 0) SB.nrects[fb] = nrect_band;
+    }
     if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; SB.cnt[fb * 4 + 3] = (int)(wall_clock64() & 0x7fffffff); }   // ([3]: 100 MHz timestamp, diagnostics)
+    if (ovf && SB.round_state && lane == 0) SB.round_state[f * 4 + 3] = 1;   // an incomplete log cannot be validated: the frame takes the serial commit
     __threadfence();   // every lane's log entries are visible device-wide before the flag
     if (lane == 0) __hip_atomic_store(&SB.done[fb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1298,6 +1306,12 @@ template <bool SG> struct SpecS {
     }
 };
 
+__device__ __forceinline__ bool spec_rounds_converged(const SpecBufs &SB, int f, int last);
+// the band's CURRENT log: side 0 = tl / recs / cnt (what the band wave wrote), side 1 = the buffers a validation round wrote (SB.side is zeroed per call)
+__device__ __forceinline__ const uint32_t *spec_log_tl(const SpecBufs &SB, size_t fb) { return (SB.side[fb] ? SB.tl_alt : SB.tl) + fb * SB.tcap; }
+__device__ __forceinline__ const SpecRec *spec_log_recs(const SpecBufs &SB, size_t fb) { return (SB.side[fb] ? SB.recs_alt : SB.recs) + fb * SB.rcap_rec; }
+__device__ __forceinline__ const int *spec_log_cnt(const SpecBufs &SB, size_t fb) { return (SB.side[fb] ? SB.cnt_alt : SB.cnt) + fb * 4; }
+
 // The one-launch schedule makes the commit wave of a frame wait for the band waves of the same launch.  The host only uses it when ALL workgroups of
 // the launch can be resident at once (occupancy query), so every band wave is dispatched whatever the dispatch order; the spin is bounded all the
 // same (~2^21 x 3 us WITHOUT a heartbeat of the awaited band wave -- it bumps cnt[3] once per seed): a scheduling surprise then surfaces as status
@@ -1339,8 +1353,9 @@ __device__ __forceinline__ unsigned long long spec_readlane64(unsigned long long
 template <bool SG, bool BUDGET>
 __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                  const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
-                                                 int *__restrict__ nrect, int *__restrict__ status, const LsdGeom &g, const SpecBufs &SB, int *__restrict__ stats)
+                                                 int *__restrict__ nrect, int *__restrict__ status, const LsdGeom &g, const SpecBufs &SB, int *__restrict__ stats, int zlast = -1)
 {
+    if (zlast >= 0 && spec_rounds_converged(SB, f, zlast)) return;   // validation rounds ran and reached their fixpoint: k_lsd_spec_assemble has written the rectangles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int W = g.sw, H = g.sh;
@@ -1352,10 +1367,10 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         for (int b = 0; b < SB.nbands; b++) {
             const size_t fb = (size_t)f * SB.nbands + b;
             if (!spec_wait_band(SB, fb, status)) return;
-            const int nrec = SB.cnt[fb * 4 + 0], tn = SB.cnt[fb * 4 + 1];
-            const uint32_t *r = reinterpret_cast<const uint32_t *>(SB.recs + fb * SB.rcap_rec);
+            const int nrec = spec_log_cnt(SB, fb)[0], tn = spec_log_cnt(SB, fb)[1];
+            const uint32_t *r = reinterpret_cast<const uint32_t *>(spec_log_recs(SB, fb));
             for (int i = t * 32; i < nrec * (int)(sizeof(SpecRec) / 4); i += 192 * 32) acc ^= r[i];
-            const uint32_t *q = SB.tl + fb * SB.tcap;
+            const uint32_t *q = spec_log_tl(SB, fb);
             for (int i = t * 32; i < tn; i += 192 * 32) acc ^= q[i];
             const int y0 = SB.band_y[f * (SB.nbands + 1) + b], y1 = SB.band_y[f * (SB.nbands + 1) + b + 1];
             const uint32_t *a = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
@@ -1406,11 +1421,11 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         if (!spec_wait_band(SB, fb, status)) return;
         const long long c_s0 = clock64();
         if (stats && f == 0 && lane == 0 && band < 64) { stats[8 + 3 * band] = SB.cnt[fb * 4 + 3]; stats[8 + 3 * band + 1] = (int)(wall_clock64() & 0x7fffffff); }
-        const int use_recs = SB.cnt[fb * 4 + 2] == 0;   // a band whose log overflowed is simply grown here
-        const uint32_t *tl = SB.tl + fb * SB.tcap;
-        const SpecRec *recs = SB.recs + fb * SB.rcap_rec;
+        const int use_recs = spec_log_cnt(SB, fb)[2] == 0;   // a band whose log overflowed is simply grown here
+        const uint32_t *tl = spec_log_tl(SB, fb);
+        const SpecRec *recs = spec_log_recs(SB, fb);
         const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
-        if (band > 0 && SB.halo_rows > 0) S.load_from(SB.halo + fb * SB.bm_words, SB.bm_words, lane);   // the band's flags after its warm-up rows
+        if (band > 0 && (SB.halo_rows > 0 || zlast >= 0)) S.load_from(SB.halo + fb * SB.bm_words, SB.bm_words, lane);   // the band's flags after its warm-up rows (after validation rounds: the state its log is consistent with)
         else S.clear_all(SB.bm_words, lane);
         for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
         CBAR();
@@ -1438,7 +1453,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
         //   * (a band whose log overflowed has no records: every defined pixel that is free in T when its turn comes is a candidate.)
         // The result is the walk's, statement for statement: same validity rule, same order of rectangles.
         const int p_end = y1 * W;
-        const int nrec_band = use_recs ? SB.cnt[fb * 4 + 0] : 0;
+        const int nrec_band = use_recs ? spec_log_cnt(SB, fb)[0] : 0;
         int r_lo = 0, p_lo = y0 * W;
         while (p_lo < p_end) {
             // ---- segment [p_lo, p_hi) x records [r_lo, r_hi)
@@ -1646,6 +1661,14 @@ __global__ void __launch_bounds__(256) k_lsd_spec_commit(float *__restrict__ ang
     if (SB.s_global) spec_commit_body<true, false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
     else spec_commit_body<false, false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats);
 }
+// after `zlast` validation rounds: only the frames that did not converge (or whose logs overflowed) are committed serially, from the logs as they stand
+__global__ void __launch_bounds__(256) k_lsd_spec_commit_rest(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                             const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
+                                                             int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats, int zlast)
+{
+    if (SB.s_global) spec_commit_body<true, false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats, zlast);
+    else spec_commit_body<false, false>(blockIdx.x, ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats, zlast);
+}
 __global__ void __launch_bounds__(256) k_lsd_spec_commit_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
                                                         const float2 *__restrict__ cs0_all, uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all,
                                                         int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats)
@@ -1683,6 +1706,385 @@ __global__ void __launch_bounds__(256) k_lsd_spec_fused_budget(float *__restrict
                                                        int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int *__restrict__ stats, int B)
 {
     spec_fused_body<true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, SB, stats, B);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parallel validation rounds (round 3; model: oracle/lsd_oracle.c, orc_lsd_band_rounds).  The serial commit wave above spends 4-6 ms per VGA frame AFTER the
+// band waves are done (2 ms of it regrowing ~90 regions one after the other).  Instead, EVERY band validates itself, all bands at once:
+//   out[b]  = the pixels band b's own records mark;   pre[b] = union of out[b'] for b' < b  (k_lsd_spec_prefix);
+//   E_b     = the state of the earlier bands that band b's log is consistent with (initially what its warm-up rows left: SB.halo).
+// A round: where pre[b] differs from E_b, band b replays the commit wave's event loop on T = pre[b], S = E_b over its own records and writes a NEW log (the other
+// side of the ping-pong buffers): records that stand are copied, the others dropped or regrown on T, skipped seeds that are free grown.  That log IS the serial
+// processing of the band's seeds from pre[b]; E_b := pre[b], out[b] := T minus pre[b].  Band 0 never changes, so after round r the bands 0..r are final; the
+// rounds stop when no out[] changed (3-6 rounds on the synthetic frames; the host enqueues a fixed number, later launches return at once).  A frame that has not
+// converged by then, or whose logs overflowed, is finished by the serial commit wave from the logs as they stand (every log is consistent with its own E_b, which
+// is all that wave needs) -- so the result is exact either way.  Rectangles: k_lsd_spec_assemble concatenates the bands' records in order.
+// round_state[f] = {changed bands in even rounds, in odd rounds, -, fall back}
+// ------------------------------------------------------------------------------------------------
+// round_state[f] = {bands whose marks changed in the even rounds, in the odd rounds, converged (sticky), fall back to the serial commit (sticky)}
+__device__ __forceinline__ bool spec_rounds_active(const SpecBufs &SB, int f)
+{
+    const int *rs = SB.round_state + f * 4;
+    return !rs[2] && !rs[3];
+}
+// after `last` rounds: a fixpoint was reached (some round found the one before it unchanged, or the last round changed nothing)
+__device__ __forceinline__ bool spec_rounds_converged(const SpecBufs &SB, int f, int last)
+{
+    const int *rs = SB.round_state + f * 4;
+    return !rs[3] && (rs[2] || rs[last & 1] == 0);
+}
+
+__global__ void __launch_bounds__(256) k_lsd_spec_prefix(SpecBufs SB, int round)
+{
+    const int f = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+    if (!spec_rounds_active(SB, f)) return;
+    if (w >= SB.bm_words) return;
+    const size_t base = (size_t)f * SB.nbands * SB.bm_words + w;
+    uint32_t acc = 0u;
+    for (int b = 0; b < SB.nbands; b++) {
+        SB.pre[base + (size_t)b * SB.bm_words] = acc;
+        acc |= SB.out[base + (size_t)b * SB.bm_words];
+    }
+}
+
+template <bool SG>
+__device__ __forceinline__ void spec_validate_body(int band, int f, float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                   const float2 *__restrict__ cs0_all, const LsdGeom &g, const SpecBufs &SB, int round)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    if (threadIdx.x >= 64) return;
+    const int W = g.sw, H = g.sh;
+    const size_t fb = (size_t)f * SB.nbands + band;
+    int *rs = SB.round_state + f * 4;
+    LDS_PTR(uint32_t) list = (LDS_PTR(uint32_t))smem;
+    LDS_PTR(uint32_t) T = list + ((g.rcap + 1 + 15) & ~15);
+    SpecS<SG> S;
+    S.l = T + SB.bm_words; S.g = SB.sglob + fb * SB.bm_words;          // (s_global frames: one S bitmap per band here)
+    const int ctx = (((W + 7) >> 3) + 31) & ~31, cty = (H + 7) >> 3, cwords = (ctx >> 5) * cty;
+    LDS_PTR(uint32_t) Dc = T + (SG ? 1 : 2) * SB.bm_words;
+    LDS_PTR(uint32_t) Hseed = Dc + ((cwords + 15) & ~15);
+    LDS_PTR(uint32_t) Ht0 = Hseed + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hnt = Ht0 + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hb0 = Hnt + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hb1 = Hb0 + SPEC_HCAP;
+    LDS_PTR(uint32_t) Hsus = Hb1 + SPEC_HCAP;
+    LDS_PTR(uint32_t) NR = Hsus + SPEC_HCAP / 32;
+    const uint32_t *pre = SB.pre + fb * SB.bm_words;
+    uint32_t *halo = SB.halo + fb * SB.bm_words;
+    // T = what the bands before this one mark now, S = what this band's log assumed they mark; nothing to do where they agree
+    bool differ = false;
+    for (int i0 = lane; i0 < SB.bm_words; i0 += 256) {
+        uint32_t a[4], e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u; a[u] = i < SB.bm_words ? pre[i] : 0u; e[u] = i < SB.bm_words ? halo[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u;
+            if (i < SB.bm_words) { T[i] = a[u]; if (SG) __hip_atomic_store(&S.g[i], e[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.l[i] = e[u]; differ |= a[u] != e[u]; }
+        }
+    }
+    if (!__ballot(differ)) return;
+    for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
+    CBAR();
+    for (int wi = lane; wi < SB.bm_words; wi += 64) {
+        uint32_t bits = T[wi] ^ S.word(wi);
+        if (!bits) continue;
+        if ((W & 31) == 0) { for (int k = 0; k < 4; k++) if ((bits >> (8 * k)) & 0xFFu) dc_mark(Dc, wi * 32 + 8 * k, W, ctx); }
+        else { while (bits) { const int a = wi * 32 + __ffs((int)bits) - 1; bits &= bits - 1; dc_mark(Dc, a, W, ctx); } }
+    }
+    CBAR();
+    RegCtx C;
+    spec_ctx(C, g, f, ang_all, modgrad_all, cs_all, cs0_all, SB.rxy + fb * g.s_stride, list, T);
+    __builtin_amdgcn_s_setprio(3);
+    const GrowTh th0 = grow_thresholds(g.prec);
+    const int sd = SB.side[fb];
+    const uint32_t *tl = (sd ? SB.tl_alt : SB.tl) + fb * SB.tcap;
+    const SpecRec *recs = (sd ? SB.recs_alt : SB.recs) + fb * SB.rcap_rec;
+    const int *cnt = (sd ? SB.cnt_alt : SB.cnt) + fb * 4;
+    uint32_t *tl_n = (sd ? SB.tl : SB.tl_alt) + fb * SB.tcap;            // the new log goes to the other side
+    SpecRec *recs_n = (sd ? SB.recs : SB.recs_alt) + fb * SB.rcap_rec;
+    int *cnt_n = (sd ? SB.cnt : SB.cnt_alt) + fb * 4;
+    uint32_t *tl2 = SB.tl2b + fb * 2 * g.s_stride;
+    uint32_t *seedmap = SB.seedmap + (size_t)f * SB.bm_words;
+    const uint32_t *defmap = SB.defmap + (size_t)f * SB.bm_words;
+    const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
+    int nrec_n = 0, tn_n = 0, nrect_n = 0;
+    bool ovf_n = false;
+    const int p_end = y1 * W;
+    const int nrec_band = cnt[0];
+    int r_lo = 0, p_lo = y0 * W;
+    while (p_lo < p_end && !ovf_n) {
+        const int nh = min(SPEC_HCAP, nrec_band - r_lo);
+        for (int i = lane; i < nh; i += 64) {
+            const int4 *hp = reinterpret_cast<const int4 *>(&recs[r_lo + i]);
+            const int4 h0 = hp[0], h1 = hp[1];
+            Hseed[i] = (uint32_t)h0.x; Ht0[i] = (uint32_t)h0.y; Hnt[i] = (uint32_t)h0.z | (h0.w ? 0x80000000u : 0u);
+            Hb0[i] = (uint32_t)h1.x | ((uint32_t)h1.y << 16); Hb1[i] = (uint32_t)h1.z | ((uint32_t)h1.w << 16);
+        }
+        int p_hi = min(p_end, ((p_lo >> 5) + SPEC_NRW) << 5);
+        if (r_lo + nh < nrec_band) p_hi = min(p_hi, recs[r_lo + nh].seed);
+        CBAR();
+        int nseg = nh;
+        for (int base = 0; base < nh; base += 64) {
+            const unsigned long long m = __ballot(base + lane < nh && (int)Hseed[base + lane] >= p_hi);
+            if (m) { nseg = base + __ffsll((long long)m) - 1; break; }
+        }
+        const int w_lo = p_lo >> 5, nw = ((p_hi + 31) >> 5) - w_lo;
+        for (int i = lane; i < nw; i += 64) NR[i] = defmap[w_lo + i] & ~seedmap[w_lo + i];
+        for (int i = lane; i < SPEC_HCAP / 32; i += 64) Hsus[i] = 0u;
+        CBAR();
+        bool rescan = true;
+        int cur = 0, pos = p_lo;
+        while (!ovf_n) {
+            if (rescan) {
+                for (int i = cur + lane; i < nseg; i += 64) {
+                    const uint32_t b0 = Hb0[i], b1 = Hb1[i];
+                    const int tx0 = (int)(b0 & 0xFFFFu) >> 3, ty0 = (int)(b0 >> 16) >> 3, tx1 = (int)(b1 & 0xFFFFu) >> 3, ty1 = (int)(b1 >> 16) >> 3;
+                    const int w0 = tx0 >> 5, w1 = tx1 >> 5;
+                    const uint32_t m0 = 0xFFFFFFFFu << (tx0 & 31), m1 = 0xFFFFFFFFu >> (31 - (tx1 & 31));
+                    bool clean = true;
+                    for (int ty = ty0; ty <= ty1 && clean; ty++) {
+                        LDS_PTR(uint32_t) row = Dc + ty * (ctx >> 5);
+                        for (int wq = w0; wq <= w1; wq++) {
+                            uint32_t bits = row[wq];
+                            if (wq == w0) bits &= m0;
+                            if (wq == w1) bits &= m1;
+                            if (bits) { clean = false; break; }
+                        }
+                    }
+                    if (!clean) __hip_atomic_fetch_or(&Hsus[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                CBAR();
+                rescan = false;
+            }
+            int rsu = nseg;
+            {
+                uint32_t wv = 0u;
+                if (lane < SPEC_HCAP / 32 && lane >= (cur >> 5)) { wv = Hsus[lane]; if (lane == (cur >> 5)) wv &= 0xFFFFFFFFu << (cur & 31); }
+                const unsigned long long m = __ballot(wv != 0u);
+                if (m) {
+                    const int l0 = __ffsll((long long)m) - 1;
+                    rsu = min(nseg, l0 * 32 + __ffs((int)__builtin_amdgcn_readlane((int)wv, l0)) - 1);
+                }
+            }
+            const int ps = rsu < nseg ? (int)Hseed[rsu] : p_hi;
+            int pc = -1;
+            for (int wb = (pos >> 5); wb <= ((ps - 1) >> 5) && pos < ps; wb += 64) {
+                const int wq = wb + lane;
+                uint32_t bits = 0u;
+                if (wq <= ((ps - 1) >> 5)) {
+                    bits = NR[wq - w_lo] & ~T[wq] & S.word(wq);
+                    if (wq == (pos >> 5)) bits &= 0xFFFFFFFFu << (pos & 31);
+                    if (wq == ((ps - 1) >> 5) && (ps & 31)) bits &= 0xFFFFFFFFu >> (32 - (ps & 31));
+                }
+                const unsigned long long m = __ballot(bits != 0u);
+                if (m) {
+                    const int l0 = __ffsll((long long)m) - 1;
+                    pc = (wb + l0) * 32 + __ffs((int)__builtin_amdgcn_readlane((int)bits, l0)) - 1;
+                    break;
+                }
+            }
+            int rk = rsu;
+            if (pc >= 0) {
+                rk = cur;
+                for (int base = cur; base < rsu; base += 64) {
+                    const unsigned long long m = __ballot(base + lane >= rsu || (int)Hseed[min(base + lane, SPEC_HCAP - 1)] > pc);
+                    if (m) { rk = min(rsu, base + __ffsll((long long)m) - 1); break; }
+                    rk = min(rsu, base + 64);
+                }
+            }
+            if (rk > cur) {   // a run of records that stand: marks into T and S, log entries and records copied to the new log
+                const int t_begin = (int)Ht0[cur], t_stop = (int)Ht0[rk - 1] + (int)(Hnt[rk - 1] & 0x7FFFFFFFu);
+                if (tn_n + (t_stop - t_begin) > SB.tcap || nrec_n + (rk - cur) > SB.rcap_rec) { ovf_n = true; break; }
+                for (int i0 = t_begin; i0 < t_stop; i0 += 256) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int i = i0 + u * 64 + lane; e[u] = i < t_stop ? tl[i] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i < t_stop) tl_n[tn_n + (i - t_begin)] = e[u];
+                        if (e[u] & 0x40000000u) { bm_set(T, (int)(e[u] & 0x3FFFFFFFu)); S.set((int)(e[u] & 0x3FFFFFFFu)); }
+                    }
+                }
+                for (int base = cur; base < rk; base += 64) {
+                    const int i = base + lane;
+                    const bool in = i < rk;
+                    if (in) {
+                        const int4 *src = reinterpret_cast<const int4 *>(&recs[r_lo + i]);
+                        int4 *dst = reinterpret_cast<int4 *>(&recs_n[nrec_n + (i - cur)]);
+                        int4 v0 = src[0];
+                        v0.y += tn_n - t_begin;                 // t0 in the new log
+                        dst[0] = v0;
+#pragma unroll
+                        for (int q = 1; q < (int)(sizeof(SpecRec) / 16); q++) dst[q] = src[q];
+                    }
+                    nrect_n += __popcll(__ballot(in && (Hnt[min(i, SPEC_HCAP - 1)] & 0x80000000u)));
+                }
+                tn_n += t_stop - t_begin; nrec_n += rk - cur;
+                cur = rk;
+                CBAR();
+            }
+            int gseed = -1;
+            if (pc >= 0) {
+                pos = pc + 1;
+                if (bm_get(T, pc)) continue;
+                gseed = pc;
+            } else {
+                if (rsu >= nseg) break;
+                const int seed = (int)Hseed[rsu], t0 = (int)Ht0[rsu], nt = (int)(Hnt[rsu] & 0x7FFFFFFFu);
+                const bool true_eff = !bm_get(T, seed);
+                bool valid = true_eff;
+                for (int i0 = 0; i0 < nt && valid; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool hit = false;
+                    if (i < nt) {
+                        const int q = (int)(tl[t0 + i] & 0x3FFFFFFFu), qx = q % W, qy = q / W;
+                        for (int dy = -1; dy <= 1; dy++) {
+                            const int yy = qy + dy;
+                            if (yy < 0 || yy >= H) continue;
+                            for (int dx = -1; dx <= 1; dx++) {
+                                const int xx = qx + dx;
+                                if (xx < 0 || xx >= W) continue;
+                                hit |= bm_get(T, yy * W + xx) != S.get(yy * W + xx);
+                            }
+                        }
+                    }
+                    if (__ballot(hit)) valid = false;
+                }
+                cur = rsu + 1; pos = seed + 1;
+                if (valid) {
+                    if (tn_n + nt > SB.tcap || nrec_n + 1 > SB.rcap_rec) { ovf_n = true; break; }
+                    for (int i = lane; i < nt; i += 64) {
+                        const uint32_t e = tl[t0 + i];
+                        tl_n[tn_n + i] = e;
+                        if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); }
+                    }
+                    if (lane == 0) { SpecRec r = recs[r_lo + rsu]; r.t0 = tn_n; recs_n[nrec_n] = r; }
+                    if (Hnt[rsu] & 0x80000000u) nrect_n++;
+                    tn_n += nt; nrec_n++;
+                    CBAR();
+                    continue;
+                }
+                for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); S.set(q); if (!bm_get(T, q)) dc_mark(Dc, q, W, ctx); } }
+                CBAR();
+                if (true_eff) gseed = seed;
+                rescan = true;
+            }
+            if (gseed >= 0) {   // grow on T; the result is a record of the new log
+                const float sdeg = __uint_as_float(C.ang[gseed]);
+                const float2 sc0 = C.cs0[gseed];
+                LsdRect rec;
+                int tn = 0, ovf = 0;
+                const bool okr = spec_seed(C, g, th0, gseed, sdeg, sc0, rec, tl2, tn, 2 * (int)g.s_stride, ovf);
+                CBAR();
+                if (ovf || tn_n + tn > SB.tcap || nrec_n + 1 > SB.rcap_rec) { ovf_n = true; break; }
+                int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
+                for (int i = lane; i < tn; i += 64) {
+                    const uint32_t q = tl2[i];
+                    const int qx = (int)(q % (uint32_t)W), qy = (int)(q / (uint32_t)W);
+                    bx0 = min(bx0, qx); bx1 = max(bx1, qx); by0 = min(by0, qy); by1 = max(by1, qy);
+                    tl_n[tn_n + i] = q | (bm_get(T, (int)q) ? 0x40000000u : 0u);
+                    if (S.get((int)q) != bm_get(T, (int)q)) dc_mark(Dc, (int)q, W, ctx);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    bx0 = min(bx0, __shfl_xor(bx0, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64));
+                    bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
+                }
+                if (lane == 0) {
+                    SpecRec r; r.seed = gseed; r.t0 = tn_n; r.nt = tn; r.has_rect = okr ? 1 : 0; r.rec = rec;
+                    r.bx0 = max(bx0 - 1, 0); r.by0 = max(by0 - 1, 0); r.bx1 = min(bx1 + 1, W - 1); r.by1 = min(by1 + 1, H - 1);
+                    recs_n[nrec_n] = r;
+                }
+                if (okr) nrect_n++;
+                tn_n += tn; nrec_n++;
+                CBAR();
+                rescan = true;
+            }
+        }
+        r_lo += nseg; p_lo = p_hi;
+    }
+    if (ovf_n) { if (lane == 0) rs[3] = 1; return; }   // the old log, E_b, out[] and the seed map are untouched: the serial commit takes the frame
+    // ---- the new log is the band's log now
+    __threadfence();
+    uint32_t *outb = SB.out + fb * SB.bm_words;
+    bool changed = false;
+    for (int i = lane; i < SB.bm_words; i += 64) {
+        const uint32_t e = pre[i], o = T[i] & ~e;
+        if (o != outb[i]) { changed = true; outb[i] = o; }
+        halo[i] = e;
+    }
+    // seed map of the band's rows: the seeds of the new log
+    {
+        const int a0 = y0 * W, a1 = p_end;
+        for (int wq = (a0 >> 5) + lane; wq <= ((a1 - 1) >> 5); wq += 64) {
+            uint32_t keep = 0u;
+            if (wq == (a0 >> 5)) keep |= (a0 & 31) ? ((1u << (a0 & 31)) - 1u) : 0u;
+            if (wq == ((a1 - 1) >> 5) && (a1 & 31)) keep |= ~((1u << (a1 & 31)) - 1u);
+            if (keep) atomicAnd(&seedmap[wq], keep); else seedmap[wq] = 0u;
+        }
+        __threadfence();
+        for (int i = lane; i < nrec_n; i += 64) { const int sdp = recs_n[i].seed; atomicOr(&seedmap[sdp >> 5], 1u << (sdp & 31)); }
+    }
+    if (lane == 0) {
+        cnt_n[0] = nrec_n; cnt_n[1] = tn_n; cnt_n[2] = 0; cnt_n[3] = 0;
+        SB.side[fb] = sd ^ 1;
+        SB.nrects[fb] = nrect_n;
+    }
+    if (__ballot(changed) && lane == 0) atomicAdd(&rs[round & 1], 1);
+}
+
+__global__ void __launch_bounds__(256) k_lsd_spec_validate(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,
+                                                          const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB, int round)
+{
+    const int band = blockIdx.x, f = blockIdx.y;
+    if (band == 0 || !spec_rounds_active(SB, f)) return;   // band 0 is consistent with the empty set for good
+    if (SB.s_global) spec_validate_body<true>(band, f, ang_all, modgrad_all, cs_all, cs0_all, g, SB, round);
+    else spec_validate_body<false>(band, f, ang_all, modgrad_all, cs_all, cs0_all, g, SB, round);
+}
+
+// first launch of round `round`: if the round before it changed nothing the frame has converged (sticky); otherwise this round's counter starts at zero.
+// (A launch of its own: the prefix / validate launches of a round then only READ the state that decides whether they run.)
+__global__ void k_lsd_spec_round_begin(SpecBufs SB, int B, int round)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= B) return;
+    int *rs = SB.round_state + f * 4;
+    if (rs[3] || rs[2]) return;
+    if (round > 1 && rs[(round - 1) & 1] == 0) { rs[2] = 1; return; }
+    rs[round & 1] = 0;
+}
+
+// rectangles of a converged frame: the bands' records in order
+__global__ void __launch_bounds__(64) k_lsd_spec_assemble(LsdRect *__restrict__ rects_all, int *__restrict__ nrect, int *__restrict__ status, LsdGeom g, SpecBufs SB, int last)
+{
+    const int band = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    if (!spec_rounds_converged(SB, f, last)) return;
+    const size_t fb = (size_t)f * SB.nbands + band;
+    int off = 0, total = 0;
+    for (int b = lane; b < SB.nbands; b += 64) { const int n = SB.nrects[(size_t)f * SB.nbands + b]; total += n; if (b < band) off += n; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); total += __shfl_xor(total, o, 64); }
+    LsdRect *rects = rects_all + (size_t)f * g.rect_cap;
+    const SpecRec *recs = spec_log_recs(SB, fb);
+    const int nrec = spec_log_cnt(SB, fb)[0];
+    int k = off;
+    for (int base = 0; base < nrec; base += 64) {
+        const int i = base + lane;
+        const bool hr = i < nrec && recs[i].has_rect != 0;
+        const unsigned long long m = __ballot(hr);
+        if (hr) {
+            const int slot = k + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < g.rect_cap) rects[slot] = recs[i].rec;
+        }
+        k += __popcll(m);
+    }
+    if (band == SB.nbands - 1 && lane == 0) {
+        nrect[f] = min(total, g.rect_cap);
+        if (total > g.rect_cap) atomicOr(status, 1);
+    }
 }
 
 #ifdef PLF_LSD_TIMING

@@ -18,6 +18,20 @@ def _need_gpu():
         pytest.fail("no GPU visible: the -m gpu tests need a real MI355X")
 
 
+# Few frames in flight take the banded speculative schedule.  Its second half exists in three forms, all of which must give the serial result:
+#   "rounds"     validation rounds (every band validates itself, all at once) until the fixpoint -- the default up to 16 frames;
+#   "one_round"  a single round, which rarely reaches the fixpoint: the serial commit wave then finishes the frame from the half-validated logs;
+#   "commit"     no rounds: the one-launch schedule with the serial commit wave (what more than 16 frames in flight take).
+SCHEDULES = pytest.mark.parametrize("schedule", ["rounds", "one_round", "commit"])
+
+
+def _set_schedule(monkeypatch, schedule):
+    if schedule == "one_round":
+        monkeypatch.setenv("PLF_LSD_SPEC_ROUNDS", "1")
+    elif schedule == "commit":
+        monkeypatch.setenv("PLF_LSD_SPEC_Z", "0")
+
+
 def _check(img, nlines, ext=None, lbd_sobel_input=0):
     from rgbd_pl_slam_amd import LineSegment
     h, w = img.shape
@@ -204,10 +218,12 @@ def test_line_and_matcher_errors():
 
 
 
+@SCHEDULES
 @pytest.mark.parametrize("bands", [2, 5, 8, 13, 32])
-def test_lines_speculative_bands(monkeypatch, bands):
+def test_lines_speculative_bands(monkeypatch, bands, schedule):
     """banded speculative region growing (<= 8 frames in flight) with different band counts: same bits as the serial oracle"""
     _need_gpu()
+    _set_schedule(monkeypatch, schedule)
     from rgbd_pl_slam_amd import LineSegment
     from rgbd_pl_slam_amd.synth import synth_frame, synth_batch
     monkeypatch.setenv("PLF_LSD_SPEC_BANDS", str(bands))
@@ -228,9 +244,11 @@ def test_lines_speculative_bands(monkeypatch, bands):
     ext.close()
 
 
-def test_lines_speculative_overflow_falls_back(monkeypatch):
+@SCHEDULES
+def test_lines_speculative_overflow_falls_back(monkeypatch, schedule):
     """record buffers too small: the commit kernel ignores the records and runs the serial loop itself"""
     _need_gpu()
+    _set_schedule(monkeypatch, schedule)
     from rgbd_pl_slam_amd import LineSegment
     from rgbd_pl_slam_amd.synth import synth_frame
     monkeypatch.setenv("PLF_LSD_SPEC_RECCAP", "4")
@@ -255,17 +273,21 @@ def test_lines_speculative_slow_band_is_not_a_timeout(monkeypatch):
     ext.close()
 
 
-def test_lines_speculative_odd_widths():
+@SCHEDULES
+def test_lines_speculative_odd_widths(monkeypatch, schedule):
     """scaled widths that are not multiples of 8 / 32 (752 -> 602, 600 -> 480, 333 -> 266) through the speculative path"""
     _need_gpu()
+    _set_schedule(monkeypatch, schedule)
     from rgbd_pl_slam_amd.synth import synth_frame
     for seed, (w, h) in enumerate([(752, 480), (600, 401), (333, 250)]):
         _check(synth_frame(60 + seed, w, h), 100)
 
 
-def test_lines_speculative_pathological_images():
+@SCHEDULES
+def test_lines_speculative_pathological_images(monkeypatch, schedule):
     """regions spanning every band, regions as long as the frame, and a log overflow caused by one giant region"""
     _need_gpu()
+    _set_schedule(monkeypatch, schedule)
     from rgbd_pl_slam_amd import LineSegment
     y, x = np.mgrid[0:480, 0:640]
     imgs = [((x * 7) % 256).astype(np.uint8),                                   # vertical sawtooth: frame-high regions, one per period
@@ -280,10 +302,12 @@ def test_lines_speculative_pathological_images():
     ext.close()
 
 
+@SCHEDULES
 @pytest.mark.parametrize("halo", [0, 5, 40])
-def test_lines_speculative_halo_rows(monkeypatch, halo):
+def test_lines_speculative_halo_rows(monkeypatch, halo, schedule):
     """warm-up rows above every band (default 16): any number of them, including none and more than a band is high, gives the serial result"""
     _need_gpu()
+    _set_schedule(monkeypatch, schedule)
     from rgbd_pl_slam_amd import LineSegment
     from rgbd_pl_slam_amd.synth import synth_frame
     monkeypatch.setenv("PLF_LSD_SPEC_HALO", str(halo))
