@@ -880,8 +880,11 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
         if (g_rounds_mode == 1) for (int y = 0; y < by[b]; y++) for (int x = 0; x < W; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) priv[(size_t)y * W + x] = USED;
         L.used = priv;
         long acc = 0;
-        if (g_rounds_mode == 2 && b > 0) {   /* the GPU's halo warm-up: the g_band_halo rows above the band grown first, unrecorded, on an empty map */
+        if ((g_rounds_mode == 2 || g_rounds_mode == 3) && b > 0) {   /* the GPU's halo warm-up: the g_band_halo rows above the band grown first, unrecorded, on an empty map */
             const int yh = by[b] - g_band_halo > 0 ? by[b] - g_band_halo : 0;
+            /* mode 3: ... on a map that has every defined pixel ABOVE the warm-up rows marked (in the serial run they all are, bar the few that refine released):
+             * the warm-up regions cannot leak upwards, which cost more than the warm-up rows themselves */
+            if (g_rounds_mode == 3) for (int y = 0; y < yh; y++) for (int x = 0; x < W; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) priv[(size_t)y * W + x] = USED;
             for (int y = yh; y < by[b]; ++y)
                 for (int x = 0; x < W - 1; ++x) {
                     const int adx = y * W + x;

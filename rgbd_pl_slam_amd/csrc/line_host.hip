@@ -39,6 +39,7 @@ __global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, i
 __global__ void k_nfa_count1(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_eval(int, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
+__global__ void k_nfa_fused(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
                                int, int *, unsigned long long *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
@@ -116,7 +117,7 @@ static void line_free(plf_line *h)
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b};
+                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -401,7 +402,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const bool s_global = (size_t)(list_words + 2 * bm_words + coarse_words + 5 * 512 + 512 / 32 + 1024 + 33) * 4 + 64 > 150 * 1024;
     const int commit_extra = 5 * 512 + 512 / 32 + 1024 + 1 + 16 + 16;   // SPEC_COMMIT_EXTRA_WORDS of lsd_kernels.hip (+ the 16-word alignment of the tile map): record headers, SUSPECT mask, "defined, no record" bits
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words + commit_extra) * 4 + 64;
-    bool spec = !seeds && g.sh <= 8192 && (g.sh - 1 + 7) / 8 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
+    bool spec = !seeds && g.sh <= 8192 && (g.sh - 1) / 4 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     // validation rounds instead of the serial commit wave (k_lsd_spec_validate): up to PLF_LSD_SPEC_Z frames in flight (16), never with a time budget
     const int zmax = getenv("PLF_LSD_SPEC_Z") ? atoi(getenv("PLF_LSD_SPEC_Z")) : 16;
     bool zmode = spec && !budget && B <= zmax;
@@ -417,7 +418,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out))) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b};
+                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
@@ -437,6 +438,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.done, Fr * K * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.sglob, Fr * (zmode ? K : 1) * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&   // (one per band for the validation rounds)
                   hipMalloc((void **)&h->spec.side, Fr * K * sizeof(int)) == hipSuccess &&
+                  hipMalloc((void **)&h->spec.band_ticks, Fr * K * 2 * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.halo, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->d_spec_stats, (Fr * 8 + 200) * sizeof(int)) == hipSuccess;
         if (ok && zmode) {
@@ -480,7 +482,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (zmode) {
             // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;
             // rectangles assembled from the bands' logs; frames that did not reach the fixpoint within the rounds are committed serially (exact either way)
-            const int rounds = getenv("PLF_LSD_SPEC_ROUNDS") ? max(1, min(64, atoi(getenv("PLF_LSD_SPEC_ROUNDS")))) : 6;
+            const int rounds = getenv("PLF_LSD_SPEC_ROUNDS") ? max(1, min(64, atoi(getenv("PLF_LSD_SPEC_ROUNDS")))) : 12;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
             PLF_HIP_TRY(hipMemsetAsync(h->spec.round_state, 0, (size_t)B * 4 * sizeof(int), s));
             const SpecBufs SBz = h->spec;
             hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);
@@ -513,7 +515,12 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         hipLaunchKernelGGL(budget ? k_lsd_regions_budget : k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
-    // rect_improve: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math)
+    // rect_improve.  Few frames in flight: one wave per rectangle runs all five stages (k_nfa_fused: a rectangle only waits for itself); otherwise the staged
+    // kernels: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math) over work lists compacted over the batch
+    const int nfa_fused_max = getenv("PLF_NFA_FUSED") ? atoi(getenv("PLF_NFA_FUSED")) : 64;
+    if (B <= nfa_fused_max) {
+        hipLaunchKernelGGL(k_nfa_fused, dim3(1024, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_keep, h->d_seg, g);
+    } else {
     PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
     hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
                        h->d_nfa_counters, status, g);
@@ -532,6 +539,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                            h->d_vals, g);
         hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],
                            h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
+    }
     }
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
                        d_lines, d_eq, d_nout, capacity, status, h->d_sort_scratch, g);
@@ -673,6 +681,19 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
     if (!h || !out8 || !h->d_spec_stats) return PLF_E_BADARG;
     PLF_HIP_TRY(hipDeviceSynchronize());
     PLF_HIP_TRY(hipMemcpy(out8, h->d_spec_stats, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    if (getenv("PLF_LSD_SPEC_TIMELINE") && h->spec.band_ticks) {   // band waves of frame 0: rows, run time, accepted pixels logged
+        std::vector<int> bt(2 * (size_t)h->spec.nbands), by((size_t)h->spec.nbands + 1);
+        PLF_HIP_TRY(hipMemcpy(bt.data(), h->spec.band_ticks, bt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        PLF_HIP_TRY(hipMemcpy(by.data(), h->spec.band_y, by.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (h->spec.round_state) {
+            int rs[4];
+            PLF_HIP_TRY(hipMemcpy(rs, h->spec.round_state, sizeof(rs), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[plf] validation rounds of frame 0: bands changed in the last even / odd round %d / %d, converged early %d, fell back to the serial commit %d\n", rs[0], rs[1], rs[2], rs[3]);
+        }
+        fprintf(stderr, "[plf] band waves of frame 0 (rows: us, logged pixels):");
+        for (int b = 0; b < h->spec.nbands; b++) fprintf(stderr, " %d-%d: %d, %d |", by[b], by[b + 1], bt[2 * b] / 100, bt[2 * b + 1]);
+        fprintf(stderr, "\n");
+    }
     if (getenv("PLF_LSD_SPEC_TIMELINE")) {   // per band: grow end, commit start (100 MHz ticks); last: commit end
         int tl[200];
         PLF_HIP_TRY(hipMemcpy(tl, h->d_spec_stats + 8, 200 * sizeof(int), hipMemcpyDeviceToHost));

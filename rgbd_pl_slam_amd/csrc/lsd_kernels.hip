@@ -1167,6 +1167,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int W = g.sw, H = g.sh;
+    const unsigned long long t_start = wall_clock64();
     LDS_PTR(uint32_t) list = (LDS_PTR(uint32_t))smem;
     LDS_PTR(uint32_t) bm = list + ((g.rcap + 1 + 15) & ~15);
     for (int i = lane; i < SB.bm_words; i += 64) bm[i] = 0u;
@@ -1183,6 +1184,20 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     const GrowTh th0 = grow_thresholds(g.prec);
     const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
     int nrec = 0, tn = 0, ovf = 0, nrect_band = 0;
+    if (band > 0 && SB.halo_rows > 0) {
+        // The warm-up starts from "every defined pixel ABOVE the warm-up rows is taken" (in the serial run they all are when this band's turn comes, bar the
+        // few that refine released) instead of an empty map: on an empty map the regions of the top warm-up rows grew upwards without bound -- work that
+        // cost more than the warm-up rows themselves (band waves with 5 own + 12 warm-up rows ran 1.6x as long as the 31-row first band).  Like everything the
+        // warm-up leaves, this is only the band's GUESS of what the earlier bands mark (its initial S): the commit / the validation rounds compare it with the truth.
+        const uint32_t *dm = SB.defmap + (size_t)f * SB.bm_words;
+        const int pa = max(0, y0 - SB.halo_rows) * W;                  // first pixel of the warm-up rows
+        for (int i = lane; i < ((pa + 31) >> 5); i += 64) {
+            uint32_t v = dm[i];
+            if (i == (pa >> 5) && (pa & 31)) v &= (1u << (pa & 31)) - 1u;
+            bm[i] = v;
+        }
+        CBAR();
+    }
     // phase 0 (bands > 0): the rows just above the band, unrecorded -- what they mark (regions poking into the band) is the state the band's
     // speculation starts from, handed to the commit wave as the initial S; phase 1: the band itself, recorded
     uint32_t *halo = SB.halo + fb * SB.bm_words;
@@ -1241,6 +1256,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     }
     if (BUDGET && truncated) break;
     }
+    if (SB.band_ticks && lane == 0) { SB.band_ticks[fb * 2] = (int)(wall_clock64() - t_start); SB.band_ticks[fb * 2 + 1] = tn; }
     if (SB.out) {   // validation rounds follow: what the band's own records mark (its flags minus the state its warm-up rows left) and its rectangle count
         uint32_t *outb = SB.out + fb * SB.bm_words;
         const bool had_halo = band > 0 && SB.halo_rows > 0;
@@ -2212,10 +2228,10 @@ struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
 // only a few rows, so a full wave per rectangle would idle)
 // NP = 6: the counts for rec.prec and the five halved precisions of the same geometry (stages 0 and 4); NP = 1: rec.prec only (the candidate
 // rectangles of stages 1..3 -- most of the pixel visits; the five unused comparisons per pixel were 37 % of the loop body)
-template <int NP>
+template <int NP, int G = 16>
 __device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, NfaCounts &out)
 {
-    const int lane = plf_lane() & 15;
+    const int lane = plf_lane() & (G - 1);   // G lanes per rectangle: 16 (four rectangles per wave, large batches) or the whole wave (k_nfa_fused)
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     // the four corners, kept in registers (no indexed array: that would live in scratch memory)
@@ -2272,9 +2288,9 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
 #pragma unroll
     for (int k = 0; k < NP; k++) alg[k] = 0;
     // 16 lanes = ry_n rows x rx_n interleaved columns: rectangles along the x axis have few, long rows
-    int ry_n = 16;
+    int ry_n = G;
     while (ry_n > 1 && ry_n > y_hi - y_lo + 1) ry_n >>= 1;
-    const int rx_n = 16 / ry_n, ry = lane & (ry_n - 1), rx = lane / ry_n;
+    const int rx_n = G / ry_n, ry = lane & (ry_n - 1), rx = lane / ry_n;
     for (int y = y_lo + ry; y <= y_hi; y += ry_n) {
         const long long al = max(0, min(y, lf.y) - y_lo), bl = (long long)(y - y_lo) - al;
         const long long ar = max(0, min(y, rt.y) - y_lo), br = (long long)(y - y_lo) - ar;
@@ -2307,7 +2323,7 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
 
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {  // butterfly inside the 16-lane group
+    for (int o = G / 2; o > 0; o >>= 1) {  // butterfly inside the group
         total += __shfl_xor(total, o, 64);
 #pragma unroll
         for (int k = 0; k < NP; k++) alg[k] += __shfl_xor(alg[k], o, 64);
@@ -2527,5 +2543,101 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
             e.nprec = ((r.width - delta) >= 0.5) ? 6 : 0;
             ent_out[q] = e;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rect_improve of ONE rectangle by ONE wave, all five stages in one launch (few frames in flight).  The staged kernels above put a grid-wide barrier after
+// every count / eval / math step, so a stage lasts as long as its slowest rectangle: with one frame in flight the 17 launches took 1.2-2.4 ms, most of it the
+// binomial tails of a few rectangles per stage.  Here a rectangle's chain only waits for itself: count with the whole wave (rect_count<NP, 64>), the up to six
+// NFA values of a step in six lanes, the "keep if better" chain replayed exactly as k_nfa_math does.  Same device functions, same operations, same results.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double nfa_bcast(double v, int src) { return shfl_d(v, src); }
+
+__global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const LsdRect *__restrict__ rects_all,
+                                                  const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
+{
+    const int f = blockIdx.y, lane = threadIdx.x, n_r = nrect[f];
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
+    for (int ri = blockIdx.x; ri < n_r; ri += gridDim.x) {
+        NfaState st;
+        st.rec = rects_all[(size_t)f * g.rect_cap + ri]; st.log_nfa = -1; st.frame = f; st.rect = ri;
+        if (lane == 0) keep_all[(size_t)f * g.rect_cap + ri] = 0;
+        bool done = false;
+        // ---- stage 0: the rectangle as found, at its precision and the five halved ones
+        {
+            NfaCounts c;
+            rect_count<6, 64>(ang, g.sw, g.sh, st.rec, c);
+            double v = -1.0e300;
+            if (lane < 6) {
+                double pp = st.rec.p;
+                for (int j = 0; j < lane; j++) pp /= 2;
+                v = nfa_d(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+            }
+            st.log_nfa = nfa_bcast(v, 0);
+            if (st.log_nfa > LOG_EPS) done = true;
+            else {
+                LsdRect r = st.rec;
+                for (int k = 1; k <= 5; ++k) {
+                    r.p /= 2;
+                    r.prec = r.p * PI_D;
+                    const double vk = nfa_bcast(v, k);
+                    if (vk > st.log_nfa) { st.log_nfa = vk; st.rec = r; }
+                }
+                if (st.log_nfa > LOG_EPS) done = true;
+            }
+        }
+        // ---- stages 1..3: five progressively narrower / shifted candidates each
+        for (int stage = 0; stage <= 2 && !done; stage++) {
+            // (the candidates are a progressive sequence: generated once for the counts, once more for the pick -- cheaper than holding five rectangles)
+            int tot = 0, al = 0, non = 0;     // lane k keeps the counts of candidate k; non: candidates that exist (the width test fails for good once it fails)
+            {
+                LsdRect r = st.rec;
+                for (int k = 0; k < 5; ++k) {
+                    if (!((r.width - delta) >= 0.5)) break;
+                    if (stage == 1) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+                    if (stage == 2) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+                    r.width -= delta;
+                    NfaCounts c;
+                    rect_count<1, 64>(ang, g.sw, g.sh, r, c);
+                    if (lane == k) { tot = c.total; al = c.alg[0]; }
+                    non = k + 1;
+                }
+            }
+            double v = -1.0e300;
+            if (lane < non) v = nfa_d(lgam, g.log_nt, tot, al, st.rec.p);
+            {
+                LsdRect r = st.rec;
+                for (int k = 0; k < non; ++k) {
+                    if (stage == 1) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+                    if (stage == 2) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+                    r.width -= delta;
+                    const double vk = nfa_bcast(v, k);
+                    if (vk > st.log_nfa) { st.rec = r; st.log_nfa = vk; }
+                }
+            }
+            if (st.log_nfa > LOG_EPS) done = true;
+        }
+        // ---- stage 4: finer precisions of the rectangle the width searches ended with
+        if (!done && (st.rec.width - delta) >= 0.5) {
+            NfaCounts c;
+            rect_count<6, 64>(ang, g.sw, g.sh, st.rec, c);
+            double v = -1.0e300;
+            if (lane >= 1 && lane < 6) {
+                double pp = st.rec.p;
+                for (int j = 0; j < lane; j++) pp /= 2;
+                v = nfa_d(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+            }
+            LsdRect r = st.rec;
+            for (int k = 1; k <= 5; ++k) {
+                r.p /= 2;
+                r.prec = r.p * PI_D;
+                const double vk = nfa_bcast(v, k);
+                if (vk > st.log_nfa) { st.log_nfa = vk; st.rec = r; }
+            }
+            if (st.log_nfa > LOG_EPS) done = true;
+        }
+        if (done && lane == 0) nfa_finish(st, seg_all, keep_all, g);
     }
 }
