@@ -394,7 +394,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // measured on one MI355X (VGA, frames/s with 16 / 8 / 4 / 2 bands): 8 frames 448 / 378 / 291 / 197; 32: 1277 / 1252 / 1079 / 679; 128: 3392 / 4321 /
     // 4007 / 1511; 256: 3866 / 5713 / 6800 / 5381; 512: - / 7237 / 8352 / 8856 (serial kernel: 7220); at 1024 the batch itself hides the latency
     // of the one-wave-per-frame kernel (9.8k with 2 bands vs 11.9k)
-    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 24 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
+    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // round 3 (validation rounds, fast commit): 48 / 32 bands up to 8 / 16 frames   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
     const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
@@ -458,7 +458,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         h->spec.s_global = s_global ? 1 : 0;
         h->spec.spin_bound = 1 << 21;
         if (const char *e = getenv("PLF_LSD_SPEC_SPINS")) { if (atoi(e) >= 64) h->spec.spin_bound = atoi(e); }   // test hook: a short bound must still let slow band waves finish (heartbeat)
-        h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : 16;
+        // warm-up rows above a band: 16 when a serial commit wave follows (every region it has to regrow is serial time), 4 with the validation rounds
+        // (the bands redo their conflicts in parallel; the warm-up rows are band-wave time): single VGA frame 7.2 / 7.2 / 6.8 ms with 12 / 8 / 4 rows
+        h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : (zmode ? 4 : 16);
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
         PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
@@ -485,7 +487,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             const int rounds = getenv("PLF_LSD_SPEC_ROUNDS") ? max(1, min(64, atoi(getenv("PLF_LSD_SPEC_ROUNDS")))) : 12;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
             PLF_HIP_TRY(hipMemsetAsync(h->spec.round_state, 0, (size_t)B * 4 * sizeof(int), s));
             const SpecBufs SBz = h->spec;
-            hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);
+            hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(256), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);   // (waves 1-3 warm the L2)
             for (int r = 1; r <= rounds; r++) {
                 hipLaunchKernelGGL(k_lsd_spec_round_begin, dim3((B + 63) / 64), dim3(64), 0, s, SBz, B, r);
                 hipLaunchKernelGGL(k_lsd_spec_prefix, dim3((bm_words + 255) / 256, B), dim3(256), 0, s, SBz, r);
@@ -498,7 +500,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             hipLaunchKernelGGL(budget ? k_lsd_spec_fused_budget : k_lsd_spec_fused, dim3(B * (spec_bands + 1)), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect,
                                status, g, SBn, h->d_spec_stats, B);
         } else {
-        hipLaunchKernelGGL(budget ? k_lsd_spec_grow_budget : k_lsd_spec_grow, dim3(spec_bands, B), dim3(64), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBn);
+        hipLaunchKernelGGL(budget ? k_lsd_spec_grow_budget : k_lsd_spec_grow, dim3(spec_bands, B), dim3(256), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBn);
         hipLaunchKernelGGL(budget ? k_lsd_spec_commit_budget : k_lsd_spec_commit, dim3(B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy, h->d_rects, nrect, status, g,
                            SBn, h->d_spec_stats);
         }

@@ -179,11 +179,13 @@ def test_rgbd_frame_constructor_batch():
     bx.close()
 
 
-def test_chunk_redo_when_the_rectangle_pool_overflows():
+def test_chunk_redo_when_the_rectangle_pool_overflows(monkeypatch):
     """Eight frames of hard-edged stripes hold more LSD rectangles than the pooled NFA buffers of an 8-frame batch (PLF_E_RECTS): the worker redoes
     the chunk through the splitting entry point and repeats the Frame tail and the line matching on the fresh lines; a normal chunk follows in the
-    same call (slot reuse after a redo)."""
+    same call (slot reuse after a redo).  (PLF_NFA_FUSED=0: the staged NFA kernels of the large batches -- up to 64 frames in flight normally take the
+    one-wave-per-rectangle kernel, which has no pool.)"""
     _need_gpu()
+    monkeypatch.setenv("PLF_NFA_FUSED", "0")
     from rgbd_pl_slam_amd.batch import BatchExtractor
     from rgbd_pl_slam_amd.frame import camera, TUM1
     from rgbd_pl_slam_amd.synth import synth_frame
@@ -301,10 +303,11 @@ def test_four_workers_on_one_gpu_config4_shape():
     bx.close()
 
 
-def test_rectangle_pool_redo_in_one_worker_while_the_other_runs():
+def test_rectangle_pool_redo_in_one_worker_while_the_other_runs(monkeypatch):
     """PLF_E_RECTS redo (host-memory re-extraction in halves + line matching on the fresh lines) inside worker 0 while worker 1 processes normal frames on the
     same GPU; lines-only batch with map lines -- the mvScaleFactors table no longer depends on an ORB handle"""
     _need_gpu()
+    monkeypatch.setenv("PLF_NFA_FUSED", "0")      # the staged NFA kernels (pooled buffers): what chunks of more than 64 frames take
     from rgbd_pl_slam_amd.batch import BatchExtractor
     from rgbd_pl_slam_amd.synth import synth_frame
     rng = np.random.default_rng(77000 + 246)

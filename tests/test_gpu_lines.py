@@ -317,7 +317,7 @@ def test_lines_speculative_halo_rows(monkeypatch, halo, schedule):
     ext.close()
 
 
-def test_lines_thousands_of_rectangles():
+def test_lines_thousands_of_rectangles(monkeypatch):
     """Textures of thousands of tiny regions: the rectangle capacity is the exact bound sw*sh/min_reg_size (a 4096-rectangle cap used to fail on the
     first image, found by tools/soak.py seed 246), and frames with more than 4096 segments sort through the global scratch row."""
     _need_gpu()
@@ -344,12 +344,22 @@ def test_lines_thousands_of_rectangles():
     res = ls8.extract_batch(np.stack([stripes] * 8))
     for f in range(8):
         assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"])
-    # ... and the fully device-resident call reports it
+    # ... and the fully device-resident call reports it.  (Up to 64 frames in flight take the one-wave-per-rectangle NFA kernel, which has no pooled buffers
+    # and therefore no such limit: checked first.  PLF_NFA_FUSED=0 selects the staged kernels of the large batches for the rest.)
     import torch
     from rgbd_pl_slam_amd import _lib as L
     d_img = torch.from_numpy(np.stack([stripes] * 8)).cuda()
     d_lines = torch.zeros(8 * 100 * 68, dtype=torch.uint8, device="cuda"); d_desc = torch.zeros(8 * 100 * 32, dtype=torch.uint8, device="cuda")
     d_eq = torch.zeros(8 * 100 * 3, dtype=torch.float64, device="cuda"); d_n = torch.zeros(8, dtype=torch.int32, device="cuda")
+    ls8.extract_batch_device(d_img, 640, 480, d_lines, d_desc, d_eq, d_n, 100)
+    assert ls8.last_status() == L.PLF_OK
+    for f in (0, 7):
+        got = np.frombuffer(d_lines.cpu().numpy().tobytes(), L.KL_DTYPE)[f * 100:f * 100 + int(d_n[f])]
+        assert got.tobytes() == ref["kl"].tobytes()
+    monkeypatch.setenv("PLF_NFA_FUSED", "0")
+    res = ls8.extract_batch(np.stack([stripes] * 8))          # staged kernels: the pool overflows, the host-buffer call splits the batch
+    for f in range(8):
+        assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"])
     ls8.extract_batch_device(d_img, 640, 480, d_lines, d_desc, d_eq, d_n, 100)
     assert ls8.last_status() == L.PLF_E_RECTS
     ls8.extract_batch_device(d_img[:2], 640, 480, d_lines, d_desc, d_eq, d_n, 100)
