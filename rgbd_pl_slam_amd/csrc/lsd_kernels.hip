@@ -2571,9 +2571,105 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double nfa_bcast(double v, int src) { return shfl_d(v, src); }
 
+// nfa_d in three pieces, so that the long exit-free part of the binomial tail can be shared by the wave.  A rectangle of n pixels needs about n / 2 - k tail
+// iterations, each `term *= ((n - i + 1) / i) * p_term; bin_tail += term`; for the large, sparse rectangles that go through all five stages that is 10^4
+// iterations per NFA value, and the fp64 division -- 14 of the 17 instructions of an iteration -- does not depend on the running product at all.  So the up to six
+// chains of a step (lanes 0..5) run in lock step and ALL 64 lanes compute the divisions of the next 512 iterations of every chain into LDS first; the chain lanes
+// then only multiply and add.  Every operation and its order inside a chain are those of nfa_d (the division is the same IEEE operation whichever lane does it).
+struct NfaIt { double term, bin_tail, p_term, val; int i, n, iend; bool live; };
+#define NFA_COOP_BLK 512
+
+__device__ __forceinline__ NfaIt nfa_head(const double *__restrict__ lgam, double LOG_NT, int n, int k, double p)
+{
+    NfaIt it;
+    it.live = false; it.term = it.bin_tail = it.p_term = 0.0; it.i = it.iend = 0; it.n = n;
+    if (n == 0 || k == 0) { it.val = -LOG_NT; return it; }
+    if (n == k) { it.val = -LOG_NT - (double)n * log10(p); return it; }
+    it.p_term = p / (1 - p);
+    const double log1term = log_gamma_int(lgam, n + 1) - log_gamma_int(lgam, k + 1) - log_gamma_int(lgam, n - k + 1) +
+                            (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    const double term = exp(log1term);
+    if (double_equal_d(term, 0)) {
+        it.val = ((double)k > (double)n * p) ? -log1term / 2.30258509299404568402 - LOG_NT : -LOG_NT;
+        return it;
+    }
+    it.live = true; it.term = term; it.bin_tail = term;
+    int i = k + 1;
+    it.i = i;
+    // the iterations nfa_d takes without an exit test (its blocks of 8, then of 4)
+    while (i + 7 <= n && n - (i + 7) + 1 >= i + 7) i += 8;
+    while (i + 3 <= n && n - (i + 3) + 1 >= i + 3) i += 4;
+    it.iend = i;
+    return it;
+}
+
+// all 64 lanes; `it` of a lane that runs no chain has live == false.  tab: NFA_COOP_BLK doubles per chain lane (lanes 0..5)
+__device__ __forceinline__ void nfa_coop(NfaIt &it, LDS_PTR(double) tab)
+{
+    const int lane = plf_lane();
+    int done_j = 0;                                                   // iterations of the exit-free part already taken (the same for every chain: lock step)
+    const int len = it.live ? it.iend - it.i : 0;
+    int maxlen = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    while (done_j < maxlen) {
+        // divisions of the next block of every chain
+        for (int c = 0; c < 6; c++) {
+            const int len_c = __builtin_amdgcn_readlane(len, c);
+            if (len_c <= done_j) continue;
+            const int n_c = __builtin_amdgcn_readlane(it.n, c), i_c = __builtin_amdgcn_readlane(it.i, c);   // (it.i: first iteration of the chain's exit-free part)
+            const int cnt = min(NFA_COOP_BLK, len_c - done_j);
+            for (int j = lane; j < cnt; j += 64) {
+                const int i = i_c + done_j + j;
+                tab[c * NFA_COOP_BLK + j] = (double)(n_c - i + 1) / (double)i;
+            }
+        }
+        CBAR();
+        if (lane < 6 && len > done_j) {
+            const int cnt = min(NFA_COOP_BLK, len - done_j);
+            LDS_PTR(double) tb = tab + lane * NFA_COOP_BLK;
+            double term = it.term, bin_tail = it.bin_tail;
+            const double p_term = it.p_term;
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {
+                const double m0 = tb[j] * p_term, m1 = tb[j + 1] * p_term, m2 = tb[j + 2] * p_term, m3 = tb[j + 3] * p_term;
+                term *= m0; bin_tail += term;
+                term *= m1; bin_tail += term;
+                term *= m2; bin_tail += term;
+                term *= m3; bin_tail += term;
+            }
+            for (; j < cnt; j++) { const double m0 = tb[j] * p_term; term *= m0; bin_tail += term; }
+            it.term = term; it.bin_tail = bin_tail;
+        }
+        CBAR();
+        done_j += NFA_COOP_BLK;
+    }
+}
+
+__device__ __forceinline__ double nfa_tail(const NfaIt &it, double LOG_NT)
+{
+    if (!it.live) return it.val;
+    const int n = it.n;
+    double term = it.term, bin_tail = it.bin_tail;
+    const double p_term = it.p_term, tolerance = 0.1;
+    for (int i = it.iend; i <= n; ++i) {
+        const double bin_term = (double)(n - i + 1) / (double)i;
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            const double err = term * ((1 - pow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - LOG_NT;
+}
+
 __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const LsdRect *__restrict__ rects_all,
                                                   const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
 {
+    __shared__ double tab_s[6 * NFA_COOP_BLK];
+    LDS_PTR(double) tab = (LDS_PTR(double))tab_s;
     const int f = blockIdx.y, lane = threadIdx.x, n_r = nrect[f];
     const float *ang = ang_all + (size_t)f * g.s_stride;
     const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
@@ -2587,10 +2683,15 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
             NfaCounts c;
             rect_count<6, 64>(ang, g.sw, g.sh, st.rec, c);
             double v = -1.0e300;
-            if (lane < 6) {
-                double pp = st.rec.p;
-                for (int j = 0; j < lane; j++) pp /= 2;
-                v = nfa_d(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+            {
+                NfaIt it; it.live = false; it.n = 0; it.i = it.iend = 0; it.val = v;
+                if (lane < 6) {
+                    double pp = st.rec.p;
+                    for (int j = 0; j < lane; j++) pp /= 2;
+                    it = nfa_head(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+                }
+                nfa_coop(it, tab);
+                if (lane < 6) v = nfa_tail(it, g.log_nt);
             }
             st.log_nfa = nfa_bcast(v, 0);
             if (st.log_nfa > LOG_EPS) done = true;
@@ -2623,7 +2724,12 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
                 }
             }
             double v = -1.0e300;
-            if (lane < non) v = nfa_d(lgam, g.log_nt, tot, al, st.rec.p);
+            {
+                NfaIt it; it.live = false; it.n = 0; it.i = it.iend = 0; it.val = v;
+                if (lane < non) it = nfa_head(lgam, g.log_nt, tot, al, st.rec.p);
+                nfa_coop(it, tab);
+                if (lane < non) v = nfa_tail(it, g.log_nt);
+            }
             {
                 LsdRect r = st.rec;
                 for (int k = 0; k < non; ++k) {
@@ -2641,10 +2747,15 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
             NfaCounts c;
             rect_count<6, 64>(ang, g.sw, g.sh, st.rec, c);
             double v = -1.0e300;
-            if (lane >= 1 && lane < 6) {
-                double pp = st.rec.p;
-                for (int j = 0; j < lane; j++) pp /= 2;
-                v = nfa_d(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+            {
+                NfaIt it; it.live = false; it.n = 0; it.i = it.iend = 0; it.val = v;
+                if (lane >= 1 && lane < 6) {
+                    double pp = st.rec.p;
+                    for (int j = 0; j < lane; j++) pp /= 2;
+                    it = nfa_head(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+                }
+                nfa_coop(it, tab);
+                if (lane >= 1 && lane < 6) v = nfa_tail(it, g.log_nt);
             }
             LsdRect r = st.rec;
             for (int k = 1; k <= 5; ++k) {
