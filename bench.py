@@ -425,7 +425,7 @@ def main():
         # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
         traffic, traffic_source = None, None
         try:
-            src = os.path.join("profiles", "r02_pmc_traffic.json")
+            src = os.path.join("profiles", "r03_pmc_traffic.json")
             with open(os.path.join(ROOT, src)) as fh:
                 pmc = json.load(fh)
             if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):

@@ -1021,28 +1021,43 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat_budget(float *__restric
 // (SpecRec / SpecBufs: lsd_geom.h, shared with line_host.hip)
 
 // append the current region list [0, n) as pixel indices
-__device__ __forceinline__ void spec_append(const RegCtx &C, int n, uint32_t *__restrict__ dst, int &tn, int cap, int &ovf)
+// (mark: OR-ed into every entry -- the band waves log "still marked at the end of the seed" optimistically, see spec_grow_body; bb: per-lane partial bounding box
+// x0, y0, x1, y1 of the appended pixels, or nullptr)
+struct SpecBB { int x0, y0, x1, y1; };
+__device__ __forceinline__ void spec_append(const RegCtx &C, int n, uint32_t *__restrict__ dst, int &tn, int cap, int &ovf, uint32_t mark, SpecBB &bb)
 {
     if (tn + n > cap) { ovf = 1; return; }
-    for (int i = plf_lane(); i < n; i += 64) { const uint32_t q = rxy_get(C, i); dst[tn + i] = (q >> 16) * (uint32_t)C.W + (q & 0xFFFFu); }
+    for (int i = plf_lane(); i < n; i += 64) {
+        const uint32_t q = rxy_get(C, i);
+        const int qx = (int)(q & 0xFFFFu), qy = (int)(q >> 16);
+        dst[tn + i] = ((uint32_t)qy * (uint32_t)C.W + (uint32_t)qx) | mark;
+        bb.x0 = min(bb.x0, qx); bb.y0 = min(bb.y0, qy); bb.x1 = max(bb.x1, qx); bb.y1 = max(bb.y1, qy);
+    }
     tn += n;
 }
 
 // the per-seed pipeline of the serial loop; the accepted pixels go to dst[t0 ..) (first growth, then the regrowth of refine)
 __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th0, int seed, float sdeg, float2 sc0, LsdRect &rec, uint32_t *__restrict__ dst,
-                                          int &tn, int cap, int &ovf)
+                                          int &tn, int cap, int &ovf, uint32_t mark, SpecBB &bb)
 {
     double reg_angle;
+    C.regrow_n = -1;
     int n = region_grow(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
     CBAR();
-    spec_append(C, n, dst, tn, cap, ovf);
+    spec_append(C, n, dst, tn, cap, ovf, mark, bb);
     if (n < g.min_reg_size) return false;
     region2rect(C, n, reg_angle, g.prec, g.p, rec);
-    C.regrow_n = -1;
     const bool okr = refine(C, n, reg_angle, g.prec, g.p, rec, 0.7);
     CBAR();
-    if (C.regrow_n >= 0) spec_append(C, C.regrow_n, dst, tn, cap, ovf);   // (reduce_region_radius only permutes that list)
+    if (C.regrow_n >= 0) spec_append(C, C.regrow_n, dst, tn, cap, ovf, mark, bb);   // (reduce_region_radius only permutes that list)
     return okr;
+}
+
+__device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th0, int seed, float sdeg, float2 sc0, LsdRect &rec, uint32_t *__restrict__ dst,
+                                          int &tn, int cap, int &ovf)
+{
+    SpecBB bb = {0, 0, 0, 0};
+    return spec_seed(C, g, th0, seed, sdeg, sc0, rec, dst, tn, cap, ovf, 0u, bb);
 }
 
 __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, float *ang_all, const double *modgrad_all, const double2 *cs_all, const float2 *cs0_all,
@@ -1240,17 +1255,21 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
             LsdRect rec;
             const int t0 = tn;
             if (lane == 0) __hip_atomic_store(&SB.cnt[fb * 4 + 3], seed + 1 + (phase << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // heartbeat (spec_wait_band)
-            const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf);
+            // every accepted pixel is logged as "still marked at the end of the seed" right away -- true unless refine released pixels (it regrew the region:
+            // C.regrow_n >= 0, ~10 % of the large regions), in which case the entries are re-read and corrected; the bounding box comes out of the append
+            // itself.  (Reading every log back to set the flag and find the box cost a global round trip per seed.)
+            SpecBB bb = {W, H, -1, -1};
+            const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf, record ? 0x40000000u : 0u, bb);
             if (!record) { tn = 0; ovf = 0; }
             if (record && nrec >= SB.rcap_rec) ovf = 1;
             if (record && okr) nrect_band++;
             if (record && !ovf) {
-                int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
-                for (int i = t0 + lane; i < tn; i += 64) {
-                    const uint32_t q = tl[i];
-                    const int qx = (int)(q % (uint32_t)W), qy = (int)(q / (uint32_t)W);
-                    bx0 = min(bx0, qx); bx1 = max(bx1, qx); by0 = min(by0, qy); by1 = max(by1, qy);
-                    if ((bm[q >> 5] >> (q & 31)) & 1u) tl[i] = q | 0x40000000u;
+                int bx0 = bb.x0, by0 = bb.y0, bx1 = bb.x1, by1 = bb.y1;
+                if (C.regrow_n >= 0) {
+                    for (int i = t0 + lane; i < tn; i += 64) {
+                        const uint32_t q = tl[i] & 0x3FFFFFFFu;
+                        if (!((bm[q >> 5] >> (q & 31)) & 1u)) tl[i] = q;
+                    }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {

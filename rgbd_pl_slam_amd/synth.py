@@ -65,27 +65,35 @@ def synth_batch(seed0, n, w=640, h=480):
     return np.stack([synth_frame(seed0 + i, w, h) for i in range(n)])
 
 
-def _synth_job(args):
-    seed, w, h = args
-    return synth_frame(seed, w, h)
-
-
 def synth_batch_parallel(seed0, n, w=640, h=480, workers=0):
-    """synth_batch on a pool of worker processes (a VGA frame costs ~70 ms of numpy: a thousand distinct frames for bench.py would take a
-    minute on one core).  'spawn' start method: safe after the parent initialised HIP; falls back to the serial loop for small n."""
-    import os
+    """synth_batch on worker PROCESSES (a VGA frame costs ~70 ms of numpy: a thousand distinct frames for bench.py would take a minute on one core).
+    The workers are plain `python -m rgbd_pl_slam_amd.synth` subprocesses writing .npy files -- no fork after the parent initialised HIP, and no
+    multiprocessing re-import of the caller's main script (a tool without a __main__ guard would run again in every worker).  Falls back to the serial
+    loop for small n or when subprocesses are not available."""
+    import os, subprocess, sys, tempfile
     if workers <= 0:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         workers = max(1, min(48, cores // 2, n // 8))
     if workers <= 1 or n < 16:
         return synth_batch(seed0, n, w, h)
-    import multiprocessing as mp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
-        with mp.get_context("spawn").Pool(workers) as pool:
-            frames = pool.map(_synth_job, [(seed0 + i, w, h) for i in range(n)], chunksize=max(1, n // (4 * workers)))
-    except Exception:          # (no process pool available: sandboxed hosts)
+        with tempfile.TemporaryDirectory(prefix="plf_synth_") as tmp:
+            procs = []
+            for k in range(workers):
+                lo, hi = k * n // workers, (k + 1) * n // workers
+                if hi > lo:
+                    out = os.path.join(tmp, "part%03d.npy" % k)
+                    procs.append((out, subprocess.Popen([sys.executable, "-m", "rgbd_pl_slam_amd.synth", str(seed0 + lo), str(hi - lo), str(w), str(h), out],
+                                                        cwd=root, env=dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", "")))))
+            parts = []
+            for out, pr in procs:
+                if pr.wait() != 0:
+                    raise RuntimeError("synth worker failed")
+                parts.append(np.load(out))
+        return np.concatenate(parts)
+    except Exception:          # (no subprocesses available: sandboxed hosts)
         return synth_batch(seed0, n, w, h)
-    return np.stack(frames)
 
 
 def texture_frame(seed, kind=None, size=None):
@@ -136,3 +144,9 @@ def texture_frame(seed, kind=None, size=None):
         img = base.copy(); b = int(rng.integers(1, 30)); img[:b] = 0; img[-b:] = 255; img[:, :b] = 255; img[:, -b:] = 0
         img[h // 3:h // 2, w // 3:w // 2] = 255
     return np.ascontiguousarray(img), kind
+
+
+if __name__ == "__main__":      # worker of synth_batch_parallel: seed0 n w h out.npy
+    import sys
+    _s0, _n, _w, _h = (int(x) for x in sys.argv[1:5])
+    np.save(sys.argv[5], synth_batch(_s0, _n, _w, _h))
