@@ -47,7 +47,8 @@ __global__ void k_blur5_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, 
 __global__ void k_lbd(const short2 *, const plf_keyline *, const int *, uint8_t *, int, LsdGeom, const LbdCoefs *);
 
 __global__ void k_lsd_spec_fused(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
-__global__ void k_lsd_spec_bands(const float *, LsdGeom, SpecBufs);
+__global__ void k_lsd_spec_rows(const float *, LsdGeom, SpecBufs, int *);
+__global__ void k_lsd_spec_bands(LsdGeom, SpecBufs, const int *, int *);
 __global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_commit(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
 __global__ void k_lsd_spec_commit_rest(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
@@ -62,6 +63,7 @@ struct plf_line {
     int spec_frames;          // frames the buffers were sized for (0: not allocated, -1: allocation failed / disabled)
     size_t fused_lds, fused_capacity;   // k_lsd_spec_fused: workgroups of that LDS size the GPU can hold at once (occupancy query)
     int *d_spec_stats;
+    int *d_spec_rowcnt;       // [frames][1024] defined pixels per row unit, then [frames][64][65] scratch of the band sweep
     int device;
     LsdGeom g;
     LsdTaps taps;
@@ -117,7 +119,7 @@ static void line_free(plf_line *h)
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks};
+                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -418,10 +420,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out))) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks};
+                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
-        memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr;
+        memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr; h->d_spec_rowcnt = nullptr;
         size_t Fr = 8;   // frames the buffers are sized for: the batch rounded up to a power of two (~23 MB per VGA frame)
         while (Fr < (size_t)B) Fr <<= 1;
         const size_t K = (size_t)spec_bands;
@@ -440,7 +442,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                   hipMalloc((void **)&h->spec.side, Fr * K * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.band_ticks, Fr * K * 2 * sizeof(int)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.halo, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
-                  hipMalloc((void **)&h->d_spec_stats, (Fr * 8 + 200) * sizeof(int)) == hipSuccess;
+                  hipMalloc((void **)&h->d_spec_stats, (Fr * 8 + 200) * sizeof(int)) == hipSuccess &&
+                  hipMalloc((void **)&h->d_spec_rowcnt, Fr * (1024 + 64 * 65) * sizeof(int)) == hipSuccess;
         if (ok && zmode) {
             ok = hipMalloc((void **)&h->spec.out, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.pre, Fr * K * (size_t)bm_words * sizeof(uint32_t)) == hipSuccess &&
@@ -479,7 +482,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         const bool fused = !zmode && (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !getenv("PLF_LSD_SPEC_NOFUSE");
         h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
         PLF_HIP_TRY(hipMemsetAsync(h->spec.side, 0, (size_t)B * spec_bands * sizeof(int), s));
-        hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(1024), 0, s, h->d_ang, g, h->spec);
+        // band boundaries: row counts + defined-pixel bitmap over the whole frame in parallel, then one wave per frame balances the bands
+        PLF_HIP_TRY(hipMemsetAsync(h->d_spec_rowcnt, 0, (size_t)B * 1024 * sizeof(int), s));
+        hipLaunchKernelGGL(k_lsd_spec_rows, dim3((bm_words * 32 + 255) / 256, B), dim3(256), 0, s, h->d_ang, g, h->spec, h->d_spec_rowcnt);
+        hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(64), 0, s, g, h->spec, h->d_spec_rowcnt, h->d_spec_rowcnt + (size_t)h->spec_frames * 1024);
         SpecBufs SBn = h->spec; SBn.out = nullptr; SBn.round_state = nullptr;   // (schedules without validation rounds: the band waves skip their part of them)
         if (zmode) {
             // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;

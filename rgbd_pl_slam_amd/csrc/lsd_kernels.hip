@@ -1100,79 +1100,80 @@ __device__ __forceinline__ int spec_band_sweep(const int *__restrict__ P, int ro
     return 1;
 }
 
-__global__ void __launch_bounds__(1024) k_lsd_spec_bands(const float *__restrict__ ang_all, LsdGeom g, SpecBufs SB)
+// (1) per-row counts of the defined pixels + the bitmap of the defined pixels (the angle words are read-only in this mode: the commit / validation waves walk
+// the bitmap instead of the angle map).  One wave per 64 pixels, the whole frame in parallel.  rowcnt[f][unit] must be zero on entry (the host clears it).
+__global__ void __launch_bounds__(256) k_lsd_spec_rows(const float *__restrict__ ang_all, LsdGeom g, SpecBufs SB, int *__restrict__ rowcnt)
 {
-    __shared__ int cnt[1024 + 1];
-    __shared__ int scan[2][1024];
-    const int f = blockIdx.x, t = threadIdx.x, W = g.sw, H = g.sh;
-    const uint32_t *ang = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
-    const int rows = H - 1;
+    const int f = blockIdx.y, W = g.sw, H = g.sh, rows = H - 1;
     const int ru = (rows + 1023) / 1024;      // rows per counting unit: 1 up to 1024 rows
+    const uint32_t *ang = reinterpret_cast<const uint32_t *>(ang_all) + (size_t)f * g.s_stride;
+    uint32_t *dm = SB.defmap + (size_t)f * SB.bm_words;
+    const int p0 = (blockIdx.x * 256 + (threadIdx.x & ~63));      // first pixel of this wave's 64
+    if (p0 >= SB.bm_words * 32) return;
+    const int p = p0 + (threadIdx.x & 63);
+    const bool def = p < W * H && ang[p] < 0x80000000u;
+    const unsigned long long m = __ballot(def);
+    if ((threadIdx.x & 63) == 0) {
+        dm[p0 >> 5] = (uint32_t)m;
+        if ((p0 >> 5) + 1 < SB.bm_words) dm[(p0 >> 5) + 1] = (uint32_t)(m >> 32);
+        // the 64 pixels lie in one row or straddle a few (narrow frames): count per row
+        unsigned long long rest = m;
+        int q = p0;
+        while (rest && q < W * rows) {
+            const int row = q / W, in_row = min(64 - (q - p0), (row + 1) * W - q);
+            const unsigned long long mk = in_row >= 64 ? ~0ull : (((1ull << in_row) - 1ull) << (q - p0));
+            const int c = __popcll(rest & mk);
+            if (c) atomicAdd(&rowcnt[f * 1024 + min(row / ru, 1023)], c);
+            rest &= ~mk;
+            q += in_row;
+        }
+    }
+}
+
+// (2) the boundaries: prefix sums of the row counts, then the 64 lanes try 64 cost bounds at once (greedy sweep, binary searches in the prefix sums); the lane
+// with the smallest feasible bound has the answer (each lane keeps the boundaries of its own sweep in a scratch row)
+__global__ void __launch_bounds__(64) k_lsd_spec_bands(LsdGeom g, SpecBufs SB, const int *__restrict__ rowcnt, int *__restrict__ sweep_scratch)
+{
+    __shared__ int P[1024 + 1];
+    const int f = blockIdx.x, t = threadIdx.x, H = g.sh;
+    const int rows = H - 1;
+    const int ru = (rows + 1023) / 1024;
     const int units = (rows + ru - 1) / ru;
-    cnt[t] = 0;
-    if (t == 0) cnt[1024] = 0;
+    // exclusive prefix sums over the units, 16 per lane + a wave scan of the lane totals
+    int v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int u = t * 16 + k; v[k] = u < units ? rowcnt[f * 1024 + u] : 0; sum += v[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(incl, o, 64); if (t >= o) incl += x; }
+    int run = incl - sum;
+    if (t == 0) P[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { run += v[k]; P[t * 16 + k + 1] = run; }
     __syncthreads();
-    if ((W & 3) == 0 && (g.s_stride & 3) == 0) {   // four pixels of one row per load, one LDS atomic per thread and step
-        const uint4 *a4 = reinterpret_cast<const uint4 *>(ang);
-        for (int q = t; q < (W >> 2) * rows; q += 1024) {
-            const uint4 v = a4[q];
-            const int c = (v.x < 0x80000000u) + (v.y < 0x80000000u) + (v.z < 0x80000000u) + (v.w < 0x80000000u);
-            if (c) atomicAdd(&cnt[min((q / (W >> 2)) / ru, 1023)], c);
-        }
-    } else {
-        for (int a = t; a < W * rows; a += 1024) if (ang[a] < 0x80000000u) atomicAdd(&cnt[min((a / W) / ru, 1023)], 1);
-    }
-    // bitmap of the defined pixels (the angle words are read-only in this mode): the commit wave walks it instead of the angle map
-    {
-        uint32_t *dm = SB.defmap + (size_t)f * SB.bm_words;
-        for (int p0 = (t >> 6) * 64; p0 < SB.bm_words * 32; p0 += 1024) {
-            const int p = p0 + (t & 63);
-            const unsigned long long m = __ballot(p < W * H && ang[p] < 0x80000000u);
-            if ((t & 63) == 0) { dm[p0 >> 5] = (uint32_t)m; if ((p0 >> 5) + 1 < SB.bm_words) dm[(p0 >> 5) + 1] = (uint32_t)(m >> 32); }
-        }
-    }
-    __syncthreads();
-    // exclusive prefix sums over the units: P[u] = defined pixels in units [0, u)
-    int v = cnt[t];
-    scan[0][t] = v;
-    __syncthreads();
-    int cur = 0;
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int x = scan[cur][t] + (t >= o ? scan[cur][t - o] : 0);
-        scan[cur ^ 1][t] = x;
-        cur ^= 1;
-        __syncthreads();
-    }
-    const int incl = scan[cur][t];
-    __syncthreads();
-    cnt[t + 1] = incl;        // cnt[] becomes P[0 .. 1024]
-    if (t == 0) cnt[0] = 0;
-    __syncthreads();
-    if (t >= 64) return;
     const int nb = SB.nbands, halo_u = (SB.halo_rows + ru - 1) / ru;
-    const int total = cnt[units];
+    const int total = P[units];
     int *by = SB.band_y + f * (nb + 1);
-    // bound on the cost per unit weight: between 0 and the whole frame (plus halos) on the lightest band
-    float lo = 0.f, hi = (float)total + 1.f;
-    for (int pass = 0; pass < 2; pass++) {
-        const float C = lo + (hi - lo) * (float)(t + 1) / 64.f;
-        const int ok = units >= nb ? spec_band_sweep(cnt, units, nb, halo_u, SB.stagger, C, nullptr) : 0;
-        const unsigned long long m = __ballot(ok != 0);
-        if (!m) break;                                  // (cannot happen for hi = total + 1 with units >= nb)
-        const int first = __ffsll((long long)m) - 1;    // smallest feasible bound of this pass
-        const float nlo = lo + (hi - lo) * (float)first / 64.f, nhi = lo + (hi - lo) * (float)(first + 1) / 64.f;
-        lo = nlo; hi = nhi;
+    int *mine = sweep_scratch + ((size_t)f * 64 + t) * 65;
+    // bound per unit weight: between the mean own cost of a band and (generously) three times that plus the heaviest warm-up
+    const float wsum = (float)nb + SB.stagger * (float)nb * (float)(nb - 1) * 0.5f;
+    const float lo = (float)total / wsum * 0.98f, hi = (float)total / wsum * 3.0f + (float)total / (float)max(units, 1) * (float)(halo_u + 2) + 64.f;
+    int ok = 0;
+    float C = lo + (hi - lo) * (float)t / 63.f;
+    if (t == 63) C = (float)total + 1.f;               // always feasible
+    if (units >= nb) ok = spec_band_sweep(P, units, nb, halo_u, SB.stagger, C, mine);
+    const unsigned long long m = __ballot(ok != 0);
+    if (units >= nb && m) {
+        const int win = __ffsll((long long)m) - 1;
+        __threadfence();
+        const int *src = sweep_scratch + ((size_t)f * 64 + win) * 65;
+        for (int b = 1 + t; b <= nb; b += 64) by[b] = min(__hip_atomic_load(&src[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * ru, rows);
+    } else {
+        for (int b = 1 + t; b <= nb; b += 64) by[b] = (int)((long long)rows * b / nb);   // fewer units than bands (the host excludes it): equal rows
     }
-    if (t == 0) {
-        by[0] = 0;
-        if (units >= nb && spec_band_sweep(cnt, units, nb, halo_u, SB.stagger, hi, by)) {
-            for (int b = 1; b <= nb; b++) by[b] = min(by[b] * ru, rows);
-        } else {   // fewer units than bands (the host excludes it) -- equal rows
-            for (int b = 1; b <= nb; b++) by[b] = (int)((long long)rows * b / nb);
-        }
-        by[nb] = rows;
-        for (int b = 1; b <= nb; b++) by[b] = max(by[b], by[b - 1]);
-    }
+    if (t == 0) { by[0] = 0; }
+    __syncthreads();
+    if (t == 0) { by[nb] = rows; for (int b = 1; b <= nb; b++) by[b] = max(by[b], by[b - 1]); }
 }
 
 template <bool BUDGET>
