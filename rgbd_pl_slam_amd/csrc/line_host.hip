@@ -62,6 +62,7 @@ struct plf_line {
     SpecBufs spec;            // banded speculative region growing (few frames in flight); allocated on first use
     int spec_frames;          // frames the buffers were sized for (0: not allocated, -1: allocation failed / disabled)
     size_t fused_lds, fused_capacity;   // k_lsd_spec_fused: workgroups of that LDS size the GPU can hold at once (occupancy query)
+    int n_cus;                // compute units of the device (queried on first use)
     int *d_spec_stats;
     int *d_spec_rowcnt;       // [frames][1024] defined pixels per row unit, then [frames][64][65] scratch of the band sweep
     int device;
@@ -396,7 +397,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // measured on one MI355X (VGA, frames/s with 16 / 8 / 4 / 2 bands): 8 frames 448 / 378 / 291 / 197; 32: 1277 / 1252 / 1079 / 679; 128: 3392 / 4321 /
     // 4007 / 1511; 256: 3866 / 5713 / 6800 / 5381; 512: - / 7237 / 8352 / 8856 (serial kernel: 7220); at 1024 the batch itself hides the latency
     // of the one-wave-per-frame kernel (9.8k with 2 bands vs 11.9k)
-    const int spec_bands = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // round 3 (validation rounds, fast commit): 48 / 32 bands up to 8 / 16 frames   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
+    const int spec_bands_req = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // round 3 (validation rounds, fast commit): 48 / 32 bands up to 8 / 16 frames   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
     const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
@@ -404,6 +405,15 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const bool s_global = (size_t)(list_words + 2 * bm_words + coarse_words + 5 * 512 + 512 / 32 + 1024 + 33) * 4 + 64 > 150 * 1024;
     const int commit_extra = 5 * 512 + 512 / 32 + 1024 + 1 + 16 + 16;   // SPEC_COMMIT_EXTRA_WORDS of lsd_kernels.hip (+ the 16-word alignment of the tile map): record headers, SUSPECT mask, "defined, no record" bits
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words + commit_extra) * 4 + 64;
+    int spec_bands = spec_bands_req;
+    if (!getenv("PLF_LSD_SPEC_BANDS") && B <= 16) {
+        // every band workgroup of the batch should be resident at once: a band wave and its validation hold the frame's flag bitmap(s) in LDS -- 29 / 68 KB at
+        // VGA, 103 / 119 KB at 1280x960, i.e. one workgroup per CU there: 8 such frames x 48 bands ran as two rounds of workgroups (277 frames/s; 372 with 32 bands)
+        const int per_cu = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max(lds_grow, lds_commit));
+        if (h->n_cus <= 0) { hipDeviceProp_t prop; h->n_cus = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256; (void)hipGetLastError(); }
+        const int fit = h->n_cus * per_cu / B;
+        if (fit < spec_bands) spec_bands = std::max(8, fit & ~7);
+    }
     bool spec = !seeds && g.sh <= 8192 && (g.sh - 1) / 4 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     // validation rounds instead of the serial commit wave (k_lsd_spec_validate): up to PLF_LSD_SPEC_Z frames in flight (16), never with a time budget
     const int zmax = getenv("PLF_LSD_SPEC_Z") ? atoi(getenv("PLF_LSD_SPEC_Z")) : 16;

@@ -135,6 +135,12 @@ KSX(k_cmpcnd_sgpr, A_CMPCND_SGPR)
 KSX(k_addco_vcc, A_ADDCO)
 KSX(k_addc_vcc, A_ADDC)
 KSX(k_addco_sgpr, A_ADDCO_SGPR)
+#define A_CMP2CND_VCC(i) "v_cmp_lt_u32_e32 vcc, %10, %" #i "\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\n"
+#define A_CMP4CND_VCC(i) "v_cmp_lt_u32_e32 vcc, %10, %" #i "\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\n"
+#define A_CMP2CND_MIX(i) "v_cmp_lt_u32_e32 vcc, %10, %" #i "\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\nv_add_u32 %" #i ", %" #i ", %10\nv_cndmask_b32_e32 %" #i ", %" #i ", %10, vcc\n"
+KSX(k_cmp2cnd_vcc, A_CMP2CND_VCC)
+KSX(k_cmp4cnd_vcc, A_CMP4CND_VCC)
+KSX(k_cmp2cnd_mix, A_CMP2CND_MIX)
 __global__ void __launch_bounds__(1024) k_cndmask_vcc_init(uint32_t *out, int iters, uint32_t b, uint32_t c, unsigned long long *clk)
 {
     uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
@@ -228,6 +234,9 @@ int main()
         {"v_cndmask_b32_e64 (vcc as explicit operand)", (void *)k_cnd_e64_vcc, false},
         {"PAIR v_cmp_lt_u32_e32 vcc + v_cndmask_b32_e32 vcc (per pair)", (void *)k_cmpcnd_vcc, false},
         {"PAIR v_cmp_lt_u32_e64 s[20:21] + v_cndmask_b32_e64 s[20:21] (per pair)", (void *)k_cmpcnd_sgpr, false},
+        {"TRIPLE v_cmp_e32 vcc + 2 x v_cndmask_b32_e32 vcc (per triple)", (void *)k_cmp2cnd_vcc, false},
+        {"QUINT v_cmp_e32 vcc + 4 x v_cndmask_b32_e32 vcc (per five)", (void *)k_cmp4cnd_vcc, false},
+        {"QUAD v_cmp_e32 vcc + v_cndmask_e32 + v_add_u32 + v_cndmask_e32 (per four)", (void *)k_cmp2cnd_mix, false},
         {"v_add_co_u32_e32 (writes vcc)", (void *)k_addco_vcc, false}, {"v_addc_co_u32_e32 (reads + writes vcc)", (void *)k_addc_vcc, false},
         {"v_add_co_u32_e64 (writes s[20:21])", (void *)k_addco_sgpr, false},
         {"v_add_f64 (inline const)", (void *)k_add_f64_const, true}, {"v_rcp_f64", (void *)k_rcp_f64, true}, {"v_sqrt_f64", (void *)k_sqrt_f64, true},
