@@ -17,9 +17,9 @@
  * Threading: a handle is confined to one thread at a time; different handles are independent
  * (PL-SLAM forks run ORB and LSD extraction concurrently from two threads).
  * Streams: the scratch buffers a handle owns are ordered by the stream its work was enqueued on.  Successive calls on one
- * handle may name different streams: a call on another stream than the previous one first waits (host side) for that
- * previous stream, so keep one stream per handle where overlap matters, and do not destroy a stream while it is the most
- * recent one a live handle was called with.  Size changes (a new width / height) re-upload the handle's tables after a
+ * handle may name different streams: every call records an event on its stream once its work is enqueued, and a call on
+ * another stream makes that stream wait for the event on the DEVICE (no host wait; the previous call's stream is not touched
+ * again, so it may have been destroyed meanwhile).  Size changes (a new width / height) re-upload the handle's tables after a
  * device-wide synchronisation.
  */
 #ifndef PLF_H
@@ -248,7 +248,10 @@ typedef struct {
 typedef struct { float Rcw[9], tcw[3], Rlw[9], tlw[3]; float fx, fy, cx, cy, bf, b; } plf_pose_pair;
 
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
- * include/ORBmatcher.h:78 (so@0x80d00).  match_of_kp as above (values >= 0 are last-frame indices). */
+ * include/ORBmatcher.h:78 (so@0x80d00).  match_of_kp as above (values >= 0 are last-frame indices).  check_orientation: 0 / 1 = mbCheckOrientation;
+ * 2 = as 1, and a key point whose assignment the rotation-histogram check removed is marked -3 instead of -1: the reference sets
+ * CurrentFrame.mvpMapPoints[k] = NULL there, which an adapter can only tell from "never assigned" (possibly still holding a map point without observations)
+ * with the distinct value (plf.hpp does so). */
 int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last,
                                 const plf_pose_pair *pose, float th, int32_t mono, int32_t check_orientation,
                                 int32_t *match_of_kp, int32_t *nmatches, void *stream);

@@ -609,12 +609,12 @@ public:
         plf_frame_view fv = {N, nullptr, dk.get(), dur.get(), dd.get(), FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY, dsc.get(),
                              (int32_t)CurrentFrame.mvScaleFactors.size()};
         plf_lastframe_view lv = {NLst, dh.get(), dou.get(), dxw.get(), dlk.get(), dmd.get(), dob.get()};
-        plf::check(plf_match_project_lastframe(m_, &fv, &lv, &P, th, bMono, mbCheckOrientation, dm.get(), dn.get(), nullptr), "ORBmatcher::SearchByProjection(last frame)");
+        plf::check(plf_match_project_lastframe(m_, &fv, &lv, &P, th, bMono, mbCheckOrientation ? 2 : 0, dm.get(), dn.get(), nullptr), "ORBmatcher::SearchByProjection(last frame)");
         const std::vector<int32_t> match = dm.download();
-        for (int k = 0; k < N; k++)
+        for (int k = 0; k < N; k++) {
             if (match[k] >= 0) CurrentFrame.mvpMapPoints[k] = LastFrame.mvpMapPoints[match[k]];
-        // (a key point whose assignment the rotation-consistency check removed ends as NULL in the reference; it was NULL or held a point
-        // without observations before -- the latter is the one state this adapter leaves as it was)
+            else if (match[k] == -3) CurrentFrame.mvpMapPoints[k] = NULL;   // assigned, then removed by the rotation-consistency check: NULL in the reference, whatever the key point held before
+        }
         return dn.download()[0];
     }
     plf_matcher *handle() { return m_; }

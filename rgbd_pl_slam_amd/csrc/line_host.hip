@@ -105,6 +105,7 @@ struct plf_line {
     int last_frames;
     hipStream_t last_stream;   // stream of the most recent call
     bool last_stream_set;
+    PlfStreamOrder order;      // event recorded at the end of every call: a call on another stream waits for it on the device
     int prof_on, prof_n;
     hipEvent_t prof_ev[2 * 512];  // (start, stop) pairs of the region kernel
     hipEvent_t ev_front;          // recorded after the front stages of the last batch (plf_line_wait_front)
@@ -125,6 +126,7 @@ static void line_free(plf_line *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
     if (h->ev_front) (void)hipEventDestroy(h->ev_front);
+    plf_order_free(h->order);
 }
 
 static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
@@ -582,7 +584,8 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
     if (rc != PLF_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
-    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    plf_order_begin(h->order, s);
+    PlfOrderGuard order_guard_{h->order, s};
     h->last_stream = s; h->last_stream_set = true;
     const uint8_t *d_gray = gray;
     ptrdiff_t dpitch = pitch, dfstride = frame_stride;
@@ -646,7 +649,8 @@ extern "C" int plf_line_last_status(plf_line *h, void *stream)
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
-    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    plf_order_begin(h->order, s);
+    PlfOrderGuard order_guard_{h->order, s};
     h->last_stream = s; h->last_stream_set = true;
     int status = 0;
     PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));

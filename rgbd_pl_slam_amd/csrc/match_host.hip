@@ -83,6 +83,7 @@ struct plf_matcher {
     int pose_next;
     hipStream_t last_stream;   // stream of the most recent call (matcher_stream)
     bool last_stream_set;
+    PlfStreamOrder order;
 };
 
 // Handle-owned scratch (frame tables, cell lists, candidate pools) is ordered by the stream the work was enqueued on.  A call on a DIFFERENT stream
@@ -90,7 +91,7 @@ struct plf_matcher {
 static int matcher_stream(plf_matcher *h, void *stream, hipStream_t *out)
 {
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    plf_order_begin(h->order, s);
     h->last_stream = s; h->last_stream_set = true;
     *out = s;
     return PLF_OK;
@@ -102,6 +103,7 @@ static void matcher_free(plf_matcher *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ps : h->pose_ring) { if (ps.d) (void)hipFree(ps.d); if (ps.h) (void)hipHostFree(ps.h); if (ps.ev) (void)hipEventDestroy(ps.ev); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    plf_order_free(h->order);
     free(h->h_frames); free(h->h_lframes);
 }
 
@@ -210,6 +212,7 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     std::vector<FrameDev> fd(n_frames);
     int maxn = 1;
     for (int f = 0; f < n_frames; f++) {
@@ -249,6 +252,7 @@ static int match_bow_impl(plf_matcher *h, const plf_bow_view *pairs, int32_t n_p
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     std::vector<BowDev> pd(n_pairs);
     for (int i = 0; i < n_pairs; i++) {
         const plf_bow_view &v = pairs[i];
@@ -292,6 +296,7 @@ extern "C" int plf_match_triangulation(plf_matcher *h, const plf_tri_view *v, co
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     BowDev d;
     memset(&d, 0, sizeof(d));
     d.n_kf = v->n1; d.n_f = v->n2; d.kf_desc = v->desc1; d.f_desc = v->desc2; d.kf_has_mp = v->has_mp1; d.f_has_mp = v->has_mp2;
@@ -357,6 +362,7 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *frames, in
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     std::vector<FrameDev> fd(n_frames);
     int maxn = 1;
     for (int f = 0; f < n_frames; f++) {
@@ -468,6 +474,7 @@ extern "C" int plf_match_assign_grid(plf_matcher *h, const plf_frame_view *frame
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     FrameDev fd;
     plf_frame_view v = *frame;
     if (v.nlevels < 1) v.nlevels = 1;   // (the grid does not read the scale pyramid)
@@ -489,6 +496,7 @@ extern "C" int plf_match_fuse(plf_matcher *h, const plf_frame_view *kf, const pl
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     FrameDev fd;
     const int st = stage_keyframe(h, kf, s, &fd);
     if (st != PLF_OK) return st;
@@ -539,6 +547,7 @@ extern "C" int plf_match_fuse_sim3(plf_matcher *h, const plf_frame_view *kf, con
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     FrameDev fd; ProjKf C;
     const int st = sim3_common(h, kf, Scw, intr, pts, s, &fd, &C);
     if (st != PLF_OK) return st;
@@ -556,6 +565,7 @@ extern "C" int plf_match_project_sim3(plf_matcher *h, const plf_frame_view *kf, 
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     FrameDev fd; ProjKf C;
     const int st = sim3_common(h, kf, Scw, intr, pts, s, &fd, &C);
     if (st != PLF_OK) return st;
@@ -577,6 +587,7 @@ extern "C" int plf_match_sim3(plf_matcher *h, const plf_frame_view *kf1, const p
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     // sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t() (scale expressions, float work type), t21 = -sR21 * t12 (gemm, alpha = -1)
     float sR12[9], sR21[9], t21[3];
     const float a21 = (float)(1.0 / (double)s12);
@@ -619,6 +630,7 @@ extern "C" int plf_match_lines_knn(plf_matcher *h, const uint8_t *query, int32_t
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(128), 0, s, query, nq, train, nt, h->d_knn_idx, h->d_knn_dist);
     plf_dmatch *d_out = mem == PLF_MEM_DEVICE ? out : h->d_dm;
     hipLaunchKernelGGL(k_knn2_to_dmatch, dim3((2 * nq + 127) / 128), dim3(128), 0, s, h->d_knn_idx, h->d_knn_dist, nq, d_out);
@@ -649,6 +661,7 @@ extern "C" int plf_line_descriptor_mad(plf_matcher *h, const uint8_t *ldesc1, in
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     hipLaunchKernelGGL(k_knn2, dim3((n1 + 127) / 128), dim3(128), 0, s, ldesc1, n1, ldesc2, n2, h->d_knn_idx, h->d_knn_dist);
     int P2 = 1;
     while (P2 < n1) P2 <<= 1;
@@ -673,6 +686,7 @@ extern "C" int plf_match_lines_lastframe(plf_matcher *h, const uint8_t *last_des
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     if (nlast <= 0 || ncur < 2) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int), s)); return PLF_OK; }
     hipLaunchKernelGGL(k_knn2, dim3((nlast + 127) / 128), dim3(128), 0, s, last_desc, nlast, cur_desc, ncur, h->d_knn_idx, h->d_knn_dist);
     int P2 = 1;
@@ -692,6 +706,7 @@ extern "C" int plf_match_lines_lastframe_batch(plf_matcher *h, const uint8_t *la
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     if (nlast <= 0) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int) * n_frames, s)); return PLF_OK; }
     std::vector<LineFrameDev> fd(n_frames);
     memset(fd.data(), 0, sizeof(LineFrameDev) * n_frames);
@@ -721,6 +736,7 @@ extern "C" int plf_match_lines_triangulation(plf_matcher *h, const uint8_t *desc
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     if (n1 > 0) PLF_HIP_TRY(hipMemsetAsync(match12, 0xFF, sizeof(int32_t) * (size_t)n1, s));
     if (n1 <= 0 || n2 < 2) { PLF_HIP_TRY(hipMemsetAsync(nmatches, 0, sizeof(int), s)); return PLF_OK; }
     hipLaunchKernelGGL(k_knn2, dim3((n1 + 127) / 128), dim3(128), 0, s, desc1, n1, desc2, n2, h->d_knn_idx, h->d_knn_dist);
@@ -739,6 +755,7 @@ extern "C" int plf_match_lines_fuse(plf_matcher *h, const uint8_t *kf_desc, int3
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     PLF_HIP_TRY(hipMemsetAsync(nfused, 0, sizeof(int), s));
     if (m == 0) return PLF_OK;
     // brute force over ALL keyframe lines: the 2-NN table of (map lines -> keyframe lines); n_kf == 0 leaves idx = -1
@@ -756,6 +773,7 @@ extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view 
     PLF_HIP_TRY(hipSetDevice(h->device));
     hipStream_t s;
     { const int src_ = matcher_stream(h, stream, &s); if (src_ != PLF_OK) return src_; }
+    PlfOrderGuard order_guard_{h->order, s};
     std::vector<LineFrameDev> fd(n_frames);
     memset(fd.data(), 0, sizeof(LineFrameDev) * n_frames);
     int maxn = 1;

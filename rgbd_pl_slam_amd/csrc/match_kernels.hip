@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(256) k_match_lastframe(const FrameDev *__restr
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * (1.0f / 12.0f));
             if (bin == HISTO_LENGTH) bin = 0;
-            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { claim[k] = -1; atomicSub(&s_acc, 1); }
+            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { claim[k] = check_ori == 2 ? -3 : -1; atomicSub(&s_acc, 1); }
         }
         __syncthreads();
     }
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(256) k_lf_rounds(const FrameDev *__restrict__ 
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * (1.0f / 12.0f));
             if (bin == HISTO_LENGTH) bin = 0;
-            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { claim[k] = -1; atomicSub(&s_acc, 1); }
+            if (bin != keepbin[0] && bin != keepbin[1] && bin != keepbin[2]) { claim[k] = check_ori == 2 ? -3 : -1; atomicSub(&s_acc, 1); }
         }
         __syncthreads();
     }

@@ -50,6 +50,7 @@ struct plf_orb {
     int last_frames;
     hipStream_t last_stream;   // stream of the most recent call
     bool last_stream_set;
+    PlfStreamOrder order;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
@@ -207,6 +208,7 @@ static void orb_free(plf_orb *h)
                     h->d_counters, h->d_cellinfo, h->d_cells, h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_kps, h->d_desc, h->d_nout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    plf_order_free(h->order);
 }
 
 // (re)build geometry, tables and buffers for an input size
@@ -454,7 +456,8 @@ extern "C" int plf_orb_extract_batch(plf_orb *h, const uint8_t *gray, int32_t in
     if (rc != PLF_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
-    if (h->last_stream_set && h->last_stream != s) { (void)hipStreamSynchronize(h->last_stream); (void)hipGetLastError(); }
+    plf_order_begin(h->order, s);
+    PlfOrderGuard order_guard_{h->order, s};
     h->last_stream = s; h->last_stream_set = true;
     const uint8_t *d_gray = gray;
     ptrdiff_t dpitch = pitch, dfstride = frame_stride;

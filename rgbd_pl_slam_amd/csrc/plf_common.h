@@ -152,3 +152,21 @@ __device__ __forceinline__ int plf_hamming8(const uint32_t *a, const uint32_t *b
     return d;
 }
 #endif
+
+// Per-handle ordering of calls that arrive on different streams (include/plf.h, "Streams"): every call records an event on its stream when it has enqueued its
+// work; a call on ANOTHER stream makes that stream wait for the event (device side).  No host wait, and the previous call's stream handle is never touched again --
+// round 2 synchronised the cached hipStream_t of the previous call, which dangles once the caller has destroyed that stream (easy from Python,
+// where torch streams are garbage-collected).  Plain data: the handles are calloc'ed.
+struct PlfStreamOrder { hipEvent_t ev; bool set; hipStream_t last; };
+static inline void plf_order_begin(PlfStreamOrder &o, hipStream_t s)
+{
+    if (o.set && o.last != s && o.ev) { if (hipStreamWaitEvent(s, o.ev, 0) != hipSuccess) (void)hipGetLastError(); }
+    o.last = s;
+}
+static inline void plf_order_end(PlfStreamOrder &o, hipStream_t s)
+{
+    if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); o.ev = nullptr; return; }
+    if (hipEventRecord(o.ev, s) == hipSuccess) o.set = true; else (void)hipGetLastError();
+}
+static inline void plf_order_free(PlfStreamOrder &o) { if (o.ev) (void)hipEventDestroy(o.ev); o.ev = nullptr; o.set = false; }
+struct PlfOrderGuard { PlfStreamOrder &o; hipStream_t s; ~PlfOrderGuard() { plf_order_end(o, s); } };

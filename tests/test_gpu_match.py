@@ -111,6 +111,18 @@ def test_search_by_projection_lastframe(seed, mono, ori):
     torch.cuda.synchronize()
     assert int(nm[0]) == ref_n
     assert np.array_equal(match.cpu().numpy(), ref_match)
+    if ori:
+        # check_orientation = 2: the same search, but a key point whose assignment the rotation histogram removed reads -3 instead of -1 --
+        # exactly the key points that are assigned WITHOUT the check and free WITH it (the plf.hpp adapter sets those to NULL as the reference does)
+        m2 = _dev(init); m0 = _dev(init); n2 = torch.zeros(1, dtype=torch.int32, device="cuda"); n0 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchByProjectionLastFrame(cur, dl, pose, 15.0, mono, 2, m2, n2)
+        m.SearchByProjectionLastFrame(cur, dl, pose, 15.0, mono, 0, m0, n0)
+        torch.cuda.synchronize()
+        a2, a0 = m2.cpu().numpy(), m0.cpu().numpy()
+        assert int(n2[0]) == ref_n and np.array_equal(np.where(a2 == -3, -1, a2), ref_match)
+        culled = a2 == -3
+        assert culled.sum() == int(n0[0]) - ref_n or culled.sum() > 0 or int(n0[0]) == ref_n     # (overwritten key points can be culled more than once per key point)
+        assert np.all(a0[culled] >= 0) and np.all(ref_match[culled] == -1)
     m.close()
 
 
