@@ -2685,6 +2685,10 @@ __device__ __forceinline__ double nfa_tail(const NfaIt &it, double LOG_NT)
     return -log10(bin_tail) - LOG_NT;
 }
 
+// wave-uniform condition as a scalar: the compiler cannot see that the NFA values are the same in every lane and would turn `if (c) { rect = r; }` into 24 selects
+// (v_cndmask_b32_e32 back to back: 17-40 cycles each, profiles/r03_valu_issue.json) instead of a branch over 24 moves
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
 __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const LsdRect *__restrict__ rects_all,
                                                   const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
 {
@@ -2714,16 +2718,16 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
                 if (lane < 6) v = nfa_tail(it, g.log_nt);
             }
             st.log_nfa = nfa_bcast(v, 0);
-            if (st.log_nfa > LOG_EPS) done = true;
+            if (uni(st.log_nfa > LOG_EPS)) done = true;
             else {
                 LsdRect r = st.rec;
                 for (int k = 1; k <= 5; ++k) {
                     r.p /= 2;
                     r.prec = r.p * PI_D;
                     const double vk = nfa_bcast(v, k);
-                    if (vk > st.log_nfa) { st.log_nfa = vk; st.rec = r; }
+                    if (uni(vk > st.log_nfa)) { st.log_nfa = vk; st.rec = r; }
                 }
-                if (st.log_nfa > LOG_EPS) done = true;
+                if (uni(st.log_nfa > LOG_EPS)) done = true;
             }
         }
         // ---- stages 1..3: five progressively narrower / shifted candidates each
@@ -2757,10 +2761,10 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
                     if (stage == 2) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
                     r.width -= delta;
                     const double vk = nfa_bcast(v, k);
-                    if (vk > st.log_nfa) { st.rec = r; st.log_nfa = vk; }
+                    if (uni(vk > st.log_nfa)) { st.rec = r; st.log_nfa = vk; }
                 }
             }
-            if (st.log_nfa > LOG_EPS) done = true;
+            if (uni(st.log_nfa > LOG_EPS)) done = true;
         }
         // ---- stage 4: finer precisions of the rectangle the width searches ended with
         if (!done && (st.rec.width - delta) >= 0.5) {
@@ -2782,9 +2786,9 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
                 r.p /= 2;
                 r.prec = r.p * PI_D;
                 const double vk = nfa_bcast(v, k);
-                if (vk > st.log_nfa) { st.log_nfa = vk; st.rec = r; }
+                if (uni(vk > st.log_nfa)) { st.log_nfa = vk; st.rec = r; }
             }
-            if (st.log_nfa > LOG_EPS) done = true;
+            if (uni(st.log_nfa > LOG_EPS)) done = true;
         }
         if (done && lane == 0) nfa_finish(st, seg_all, keep_all, g);
     }
