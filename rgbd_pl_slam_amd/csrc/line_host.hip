@@ -476,6 +476,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         // warm-up rows above a band: 16 when a serial commit wave follows (every region it has to regrow is serial time), 4 with the validation rounds
         // (the bands redo their conflicts in parallel; the warm-up rows are band-wave time): single VGA frame 7.2 / 7.2 / 6.8 ms with 12 / 8 / 4 rows
         h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : (zmode ? 4 : 16);
+        // rows below the band the warm-up regions may reach (< 0: unbounded).  Clipping shortens the band waves (2.79 -> 2.51 ms, one VGA frame) and lengthens the
+        // validation rounds (2.08 -> 2.77 ms): it loses for one frame (6.0 vs 6.5 ms) and wins once a round lasts as long as the slowest band of several frames
+        // anyway (8 frames in flight: 977 -> 1014 frames/s)
+        h->spec.halo_clip = getenv("PLF_LSD_SPEC_CLIP") ? atoi(getenv("PLF_LSD_SPEC_CLIP")) : (B >= 4 ? 16 : -1);
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
         PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they

@@ -312,10 +312,16 @@ __device__ long long g_lsd_t[16];
 #define TIC(v) const long long v = clock64()
 #define TOC(slot, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += clock64() - (v); } while (0)
 #define CNT(slot, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += (k); } while (0)
+// (band waves of the speculative schedule: band PLF_TIMING_BAND of frame 0)
+#ifndef PLF_TIMING_BAND
+#define PLF_TIMING_BAND 20
+#endif
+#define TOCB(slot, v) do { if (blockIdx.x == PLF_TIMING_BAND && blockIdx.y == 0 && threadIdx.x == 0) g_lsd_t[slot] += clock64() - (v); } while (0)
 #else
 #define TIC(v)
 #define TOC(slot, v)
 #define CNT(slot, k)
+#define TOCB(slot, v)
 #endif
 #define CBAR() asm volatile("" ::: "memory")   // single-wave kernel: LDS ops stay in program order; only the compiler must not reorder
 
@@ -1042,13 +1048,21 @@ __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th
 {
     double reg_angle;
     C.regrow_n = -1;
+    TIC(ts0);
     int n = region_grow(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
     CBAR();
+    TOCB(10, ts0);
+    TIC(ts1);
     spec_append(C, n, dst, tn, cap, ovf, mark, bb);
+    TOCB(11, ts1);
     if (n < g.min_reg_size) return false;
+    TIC(ts2);
     region2rect(C, n, reg_angle, g.prec, g.p, rec);
+    TOCB(12, ts2);
+    TIC(ts3);
     const bool okr = refine(C, n, reg_angle, g.prec, g.p, rec, 0.7);
     CBAR();
+    TOCB(13, ts3);
     if (C.regrow_n >= 0) spec_append(C, C.regrow_n, dst, tn, cap, ovf, mark, bb);   // (reduce_region_radius only permutes that list)
     return okr;
 }
@@ -1237,6 +1251,28 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     uint32_t *halo = SB.halo + fb * SB.bm_words;
     for (int phase = (band > 0 && SB.halo_rows > 0) ? 0 : 1; phase < 2; phase++) {
     const bool record = phase == 1;
+    TIC(tph);
+    // The warm-up regions are clipped below the band: a region that crosses the warm-up rows from above is regrown here from its first pixel in those rows, and
+    // without a bound EVERY band a 100-row region crosses grew all of its lower part again -- the 4 warm-up rows cost a band wave more (1.6 ms) than its 8 own
+    // rows (1.0 ms).  Only what the warm-up marks inside and just below the band can matter to the band's own seeds; the rows further down are made to look taken
+    // while the warm-up runs and are cleared again before the band's own seeds start (nothing real was marked there).  Again only the quality of a guess.
+    const int clip_px = (SB.halo_clip >= 0 && y1 + SB.halo_clip < H) ? (y1 + SB.halo_clip) * W : W * H;
+    if (!record && clip_px < W * H) {
+        for (int i = (clip_px >> 5) + lane; i < SB.bm_words; i += 64) {
+            uint32_t v = 0xFFFFFFFFu;
+            if (i == (clip_px >> 5) && (clip_px & 31)) v = bm[i] | (0xFFFFFFFFu << (clip_px & 31));
+            bm[i] = v;
+        }
+        CBAR();
+    }
+    if (record && clip_px < W * H && band > 0 && SB.halo_rows > 0) {
+        for (int i = (clip_px >> 5) + lane; i < SB.bm_words; i += 64) {
+            uint32_t v = 0u;
+            if (i == (clip_px >> 5) && (clip_px & 31)) v = bm[i] & ((1u << (clip_px & 31)) - 1u);
+            bm[i] = v;
+        }
+        CBAR();
+    }
     const int ya = record ? y0 : max(0, y0 - SB.halo_rows), yb = record ? y1 : y0;
     if (record) { CBAR(); for (int i = lane; i < SB.bm_words; i += 64) halo[i] = bm[i]; }
     for (int base = ya * W; base < yb * W; base += 64) {
@@ -1292,6 +1328,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
         }
         if (BUDGET && truncated) break;
     }
+    TOCB(14 + phase, tph);
     if (BUDGET && truncated) break;
     }
     if (SB.band_ticks && lane == 0) { SB.band_ticks[fb * 2] = (int)(wall_clock64() - t_start); SB.band_ticks[fb * 2 + 1] = tn; }
@@ -2147,6 +2184,7 @@ extern "C" void plf_lsd_timing_dump()
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_lsd_t), sizeof(t));
     printf("[lsd timing, frame 0 accumulated] grow %lld  rect %lld  refine %lld  total %lld cycles | regions %lld points %lld big %lld | iters %lld groups %lld accepts %lld\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+    printf("[lsd timing, band wave %d of frame 0 accumulated, cycles] region_grow %lld  log append %lld  region2rect %lld  refine %lld | warm-up phase %lld  own phase %lld\n", PLF_TIMING_BAND, t[10], t[11], t[12], t[13], t[14], t[15]);
 }
 #endif
 
