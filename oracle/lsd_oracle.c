@@ -880,6 +880,33 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
         if (g_rounds_mode == 1) for (int y = 0; y < by[b]; y++) for (int x = 0; x < W; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) priv[(size_t)y * W + x] = USED;
         L.used = priv;
         long acc = 0;
+        if (g_rounds_mode == 4 && b > 0) {
+            /* mode 4: NO warm-up growth.  The guess: every defined pixel above the band is taken, and so is every pixel of the band's first g_band_halo rows that
+             * hangs on such a pixel through a chain of 8-neighbours whose level-line angles differ by at most prec (pairwise: a cheap stand-in for "the region from
+             * above pokes down to here"), found by a row-by-row fill with two horizontal sweeps per row */
+            for (int y = 0; y < by[b]; y++) for (int x = 0; x < W; x++) if (L.angles[(size_t)y * W + x] != NOTDEF) priv[(size_t)y * W + x] = USED;
+            const int yd = by[b] + g_band_halo < H - 1 ? by[b] + g_band_halo : H - 1;
+            for (int y = by[b]; y < yd; y++) {
+                for (int x = 0; x < W - 1; x++) {
+                    const size_t a = (size_t)y * W + x;
+                    if (L.angles[a] == NOTDEF) continue;
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int xx = x + dx;
+                        if (xx < 0 || xx >= W) continue;
+                        const size_t q = (size_t)(y - 1) * W + xx;
+                        if (priv[q] == USED && L.angles[q] != NOTDEF && angle_diff(L.angles[a], L.angles[q]) <= prec) { priv[a] = USED; break; }
+                    }
+                }
+                for (int x = 1; x < W - 1; x++) {
+                    const size_t a = (size_t)y * W + x;
+                    if (priv[a] != USED && L.angles[a] != NOTDEF && priv[a - 1] == USED && L.angles[a - 1] != NOTDEF && angle_diff(L.angles[a], L.angles[a - 1]) <= prec) priv[a] = USED;
+                }
+                for (int x = W - 3; x >= 0; x--) {
+                    const size_t a = (size_t)y * W + x;
+                    if (priv[a] != USED && L.angles[a] != NOTDEF && priv[a + 1] == USED && L.angles[a + 1] != NOTDEF && angle_diff(L.angles[a], L.angles[a + 1]) <= prec) priv[a] = USED;
+                }
+            }
+        }
         if ((g_rounds_mode == 2 || g_rounds_mode == 3) && b > 0) {   /* the GPU's halo warm-up: the g_band_halo rows above the band grown first, unrecorded, on an empty map */
             const int yh = by[b] - g_band_halo > 0 ? by[b] - g_band_halo : 0;
             /* mode 3: ... on a map that has every defined pixel ABOVE the warm-up rows marked (in the serial run they all are, bar the few that refine released):
