@@ -392,44 +392,23 @@ __device__ __forceinline__ GrowTh grow_thresholds(double prec)
     return t;
 }
 
-// 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order.
-// w: angle word (candidate iff < 0x80000000), xy: x | y << 16 (0xFFFFFFFF: no pixel -- outside the image or an unused lane), cs: the cos / sin increment.
-// (Round 3: no pixel index in the group any more -- it is y * W + x whenever it is needed -- so that THREE groups fit the registers two did: the words of a group
-// are fetched two groups ahead and its 16-byte increments one group ahead, for the lanes that turned out to be candidates only.  Round 2 fetched the increment
-// with the word for all 63 lanes, candidate or not: 80 % of the kernel's 33 GB of fetch traffic per 4096 frames.)
-struct Grp { uint32_t w; double csx, csy; uint32_t xy; };
-struct GrpW { uint32_t w; uint32_t xy; };
-#define GRP_NONE 0xFFFFFFFFu
-__device__ __forceinline__ int grp_addr(const RegCtx &C, uint32_t xy) { return (int)(xy >> 16) * C.W + (int)(xy & 0xFFFFu); }
-
-// words of the 3x3 neighbourhoods of list entries [first, first + cnt)
-__device__ __forceinline__ GrpW load_words(const RegCtx &C, int first, int cnt, int lane, int slot, int kx, int ky)
-{
-    GrpW G;
-    G.w = 0xFFFFFFFFu; G.xy = GRP_NONE;
-    if (lane < 63 && slot < cnt) {
-        const uint32_t pxy = rxy_get(C, first + slot);
-        const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
-        if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
-            G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            G.w = ang_load(C, yy * C.W + xx);
-        }
-    }
-    return G;
-}
-// words AND increments in one round trip (the list is too short to look two groups ahead: every lane's increment is fetched blind, as in round 2)
+// 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order
+struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle word (candidate iff < 0x80000000)
+// The cos/sin increment is fetched together with the angle word (fetching it only for candidates, after the word has arrived, saves HBM traffic but puts a
+// second dependent round trip -- and an s_waitcnt that also stalls the group being processed -- into every step of the chain: 77.2 -> 71.4 ms per 4096
+// frames).  (A single-predicate, single-branch form of this function was measured too: 3 VGPRs more and 2.6 % slower.)
 __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, int lane, int slot, int kx, int ky)
 {
     Grp G;
-    G.w = 0xFFFFFFFFu; G.csx = 0.0; G.csy = 0.0; G.xy = GRP_NONE;
+    G.w = 0xFFFFFFFFu; G.csx = 0.0; G.csy = 0.0; G.a = -1; G.xy = 0u;
     if (lane < 63 && slot < cnt) {
         const uint32_t pxy = rxy_get(C, first + slot);
         const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
         if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
-            const int a = yy * C.W + xx;
+            G.a = yy * C.W + xx;
             G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            const double2 c = C.cs[a];
-            G.w = ang_load(C, a);
+            const double2 c = C.cs[G.a];
+            G.w = ang_load(C, G.a);
             G.csx = c.x; G.csy = c.y;
         }
     }
@@ -439,8 +418,8 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
 // LineSegmentDetectorImpl::region_grow.  All lanes return the same (n, reg_angle).
 // The accept steps happen strictly in the reference order (centre by centre, neighbours in (yy, xx) order, the
 // region angle a function of the sums after every accepted pixel).  Up to 7 queued centres are handled as one
-// group of 63 lanes whose lane order IS the reference's test order; the data of the next groups is loaded while the current group is processed:
-// the angle words two groups ahead, the cos/sin increments of the lanes that turned out to be candidates one group ahead.
+// group of 63 lanes whose lane order IS the reference's test order; the data of the next group (angle + cos/sin
+// increment per neighbour) is loaded while the current group is processed.
 //
 // The reference recomputes reg_angle = fastAtan2(sumdy, sumdx) after every accept and tests every later neighbour
 // against it.  Here the fastAtan2 + exact double test is only evaluated when it can matter: with S = (sumdx, sumdy)
@@ -449,7 +428,7 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
 // one above prec + 0.05 deg is not, whatever the exact test would compute.  Only candidates inside that 0.1 degree
 // band ("border") are decided by the exact test.  The USED flags arrive with the angle words of a group, i.e. they
 // are as old as the group's load: a pixel accepted since then is removed from the later lanes of the current group
-// and from the lanes of the already-loaded groups by comparing coordinates.
+// and from the lanes of the already-loaded next group by comparing addresses.
 __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out)
 {
     const int lane = plf_lane();
@@ -467,42 +446,27 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     int cur_n = 1;
     // (the first group is the seed itself: its neighbourhood is addressed from (sx, sy) directly, not through the list entry lane 0 has just written)
     Grp cur;
-    cur.w = 0xFFFFFFFFu; cur.csx = 0.0; cur.csy = 0.0; cur.xy = GRP_NONE;
+    cur.w = 0xFFFFFFFFu; cur.csx = 0.0; cur.csy = 0.0; cur.a = -1; cur.xy = 0u;
     if (lane < 9) {
         const int xx = sx + kx, yy = sy + ky;
         if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
-            const int a = yy * C.W + xx;
+            cur.a = yy * C.W + xx;
             cur.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            const double2 c = C.cs[a];
-            cur.w = ang_load(C, a);
+            const double2 c = C.cs[cur.a];
+            cur.w = ang_load(C, cur.a);
             cur.csx = c.x; cur.csy = c.y;
         }
     }
     unsigned long long cur_stale = 0ull;   // lanes whose pixel was accepted after its word was loaded
-    // the group after the current one (nx: words, and -- once nx_cs -- increments) and the one after that (n2: words only)
-    Grp nx;
-    nx.w = 0xFFFFFFFFu; nx.csx = 0.0; nx.csy = 0.0; nx.xy = GRP_NONE;
-    GrpW n2;
-    n2.w = 0xFFFFFFFFu; n2.xy = GRP_NONE;
-    int nx_n = 0, n2_n = 0;
-    bool nx_cs = false;
-    unsigned long long nx_stale = 0ull, n2_stale = 0ull;
     // All per-lane predicates of the accept loop are kept as wave-uniform 64-bit masks (the compares write them
     // directly), so the loop control is scalar and nothing bounces between VGPR booleans and masks.
     while (i < n) {
         CNT(7, 1);
-        // ---- loads ahead: list entries that exist now
-        if (nx_n == 0) {                          // nothing in flight for the next group: words and increments together
-            nx_n = max(0, min(7, n - (i + cur_n)));
-            if (nx_n) { nx = load_group(C, i + cur_n, nx_n, lane, slot, kx, ky); nx_cs = true; nx_stale = 0ull; }
-        } else if (!nx_cs) {                      // its words came in as the group after next: now the increments, for its candidate lanes only
-            if (nx.w < 0x80000000u) { const double2 c = C.cs[grp_addr(C, nx.xy)]; nx.csx = c.x; nx.csy = c.y; }
-            nx_cs = true;
-        }
-        if (n2_n == 0 && nx_n > 0) {              // words of the group after next
-            n2_n = max(0, min(7, n - (i + cur_n + nx_n)));
-            if (n2_n) { n2 = load_words(C, i + cur_n + nx_n, n2_n, lane, slot, kx, ky); n2_stale = 0ull; }
-        }
+        // ---- issue the loads of the next group: list entries that exist now
+        int nx_n = min(7, n - (i + cur_n));
+        if (nx_n < 0) nx_n = 0;
+        Grp nx = load_group(C, i + cur_n, nx_n, lane, slot, kx, ky);
+        unsigned long long nx_stale = 0ull;
         // ---- process the current group
         CNT(8, cur_n);
         unsigned long long candm = __ballot(cur.w < 0x80000000u) & ~cur_stale;
@@ -545,20 +509,18 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             }
             CNT(9, 1);
             if (lane == k) {
-                used_set(C, grp_addr(C, cur.xy), cur.w);
+                used_set(C, cur.a, cur.w);
                 rxy_put(C, n, cur.xy);
             }
             const double cc = readlane_d(cur.csx, k), ss = readlane_d(cur.csy, k);
-            const uint32_t kxy = (uint32_t)__builtin_amdgcn_readlane((int)cur.xy, k);
+            const int ka = __builtin_amdgcn_readlane(cur.a, k);
             // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
             sumdx = (float)((double)sumdx + cc);
             sumdy = (float)((double)sumdy + ss);
             theta_valid = false;
             ++n;
-            candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.xy == kxy);   // lanes up to k are decided; the pixel is taken
-            nx_stale |= __ballot(nx.xy == kxy);
-            n2_stale |= __ballot(n2.xy == kxy);
-            const int ka = (int)(kxy >> 16) * C.W + (int)(kxy & 0xFFFFu);
+            candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.a == ka);   // lanes up to k are decided; the pixel is taken
+            nx_stale |= __ballot(nx.a == ka);
             if ((unsigned)(ka - C.cbase) < 64u) C.cused |= 1ull << (ka - C.cbase);
         }
         CBAR();
@@ -566,17 +528,9 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         if (nx_n == 0 && i < n) {   // nothing could be loaded ahead (short list): load the next group now
             nx_n = min(7, n - i);
             nx = load_group(C, i, nx_n, lane, slot, kx, ky);
-            nx_cs = true;
             nx_stale = 0ull;
         }
-        if (nx_n > 0 && !nx_cs) {   // (the group was promoted from "after next" in this very iteration and becomes current at once: cannot happen -- a promoted group waits one iteration; kept for safety)
-            if (nx.w < 0x80000000u) { const double2 c = C.cs[grp_addr(C, nx.xy)]; nx.csx = c.x; nx.csy = c.y; }
-            nx_cs = true;
-        }
         cur = nx; cur_n = nx_n; cur_stale = nx_stale;
-        // the group after next moves up: its increments are fetched at the top of the next iteration, while the new current group is processed
-        nx.w = n2.w; nx.xy = n2.xy; nx.csx = 0.0; nx.csy = 0.0; nx_n = n2_n; nx_cs = false; nx_stale = n2_stale;
-        n2.w = 0xFFFFFFFFu; n2.xy = GRP_NONE; n2_n = 0; n2_stale = 0ull;
     }
     if (!theta_valid) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
