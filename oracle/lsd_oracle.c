@@ -799,6 +799,8 @@ static void band_log_push(band_log *B, int seed, int has_rect, const rect_t *rec
 }
 
 static int g_rounds_mode = 0, g_rounds_refined = 0;
+static double g_fill_tol = 1.0;
+void orc_lsd_band_rounds_fill_tol(double t) { g_fill_tol = t; }
 void orc_lsd_band_rounds_refined(int m) { g_rounds_refined = m; }
 void orc_lsd_band_rounds_mode(int m) { g_rounds_mode = m; }
 
@@ -894,16 +896,16 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
                         const int xx = x + dx;
                         if (xx < 0 || xx >= W) continue;
                         const size_t q = (size_t)(y - 1) * W + xx;
-                        if (priv[q] == USED && L.angles[q] != NOTDEF && angle_diff(L.angles[a], L.angles[q]) <= prec) { priv[a] = USED; break; }
+                        if (priv[q] == USED && L.angles[q] != NOTDEF && angle_diff(L.angles[a], L.angles[q]) <= prec * g_fill_tol) { priv[a] = USED; break; }
                     }
                 }
                 for (int x = 1; x < W - 1; x++) {
                     const size_t a = (size_t)y * W + x;
-                    if (priv[a] != USED && L.angles[a] != NOTDEF && priv[a - 1] == USED && L.angles[a - 1] != NOTDEF && angle_diff(L.angles[a], L.angles[a - 1]) <= prec) priv[a] = USED;
+                    if (priv[a] != USED && L.angles[a] != NOTDEF && priv[a - 1] == USED && L.angles[a - 1] != NOTDEF && angle_diff(L.angles[a], L.angles[a - 1]) <= prec * g_fill_tol) priv[a] = USED;
                 }
                 for (int x = W - 3; x >= 0; x--) {
                     const size_t a = (size_t)y * W + x;
-                    if (priv[a] != USED && L.angles[a] != NOTDEF && priv[a + 1] == USED && L.angles[a + 1] != NOTDEF && angle_diff(L.angles[a], L.angles[a + 1]) <= prec) priv[a] = USED;
+                    if (priv[a] != USED && L.angles[a] != NOTDEF && priv[a + 1] == USED && L.angles[a + 1] != NOTDEF && angle_diff(L.angles[a], L.angles[a + 1]) <= prec * g_fill_tol) priv[a] = USED;
                 }
             }
         }

@@ -476,6 +476,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         // warm-up rows above a band: 16 when a serial commit wave follows (every region it has to regrow is serial time), 4 with the validation rounds
         // (the bands redo their conflicts in parallel; the warm-up rows are band-wave time): single VGA frame 7.2 / 7.2 / 6.8 ms with 12 / 8 / 4 rows
         h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : (zmode ? 4 : 16);
+        // validation rounds: the band's guess of what the earlier bands take from it can be made WITHOUT growing anything (k spec_grow_body: fill): rows and tolerance
+        h->spec.fill_rows = zmode ? (getenv("PLF_LSD_SPEC_FILL") ? atoi(getenv("PLF_LSD_SPEC_FILL")) : 0) : 0;
+        h->spec.fill_tol_deg = getenv("PLF_LSD_SPEC_FILL_TOL") ? (float)atof(getenv("PLF_LSD_SPEC_FILL_TOL")) : 11.25f;
+        if (h->spec.fill_rows > 0) h->spec.halo_rows = 0;
         // rows below the band the warm-up regions may reach (< 0: unbounded).  Clipping shortens the band waves (2.79 -> 2.51 ms, one VGA frame) and lengthens the
         // validation rounds (2.08 -> 2.77 ms): it loses for one frame (6.0 vs 6.5 ms) and wins once a round lasts as long as the slowest band of several frames
         // anyway (8 frames in flight: 977 -> 1014 frames/s)

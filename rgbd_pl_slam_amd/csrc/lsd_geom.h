@@ -43,6 +43,8 @@ struct SpecBufs {
     uint32_t *halo;     // [frame][band][bm_words]: the band's speculative flags after its warm-up rows = its initial state S
     int halo_rows;      // rows above a band that its wave grows first, unrecorded (model: orc_lsd_band_speculation_halo)
     int halo_clip;      // the warm-up regions may not grow below the band's last row + halo_clip (< 0: unbounded)
+    int fill_rows;      // > 0: no warm-up growth; the band's first fill_rows rows are presumed taken where they hang on the pixels above through chains of aligned neighbours
+    float fill_tol_deg; // largest difference of level-line angles (degrees) between neighbours of such a chain
     int s_global;
     int tcap, rcap_rec, nbands, bm_words;
     // parallel validation rounds (k_lsd_spec_prefix / _validate / _assemble): every band keeps its log consistent with what the bands before it mark

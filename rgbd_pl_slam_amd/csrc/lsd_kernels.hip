@@ -308,16 +308,22 @@ struct RegCtx {
 };
 
 #ifdef PLF_LSD_TIMING
-__device__ long long g_lsd_t[16];
+__device__ long long g_lsd_t[24];
 #define TIC(v) const long long v = clock64()
 #define TOC(slot, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += clock64() - (v); } while (0)
-#define CNT(slot, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += (k); } while (0)
+#ifdef PLF_LSD_TIMING_NOCNT
+#define CNT(slot, k)
+#else
+#define CNT(slot, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lsd_t[slot] += (k); } while (0)   // (a global read-modify-write: counts distort the cycle figures)
+#endif
 // (band waves of the speculative schedule: band PLF_TIMING_BAND of frame 0)
 #ifndef PLF_TIMING_BAND
 #define PLF_TIMING_BAND 20
 #endif
 #define TOCB(slot, v) do { if (blockIdx.x == PLF_TIMING_BAND && blockIdx.y == 0 && threadIdx.x == 0) g_lsd_t[slot] += clock64() - (v); } while (0)
+#define CNTB(slot, k) do { if (blockIdx.x == PLF_TIMING_BAND && blockIdx.y == 0 && threadIdx.x == 0) g_lsd_t[slot] += (k); } while (0)
 #else
+#define CNTB(slot, k)
 #define TIC(v)
 #define TOC(slot, v)
 #define CNT(slot, k)
@@ -469,6 +475,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         unsigned long long nx_stale = 0ull;
         // ---- process the current group
         CNT(8, cur_n);
+        TIC(tacc);
         unsigned long long candm = __ballot(cur.w < 0x80000000u) & ~cur_stale;
         const float ux = (float)cur.csx, uy = (float)cur.csy;
         while (candm) {
@@ -524,6 +531,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             if ((unsigned)(ka - C.cbase) < 64u) C.cused |= 1ull << (ka - C.cbase);
         }
         CBAR();
+        TOC(19, tacc); TOCB(21, tacc);
         i += cur_n;
         if (nx_n == 0 && i < n) {   // nothing could be loaded ahead (short list): load the next group now
             nx_n = min(7, n - i);
@@ -531,6 +539,9 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             nx_stale = 0ull;
         }
         cur = nx; cur_n = nx_n; cur_stale = nx_stale;
+#ifdef PLF_LSD_TIMING
+        { TIC(tw); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TOC(20, tw); TOCB(22, tw); }
+#endif
     }
     if (!theta_valid) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
@@ -1052,6 +1063,7 @@ __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th
     int n = region_grow(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
     CBAR();
     TOCB(10, ts0);
+    CNTB(16, 1); CNTB(17, n);
     TIC(ts1);
     spec_append(C, n, dst, tn, cap, ovf, mark, bb);
     TOCB(11, ts1);
@@ -1232,19 +1244,97 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     const GrowTh th0 = grow_thresholds(g.prec);
     const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
     int nrec = 0, tn = 0, ovf = 0, nrect_band = 0;
-    if (band > 0 && SB.halo_rows > 0) {
+    if (band > 0 && (SB.halo_rows > 0 || SB.fill_rows > 0)) {
         // The warm-up starts from "every defined pixel ABOVE the warm-up rows is taken" (in the serial run they all are when this band's turn comes, bar the
         // few that refine released) instead of an empty map: on an empty map the regions of the top warm-up rows grew upwards without bound -- work that
         // cost more than the warm-up rows themselves (band waves with 5 own + 12 warm-up rows ran 1.6x as long as the 31-row first band).  Like everything the
         // warm-up leaves, this is only the band's GUESS of what the earlier bands mark (its initial S): the commit / the validation rounds compare it with the truth.
         const uint32_t *dm = SB.defmap + (size_t)f * SB.bm_words;
-        const int pa = max(0, y0 - SB.halo_rows) * W;                  // first pixel of the warm-up rows
+        const int pa = max(0, y0 - (SB.fill_rows > 0 ? 0 : SB.halo_rows)) * W;                  // first pixel of the warm-up rows
         for (int i = lane; i < ((pa + 31) >> 5); i += 64) {
             uint32_t v = dm[i];
             if (i == (pa >> 5) && (pa & 31)) v &= (1u << (pa & 31)) - 1u;
             bm[i] = v;
         }
         CBAR();
+    }
+    if (band > 0 && SB.fill_rows > 0) {
+        // NO warm-up growth (validation rounds only; model: orc_lsd_band_rounds mode 4).  A region that crosses into the band from above was regrown, lower part by lower
+        // part, by every band it crosses -- with 48 bands the band waves did ~2.6x the serial work, most of it in the warm-up.  The guess is made without growing
+        // anything: a pixel of the band's first fill_rows rows is presumed taken if it hangs on a taken pixel of the row above, or of its own row, through
+        // neighbours whose level-line angles differ by at most fill_tol_deg (half the region tolerance) -- a stand-in for "the region from above reaches down to here".
+        // Row by row: vertical step per pixel (one lane each), then the closure along the row as a carry chain over 64-bit masks (Kogge-Stone inside a
+        // chunk, the carry handed from chunk to chunk), left to right and right to left.  A dozen microseconds per band; what it gets wrong the rounds redo.
+        const uint32_t *angw = C.ang;
+        const float tol = SB.fill_tol_deg;
+        const int r_end = min(y0 + SB.fill_rows, H - 1), nch = (W + 63) >> 6;
+        LDS_PTR(unsigned long long) sc = (LDS_PTR(unsigned long long))list;      // per chunk: vertical marks, links to the left neighbour (the region list is idle)
+        for (int r = y0; r < r_end; r++) {
+            for (int c = 0; c < nch; c++) {
+                const int x = c * 64 + lane;
+                bool vm = false, lk = false;
+                if (x < W) {
+                    const int pp = r * W + x;
+                    const uint32_t wp = angw[pp];
+                    if (wp < 0x80000000u) {
+                        const float ap = __uint_as_float(wp);
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            const int xx = x + dx;
+                            if (xx < 0 || xx >= W) continue;
+                            const int q = pp - W + dx;
+                            if (!((bm[q >> 5] >> (q & 31)) & 1u)) continue;
+                            const uint32_t wq = angw[q];
+                            if (wq >= 0x80000000u) continue;
+                            float d = fabsf(ap - __uint_as_float(wq));
+                            if (d > 180.f) d = 360.f - d;
+                            vm |= d <= tol;
+                        }
+                        if (x > 0) {
+                            const uint32_t wl = angw[pp - 1];
+                            if (wl < 0x80000000u) { float d = fabsf(ap - __uint_as_float(wl)); if (d > 180.f) d = 360.f - d; lk = d <= tol; }
+                        }
+                    }
+                }
+                const unsigned long long V = __ballot(vm), Lk = __ballot(lk);
+                if (lane == 0) { sc[2 * c] = V; sc[2 * c + 1] = Lk; }
+            }
+            CBAR();
+            // closure along the row (wave-uniform 64-bit arithmetic)
+            unsigned long long carry = 0ull;
+            for (int c = 0; c < nch; c++) {              // left to right: bit i of Lk links pixel i to pixel i - 1
+                unsigned long long fl = sc[2 * c], pr = sc[2 * c + 1];
+                fl |= carry & pr & 1ull;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) { fl |= pr & (fl << sft); pr &= pr << sft; }
+                if (lane == 0) sc[2 * c] = fl;
+                carry = fl >> 63;
+            }
+            CBAR();
+            carry = 0ull;
+            for (int c = nch - 1; c >= 0; c--) {         // right to left: pixel i hangs on pixel i + 1 through link bit i + 1
+                unsigned long long fl = sc[2 * c];
+                const unsigned long long lk_here = sc[2 * c + 1], lk_next = c + 1 < nch ? sc[2 * c + 3] : 0ull;
+                unsigned long long pr = (lk_here >> 1) | ((lk_next & 1ull) << 63);
+                fl |= (carry << 63) & pr;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) { fl |= pr & (fl >> sft); pr &= pr >> sft; }
+                carry = fl & 1ull;
+                // the chunk's marks into the band's flags: 64 bits at pixel r * W + c * 64, i.e. up to three words
+                const int p0 = r * W + c * 64, w0 = p0 >> 5, o = p0 & 31;
+                const int npx = min(64, W - c * 64);
+                if (npx < 64) fl &= (1ull << npx) - 1ull;
+                if (lane < 3) {
+                    uint32_t part;
+                    if (lane == 0) part = (uint32_t)(fl << o);
+                    else if (lane == 1) part = o ? (uint32_t)(fl >> (32 - o)) : (uint32_t)(fl >> 32);
+                    else part = o ? (uint32_t)(fl >> (64 - o)) : 0u;
+                    const int wi = w0 + lane;
+                    if (part && wi < SB.bm_words) __hip_atomic_fetch_or(&bm[wi], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            CBAR();
+        }
     }
     // phase 0 (bands > 0): the rows just above the band, unrecorded -- what they mark (regions poking into the band) is the state the band's
     // speculation starts from, handed to the commit wave as the initial S; phase 1: the band itself, recorded
@@ -1297,6 +1387,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
             // itself.  (Reading every log back to set the flag and find the box cost a global round trip per seed.)
             SpecBB bb = {W, H, -1, -1};
             const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf, record ? 0x40000000u : 0u, bb);
+            TIC(trec);
             if (!record) { tn = 0; ovf = 0; }
             if (record && nrec >= SB.rcap_rec) ovf = 1;
             if (record && okr) nrect_band++;
@@ -1325,6 +1416,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
             w = px < yb * W ? ang_load(C, px) : 0xFFFFFFFFu;   // flags from the bitmap: cheap, always current
             ok = ok && lane > j && w < 0x80000000u;
             mask = __ballot(ok);
+            TOCB(18, trec);
         }
         if (BUDGET && truncated) break;
     }
@@ -1334,8 +1426,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     if (SB.band_ticks && lane == 0) { SB.band_ticks[fb * 2] = (int)(wall_clock64() - t_start); SB.band_ticks[fb * 2 + 1] = tn; }
     if (SB.out) {   // validation rounds follow: what the band's own records mark (its flags minus the state its warm-up rows left) and its rectangle count
         uint32_t *outb = SB.out + fb * SB.bm_words;
-        const bool had_halo = band > 0 && SB.halo_rows > 0;
-        for (int i = lane; i < SB.bm_words; i += 64) outb[i] = bm[i] & ~(had_halo ? halo[i] : 0u);
+        for (int i = lane; i < SB.bm_words; i += 64) outb[i] = bm[i] & ~halo[i];   // (halo[] = the band's initial state, written when its own seeds started: zeros for band 0)
         if (lane == 0) SB.nrects[fb] = nrect_band;
     }
     if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; SB.cnt[fb * 4 + 3] = (int)(wall_clock64() & 0x7fffffff); }   // ([3]: 100 MHz timestamp, diagnostics)
@@ -2180,11 +2271,13 @@ __global__ void __launch_bounds__(64) k_lsd_spec_assemble(LsdRect *__restrict__ 
 #ifdef PLF_LSD_TIMING
 extern "C" void plf_lsd_timing_dump()
 {
-    long long t[16];
+    long long t[24];
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_lsd_t), sizeof(t));
     printf("[lsd timing, frame 0 accumulated] grow %lld  rect %lld  refine %lld  total %lld cycles | regions %lld points %lld big %lld | iters %lld groups %lld accepts %lld\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
     printf("[lsd timing, band wave %d of frame 0 accumulated, cycles] region_grow %lld  log append %lld  region2rect %lld  refine %lld | warm-up phase %lld  own phase %lld\n", PLF_TIMING_BAND, t[10], t[11], t[12], t[13], t[14], t[15]);
+    printf("[lsd timing] region_grow of frame 0: accept loops %lld cycles, exposed load wait %lld cycles | band wave: %lld, %lld\n", t[19], t[20], t[21], t[22]);
+    printf("[lsd timing, band wave %d] seeds %lld  pixels grown %lld  per-seed record + rescan %lld cycles\n", PLF_TIMING_BAND, t[16], t[17], t[18]);
 }
 #endif
 
