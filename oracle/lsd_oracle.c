@@ -803,6 +803,11 @@ static double g_fill_tol = 1.0;
 void orc_lsd_band_rounds_fill_tol(double t) { g_fill_tol = t; }
 void orc_lsd_band_rounds_refined(int m) { g_rounds_refined = m; }
 void orc_lsd_band_rounds_mode(int m) { g_rounds_mode = m; }
+/* model experiments: explicit band boundaries (n = bands + 1 row numbers, first 0, last rows; NULL / 0: the defined-pixel balance) and the phase-1 accepts per band */
+static int g_rounds_by[258], g_rounds_nby = 0;
+static long g_rounds_band_acc[257];
+void orc_lsd_band_rounds_set_bounds(const int *by, int n) { g_rounds_nby = (by && n >= 2 && n <= 258) ? n : 0; for (int i = 0; i < g_rounds_nby; i++) g_rounds_by[i] = by[i]; }
+void orc_lsd_band_rounds_get_band_accepts(long *out, int n) { for (int i = 0; i < n && i < 257; i++) out[i] = g_rounds_band_acc[i]; }
 
 int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int nbands, long *stats)
 {
@@ -872,6 +877,7 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
         by[nbands] = rows;
         free(cnt);
     }
+    if (g_rounds_nby == nbands + 1) for (int b = 0; b <= nbands; b++) by[b] = g_rounds_by[b] < rows ? g_rounds_by[b] : rows;
     /* ---- phase 1: every band against an empty map */
     band_log *B = (band_log *)calloc(nbands, sizeof(band_log)), *B2 = (band_log *)calloc(nbands, sizeof(band_log));
     uint8_t *priv = (uint8_t *)malloc(NP);
@@ -937,6 +943,7 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
         for (size_t i = 0; i < NP; i++) B[b].out[i] = (priv[i] == USED && B[b].E[i] != USED) ? USED : NOTUSED;
         if (getenv("ORC_ROUNDS_VERBOSE")) fprintf(stderr, "  band %d rows %d-%d: %ld accepts, %d records\n", b, by[b], by[b + 1], acc, B[b].nrecs);
         if (acc > stats[1]) stats[1] = acc;
+        if (b < 257) g_rounds_band_acc[b] = acc;
     }
     /* ---- rounds */
     uint8_t *T = (uint8_t *)malloc(NP), *S = (uint8_t *)malloc(NP), *D = (uint8_t *)malloc(NP), *En = (uint8_t *)malloc(NP);

@@ -110,6 +110,8 @@ struct plf_line {
     hipEvent_t prof_ev[2 * 512];  // (start, stop) pairs of the region kernel
     hipEvent_t ev_front;          // recorded after the front stages of the last batch (plf_line_wait_front)
     bool ev_front_set;
+    uint8_t *h_pin;        // pinned staging of the host-output path for a few frames in flight (results of <= PIN_FRAMES frames come back in one go)
+    size_t h_pin_bytes;
     double prof_ms;
     int prof_launches;
 };
@@ -126,6 +128,7 @@ static void line_free(plf_line *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
     if (h->ev_front) (void)hipEventDestroy(h->ev_front);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     plf_order_free(h->order);
 }
 
@@ -614,8 +617,44 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
     if (rc != PLF_OK) return rc;
     if (!host_out && in_mem == PLF_MEM_DEVICE) return PLF_OK;
     int status = 0;
-    PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     int ret = PLF_OK;
+    // A few frames in flight (the drop-in loop): status, counts and the three result arrays come back through pinned memory with ONE synchronisation -- five
+    // copies into pageable memory, the first two followed by a wait for the counts, cost 150 us of a 6 ms call.
+    const int PIN_FRAMES = 8;
+    const size_t per_frame = (size_t)cap_dev * (sizeof(plf_keyline) + 32 + 3 * sizeof(double));
+    if (host_out && n_frames <= PIN_FRAMES) {
+        const size_t need = 64 + sizeof(int) * PIN_FRAMES + (size_t)PIN_FRAMES * per_frame + 16;
+        if (!h->h_pin || h->h_pin_bytes < need) {
+            if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; }
+            PLF_HIP_TRY(hipHostMalloc((void **)&h->h_pin, need, hipHostMallocDefault));
+            h->h_pin_bytes = need;
+        }
+        int *p_status = (int *)h->h_pin, *p_cnt = (int *)(h->h_pin + 64);
+        uint8_t *p_lines = h->h_pin + 64 + sizeof(int) * PIN_FRAMES;
+        uint8_t *p_eq = p_lines + (size_t)n_frames * cap_dev * sizeof(plf_keyline);      // (doubles: 8-byte aligned, plf_keyline is 68 bytes -- cap_dev * n * 68 is a multiple of 4 only)
+        p_eq += (8 - ((uintptr_t)p_eq & 7)) & 7;
+        uint8_t *p_desc = p_eq + (size_t)n_frames * cap_dev * 3 * sizeof(double);
+        PLF_HIP_TRY(hipMemcpyAsync(p_status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipMemcpyAsync(p_cnt, d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipMemcpyAsync(p_lines, d_lines, (size_t)n_frames * cap_dev * sizeof(plf_keyline), hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipMemcpyAsync(p_eq, d_eq, (size_t)n_frames * cap_dev * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipMemcpyAsync(p_desc, d_ldesc, (size_t)n_frames * cap_dev * 32, hipMemcpyDeviceToHost, s));
+        PLF_HIP_TRY(hipStreamSynchronize(s));
+        status = *p_status;
+        if (!(status & (4 | 1))) {
+            for (int f = 0; f < n_frames; f++) {
+                int n = p_cnt[f];
+                if (n > capacity) { n = capacity; ret = PLF_E_CAPACITY; }
+                n_out[f] = n;
+                if (n > 0) {
+                    memcpy(lines + (size_t)f * capacity, p_lines + (size_t)f * cap_dev * sizeof(plf_keyline), sizeof(plf_keyline) * n);
+                    memcpy(ldesc + (size_t)f * capacity * 32, p_desc + (size_t)f * cap_dev * 32, (size_t)32 * n);
+                    memcpy(line_eq + (size_t)f * capacity * 3, p_eq + (size_t)f * cap_dev * 3 * sizeof(double), sizeof(double) * 3 * n);
+                }
+            }
+        }
+    } else {
+    PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     if (host_out) {
         std::vector<int> cnt(n_frames);
         PLF_HIP_TRY(hipMemcpyAsync(cnt.data(), d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, s));
@@ -632,6 +671,7 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
         }
     }
     PLF_HIP_TRY(hipStreamSynchronize(s));
+    }
     if (status & 4) return PLF_E_HIP;   // the fused speculative launch gave up waiting for a band wave (never seen; see spec_wait_band)
     if (status & 1) {
         // The batch as a whole produced more rectangles than the pooled NFA buffers hold (thousands per frame on average: synthetic textures).

@@ -5,8 +5,12 @@ import csv, glob, os, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 bargs = sys.argv[1:] or ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--serial"]
 env = dict(os.environ, TMPDIR="/tmp")
+if os.environ.get("PMC_GROUPS"):
+    groups_env = [g.split(",") for g in os.environ["PMC_GROUPS"].split(";")]
 groups = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"], ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
           ["SQ_INST_CYCLES_SALU", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES"]]
+if os.environ.get("PMC_GROUPS"):
+    groups = groups_env
 res = collections.defaultdict(dict)
 for gi, g in enumerate(groups):
     d = "/tmp/pmc_sq_%d" % gi
