@@ -22,7 +22,7 @@ def _need_gpu():
 #   "rounds"     validation rounds (every band validates itself, all at once) until the fixpoint -- the default up to 16 frames;
 #   "one_round"  a single round, which rarely reaches the fixpoint: the serial commit wave then finishes the frame from the half-validated logs;
 #   "commit"     no rounds: the one-launch schedule with the serial commit wave (what more than 16 frames in flight take).
-SCHEDULES = pytest.mark.parametrize("schedule", ["rounds", "one_round", "commit"])
+SCHEDULES = pytest.mark.parametrize("schedule", ["rounds", "one_round", "commit", "fill"])
 
 
 def _set_schedule(monkeypatch, schedule):
@@ -30,6 +30,8 @@ def _set_schedule(monkeypatch, schedule):
         monkeypatch.setenv("PLF_LSD_SPEC_ROUNDS", "1")
     elif schedule == "commit":
         monkeypatch.setenv("PLF_LSD_SPEC_Z", "0")
+    elif schedule == "fill":       # validation rounds on the no-growth guess of the state above a band (PLF_LSD_SPEC_FILL, off by default)
+        monkeypatch.setenv("PLF_LSD_SPEC_FILL", "8")
 
 
 def _check(img, nlines, ext=None, lbd_sobel_input=0):
