@@ -1,3 +1,5 @@
+"""kernels of the LAST line-extractor call of a rocprofv3 --kernel-trace run, in order, with start and duration:
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python tools/latency_probe.py; python tools/kernel_sequence.py /tmp/kt"""
 import csv, sys, glob
 fn = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(fn)))

@@ -1,5 +1,7 @@
+"""single-frame LSD+LBD latency over six synthetic frames (host in, host out: the drop-in call)
+    python tools/latency_probe.py"""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from rgbd_pl_slam_amd import LineSegment
 from rgbd_pl_slam_amd.synth import synth_frame
