@@ -544,7 +544,9 @@ typedef struct {
  * plf_orb_extract_batch / plf_line_extract_batch with PLF_MEM_HOST).  Pointers of a disabled extractor may be NULL;
  * the match arrays are only written when a local map is set and may be NULL otherwise.
  * match_of_kp / match_of_line: -1 = none, >= 0 = index into the local map (ORBmatcher::SearchByProjection(Frame&, map points, th)
- * include/ORBmatcher.h:61; LSDmatcher::SearchByProjection(Frame&, map lines, th) include/LSDmatcher.h:40). */
+ * include/ORBmatcher.h:61; LSDmatcher::SearchByProjection(Frame&, map lines, th) include/LSDmatcher.h:40).
+ * n_kp_matches / n_line_matches count the entries >= 0 of the frame's match_of_* row AS RETURNED: when kp_capacity / line_capacity cut
+ * features (PLF_E_CAPACITY), the matches of the cut ones are not counted. */
 typedef struct {
     plf_keypoint *kps; uint8_t *desc; int32_t *n_kps; int32_t kp_capacity;
     plf_keyline *lines; uint8_t *ldesc; double *line_eq; int32_t *n_lines; int32_t line_capacity;

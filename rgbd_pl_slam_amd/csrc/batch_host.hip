@@ -512,7 +512,14 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
                 if (match_pts) memcpy(O.match_of_kp + g * O.kp_capacity, s.h_mkp + (size_t)f * w->orb_cap, sizeof(int32_t) * n);
                 else for (int i = 0; i < n; i++) O.match_of_kp[g * O.kp_capacity + i] = -1;
             }
-            if (O.n_kp_matches) O.n_kp_matches[g] = match_pts ? s.h_nmkp[f] : 0;
+            if (O.n_kp_matches) {
+                int nm = match_pts ? s.h_nmkp[f] : 0;
+                if (match_pts && n < s.h_nk[f]) {     // the caller's capacity cut key points: count what match_of_kp shows
+                    nm = 0;
+                    for (int i = 0; i < n; i++) nm += s.h_mkp[(size_t)f * w->orb_cap + i] >= 0;
+                }
+                O.n_kp_matches[g] = nm;
+            }
             if (J.rgbd) {
                 const plf_batch_rgbd &R = J.R;
                 if (R.kps_un) memcpy(R.kps_un + g * O.kp_capacity, s.h_kun + (size_t)f * w->orb_cap, sizeof(plf_keypoint) * n);
@@ -564,7 +571,14 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
                 if (match_lns) memcpy(O.match_of_line + g * O.line_capacity, s.h_mln + (size_t)f * w->line_cap, sizeof(int32_t) * n);
                 else for (int i = 0; i < n; i++) O.match_of_line[g * O.line_capacity + i] = -1;
             }
-            if (O.n_line_matches) O.n_line_matches[g] = match_lns ? s.h_nmln[f] : 0;
+            if (O.n_line_matches) {
+                int nm = match_lns ? s.h_nmln[f] : 0;
+                if (match_lns && n < s.h_nl[f]) {
+                    nm = 0;
+                    for (int i = 0; i < n; i++) nm += s.h_mln[(size_t)f * w->line_cap + i] >= 0;
+                }
+                O.n_line_matches[g] = nm;
+            }
             if ((s.h_status[1] & 8) && s.h_trunc[f]) w->n_trunc++;
             if (J.rgbd) {
                 const plf_batch_rgbd &R = J.R;

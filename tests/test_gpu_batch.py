@@ -339,6 +339,39 @@ def test_rectangle_pool_redo_in_one_worker_while_the_other_runs(monkeypatch):
         bx.close()
 
 
+def test_match_counts_follow_the_callers_capacity():
+    """kp_capacity / line_capacity below what the frame yields: PLF_E_CAPACITY, the rows hold the first `capacity` features and n_*_matches counts
+    the matches of THOSE"""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd import _lib as L
+    from rgbd_pl_slam_amd.synth import synth_frame
+    imgs = np.stack([synth_frame(310 + i) for i in range(3)])
+    r0 = orc.orb_extract(imgs[0], nfeatures=1000); l0 = orc.line_extract(imgs[0], 100)
+    mp = matchgen.make_local_map(r0["kps"], r0["desc"], 2000, 5)
+    ml = matchgen.make_map_lines(l0["kl"], l0["desc"], 300, 6)
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    bx = BatchExtractor(nfeatures=1000, nlines=100, width=640, height=480, frames_in_flight=4, devices=[0], max_mappoints=4096, max_maplines=512)
+    bx.set_local_map(mp, ml, th=3.0, nnratio=0.8, bounds=bounds)
+    bx.kp_capacity = 300; bx.nlines = 40          # what the wrapper hands to the driver as the caller's capacities
+    out = bx.alloc_outputs(3)
+    st = bx.extract_into(imgs, out)
+    assert st == L.PLF_E_CAPACITY
+    for f in range(3):
+        ro = orc.orb_extract(imgs[f], nfeatures=1000); rl = orc.line_extract(imgs[f], 100)
+        assert len(ro["kps"]) > 300 and len(rl["kl"]) > 40
+        assert out["n_kps"][f] == 300 and out["n_lines"][f] == 40
+        assert out["kps"][f].tobytes() == ro["kps"][:300].tobytes() and out["lines"][f].tobytes() == rl["kl"][:40].tobytes()
+        rm, rn = orc.search_by_projection_map(ro["kps"], ro["desc"], None, scale, bounds, mp, 3.0, 0.8, np.full(len(ro["kps"]), -1, np.int32))
+        assert np.array_equal(out["match_of_kp"][f], rm[:300]) and out["n_kp_matches"][f] == int((rm[:300] >= 0).sum())
+        lm, ln = orc.search_lines_by_projection(rl["kl"], rl["desc"], scale, ml, 3.0, 0.8, np.full(len(rl["kl"]), -1, np.int32))
+        assert np.array_equal(out["match_of_line"][f], lm[:40]) and out["n_line_matches"][f] == int((lm[:40] >= 0).sum())
+        if f == 0:
+            assert rn > int((rm[:300] >= 0).sum()) > 0    # the cut really drops matches
+    bx.close()
+
+
 def test_empty_and_bad_arguments():
     _need_gpu()
     import ctypes as C
