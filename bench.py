@@ -9,7 +9,7 @@ One "step" = one pass of the whole hot path over one batch of synthetic frames a
   LSDmatcher::SearchByProjection(Frame, map lines)   (500 map lines)
   LSDmatcher::SearchByProjection(Cur, Last)          (the brute-force Hamming kNN (k = 2) of the LBD descriptors + MAD rule)
 Workloads (--config, numbering = BASELINE.json configs[] counted from 1):
-  2 (default)  configs[1]: 640x480, 1000 ORB + 100 lines, the headline metric; --batch frames in flight per GPU (default 4096)
+  2 (default)  configs[1]: 640x480, 1000 ORB + 100 lines, the headline metric; --batch frames in flight per GPU (default 8192: eight region-growing chains per SIMD)
   3            configs[2]: 640x480, 2000 ORB + 200 lines, 8 frames in flight on one GPU
   4            configs[3]: 1280x960, 4000 ORB + 400 lines, batch 64 sharded over 8 GPUs = 8 frames in flight per GPU
 Frames are independent, so ranks shard the job with no collective (rgbd_pl_slam_amd.batch.shard = plf_batch_shard; weak scaling:
@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 M_POINTS, M_LINES = 5000, 500
 CONFIGS = {   # --config -> (width, height, ORB features, lines, frames in flight per GPU, label)
-    2: (640, 480, 1000, 100, 4096, "BASELINE configs[1]: VGA, 1000 ORB feats (8 levels) + 100 lines"),
+    2: (640, 480, 1000, 100, 8192, "BASELINE configs[1]: VGA, 1000 ORB feats (8 levels) + 100 lines"),
     3: (640, 480, 2000, 200, 8, "BASELINE configs[2]: VGA, 2000 ORB + 200 lines, 8 frames in flight"),
     4: (1280, 960, 4000, 400, 8, "BASELINE configs[3]: 1280x960, 4000 ORB + 400 lines, batch 64 over 8 GPUs = 8 frames in flight per GPU"),
 }

@@ -536,9 +536,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else if (B <= lat_max)
         hipLaunchKernelGGL(budget ? k_lsd_regions_lat_budget : k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
-    else if ((size_t)(g.rcap + 1) * 4 <= 5120) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
+    else if (!getenv("PLF_LSD_ONE_WAVE_GROUPS")) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
         const int wpg = getenv("PLF_LSD_WPG") ? max(1, min(16, atoi(getenv("PLF_LSD_WPG")))) : 8;
-        const size_t wave_lds = 5120 + 1024;
+        const size_t wave_lds = PLF_LSD_WAVE_LDS;
         hipLaunchKernelGGL(budget ? k_lsd_regions2_budget : k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B);
     }

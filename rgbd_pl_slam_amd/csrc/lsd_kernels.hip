@@ -777,8 +777,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
 }
 
 // LDS of one wave of the large-batch region kernel: the first 1280 words of the region list (rcap <= 1279 + the mailbox word) and 1 KB for the parked seed chunk
-#define PLF_LSD_WAVE_LIST 5120
-#define PLF_LSD_WAVE_LDS (PLF_LSD_WAVE_LIST + 1024)
+// (PLF_LSD_WAVE_LIST / PLF_LSD_WAVE_LDS: lsd_geom.h, shared with the host)
 #ifndef PLF_REGIONS_PRIO
 #define PLF_REGIONS_PRIO 3
 #endif
@@ -806,7 +805,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
     C.rxy_l = (LDS_PTR(uint32_t))smem;
-    C.rcap = g.rcap;
+    C.rcap = LDSOFF < 0 ? min(g.rcap, PLF_LSD_WAVE_LIST / 4 - 1) : g.rcap;   // (the large-batch kernel keeps a shorter head of the list in LDS)
     C.gcap = (int)g.s_stride;
     C.use_bm = 0; C.bm = (LDS_PTR(uint32_t))smem; C.regrow_n = -1;
     C.t_dead = BUDGET ? wall_clock64() + g.budget_ticks : 0ull;
@@ -954,7 +953,13 @@ __global__ void __launch_bounds__(64) k_lsd_regions_budget(float *__restrict__ a
     regions_body<0, 1, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
 }
 
-#ifdef PLF_REGIONS_WPE   // experiment switch (tools/variant_build.sh): cap the VGPRs of the large-batch region kernel for N waves per SIMD
+// VGPR cap of the large-batch region kernel = waves per SIMD it is built for (tools/variant_build.sh overrides it).  8: 64 VGPRs, 19 of them spilled (80 bytes of
+// scratch per lane) -- the kernel is slower per wave, and eight chains per SIMD instead of four more than make up for it (end of round 3: 8192 frames in
+// flight 35.3 k frames/s against 33.1 k with 4096 at 96 VGPRs; at 4096 in flight the two builds are equal, the co-runners get the registers)
+#ifndef PLF_REGIONS_WPE
+#define PLF_REGIONS_WPE 8
+#endif
+#if PLF_REGIONS_WPE > 0
 #define PLF_REGIONS_OCC __attribute__((amdgpu_waves_per_eu(PLF_REGIONS_WPE, PLF_REGIONS_WPE)))
 #else
 #define PLF_REGIONS_OCC

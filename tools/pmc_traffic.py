@@ -25,7 +25,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[k][0] += 1
             acc[k][1] += float(r["Counter_Value"])
     out["counters"][ctr] = {k: {"launches": v[0], "per_launch_KB": round(v[1] / v[0], 1)} for k, v in acc.items() if k.startswith("k_")}
-B = 4096
+B = 8192   # bench.py's default frames in flight (config 2)
 for i, a in enumerate(bargs):
     if a == "--batch":
         B = int(bargs[i + 1])
