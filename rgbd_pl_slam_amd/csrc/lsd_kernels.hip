@@ -826,6 +826,8 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     // One 16-byte broadcast read per seed replaces four readlanes; the kernel's own time is unchanged (69.5 vs 69.0 ms per 4096 frames), the step
     // goes from 131.7 to 129.3 ms.  (With two-wave workgroups this build lost: a fifth workgroup pair per CU became possible and the 2048 workgroups
     // of a launch were placed unevenly; an 8-wave workgroup cannot be placed a third time on a CU.)
+    // (Round 3, end: the kernel is capped at 64 VGPRs and the list head at 768 entries -- PLF_REGIONS_WPE, PLF_LSD_WAVE_LIST -- so that FOUR 8-wave workgroups fit a
+    // CU; the parked chunk matters more than before: the four registers would be four more spills.)
     typedef uint32_t park_t __attribute__((ext_vector_type(4)));
     LDS_PTR(park_t) park = (LDS_PTR(park_t))(smem + PLF_LSD_WAVE_LIST);
     for (int base = 0; base < NP; base += 64) {
