@@ -11,15 +11,15 @@ import bench
 
 out = {}
 cores = len(os.sched_getaffinity(0))
-for cfg, big in ((2, 4096), (3, 4096), (4, 1024)):
+for cfg, big in ((2, 8192), (3, 8192), (4, 2048)):   # (eight region chains per SIMD: 32 frames per CU x 256 CUs)
     W, H, NF, NL, B0, label = bench.CONFIGS[cfg]
     row = {"label": label}
-    for B in sorted({B0, big} if cfg != 2 else {8, 4096}):
+    for B in sorted({B0, big} if cfg != 2 else {8, big}):
         p = bench.Pipeline(W, H, NF, NL, B, 0, 30_000 + cfg)
         steps = 5 if B >= 1024 else 30
         el, _, _ = bench.timed(p, steps, 2)
         row["gpu_fps_%d_in_flight" % B] = round(B * steps / el, 1)
-        if cfg == 2 and B == 4096:   # config 5: the four matchers alone on resident features
+        if cfg == 2 and B == big:   # config 5: the four matchers alone on resident features
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(5): p.match_step()
             torch.cuda.synchronize()
