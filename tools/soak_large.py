@@ -1,0 +1,26 @@
+"""Large batches through the one-wave-per-frame region kernel (k_lsd_regions2: eight chains per SIMD, 768-entry list head in LDS): N mixed frames (texture
+families + polygon scenes) in ONE call, every frame against the oracle byte for byte.
+    python tools/soak_large.py [first_seed=0] [N=3000]"""
+import sys, os
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import orc
+from rgbd_pl_slam_amd import LineSegment
+from rgbd_pl_slam_amd.synth import texture_frame, synth_frame
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+pool = ThreadPoolExecutor(min(64, os.cpu_count() or 8))
+imgs = list(pool.map(lambda s: texture_frame(seed0 + s, size=(640, 480))[0] if s % 3 else synth_frame(seed0 + s), range(N)))
+refs = list(pool.map(lambda im: orc.line_extract(im, 100), imgs))
+ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=N)
+bad = 0
+for rep in range(2):
+    res = ls.extract_batch(np.stack(imgs))
+    nb = sum(not (res[f][0].tobytes() == refs[f]["kl"].tobytes() and np.array_equal(res[f][1], refs[f]["desc"])) for f in range(N))
+    print("batch of %d frames (seeds %d..%d), call %d: %d mismatches" % (N, seed0, seed0 + N - 1, rep + 1, nb), flush=True)
+    bad += nb
+ls.close()
+sys.exit(1 if bad else 0)
