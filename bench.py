@@ -408,8 +408,18 @@ def main():
     # the job = world * B frames per step; this rank's block of it (contiguous, plf_batch_shard) -- always B frames: weak scaling
     lo, hi = shard(world * B, world, rank)
     assert hi - lo == B
-    pipe = Pipeline(W, H, NFEAT, NLINES, B, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait, defer_match=not args.no_defer_match,
-                    distinct=args.distinct)
+    def make_pipe(nb):
+        return Pipeline(W, H, NFEAT, NLINES, nb, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait,
+                        defer_match=not args.no_defer_match, distinct=args.distinct)
+    try:
+        pipe = make_pipe(B)
+    except Exception as e:   # (8192 frames in flight hold ~150 GB of the 288 GB: a GPU that cannot give them runs the 4096-frame workload, and says so)
+        if args.batch > 0 or B <= 4096 or world > 1:
+            raise
+        sys.stderr.write("bench.py: %d frames in flight could not be set up (%r); falling back to 4096\n" % (B, e))
+        torch.cuda.empty_cache()
+        B = 4096
+        pipe = make_pipe(B)
     elapsed, reg_ms, reg_launches = timed(pipe, args.steps, args.warmup, dist)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
