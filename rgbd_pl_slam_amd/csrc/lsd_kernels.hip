@@ -1436,6 +1436,11 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
         for (int i = lane; i < SB.bm_words; i += 64) outb[i] = bm[i] & ~halo[i];   // (halo[] = the band's initial state, written when its own seeds started: zeros for band 0)
         if (lane == 0) SB.nrects[fb] = nrect_band;
     }
+    // A band wave that ran out of its time budget leaves an INCOMPLETE log: the seeds it did not reach are in neither S nor T, so the commit wave -- a later launch
+    // with a clock of its own in the two-launch schedule -- would never see them as candidates and could finish "in time" with regions missing.  Such a
+    // log is published like an overflowed one (cnt[2] != 0): the commit wave then grows the band itself, from T, under its own budget -- exact if it finishes,
+    // truncated and reported if it does not.
+    if (BUDGET && truncated) ovf = 2;
     if (lane == 0) { SB.cnt[fb * 4 + 0] = nrec; SB.cnt[fb * 4 + 1] = tn; SB.cnt[fb * 4 + 2] = ovf; SB.cnt[fb * 4 + 3] = (int)(wall_clock64() & 0x7fffffff); }   // ([3]: 100 MHz timestamp, diagnostics)
     if (ovf && SB.round_state && lane == 0) SB.round_state[f * 4 + 3] = 1;   // an incomplete log cannot be validated: the frame takes the serial commit
     __threadfence();   // every lane's log entries are visible device-wide before the flag

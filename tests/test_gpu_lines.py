@@ -440,3 +440,27 @@ def test_time_budget_leaves_a_prefix_and_is_invisible_when_not_spent():
             if not flags[f]:
                 assert len(segs) == len(refs[f % 6])
         ls.close()
+
+
+@pytest.mark.parametrize("B,ms", [(16, 2.0), (16, 4.0), (64, 3.0), (64, 8.0)])
+def test_time_budget_two_launch_speculative_schedule(B, ms):
+    """with 14-16 or more than 49 frames in flight the speculative schedule is two launches (band waves, then commit waves), each with a clock of its own.
+    A band wave that runs out of time leaves an incomplete log; the commit wave -- which may well finish inside ITS budget -- must not take that log for the whole
+    band.  Every frame is a prefix of the reference's segments, and a frame that is not flagged as truncated is complete."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment, _lib as L
+    from rgbd_pl_slam_amd.synth import synth_frame
+    imgs = np.stack([synth_frame(9200 + i) for i in range(8)])
+    refs = [orc.lsd_detect(im)["lines"] for im in imgs]
+    ls = LineSegment(nlines=100, max_batch=B, max_ms=ms)
+    batch = np.stack([imgs[i % 8] for i in range(B)])
+    ls.extract_batch(batch); ls.extract_batch(batch)
+    flags = ls.truncated(B)
+    status = ls.last_status()
+    assert status in (0, L.PLF_W_TRUNCATED) and (status == L.PLF_W_TRUNCATED) == bool(flags.sum() > 0)
+    for f in range(B):
+        segs = ls.segments(f)
+        assert _is_prefix(segs, refs[f % 8]), "frame %d" % f
+        if not flags[f]:
+            assert len(segs) == len(refs[f % 8]), "frame %d finished in time but holds %d of %d segments" % (f, len(segs), len(refs[f % 8]))
+    ls.close()

@@ -138,43 +138,59 @@ def test_hamming_properties_full_size():
     assert bool((dab[i, j] <= dab[i, k] + dbb[k, j]).all())
 
 
-def test_bench_size_batch_is_exact_and_deterministic():
-    """BASELINE-size run: 4096 frames in flight (the default of bench.py; 16 region-growing chains per CU).  Every replica of a
-    frame must reproduce the bytes of its original, and the originals must equal the oracle: key lines, LBD rows, line
-    equations, key points, descriptors.  (Size-independent property: idempotence under batching.)"""
+@pytest.mark.parametrize("w,h,B,R,nfeat,nlines", [(640, 480, 8192, 64, 1000, 100), (1280, 960, 2048, 16, 4000, 400)])
+def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines):
+    """The shapes the headline is quoted on: 8192 VGA frames in flight (the default of bench.py: eight region-growing chains per SIMD, the 64-register build of
+    k_lsd_regions2) and 2048 frames of 1280x960 with 4000 ORB + 400 lines (BASELINE.md's configs[3] shape at bench scale), R independently seeded frames tiled to
+    the batch.  Every replica of a frame must reproduce the bytes of its original, and the originals must equal the oracle: key lines, LBD rows, line equations,
+    key points, descriptors.  (Size-independent property: idempotence under batching.)  Falls back to half the batch if the device memory does not hold it."""
     _need_gpu()
     import torch
-    from rgbd_pl_slam_amd import ORBextractor, LineSegment
-    from rgbd_pl_slam_amd.synth import synth_batch
+    from concurrent.futures import ThreadPoolExecutor
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment, PlfError
+    from rgbd_pl_slam_amd.synth import synth_frame, texture_frame
     from rgbd_pl_slam_amd._lib import KP_DTYPE
-    B, R = 4096, 8
-    base = synth_batch(900, R)
+    base = np.stack([synth_frame(900 + r, w=w, h=h) if r % 3 else texture_frame(7000 + r, size=(w, h))[0] for r in range(R)])
+    with ThreadPoolExecutor(16) as pool:
+        ref_orb = list(pool.map(lambda im: orc.orb_extract(im, nfeatures=nfeat), base))
+        ref_line = list(pool.map(lambda im: orc.line_extract(im, nlines), base))
+    while True:
+        try:
+            ext = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, max_batch=B)
+            try:
+                ls = LineSegment(nlines=nlines, max_width=w, max_height=h, max_batch=B)
+            except PlfError:
+                ext.close(); raise
+            break
+        except PlfError:
+            assert B > 512, "not even 512 frames of %dx%d fit" % (w, h)
+            B //= 2
     d = torch.from_numpy(np.concatenate([base] * (B // R))).cuda()
-    ext = ORBextractor(max_width=640, max_height=480, max_batch=B)
-    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
     cap = ext.capacity
     kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
     n = torch.zeros(B, dtype=torch.int32, device="cuda")
-    lines = torch.zeros((B, 100, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, 100, 32), dtype=torch.uint8, device="cuda")
-    leq = torch.zeros((B, 100, 3), dtype=torch.float64, device="cuda"); nl = torch.zeros(B, dtype=torch.int32, device="cuda")
+    lines = torch.zeros((B, nlines, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, nlines, 32), dtype=torch.uint8, device="cuda")
+    leq = torch.zeros((B, nlines, 3), dtype=torch.float64, device="cuda"); nl = torch.zeros(B, dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    ext.extract_batch_device(d, 640, 480, kps, desc, n, cap, s)
-    ls.extract_batch_device(d, 640, 480, lines, ldesc, leq, nl, 100, s)
+    ext.extract_batch_device(d, w, h, kps, desc, n, cap, s)
+    ls.extract_batch_device(d, w, h, lines, ldesc, leq, nl, nlines, s)
     torch.cuda.synchronize()
+    assert ls.last_status() == 0
     nh, nlh = n.cpu().numpy(), nl.cpu().numpy()
     assert (nh.reshape(-1, R) == nh[:R]).all() and (nlh.reshape(-1, R) == nlh[:R]).all()
-    for f in range(R):   # replicas == originals, compared on the device (the full arrays are ~1 GB)
+    for f in range(R):   # replicas == originals, compared on the device (the full arrays are > 1 GB)
         k = int(nh[f]); l = int(nlh[f])
         assert bool((desc[f::R, :k] == desc[f, :k]).all()) and bool((kps[f::R, :k].view(torch.int32) == kps[f, :k].view(torch.int32)).all())
         assert bool((ldesc[f::R, :l] == ldesc[f, :l]).all()) and bool((lines[f::R, :l].view(torch.int32) == lines[f, :l].view(torch.int32)).all())
         assert bool((leq[f::R, :l].view(torch.int64) == leq[f, :l].view(torch.int64)).all())
-        ref = orc.orb_extract(base[f])
-        assert k == len(ref["kps"]) and np.array_equal(desc[f, :k].cpu().numpy(), ref["desc"])
+        ref = ref_orb[f]
+        assert k == len(ref["kps"]) and np.array_equal(desc[f, :k].cpu().numpy(), ref["desc"]), "frame %d" % f
         kk = np.frombuffer(kps[f, :k].cpu().numpy().tobytes(), KP_DTYPE)
         for fld in ("x", "y", "angle", "response"):
             assert np.array_equal(kk[fld].view(np.uint32), ref["kps"][fld].view(np.uint32)), fld
-        rl = orc.line_extract(base[f], 100)
-        assert l == len(rl["kl"]) and np.array_equal(ldesc[f, :l].cpu().numpy(), rl["desc"])
+        rl = ref_line[f]
+        assert l == len(rl["kl"]) and np.array_equal(ldesc[f, :l].cpu().numpy(), rl["desc"]), "frame %d" % f
+        assert lines[f, :l].cpu().numpy().tobytes() == rl["kl"].tobytes() and np.array_equal(leq[f, :l].cpu().numpy().view(np.uint64), rl["eq"].view(np.uint64)), "frame %d" % f
     ext.close(); ls.close()
 
 
