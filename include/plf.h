@@ -251,7 +251,7 @@ typedef struct { float Rcw[9], tcw[3], Rlw[9], tlw[3]; float fx, fy, cx, cy, bf,
  * include/ORBmatcher.h:78 (so@0x80d00).  match_of_kp as above (values >= 0 are last-frame indices).  check_orientation: 0 / 1 = mbCheckOrientation;
  * 2 = as 1, and a key point whose assignment the rotation-histogram check removed is marked -3 instead of -1: the reference sets
  * CurrentFrame.mvpMapPoints[k] = NULL there, which an adapter can only tell from "never assigned" (possibly still holding a map point without observations)
- * with the distinct value (plf.hpp does so). */
+ * with the distinct value (plf.hpp does so).  On INPUT -3 reads as -1 (free) in every matcher, so the array of one call can be handed to the next. */
 int plf_match_project_lastframe(plf_matcher *h, const plf_frame_view *cur, const plf_lastframe_view *last,
                                 const plf_pose_pair *pose, float th, int32_t mono, int32_t check_orientation,
                                 int32_t *match_of_kp, int32_t *nmatches, void *stream);

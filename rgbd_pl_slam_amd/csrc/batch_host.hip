@@ -542,6 +542,9 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
             if (rc != PLF_OK && rc != PLF_E_CAPACITY) return rc;
             if (rc == PLF_E_CAPACITY) *soft = PLF_E_CAPACITY;
             for (int f = 0; f < s.n; f++) s.h_nl[f] = nl[f];
+            // the time-budget flags of the failed pass are meaningless as well: those of the redo (collected over its pieces by the line extractor)
+            s.h_status[1] &= ~8;
+            if (plf_line_last_status(w->line, w->s_line) == PLF_W_TRUNCATED && plf_line_truncated(w->line, s.h_trunc, s.n) == PLF_OK) s.h_status[1] |= 8;
             if (match_lns || J.rgbd) {   // the Frame tail / matches of the failed pass are meaningless: redo them on the fresh lines
                 const size_t K = (size_t)s.n * w->line_cap;
                 W_TRY(hipMemcpyAsync(s.d_lines, s.h_lines, K * sizeof(plf_keyline), hipMemcpyHostToDevice, w->s_out));
@@ -808,7 +811,7 @@ extern "C" int plf_batch_extract_rgbd(plf_batch *b, const uint8_t *images, int64
 // frames of the last plf_batch_extract* call whose LSD region growing ran out of plf_line_params.max_ms (0 without a budget)
 extern "C" int64_t plf_batch_truncated_frames(const plf_batch *b)
 {
-    if (!b) return PLF_E_BADARG;
+    if (!b) return 0;   // (a count, not a status: no handle, no frames)
     int64_t n = 0;
     for (const Worker *w : b->workers) n += w->n_trunc;
     return n;

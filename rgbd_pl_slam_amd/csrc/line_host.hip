@@ -114,6 +114,11 @@ struct plf_line {
     size_t h_pin_bytes;
     double prof_ms;
     int prof_launches;
+    // a batch that was redone in halves (status bit 1): the per-frame "ran out of max_ms" flags and the status bits of ALL the pieces, accumulated on the host
+    // (the device words only ever hold the last piece's)
+    int32_t *retry_flags;      // [max_batch]
+    int retry_status, retry_depth;
+    bool retry_valid;
 };
 
 static void line_free(plf_line *h)
@@ -129,6 +134,7 @@ static void line_free(plf_line *h)
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
     if (h->ev_front) (void)hipEventDestroy(h->ev_front);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    free(h->retry_flags); h->retry_flags = nullptr;
     plf_order_free(h->order);
 }
 
@@ -251,9 +257,11 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     plf_line *h = (plf_line *)calloc(1, sizeof(plf_line));
     if (!h) return PLF_E_NOMEM;
     h->prm = *p; h->device = p->device;
+    h->retry_flags = (int32_t *)calloc((size_t)p->max_batch, sizeof(int32_t));
+    if (!h->retry_flags) { free(h); return PLF_E_NOMEM; }
     LsdGeom g;
     int rc = line_geometry(h, p->max_width, p->max_height, &g);
-    if (rc != PLF_OK) { free(h); return rc; }
+    if (rc != PLF_OK) { free(h->retry_flags); free(h); return rc; }
     h->alloc_full = g.full_stride; h->alloc_scaled = g.s_stride; h->alloc_rect_cap = g.rect_cap;
     h->alloc_nfa_pool = (int)line_nfa_pool(g, (size_t)p->max_batch);
     // cv::getGaussianKernel(7, 0.6/0.8, CV_64F):  h = ceil(sigma * sqrt(2 * 3 * ln 10)) = 3 -> ksize 7
@@ -593,6 +601,7 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
     PLF_HIP_TRY(hipSetDevice(h->device));
     int rc = line_configure(h, width, height);
     if (rc != PLF_OK) return rc;
+    if (h->retry_depth == 0) { h->retry_valid = false; h->retry_status = 0; }
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
     plf_order_begin(h->order, s);
@@ -678,14 +687,28 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
         // One frame always fits, so the batch is redone in halves.
         if (n_frames == 1) return PLF_E_RECTS;
         const int32_t h1 = n_frames / 2;
+        int32_t *const flags0 = h->retry_flags;        // the pieces file their flags at their own frame offsets
+        h->retry_depth++;
         const int ra = plf_line_extract_batch(h, gray, in_mem, h1, width, height, pitch, frame_stride, lines, ldesc, line_eq, n_out, out_mem, capacity,
                                               stream);
+        h->retry_flags = flags0 + h1;
         const int rb = plf_line_extract_batch(h, gray + (size_t)h1 * frame_stride, in_mem, n_frames - h1, width, height, pitch, frame_stride,
                                               lines + (size_t)h1 * capacity, ldesc + (size_t)h1 * capacity * 32, line_eq + (size_t)h1 * capacity * 3,
                                               n_out + h1, out_mem, capacity, stream);
+        h->retry_flags = flags0;
+        h->retry_depth--;
+        h->last_frames = n_frames;
+        if (h->retry_depth == 0) h->retry_valid = true;
         if (ra != PLF_OK && ra != PLF_E_CAPACITY) return ra;
         if (rb != PLF_OK && rb != PLF_E_CAPACITY) return rb;
         return (ra == PLF_E_CAPACITY || rb == PLF_E_CAPACITY) ? PLF_E_CAPACITY : PLF_OK;
+    }
+    if (h->retry_depth > 0) {   // a piece of a batch that is being redone in halves: its flags and status bits go to the host copy
+        h->retry_status |= status & (2 | 8);
+        if (h->g.budget_ticks) {
+            PLF_HIP_TRY(hipMemcpyAsync(h->retry_flags, h->d_counters + 3 * (size_t)h->prm.max_batch + 16, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, s));
+            PLF_HIP_TRY(hipStreamSynchronize(s));
+        } else memset(h->retry_flags, 0, sizeof(int32_t) * n_frames);
     }
     if (status & 2) ret = PLF_E_CAPACITY;
     return ret;
@@ -703,6 +726,7 @@ extern "C" int plf_line_last_status(plf_line *h, void *stream)
     int status = 0;
     PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
+    if (h->retry_valid) status = (status & ~1) | h->retry_status;   // a batch redone in halves: the bits of all its pieces
     return (status & 4) ? PLF_E_HIP : (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : (status & 8) ? PLF_W_TRUNCATED : PLF_OK;
 }
 
@@ -711,7 +735,11 @@ extern "C" int plf_line_truncated(plf_line *h, int32_t *flags, int32_t n)
 {
     if (!h || !flags || n < 1 || n > h->last_frames) return PLF_E_BADARG;
     PLF_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = h->last_stream_set ? h->last_stream : h->stream;
+    if (h->retry_valid) { memcpy(flags, h->retry_flags, sizeof(int32_t) * n); return PLF_OK; }   // the batch was redone in halves: flags collected piece by piece
+    // on the handle's own stream, behind the event of the last call (never on the caller's stream of that call, which may be gone by now: ADVICE r03)
+    hipStream_t s = h->stream;
+    plf_order_begin(h->order, s);
+    PlfOrderGuard order_guard_{h->order, s};
     PLF_HIP_TRY(hipMemcpyAsync(flags, h->d_counters + 3 * (size_t)h->prm.max_batch + 16, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
     return PLF_OK;

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_match_project_points_slow(const FrameDe
     int *match = match_all + (size_t)f * kp_stride;
     uint8_t *done = done_all + (size_t)f * MP.m;
     const bool bFactor = th != 1.0f;
-    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
     if (t == 0) s_acc = 0;
     for (int m = t; m < MP.m; m += T) done[m] = MP.in_view[m] ? 0 : 1;
     __syncthreads();
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_mp_rounds(const FrameDev *__restrict__ 
     const uint8_t *done = done_all + (size_t)f * MP.m;
     const uint32_t *cand = cand_all + (size_t)f * cand_cap;
     const int2 *span = span_all + (size_t)f * MP.m;
-    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
     if (t == 0) { s_acc = 0; s_n[0] = 0; s_n[1] = 0; }
     __syncthreads();
     for (int m0 = 0; m0 < MP.m; m0 += T) {
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) k_match_lastframe(const FrameDev *__restr
     // point of localisation mode) stays available to later points and is overwritten; the relocalisation overload tests the pointer only
     const uint8_t *obs = RL.on ? nullptr : Lf.obs_positive;
 #define KP_FREE(idx) (claim[idx] == -1 || (obs && claim[idx] >= 0 && !obs[claim[idx]]))
-    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
     if (t < HISTO_LENGTH) hist[t] = 0;
     if (t == 0) s_acc = 0;
     for (int i = t; i < Lf.n; i += T) {
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(256) k_lf_rounds(const FrameDev *__restrict__ 
     const uint32_t *cand = cand_all + (size_t)f * cand_cap;
     const int2 *span = span_all + (size_t)f * item_stride;
     const uint8_t *obs = Lf.obs_positive;
-    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
     for (int i = t; i < Lf.n; i += T) assign[i] = 0xFFFFu;
     if (t < HISTO_LENGTH) hist[t] = 0;
     if (t == 0) { s_acc = 0; s_n[0] = 0; s_n[1] = 0; }
@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(256) k_project_kf_greedy(FrameDev F, Pts3Dev P
     __shared__ int s_left, s_acc;
     const int t = threadIdx.x, T = blockDim.x;
     if (F.n_dev) F.n = min(F.n, *F.n_dev);
-    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
     if (t == 0) s_acc = 0;
     for (int i = t; i < P.m; i += T) {
         float u = 0.f, v = 0.f, invz = 0.f, radius = 0.f;
@@ -1325,7 +1325,7 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
     int *match = match_all + (size_t)f * line_stride;
     uint8_t *done = done_all + (size_t)f * ML.m;
     const bool bFactor = th != 1.0f;
-    for (int k = t; k < F.n; k += T) claim[k] = match[k];
+    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
     if (t == 0) s_acc = 0;
     for (int m = t; m < ML.m; m += T) done[m] = ML.in_view[m] ? 0 : 1;
     __syncthreads();

@@ -362,6 +362,7 @@ def test_lines_thousands_of_rectangles(monkeypatch):
     res = ls8.extract_batch(np.stack([stripes] * 8))          # staged kernels: the pool overflows, the host-buffer call splits the batch
     for f in range(8):
         assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"])
+    assert ls8.last_status() == L.PLF_OK and not ls8.truncated(8).any()   # status and per-frame flags cover all the pieces of a batch that was redone in halves
     ls8.extract_batch_device(d_img, 640, 480, d_lines, d_desc, d_eq, d_n, 100)
     assert ls8.last_status() == L.PLF_E_RECTS
     ls8.extract_batch_device(d_img[:2], 640, 480, d_lines, d_desc, d_eq, d_n, 100)
