@@ -156,7 +156,7 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     // The USED flags live in the angle map, so a workgroup needs ~6 KB and a CU hosts as many frames as it has wave
     // slots: the kernel is a latency-bound serial chain per frame and its throughput is the number of frames in flight.
     g->rcap = 1279;   // (1535 until the large-batch kernel parked its seed chunk in LDS: no measurable difference, 68.8 vs 68.8 ms per 4096 frames)
-    if (const char *e = getenv("PLF_LSD_RCAP")) { if (atoi(e) >= 63 && atoi(e) <= 16384) g->rcap = atoi(e); }
+    if (const char *e = getenv("PLF_LSD_RCAP")) { if (atoi(e) >= 127 && atoi(e) <= 16384) g->rcap = atoi(e); }   // (>= 96: chunk_taken parks its flag words in list entries 32..95)
     // Rectangles per frame: regions are disjoint and one that yields a rectangle owns >= min_reg_size pixels, so sw * sh / min_reg_size bounds
     // their number for ANY image (13107 at VGA, 46k at 1280x960; real frames produce 500-1500): no frame can overflow its rows.  Only the NFA
     // stage buffers are pooled over the batch (line_nfa_pool).
@@ -232,7 +232,7 @@ static int line_configure(plf_line *h, int w, int hh)
     PLF_HIP_TRY(hipMemcpy(h->d_yofs, yofs.data(), sizeof(int) * g.sh, hipMemcpyHostToDevice));
     PLF_HIP_TRY(hipMemcpy(h->d_yb, yb.data(), sizeof(float2) * g.sh, hipMemcpyHostToDevice));
     h->g = g;
-    h->regions_lds = (size_t)(g.rcap + 1) * 4 + 64;
+    h->regions_lds = (size_t)(g.rcap + 1) * 4 + 8 + 768 + 64;   // list + mailbox word, region2rect's staging (RegCtx::stg)
     h->finalize_lds = (size_t)g.sort_lds * 8 + 260 * 4;   // (the compaction flags alias the sort keys)
     h->nfa_lds = (size_t)g.sh * 2 * sizeof(int) + 64;
     h->cur_w = w; h->cur_h = hh;

@@ -9,11 +9,11 @@ struct LsdTaps { double k[7]; };  // cv::getGaussianKernel(7, 0.75, CV_64F)
 struct LbdCoefs { float gL[21]; float gG[63]; };  // (float) of the double LBD band / global Gaussian weights
 
 // LDS of one wave of the large-batch region kernel (k_lsd_regions2): the first words of the region list (rcap + the mailbox word) and 1 KB for the parked seed chunk
-// (3072 + 1024 bytes: 32 waves = 128 KB per CU -- eight region waves per SIMD, see k_lsd_regions2)
+// and 768 bytes of staging for region2rect's ordered sums (3072 + 1024 + 768 bytes: 32 waves = 152 KB per CU -- eight region waves per SIMD, see k_lsd_regions2)
 #ifndef PLF_LSD_WAVE_LIST
 #define PLF_LSD_WAVE_LIST 3072
 #endif
-#define PLF_LSD_WAVE_LDS (PLF_LSD_WAVE_LIST + 1024)
+#define PLF_LSD_WAVE_LDS (PLF_LSD_WAVE_LIST + 1024 + 768)
 
 struct LsdGeom {
     int w, h;             // input image

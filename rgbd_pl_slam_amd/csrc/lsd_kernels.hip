@@ -294,8 +294,7 @@ struct RegCtx {
     const double *modgrad;
     const double2 *cs;
     const float2 *cs0;
-    int cbase;                 // first pixel of the 64-pixel seed chunk being scanned
-    unsigned long long cused;  // pixels of that chunk accepted into a region since the chunk was loaded
+    int cbase;                 // first pixel of the 64-pixel seed chunk being scanned (regions_body; chunk_taken)
     LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
     int rcap;
@@ -303,6 +302,7 @@ struct RegCtx {
     int use_bm;                // speculative mode: the USED flags live in an LDS bitmap (bm), the angle words are read-only
     LDS_PTR(uint32_t) bm;
     int regrow_n;              // size of the list refine() regrew (-1: it did not regrow)
+    LDS_PTR(double) stg;       // 96 doubles of staging for region2rect's ordered sums (32 points x 3), or null: the sums are then replayed with v_readlane
     unsigned long long t_dead; // time budget (plf_line_params.max_ms): wall_clock64() value after which the frame stops; 0 = no budget (a constant in every
                                // kernel without the budget, so the test folds away)
 };
@@ -399,25 +399,38 @@ __device__ __forceinline__ GrowTh grow_thresholds(double prec)
 }
 
 // 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order
-struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle word (candidate iff < 0x80000000)
+struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle word (candidate iff < 0x80000000 and the lane is valid)
 // The cos/sin increment is fetched together with the angle word (fetching it only for candidates, after the word has arrived, saves HBM traffic but puts a
 // second dependent round trip -- and an s_waitcnt that also stalls the group being processed -- into every step of the chain: 77.2 -> 71.4 ms per 4096
-// frames).  (A single-predicate, single-branch form of this function was measured too: 3 VGPRs more and 2.6 % slower.)
-__device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, int lane, int slot, int kx, int ky)
+// frames).
+// Round 4: EVERY lane loads (from a clamped address) and the lanes that hold nothing come back as a wave-wide mask (`valid`, scalar registers), instead of three
+// nested EXEC regions that each re-materialised five default values: ~35 vector + ~20 scalar instructions per group became ~15 + 6.  One test covers the image
+// border: a region point is a DEFINED pixel, and ll_angle leaves the last row and the last column NOTDEF, so x <= W-2 and y <= H-2; x-1 = -1 addresses the last
+// column of the row above (NOTDEF: never a candidate), and only y-1 = -1 leaves the frame -- with a negative index.
+__device__ __forceinline__ Grp group_at(const RegCtx &C, uint32_t pxy, int kx, int ky, unsigned long long &valid)
 {
     Grp G;
-    G.w = 0xFFFFFFFFu; G.csx = 0.0; G.csy = 0.0; G.a = -1; G.xy = 0u;
-    if (lane < 63 && slot < cnt) {
-        const uint32_t pxy = rxy_get(C, first + slot);
-        const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
-        if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
-            G.a = yy * C.W + xx;
-            G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            const double2 c = C.cs[G.a];
-            G.w = ang_load(C, G.a);
-            G.csx = c.x; G.csy = c.y;
-        }
-    }
+    const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
+    G.a = yy * C.W + xx;
+    G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
+    valid = __ballot(G.a >= 0);
+    const int af = min(max(G.a, 0), C.W * C.H - 1);   // (lanes past the group's last point hold whatever their list slot holds)
+    const double2 c = C.cs[af];
+    G.w = ang_load(C, af);
+    G.csx = c.x; G.csy = c.y;
+    return G;
+}
+__device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, int slot, int kx, int ky, unsigned long long &valid)
+{
+    const int idx = first + slot;
+    uint32_t pxy = C.rxy_l[min(idx, C.rcap)];      // (the word at rcap is the spare mailbox word: readable)
+    Grp G;
+    if (first + cnt > C.rcap) {                    // rare, wave-uniform: part of the group lives in the global part of the list.  A branch of its own, with the
+        asm volatile("");                          // dependent load and its wait inside: merged into the common path it would put an s_waitcnt vmcnt(0) -- i.e. a
+        if (slot < cnt && idx >= C.rcap) pxy = C.rxy_g[idx];   // wait for the CURRENT group's data -- in front of every prefetch
+        G = group_at(C, pxy, kx, ky, valid);
+    } else G = group_at(C, pxy, kx, ky, valid);
+    valid &= (1ull << (9 * cnt)) - 1ull;           // cnt <= 7: lane 63 never
     return G;
 }
 
@@ -435,57 +448,65 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
 // band ("border") are decided by the exact test.  The USED flags arrive with the angle words of a group, i.e. they
 // are as old as the group's load: a pixel accepted since then is removed from the later lanes of the current group
 // and from the lanes of the already-loaded next group by comparing addresses.
+// Round 4 (the step is bound by instruction issue, vector and scalar alike): two tests of the classification went -- `S . u > 0` is implied by both cone
+// comparisons (|S x u| >= 0 and t1, t2 > 0), and |S|^2 >= 0.25 always holds: S starts as a unit vector and every accepted lane has S . u > 0 (it passed the
+// cone test, or it was a border lane, and border lanes pass `|S x u| < t2 * S . u` as well), so |S| only grows; and the pixels a region takes out of the seed
+// chunk are no longer tracked per accept (seven scalar instructions each) but read off the list once, when a small region ends (regions_body).
 __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out)
 {
     const int lane = plf_lane();
     double reg_angle = (double)deg0 * DEG2RAD_D;
     bool theta_valid = true;              // reg_angle is the value the reference holds for the current sums
     float sumdx = cs0.x, sumdy = cs0.y;   // float(cos(reg_angle)), float(sin(reg_angle))
+    const uint32_t sxy = (uint32_t)sx | ((uint32_t)sy << 16);
     if (lane == 0) {
-        rxy_put(C, 0, (uint32_t)sx | ((uint32_t)sy << 16));
+        rxy_put(C, 0, sxy);
         used_set(C, sy * C.W + sx, __float_as_uint(deg0));
     }
     CBAR();
     int n = 1, i = 0;
     const int slot = lane / 9, k9 = lane - slot * 9;
     const int kx = k9 % 3 - 1, ky = k9 / 3 - 1;
-    int cur_n = 1;
     // (the first group is the seed itself: its neighbourhood is addressed from (sx, sy) directly, not through the list entry lane 0 has just written)
-    Grp cur;
-    cur.w = 0xFFFFFFFFu; cur.csx = 0.0; cur.csy = 0.0; cur.a = -1; cur.xy = 0u;
-    if (lane < 9) {
-        const int xx = sx + kx, yy = sy + ky;
-        if (xx >= 0 && xx < C.W && yy >= 0 && yy < C.H) {
-            cur.a = yy * C.W + xx;
-            cur.xy = (uint32_t)xx | ((uint32_t)yy << 16);
-            const double2 c = C.cs[cur.a];
-            cur.w = ang_load(C, cur.a);
-            cur.csx = c.x; cur.csy = c.y;
-        }
-    }
-    unsigned long long cur_stale = 0ull;   // lanes whose pixel was accepted after its word was loaded
+    // The group being processed (`cur`) is only ever written by the hand-over copy at the top of the loop, never by a load: with the seed's group loaded straight
+    // into `cur` in front of the loop (rounds 1-3) the compiler had to place the wait for THOSE loads at the first use of `cur` inside the loop -- behind the
+    // prefetch of the next group -- and that one static s_waitcnt vmcnt(0) made every iteration wait for the prefetch it had just issued.
+    int nx_n = 1, cur_n;
+    unsigned long long nx_valid, nx_stale = 0ull;   // nx_stale: lanes whose pixel was accepted after its word was loaded
+    Grp nx = group_at(C, sxy, kx, ky, nx_valid);
+    nx_valid &= 0x1FFull;
     // All per-lane predicates of the accept loop are kept as wave-uniform 64-bit masks (the compares write them
     // directly), so the loop control is scalar and nothing bounces between VGPR booleans and masks.
-    while (i < n) {
+    for (;;) {
         CNT(7, 1);
+        // ---- hand-over: the group fetched ahead becomes the current one (the wait for its loads lands here)
+        const Grp cur = nx;
+        const unsigned long long cur_valid = nx_valid, cur_stale = nx_stale;
+        cur_n = nx_n;
+#ifdef PLF_LSD_TIMING
+        { TIC(tw); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TOC(20, tw); TOCB(22, tw); }
+#endif
+        // (everything that reads what the current group's loads brought is computed HERE, in front of the prefetch, with a compiler barrier behind it: the wait for
+        // those loads must not end up behind the loads of the next group -- vmcnt counts in order, so it would wait for them as well)
+        unsigned long long candm = __ballot(cur.w < 0x80000000u) & cur_valid & ~cur_stale;
+        const float ux = (float)cur.csx, uy = (float)cur.csy;
+        asm volatile("" : "+s"(candm) : "v"(ux), "v"(uy) : "memory");
         // ---- issue the loads of the next group: list entries that exist now
-        int nx_n = min(7, n - (i + cur_n));
+        nx_n = min(7, n - (i + cur_n));
         if (nx_n < 0) nx_n = 0;
-        Grp nx = load_group(C, i + cur_n, nx_n, lane, slot, kx, ky);
-        unsigned long long nx_stale = 0ull;
+        nx.w = 0xFFFFFFFFu; nx.csx = 0.0; nx.csy = 0.0; nx.a = -1; nx.xy = 0u;
+        nx_valid = 0ull; nx_stale = 0ull;
+        if (nx_n > 0) nx = load_group(C, i + cur_n, nx_n, slot, kx, ky, nx_valid);
         // ---- process the current group
         CNT(8, cur_n);
         TIC(tacc);
-        unsigned long long candm = __ballot(cur.w < 0x80000000u) & ~cur_stale;
-        const float ux = (float)cur.csx, uy = (float)cur.csy;
         while (candm) {
             // classification of the remaining candidates against the current sums
             unsigned long long mA = 0ull, mB = candm;
-            if (th.t1 >= 0.f && sumdx * sumdx + sumdy * sumdy >= 0.25f) {
+            if (th.t1 >= 0.f) {
                 const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
-                const unsigned long long pos = __ballot(dot > 0.f);
-                mA = candm & pos & __ballot(acr <= th.t1 * dot);
-                mB = candm & ~mA & pos & ~__ballot(acr >= th.t2 * dot);
+                mA = candm & __ballot(acr <= th.t1 * dot);
+                mB = candm & ~mA & ~__ballot(acr >= th.t2 * dot);
             }
             // the first remaining candidate that is not surely misaligned; border lanes are rare (the cone pre-test decides ~99.8 % of the candidates), so the
             // loop is flat: one rarely taken branch for the reference's own test instead of an inner loop over the masks.  A candidate the exact test rejects
@@ -528,20 +549,17 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             ++n;
             candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.a == ka);   // lanes up to k are decided; the pixel is taken
             nx_stale |= __ballot(nx.a == ka);
-            if ((unsigned)(ka - C.cbase) < 64u) C.cused |= 1ull << (ka - C.cbase);
         }
         CBAR();
         TOC(19, tacc); TOCB(21, tacc);
         i += cur_n;
-        if (nx_n == 0 && i < n) {   // nothing could be loaded ahead (short list): load the next group now
+        if (nx_n == 0) {
+            if (i >= n) break;
+            // nothing could be loaded ahead (short list): load the next group now
             nx_n = min(7, n - i);
-            nx = load_group(C, i, nx_n, lane, slot, kx, ky);
+            nx = load_group(C, i, nx_n, slot, kx, ky, nx_valid);
             nx_stale = 0ull;
         }
-        cur = nx; cur_n = nx_n; cur_stale = nx_stale;
-#ifdef PLF_LSD_TIMING
-        { TIC(tw); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TOC(20, tw); TOCB(22, tw); }
-#endif
     }
     if (!theta_valid) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
@@ -566,6 +584,52 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
 {
     const int lane = plf_lane();
     double x = 0, y = 0, sum = 0;
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    if (C.stg) {
+        // Round 4: the running sums are the reference's additions in list order, but ONE SUM PER LANE: 32 lanes compute the products of 32 points (order-free)
+        // and stage them in LDS, lanes 0-2 read their component of the 32 triples back and add them one after the other -- 2 instructions per point for all three
+        // sums instead of 9 (two v_readlane and an add per sum).  Points past the end add +0.0, which leaves a sum unchanged bit for bit (it is never -0.0).
+        const int Lc = min(lane, 2);
+        double acc = 0.0;
+        for (int base = 0; base < n; base += 32) {
+            const int i = base + lane;
+            double wx = 0.0, wy = 0.0, w = 0.0;
+            if (lane < 32 && i < n) {
+                const uint32_t q = rxy_get(C, i);
+                w = C.modgrad[(int)(q >> 16) * C.W + (int)(q & 0xFFFF)];
+                wx = (double)(int)(q & 0xFFFF) * w;
+                wy = (double)(int)(q >> 16) * w;
+            }
+            if (lane < 32) { C.stg[lane * 3 + 0] = wx; C.stg[lane * 3 + 1] = wy; C.stg[lane * 3 + 2] = w; }
+            CBAR();
+#pragma unroll
+            for (int q = 0; q < 32; q++) acc += C.stg[q * 3 + Lc];
+            CBAR();
+        }
+        x = readlane_d(acc, 0); y = readlane_d(acc, 1); sum = readlane_d(acc, 2);
+        x /= sum;
+        y /= sum;
+        acc = 0.0;
+        for (int base = 0; base < n; base += 32) {
+            const int i = base + lane;
+            double txx = 0.0, tyy = 0.0, txy = 0.0;
+            if (lane < 32 && i < n) {
+                const uint32_t q = rxy_get(C, i);
+                const double w = C.modgrad[(int)(q >> 16) * C.W + (int)(q & 0xFFFF)];
+                const double dx = (double)(int)(q & 0xFFFF) - x, dy = (double)(int)(q >> 16) - y;
+                txx = dy * dy * w;
+                tyy = dx * dx * w;
+                txy = -(dx * dy * w);    // (`Ixy -= t` is `Ixy += -t`, exactly)
+                if (txy == 0.0) txy = 0.0;   // (-0.0 -> +0.0: keeps "a running sum is never -0.0" true for the padding argument above)
+            }
+            if (lane < 32) { C.stg[lane * 3 + 0] = txx; C.stg[lane * 3 + 1] = tyy; C.stg[lane * 3 + 2] = txy; }
+            CBAR();
+#pragma unroll
+            for (int q = 0; q < 32; q++) acc += C.stg[q * 3 + Lc];
+            CBAR();
+        }
+        Ixx = readlane_d(acc, 0); Iyy = readlane_d(acc, 1); Ixy = readlane_d(acc, 2);
+    } else {
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         double wx = 0.0, wy = 0.0, w = 0.0;
@@ -588,7 +652,6 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
     }
     x /= sum;
     y /= sum;
-    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         double txx = 0.0, tyy = 0.0, txy = 0.0;
@@ -609,6 +672,7 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
                 Ixy -= readlane_d(txy, k0 + q);
             }
         }
+    }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)plf_fast_atan2((float)(lambda - Ixx), (float)Ixy)
@@ -776,6 +840,24 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     return true;
 }
 
+// The pixels of the 64-pixel seed chunk at C.cbase that the SMALL region just grown (n < 32 list entries, all of them in LDS) has taken: its list entries are
+// scattered into 64 flag words parked in the unused part of the list (entries 32..95) and read back as a ballot.  Replaces a mask that region_grow updated with
+// seven scalar instructions per accepted pixel.
+__device__ __forceinline__ unsigned long long chunk_taken(RegCtx &C, int n, int lane)
+{
+    C.rxy_l[32 + lane] = 0u;
+    CBAR();
+    if (lane >= 1 && lane < n) {
+        const uint32_t q = C.rxy_l[lane];
+        const int d = (int)(q >> 16) * C.W + (int)(q & 0xFFFF) - C.cbase;
+        if ((unsigned)d < 64u) C.rxy_l[32 + d] = 1u;
+    }
+    CBAR();
+    const uint32_t v = C.rxy_l[32 + lane];
+    CBAR();
+    return __ballot(v != 0u);
+}
+
 // LDS of one wave of the large-batch region kernel: the first 1280 words of the region list (rcap <= 1279 + the mailbox word) and 1 KB for the parked seed chunk
 // (PLF_LSD_WAVE_LIST / PLF_LSD_WAVE_LDS: lsd_geom.h, shared with the host)
 #ifndef PLF_REGIONS_PRIO
@@ -808,6 +890,8 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.rcap = LDSOFF < 0 ? min(g.rcap, PLF_LSD_WAVE_LIST / 4 - 1) : g.rcap;   // (the large-batch kernel keeps a shorter head of the list in LDS)
     C.gcap = (int)g.s_stride;
     C.use_bm = 0; C.bm = (LDS_PTR(uint32_t))smem; C.regrow_n = -1;
+    // region2rect's staging: behind the parked seed chunk (large-batch kernel), or behind the list and its mailbox word (one frame per workgroup)
+    C.stg = (LDS_PTR(double))(smem + (LDSOFF < 0 ? PLF_LSD_WAVE_LIST + 1024 : (((g.rcap + 1) * 4 + 7) & ~7)));
     C.t_dead = BUDGET ? wall_clock64() + g.budget_ticks : 0ull;
     bool truncated = false;
     C.rxy_g = rxy_all + (size_t)f * g.s_stride;
@@ -843,7 +927,6 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
         }
         CBAR();
         C.cbase = seeds ? -0x40000000 : base;
-        C.cused = 0ull;
         while (mask) {
             if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
@@ -873,13 +956,12 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             }
             CBAR();
             mask &= ~((2ull << j) - 1ull);
-            if (big || seeds) {   // refine / reduce may have released pixels again: take the flags from memory
+            if (big || seeds || n >= 32) {   // refine / reduce may have released pixels again: take the flags from memory
                 const int px = (int)park[lane].x;
                 const uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
-                C.cused = 0ull;
                 mask &= __ballot(w < 0x80000000u);
-            } else {
-                mask &= ~C.cused;
+            } else if (n > 1 && mask) {
+                mask &= ~chunk_taken(C, n, lane);
             }
         }
         if (BUDGET && truncated) break;
@@ -895,7 +977,6 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
         bool ok = w < 0x80000000u;
         const float deg = __uint_as_float(w);
         C.cbase = seeds ? -0x40000000 : base;   // (list order: the chunk is not contiguous, flags are re-read after every region)
-        C.cused = 0ull;
         unsigned long long mask = __ballot(ok);
         while (mask) {
             if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
@@ -924,12 +1005,12 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
                 }
             }
             CBAR();
-            if (big || seeds) {   // refine / reduce may have released pixels again: take the flags from memory
+            if (big || seeds || n >= 32) {   // refine / reduce may have released pixels again: take the flags from memory
                 w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
-                C.cused = 0ull;
                 ok = ok && lane > j && w < 0x80000000u;
             } else {
-                ok = ok && lane > j && !((C.cused >> lane) & 1ull);
+                const unsigned long long tk = n > 1 ? chunk_taken(C, n, lane) : 0ull;
+                ok = ok && lane > j && !((tk >> lane) & 1ull);
             }
             mask = __ballot(ok);
         }
@@ -1103,7 +1184,8 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
     C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
     C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
-    C.cbase = -0x40000000; C.cused = 0ull;
+    C.cbase = -0x40000000;
+    C.stg = nullptr;   // (the speculative kernels' LDS layouts have no staging area: region2rect replays its sums with v_readlane there)
     C.t_dead = 0ull;
 }
 
