@@ -805,6 +805,33 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     const double ang_c = (double)deg_c * DEG2RAD_D;
     double sum = 0, s_sum = 0;
     int cnt = 0;
+    if (C.stg) {
+        // (as in region2rect: the two ordered sums are owned by lanes 0 and 1, fed through LDS; a point outside the radius adds +0.0 -- neither sum is ever -0.0:
+        // a difference of two non-negative angles is never -0.0 -- and the count is a popcount)
+        const int Lc = min(lane, 1);
+        double acc = 0.0;
+        for (int base = 0; base < n; base += 48) {
+            const int i = base + lane;
+            bool inc = false;
+            double ang_d = 0.0;
+            if (lane < 48 && i < n) {
+                const uint32_t q = rxy_get(C, i);
+                const int a = (int)(q >> 16) * C.W + (int)(q & 0xFFFF);
+                used_clr(C, a);
+                if (dist_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) < rec.width) {
+                    inc = true;
+                    ang_d = angle_diff_signed_d((double)ang_value(ang_load(C, a)) * DEG2RAD_D, ang_c);
+                }
+            }
+            cnt += __popcll(__ballot(inc));
+            if (lane < 48) { C.stg[lane * 2 + 0] = ang_d; C.stg[lane * 2 + 1] = ang_d * ang_d; }
+            CBAR();
+#pragma unroll
+            for (int q = 0; q < 48; q++) acc += C.stg[q * 2 + Lc];
+            CBAR();
+        }
+        sum = readlane_d(acc, 0); s_sum = readlane_d(acc, 1);
+    } else
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         bool inc = false;
@@ -1185,7 +1212,9 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
     C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
     C.cbase = -0x40000000;
-    C.stg = nullptr;   // (the speculative kernels' LDS layouts have no staging area: region2rect replays its sums with v_readlane there)
+    // region2rect's staging (96 doubles = 192 words) is carved out of the END of the list's LDS words: the list keeps rcap - 192 entries (+ its mailbox word) there
+    C.stg = nullptr;
+    if (g.rcap >= 192 + 127 && ((g.rcap - 191) & 1) == 0) { C.rcap = g.rcap - 192; C.stg = (LDS_PTR(double))(list + (g.rcap - 191)); }
     C.t_dead = 0ull;
 }
 
