@@ -580,12 +580,13 @@ __device__ __forceinline__ double angle_diff_signed_d(double a, double b)
 // region2rect incl. get_theta.  The per-point products are order-free and computed by all lanes (64 points at a
 // time, modgrad gathered by coordinate); only the running sums are accumulated serially in list order, exactly the
 // reference's additions.  Extents (min/max) are order-free and reduced across the wave.
+template <int STG>
 __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, double p, LsdRect &rec)
 {
     const int lane = plf_lane();
     double x = 0, y = 0, sum = 0;
     double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
-    if (C.stg) {
+    if (STG || C.stg) {   // (STG: known at compile time -- the kernel then holds no copy of the v_readlane path)
         // Round 4: the running sums are the reference's additions in list order, but ONE SUM PER LANE: 32 lanes compute the products of 32 points (order-free)
         // and stage them in LDS, lanes 0-2 read their component of the 32 triples back and add them one after the other -- 2 instructions per point for all three
         // sums instead of 9 (two v_readlane and an add per sum).  Points past the end add +0.0, which leaves a sum unchanged bit for bit (it is never -0.0).
@@ -707,6 +708,7 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
 
 // reduce_region_radius: the swap-with-last removal is replayed literally (it permutes the list, and the
 // order of the list decides the rounding of the next region2rect sums).
+template <int STG>
 __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double prec, double p, LsdRect &rec, double density,
                                      double density_th)
 {
@@ -787,12 +789,13 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
         CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
         }
         if (n < 2) return false;
-        region2rect(C, n, reg_angle, prec, p, rec);
+        region2rect<STG>(C, n, reg_angle, prec, p, rec);
         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     }
     return true;
 }
 
+template <int STG>
 __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double p, LsdRect &rec, double density_th)
 {
     const int lane = plf_lane();
@@ -805,7 +808,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     const double ang_c = (double)deg_c * DEG2RAD_D;
     double sum = 0, s_sum = 0;
     int cnt = 0;
-    if (C.stg) {
+    if (STG || C.stg) {
         // (as in region2rect: the two ordered sums are owned by lanes 0 and 1, fed through LDS; a point outside the radius adds +0.0 -- neither sum is ever -0.0:
         // a difference of two non-negative angles is never -0.0 -- and the count is a popcount)
         const int Lc = min(lane, 1);
@@ -861,9 +864,9 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
     C.regrow_n = n;
     if (n < 2) return false;
-    region2rect(C, n, reg_angle, prec, p, rec);
+    region2rect<STG>(C, n, reg_angle, prec, p, rec);
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-    if (density < density_th) return reduce_region_radius(C, n, reg_angle, prec, p, rec, density, density_th);
+    if (density < density_th) return reduce_region_radius<STG>(C, n, reg_angle, prec, p, rec, density, density_th);
     return true;
 }
 
@@ -970,10 +973,10 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             if (big) {
                 LsdRect rec;
                 TIC(t1);
-                region2rect(C, n, reg_angle, prec, p, rec);
+                region2rect<1>(C, n, reg_angle, prec, p, rec);
                 TOC(1, t1); CNT(6, 1);
                 TIC(t2);
-                const bool okr = refine(C, n, reg_angle, prec, p, rec, 0.7);
+                const bool okr = refine<1>(C, n, reg_angle, prec, p, rec, 0.7);
                 TOC(2, t2);
                 if (okr) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
@@ -1020,10 +1023,10 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             if (big) {
                 LsdRect rec;
                 TIC(t1);
-                region2rect(C, n, reg_angle, prec, p, rec);
+                region2rect<1>(C, n, reg_angle, prec, p, rec);
                 TOC(1, t1); CNT(6, 1);
                 TIC(t2);
-                const bool okr = refine(C, n, reg_angle, prec, p, rec, 0.7);
+                const bool okr = refine<1>(C, n, reg_angle, prec, p, rec, 0.7);
                 TOC(2, t2);
                 if (okr) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
@@ -1184,10 +1187,10 @@ __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th
     TOCB(11, ts1);
     if (n < g.min_reg_size) return false;
     TIC(ts2);
-    region2rect(C, n, reg_angle, g.prec, g.p, rec);
+    region2rect<0>(C, n, reg_angle, g.prec, g.p, rec);
     TOCB(12, ts2);
     TIC(ts3);
-    const bool okr = refine(C, n, reg_angle, g.prec, g.p, rec, 0.7);
+    const bool okr = refine<0>(C, n, reg_angle, g.prec, g.p, rec, 0.7);
     CBAR();
     TOCB(13, ts3);
     if (C.regrow_n >= 0) spec_append(C, C.regrow_n, dst, tn, cap, ovf, mark, bb);   // (reduce_region_radius only permutes that list)
