@@ -285,9 +285,10 @@ __global__ void __launch_bounds__(256) k_lsd_count_used(const float *__restrict_
 // The USED flag of a pixel is the SIGN BIT of its entry in the frame's angle map (angles are in [0, 360), NOTDEF is
 // -1024): a pixel is a candidate iff its word is < 0x80000000.  The map lives in HBM/L2, not LDS, so that a
 // workgroup needs only a few KB of LDS and a CU hosts many frames at once -- the kernel is a chain of dependent
-// memory accesses per frame, and its throughput is the number of frames in flight.  Flag updates are relaxed
-// device-scope atomics and flag reads relaxed device-scope atomic loads: per-location program order holds, so the
-// single wave that owns the frame always reads its own latest write.  k_nfa_count strips the sign afterwards.
+// memory accesses per frame, and its throughput is the number of frames in flight.  ONE wave owns a frame for the whole kernel, so its flag updates and reads are
+// relaxed WORKGROUP-scope atomics, i.e. plain loads and stores that the compiler may neither cache in registers nor reorder: per-location program order is all that
+// is needed.  (Rounds 1-3 used device scope: on gfx950 that marks every access sc1 -- the loads bypass the CU's L1 and the 4-byte stores are written THROUGH the L2,
+// 64 bytes of HBM write traffic each: 3.9 MB per frame, a third of the kernel's traffic.)  k_nfa_count strips the sign afterwards.
 struct RegCtx {
     int W, H;
     uint32_t *ang;             // angle map words (float bits), sign bit = USED
@@ -339,7 +340,7 @@ __device__ __forceinline__ uint32_t ang_load(const RegCtx &C, int a)
         if ((C.bm[a >> 5] >> (a & 31)) & 1u) w |= 0x80000000u;
         return w;
     }
-    return __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ float ang_value(uint32_t w) { return __uint_as_float(w & 0x7FFFFFFFu); }   // of a defined pixel
 // w = the pixel's angle word as this wave last read it (sign clear: it was a candidate).  The wave that owns the frame is the only writer of its
@@ -348,12 +349,14 @@ __device__ __forceinline__ float ang_value(uint32_t w) { return __uint_as_float(
 __device__ __forceinline__ void used_set(RegCtx &C, int a, uint32_t w)
 {
     if (C.use_bm) { __hip_atomic_fetch_or(&C.bm[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
-    __hip_atomic_store(&C.ang[a], w | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&C.ang[a], w | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void used_clr(RegCtx &C, int a)
 {
     if (C.use_bm) { __hip_atomic_fetch_and(&C.bm[a >> 5], ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
-    __hip_atomic_fetch_and(&C.ang[a], 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a load and a store, not a read-modify-write at the L2: the L2 would change the word behind the back of the CU's L1, which the plain loads above may hit)
+    const uint32_t w = __hip_atomic_load(&C.ang[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&C.ang[a], w & 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ uint32_t rxy_get(const RegCtx &C, int i)
 {
@@ -407,14 +410,16 @@ struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle w
 // nested EXEC regions that each re-materialised five default values: ~35 vector + ~20 scalar instructions per group became ~15 + 6.  One test covers the image
 // border: a region point is a DEFINED pixel, and ll_angle leaves the last row and the last column NOTDEF, so x <= W-2 and y <= H-2; x-1 = -1 addresses the last
 // column of the row above (NOTDEF: never a candidate), and only y-1 = -1 leaves the frame -- with a negative index.
-__device__ __forceinline__ Grp group_at(const RegCtx &C, uint32_t pxy, int kx, int ky, unsigned long long &valid)
+__device__ __forceinline__ Grp group_at(const RegCtx &C, uint32_t pxy, int kx, int ky, int nlanes, unsigned long long &valid)
 {
     Grp G;
     const int xx = (int)(pxy & 0xFFFF) + kx, yy = (int)(pxy >> 16) + ky;
     G.a = yy * C.W + xx;
     G.xy = (uint32_t)xx | ((uint32_t)yy << 16);
     valid = __ballot(G.a >= 0);
-    const int af = min(max(G.a, 0), C.W * C.H - 1);   // (lanes past the group's last point hold whatever their list slot holds)
+    // lanes past the group's last point hold whatever their list slot holds: they read pixel 0 (one cached line for all of them) -- with the address of that stale
+    // slot they pulled 25 GB of unrelated lines per 8192-frame launch through the L2
+    const int af = plf_lane() < nlanes ? min(max(G.a, 0), C.W * C.H - 1) : 0;
     const double2 c = C.cs[af];
     G.w = ang_load(C, af);
     G.csx = c.x; G.csy = c.y;
@@ -428,8 +433,8 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
     if (first + cnt > C.rcap) {                    // rare, wave-uniform: part of the group lives in the global part of the list.  A branch of its own, with the
         asm volatile("");                          // dependent load and its wait inside: merged into the common path it would put an s_waitcnt vmcnt(0) -- i.e. a
         if (slot < cnt && idx >= C.rcap) pxy = C.rxy_g[idx];   // wait for the CURRENT group's data -- in front of every prefetch
-        G = group_at(C, pxy, kx, ky, valid);
-    } else G = group_at(C, pxy, kx, ky, valid);
+        G = group_at(C, pxy, kx, ky, 9 * cnt, valid);
+    } else G = group_at(C, pxy, kx, ky, 9 * cnt, valid);
     valid &= (1ull << (9 * cnt)) - 1ull;           // cnt <= 7: lane 63 never
     return G;
 }
@@ -473,7 +478,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
     // prefetch of the next group -- and that one static s_waitcnt vmcnt(0) made every iteration wait for the prefetch it had just issued.
     int nx_n = 1, cur_n;
     unsigned long long nx_valid, nx_stale = 0ull;   // nx_stale: lanes whose pixel was accepted after its word was loaded
-    Grp nx = group_at(C, sxy, kx, ky, nx_valid);
+    Grp nx = group_at(C, sxy, kx, ky, 9, nx_valid);
     nx_valid &= 0x1FFull;
     // All per-lane predicates of the accept loop are kept as wave-uniform 64-bit masks (the compares write them
     // directly), so the loop control is scalar and nothing bounces between VGPR booleans and masks.
@@ -490,7 +495,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         // those loads must not end up behind the loads of the next group -- vmcnt counts in order, so it would wait for them as well)
         unsigned long long candm = __ballot(cur.w < 0x80000000u) & cur_valid & ~cur_stale;
         const float ux = (float)cur.csx, uy = (float)cur.csy;
-        asm volatile("" : "+s"(candm) : "v"(ux), "v"(uy) : "memory");
+        asm volatile("" : : "v"(ux), "v"(uy), "v"(cur.w) : "memory");
         // ---- issue the loads of the next group: list entries that exist now
         nx_n = min(7, n - (i + cur_n));
         if (nx_n < 0) nx_n = 0;
@@ -746,7 +751,7 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
                     out = distsq_d(xc, yc, (double)(int)(q & 0xFFFF), (double)(int)(q >> 16)) > radSq;
                 }
                 const unsigned long long om = __ballot(out);
-                if (out) __hip_atomic_store(&tmp[hcount + __popcll(om & ((1ull << lane) - 1ull))], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (out) __hip_atomic_store(&tmp[hcount + __popcll(om & ((1ull << lane) - 1ull))], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 hcount += __popcll(om);
             }
             CBAR();
@@ -762,7 +767,7 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
                 const unsigned long long im = __ballot(in);
                 if (in) {
                     const int k = fcount + __popcll(im & ~((2ull << lane) - 1ull));   // kept points with a higher index come first
-                    rxy_put(C, (int)__hip_atomic_load(&tmp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q);
+                    rxy_put(C, (int)__hip_atomic_load(&tmp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), q);
                 }
                 fcount += __popcll(im);
             }
