@@ -278,7 +278,7 @@ def single_frame_latency(device, w, h, nfeat, nlines, reps=20):
             "what": "one %dx%d frame, host memory in and out, nothing else in flight" % (w, h)}
 
 
-def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml):
+def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml, reps=2, warm=1, dist=None):
     """host frames in, host features + matches out through the product's batch driver (plf_batch_*): pinned caller buffer, double-buffered
     async H2D / D2H, one worker thread per GPU"""
     import numpy as np
@@ -293,18 +293,30 @@ def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml):
     for i in range(n_frames):
         pin[i] = distinct[i % nd]
     out = bx.alloc_outputs(n_frames)
-    bx.extract_into(pin[:min(n_frames, 2 * in_flight)], {k: v[:min(n_frames, 2 * in_flight)] for k, v in out.items()})   # warm-up (allocations, tables)
-    best = None
-    for _ in range(2):
+    for _ in range(warm):
+        bx.extract_into(pin[:min(n_frames, 2 * in_flight)], {k: v[:min(n_frames, 2 * in_flight)] for k, v in out.items()})   # warm-up (allocations, tables)
+    best, total = None, 0.0
+    if dist is not None:
+        dist.barrier()
+    for _ in range(reps):
         t0 = time.perf_counter()
         bx.extract_into(pin, out)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+        total += dt
+    elapsed_max = total
+    if dist is not None:   # the job lasts as long as its slowest rank
+        import torch
+        t = torch.tensor([total], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t[0])
     tm = bx.last_timing()
+    aff = bx.worker_affinity(0)
     bx.close(); free_pinned(pin)
     mb = n_frames * w * h / 1e6
     return {"value": round(n_frames / best, 1), "unit": "frames/s", "frames": n_frames, "frames_in_flight": in_flight,
             "h2d_MBps": round(mb / best, 1), "worker_seconds": {k: round(v, 4) for k, v in tm.items()},
+            "worker_numa_node": aff[0], "worker_cpus_bound": aff[1], "elapsed_max": elapsed_max,
             "what": "plf_batch_extract: %d host frames (pinned, %d distinct) -> key points, descriptors, lines and local-map matches in host memory, 1 GPU" % (n_frames, nd)}
 
 
@@ -389,6 +401,8 @@ def main():
     ap.add_argument("--no-defer-match", action="store_true", help="diagnostic: enqueue the matchers of step k in step k (default: behind the line front stages of "
                     "step k+1, so that they run in the shadow of the next region-growing kernel; +2.7 %%)")
     ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
+    ap.add_argument("--pcie", action="store_true", help="time the PCIe-INCLUSIVE leg instead (plf_batch_extract: pinned host frames in, features + local-map matches "
+                    "out in host memory) on every rank; value = aggregate frames/s, plus the aggregate host read rate")
     args = ap.parse_args()
 
     import torch
@@ -405,6 +419,31 @@ def main():
     from rgbd_pl_slam_amd.batch import shard
     W, H, NFEAT, NLINES, B0, label = CONFIGS[args.config]
     B = args.batch if args.batch > 0 else B0
+    if args.pcie:
+        # every rank drives ITS GPU through the product's batch driver with host buffers of its own (the worker thread is bound to the GPU's NUMA node, where
+        # the pinned buffers are then placed); K timed calls of 4 x in-flight frames each between barriers, MAX over the ranks
+        in_flight = min(B, 4096)
+        n_frames = 4 * in_flight
+        pm = Pipeline(W, H, NFEAT, NLINES, 8, local_rank, 10_000 * rank)   # (only for its local map: built from the features of a synthetic frame)
+        mp, ml = pm.mp, pm.ml
+        pm.close(); del pm
+        r = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, n_frames, in_flight, mp, ml, reps=max(1, args.steps), warm=max(1, args.warmup), dist=dist)
+        if rank == 0:
+            el = r.pop("elapsed_max")
+            frames = world * n_frames * max(1, args.steps)
+            print(json.dumps({
+                "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d, PCIe-inclusive" % (W, H),
+                "value": round(frames / el, 2), "unit": "frames/s", "n_gpus": world, "steps": max(1, args.steps), "warmup": max(1, args.warmup),
+                "ms_per_step": round(1e3 * el / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64",
+                "data": "synthetic (pinned host frames, 256 distinct per GPU)",
+                "config": {"workload": label + "; host frames in, key points / descriptors / lines / local-map matches out in host memory (plf_batch_extract)",
+                           "baseline_config": args.config, "frames_per_call_per_gpu": n_frames, "frames_in_flight_per_gpu": in_flight,
+                           "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
+                "pcie": {"host_read_GBps_aggregate": round(frames * W * H / el / 1e9, 2), "host_read_GBps_per_gpu": round(frames * W * H / el / 1e9 / world, 2),
+                         "rank0": r}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     # the job = world * B frames per step; this rank's block of it (contiguous, plf_batch_shard) -- always B frames: weak scaling
     lo, hi = shard(world * B, world, rank)
     assert hi - lo == B
@@ -484,6 +523,20 @@ def main():
         mp, ml = pipe.mp, pipe.ml
         pipe.close(); del pipe
         if world == 1 and args.config == 2 and not args.no_extras and not args.serial:
+            # where the 5,000 frames/s of BASELINE.json's target is crossed: the same step with fewer frames in flight (the few-frames schedules of the line
+            # extractor take over below ~640)
+            curve = []
+            for nb in (8, 64, 512, 4096):
+                if nb >= B:
+                    continue
+                pn = Pipeline(W, H, NFEAT, NLINES, nb, local_rank, 30_000, distinct=min(nb, 1024))
+                k = 30 if nb <= 64 else (12 if nb <= 512 else 6)
+                en, _, _ = timed(pn, k, 3)
+                curve.append({"frames_in_flight": nb, "value": round(nb * k / en, 1), "ms_per_step": round(1e3 * en / k, 3)})
+                pn.close(); del pn
+            curve.append({"frames_in_flight": B, "value": round(fps, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 3)})
+            out["fps_vs_in_flight"] = {"unit": "frames/s", "points": curve, "what": "the default step (config 2 workload) at fewer frames in flight, same run"}
+        if world == 1 and args.config == 2 and not args.no_extras and not args.serial:
             # secondary figures, driver-timed in the same run
             p3 = Pipeline(*CONFIGS[3][:5], local_rank, 20_000)
             e3, r3, n3 = timed(p3, 30, 5)
@@ -492,6 +545,7 @@ def main():
             p3.close(); del p3
             out["single_frame_latency"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES)
             out["pcie_inclusive"] = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, 16384, 4096, mp, ml)
+            out["pcie_inclusive"].pop("elapsed_max", None)
         if world == 1 and args.cpu_seconds > 0:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(float(args.cpu_seconds), cores, W, H, NFEAT, NLINES)

@@ -602,6 +602,10 @@ int64_t plf_batch_truncated_frames(const plf_batch *b);
 /* Seconds the workers of the last plf_batch_extract spent (max over workers): [0] total, [1] staging copies into pinned
  * memory, [2] waiting for the GPU, [3] unpacking outputs. */
 int plf_batch_last_timing(const plf_batch *b, double *out4);
+/* Where worker `worker` (= GPU devices[worker]) runs: the NUMA node of its GPU (-1: unknown / single node) and the number of CPUs its thread was bound to before it
+ * allocated its pinned staging slots (0: not bound -- no sysfs view, or PLF_BATCH_NO_AFFINITY=1).  Eight GPUs on a two-socket host: every worker reads its
+ * images through its own socket's memory controllers. */
+int plf_batch_worker_affinity(const plf_batch *b, int32_t worker, int32_t *numa_node, int32_t *n_cpus);
 
 /* Device memory helpers for host code above this ABI that does not link the HIP runtime itself (the exact-signature adapters of include/plf.hpp
  * stage the Frame / MapPoint / MapLine members the matchers read with them).  With a stream: plf_upload / plf_fill enqueue on it, plf_download

@@ -203,6 +203,12 @@ class BatchExtractor:
         f.restype = C.c_int64
         return int(f(self._h))
 
+    def worker_affinity(self, worker):
+        """(NUMA node of the worker's GPU or -1, CPUs its thread was bound to or 0) -- plf_batch_worker_affinity"""
+        node, n = C.c_int32(-2), C.c_int32(-1)
+        L.check(L.lib().plf_batch_worker_affinity(self._h, int(worker), C.byref(node), C.byref(n)), "plf_batch_worker_affinity")
+        return node.value, n.value
+
     def last_timing(self):
         t = (C.c_double * 4)()
         L.check(L.lib().plf_batch_last_timing(self._h, t), "plf_batch_last_timing")

@@ -949,7 +949,11 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     // CU; the parked chunk matters more than before: the four registers would be four more spills.)
     typedef uint32_t park_t __attribute__((ext_vector_type(4)));
     LDS_PTR(park_t) park = (LDS_PTR(park_t))(smem + PLF_LSD_WAVE_LIST);
-    for (int base = 0; base < NP; base += 64) {
+    // (raster order: the coordinates of a seed follow from those of its chunk's first pixel -- no integer division by W per seed, ~30 instructions on this path)
+    const bool walk = !seeds && W >= 64;
+    int bx = 0, by = 0;
+    for (int base = 0; base < NP; base += 64, bx += 64) {
+        if (bx >= W) { bx -= W; by++; }
         unsigned long long mask;
         {
             int px = base + lane;
@@ -972,7 +976,10 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
                                            __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sv.w)));
             double reg_angle;
             TIC(t0);
-            int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
+            int sx, sy;
+            if (walk) { sx = bx + j; sy = by; if (sx >= W) { sx -= W; sy++; } }
+            else { sx = seed % W; sy = seed / W; }
+            int n = region_grow(C, sx, sy, sdeg, sc0, prec, th0, reg_angle);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
             const bool big = n >= g.min_reg_size;
             if (big) {

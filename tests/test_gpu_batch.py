@@ -386,3 +386,26 @@ def test_empty_and_bad_arguments():
         bx.extract_into(big, bx.alloc_outputs(1))
     assert e.value.status == L.PLF_E_BADARG
     bx.close()
+
+
+def test_batch_workers_are_bound_to_the_numa_node_of_their_gpu(monkeypatch):
+    """plf_batch_worker_affinity: a worker thread is bound to the CPUs of its GPU's NUMA node before it allocates its pinned slots (two workers on GPU 0 land on
+    the same node); hosts without the sysfs view -- or PLF_BATCH_NO_AFFINITY=1 -- leave the thread unbound, and the call still works"""
+    _need_gpu()
+    import os
+    from rgbd_pl_slam_amd.batch import BatchExtractor
+    from rgbd_pl_slam_amd import PlfError
+    bx = BatchExtractor(nfeatures=500, nlines=50, width=320, height=240, frames_in_flight=2, devices=[0, 0])
+    a0, a1 = bx.worker_affinity(0), bx.worker_affinity(1)
+    assert a0 == a1 and a0[0] >= -1 and a0[1] >= 0
+    if a0[0] >= 0:   # the node is known: the thread was bound to (a subset of) its CPUs
+        cpus = open("/sys/devices/system/node/node%d/cpulist" % a0[0]).read().strip()
+        assert a0[1] > 0, "node %d (CPUs %s) known, but the worker was not bound" % (a0[0], cpus)
+        assert a0[1] <= len(os.sched_getaffinity(0))
+    with pytest.raises(PlfError):
+        bx.worker_affinity(2)
+    bx.close()
+    monkeypatch.setenv("PLF_BATCH_NO_AFFINITY", "1")
+    bx = BatchExtractor(nfeatures=500, nlines=50, width=320, height=240, frames_in_flight=2, devices=[0])
+    assert bx.worker_affinity(0)[1] == 0
+    bx.close()
