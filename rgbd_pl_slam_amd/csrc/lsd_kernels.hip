@@ -387,13 +387,14 @@ __device__ __forceinline__ double readlane_d(double v, int src)
 // The pre-test only sorts candidates into "surely aligned", "surely not" and "border" (decided by the reference's own test), so ANY t1 below and
 // t2 above those tangents is sound: single-precision tanf with a 1e-4 relative safety factor (its error is ~1e-7; the band is ~2.5e-3 wide) keeps
 // the double-precision tan -- a double-double routine that alone costs ~40 VGPRs -- out of this kernel.
-// t1 < 0 switches the pre-test off (every decision is then taken by the exact test).
+// NaN thresholds switch the pre-test off (every decision is then taken by the exact test): both comparisons of the classification are false for a NaN, which
+// leaves no lane "surely aligned" and none "surely not" -- without a test of its own in the accept loop.
 struct GrowTh { float t1, t2; };
 __device__ __forceinline__ GrowTh grow_thresholds(double prec)
 {
     const double delta = 8.7266462599716e-4;
     GrowTh t;
-    t.t1 = -1.f; t.t2 = 0.f;
+    t.t1 = __uint_as_float(0x7FC00000u); t.t2 = t.t1;
     if (prec - delta > 0.0 && prec + delta < 1.55) {
         t.t1 = tanf((float)(prec - delta)) * (1.0f - 1.0e-4f);
         t.t2 = tanf((float)(prec + delta)) * (1.0f + 1.0e-4f);
@@ -505,14 +506,11 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         // ---- process the current group
         CNT(8, cur_n);
         TIC(tacc);
-        while (candm) {
-            // classification of the remaining candidates against the current sums
-            unsigned long long mA = 0ull, mB = candm;
-            if (th.t1 >= 0.f) {
-                const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
-                mA = candm & __ballot(acr <= th.t1 * dot);
-                mB = candm & ~mA & ~__ballot(acr >= th.t2 * dot);
-            }
+        for (;;) {
+            // classification of the remaining candidates against the current sums (one exit test per trip: no candidate left implies mAB == 0)
+            const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
+            const unsigned long long mA = candm & __ballot(acr <= th.t1 * dot);
+            const unsigned long long mB = candm & ~mA & ~__ballot(acr >= th.t2 * dot);
             // the first remaining candidate that is not surely misaligned; border lanes are rare (the cone pre-test decides ~99.8 % of the candidates), so the
             // loop is flat: one rarely taken branch for the reference's own test instead of an inner loop over the masks.  A candidate the exact test rejects
             // is decided for good -- it precedes every lane that can still be accepted, and a later accept drops the lanes before it anyway.
