@@ -139,6 +139,12 @@ enum { PLF_LBD_BLURRED = 0, PLF_LBD_RAW = 1 };
 
 int plf_line_create(const plf_line_params *params, plf_line **out);
 void plf_line_destroy(plf_line *h);
+/* Schedule knobs of a line-extractor handle (frames-in-flight thresholds of its schedules, band counts ...).  They are read from the environment ONCE, when the handle
+ * is created (PLF_LSD_*, PLF_NFA_FUSED: experiments), and never again; this call changes one of them afterwards -- a tuning and test hook, not needed in production:
+ * "spec_max" (frames in flight up to which the banded speculative schedule is used, 640), "spec_bands", "spec_z", "spec_rounds", "spec_halo", "spec_clip", "spec_fill",
+ * "spec_fill_tol", "spec_stagger", "spec_nofuse", "spec_spins", "spec_reccap", "lat_max", "wpg", "one_wave_groups", "nfa_fused" (frames in flight up to which one wave per
+ * rectangle runs all NFA stages, 64).  Every schedule gives the same bits.  PLF_E_BADARG for an unknown name or a value out of range. */
+int plf_line_tune(plf_line *h, const char *name, double value);
 
 /* void LineSegment::ExtractLineSegment(const Mat& img, vector<KeyLine>&, Mat& ldesc, vector<Vector3d>& lineFunctions,
  *                                      int scale = 1.2, int numOctaves = 1)      include/ExtractLineSegment.h:38

@@ -57,8 +57,53 @@ __global__ void k_lsd_spec_round_begin(SpecBufs, int, int);
 __global__ void k_lsd_spec_validate(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs, int);
 __global__ void k_lsd_spec_assemble(LsdRect *, int *, int *, LsdGeom, SpecBufs, int);
 
+// Schedule knobs of the line extractor.  Read ONCE, when the handle is created (environment: PLF_LSD_* / PLF_NFA_FUSED, for experiments and the test hooks that force a
+// schedule), changed afterwards only through plf_line_tune(); a call never looks at the environment (round 3 did, ~30 getenv per call).  PLF_TUNE_AUTO = chosen per
+// call from the number of frames in flight (the table in line_enqueue).
+#define PLF_TUNE_AUTO (-0x7fffffff)
+struct LineTune {
+    int lat_max;          // PLF_LSD_LAT_MAX      frames in flight up to which the latency kernel (one frame per workgroup + L2 warm-up waves) is used when speculation is off
+    int spec_bands;       // PLF_LSD_SPEC_BANDS   row bands of the speculative schedule (AUTO: 48 / 32 / 16 / 8 / 4 / 2 by frames in flight)
+    int spec_max;         // PLF_LSD_SPEC_MAX     frames in flight up to which the speculative schedule is used (640; 0 = never)
+    int spec_z;           // PLF_LSD_SPEC_Z       ... up to which the validation rounds replace the serial commit wave (16)
+    int spec_rounds;      // PLF_LSD_SPEC_ROUNDS  validation rounds enqueued (12)
+    int spec_halo;        // PLF_LSD_SPEC_HALO    warm-up rows above a band (AUTO: 4 with validation rounds, 16 otherwise)
+    int spec_fill;        // PLF_LSD_SPEC_FILL    rows of the no-growth guess instead of warm-up growth (0 = off)
+    float spec_fill_tol;  // PLF_LSD_SPEC_FILL_TOL
+    int spec_clip;        // PLF_LSD_SPEC_CLIP    rows below a band its warm-up regions may reach (AUTO: 16 from 4 frames in flight on, unbounded below; < 0 = unbounded)
+    float spec_stagger;   // PLF_LSD_SPEC_STAGGER band shares of the one-launch schedule (0.2)
+    int spec_nofuse;      // PLF_LSD_SPEC_NOFUSE  never the one-launch schedule
+    int spec_spins;       // PLF_LSD_SPEC_SPINS   polls without a heartbeat before the commit wave gives up (test hook)
+    int spec_reccap;      // PLF_LSD_SPEC_RECCAP  records per band log (test hook: forces the overflow path)
+    int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (8)
+    int one_wave_groups;  // PLF_LSD_ONE_WAVE_GROUPS  one frame per workgroup for large batches too
+    int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
+};
+static int tune_env_i(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static float tune_env_f(const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; }
+static void line_tune_init(LineTune *t)
+{
+    t->lat_max = tune_env_i("PLF_LSD_LAT_MAX", 8);
+    t->spec_bands = tune_env_i("PLF_LSD_SPEC_BANDS", PLF_TUNE_AUTO);
+    t->spec_max = tune_env_i("PLF_LSD_SPEC_MAX", 640);
+    t->spec_z = tune_env_i("PLF_LSD_SPEC_Z", 16);
+    t->spec_rounds = std::max(1, std::min(64, tune_env_i("PLF_LSD_SPEC_ROUNDS", 12)));
+    t->spec_halo = tune_env_i("PLF_LSD_SPEC_HALO", PLF_TUNE_AUTO);
+    t->spec_fill = tune_env_i("PLF_LSD_SPEC_FILL", 0);
+    t->spec_fill_tol = tune_env_f("PLF_LSD_SPEC_FILL_TOL", 11.25f);
+    t->spec_clip = tune_env_i("PLF_LSD_SPEC_CLIP", PLF_TUNE_AUTO);
+    t->spec_stagger = tune_env_f("PLF_LSD_SPEC_STAGGER", 0.2f);
+    t->spec_nofuse = getenv("PLF_LSD_SPEC_NOFUSE") ? 1 : 0;
+    t->spec_spins = std::max(64, tune_env_i("PLF_LSD_SPEC_SPINS", 1 << 21));
+    { const int v = tune_env_i("PLF_LSD_SPEC_RECCAP", 8192); t->spec_reccap = (v >= 1 && v <= 8192) ? v : 8192; }
+    t->wpg = std::max(1, std::min(16, tune_env_i("PLF_LSD_WPG", 8)));
+    t->one_wave_groups = getenv("PLF_LSD_ONE_WAVE_GROUPS") ? 1 : 0;
+    t->nfa_fused = tune_env_i("PLF_NFA_FUSED", 64);
+}
+
 struct plf_line {
     plf_line_params prm;
+    LineTune tune;
     SpecBufs spec;            // banded speculative region growing (few frames in flight); allocated on first use
     int spec_frames;          // frames the buffers were sized for (0: not allocated, -1: allocation failed / disabled)
     size_t fused_lds, fused_capacity;   // k_lsd_spec_fused: workgroups of that LDS size the GPU can hold at once (occupancy query)
@@ -257,6 +302,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     plf_line *h = (plf_line *)calloc(1, sizeof(plf_line));
     if (!h) return PLF_E_NOMEM;
     h->prm = *p; h->device = p->device;
+    line_tune_init(&h->tune);
     h->retry_flags = (int32_t *)calloc((size_t)p->max_batch, sizeof(int32_t));
     if (!h->retry_flags) { free(h); return PLF_E_NOMEM; }
     LsdGeom g;
@@ -359,6 +405,30 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     return PLF_OK;
 }
 
+// Tuning / test hook: change one schedule knob of a handle (the names of struct LineTune, e.g. "nfa_fused", "spec_max"; value PLF_TUNE_AUTO = -2147483647 restores the
+// per-call choice where there is one).  Takes effect from the next call on.
+extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
+{
+    if (!h || !name) return PLF_E_BADARG;
+    LineTune &t = h->tune;
+    const int v = (int)value;
+    struct { const char *n; int *p; } ints[] = {{"lat_max", &t.lat_max}, {"spec_bands", &t.spec_bands}, {"spec_max", &t.spec_max}, {"spec_z", &t.spec_z},
+        {"spec_rounds", &t.spec_rounds}, {"spec_halo", &t.spec_halo}, {"spec_fill", &t.spec_fill}, {"spec_clip", &t.spec_clip}, {"spec_nofuse", &t.spec_nofuse},
+        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}};
+    for (auto &e : ints)
+        if (!strcmp(name, e.n)) {
+            if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
+            if (!strcmp(name, "spec_reccap") && (v < 1 || v > 8192)) return PLF_E_BADARG;
+            if (!strcmp(name, "spec_spins") && v < 64) return PLF_E_BADARG;
+            if (!strcmp(name, "wpg") && (v < 1 || v > 16)) return PLF_E_BADARG;
+            *e.p = v;
+            return PLF_OK;
+        }
+    if (!strcmp(name, "spec_fill_tol")) { t.spec_fill_tol = (float)value; return PLF_OK; }
+    if (!strcmp(name, "spec_stagger")) { t.spec_stagger = (float)value; return PLF_OK; }
+    return PLF_E_BADARG;
+}
+
 extern "C" void plf_line_destroy(plf_line *h)
 {
     if (!h) return;
@@ -406,12 +476,13 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         seeds = h->d_keys[1];
     }
     // up to one frame per XCD: latency mode (the maps of one frame fit the XCD's 4 MB L2); otherwise the batch hides the latency
-    const int lat_max = getenv("PLF_LSD_LAT_MAX") ? atoi(getenv("PLF_LSD_LAT_MAX")) : 8;               // (read per call: test hooks)
+    const LineTune &T = h->tune;
+    const int lat_max = T.lat_max;
     // measured on one MI355X (VGA, frames/s with 16 / 8 / 4 / 2 bands): 8 frames 448 / 378 / 291 / 197; 32: 1277 / 1252 / 1079 / 679; 128: 3392 / 4321 /
     // 4007 / 1511; 256: 3866 / 5713 / 6800 / 5381; 512: - / 7237 / 8352 / 8856 (serial kernel: 7220); at 1024 the batch itself hides the latency
     // of the one-wave-per-frame kernel (9.8k with 2 bands vs 11.9k)
-    const int spec_bands_req = getenv("PLF_LSD_SPEC_BANDS") ? atoi(getenv("PLF_LSD_SPEC_BANDS")) : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // round 3 (validation rounds, fast commit): 48 / 32 bands up to 8 / 16 frames   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
-    const int spec_max = getenv("PLF_LSD_SPEC_MAX") ? atoi(getenv("PLF_LSD_SPEC_MAX")) : 640;
+    const int spec_bands_req = T.spec_bands != PLF_TUNE_AUTO ? T.spec_bands : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // round 3 (validation rounds, fast commit): 48 / 32 bands up to 8 / 16 frames   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
+    const int spec_max = T.spec_max;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
     // commit wave: T and S in LDS when they fit, otherwise S in global memory
@@ -419,7 +490,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const int commit_extra = 5 * 512 + 512 / 32 + 1024 + 1 + 16 + 16;   // SPEC_COMMIT_EXTRA_WORDS of lsd_kernels.hip (+ the 16-word alignment of the tile map): record headers, SUSPECT mask, "defined, no record" bits
     const size_t lds_grow = (size_t)(list_words + bm_words) * 4, lds_commit = (size_t)(list_words + (s_global ? 1 : 2) * bm_words + coarse_words + commit_extra) * 4 + 64;
     int spec_bands = spec_bands_req;
-    if (!getenv("PLF_LSD_SPEC_BANDS") && B <= 16) {
+    if (T.spec_bands == PLF_TUNE_AUTO && B <= 16) {
         // every band workgroup of the batch should be resident at once: a band wave and its validation hold the frame's flag bitmap(s) in LDS -- 29 / 68 KB at
         // VGA, 103 / 119 KB at 1280x960, i.e. one workgroup per CU there: 8 such frames x 48 bands ran as two rounds of workgroups (277 frames/s; 372 with 32 bands)
         const int per_cu = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max(lds_grow, lds_commit));
@@ -429,7 +500,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     bool spec = !seeds && g.sh <= 8192 && (g.sh - 1) / 4 >= spec_bands && spec_bands >= 2 && spec_bands <= 64 && B <= spec_max && lds_commit <= 150 * 1024 && h->spec_frames >= 0;
     // validation rounds instead of the serial commit wave (k_lsd_spec_validate): up to PLF_LSD_SPEC_Z frames in flight (16), never with a time budget
-    const int zmax = getenv("PLF_LSD_SPEC_Z") ? atoi(getenv("PLF_LSD_SPEC_Z")) : 16;
+    const int zmax = T.spec_z;
     bool zmode = spec && !budget && B <= zmax;
     if (spec) {   // scratch of the speculation: ~23 MB per VGA frame, ~65 MB per 1280x960 frame (x 2.5 with the buffers of the validation rounds); keep it below 32 GiB
         size_t Fr = 8;
@@ -451,7 +522,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         while (Fr < (size_t)B) Fr <<= 1;
         const size_t K = (size_t)spec_bands;
         h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192;
-        if (const char *e = getenv("PLF_LSD_SPEC_RECCAP")) { if (atoi(e) >= 1 && atoi(e) <= 8192) h->spec.rcap_rec = atoi(e); }   // test hook: force the overflow fallback
+        h->spec.rcap_rec = T.spec_reccap;   // (test hook: a small value forces the overflow fallback)
         bool ok = hipMalloc((void **)&h->spec.rxy, Fr * K * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.recs, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
@@ -482,19 +553,18 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     if (spec) {
         h->spec.s_global = s_global ? 1 : 0;
-        h->spec.spin_bound = 1 << 21;
-        if (const char *e = getenv("PLF_LSD_SPEC_SPINS")) { if (atoi(e) >= 64) h->spec.spin_bound = atoi(e); }   // test hook: a short bound must still let slow band waves finish (heartbeat)
+        h->spec.spin_bound = T.spec_spins;   // (test hook: a short bound must still let slow band waves finish -- heartbeat)
         // warm-up rows above a band: 16 when a serial commit wave follows (every region it has to regrow is serial time), 4 with the validation rounds
         // (the bands redo their conflicts in parallel; the warm-up rows are band-wave time): single VGA frame 7.2 / 7.2 / 6.8 ms with 12 / 8 / 4 rows
-        h->spec.halo_rows = getenv("PLF_LSD_SPEC_HALO") ? atoi(getenv("PLF_LSD_SPEC_HALO")) : (zmode ? 4 : 16);
+        h->spec.halo_rows = T.spec_halo != PLF_TUNE_AUTO ? T.spec_halo : (zmode ? 4 : 16);
         // validation rounds: the band's guess of what the earlier bands take from it can be made WITHOUT growing anything (k spec_grow_body: fill): rows and tolerance
-        h->spec.fill_rows = zmode ? (getenv("PLF_LSD_SPEC_FILL") ? atoi(getenv("PLF_LSD_SPEC_FILL")) : 0) : 0;
-        h->spec.fill_tol_deg = getenv("PLF_LSD_SPEC_FILL_TOL") ? (float)atof(getenv("PLF_LSD_SPEC_FILL_TOL")) : 11.25f;
+        h->spec.fill_rows = zmode ? T.spec_fill : 0;
+        h->spec.fill_tol_deg = T.spec_fill_tol;
         if (h->spec.fill_rows > 0) h->spec.halo_rows = 0;
         // rows below the band the warm-up regions may reach (< 0: unbounded).  Clipping shortens the band waves (2.79 -> 2.51 ms, one VGA frame) and lengthens the
         // validation rounds (2.08 -> 2.77 ms): it loses for one frame (6.0 vs 6.5 ms) and wins once a round lasts as long as the slowest band of several frames
         // anyway (8 frames in flight: 977 -> 1014 frames/s)
-        h->spec.halo_clip = getenv("PLF_LSD_SPEC_CLIP") ? atoi(getenv("PLF_LSD_SPEC_CLIP")) : (B >= 4 ? 16 : -1);
+        h->spec.halo_clip = T.spec_clip != PLF_TUNE_AUTO ? T.spec_clip : (B >= 4 ? 16 : -1);
         PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
         PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
@@ -510,8 +580,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             h->fused_lds = lds_commit; h->fused_capacity = (size_t)per_cu * (size_t)cus;
         }
         zmode = zmode && h->spec.out != nullptr;
-        const bool fused = !zmode && (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !getenv("PLF_LSD_SPEC_NOFUSE");
-        h->spec.stagger = fused ? (getenv("PLF_LSD_SPEC_STAGGER") ? (float)atof(getenv("PLF_LSD_SPEC_STAGGER")) : 0.2f) : 0.f;
+        const bool fused = !zmode && (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !T.spec_nofuse;
+        h->spec.stagger = fused ? T.spec_stagger : 0.f;
         PLF_HIP_TRY(hipMemsetAsync(h->spec.side, 0, (size_t)B * spec_bands * sizeof(int), s));
         // band boundaries: row counts + defined-pixel bitmap over the whole frame in parallel, then one wave per frame balances the bands
         PLF_HIP_TRY(hipMemsetAsync(h->d_spec_rowcnt, 0, (size_t)B * 1024 * sizeof(int), s));
@@ -521,7 +591,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (zmode) {
             // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;
             // rectangles assembled from the bands' logs; frames that did not reach the fixpoint within the rounds are committed serially (exact either way)
-            const int rounds = getenv("PLF_LSD_SPEC_ROUNDS") ? max(1, min(64, atoi(getenv("PLF_LSD_SPEC_ROUNDS")))) : 12;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
+            const int rounds = T.spec_rounds;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
             PLF_HIP_TRY(hipMemsetAsync(h->spec.round_state, 0, (size_t)B * 4 * sizeof(int), s));
             const SpecBufs SBz = h->spec;
             hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(256), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);   // (waves 1-3 warm the L2)
@@ -544,8 +614,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else if (B <= lat_max)
         hipLaunchKernelGGL(budget ? k_lsd_regions_lat_budget : k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
-    else if (!getenv("PLF_LSD_ONE_WAVE_GROUPS")) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
-        const int wpg = getenv("PLF_LSD_WPG") ? max(1, min(16, atoi(getenv("PLF_LSD_WPG")))) : 8;
+    else if (!T.one_wave_groups) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
+        const int wpg = T.wpg;
         const size_t wave_lds = PLF_LSD_WAVE_LDS;
         hipLaunchKernelGGL(budget ? k_lsd_regions2_budget : k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B);
@@ -556,7 +626,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve.  Few frames in flight: one wave per rectangle runs all five stages (k_nfa_fused: a rectangle only waits for itself); otherwise the staged
     // kernels: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math) over work lists compacted over the batch
-    const int nfa_fused_max = getenv("PLF_NFA_FUSED") ? atoi(getenv("PLF_NFA_FUSED")) : 64;
+    const int nfa_fused_max = T.nfa_fused;
     if (B <= nfa_fused_max) {
         hipLaunchKernelGGL(k_nfa_fused, dim3(1024, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_keep, h->d_seg, g);
     } else {

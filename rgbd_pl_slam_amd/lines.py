@@ -84,6 +84,12 @@ class LineSegment:
                                                L.vp(d_lines), L.vp(d_desc), L.vp(d_eq), L.vp(d_n), L.MEM_DEVICE, capacity,
                                                C.c_void_p(stream) if stream else None), "plf_line_extract_batch")
 
+    def tune(self, name, value):
+        """change one schedule knob of this handle (plf_line_tune: a tuning / test hook -- every schedule gives the same bits)"""
+        f = L.lib().plf_line_tune
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.check(f(self._h, name.encode(), float(value)), "plf_line_tune")
+
     def last_status(self, stream=None):
         """status of the last extract_batch_device call (waits for the stream): 0, PLF_E_CAPACITY or PLF_E_RECTS"""
         return int(L.lib().plf_line_last_status(self._h, C.c_void_p(stream) if stream else None))

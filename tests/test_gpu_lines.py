@@ -358,7 +358,7 @@ def test_lines_thousands_of_rectangles(monkeypatch):
     for f in (0, 7):
         got = np.frombuffer(d_lines.cpu().numpy().tobytes(), L.KL_DTYPE)[f * 100:f * 100 + int(d_n[f])]
         assert got.tobytes() == ref["kl"].tobytes()
-    monkeypatch.setenv("PLF_NFA_FUSED", "0")
+    ls8.tune("nfa_fused", 0)                                    # (the knobs are read from the environment when a handle is created; afterwards: plf_line_tune)
     res = ls8.extract_batch(np.stack([stripes] * 8))          # staged kernels: the pool overflows, the host-buffer call splits the batch
     for f in range(8):
         assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"])
