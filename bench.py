@@ -474,7 +474,9 @@ def main():
         # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
         traffic, traffic_source = None, None
         try:
-            src = os.path.join("profiles", "r03_pmc_traffic.json")
+            src = os.path.join("profiles", "r04_pmc_traffic.json")
+            if not os.path.exists(os.path.join(ROOT, src)):
+                src = os.path.join("profiles", "r03_pmc_traffic.json")
             with open(os.path.join(ROOT, src)) as fh:
                 pmc = json.load(fh)
             if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):
@@ -488,13 +490,14 @@ def main():
         # everything else (packed integer, v_perm, dot4, fp64, SGPR operands: what these kernels are made of) every ~4.2
         valu_range, valu_source = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_valu_counts.json")) as fh:
+            vsrc = "r04_valu_counts.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_valu_counts.json")) else "r03_valu_counts.json"
+            with open(os.path.join(ROOT, "profiles", vsrc)) as fh:
                 vc = json.load(fh)
             if args.config == 2:
                 insts = vc["valu_wave_instructions_per_step"] * B / vc["frames_per_step"]
                 step_s = elapsed / args.steps
                 valu_range = [round(insts / vc["rate_full_wave_instr_per_s"] / step_s, 3), round(insts / vc["rate_half_wave_instr_per_s"] / step_s, 3)]
-                valu_source = "profiles/r03_valu_counts.json (SQ_INSTS_VALU per step) / profiles/r03_valu_issue.json (1.12 and 0.585 T wave-instructions/s)"
+                valu_source = "profiles/%s (SQ_INSTS_VALU per step) / profiles/r03_valu_issue.json (1.12 and 0.585 T wave-instructions/s)" % vsrc
         except Exception:
             valu_range = None
         out = {

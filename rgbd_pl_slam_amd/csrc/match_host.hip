@@ -36,7 +36,7 @@ struct MapLineDev { int m; const float *x1, *y1, *x2, *y2; const int *level; con
 
 __global__ void k_build_grid(const FrameDev *, int *, int *, int *, int);
 __global__ void k_mp_candidates(const FrameDev *, MapDev, float, const int *, int, uint8_t *, uint32_t *, int2 *, int, int *, int *);
-__global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, const uint8_t *, int, const uint32_t *, const int2 *, int, const int *);
+__global__ void k_mp_rounds(const FrameDev *, MapDev, float, int *, int, int *, const uint8_t *, int, const uint32_t *, const int2 *, int, const int *, unsigned long long *, int);
 struct TriDev { const plf_keypoint *keys1, *keys2; const float *uright1, *uright2, *scale2, *sigma2_2; float F[9]; float ex, ey; int only_stereo; };
 __global__ void k_match_bow(const BowDev *, float, int, int, int *, int, int *, int *, int *, TriDev);
 __global__ void k_match_project_points_slow(const FrameDev *, MapDev, float, float, int *, int, int *, uint8_t *, int, const int *);
@@ -71,6 +71,7 @@ struct plf_matcher {
     plf_dmatch *d_dm;
     double *d_mad;
     uint32_t *d_cand;        // cached candidate lists of the projection matcher
+    unsigned long long *d_top2;   // [frame][max_mappoints]: the two best free candidates of every unfinished map point in the current round (k_mp_rounds)
     int *d_cand_off, *d_overflow;
     int cand_cap;
     FrameDev *h_frames;      // host copy of the frame table last uploaded (skips the upload + sync when unchanged)
@@ -99,7 +100,7 @@ static int matcher_stream(plf_matcher *h, void *stream, hipStream_t *out)
 
 static void matcher_free(plf_matcher *h)
 {
-    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_mad, h->d_cand, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used};
+    void *ptrs[] = {h->d_frames, h->d_lframes, h->d_cell_start, h->d_cell_idx, h->d_cell_of, h->d_knn_idx, h->d_knn_dist, h->d_done, h->d_proj, h->d_dm, h->d_mad, h->d_cand, h->d_top2, h->d_cand_off, h->d_overflow, h->d_cell_kp, h->d_bow, h->d_bow_fnode, h->d_bow_used};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ps : h->pose_ring) { if (ps.d) (void)hipFree(ps.d); if (ps.h) (void)hipHostFree(ps.h); if (ps.ev) (void)hipEventDestroy(ps.ev); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -160,6 +161,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     h->cand_cap = cand_avg * max_mappoints;
     ALLOC(h->d_cand, B * (size_t)h->cand_cap * sizeof(uint32_t));
     ALLOC(h->d_cand_off, B * (size_t)max_mappoints * sizeof(int2));   // (start, count) of every map point's span in the pool
+    ALLOC(h->d_top2, B * (size_t)max_mappoints * sizeof(unsigned long long));
     ALLOC(h->d_overflow, 2 * B * sizeof(int));                         // [0, B) overflow flags, [B, 2B) pool fill
 #undef ALLOC
     h->h_frames = (FrameDev *)calloc(B, sizeof(FrameDev));
@@ -237,7 +239,7 @@ extern "C" int plf_match_project_points(plf_matcher *h, const plf_frame_view *fr
         hipLaunchKernelGGL(k_mp_candidates, dim3((M.m + 255) / 256, n_frames), dim3(256), 0, s, h->d_frames, M, th, match_of_kp, kp_stride,
                            h->d_done, h->d_cand, (int2 *)h->d_cand_off, h->cand_cap, h->d_overflow, h->d_overflow + h->max_batch);
         hipLaunchKernelGGL(k_mp_rounds, dim3(n_frames), dim3(256), lds_fast, s, h->d_frames, M, nnratio, match_of_kp, kp_stride, nmatches,
-                           h->d_done, kp_cap, h->d_cand, (const int2 *)h->d_cand_off, h->cand_cap, h->d_overflow);
+                           h->d_done, kp_cap, h->d_cand, (const int2 *)h->d_cand_off, h->cand_cap, h->d_overflow, h->d_top2, h->max_mp);
     }
     hipLaunchKernelGGL(k_match_project_points_slow, dim3(n_frames), dim3(256), (size_t)kp_cap * 8, s, h->d_frames, M, th, nnratio, match_of_kp,
                        kp_stride, nmatches, h->d_done, kp_cap, h->d_overflow);

@@ -2,7 +2,7 @@
 """BASELINE.md section 4 table, measured in ONE run on the GPU box: for BASELINE configs 1-2 / 3 / 4 the GPU frames/s on one MI355X (device-resident
 step of bench.py, the config's own frames in flight and -- for comparison -- many frames in flight), the CPU figures (a) one frame at a time on one
 thread and (b) one frame per thread on all cores (oracle port, -O3 -march=native), and for config 5 the matchers alone.
-    python tools/baseline_table.py  ->  gpurun_out/r03_baseline_table.json + a markdown table on stdout"""
+    python tools/baseline_table.py  ->  gpurun_out/r04_baseline_table.json + a markdown table on stdout"""
 import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -38,5 +38,5 @@ for cfg, big in ((2, 8192), (3, 8192), (4, 2048)):   # (eight region chains per 
         out.setdefault("config5_match_only", {})["cpu_single_thread_frames_per_s"] = round(1e3 / (st["match_points"] + st["match_lines"]), 1)
 out["host_cores"] = cores
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_baseline_table.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_baseline_table.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -1,0 +1,36 @@
+"""Few-frames schedule sweep: LSD+LBD of B frames in flight (host in / out) for band counts / warm-up rows / clip, knobs set per handle with plf_line_tune.
+    python tools/sweep_few.py [B=1] [nlines=100] [w=640] [h=480]"""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from rgbd_pl_slam_amd import LineSegment
+from rgbd_pl_slam_amd.synth import synth_frame
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 640
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 480
+sets = [np.stack([synth_frame(300 + 17 * s + i, W, H) for i in range(B)]) for s in range(4)]
+def run(**kn):
+    ls = LineSegment(nlines=NL, max_width=W, max_height=H, max_batch=B)
+    for k, v in kn.items():
+        ls.tune(k, v)
+    for im in sets: ls.extract_batch(im)
+    ts = []
+    for r in range(3):
+        for im in sets:
+            t = time.perf_counter(); ls.extract_batch(im); ts.append((time.perf_counter() - t) * 1e3)
+    ls.close()
+    return float(np.median(ts)), float(np.max(ts))
+print("B=%d %dx%d, %d lines: median / max ms per call over 4 frame sets" % (B, W, H, NL))
+base = run()
+print("  default                         %.2f / %.2f ms  -> %.0f frames/s" % (base[0], base[1], B / base[0] * 1e3))
+for bands in (24, 32, 40, 48, 56, 64):
+    for halo in (2, 4, 6):
+        m = run(spec_bands=bands, spec_halo=halo)
+        print("  bands %2d  warm-up rows %d        %.2f / %.2f ms  -> %.0f frames/s" % (bands, halo, m[0], m[1], B / m[0] * 1e3))
+for clip in (-1, 8, 16, 32):
+    m = run(spec_clip=clip)
+    print("  clip %3d                         %.2f / %.2f ms" % (clip, m[0], m[1]))
+for rounds in (6, 8, 12, 16):
+    m = run(spec_rounds=rounds)
+    print("  rounds %2d                        %.2f / %.2f ms" % (rounds, m[0], m[1]))
