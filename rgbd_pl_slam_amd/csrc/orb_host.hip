@@ -18,7 +18,7 @@ __global__ void k_orb_level(const uint8_t *, ptrdiff_t, ptrdiff_t, uint8_t *, ui
                             int2 *, uint2 *, int *, int *, OrbGeom, int4);
 __global__ void k_octree(const int2 *, const uint2 *, int *, uint2 *, int *, uint8_t *, uint2 *, int *, int *, int *, OrbGeom, int, int);
 __global__ void k_orient_brief(const uint8_t *, const uint8_t *, const uint2 *, const int *, plf_keypoint *, uint8_t *, int *, int,
-                               int *, OrbGeom);
+                               int *, OrbGeom, int);
 
 struct plf_orb {
     plf_orb_params prm;
@@ -435,8 +435,8 @@ static int orb_enqueue(plf_orb *h, const uint8_t *d_gray, int n_frames, ptrdiff_
     int slots = 0;   // at most sum of the per-level selection caps, and never more than the caller can take
     for (int l = 0; l < nl; l++) slots += (int)g.lv[l].sel_cap;
     if (slots > capacity) slots = capacity;
-    hipLaunchKernelGGL(k_orient_brief, dim3(slots, B), dim3(64), 0, s, h->d_pyr, h->d_blur, h->d_sel, selcnt, d_kps, d_desc,
-                       d_nout, capacity, status, g);
+    hipLaunchKernelGGL(k_orient_brief, dim3(8 * slots, (B + 7) / 8), dim3(64), 0, s, h->d_pyr, h->d_blur, h->d_sel, selcnt, d_kps, d_desc,
+                       d_nout, capacity, status, g, B);
     PLF_HIP_TRY(hipGetLastError());
     h->last_frames = B;
     return PLF_OK;
