@@ -174,6 +174,10 @@ int plf_line_truncated(plf_line *h, int32_t *flags, int32_t n);
  * kilo-cycles spent regrowing, validating, in total, in per-band setup}.  PLF_E_BADARG if the path has not run on this handle. */
 int plf_line_debug_spec_stats(plf_line *h, int32_t *out8);
 
+/* Diagnostics (tools/nfa_stats.py): out16[s] = rectangles of the last batch that entered rect_improve stage s (0..4; [5] = left over after stage 4), for batches
+ * that took the staged NFA kernels (more than 64 frames in flight).  Synchronises the device. */
+int plf_line_debug_nfa_counters(plf_line *h, int32_t *out16);
+
 /* Diagnostics (bench.py): out[f] = length of frame f's region-growing chain in the last batch = pixels left marked USED (accept steps minus the pixels
  * refine released again), n <= frames of that batch.  The launch of the one-wave-per-frame kernel lasts as long as its longest chain.  Zero for batches
  * that took the speculative schedule (its flags live in LDS).  Synchronises the device. */

@@ -37,7 +37,9 @@ __global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, 
 __global__ void k_nfa_clamp(int *, int *, LsdGeom);
 __global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_count1(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
-__global__ void k_nfa_eval(int, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
+__global__ void k_nfa_eval(int, const double *, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
+__global__ void k_nfa_table(double *, const double *, double);
+__global__ void k_nfa_small(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_nfa_fused(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
@@ -78,6 +80,8 @@ struct LineTune {
     int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (8)
     int one_wave_groups;  // PLF_LSD_ONE_WAVE_GROUPS  one frame per workgroup for large batches too
     int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
+    int nfa_small;        // PLF_NFA_SMALL        1: large batches run rect_improve of rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle
+    int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
 };
 static int tune_env_i(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static float tune_env_f(const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; }
@@ -99,6 +103,8 @@ static void line_tune_init(LineTune *t)
     t->wpg = std::max(1, std::min(16, tune_env_i("PLF_LSD_WPG", 8)));
     t->one_wave_groups = getenv("PLF_LSD_ONE_WAVE_GROUPS") ? 1 : 0;
     t->nfa_fused = tune_env_i("PLF_NFA_FUSED", 64);
+    t->nfa_table = tune_env_i("PLF_NFA_TABLE", 1);
+    t->nfa_small = tune_env_i("PLF_NFA_SMALL", 1);
 }
 
 struct plf_line {
@@ -124,6 +130,8 @@ struct plf_line {
     hipStream_t stream;
     uint8_t *d_in, *d_keep, *d_ldesc;
     double *d_modgrad, *d_lineeq, *d_lgam;
+    double *d_nfa_tab;        // nfa(n, k, p) of small rectangles (k_nfa_table), valid for scaled images with LOG_NT == nfa_tab_log_nt
+    double nfa_tab_log_nt;
     // seed_order = 1 only: per-frame max gradient, (bin, pixel) keys before / after the segmented sort, segment offsets, sort scratch
     double *d_maxgrad;
     uint32_t *d_keys[2];
@@ -170,7 +178,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
                   h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
@@ -360,6 +368,8 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
     ALLOC(h->d_counters, (5 * B + 16) * sizeof(int));   // nrect[B], nseg[B], nout[B], status[16] + truncated[B], chain lengths[B]
     ALLOC(h->d_lgam, 65536 * sizeof(double));
+    ALLOC(h->d_nfa_tab, (size_t)11 * 512 * 512 * sizeof(double));   // NFA_TAB_P x NFA_TAB_N x NFA_TAB_N (lsd_kernels.hip)
+    h->nfa_tab_log_nt = -1.0;
     ALLOC(h->d_lbd, sizeof(LbdCoefs));
     ALLOC(h->d_ent[0], NP * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], NP * 5 * sizeof(NfaEntry));
     ALLOC(h->d_st[0], NP * sizeof(NfaState)); ALLOC(h->d_st[1], NP * sizeof(NfaState));
@@ -414,7 +424,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
     const int v = (int)value;
     struct { const char *n; int *p; } ints[] = {{"lat_max", &t.lat_max}, {"spec_bands", &t.spec_bands}, {"spec_max", &t.spec_max}, {"spec_z", &t.spec_z},
         {"spec_rounds", &t.spec_rounds}, {"spec_halo", &t.spec_halo}, {"spec_fill", &t.spec_fill}, {"spec_clip", &t.spec_clip}, {"spec_nofuse", &t.spec_nofuse},
-        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}};
+        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}};
     for (auto &e : ints)
         if (!strcmp(name, e.n)) {
             if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
@@ -627,10 +637,18 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // rect_improve.  Few frames in flight: one wave per rectangle runs all five stages (k_nfa_fused: a rectangle only waits for itself); otherwise the staged
     // kernels: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math) over work lists compacted over the batch
     const int nfa_fused_max = T.nfa_fused;
+    if (T.nfa_table && h->nfa_tab_log_nt != g.log_nt) {   // (first batch of this image size)
+        hipLaunchKernelGGL(k_nfa_table, dim3(11 * 512 * 512 / 256), dim3(256), 0, s, h->d_nfa_tab, h->d_lgam, g.log_nt);
+        h->nfa_tab_log_nt = g.log_nt;
+    }
     if (B <= nfa_fused_max) {
         hipLaunchKernelGGL(k_nfa_fused, dim3(1024, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_keep, h->d_seg, g);
     } else {
     PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
+    if (T.nfa_table && T.nfa_small)   // rectangles of fewer than 512 pixels: all five stages by 16 lanes, values from the table; the others are queued for the staged kernels
+        hipLaunchKernelGGL(k_nfa_small, dim3(8 * (g.rect_cap < 640 ? (g.rect_cap + 3) / 4 : 160), (B + 7) / 8), dim3(64), 0, s, h->d_ang, h->d_nfa_tab, h->d_rects, nrect, h->d_keep,
+                           h->d_seg, h->d_ent[0], h->d_st[0], h->d_nfa_counters, status, g, B);
+    else
     hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
                        h->d_nfa_counters, status, g);
     hipLaunchKernelGGL(k_nfa_clamp, dim3(1), dim3(1), 0, s, h->d_nfa_counters, status, g);
@@ -644,7 +662,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             hipLaunchKernelGGL(k_nfa_count1, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 5, h->d_cnt, g);
         else
             hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 1, h->d_cnt, g);
-        hipLaunchKernelGGL(k_nfa_eval, dim3(2 * math_blocks), dim3(256), 0, s, stage, h->d_lgam, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
+        hipLaunchKernelGGL(k_nfa_eval, dim3(2 * math_blocks), dim3(256), 0, s, stage, h->d_lgam, T.nfa_table ? h->d_nfa_tab : nullptr, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
                            h->d_vals, g);
         hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],
                            h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
@@ -871,6 +889,15 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
         for (int b = 0; b < h->spec.nbands && b < 63; b++) fprintf(stderr, " b%d grow_end %d commit_start %d |", b, (tl[3 * b] - t0) / 100, (tl[3 * b + 1] - t0) / 100);
         fprintf(stderr, " commit_end %d\n", (tl[3 * 63 + 2] - t0) / 100);
     }
+    return PLF_OK;
+}
+
+// diagnostics (tools/nfa_stats.py): rectangles that entered each rect_improve stage of the last staged batch (out16[0..5]; [5] = not meaningful after the last stage)
+extern "C" int plf_line_debug_nfa_counters(plf_line *h, int32_t *out16)
+{
+    if (!h || !out16 || !h->d_nfa_counters) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    PLF_HIP_TRY(hipMemcpy(out16, h->d_nfa_counters, 16 * sizeof(int), hipMemcpyDeviceToHost));
     return PLF_OK;
 }
 

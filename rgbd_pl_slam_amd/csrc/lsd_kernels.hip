@@ -2509,6 +2509,33 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
     return -log10(bin_tail) - LOG_NT;
 }
 
+// NFA values of small rectangles, tabulated: rect_improve asks for nfa(n, k, p) tens of millions of times per large batch (9,600 values per VGA frame), nearly
+// always with a pixel count n of a few dozen to a few hundred and always with p = 1/8 * 2^-j, j = 0..10 (region2rect's p, halved by the two precision stages).  The
+// table holds nfa_d's own result for every n < NFA_TAB_N, k <= n and those eleven p -- filled by k_nfa_table with the very same device function (the lgamma table's
+// argument: a lookup is bit-identical to evaluating in place), once per scaled-image size (LOG_NT enters the loop's exit test, so the values depend on it).
+#define NFA_TAB_N 512
+#define NFA_TAB_P 11
+__global__ void __launch_bounds__(256) k_nfa_table(double *__restrict__ tab, const double *__restrict__ lgam, double log_nt)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NFA_TAB_P * NFA_TAB_N * NFA_TAB_N) return;
+    const int j = idx / (NFA_TAB_N * NFA_TAB_N), n = (idx / NFA_TAB_N) % NFA_TAB_N, k = idx % NFA_TAB_N;
+    if (k > n) return;
+    double p = 0.125;
+    for (int q = 0; q < j; q++) p /= 2;
+    tab[idx] = nfa_d(lgam, log_nt, n, k, p);
+}
+
+// true (and v) if (n, k, p) is tabulated
+__device__ __forceinline__ bool nfa_lookup(const double *__restrict__ tab, int n, int k, double p, double &v)
+{
+    const long long bits = __double_as_longlong(p);
+    const int j = 1023 - 3 - (int)(bits >> 52);   // p = 2^-(3 + j) exactly <=> mantissa 0, sign 0
+    if ((bits & 0xFFFFFFFFFFFFFll) != 0 || j < 0 || j >= NFA_TAB_P || n < 0 || n >= NFA_TAB_N || k < 0 || k > n) return false;
+    v = tab[(j * NFA_TAB_N + n) * NFA_TAB_N + k];
+    return true;
+}
+
 struct EdgePt { int x, y, taken; };
 
 // ------------------------------------------------------------------------------------------------
@@ -2532,10 +2559,13 @@ struct NfaState { LsdRect rec; double log_nfa; int frame, rect; };
 // only a few rows, so a full wave per rectangle would idle)
 // NP = 6: the counts for rec.prec and the five halved precisions of the same geometry (stages 0 and 4); NP = 1: rec.prec only (the candidate
 // rectangles of stages 1..3 -- most of the pixel visits; the five unused comparisons per pixel were 37 % of the loop body)
-template <int NP, int G = 16>
-__device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, NfaCounts &out)
+__device__ __forceinline__ int div_small(int a, int b);
+
+// scan-line description of a rectangle: everything rect_count's row walk needs (all integers)
+struct RectScan { int mnx, y_lo, y_hi, lfy, rty, fl, sl, fr, sr; };
+
+__device__ __forceinline__ void rect_scan_setup(const LsdRect &rec, int H, RectScan &S)
 {
-    const int lane = plf_lane() & (G - 1);   // G lanes per rectangle: 16 (four rectangles per wave, large batches) or the whole wave (k_nfa_fused)
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     // the four corners, kept in registers (no indexed array: that would live in scratch memory)
@@ -2573,14 +2603,70 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
 #undef PLF_SELX
 #undef PLF_SELY
     // upstream: integer divisions, and `tailp->p.x` where p.y was meant
-    const long long flstep = (mn.y != lf.y) ? (mn.x - lf.x) / (mn.y - lf.y) : 0;
-    const long long slstep = (lf.y != tl.x) ? (lf.x - tl.x) / (lf.y - tl.x) : 0;
-    const long long frstep = (mn.y != rt.y) ? (mn.x - rt.x) / (mn.y - rt.y) : 0;
-    const long long srstep = (rt.y != tl.x) ? (rt.x - tl.x) / (rt.y - tl.x) : 0;
+    S.fl = (mn.y != lf.y) ? div_small(mn.x - lf.x, mn.y - lf.y) : 0;
+    S.sl = (lf.y != tl.x) ? div_small(lf.x - tl.x, lf.y - tl.x) : 0;
+    S.fr = (mn.y != rt.y) ? div_small(mn.x - rt.x, mn.y - rt.y) : 0;
+    S.sr = (rt.y != tl.x) ? div_small(rt.x - tl.x, rt.y - tl.x) : 0;
     // rows outside the image are skipped BEFORE the step update (upstream `continue`): the walk starts at y_lo.
-    // After visiting row y' the walk adds (y' >= lf.y ? slstep : flstep); all terms are integers, so the span of
-    // row y is exact in closed form.
-    const int y_lo = max(mn.y, 0), y_hi = min(mx.y, H - 1);
+    S.mnx = mn.x; S.lfy = lf.y; S.rty = rt.y;
+    S.y_lo = max(mn.y, 0); S.y_hi = min(mx.y, H - 1);
+}
+
+// span of row y (y_lo <= y <= y_hi).  After visiting row y' the walk adds (y' >= lf.y ? slstep : flstep); all terms are integers, so the span of
+// row y is exact in closed form.
+__device__ __forceinline__ void rect_span(const RectScan &S, int y, int W, int &xl, int &xr)
+{
+    // (32-bit: slopes and row counts are below 2^15 for any image the handle accepts -- line_configure checks -- so the products stay below 2^30 and the 24-bit
+    // multiplier's result is the full product; upstream's own arithmetic is int)
+    const int al = max(0, min(y, S.lfy) - S.y_lo), bl = (y - S.y_lo) - al;
+    const int ar = max(0, min(y, S.rty) - S.y_lo), br = (y - S.y_lo) - ar;
+    const int left = S.mnx + __mul24(S.fl, al) + __mul24(S.sl, bl), right = S.mnx + __mul24(S.fr, ar) + __mul24(S.sr, br);
+    xl = max(left, 0); xr = min(right, W - 1);
+}
+
+// truncating integer division (C semantics) of operands below 2^23 in magnitude, b != 0: the float quotient estimate is within 1 of the truth, fixed up exactly
+// with the remainder (the compiler's general 32-bit division is ~35 instructions; rect_scan_setup has four)
+__device__ __forceinline__ int div_small(int a, int b)
+{
+    const unsigned ua = (unsigned)abs(a), ub = (unsigned)abs(b);
+    unsigned q = (unsigned)((float)ua * __builtin_amdgcn_rcpf((float)ub));
+    int r = (int)ua - (int)(q * ub);
+    if (r < 0) { q--; r += (int)ub; }
+    if (r >= (int)ub) { q++; }
+    return ((a ^ b) < 0) ? -(int)q : (int)q;
+}
+
+// sum over the 16 lanes of a DPP row (= one rectangle's group), result in every lane: four rotate-and-add steps, one instruction each (ds_bpermute + address
+// arithmetic before)
+__device__ __forceinline__ int row16_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    return v;
+}
+
+// |level-line angle - theta| folded as upstream's isAligned does
+__device__ __forceinline__ double rect_ntheta(float dw, double theta)
+{
+    const double a = (double)fabsf(dw) * DEG2RAD_D;   // the sign bit is k_lsd_regions' USED flag
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_D) {
+        n_theta -= M_2__PI_D;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta;
+}
+
+template <int NP, int G = 16>
+__device__ void rect_count(const float *__restrict__ ang, int W, int H, const LsdRect &rec, NfaCounts &out)
+{
+    const int lane = plf_lane() & (G - 1);   // G lanes per rectangle: 16 (four rectangles per wave, large batches) or the whole wave (k_nfa_fused)
+    RectScan S;
+    rect_scan_setup(rec, H, S);
+    const int y_lo = S.y_lo, y_hi = S.y_hi;
     double precs[NP];
     precs[0] = rec.prec;
     if (NP > 1) {
@@ -2596,10 +2682,8 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
     while (ry_n > 1 && ry_n > y_hi - y_lo + 1) ry_n >>= 1;
     const int rx_n = G / ry_n, ry = lane & (ry_n - 1), rx = lane / ry_n;
     for (int y = y_lo + ry; y <= y_hi; y += ry_n) {
-        const long long al = max(0, min(y, lf.y) - y_lo), bl = (long long)(y - y_lo) - al;
-        const long long ar = max(0, min(y, rt.y) - y_lo), br = (long long)(y - y_lo) - ar;
-        const long long left = (long long)mn.x + flstep * al + slstep * bl, right = (long long)mn.x + frstep * ar + srstep * br;
-        const int xl = (int)max(left, 0ll), xr = (int)min(right, (long long)(W - 1));
+        int xl, xr;
+        rect_span(S, y, W, xl, xr);
         const float *row = ang + (size_t)y * W;
         // the angle words of a row sit in HBM (thousands of frames in flight: no cache holds them) and the kernel is bound by that latency: NFA_U gathers
         // in flight per lane instead of 1, and 16 waves per SIMD-quad slot (line_host.hip) -- 15.9 -> 7.9 ms per 4096 frames for the five stages
@@ -2613,28 +2697,89 @@ __device__ void rect_count(const float *__restrict__ ang, int W, int H, const Ls
                 ++total;
                 const float dw = dwv[q];
                 if (dw == NOTDEF_F) continue;
-                const double a = (double)fabsf(dw) * DEG2RAD_D;   // the sign bit is k_lsd_regions' USED flag
-                double n_theta = rec.theta - a;
-                if (n_theta < 0) n_theta = -n_theta;
-                if (n_theta > M_3_2_PI_D) {
-                    n_theta -= M_2__PI_D;
-                    if (n_theta < 0) n_theta = -n_theta;
-                }
+                const double n_theta = rect_ntheta(dw, rec.theta);
 #pragma unroll
                 for (int k = 0; k < NP; k++) if (n_theta <= precs[k]) ++alg[k];
             }
         }
 
     }
+    if (G == 16) {
+        total = row16_sum(total);
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {  // butterfly inside the group
-        total += __shfl_xor(total, o, 64);
+        for (int k = 0; k < NP; k++) alg[k] = row16_sum(alg[k]);
+    } else {
 #pragma unroll
-        for (int k = 0; k < NP; k++) alg[k] += __shfl_xor(alg[k], o, 64);
+        for (int o = G / 2; o > 0; o >>= 1) {  // butterfly inside the group
+            total += __shfl_xor(total, o, 64);
+#pragma unroll
+            for (int k = 0; k < NP; k++) alg[k] += __shfl_xor(alg[k], o, 64);
+        }
     }
     out.total = total;
 #pragma unroll
     for (int k = 0; k < 6; k++) out.alg[k] = k < NP ? alg[k < NP ? k : 0] : 0;
+}
+
+// The five candidate rectangles of one width stage (1..3) of rect_improve, counted in ONE pass by a group of 16 lanes.  They share theta and the precision and
+// cover nearly the same pixels, so (i) lane c < 5 does candidate c's scan-line set-up (corners, ordering, the four integer slopes -- two thirds of the instructions
+// of a rect_count call on the small rectangles that make up most of a frame) while the others idle instead of the whole group doing it five times, (ii) every
+// pixel of the union of the spans is fetched and its angle folded once, then tested against each candidate's span.  Per candidate the counted set is exactly
+// rect_count<1>'s: the pixels of rows y_lo..y_hi inside [xl, xr] of rect_span.  par: 5 x 12 ints of LDS owned by the group.
+__device__ void rect_count5(const float *__restrict__ ang, int W, int H, const LsdRect &cand, bool valid, double theta, double prec, int *par, int (&total)[5],
+                            int (&alg)[5])
+{
+    const int lane = plf_lane() & 15;
+    RectScan S;
+    rect_scan_setup(cand, H, S);
+    const bool mine = lane < 5 && valid;
+    if (lane < 5) {
+        int *P = par + lane * 12;
+        P[0] = S.mnx; P[1] = mine ? S.y_lo : 1; P[2] = mine ? S.y_hi : 0; P[3] = S.lfy; P[4] = S.rty; P[5] = S.fl; P[6] = S.sl; P[7] = S.fr; P[8] = S.sr;
+    }
+    int y_lo = mine ? S.y_lo : (1 << 30), y_hi = mine ? S.y_hi : -(1 << 30);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { y_lo = min(y_lo, __shfl_xor(y_lo, o, 64)); y_hi = max(y_hi, __shfl_xor(y_hi, o, 64)); }
+    CBAR();
+#pragma unroll
+    for (int c = 0; c < 5; c++) total[c] = alg[c] = 0;
+    int ry_n = 16;
+    while (ry_n > 1 && ry_n > y_hi - y_lo + 1) ry_n >>= 1;
+    const int rx_n = 16 / ry_n, ry = lane & (ry_n - 1), rx = lane / ry_n;
+    for (int y = y_lo + ry; y <= y_hi; y += ry_n) {
+        int xl[5], xr[5], uxl = 1 << 30, uxr = -1;   // (a row none of the candidates has pixels in: an empty loop below, without overflowing uxl + rx)
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const int *P = par + c * 12;
+            RectScan Sc;
+            Sc.mnx = P[0]; Sc.y_lo = P[1]; Sc.y_hi = P[2]; Sc.lfy = P[3]; Sc.rty = P[4]; Sc.fl = P[5]; Sc.sl = P[6]; Sc.fr = P[7]; Sc.sr = P[8];
+            rect_span(Sc, y, W, xl[c], xr[c]);
+            if (y < Sc.y_lo || y > Sc.y_hi) { xl[c] = 1; xr[c] = 0; }
+            if (xl[c] <= xr[c]) { uxl = min(uxl, xl[c]); uxr = max(uxr, xr[c]); }
+        }
+        const float *row = ang + (size_t)y * W;
+        for (int x = uxl + rx; x <= uxr; x += NFA_U * rx_n) {
+            float dwv[NFA_U];
+#pragma unroll
+            for (int q = 0; q < NFA_U; q++) dwv[q] = (x + q * rx_n <= uxr) ? row[x + q * rx_n] : NOTDEF_F;
+#pragma unroll
+            for (int q = 0; q < NFA_U; q++) {
+                const int xq = x + q * rx_n;
+                if (xq > uxr) continue;
+                const float dw = dwv[q];
+                const bool al = dw != NOTDEF_F && rect_ntheta(dw, theta) <= prec;
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const bool in = xq >= xl[c] && xq <= xr[c];
+                    total[c] += in ? 1 : 0;
+                    alg[c] += (in && al) ? 1 : 0;
+                }
+            }
+        }
+    }
+    CBAR();
+#pragma unroll
+    for (int c = 0; c < 5; c++) { total[c] = row16_sum(total[c]); alg[c] = row16_sum(alg[c]); }
 }
 
 __device__ __forceinline__ void emit_segment(LsdRect rec, float4 *seg)
@@ -2731,7 +2876,7 @@ __device__ __forceinline__ bool nfa_item(int stage, bool multi, int it, const Nf
     return true;
 }
 
-__global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__restrict__ lgam, const NfaCounts *__restrict__ counts,
+__global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__restrict__ lgam, const double *__restrict__ tab, const NfaCounts *__restrict__ counts,
                                                    const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
                                                    double *__restrict__ vals, LsdGeom g)
 {
@@ -2754,7 +2899,8 @@ __global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__re
                 int n = 0, k = 0;
                 double p;
                 int b = 0;
-                if (nfa_item(stage, multi, it, entries, counts, n, k, p) && n != 0 && k != 0 && n != k) {
+                double tv;
+                if (nfa_item(stage, multi, it, entries, counts, n, k, p) && n != 0 && k != 0 && n != k && !(tab && nfa_lookup(tab, n, k, p, tv))) {
                     const int L = max(1, (n + 1) / 2 - k);
                     const int lz = 31 - __clz(L);
                     b = min(31, 1 + 2 * lz + (lz > 0 ? ((L >> (lz - 1)) & 1) : 0));
@@ -2778,7 +2924,7 @@ __global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__re
             const int it = c0 + order[i];
             int n = 0, k = 0;
             double p = 0.0, v = -1.0e300;
-            if (nfa_item(stage, multi, it, entries, counts, n, k, p)) v = nfa_d(lgam, g.log_nt, n, k, p);
+            if (nfa_item(stage, multi, it, entries, counts, n, k, p) && !(tab && nfa_lookup(tab, n, k, p, v))) v = nfa_d(lgam, g.log_nt, n, k, p);
             vals[it] = v;
         }
         __syncthreads();
@@ -2847,6 +2993,106 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
             e.nprec = ((r.width - delta) >= 0.5) ? 6 : 0;
             ent_out[q] = e;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rect_improve of one SMALL rectangle by a group of 16 lanes, all five stages in one launch (large batches).  Two thirds of a frame's ~550 rectangles are small
+// regions that fail the first test and walk through all five stages (22 pixel counts, 21 NFA values each) only to be rejected; with the staged kernels above that is
+// 17 grid-wide launches whose eval / math steps mostly move 112-byte work-list entries around.  Here every NFA value is one load from k_nfa_table's table and the
+// "keep it if better" chain stays in registers (the same chain as k_nfa_math, the same rect_count).  A rectangle with a candidate the table does not hold (512 pixels
+// or more) is handed, untouched, to the staged kernels through their stage-0 work list, exactly as k_nfa_init would have queued it.
+// ------------------------------------------------------------------------------------------------
+#ifndef PLF_NFA_SMALL_WPE
+#define PLF_NFA_SMALL_WPE 0
+#endif
+#if PLF_NFA_SMALL_WPE > 0
+#define PLF_NFA_SMALL_OCC __attribute__((amdgpu_waves_per_eu(PLF_NFA_SMALL_WPE, PLF_NFA_SMALL_WPE)))
+#else
+#define PLF_NFA_SMALL_OCC
+#endif
+__global__ void PLF_NFA_SMALL_OCC __launch_bounds__(64) k_nfa_small(const float *__restrict__ ang_all, const double *__restrict__ tab, const LsdRect *__restrict__ rects_all,
+                                                  const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all,
+                                                  NfaEntry *__restrict__ entries, NfaState *__restrict__ states, int *__restrict__ counters,
+                                                  int *__restrict__ status, LsdGeom g, int nframes)
+{
+    // grid (8 * slots, ceil(B / 8)): workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), so XCD x works through frame 8 * blockIdx.y + x and the
+    // angle words of a frame are pulled into ONE L2 (k_orient_brief's order)
+    const int f = 8 * (int)blockIdx.y + ((int)blockIdx.x & 7), slot = (int)blockIdx.x >> 3, nslots = (int)gridDim.x >> 3;
+    if (f >= nframes) return;
+    __shared__ int s_par[4][5 * 12];
+    const int n_r = nrect[f], grp = threadIdx.x >> 4, lane16 = threadIdx.x & 15;
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
+    for (int i0 = slot * 4; i0 < n_r; i0 += nslots * 4) {
+        const int ri = i0 + grp;
+        if (ri >= n_r) continue;   // (groups are independent: rect_count's butterflies stay inside the 16 lanes)
+        LsdRect rec = rects_all[(size_t)f * g.rect_cap + ri];
+        double log_nfa = -1;
+        bool keep = false, defer = false, fin = false;
+        NfaCounts c;
+        for (int stage = 0; stage <= 4 && !fin; stage++) {
+            if (stage == 0 || stage == 4) {
+                if (stage == 4 && !((rec.width - delta) >= 0.5)) break;   // (nprec 0 in k_nfa_math: nothing to evaluate, not meaningful)
+                rect_count<6, 16>(ang, g.sw, g.sh, rec, c);
+                LsdRect r = rec;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if (k > 0) { r.p /= 2; r.prec = r.p * PI_D; }
+                    if (stage == 4 && k == 0) continue;
+                    double v;
+                    if (!nfa_lookup(tab, c.total, c.alg[k], r.p, v)) { defer = fin = true; break; }
+                    if (stage == 0 && k == 0) {
+                        log_nfa = v;
+                        if (v > LOG_EPS) { keep = fin = true; break; }
+                    } else if (v > log_nfa) { log_nfa = v; rec.p = r.p; rec.prec = r.prec; }
+                }
+            } else {
+                // 1: reduce the width, 2: reduce one side, 3: reduce the other side -- five candidates, each derived from the previous one: lane c of the group
+                // builds candidate c by the same c + 1 steps (lanes 5..15 idle along with candidate 4), then one pass counts all five
+                LsdRect r = rec;
+                bool valid = true;
+                const int myc = min(lane16, 4);
+                for (int k = 0; k <= 4; k++) {
+                    if (k > myc) break;
+                    if (!((r.width - delta) >= 0.5)) { valid = false; break; }   // (every later candidate fails the same test)
+                    if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+                    if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+                    r.width -= delta;
+                }
+                const int nvalid = __popcll((__ballot(valid && lane16 < 5) >> (16 * grp)) & 31ull);   // (monotone: candidates 0 .. nvalid - 1)
+                if (nvalid > 0) {
+                    int total[5], alg[5];
+                    rect_count5(ang, g.sw, g.sh, r, valid, rec.theta, rec.prec, &s_par[grp][0], total, alg);
+                    int best = -1;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        if (k >= nvalid || fin) continue;
+                        double v;
+                        if (!nfa_lookup(tab, total[k], alg[k], rec.p, v)) { defer = fin = true; continue; }
+                        if (v > log_nfa) { log_nfa = v; best = k; }
+                    }
+                    if (best >= 0 && !defer) {
+                        const int src = (threadIdx.x & 48) + best;
+                        rec.x1 = shfl_d(r.x1, src); rec.y1 = shfl_d(r.y1, src); rec.x2 = shfl_d(r.x2, src); rec.y2 = shfl_d(r.y2, src); rec.width = shfl_d(r.width, src);
+                    }
+                }
+            }
+            if (!fin && log_nfa > LOG_EPS) keep = fin = true;
+        }
+        if ((threadIdx.x & 15) != 0) continue;
+        const size_t o = (size_t)f * g.rect_cap + ri;
+        keep_all[o] = keep && !defer ? 1 : 0;
+        if (defer) {
+            const int q = atomicAdd(&counters[0], 1);
+            if (q >= g.nfa_pool) { atomicOr(status, 1); continue; }
+            NfaEntry e;
+            e.r = rects_all[o]; e.frame = f; e.nprec = 6; e.pad0 = e.pad1 = 0;
+            entries[q] = e;
+            NfaState st;
+            st.rec = e.r; st.log_nfa = -1; st.frame = f; st.rect = ri;
+            states[q] = st;
+        } else if (keep) emit_segment(rec, &seg_all[o]);
     }
 }
 

@@ -116,6 +116,12 @@ class LineSegment:
         L.check(L.lib().plf_line_chain_lengths(self._h, L.vp(out), n), "plf_line_chain_lengths")
         return out
 
+    def nfa_counters(self):
+        """rectangles of the last batch that entered each rect_improve stage (plf_line_debug_nfa_counters)"""
+        out = np.zeros(16, np.int32)
+        L.check(L.lib().plf_line_debug_nfa_counters(self._h, L.vp(out)), "plf_line_debug_nfa_counters")
+        return out
+
     def segments(self, frame=0):
         """test hook: all LSD segments of the last call in detection order"""
         n = C.c_int32()

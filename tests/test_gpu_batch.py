@@ -186,6 +186,7 @@ def test_chunk_redo_when_the_rectangle_pool_overflows(monkeypatch):
     one-wave-per-rectangle kernel, which has no pool.)"""
     _need_gpu()
     monkeypatch.setenv("PLF_NFA_FUSED", "0")
+    monkeypatch.setenv("PLF_NFA_SMALL", "0")      # (with k_nfa_small only rectangles of 512 pixels or more use the pool: these frames would fit)
     from rgbd_pl_slam_amd.batch import BatchExtractor
     from rgbd_pl_slam_amd.frame import camera, TUM1
     from rgbd_pl_slam_amd.synth import synth_frame
@@ -308,6 +309,7 @@ def test_rectangle_pool_redo_in_one_worker_while_the_other_runs(monkeypatch):
     same GPU; lines-only batch with map lines -- the mvScaleFactors table no longer depends on an ORB handle"""
     _need_gpu()
     monkeypatch.setenv("PLF_NFA_FUSED", "0")      # the staged NFA kernels (pooled buffers): what chunks of more than 64 frames take
+    monkeypatch.setenv("PLF_NFA_SMALL", "0")      # every rectangle through them, so that the pool overflows
     from rgbd_pl_slam_amd.batch import BatchExtractor
     from rgbd_pl_slam_amd.synth import synth_frame
     rng = np.random.default_rng(77000 + 246)

@@ -359,7 +359,14 @@ def test_lines_thousands_of_rectangles(monkeypatch):
         got = np.frombuffer(d_lines.cpu().numpy().tobytes(), L.KL_DTYPE)[f * 100:f * 100 + int(d_n[f])]
         assert got.tobytes() == ref["kl"].tobytes()
     ls8.tune("nfa_fused", 0)                                    # (the knobs are read from the environment when a handle is created; afterwards: plf_line_tune)
-    res = ls8.extract_batch(np.stack([stripes] * 8))          # staged kernels: the pool overflows, the host-buffer call splits the batch
+    # large-batch schedule: rectangles of fewer than 512 pixels never enter the pooled buffers (k_nfa_small), so these frames fit
+    ls8.extract_batch_device(d_img, 640, 480, d_lines, d_desc, d_eq, d_n, 100)
+    assert ls8.last_status() == L.PLF_OK
+    for f in (0, 7):
+        got = np.frombuffer(d_lines.cpu().numpy().tobytes(), L.KL_DTYPE)[f * 100:f * 100 + int(d_n[f])]
+        assert got.tobytes() == ref["kl"].tobytes()
+    ls8.tune("nfa_small", 0)                                    # every rectangle through the staged kernels
+    res = ls8.extract_batch(np.stack([stripes] * 8))          # the pool overflows, the host-buffer call splits the batch
     for f in range(8):
         assert res[f][0].tobytes() == ref["kl"].tobytes() and np.array_equal(res[f][1], ref["desc"])
     assert ls8.last_status() == L.PLF_OK and not ls8.truncated(8).any()   # status and per-frame flags cover all the pieces of a batch that was redone in halves
