@@ -37,8 +37,11 @@ __global__ void k_nfa_init(const LsdRect *, const int *, uint8_t *, NfaEntry *, 
 __global__ void k_nfa_clamp(int *, int *, LsdGeom);
 __global__ void k_nfa_count(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_count1(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
+__global__ void k_nfa_count_w(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
+__global__ void k_nfa_count1_w(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_eval(int, const double *, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
 __global__ void k_nfa_table(double *, const double *, double);
+__global__ void k_nfa_fused_list(const float *, const double *, const NfaState *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_nfa_small(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_nfa_fused(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, LsdGeom);
@@ -80,7 +83,9 @@ struct LineTune {
     int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (8)
     int one_wave_groups;  // PLF_LSD_ONE_WAVE_GROUPS  one frame per workgroup for large batches too
     int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
-    int nfa_small;        // PLF_NFA_SMALL        1: large batches run rect_improve of rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle
+    int nfa_small;        // PLF_NFA_SMALL        1: large batches run rect_improve of rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle; 2: every batch; 0: off
+    int nfa_list;         // PLF_NFA_LIST         1: the rectangles k_nfa_small hands over take one wave each, all stages in one launch (k_nfa_fused_list: 3 NFA launches per
+                          //                      batch instead of 17, but 17 ms instead of 9.5 per 8192 VGA frames); 0: the staged kernels
     int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
 };
 static int tune_env_i(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -105,6 +110,7 @@ static void line_tune_init(LineTune *t)
     t->nfa_fused = tune_env_i("PLF_NFA_FUSED", 64);
     t->nfa_table = tune_env_i("PLF_NFA_TABLE", 1);
     t->nfa_small = tune_env_i("PLF_NFA_SMALL", 1);
+    t->nfa_list = tune_env_i("PLF_NFA_LIST", 0);
 }
 
 struct plf_line {
@@ -368,7 +374,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
     ALLOC(h->d_counters, (5 * B + 16) * sizeof(int));   // nrect[B], nseg[B], nout[B], status[16] + truncated[B], chain lengths[B]
     ALLOC(h->d_lgam, 65536 * sizeof(double));
-    ALLOC(h->d_nfa_tab, (size_t)11 * 512 * 512 * sizeof(double));   // NFA_TAB_P x NFA_TAB_N x NFA_TAB_N (lsd_kernels.hip)
+    ALLOC(h->d_nfa_tab, (size_t)NFA_TAB_P * (NFA_TAB_N * (NFA_TAB_N + 1) / 2) * sizeof(double));   // (lsd_geom.h)
     h->nfa_tab_log_nt = -1.0;
     ALLOC(h->d_lbd, sizeof(LbdCoefs));
     ALLOC(h->d_ent[0], NP * 5 * sizeof(NfaEntry)); ALLOC(h->d_ent[1], NP * 5 * sizeof(NfaEntry));
@@ -424,7 +430,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
     const int v = (int)value;
     struct { const char *n; int *p; } ints[] = {{"lat_max", &t.lat_max}, {"spec_bands", &t.spec_bands}, {"spec_max", &t.spec_max}, {"spec_z", &t.spec_z},
         {"spec_rounds", &t.spec_rounds}, {"spec_halo", &t.spec_halo}, {"spec_fill", &t.spec_fill}, {"spec_clip", &t.spec_clip}, {"spec_nofuse", &t.spec_nofuse},
-        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}};
+        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_list", &t.nfa_list}};
     for (auto &e : ints)
         if (!strcmp(name, e.n)) {
             if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
@@ -638,35 +644,43 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // kernels: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math) over work lists compacted over the batch
     const int nfa_fused_max = T.nfa_fused;
     if (T.nfa_table && h->nfa_tab_log_nt != g.log_nt) {   // (first batch of this image size)
-        hipLaunchKernelGGL(k_nfa_table, dim3(11 * 512 * 512 / 256), dim3(256), 0, s, h->d_nfa_tab, h->d_lgam, g.log_nt);
+        hipLaunchKernelGGL(k_nfa_table, dim3(NFA_TAB_N, NFA_TAB_P), dim3(256), 0, s, h->d_nfa_tab, h->d_lgam, g.log_nt);
         h->nfa_tab_log_nt = g.log_nt;
     }
-    if (B <= nfa_fused_max) {
+    const bool small_first = T.nfa_table && (T.nfa_small >= 2 || (T.nfa_small == 1 && B > nfa_fused_max));
+    if (!small_first && B <= nfa_fused_max) {
         hipLaunchKernelGGL(k_nfa_fused, dim3(1024, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_keep, h->d_seg, g);
     } else {
-    PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
-    if (T.nfa_table && T.nfa_small)   // rectangles of fewer than 512 pixels: all five stages by 16 lanes, values from the table; the others are queued for the staged kernels
-        hipLaunchKernelGGL(k_nfa_small, dim3(8 * (g.rect_cap < 640 ? (g.rect_cap + 3) / 4 : 160), (B + 7) / 8), dim3(64), 0, s, h->d_ang, h->d_nfa_tab, h->d_rects, nrect, h->d_keep,
-                           h->d_seg, h->d_ent[0], h->d_st[0], h->d_nfa_counters, status, g, B);
-    else
-    hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
-                       h->d_nfa_counters, status, g);
-    hipLaunchKernelGGL(k_nfa_clamp, dim3(1), dim3(1), 0, s, h->d_nfa_counters, status, g);
+        PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
+        if (small_first)   // rectangles of fewer than 512 pixels: all five stages by 16 lanes, values from the table; the others are queued in the stage-0 work list
+            hipLaunchKernelGGL(k_nfa_small, dim3(8 * (g.rect_cap < 640 ? (g.rect_cap + 3) / 4 : 160), (B + 7) / 8), dim3(64), 0, s, h->d_ang, h->d_nfa_tab, h->d_rects, nrect,
+                               h->d_keep, h->d_seg, h->d_ent[0], h->d_st[0], h->d_nfa_counters, status, g, B);
+        else
+            hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
+                               h->d_nfa_counters, status, g);
+        if (small_first && T.nfa_list) {
+            // the queued rectangles (a few per frame): one wave each, all stages (2 waves per SIMD by registers: 2048 persistent waves)
+            hipLaunchKernelGGL(k_nfa_fused_list, dim3(2048), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_st[0], h->d_nfa_counters, h->d_keep, h->d_seg, g);
+        } else {
+            hipLaunchKernelGGL(k_nfa_clamp, dim3(1), dim3(1), 0, s, h->d_nfa_counters, status, g);
 #ifndef PLF_NFA_COUNT_WAVES
 #define PLF_NFA_COUNT_WAVES (256 * 64)   // persistent waves of k_nfa_count: 16 per SIMD offered (occupancy by VGPRs: 8); the kernel is HBM-latency bound
 #endif
-    const int count_waves = PLF_NFA_COUNT_WAVES, math_blocks = 1024;
-    for (int stage = 0; stage <= 4; stage++) {
-        const int in = stage & 1, out = in ^ 1;
-        if (stage >= 1 && stage <= 3)
-            hipLaunchKernelGGL(k_nfa_count1, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 5, h->d_cnt, g);
-        else
-            hipLaunchKernelGGL(k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 1, h->d_cnt, g);
-        hipLaunchKernelGGL(k_nfa_eval, dim3(2 * math_blocks), dim3(256), 0, s, stage, h->d_lgam, T.nfa_table ? h->d_nfa_tab : nullptr, h->d_cnt, h->d_ent[in], h->d_nfa_counters,
-                           h->d_vals, g);
-        hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],
-                           h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
-    }
+            const int count_waves = PLF_NFA_COUNT_WAVES, math_blocks = 1024;
+            for (int stage = 0; stage <= 4; stage++) {
+                const int in = stage & 1, out = in ^ 1;
+                if (stage >= 1 && stage <= 3)
+                    hipLaunchKernelGGL(small_first ? k_nfa_count1_w : k_nfa_count1, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 5,
+                                       h->d_cnt, g);
+                else
+                    hipLaunchKernelGGL(small_first ? k_nfa_count_w : k_nfa_count, dim3(count_waves), dim3(64), 0, s, h->d_ang, h->d_ent[in], h->d_nfa_counters, stage, 1,
+                                       h->d_cnt, g);
+                hipLaunchKernelGGL(k_nfa_eval, dim3(2 * math_blocks), dim3(256), 0, s, stage, h->d_lgam, T.nfa_table ? h->d_nfa_tab : nullptr, h->d_cnt, h->d_ent[in],
+                                   h->d_nfa_counters, h->d_vals, g);
+                hipLaunchKernelGGL(k_nfa_math, dim3(math_blocks), dim3(64), 0, s, stage, h->d_vals, h->d_ent[in], h->d_st[in], h->d_st[out],
+                                   h->d_ent[out], h->d_nfa_counters, h->d_seg, h->d_keep, g);
+            }
+        }
     }
     hipLaunchKernelGGL(k_lsd_finalize, dim3(B), dim3(256), h->finalize_lds, s, h->d_seg, h->d_keep, nrect, h->d_segs_out, nseg, h->d_kl_tmp,
                        d_lines, d_eq, d_nout, capacity, status, h->d_sort_scratch, g);

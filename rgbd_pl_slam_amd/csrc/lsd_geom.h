@@ -67,3 +67,8 @@ struct SpecBufs {
     int *band_ticks;    // [frame][band][2]: run time of the band wave in 100 MHz ticks, accepted pixels it logged (diagnostics: how well the band shares are balanced)
 };
 
+// NFA table (k_nfa_table): rectangles of fewer than NFA_TAB_N pixels, p = 1/8 * 2^-j for j < NFA_TAB_P
+#ifndef NFA_TAB_N
+#define NFA_TAB_N 512
+#endif
+#define NFA_TAB_P 11

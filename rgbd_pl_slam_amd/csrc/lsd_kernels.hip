@@ -2459,6 +2459,13 @@ __device__ __forceinline__ double log_gamma_int(const double *__restrict__ tab, 
     return (i > 0 && i < LGAM_N) ? tab[i] : log_gamma_d((double)i);
 }
 
+// The rest of the binomial tail cannot change the result any more: the ratio term(i+1) / term(i) = mult_term falls with i, so once it is below 1 every later term is
+// smaller than this one, and a term below bin_tail * 2^-54 is less than half an ulp of bin_tail -- every remaining `bin_tail += term` returns bin_tail unchanged
+// (round to nearest), and whichever way the loop ends it returns -log10(bin_tail) - LOG_NT of this very bin_tail.  (A rectangle of a few thousand pixels with more
+// aligned pixels than n p -- any real edge -- spends nearly all of upstream's n / 2 - k iterations adding such terms.  If bin_tail * 2^-54 underflows the test
+// never fires and the loop runs as upstream's.)
+#define NFA_DEAD_TAIL(mult, term, bin_tail) ((mult) < 1.0 && (term) < (bin_tail) * 0x1p-54)
+
 __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, int k, double p)
 {
     if (n == 0 || k == 0) return -LOG_NT;
@@ -2485,6 +2492,7 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
 #pragma unroll
         for (int q = 0; q < 8; q++) { term *= m[q]; bin_tail += term; }
         i += 8;
+        if (NFA_DEAD_TAIL(m[7], term, bin_tail)) return -log10(bin_tail) - LOG_NT;
     }
     while (i + 3 <= n && n - (i + 3) + 1 >= i + 3) {
         const double b0 = (double)(n - i + 1) / (double)i, b1 = (double)(n - i) / (double)(i + 1), b2 = (double)(n - i - 1) / (double)(i + 2),
@@ -2495,6 +2503,7 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
         term *= m2; bin_tail += term;
         term *= m3; bin_tail += term;
         i += 4;
+        if (NFA_DEAD_TAIL(m3, term, bin_tail)) return -log10(bin_tail) - LOG_NT;
     }
     for (; i <= n; ++i) {
         const double bin_term = (double)(n - i + 1) / (double)i;
@@ -2513,17 +2522,13 @@ __device__ double nfa_d(const double *__restrict__ lgam, double LOG_NT, int n, i
 // always with a pixel count n of a few dozen to a few hundred and always with p = 1/8 * 2^-j, j = 0..10 (region2rect's p, halved by the two precision stages).  The
 // table holds nfa_d's own result for every n < NFA_TAB_N, k <= n and those eleven p -- filled by k_nfa_table with the very same device function (the lgamma table's
 // argument: a lookup is bit-identical to evaluating in place), once per scaled-image size (LOG_NT enters the loop's exit test, so the values depend on it).
-#define NFA_TAB_N 512
-#define NFA_TAB_P 11
+#define NFA_TAB_ROW (NFA_TAB_N * (NFA_TAB_N + 1) / 2)   // (n, k <= n) -> n (n + 1) / 2 + k
 __global__ void __launch_bounds__(256) k_nfa_table(double *__restrict__ tab, const double *__restrict__ lgam, double log_nt)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= NFA_TAB_P * NFA_TAB_N * NFA_TAB_N) return;
-    const int j = idx / (NFA_TAB_N * NFA_TAB_N), n = (idx / NFA_TAB_N) % NFA_TAB_N, k = idx % NFA_TAB_N;
-    if (k > n) return;
+    const int n = blockIdx.x, j = blockIdx.y;
     double p = 0.125;
     for (int q = 0; q < j; q++) p /= 2;
-    tab[idx] = nfa_d(lgam, log_nt, n, k, p);
+    for (int k = threadIdx.x; k <= n; k += 256) tab[(size_t)j * NFA_TAB_ROW + n * (n + 1) / 2 + k] = nfa_d(lgam, log_nt, n, k, p);
 }
 
 // true (and v) if (n, k, p) is tabulated
@@ -2532,7 +2537,7 @@ __device__ __forceinline__ bool nfa_lookup(const double *__restrict__ tab, int n
     const long long bits = __double_as_longlong(p);
     const int j = 1023 - 3 - (int)(bits >> 52);   // p = 2^-(3 + j) exactly <=> mantissa 0, sign 0
     if ((bits & 0xFFFFFFFFFFFFFll) != 0 || j < 0 || j >= NFA_TAB_P || n < 0 || n >= NFA_TAB_N || k < 0 || k > n) return false;
-    v = tab[(j * NFA_TAB_N + n) * NFA_TAB_N + k];
+    v = tab[(size_t)j * NFA_TAB_ROW + n * (n + 1) / 2 + k];
     return true;
 }
 
@@ -2842,6 +2847,34 @@ __global__ void __launch_bounds__(64) k_nfa_count1(const float *__restrict__ ang
                                                    const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
 {
     nfa_count_body<1>(ang_all, entries, counters, cidx, mult, counts, g);
+}
+
+// the same with a whole wave per rectangle: what is left for the staged kernels after k_nfa_small are the rectangles of 512 pixels and more (16 lanes would walk
+// 32+ pixels each, one dependent gather after the other)
+template <int NP>
+__device__ __forceinline__ void nfa_count_wave_body(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
+                                                    int cidx, int mult, NfaCounts *__restrict__ counts, const LsdGeom &g)
+{
+    const int n = counters[cidx] * mult;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const NfaEntry en = entries[e];
+        if (en.nprec == 0) continue;
+        NfaCounts c;
+        if (en.nprec == NP) rect_count<NP, 64>(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, c);
+        else if (NP == 1) rect_count<6, 64>(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, c);
+        else rect_count<1, 64>(ang_all + (size_t)en.frame * g.s_stride, g.sw, g.sh, en.r, c);
+        if (threadIdx.x == 0) counts[e] = c;
+    }
+}
+__global__ void __launch_bounds__(64) k_nfa_count_w(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
+                                                    const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
+{
+    nfa_count_wave_body<6>(ang_all, entries, counters, cidx, mult, counts, g);
+}
+__global__ void __launch_bounds__(64) k_nfa_count1_w(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
+                                                     const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
+{
+    nfa_count_wave_body<1>(ang_all, entries, counters, cidx, mult, counts, g);
 }
 
 __device__ __forceinline__ void nfa_finish(const NfaState &st, float4 *__restrict__ seg_all, uint8_t *__restrict__ keep_all, const LsdGeom &g)
@@ -3202,18 +3235,13 @@ __device__ __forceinline__ double nfa_tail(const NfaIt &it, double LOG_NT)
 // (v_cndmask_b32_e32 back to back: 17-40 cycles each, profiles/r03_valu_issue.json) instead of a branch over 24 moves
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
-__global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const LsdRect *__restrict__ rects_all,
-                                                  const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
+// (st: the rectangle as found, log_nfa -1; keep_all of its slot is already 0)
+__device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, const double *__restrict__ lgam, LDS_PTR(double) tab, NfaState &st,
+                                               uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, const LsdGeom &g)
 {
-    __shared__ double tab_s[6 * NFA_COOP_BLK];
-    LDS_PTR(double) tab = (LDS_PTR(double))tab_s;
-    const int f = blockIdx.y, lane = threadIdx.x, n_r = nrect[f];
-    const float *ang = ang_all + (size_t)f * g.s_stride;
+    const int lane = threadIdx.x;
     const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
-    for (int ri = blockIdx.x; ri < n_r; ri += gridDim.x) {
-        NfaState st;
-        st.rec = rects_all[(size_t)f * g.rect_cap + ri]; st.log_nfa = -1; st.frame = f; st.rect = ri;
-        if (lane == 0) keep_all[(size_t)f * g.rect_cap + ri] = 0;
+    {
         bool done = false;
         // ---- stage 0: the rectangle as found, at its precision and the five halved ones
         {
@@ -3304,5 +3332,33 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
             if (uni(st.log_nfa > LOG_EPS)) done = true;
         }
         if (done && lane == 0) nfa_finish(st, seg_all, keep_all, g);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const LsdRect *__restrict__ rects_all,
+                                                  const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
+{
+    __shared__ double tab_s[6 * NFA_COOP_BLK];
+    LDS_PTR(double) tab = (LDS_PTR(double))tab_s;
+    const int f = blockIdx.y, lane = threadIdx.x, n_r = nrect[f];
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    for (int ri = blockIdx.x; ri < n_r; ri += gridDim.x) {
+        NfaState st;
+        st.rec = rects_all[(size_t)f * g.rect_cap + ri]; st.log_nfa = -1; st.frame = f; st.rect = ri;
+        if (lane == 0) keep_all[(size_t)f * g.rect_cap + ri] = 0;
+        nfa_fused_rect(ang, lgam, tab, st, keep_all, seg_all, g);
+    }
+}
+
+// the same for the rectangles k_nfa_small handed over (the stage-0 work list; the few per frame that have 512 pixels or more): persistent waves over the list
+__global__ void __launch_bounds__(64) k_nfa_fused_list(const float *__restrict__ ang_all, const double *__restrict__ lgam, const NfaState *__restrict__ states,
+                                                       const int *__restrict__ counters, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
+{
+    __shared__ double tab_s[6 * NFA_COOP_BLK];
+    LDS_PTR(double) tab = (LDS_PTR(double))tab_s;
+    const int n = min(counters[0], g.nfa_pool);   // (a fuller list: k_nfa_small has set the status bit)
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        NfaState st = states[q];
+        nfa_fused_rect(ang_all + (size_t)st.frame * g.s_stride, lgam, tab, st, keep_all, seg_all, g);
     }
 }
