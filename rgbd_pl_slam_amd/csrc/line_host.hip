@@ -44,7 +44,7 @@ __global__ void k_nfa_table(double *, const double *, double);
 __global__ void k_nfa_fused_list(const float *, const double *, const NfaState *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_nfa_small(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
-__global__ void k_nfa_fused(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, LsdGeom);
+__global__ void k_nfa_fused(const float *, const double *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
                                int, int *, unsigned long long *, LsdGeom);
 __global__ void k_sobel3(const uint8_t *, ptrdiff_t, ptrdiff_t, short2 *, LsdGeom);
@@ -83,7 +83,8 @@ struct LineTune {
     int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (8)
     int one_wave_groups;  // PLF_LSD_ONE_WAVE_GROUPS  one frame per workgroup for large batches too
     int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
-    int nfa_small;        // PLF_NFA_SMALL        1: large batches run rect_improve of rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle; 2: every batch; 0: off
+    int nfa_small;        // PLF_NFA_SMALL        2: rect_improve of the rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle; 1: only for more
+                          //                      than nfa_fused frames in flight (one frame: 4.41 ms with it, 4.63 ms with k_nfa_fused); 0: off
     int nfa_list;         // PLF_NFA_LIST         1: the rectangles k_nfa_small hands over take one wave each, all stages in one launch (k_nfa_fused_list: 3 NFA launches per
                           //                      batch instead of 17, but 17 ms instead of 9.5 per 8192 VGA frames); 0: the staged kernels
     int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
@@ -109,7 +110,7 @@ static void line_tune_init(LineTune *t)
     t->one_wave_groups = getenv("PLF_LSD_ONE_WAVE_GROUPS") ? 1 : 0;
     t->nfa_fused = tune_env_i("PLF_NFA_FUSED", 64);
     t->nfa_table = tune_env_i("PLF_NFA_TABLE", 1);
-    t->nfa_small = tune_env_i("PLF_NFA_SMALL", 1);
+    t->nfa_small = tune_env_i("PLF_NFA_SMALL", 2);
     t->nfa_list = tune_env_i("PLF_NFA_LIST", 0);
 }
 
@@ -649,7 +650,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     }
     const bool small_first = T.nfa_table && (T.nfa_small >= 2 || (T.nfa_small == 1 && B > nfa_fused_max));
     if (!small_first && B <= nfa_fused_max) {
-        hipLaunchKernelGGL(k_nfa_fused, dim3(1024, B), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_rects, nrect, h->d_keep, h->d_seg, g);
+        hipLaunchKernelGGL(k_nfa_fused, dim3(1024, B), dim3(64), 0, s, h->d_ang, h->d_lgam, T.nfa_table ? h->d_nfa_tab : nullptr, h->d_rects, nrect, h->d_keep, h->d_seg, g);
     } else {
         PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
         if (small_first)   // rectangles of fewer than 512 pixels: all five stages by 16 lanes, values from the table; the others are queued in the stage-0 work list

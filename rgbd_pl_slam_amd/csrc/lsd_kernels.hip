@@ -3170,15 +3170,17 @@ __device__ __forceinline__ NfaIt nfa_head(const double *__restrict__ lgam, doubl
 }
 
 // all 64 lanes; `it` of a lane that runs no chain has live == false.  tab: NFA_COOP_BLK doubles per chain lane (lanes 0..5)
-__device__ __forceinline__ void nfa_coop(NfaIt &it, LDS_PTR(double) tab)
+__device__ __forceinline__ void nfa_coop(NfaIt &it, LDS_PTR(double) tab, double LOG_NT)
 {
     const int lane = plf_lane();
     int done_j = 0;                                                   // iterations of the exit-free part already taken (the same for every chain: lock step)
-    const int len = it.live ? it.iend - it.i : 0;
-    int maxlen = len;
+    int len = it.live ? it.iend - it.i : 0;
+    for (;;) {
+        int maxlen = len;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-    while (done_j < maxlen) {
+        for (int o = 4; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));   // (chains live in lanes 0..5)
+        maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+        if (done_j >= maxlen) break;
         // divisions of the next block of every chain
         for (int c = 0; c < 6; c++) {
             const int len_c = __builtin_amdgcn_readlane(len, c);
@@ -3194,7 +3196,7 @@ __device__ __forceinline__ void nfa_coop(NfaIt &it, LDS_PTR(double) tab)
         if (lane < 6 && len > done_j) {
             const int cnt = min(NFA_COOP_BLK, len - done_j);
             LDS_PTR(double) tb = tab + lane * NFA_COOP_BLK;
-            double term = it.term, bin_tail = it.bin_tail;
+            double term = it.term, bin_tail = it.bin_tail, lastm = 2.0;
             const double p_term = it.p_term;
             int j = 0;
             for (; j + 4 <= cnt; j += 4) {
@@ -3203,9 +3205,13 @@ __device__ __forceinline__ void nfa_coop(NfaIt &it, LDS_PTR(double) tab)
                 term *= m1; bin_tail += term;
                 term *= m2; bin_tail += term;
                 term *= m3; bin_tail += term;
+                lastm = m3;
             }
-            for (; j < cnt; j++) { const double m0 = tb[j] * p_term; term *= m0; bin_tail += term; }
+            for (; j < cnt; j++) { const double m0 = tb[j] * p_term; term *= m0; bin_tail += term; lastm = m0; }
             it.term = term; it.bin_tail = bin_tail;
+            if (NFA_DEAD_TAIL(lastm, term, bin_tail)) {   // (nfa_d's early exit, checked once per block)
+                it.live = false; it.val = -log10(bin_tail) - LOG_NT; len = 0;
+            }
         }
         CBAR();
         done_j += NFA_COOP_BLK;
@@ -3236,7 +3242,18 @@ __device__ __forceinline__ double nfa_tail(const NfaIt &it, double LOG_NT)
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
 // (st: the rectangle as found, log_nfa -1; keep_all of its slot is already 0)
-__device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, const double *__restrict__ lgam, LDS_PTR(double) tab, NfaState &st,
+__device__ __forceinline__ NfaIt nfa_head_tab(const double *__restrict__ lgam, const double *__restrict__ nfatab, double LOG_NT, int n, int k, double p)
+{
+    double v;
+    if (nfatab && nfa_lookup(nfatab, n, k, p, v)) {   // (k_nfa_table's value: bit-identical to evaluating here)
+        NfaIt it;
+        it.live = false; it.term = it.bin_tail = it.p_term = 0.0; it.i = it.iend = 0; it.n = n; it.val = v;
+        return it;
+    }
+    return nfa_head(lgam, LOG_NT, n, k, p);
+}
+
+__device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, const double *__restrict__ lgam, const double *__restrict__ nfatab, LDS_PTR(double) tab, NfaState &st,
                                                uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, const LsdGeom &g)
 {
     const int lane = threadIdx.x;
@@ -3253,9 +3270,9 @@ __device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, co
                 if (lane < 6) {
                     double pp = st.rec.p;
                     for (int j = 0; j < lane; j++) pp /= 2;
-                    it = nfa_head(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+                    it = nfa_head_tab(lgam, nfatab, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
                 }
-                nfa_coop(it, tab);
+                nfa_coop(it, tab, g.log_nt);
                 if (lane < 6) v = nfa_tail(it, g.log_nt);
             }
             st.log_nfa = nfa_bcast(v, 0);
@@ -3291,8 +3308,8 @@ __device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, co
             double v = -1.0e300;
             {
                 NfaIt it; it.live = false; it.n = 0; it.i = it.iend = 0; it.val = v;
-                if (lane < non) it = nfa_head(lgam, g.log_nt, tot, al, st.rec.p);
-                nfa_coop(it, tab);
+                if (lane < non) it = nfa_head_tab(lgam, nfatab, g.log_nt, tot, al, st.rec.p);
+                nfa_coop(it, tab, g.log_nt);
                 if (lane < non) v = nfa_tail(it, g.log_nt);
             }
             {
@@ -3317,9 +3334,9 @@ __device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, co
                 if (lane >= 1 && lane < 6) {
                     double pp = st.rec.p;
                     for (int j = 0; j < lane; j++) pp /= 2;
-                    it = nfa_head(lgam, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
+                    it = nfa_head_tab(lgam, nfatab, g.log_nt, c.total, c.alg[lane < 6 ? lane : 0], pp);
                 }
-                nfa_coop(it, tab);
+                nfa_coop(it, tab, g.log_nt);
                 if (lane >= 1 && lane < 6) v = nfa_tail(it, g.log_nt);
             }
             LsdRect r = st.rec;
@@ -3335,7 +3352,7 @@ __device__ __forceinline__ void nfa_fused_rect(const float *__restrict__ ang, co
     }
 }
 
-__global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const LsdRect *__restrict__ rects_all,
+__global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_all, const double *__restrict__ lgam, const double *__restrict__ nfatab, const LsdRect *__restrict__ rects_all,
                                                   const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
 {
     __shared__ double tab_s[6 * NFA_COOP_BLK];
@@ -3346,7 +3363,7 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
         NfaState st;
         st.rec = rects_all[(size_t)f * g.rect_cap + ri]; st.log_nfa = -1; st.frame = f; st.rect = ri;
         if (lane == 0) keep_all[(size_t)f * g.rect_cap + ri] = 0;
-        nfa_fused_rect(ang, lgam, tab, st, keep_all, seg_all, g);
+        nfa_fused_rect(ang, lgam, nfatab, tab, st, keep_all, seg_all, g);
     }
 }
 
@@ -3359,6 +3376,6 @@ __global__ void __launch_bounds__(64) k_nfa_fused_list(const float *__restrict__
     const int n = min(counters[0], g.nfa_pool);   // (a fuller list: k_nfa_small has set the status bit)
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         NfaState st = states[q];
-        nfa_fused_rect(ang_all + (size_t)st.frame * g.s_stride, lgam, tab, st, keep_all, seg_all, g);
+        nfa_fused_rect(ang_all + (size_t)st.frame * g.s_stride, lgam, nullptr, tab, st, keep_all, seg_all, g);
     }
 }
