@@ -485,21 +485,22 @@ def main():
         except Exception:
             traffic = None
         achieved = (b_region * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
-        # share of the step the SIMDs spend ISSUING vector instructions: counted instructions (rocprofv3 --pmc SQ_INSTS_VALU of this command, committed) over
-        # the measured issue rates of the chip (tools/valu_issue.hip) -- a range, because plain 32-bit / fp32 instructions issue every ~2.2 cycles per SIMD and
-        # everything else (packed integer, v_perm, dot4, fp64, SGPR operands: what these kernels are made of) every ~4.2
-        valu_range, valu_source = None, None
+        # share of the step during which an average SIMD's vector issue port is taken: counted VALU instructions per kernel (rocprofv3 --pmc SQ_INSTS_VALU of this
+        # command, committed) x the issue interval of their class (2.2 / 4.2 / 8 / 16 cycles per SIMD, measured by tools/valu_issue.hip; mix per kernel from its ISA:
+        # tools/classify_isa.py) over 1024 SIMDs x clock x the step time measured here
+        valu_frac, valu_source = None, None
         try:
-            vsrc = "r04_valu_counts.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_valu_counts.json")) else "r03_valu_counts.json"
-            with open(os.path.join(ROOT, "profiles", vsrc)) as fh:
+            with open(os.path.join(ROOT, "profiles", "r04_valu_classes.json")) as fh:
                 vc = json.load(fh)
             if args.config == 2:
-                insts = vc["valu_wave_instructions_per_step"] * B / vc["frames_per_step"]
+                cyc = vc["valu_issue_simd_cycles_per_step"] * B / vc["frames_per_step"]
                 step_s = elapsed / args.steps
-                valu_range = [round(insts / vc["rate_full_wave_instr_per_s"] / step_s, 3), round(insts / vc["rate_half_wave_instr_per_s"] / step_s, 3)]
-                valu_source = "profiles/%s (SQ_INSTS_VALU per step) / profiles/r03_valu_issue.json (1.12 and 0.585 T wave-instructions/s)" % vsrc
+                valu_frac = round(cyc / (vc["simds"] * vc["clock_hz"] * step_s), 3)
+                valu_source = ("profiles/r04_valu_classes.json: %.3g VALU wave-instructions per %d-frame step (SQ_INSTS_VALU), mean %.2f issue cycles each by class "
+                               "(tools/classify_isa.py; intervals from profiles/r03_valu_issue.json)" % (vc["valu_wave_instructions_per_step"], vc["frames_per_step"],
+                                                                                                        vc["mean_cycles_per_valu"]))
         except Exception:
-            valu_range = None
+            valu_frac = None
         out = {
             "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d" % (W, H),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -513,7 +514,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "LSD region growing (k_lsd_regions2 / k_lsd_spec_* for few frames in flight)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches, "algorithmic_bytes_per_launch": b_region * B,
-                         "valu_issue_frac_range": valu_range, "valu_issue_source": valu_source},
+                         "valu_issue_frac": valu_frac, "valu_issue_source": valu_source},
         }
         out["region_chain_length"] = pipe.chain_stats()
         if world == 1 and args.config == 2 and not args.no_extras and not args.serial and pipe.ndist > 32:
