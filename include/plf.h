@@ -174,6 +174,11 @@ int plf_line_truncated(plf_line *h, int32_t *flags, int32_t n);
  * kilo-cycles spent regrowing, validating, in total, in per-band setup}.  PLF_E_BADARG if the path has not run on this handle. */
 int plf_line_debug_spec_stats(plf_line *h, int32_t *out8);
 
+/* Diagnostics (tools/spec_redo.py) of the validation-round schedule (few frames in flight), per frame f < n_frames of the last batch: out[4 f + 0 / 1] = bands whose
+ * marks changed in the last even / odd round, out[4 f + 2] = the round that found nothing left to change (0: none within the enqueued rounds), out[4 f + 3] = 1 if
+ * the frame was finished by the serial commit wave (log overflow or no fixpoint): the schedule's redo.  PLF_E_BADARG if that schedule has not run on this handle. */
+int plf_line_debug_spec_rounds(plf_line *h, int32_t *out, int32_t n_frames);
+
 /* Diagnostics (tools/nfa_stats.py): out16[s] = rectangles of the last batch that entered rect_improve stage s (0..4; [5] = left over after stage 4), for batches
  * that took the staged NFA kernels (more than 64 frames in flight).  Synchronises the device. */
 int plf_line_debug_nfa_counters(plf_line *h, int32_t *out16);

@@ -907,6 +907,16 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
     return PLF_OK;
 }
 
+// diagnostics (tools/spec_redo.py): per frame of the last batch that took the validation-round schedule, out[4 f ..] = {bands changed in the last even round, in the
+// last odd round, round that found nothing left to change (0: none within the enqueued rounds), 1 if the frame was finished by the serial commit wave instead}
+extern "C" int plf_line_debug_spec_rounds(plf_line *h, int32_t *out, int32_t n_frames)
+{
+    if (!h || !out || n_frames < 1 || n_frames > h->prm.max_batch || !h->spec.round_state) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    PLF_HIP_TRY(hipMemcpy(out, h->spec.round_state, (size_t)n_frames * 4 * sizeof(int), hipMemcpyDeviceToHost));
+    return PLF_OK;
+}
+
 // diagnostics (tools/nfa_stats.py): rectangles that entered each rect_improve stage of the last staged batch (out16[0..5]; [5] = not meaningful after the last stage)
 extern "C" int plf_line_debug_nfa_counters(plf_line *h, int32_t *out16)
 {

@@ -2370,7 +2370,7 @@ __global__ void k_lsd_spec_round_begin(SpecBufs SB, int B, int round)
     if (f >= B) return;
     int *rs = SB.round_state + f * 4;
     if (rs[3] || rs[2]) return;
-    if (round > 1 && rs[(round - 1) & 1] == 0) { rs[2] = 1; return; }
+    if (round > 1 && rs[(round - 1) & 1] == 0) { rs[2] = round - 1; return; }   // (non-zero = converged; the value is the round that found nothing to change: diagnostics)
     rs[round & 1] = 0;
 }
 

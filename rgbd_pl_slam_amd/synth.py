@@ -146,6 +146,29 @@ def texture_frame(seed, kind=None, size=None):
     return np.ascontiguousarray(img), kind
 
 
+def natural_frame(seed, w=640, h=480):
+    """Natural-image-like frame (every schedule threshold had only ever seen hard-edged polygons): a 1/f^b amplitude spectrum (b drawn in 0.9..1.4,
+    random phases) for texture at every scale, a polygon scene blurred by a lens-like Gaussian (sigma 0.8..2.2 px: soft edges, gradients spread over several
+    pixels), slow illumination falloff, and sensor noise (signal-dependent shot noise + read noise) before 8-bit quantisation."""
+    rng = np.random.default_rng(91000 + seed)
+    fy = np.fft.fftfreq(h)[:, None]; fx = np.fft.rfftfreq(w)[None, :]
+    rad = np.sqrt(fx * fx + fy * fy); rad[0, 0] = 1.0
+    amp = rad ** (-rng.uniform(0.9, 1.4)); amp[0, 0] = 0.0
+    tex = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(h, w))
+    tex = (tex - tex.mean()) / (tex.std() + 1e-12)
+    scene = synth_frame(7000 + seed, w, h).astype(np.float64)
+    sig = rng.uniform(0.8, 2.2); r = int(np.ceil(3 * sig)); k = np.exp(-0.5 * (np.arange(-r, r + 1) / sig) ** 2); k /= k.sum()
+    pad = np.pad(scene, r, mode="reflect")
+    pad = np.apply_along_axis(lambda v: np.convolve(v, k, mode="valid"), 1, pad)
+    scene = np.apply_along_axis(lambda v: np.convolve(v, k, mode="valid"), 0, pad)
+    yy, xx = np.mgrid[0:h, 0:w]
+    fall = 1.0 - rng.uniform(0.05, 0.35) * (((xx - w * rng.uniform(0.3, 0.7)) / w) ** 2 + ((yy - h * rng.uniform(0.3, 0.7)) / h) ** 2)
+    img = (rng.uniform(0.45, 0.8) * scene + rng.uniform(14, 34) * tex + rng.uniform(5, 40)) * fall
+    img = np.clip(img, 0, 255)
+    img = img + rng.normal(0, 1, img.shape) * np.sqrt(rng.uniform(0.02, 0.12) * img + rng.uniform(0.5, 4.0))   # shot + read noise
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+
+
 if __name__ == "__main__":      # worker of synth_batch_parallel: seed0 n w h out.npy
     import sys
     _s0, _n, _w, _h = (int(x) for x in sys.argv[1:5])

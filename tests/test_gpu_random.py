@@ -235,3 +235,34 @@ def test_texture_families_single_and_batched():
         _eq_orb(ro[k][0], ro[k][1], refs_o[k])
         assert rl[k][0].tobytes() == refs_l[k]["kl"].tobytes() and np.array_equal(rl[k][1], refs_l[k]["desc"]), k
     ext.close(); ls.close()
+
+
+def test_natural_image_family_single_few_and_many():
+    """Natural-image-like frames (synth.natural_frame: 1/f spectrum, lens-blurred edges, illumination falloff, shot + read noise -- what every schedule
+    threshold had never seen): ORB and LSD+LBD of one frame, of 8 frames in flight (speculative banded schedule) and of a 96-frame batch (the
+    one-wave-per-frame schedule), two image sizes, byte for byte against the oracle."""
+    _need_gpu()
+    from concurrent.futures import ThreadPoolExecutor
+    from rgbd_pl_slam_amd import ORBextractor, LineSegment
+    from rgbd_pl_slam_amd.synth import natural_frame
+    pool = ThreadPoolExecutor(16)
+    for (w, h, n) in ((640, 480, 12), (800, 600, 4)):
+        imgs = list(pool.map(lambda s: natural_frame(40 + s, w, h), range(n)))
+        refs_o = list(pool.map(lambda im: orc.orb_extract(im), imgs))
+        refs_l = list(pool.map(lambda im: orc.line_extract(im, 100), imgs))
+        assert min(len(r["kl"]) for r in refs_l) > 10 and min(len(r["kps"]) for r in refs_o) > 500
+        ext = ORBextractor(nfeatures=1000, max_width=w, max_height=h, max_batch=96)
+        ls = LineSegment(nlines=100, max_width=w, max_height=h, max_batch=96)
+        for k in range(min(n, 3)):
+            kps, desc = ext(imgs[k])
+            _eq_orb(kps, desc, refs_o[k])
+            kl, ld, eq = ls.ExtractLineSegment(imgs[k])
+            assert kl.tobytes() == refs_l[k]["kl"].tobytes() and np.array_equal(ld, refs_l[k]["desc"]), (w, k)
+        for B in (min(n, 8), 96):
+            idx = [i % n for i in range(B)]
+            stack = np.stack([imgs[i] for i in idx])
+            ro = ext.extract_batch(stack); rl = ls.extract_batch(stack)
+            for f, i in enumerate(idx):
+                _eq_orb(ro[f][0], ro[f][1], refs_o[i])
+                assert rl[f][0].tobytes() == refs_l[i]["kl"].tobytes() and np.array_equal(rl[f][1], refs_l[i]["desc"]), (w, B, f)
+        ext.close(); ls.close()
