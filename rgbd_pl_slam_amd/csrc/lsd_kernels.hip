@@ -506,6 +506,12 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         // ---- process the current group
         CNT(8, cur_n);
         TIC(tacc);
+        // The accepted lanes of the group are collected as a mask and their USED flags and list entries written ONCE, behind the loop (they are accepted in
+        // ascending lane order, so a lane's list position is the count before the group + its rank in the mask): a one-lane EXEC region with two stores per
+        // accept -- 15 instructions of the 125 an accept costs -- became one scalar OR.  Nothing reads them earlier: the next group was fetched before this loop
+        // (its lanes are struck out by address), the one after is fetched at the top of the next trip.
+        unsigned long long accm = 0ull;
+        const int n0 = n;
         for (;;) {
             // classification of the remaining candidates against the current sums (one exit test per trip: no candidate left implies mAB == 0)
             const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
@@ -539,10 +545,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
                 if (!__ballot(al)) { candm &= ~(1ull << k); continue; }   // not aligned: the sums did not change
             }
             CNT(9, 1);
-            if (lane == k) {
-                used_set(C, cur.a, cur.w);
-                rxy_put(C, n, cur.xy);
-            }
+            accm |= 1ull << k;
             const double cc = readlane_d(cur.csx, k), ss = readlane_d(cur.csy, k);
             const int ka = __builtin_amdgcn_readlane(cur.a, k);
             // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
@@ -552,6 +555,12 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             ++n;
             candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.a == ka);   // lanes up to k are decided; the pixel is taken
             nx_stale |= __ballot(nx.a == ka);
+        }
+        if (accm) {
+            if (__builtin_amdgcn_inverse_ballot_w64(accm)) {
+                used_set(C, cur.a, cur.w);
+                rxy_put(C, n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(accm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)accm, 0u)), cur.xy);
+            }
         }
         CBAR();
         TOC(19, tacc); TOCB(21, tacc);
