@@ -462,7 +462,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
 {
     const int lane = plf_lane();
     double reg_angle = (double)deg0 * DEG2RAD_D;
-    bool theta_valid = true;              // reg_angle is the value the reference holds for the current sums
+    int n_theta = 1;                      // reg_angle is the value the reference holds for the sums of the first n_theta pixels (scalar; only the rare border path and the end touch it)
     float sumdx = cs0.x, sumdy = cs0.y;   // float(cos(reg_angle)), float(sin(reg_angle))
     const uint32_t sxy = (uint32_t)sx | ((uint32_t)sy << 16);
     if (lane == 0) {
@@ -512,37 +512,41 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         // (its lanes are struck out by address), the one after is fetched at the top of the next trip.
         unsigned long long accm = 0ull;
         const int n0 = n;
-        for (;;) {
-            // classification of the remaining candidates against the current sums (one exit test per trip: no candidate left implies mAB == 0)
-            const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);
-            const unsigned long long mA = candm & __ballot(acr <= th.t1 * dot);
-            const unsigned long long mB = candm & ~mA & ~__ballot(acr >= th.t2 * dot);
-            // the first remaining candidate that is not surely misaligned; border lanes are rare (the cone pre-test decides ~99.8 % of the candidates), so the
-            // loop is flat: one rarely taken branch for the reference's own test instead of an inner loop over the masks.  A candidate the exact test rejects
-            // is decided for good -- it precedes every lane that can still be accepted, and a later accept drops the lanes before it anyway.
-            const unsigned long long mAB = mA | mB;
-            if (!mAB) break;
+        // classification of the remaining candidates against the current sums: mA surely aligned, mB border.  The first remaining candidate that is not surely
+        // misaligned is next; border lanes are rare (the cone pre-test decides ~99.8 % of the candidates), so the loop is flat: one rarely taken branch for the
+        // reference's own test instead of an inner loop over the masks.  A candidate the exact test rejects is decided for good -- it precedes every lane that
+        // can still be accepted, and a later accept drops the lanes before it anyway.  (Rotated loop: one scalar exit test per trip, at the bottom.)
+        unsigned long long mB, mAB;
+#define PLF_GROW_CLASSIFY()                                                                                   \
+        {                                                                                                     \
+            const float dot = sumdx * ux + sumdy * uy, acr = fabsf(sumdx * uy - sumdy * ux);                  \
+            const unsigned long long mA = candm & __ballot(acr <= th.t1 * dot);                               \
+            mB = candm & ~mA & ~__ballot(acr >= th.t2 * dot);                                                 \
+            mAB = mA | mB;                                                                                    \
+        }
+        PLF_GROW_CLASSIFY()
+        if (mAB) do {
             const int k = __ffsll((long long)mAB) - 1;
             if ((mB >> k) & 1ull) {
-                if (!theta_valid) {
+                if (n_theta != n) {
                     // (the empty asm pins the fastAtan2 -- two IEEE divisions -- inside this rarely taken branch; the
                     // compiler would otherwise evaluate it speculatively on every accept step)
                     float fx = sumdx, fy = sumdy;
                     asm volatile("" : "+v"(fx), "+v"(fy));
                     reg_angle = (double)plf_fast_atan2(fy, fx) * DEG2RAD_D;
-                    theta_valid = true;
+                    n_theta = n;
                 }
                 bool al = false;
                 if (lane == k) {
-                    double n_theta = reg_angle - (double)__uint_as_float(cur.w) * DEG2RAD_D;
-                    if (n_theta < 0) n_theta = -n_theta;
-                    if (n_theta > M_3_2_PI_D) {
-                        n_theta -= M_2__PI_D;
-                        if (n_theta < 0) n_theta = -n_theta;
+                    double n_th = reg_angle - (double)__uint_as_float(cur.w) * DEG2RAD_D;
+                    if (n_th < 0) n_th = -n_th;
+                    if (n_th > M_3_2_PI_D) {
+                        n_th -= M_2__PI_D;
+                        if (n_th < 0) n_th = -n_th;
                     }
-                    al = n_theta <= prec;
+                    al = n_th <= prec;
                 }
-                if (!__ballot(al)) { candm &= ~(1ull << k); continue; }   // not aligned: the sums did not change
+                if (!__ballot(al)) { candm &= ~(1ull << k); PLF_GROW_CLASSIFY() continue; }   // not aligned: the sums did not change
             }
             CNT(9, 1);
             accm |= 1ull << k;
@@ -551,11 +555,12 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             // `sumdx += cos(float(angle))`: ::cos(double) of the float-rounded angle, float accumulator
             sumdx = (float)((double)sumdx + cc);
             sumdy = (float)((double)sumdy + ss);
-            theta_valid = false;
             ++n;
             candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.a == ka);   // lanes up to k are decided; the pixel is taken
             nx_stale |= __ballot(nx.a == ka);
-        }
+            PLF_GROW_CLASSIFY()
+        } while (mAB);
+#undef PLF_GROW_CLASSIFY
         if (accm) {
             if (__builtin_amdgcn_inverse_ballot_w64(accm)) {
                 used_set(C, cur.a, cur.w);
@@ -573,7 +578,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             nx_stale = 0ull;
         }
     }
-    if (!theta_valid) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
+    if (n_theta != n) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
     return n;
 }
