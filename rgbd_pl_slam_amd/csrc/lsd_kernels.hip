@@ -458,6 +458,7 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
 // comparisons (|S x u| >= 0 and t1, t2 > 0), and |S|^2 >= 0.25 always holds: S starts as a unit vector and every accepted lane has S . u > 0 (it passed the
 // cone test, or it was a border lane, and border lanes pass `|S x u| < t2 * S . u` as well), so |S| only grows; and the pixels a region takes out of the seed
 // chunk are no longer tracked per accept (seven scalar instructions each) but read off the list once, when a small region ends (regions_body).
+template <int PF>
 __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out)
 {
     const int lane = plf_lane();
@@ -498,7 +499,10 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         const float ux = (float)cur.csx, uy = (float)cur.csy;
         asm volatile("" : : "v"(ux), "v"(uy), "v"(cur.w) : "memory");
         // ---- issue the loads of the next group: list entries that exist now
-        nx_n = min(7, n - (i + cur_n));
+        // PF == 0 (k_lsd_regions2: eight chains per SIMD): NO fetch ahead -- the next group is loaded when this one is done and then holds every centre accepted
+        // by now, i.e. fewer, fuller groups (a group costs ~95 instructions whatever it holds; 2.7 centres per group with the fetch ahead).  The exposed round
+        // trip costs nothing there: the kernel is bound by instruction issue and seven other chains fill the wait.  73.7 -> 69.2 ms per 8192 frames.
+        nx_n = PF ? min(7, n - (i + cur_n)) : 0;
         if (nx_n < 0) nx_n = 0;
         nx.w = 0xFFFFFFFFu; nx.csx = 0.0; nx.csy = 0.0; nx.a = -1; nx.xy = 0u;
         nx_valid = 0ull; nx_stale = 0ull;
@@ -557,7 +561,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             sumdy = (float)((double)sumdy + ss);
             ++n;
             candm &= ~((2ull << k) - 1ull) & ~__ballot(cur.a == ka);   // lanes up to k are decided; the pixel is taken
-            nx_stale |= __ballot(nx.a == ka);
+            if (PF) nx_stale |= __ballot(nx.a == ka);
             PLF_GROW_CLASSIFY()
         } while (mAB);
 #undef PLF_GROW_CLASSIFY
@@ -878,7 +882,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    n = region_grow(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
+    n = region_grow<STG != 2>(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
     C.regrow_n = n;
     if (n < 2) return false;
     region2rect<STG>(C, n, reg_angle, prec, p, rec);
@@ -991,16 +995,16 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             int sx, sy;
             if (walk) { sx = bx + j; sy = by; if (sx >= W) { sx -= W; sy++; } }
             else { sx = seed % W; sy = seed / W; }
-            int n = region_grow(C, sx, sy, sdeg, sc0, prec, th0, reg_angle);
+            int n = region_grow<(LDSOFF >= 0)>(C, sx, sy, sdeg, sc0, prec, th0, reg_angle);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
             const bool big = n >= g.min_reg_size;
             if (big) {
                 LsdRect rec;
                 TIC(t1);
-                region2rect<1>(C, n, reg_angle, prec, p, rec);
+                region2rect<(LDSOFF < 0 ? 2 : 1)>(C, n, reg_angle, prec, p, rec);
                 TOC(1, t1); CNT(6, 1);
                 TIC(t2);
-                const bool okr = refine<1>(C, n, reg_angle, prec, p, rec, 0.7);
+                const bool okr = refine<(LDSOFF < 0 ? 2 : 1)>(C, n, reg_angle, prec, p, rec, 0.7);
                 TOC(2, t2);
                 if (okr) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
@@ -1041,16 +1045,16 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             double reg_angle;
             TIC(t0);
-            int n = region_grow(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
+            int n = region_grow<(LDSOFF >= 0)>(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
             const bool big = n >= g.min_reg_size;
             if (big) {
                 LsdRect rec;
                 TIC(t1);
-                region2rect<1>(C, n, reg_angle, prec, p, rec);
+                region2rect<(LDSOFF < 0 ? 2 : 1)>(C, n, reg_angle, prec, p, rec);
                 TOC(1, t1); CNT(6, 1);
                 TIC(t2);
-                const bool okr = refine<1>(C, n, reg_angle, prec, p, rec, 0.7);
+                const bool okr = refine<(LDSOFF < 0 ? 2 : 1)>(C, n, reg_angle, prec, p, rec, 0.7);
                 TOC(2, t2);
                 if (okr) {
                     if (nr < g.rect_cap) { if (lane == 0) rects[nr] = rec; }
@@ -1202,7 +1206,7 @@ __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th
     double reg_angle;
     C.regrow_n = -1;
     TIC(ts0);
-    int n = region_grow(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
+    int n = region_grow<1>(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
     CBAR();
     TOCB(10, ts0);
     CNTB(16, 1); CNTB(17, n);
