@@ -420,7 +420,8 @@ __device__ __forceinline__ Grp group_at(const RegCtx &C, uint32_t pxy, int kx, i
     valid = __ballot(G.a >= 0);
     // lanes past the group's last point hold whatever their list slot holds: they read pixel 0 (one cached line for all of them) -- with the address of that stale
     // slot they pulled 25 GB of unrelated lines per 8192-frame launch through the L2
-    const int af = plf_lane() < nlanes ? min(max(G.a, 0), C.W * C.H - 1) : 0;
+    // (no upper clamp: a region point is a defined pixel, x <= W-2 and y <= H-2, so its neighbours end at the last pixel of the frame)
+    const int af = plf_lane() < nlanes ? max(G.a, 0) : 0;
     const double2 c = C.cs[af];
     G.w = ang_load(C, af);
     G.csx = c.x; G.csy = c.y;
