@@ -119,6 +119,8 @@ struct plf_line {
     LineTune tune;
     SpecBufs spec;            // banded speculative region growing (few frames in flight); allocated on first use
     int spec_frames;          // frames the buffers were sized for (0: not allocated, -1: allocation failed / disabled)
+    size_t spec_slots;        // (frame, band) slots they hold = frames x bands at allocation time
+    bool spec_sglob_per_band; // sglob was allocated with one bitmap per band (validation rounds)
     size_t fused_lds, fused_capacity;   // k_lsd_spec_fused: workgroups of that LDS size the GPU can hold at once (occupancy query)
     int n_cus;                // compute units of the device (queried on first use)
     int *d_spec_stats;
@@ -528,7 +530,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (zmode && Fr * (per_frame + per_frame_z) > ((size_t)32 << 30)) zmode = false;
         if (!spec) zmode = false;
     }
-    if (spec && (h->spec_frames < B || h->spec.nbands != spec_bands || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out))) {
+    // (the band count depends on the batch size -- 48 / 32 / 16 / ... -- and every change used to free and re-allocate hundreds of MB behind a stream
+    // synchronisation, e.g. in a loop that mixes 1-frame and 12-frame calls.  The buffers are indexed by (frame * nbands + band) with the CURRENT band count as the
+    // stride, so an allocation made for Fr frames x K bands serves every call with B <= Fr and B * nbands <= Fr * K.)
+    if (spec && (h->spec_frames < B || (size_t)B * spec_bands > h->spec_slots || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out))) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
                        h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
@@ -566,9 +571,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                  hipMalloc((void **)&h->spec.tl2b, Fr * K * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess;
         }
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; zmode = false; }
-        else h->spec_frames = (int)Fr;
+        else { h->spec_frames = (int)Fr; h->spec_slots = Fr * K; h->spec_sglob_per_band = zmode; }
     }
     if (spec) {
+        h->spec.nbands = spec_bands;   // (the stride of this call; the allocation may hold more)
         h->spec.s_global = s_global ? 1 : 0;
         h->spec.spin_bound = T.spec_spins;   // (test hook: a short bound must still let slow band waves finish -- heartbeat)
         // warm-up rows above a band: 16 when a serial commit wave follows (every region it has to regrow is serial time), 4 with the validation rounds

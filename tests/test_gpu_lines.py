@@ -472,3 +472,22 @@ def test_time_budget_two_launch_speculative_schedule(B, ms):
         if not flags[f]:
             assert len(segs) == len(refs[f % 8]), "frame %d finished in time but holds %d of %d segments" % (f, len(segs), len(refs[f % 8]))
     ls.close()
+
+
+def test_alternating_batch_sizes_share_the_speculation_buffers():
+    """the band count of the speculative schedule depends on the batch size (48 / 32 / 16 / ...), and every change used to re-allocate its buffers.
+    They are now indexed with the current band count as the stride and re-used whenever frames x bands fits the allocation: one handle, batch sizes in an order
+    that shrinks and grows the band count (and switches the validation rounds on and off), every frame against the oracle."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    imgs = [synth_frame(8100 + i) for i in range(40)]
+    refs = [orc.line_extract(im, 100) for im in imgs]
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=40)
+    for B in (40, 1, 12, 3, 40, 2, 20, 1, 17, 8):
+        off = (7 * B) % 40
+        idx = [(off + i) % 40 for i in range(B)]
+        res = ls.extract_batch(np.stack([imgs[i] for i in idx]))
+        for f, i in enumerate(idx):
+            assert res[f][0].tobytes() == refs[i]["kl"].tobytes() and np.array_equal(res[f][1], refs[i]["desc"]), (B, f)
+    ls.close()
