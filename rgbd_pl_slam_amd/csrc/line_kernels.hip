@@ -217,13 +217,8 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int X = x0 - 1 + 4 * g4 + j, s_ = sv[j];
-                int v;
-                if (X < wvec) {
-                    v = s_ >> 16;
-                    const int rem = s_ & 0xFFFF;
-                    if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
-                } else
-                    v = (s_ + 32768) >> 16;
+                // half to even = (s + 0x7FFF + bit 16 of s) >> 16 (as in the 7x7 blur of the ORB path); the scalar tail rounds half up
+                const int v = (s_ + (X < wvec ? 0x7FFF + ((s_ >> 16) & 1) : 0x8000)) >> 16;
                 out |= (uint32_t)(v > 255 ? 255 : v) << (8 * j);
             }
             *reinterpret_cast<uint32_t *>(&blur[r][4 * g4]) = out;
@@ -238,19 +233,33 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
         const int ym = plf_reflect101(y - 1, H) - (y0 - 1), yc = ry + 1, yp = plf_reflect101(y + 1, H) - (y0 - 1);
         short2 *out = grad + (size_t)f * g.full_stride + (size_t)y * W + x;
         if (x >= 1 && x + 4 < W) {   // blurred columns x - 1 .. x + 4 exist: blur[][cx .. cx + 5]
-#define LD8_(row) ((unsigned long long)*reinterpret_cast<const uint32_t *>(&blur[row][cx]) | ((unsigned long long)*reinterpret_cast<const uint32_t *>(&blur[row][cx + 4]) << 32))
-            const unsigned long long a0 = LD8_(ym), a1 = LD8_(yc), a2 = LD8_(yp);
-#undef LD8_
-            short2 o[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#define B_(A, k) ((int)(((A) >> (8 * (k))) & 0xFF))
-                const int gx = (B_(a0, j + 2) + 2 * B_(a1, j + 2) + B_(a2, j + 2)) - (B_(a0, j) + 2 * B_(a1, j) + B_(a2, j));
-                const int gy = (B_(a2, j) + 2 * B_(a2, j + 1) + B_(a2, j + 2)) - (B_(a0, j) + 2 * B_(a0, j + 1) + B_(a0, j + 2));
-#undef B_
-                o[j] = make_short2((short)gx, (short)gy);
-            }
-            plf_short8 v; v.a = o[0]; v.b = o[1]; v.c = o[2]; v.d = o[3];
+            // Packed 16-bit lanes (round 4; the scalar form extracted 36 bytes and did ~100 instructions per 4 pixels, a third of the kernel): the bytes b0..b5 of
+            // a row as pairs P01 P23 P45 (and Q12 Q34 for the rows' own sums), column sums C = top + 2 mid + bottom per pair, gx[j] = C[j+2] - C[j];
+            // row sums T = P + 2 Q + P', gy = bottom - top.  All values fit 11 bits + sign.
+            typedef short s2v __attribute__((ext_vector_type(2)));
+#define PERM_(hi, lo, sel) __builtin_bit_cast(s2v, __builtin_amdgcn_perm((hi), (lo), (sel)))
+            const uint32_t t0 = *reinterpret_cast<const uint32_t *>(&blur[ym][cx]), t1 = *reinterpret_cast<const uint32_t *>(&blur[ym][cx + 4]);
+            const uint32_t m0 = *reinterpret_cast<const uint32_t *>(&blur[yc][cx]), m1 = *reinterpret_cast<const uint32_t *>(&blur[yc][cx + 4]);
+            const uint32_t b0 = *reinterpret_cast<const uint32_t *>(&blur[yp][cx]), b1 = *reinterpret_cast<const uint32_t *>(&blur[yp][cx + 4]);
+            const s2v two = {2, 2};
+            const s2v tP01 = PERM_(0u, t0, 0x0C010C00u), tP23 = PERM_(0u, t0, 0x0C030C02u), tP45 = PERM_(0u, t1, 0x0C010C00u);
+            const s2v tQ12 = PERM_(0u, t0, 0x0C020C01u), tQ34 = PERM_(t1, t0, 0x0C040C03u);
+            const s2v mP01 = PERM_(0u, m0, 0x0C010C00u), mP23 = PERM_(0u, m0, 0x0C030C02u), mP45 = PERM_(0u, m1, 0x0C010C00u);
+            const s2v bP01 = PERM_(0u, b0, 0x0C010C00u), bP23 = PERM_(0u, b0, 0x0C030C02u), bP45 = PERM_(0u, b1, 0x0C010C00u);
+            const s2v bQ12 = PERM_(0u, b0, 0x0C020C01u), bQ34 = PERM_(b1, b0, 0x0C040C03u);
+            const s2v C01 = mP01 * two + tP01 + bP01, C23 = mP23 * two + tP23 + bP23, C45 = mP45 * two + tP45 + bP45;
+            const s2v gx01 = C23 - C01, gx23 = C45 - C23;
+            const s2v T01 = tQ12 * two + tP01 + tP23, T23 = tQ34 * two + tP23 + tP45;
+            const s2v B01 = bQ12 * two + bP01 + bP23, B23 = bQ34 * two + bP23 + bP45;
+            const s2v gy01 = B01 - T01, gy23 = B23 - T23;
+            const uint32_t X01 = __builtin_bit_cast(uint32_t, gx01), Y01 = __builtin_bit_cast(uint32_t, gy01);
+            const uint32_t X23 = __builtin_bit_cast(uint32_t, gx23), Y23 = __builtin_bit_cast(uint32_t, gy23);
+            uint4 o4;   // (gx, gy) of pixels 0..3 as short2 each
+            o4.x = __builtin_amdgcn_perm(Y01, X01, 0x05040100u); o4.y = __builtin_amdgcn_perm(Y01, X01, 0x07060302u);
+            o4.z = __builtin_amdgcn_perm(Y23, X23, 0x05040100u); o4.w = __builtin_amdgcn_perm(Y23, X23, 0x07060302u);
+#undef PERM_
+            plf_short8 v;
+            v.a = __builtin_bit_cast(short2, o4.x); v.b = __builtin_bit_cast(short2, o4.y); v.c = __builtin_bit_cast(short2, o4.z); v.d = __builtin_bit_cast(short2, o4.w);
             *(plf_short8 *)out = v;
             return;
         }
