@@ -58,7 +58,7 @@ __global__ void k_lsd_spec_grow(float *, const double *, const double2 *, const 
 __global__ void k_lsd_spec_commit(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
 __global__ void k_lsd_spec_commit_rest(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
 __global__ void k_lsd_spec_prefix(SpecBufs, int);
-__global__ void k_lsd_spec_round_begin(SpecBufs, int, int);
+__global__ void k_lsd_spec_clear(SpecBufs, int *, int);
 __global__ void k_lsd_spec_validate(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs, int);
 __global__ void k_lsd_spec_assemble(LsdRect *, int *, int *, LsdGeom, SpecBufs, int);
 
@@ -543,7 +543,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         size_t Fr = 8;   // frames the buffers are sized for: the batch rounded up to a power of two (~23 MB per VGA frame)
         while (Fr < (size_t)B) Fr <<= 1;
         const size_t K = (size_t)spec_bands;
-        h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192;
+        h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192; h->spec.frames_cap = (int)Fr;
         h->spec.rcap_rec = T.spec_reccap;   // (test hook: a small value forces the overflow fallback)
         bool ok = hipMalloc((void **)&h->spec.rxy, Fr * K * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
@@ -567,7 +567,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                  hipMalloc((void **)&h->spec.recs_alt, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.cnt_alt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.nrects, Fr * K * sizeof(int)) == hipSuccess &&
-                 hipMalloc((void **)&h->spec.round_state, Fr * 4 * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.round_state, Fr * 5 * sizeof(int)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.tl2b, Fr * K * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess;
         }
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; zmode = false; }
@@ -588,8 +588,6 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         // validation rounds (2.08 -> 2.77 ms): it loses for one frame (6.0 vs 6.5 ms) and wins once a round lasts as long as the slowest band of several frames
         // anyway (8 frames in flight: 977 -> 1014 frames/s)
         h->spec.halo_clip = T.spec_clip != PLF_TUNE_AUTO ? T.spec_clip : (B >= 4 ? 16 : -1);
-        PLF_HIP_TRY(hipMemsetAsync(h->spec.seedmap, 0, (size_t)B * bm_words * sizeof(uint32_t), s));
-        PLF_HIP_TRY(hipMemsetAsync(h->spec.done, 0, (size_t)B * spec_bands * sizeof(int), s));
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
         // finish, and the bands are staggered for that; otherwise two launches with equal bands
         // ... and only while EVERY workgroup of the launch can be resident at the same time: the commit workgroups wait for band workgroups of the
@@ -605,9 +603,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         zmode = zmode && h->spec.out != nullptr;
         const bool fused = !zmode && (size_t)B * (spec_bands + 1) <= 448 && (size_t)B * (spec_bands + 1) <= h->fused_capacity && !T.spec_nofuse;
         h->spec.stagger = fused ? T.spec_stagger : 0.f;
-        PLF_HIP_TRY(hipMemsetAsync(h->spec.side, 0, (size_t)B * spec_bands * sizeof(int), s));
+        // seed map, band flags, row counts, round state: one launch (k_lsd_spec_clear)
+        hipLaunchKernelGGL(k_lsd_spec_clear, dim3(B), dim3(256), 0, s, h->spec, h->d_spec_rowcnt, zmode ? 1 : 0);
         // band boundaries: row counts + defined-pixel bitmap over the whole frame in parallel, then one wave per frame balances the bands
-        PLF_HIP_TRY(hipMemsetAsync(h->d_spec_rowcnt, 0, (size_t)B * 1024 * sizeof(int), s));
         hipLaunchKernelGGL(k_lsd_spec_rows, dim3((bm_words * 32 + 255) / 256, B), dim3(256), 0, s, h->d_ang, g, h->spec, h->d_spec_rowcnt);
         hipLaunchKernelGGL(k_lsd_spec_bands, dim3(B), dim3(64), 0, s, g, h->spec, h->d_spec_rowcnt, h->d_spec_rowcnt + (size_t)h->spec_frames * 1024);
         SpecBufs SBn = h->spec; SBn.out = nullptr; SBn.round_state = nullptr;   // (schedules without validation rounds: the band waves skip their part of them)
@@ -615,11 +613,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;
             // rectangles assembled from the bands' logs; frames that did not reach the fixpoint within the rounds are committed serially (exact either way)
             const int rounds = T.spec_rounds;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
-            PLF_HIP_TRY(hipMemsetAsync(h->spec.round_state, 0, (size_t)B * 4 * sizeof(int), s));
             const SpecBufs SBz = h->spec;
             hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(256), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);   // (waves 1-3 warm the L2)
             for (int r = 1; r <= rounds; r++) {
-                hipLaunchKernelGGL(k_lsd_spec_round_begin, dim3((B + 63) / 64), dim3(64), 0, s, SBz, B, r);
                 hipLaunchKernelGGL(k_lsd_spec_prefix, dim3((bm_words + 255) / 256, B), dim3(256), 0, s, SBz, r);
                 hipLaunchKernelGGL(k_lsd_spec_validate, dim3(spec_bands, B), dim3(256), lds_commit, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz, r);
             }

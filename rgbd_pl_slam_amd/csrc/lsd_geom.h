@@ -62,7 +62,8 @@ struct SpecBufs {
     int *cnt_alt;
     int *side;          // [frame][band]: side that holds the band's current log (0: tl / recs / cnt)
     int *nrects;        // [frame][band]: rectangles in the band's current log
-    int *round_state;   // [frame][4]: bands whose marks changed in the even / odd rounds, converged, fall back to the serial commit
+    int *round_state;   // [frame][4]: bands whose marks changed in the even / odd rounds, converged, fall back to the serial commit; behind the frames_cap frames: [frame] band workgroups through the current round
+    int frames_cap;     // frames round_state was allocated for
     uint32_t *tl2b;     // [frame][band][2 * s_stride]: accepted pixels of a seed regrown by a validation
     int *band_ticks;    // [frame][band][2]: run time of the band wave in 100 MHz ticks, accepted pixels it logged (diagnostics: how well the band shares are balanced)
 };

@@ -2376,21 +2376,38 @@ __global__ void __launch_bounds__(256) k_lsd_spec_validate(float *__restrict__ a
                                                           const float2 *__restrict__ cs0_all, LsdGeom g, SpecBufs SB, int round)
 {
     const int band = blockIdx.x, f = blockIdx.y;
-    if (band == 0 || !spec_rounds_active(SB, f)) return;   // band 0 is consistent with the empty set for good
-    if (SB.s_global) spec_validate_body<true>(band, f, ang_all, modgrad_all, cs_all, cs0_all, g, SB, round);
-    else spec_validate_body<false>(band, f, ang_all, modgrad_all, cs_all, cs0_all, g, SB, round);
+    if (band == 0) return;   // band 0 is consistent with the empty set for good
+    if (spec_rounds_active(SB, f)) {
+        if (SB.s_global) spec_validate_body<true>(band, f, ang_all, modgrad_all, cs_all, cs0_all, g, SB, round);
+        else spec_validate_body<false>(band, f, ang_all, modgrad_all, cs_all, cs0_all, g, SB, round);
+    }
+    // The bookkeeping between two rounds, by the LAST band workgroup of the frame to get here (round 4; it was a launch of its own, 12 per call): if this round
+    // changed nothing the frame has converged (sticky, the value is the round); otherwise the next round's counter starts at zero.  The state that decides
+    // whether the prefix / validate launches of a round run is still only READ while that round runs -- it changes when all of the frame's bands are through.
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned prev = atomicInc(reinterpret_cast<unsigned *>(SB.round_state + (size_t)SB.frames_cap * 4 + f), (unsigned)SB.nbands - 2u);   // (wraps: bands 1 .. nbands - 1 count)
+        if (prev == (unsigned)SB.nbands - 2u) {
+            __threadfence();
+            int *rs = SB.round_state + f * 4;
+            if (!rs[3] && !rs[2]) {
+                if (__hip_atomic_load(&rs[round & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) rs[2] = round;
+                else rs[(round + 1) & 1] = 0;
+            }
+        }
+    }
 }
 
-// first launch of round `round`: if the round before it changed nothing the frame has converged (sticky); otherwise this round's counter starts at zero.
-// (A launch of its own: the prefix / validate launches of a round then only READ the state that decides whether they run.)
-__global__ void k_lsd_spec_round_begin(SpecBufs SB, int B, int round)
+// everything the speculative schedule wants zeroed at the start of a call, in one launch (six memsets of ~5 us each before; one VGA frame in flight: 4.06 ms)
+__global__ void __launch_bounds__(256) k_lsd_spec_clear(SpecBufs SB, int *__restrict__ rowcnt, int rounds_state)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= B) return;
-    int *rs = SB.round_state + f * 4;
-    if (rs[3] || rs[2]) return;
-    if (round > 1 && rs[(round - 1) & 1] == 0) { rs[2] = round - 1; return; }   // (non-zero = converged; the value is the round that found nothing to change: diagnostics)
-    rs[round & 1] = 0;
+    const int f = blockIdx.x, t = threadIdx.x;
+    uint32_t *sm = SB.seedmap + (size_t)f * SB.bm_words;
+    for (int i = t; i < SB.bm_words; i += 256) sm[i] = 0u;
+    for (int i = t; i < 1024; i += 256) rowcnt[f * 1024 + i] = 0;
+    for (int i = t; i < SB.nbands; i += 256) { SB.done[f * SB.nbands + i] = 0; SB.side[f * SB.nbands + i] = 0; }
+    if (rounds_state && t < 4) SB.round_state[f * 4 + t] = 0;
+    if (rounds_state && t == 4) SB.round_state[(size_t)SB.frames_cap * 4 + f] = 0;
 }
 
 // rectangles of a converged frame: the bands' records in order
