@@ -491,3 +491,21 @@ def test_alternating_batch_sizes_share_the_speculation_buffers():
         for f, i in enumerate(idx):
             assert res[f][0].tobytes() == refs[i]["kl"].tobytes() and np.array_equal(res[f][1], refs[i]["desc"]), (B, f)
     ls.close()
+
+
+def test_one_handle_alternating_image_sizes_rebuilds_the_nfa_table():
+    """The table of NFA values (k_nfa_table) depends on the scaled image size (LOG_NT enters nfa_d's exit test): a handle that sees a different size must refill it.
+    One handle, sizes 640x480 -> 320x240 -> 800x600 -> 640x480, single frames and a batch of 70 (the staged NFA kernels' hand-over), against the oracle."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    ls = LineSegment(nlines=100, max_width=800, max_height=600, max_batch=70)
+    for (w, h) in ((640, 480), (320, 240), (800, 600), (640, 480)):
+        imgs = [synth_frame(8300 + i, w, h) for i in range(5)]
+        refs = [orc.line_extract(im, 100) for im in imgs]
+        kl, ld, eq = ls.ExtractLineSegment(imgs[0])
+        assert kl.tobytes() == refs[0]["kl"].tobytes() and np.array_equal(ld, refs[0]["desc"]), (w, h)
+        res = ls.extract_batch(np.stack([imgs[i % 5] for i in range(70)]))
+        for f in range(70):
+            assert res[f][0].tobytes() == refs[f % 5]["kl"].tobytes() and np.array_equal(res[f][1], refs[f % 5]["desc"]), (w, h, f)
+    ls.close()
