@@ -42,7 +42,8 @@ __global__ void k_nfa_count1_w(const float *, const NfaEntry *, const int *, int
 __global__ void k_nfa_eval(int, const double *, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
 __global__ void k_nfa_table(double *, const double *, double);
 __global__ void k_nfa_fused_list(const float *, const double *, const NfaState *, const int *, uint8_t *, float4 *, LsdGeom);
-__global__ void k_nfa_small(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int);
+__global__ void k_nfa_small(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int, NfaState *, int *, int);
+__global__ void k_nfa_small2(const float *, const double *, const LsdRect *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int, const NfaState *, const int *, int);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
 __global__ void k_nfa_fused(const float *, const double *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_lsd_finalize(const float4 *, const uint8_t *, const int *, float4 *, int *, plf_keyline *, plf_keyline *, double *, int *,
@@ -85,6 +86,7 @@ struct LineTune {
     int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
     int nfa_small;        // PLF_NFA_SMALL        2: rect_improve of the rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle; 1: only for more
                           //                      than nfa_fused frames in flight (one frame: 4.41 ms with it, 4.63 ms with k_nfa_fused); 0: off
+    int nfa_two_pass;     // PLF_NFA_TWO_PASS     1: above nfa_fused frames in flight k_nfa_small only runs stage 0 and queues the undecided rectangles for k_nfa_small2 (stages 1-4)
     int nfa_list;         // PLF_NFA_LIST         1: the rectangles k_nfa_small hands over take one wave each, all stages in one launch (k_nfa_fused_list: 3 NFA launches per
                           //                      batch instead of 17, but 17 ms instead of 9.5 per 8192 VGA frames); 0: the staged kernels
     int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
@@ -112,6 +114,7 @@ static void line_tune_init(LineTune *t)
     t->nfa_table = tune_env_i("PLF_NFA_TABLE", 1);
     t->nfa_small = tune_env_i("PLF_NFA_SMALL", 2);
     t->nfa_list = tune_env_i("PLF_NFA_LIST", 0);
+    t->nfa_two_pass = tune_env_i("PLF_NFA_TWO_PASS", 1);
 }
 
 struct plf_line {
@@ -151,6 +154,7 @@ struct plf_line {
     NfaState *d_st[2];
     NfaCounts *d_cnt;
     int *d_nfa_counters;
+    int *d_nfa_fcnt;          // [frame]: rectangles queued for k_nfa_small2
     double *d_vals;
     unsigned long long *d_sort_scratch;   // [frame][sort_cap] when sort_cap > sort_lds
     double2 *d_cs;
@@ -187,7 +191,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_vals, h->d_sort_scratch, h->d_lbd};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_nfa_fcnt, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
                   h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
@@ -384,6 +388,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_st[0], NP * sizeof(NfaState)); ALLOC(h->d_st[1], NP * sizeof(NfaState));
     ALLOC(h->d_cnt, NP * 5 * sizeof(NfaCounts));
     ALLOC(h->d_nfa_counters, 16 * sizeof(int));
+    ALLOC(h->d_nfa_fcnt, B * sizeof(int));
     ALLOC(h->d_vals, NP * 6 * sizeof(double));
     if (g.sort_cap > g.sort_lds) ALLOC(h->d_sort_scratch, B * (size_t)g.sort_cap * sizeof(unsigned long long));
     if (p->seed_order == 1) {
@@ -433,7 +438,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
     const int v = (int)value;
     struct { const char *n; int *p; } ints[] = {{"lat_max", &t.lat_max}, {"spec_bands", &t.spec_bands}, {"spec_max", &t.spec_max}, {"spec_z", &t.spec_z},
         {"spec_rounds", &t.spec_rounds}, {"spec_halo", &t.spec_halo}, {"spec_fill", &t.spec_fill}, {"spec_clip", &t.spec_clip}, {"spec_nofuse", &t.spec_nofuse},
-        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_list", &t.nfa_list}};
+        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_list", &t.nfa_list}, {"nfa_two_pass", &t.nfa_two_pass}};
     for (auto &e : ints)
         if (!strcmp(name, e.n)) {
             if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
@@ -656,8 +661,18 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else {
         PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_counters, 0, 16 * sizeof(int), s));
         if (small_first)   // rectangles of fewer than 512 pixels: all five stages by 16 lanes, values from the table; the others are queued in the stage-0 work list
+        {
+            // two passes for large batches: stage 0 of every rectangle, then stages 1-4 of the two thirds it does not decide (queued in the second state buffer, which the
+            // staged kernels only write later in the stream)
+            NfaState *surv = (T.nfa_two_pass && B > nfa_fused_max) ? h->d_st[1] : nullptr;
+            const int scap = (int)std::min<size_t>((size_t)g.nfa_pool / (size_t)B, (size_t)g.rect_cap);   // queue entries per frame
+            if (surv) PLF_HIP_TRY(hipMemsetAsync(h->d_nfa_fcnt, 0, (size_t)B * sizeof(int), s));
             hipLaunchKernelGGL(k_nfa_small, dim3(8 * (g.rect_cap < 640 ? (g.rect_cap + 3) / 4 : 160), (B + 7) / 8), dim3(64), 0, s, h->d_ang, h->d_nfa_tab, h->d_rects, nrect,
-                               h->d_keep, h->d_seg, h->d_ent[0], h->d_st[0], h->d_nfa_counters, status, g, B);
+                               h->d_keep, h->d_seg, h->d_ent[0], h->d_st[0], h->d_nfa_counters, status, g, B, surv, h->d_nfa_fcnt, scap);
+            if (surv)
+                hipLaunchKernelGGL(k_nfa_small2, dim3(8 * (g.rect_cap < 512 ? (g.rect_cap + 3) / 4 : 128), (B + 7) / 8), dim3(64), 0, s, h->d_ang, h->d_nfa_tab, h->d_rects, h->d_keep,
+                                   h->d_seg, h->d_ent[0], h->d_st[0], h->d_nfa_counters, status, g, B, surv, h->d_nfa_fcnt, scap);
+        }
         else
             hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
                                h->d_nfa_counters, status, g);

@@ -3080,10 +3080,91 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
 #else
 #define PLF_NFA_SMALL_OCC
 #endif
+// stages LO..HI of one rectangle by its group of 16 lanes (all lanes of the group return the same state)
+template <int LO, int HI>
+__device__ __forceinline__ void nfa_small_stages(const float *__restrict__ ang, const double *__restrict__ tab, const LsdGeom &g, int *par, int grp, int lane16,
+                                                 LsdRect &rec, double &log_nfa, bool &keep, bool &defer, bool &fin)
+{
+    const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
+    NfaCounts c;
+    for (int stage = LO; stage <= HI && !fin; stage++) {
+        if (stage == 0 || stage == 4) {
+            if (stage == 4 && !((rec.width - delta) >= 0.5)) break;   // (nprec 0 in k_nfa_math: nothing to evaluate, not meaningful)
+            rect_count<6, 16>(ang, g.sw, g.sh, rec, c);
+            LsdRect r = rec;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (k > 0) { r.p /= 2; r.prec = r.p * PI_D; }
+                if (stage == 4 && k == 0) continue;
+                double v;
+                if (!nfa_lookup(tab, c.total, c.alg[k], r.p, v)) { defer = fin = true; break; }
+                if (stage == 0 && k == 0) {
+                    log_nfa = v;
+                    if (v > LOG_EPS) { keep = fin = true; break; }
+                } else if (v > log_nfa) { log_nfa = v; rec.p = r.p; rec.prec = r.prec; }
+            }
+        } else {
+            // 1: reduce the width, 2: reduce one side, 3: reduce the other side -- five candidates, each derived from the previous one: lane c of the group
+            // builds candidate c by the same c + 1 steps (lanes 5..15 idle along with candidate 4), then one pass counts all five
+            LsdRect r = rec;
+            bool valid = true;
+            const int myc = min(lane16, 4);
+            for (int k = 0; k <= 4; k++) {
+                if (k > myc) break;
+                if (!((r.width - delta) >= 0.5)) { valid = false; break; }   // (every later candidate fails the same test)
+                if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+                if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+                r.width -= delta;
+            }
+            const int nvalid = __popcll((__ballot(valid && lane16 < 5) >> (16 * grp)) & 31ull);   // (monotone: candidates 0 .. nvalid - 1)
+            if (nvalid > 0) {
+                int total[5], alg[5];
+                rect_count5(ang, g.sw, g.sh, r, valid, rec.theta, rec.prec, par, total, alg);
+                int best = -1;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    if (k >= nvalid || fin) continue;
+                    double v;
+                    if (!nfa_lookup(tab, total[k], alg[k], rec.p, v)) { defer = fin = true; continue; }
+                    if (v > log_nfa) { log_nfa = v; best = k; }
+                }
+                if (best >= 0 && !defer) {
+                    const int src = (threadIdx.x & 48) + best;
+                    rec.x1 = shfl_d(r.x1, src); rec.y1 = shfl_d(r.y1, src); rec.x2 = shfl_d(r.x2, src); rec.y2 = shfl_d(r.y2, src); rec.width = shfl_d(r.width, src);
+                }
+            }
+        }
+        if (!fin && log_nfa > LOG_EPS) keep = fin = true;
+    }
+}
+
+// what a group's first lane does when its rectangle is decided: keep flag and segment, or the hand-over to the staged kernels (the rectangle as found)
+__device__ __forceinline__ void nfa_small_finish(int f, int ri, const LsdRect &rec, bool keep, bool defer, const LsdRect *__restrict__ rects_all, uint8_t *__restrict__ keep_all,
+                                                 float4 *__restrict__ seg_all, NfaEntry *__restrict__ entries, NfaState *__restrict__ states, int *__restrict__ counters,
+                                                 int *__restrict__ status, const LsdGeom &g)
+{
+    const size_t o = (size_t)f * g.rect_cap + ri;
+    keep_all[o] = keep && !defer ? 1 : 0;
+    if (defer) {
+        const int q = atomicAdd(&counters[0], 1);
+        if (q >= g.nfa_pool) { atomicOr(status, 1); return; }
+        NfaEntry e;
+        e.r = rects_all[o]; e.frame = f; e.nprec = 6; e.pad0 = e.pad1 = 0;
+        entries[q] = e;
+        NfaState st;
+        st.rec = e.r; st.log_nfa = -1; st.frame = f; st.rect = ri;
+        states[q] = st;
+    } else if (keep) emit_segment(rec, &seg_all[o]);
+}
+
+// surv != null (large batches): the rectangles that are not decided by stage 0 -- two thirds -- are queued per FRAME (surv[f * scap ..], fcnt[f]) for
+// k_nfa_small2 instead of walking through stages 1-4 here: the four groups of a wave then always have work (a wave of this kernel lasted as long as its longest
+// rectangle: 30 % of the group slots idled behind rectangles that stage 0 had already decided).  A full list is no error: the group carries on here.  (One counter
+// per frame, not per XCD: 350 k atomics on one address cost more than the stages they were to save.)
 __global__ void PLF_NFA_SMALL_OCC __launch_bounds__(64) k_nfa_small(const float *__restrict__ ang_all, const double *__restrict__ tab, const LsdRect *__restrict__ rects_all,
                                                   const int *__restrict__ nrect, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all,
                                                   NfaEntry *__restrict__ entries, NfaState *__restrict__ states, int *__restrict__ counters,
-                                                  int *__restrict__ status, LsdGeom g, int nframes)
+                                                  int *__restrict__ status, LsdGeom g, int nframes, NfaState *__restrict__ surv, int *__restrict__ fcnt, int scap)
 {
     // grid (8 * slots, ceil(B / 8)): workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), so XCD x works through frame 8 * blockIdx.y + x and the
     // angle words of a frame are pulled into ONE L2 (k_orient_brief's order)
@@ -3092,76 +3173,53 @@ __global__ void PLF_NFA_SMALL_OCC __launch_bounds__(64) k_nfa_small(const float 
     __shared__ int s_par[4][5 * 12];
     const int n_r = nrect[f], grp = threadIdx.x >> 4, lane16 = threadIdx.x & 15;
     const float *ang = ang_all + (size_t)f * g.s_stride;
-    const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
     for (int i0 = slot * 4; i0 < n_r; i0 += nslots * 4) {
         const int ri = i0 + grp;
         if (ri >= n_r) continue;   // (groups are independent: rect_count's butterflies stay inside the 16 lanes)
         LsdRect rec = rects_all[(size_t)f * g.rect_cap + ri];
         double log_nfa = -1;
         bool keep = false, defer = false, fin = false;
-        NfaCounts c;
-        for (int stage = 0; stage <= 4 && !fin; stage++) {
-            if (stage == 0 || stage == 4) {
-                if (stage == 4 && !((rec.width - delta) >= 0.5)) break;   // (nprec 0 in k_nfa_math: nothing to evaluate, not meaningful)
-                rect_count<6, 16>(ang, g.sw, g.sh, rec, c);
-                LsdRect r = rec;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    if (k > 0) { r.p /= 2; r.prec = r.p * PI_D; }
-                    if (stage == 4 && k == 0) continue;
-                    double v;
-                    if (!nfa_lookup(tab, c.total, c.alg[k], r.p, v)) { defer = fin = true; break; }
-                    if (stage == 0 && k == 0) {
-                        log_nfa = v;
-                        if (v > LOG_EPS) { keep = fin = true; break; }
-                    } else if (v > log_nfa) { log_nfa = v; rec.p = r.p; rec.prec = r.prec; }
-                }
-            } else {
-                // 1: reduce the width, 2: reduce one side, 3: reduce the other side -- five candidates, each derived from the previous one: lane c of the group
-                // builds candidate c by the same c + 1 steps (lanes 5..15 idle along with candidate 4), then one pass counts all five
-                LsdRect r = rec;
-                bool valid = true;
-                const int myc = min(lane16, 4);
-                for (int k = 0; k <= 4; k++) {
-                    if (k > myc) break;
-                    if (!((r.width - delta) >= 0.5)) { valid = false; break; }   // (every later candidate fails the same test)
-                    if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
-                    if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
-                    r.width -= delta;
-                }
-                const int nvalid = __popcll((__ballot(valid && lane16 < 5) >> (16 * grp)) & 31ull);   // (monotone: candidates 0 .. nvalid - 1)
-                if (nvalid > 0) {
-                    int total[5], alg[5];
-                    rect_count5(ang, g.sw, g.sh, r, valid, rec.theta, rec.prec, &s_par[grp][0], total, alg);
-                    int best = -1;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        if (k >= nvalid || fin) continue;
-                        double v;
-                        if (!nfa_lookup(tab, total[k], alg[k], rec.p, v)) { defer = fin = true; continue; }
-                        if (v > log_nfa) { log_nfa = v; best = k; }
-                    }
-                    if (best >= 0 && !defer) {
-                        const int src = (threadIdx.x & 48) + best;
-                        rec.x1 = shfl_d(r.x1, src); rec.y1 = shfl_d(r.y1, src); rec.x2 = shfl_d(r.x2, src); rec.y2 = shfl_d(r.y2, src); rec.width = shfl_d(r.width, src);
-                    }
-                }
+        nfa_small_stages<0, 0>(ang, tab, g, &s_par[grp][0], grp, lane16, rec, log_nfa, keep, defer, fin);
+        if (!fin) {
+            int q = -1;
+            if (surv) {
+                if (lane16 == 0) q = atomicAdd(&fcnt[f], 1);
+                q = __shfl(q, threadIdx.x & 48, 64);
             }
-            if (!fin && log_nfa > LOG_EPS) keep = fin = true;
+            if (q >= 0 && q < scap) {
+                if (lane16 == 0) {
+                    NfaState st;
+                    st.rec = rec; st.log_nfa = log_nfa; st.frame = f; st.rect = ri;
+                    surv[(size_t)f * scap + q] = st;
+                }
+                continue;
+            }
+            nfa_small_stages<1, 4>(ang, tab, g, &s_par[grp][0], grp, lane16, rec, log_nfa, keep, defer, fin);
         }
-        if ((threadIdx.x & 15) != 0) continue;
-        const size_t o = (size_t)f * g.rect_cap + ri;
-        keep_all[o] = keep && !defer ? 1 : 0;
-        if (defer) {
-            const int q = atomicAdd(&counters[0], 1);
-            if (q >= g.nfa_pool) { atomicOr(status, 1); continue; }
-            NfaEntry e;
-            e.r = rects_all[o]; e.frame = f; e.nprec = 6; e.pad0 = e.pad1 = 0;
-            entries[q] = e;
-            NfaState st;
-            st.rec = e.r; st.log_nfa = -1; st.frame = f; st.rect = ri;
-            states[q] = st;
-        } else if (keep) emit_segment(rec, &seg_all[o]);
+        if (lane16 == 0) nfa_small_finish(f, ri, rec, keep, defer, rects_all, keep_all, seg_all, entries, states, counters, status, g);
+    }
+}
+
+// stages 1-4 of the rectangles k_nfa_small queued, same (frame, slot) grid: XCD x works through the frames 8 * blockIdx.y + x
+__global__ void PLF_NFA_SMALL_OCC __launch_bounds__(64) k_nfa_small2(const float *__restrict__ ang_all, const double *__restrict__ tab, const LsdRect *__restrict__ rects_all,
+                                                   uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, NfaEntry *__restrict__ entries,
+                                                   NfaState *__restrict__ states, int *__restrict__ counters, int *__restrict__ status, LsdGeom g, int nframes,
+                                                   const NfaState *__restrict__ surv, const int *__restrict__ fcnt, int scap)
+{
+    const int f = 8 * (int)blockIdx.y + ((int)blockIdx.x & 7), slot = (int)blockIdx.x >> 3, nslots = (int)gridDim.x >> 3;
+    if (f >= nframes) return;
+    __shared__ int s_par[4][5 * 12];
+    const int n = min(fcnt[f], scap), grp = threadIdx.x >> 4, lane16 = threadIdx.x & 15;
+    const float *ang = ang_all + (size_t)f * g.s_stride;
+    for (int i0 = slot * 4; i0 < n; i0 += nslots * 4) {
+        const int i = i0 + grp;
+        if (i >= n) continue;
+        const NfaState st = surv[(size_t)f * scap + i];
+        LsdRect rec = st.rec;
+        double log_nfa = st.log_nfa;
+        bool keep = false, defer = false, fin = false;
+        nfa_small_stages<1, 4>(ang, tab, g, &s_par[grp][0], grp, lane16, rec, log_nfa, keep, defer, fin);
+        if (lane16 == 0) nfa_small_finish(f, st.rect, rec, keep, defer, rects_all, keep_all, seg_all, entries, states, counters, status, g);
     }
 }
 
