@@ -11,9 +11,6 @@
 #include "plf_common.h"
 #include "lsd_geom.h"
 
-#ifndef PRE_NT
-#define PRE_NT 512   // threads per k_lsd_pre tile (lsd_kernels.hip)
-#endif
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *);
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
@@ -27,7 +24,7 @@ __global__ void k_lsd_spec_fused_budget(float *, const double *, const double2 *
 __global__ void k_lsd_spec_grow_budget(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
 __global__ void k_lsd_spec_commit_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *);
 __global__ void k_lsd_maxgrad(const float *, const double *, double *, LsdGeom);
-__global__ void k_lsd_seedkeys(const double *, const double *, uint32_t *, LsdGeom);
+__global__ void k_lsd_seedkeys(const float *, const double *, const double *, uint32_t *, LsdGeom);
 __global__ void k_lsd_lgamma_table(double *);
 __global__ void k_lsd_count_used(const float *, int *, LsdGeom);
 struct NfaEntry { LsdRect r; int frame, nprec, pad0, pad1; };
@@ -216,6 +213,12 @@ static int line_geometry(const plf_line *h, int w, int hh, LsdGeom *g)
     g->prec = 3.1415926535897932384626433832795 * ANG_TH / 180;
     g->p = ANG_TH / 180;
     g->rho = QUANT / sin(g->prec);
+    {   // ll_angle's test `norm <= rho` on the squared norm: IEEE sqrt is correctly rounded and monotone, so the pixels with sqrt(q) <= rho are exactly q <= rho_q
+        double t = g->rho * g->rho;
+        while (sqrt(t) > g->rho) t = nextafter(t, -INFINITY);
+        while (sqrt(nextafter(t, INFINITY)) <= g->rho) t = nextafter(t, INFINITY);
+        g->rho_q = t;
+    }
     g->log_nt = 5 * (log10((double)g->sw) + log10((double)g->sh)) / 2 + log10(11.0);
     g->min_reg_size = (int)(-g->log_nt / log10(g->p));
     // LDS of k_lsd_regions = the first rcap entries of the region list (+1 mailbox word); longer regions spill to HBM.
@@ -279,11 +282,11 @@ static int line_configure(plf_line *h, int w, int hh)
     }
     g.xmax = xmax;
     // k_lsd_pre keeps the blurred source pixels of a 65 x 17 scaled tile in LDS: PRE_SC x PRE_SR
-    for (int d0 = 0; d0 < g.sw; d0 += 64)
-        if (std::min(xofs[std::min(d0 + 64, g.sw - 1)] + 1, w - 1) - xofs[d0] + 1 > 88) return PLF_E_BADARG;
-    for (int d0 = 0; d0 < g.sh; d0 += 16) {
-        const int lo = std::min(std::max(yofs[d0], 0), hh - 1), hi = std::min(std::max(yofs[std::min(d0 + 16, g.sh - 1)] + 1, 0), hh - 1);
-        if (hi - lo + 1 > 26) return PLF_E_BADARG;
+    for (int d0 = 0; d0 < g.sw; d0 += PRE_TW)
+        if (std::min(xofs[std::min(d0 + PRE_TW, g.sw - 1)] + 1, w - 1) - xofs[d0] + 1 > PRE_SC) return PLF_E_BADARG;
+    for (int d0 = 0; d0 < g.sh; d0 += PRE_TH) {
+        const int lo = std::min(std::max(yofs[d0], 0), hh - 1), hi = std::min(std::max(yofs[std::min(d0 + PRE_TH, g.sh - 1)] + 1, 0), hh - 1);
+        if (hi - lo + 1 > PRE_SR) return PLF_E_BADARG;
     }
     // keep the allocation strides so that per-frame offsets stay inside the buffers
     g.full_stride = (uint32_t)h->alloc_full; g.s_stride = (uint32_t)h->alloc_scaled; g.rect_cap = h->alloc_rect_cap;
@@ -470,7 +473,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail_unused = h->d_counters + 3 * MB + 16;
     (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
-    hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + 63) / 64, (g.sh + 15) / 16, B), dim3(PRE_NT), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
+    hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + PRE_TW - 1) / PRE_TW, (g.sh + PRE_TH - 1) / PRE_TH, B), dim3(PRE_NT), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
                        h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
     if (h->prm.lbd_sobel_input == PLF_LBD_RAW)
         hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
@@ -493,7 +496,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         PLF_HIP_TRY(hipMemcpyAsync(h->d_seg_off, off.data(), sizeof(int) * 2 * B, hipMemcpyHostToDevice, s));
         PLF_HIP_TRY(hipStreamSynchronize(s));
         hipLaunchKernelGGL(k_lsd_maxgrad, dim3(B), dim3(256), 0, s, h->d_ang, h->d_modgrad, h->d_maxgrad, g);
-        hipLaunchKernelGGL(k_lsd_seedkeys, dim3((g.sw * g.sh + 255) / 256, B), dim3(256), 0, s, h->d_modgrad, h->d_maxgrad, h->d_keys[0], g);
+        hipLaunchKernelGGL(k_lsd_seedkeys, dim3((g.sw * g.sh + 255) / 256, B), dim3(256), 0, s, h->d_ang, h->d_modgrad, h->d_maxgrad, h->d_keys[0], g);
         size_t tmp = h->sort_tmp_bytes;
         PLF_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(h->d_sort_tmp, tmp, h->d_keys[0], h->d_keys[1], (int)((size_t)h->prm.max_batch * g.s_stride), B,
                                                                h->d_seg_off, h->d_seg_off + B, 0, 30, s));

@@ -15,6 +15,20 @@ struct LbdCoefs { float gL[21]; float gG[63]; };  // (float) of the double LBD b
 #endif
 #define PLF_LSD_WAVE_LDS (PLF_LSD_WAVE_LIST + 1024 + 768)
 
+// k_lsd_pre: a workgroup of PRE_NT threads produces a PRE_TW x PRE_TH tile of the 0.8x scaled image; the tile (+1 column / row for the 2x2 gradient) needs at most
+// PRE_SC x PRE_SR blurred source pixels (checked on the host for the actual geometry) and 6 more rows of the row pass
+#define PRE_TW 64
+#ifndef PRE_TH
+#define PRE_TH 16
+#endif
+#define PRE_SC 88
+#ifndef PRE_SR
+#define PRE_SR (PRE_TH * 5 / 4 + 6)
+#endif
+#ifndef PRE_NT
+#define PRE_NT 512   // 8 waves share the tile's LDS (4 tiles per CU = 8 waves per SIMD); 256 / 384 / 448 / 512 / 1024 threads: 16.3 / 14.7 / 15.1 / 13.5 / 18.9 ms per 4096 frames (round 2)
+#endif
+
 struct LsdGeom {
     int w, h;             // input image
     int sw, sh;           // 0.8x scaled image
@@ -22,6 +36,7 @@ struct LsdGeom {
     uint32_t full_stride; // elements per frame of the full-resolution double maps
     uint32_t s_stride;    // elements per frame of the scaled maps
     double rho, prec, p, log_nt;
+    double rho_q;         // largest double q with sqrt(q) <= rho: a gradient has a level-line angle iff its squared norm / 4 exceeds it (k_lsd_pre)
     int min_reg_size;
     int rcap;             // region-list entries kept in LDS (one spare word follows)
     int rect_cap;         // rectangles / segments per frame: sw * sh / min_reg_size (every region owns >= min_reg_size pixels), at most 16384

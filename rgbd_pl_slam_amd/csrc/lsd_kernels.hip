@@ -43,13 +43,7 @@
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long __attribute__((aligned(1))) plf_u64u;   // 8-byte access at byte alignment (legal on gfx950 global memory)
 typedef uint32_t __attribute__((aligned(1))) plf_u32u_pre;
-#define PRE_TW 64
-#define PRE_TH 16
-#define PRE_SC 88
-#define PRE_SR 26
-#ifndef PRE_NT
-#define PRE_NT 512   // threads per tile: 8 waves share the 31 KB of LDS (4 tiles per CU = 8 waves per SIMD); 256 / 384 / 448 / 512 / 1024: 16.3 / 14.7 / 15.1 / 13.5 / 18.9 ms per 4096 frames
-#endif
+// (PRE_TW, PRE_TH, PRE_SC, PRE_SR, PRE_NT: lsd_geom.h -- the host sizes the launch and checks the geometry with the same constants)
 __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, float *__restrict__ ang,
                                                  double *__restrict__ modgrad, double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g,
                                                  LsdTaps t, const int *__restrict__ xofs, const float2 *__restrict__ xa,
@@ -58,7 +52,7 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     // LDS: the row-pass tile (22.5 KB; the column pass overwrites it IN PLACE with the blurred tile -- every thread first reads the 14 rows behind its
     // 8 outputs into registers, one barrier, then writes -- and the list of defined pixels reuses it at the end) + the scaled tile (8.8 KB): 31 KB per
     // workgroup, 4 resident tiles of 8 waves per CU (a separate 18 KB blurred tile made it 40 KB / 3 tiles)
-    __shared__ double s_tmp[(PRE_SR + 6) * PRE_SC];
+    __shared__ double s_tmp[(PRE_SR + 12) * PRE_SC];   // (+6 rows for the row pass, +6 that only keep the column pass's unconditional reads in bounds)
     __shared__ double s_sc[(PRE_TH + 1) * (PRE_TW + 1)];
     double *s_blur = s_tmp;   // blurred row r at s_tmp row r (after the column pass)
     const int f = blockIdx.z, tid = threadIdx.x;
@@ -129,46 +123,64 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         const bool item = cc < nc && rb0 < nr;
         double v[14];
         if (item) {
+            // (no row tests: the 6 spare rows of s_tmp keep rb0 + 13 inside the array; rows past nr + 6 hold stale values and only feed outputs nobody reads)
 #pragma unroll
-            for (int j = 0; j < 14; j++) v[j] = (rb0 + j < nr + 6) ? s_tmp[(rb0 + j) * PRE_SC + cc] : 0.0;
+            for (int j = 0; j < 14; j++) v[j] = s_tmp[(rb0 + j) * PRE_SC + cc];
         }
         __syncthreads();
         if (item) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if (rb0 + j < nr) {
-                    double s_ = t.k[3] * v[j + 3] + 0.0;
+                double s_ = t.k[3] * v[j + 3] + 0.0;
 #pragma unroll
-                    for (int q = 1; q <= 3; q++) s_ += t.k[3 + q] * (v[j + 3 + q] + v[j + 3 - q]);
-                    s_blur[(rb0 + j) * PRE_SC + cc] = s_;
-                }
+                for (int q = 1; q <= 3; q++) s_ += t.k[3 + q] * (v[j + 3 + q] + v[j + 3 - q]);
+                s_blur[(rb0 + j) * PRE_SC + cc] = s_;
             }
         }
     }
     __syncthreads();
     const int ncs = dx1 - dx0 + 1, nrs = dy1 - dy0 + 1;
-    for (int i = tid; i < nrs * (PRE_TW + 1); i += PRE_NT) {
-        const int ry = i / (PRE_TW + 1), rx = i - ry * (PRE_TW + 1);
-        if (rx >= ncs) continue;
-        const int dx = dx0 + rx, dy = dy0 + ry;
-        const int sx = xofs[dx] - c_lo, sy = yofs[dy];
-        const float2 a = xa[dx], b = yb[dy];
-        const double *S0 = s_blur + (min(max(sy, 0), g.h - 1) - r_lo) * PRE_SC, *S1 = s_blur + (min(max(sy + 1, 0), g.h - 1) - r_lo) * PRE_SC;
-        double r0, r1;
-        if (dx < g.xmax) {
-            r0 = S0[sx] * (double)a.x + S0[sx + 1] * (double)a.y;
-            r1 = S1[sx] * (double)a.x + S1[sx + 1] * (double)a.y;
-        } else {
-            r0 = S0[sx] * 1.0;
-            r1 = S1[sx] * 1.0;
+    {
+        // resize: a lane owns one column of the scaled tile (its source column and coefficients are loaded once), a wave walks rows -- the row's source rows
+        // and coefficients are wave-uniform (scalar loads); per pixel two LDS reads of two doubles and the nine products / sums of cv::resize.
+        // (One item per (row, column) with the four table loads per pixel was 60 instructions per pixel, a sixth of the kernel.)
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        auto px = [&](int rx, int sx, double ax, double ay, bool lin, int ry, int sy, float2 b) {
+            const double *S0 = s_blur + (min(max(sy, 0), g.h - 1) - r_lo) * PRE_SC + sx, *S1 = s_blur + (min(max(sy + 1, 0), g.h - 1) - r_lo) * PRE_SC + sx;
+            double r0, r1;
+            if (lin) {
+                r0 = S0[0] * ax + S0[1] * ay;
+                r1 = S1[0] * ax + S1[1] * ay;
+            } else {
+                r0 = S0[0] * 1.0;
+                r1 = S1[0] * 1.0;
+            }
+            s_sc[ry * (PRE_TW + 1) + rx] = r0 * (double)b.x + r1 * (double)b.y;
+        };
+        if (lane < ncs) {
+            const int dx = dx0 + lane, sx = xofs[dx] - c_lo;
+            const float2 a = xa[dx];
+            const double ax = (double)a.x, ay = (double)a.y;
+            const bool lin = dx < g.xmax;
+            for (int ry = wv; ry < nrs; ry += PRE_NT / 64) px(lane, sx, ax, ay, lin, ry, yofs[dy0 + ry], yb[dy0 + ry]);
         }
-        s_sc[i] = r0 * (double)b.x + r1 * (double)b.y;
+        if (wv == PRE_NT / 64 - 1 && ncs == PRE_TW + 1 && lane < nrs) {   // the 65th column (the gradient's right neighbour), one lane per row
+            const int dx = dx0 + PRE_TW;
+            const float2 a = xa[dx];
+            px(PRE_TW, xofs[dx] - c_lo, (double)a.x, (double)a.y, dx < g.xmax, lane, yofs[dy0 + lane], yb[dy0 + lane]);
+        }
     }
     __syncthreads();
-    // ll_angle for the tile; the pixels with a defined angle are compacted (wave ballots) into an LDS list so that the double-precision sincos
-    // below runs on full waves (about a quarter of the pixels have a gradient above the threshold)
+    // ll_angle for the tile.  Only the 2x2 gradient and its squared norm are computed for every pixel: norm = sqrt(q) <= rho (no level-line angle) is decided
+    // on q itself -- sqrt is correctly rounded and monotone, so sqrt(q) <= rho  <=>  q <= g.rho_q, the largest double whose root does not exceed rho (found
+    // on the host) -- and the pixels with a defined angle (about a quarter) are compacted (wave ballots) into LDS lists, so that the double-precision sqrt,
+    // fastAtan2 and sincos below run on full waves of defined pixels only.  modgrad is written for those pixels alone: nothing reads it elsewhere
+    // (region2rect weighs region points, k_lsd_maxgrad / k_lsd_seedkeys test the angle first).
     __shared__ int s_ndef;
-    float2 *s_list = reinterpret_cast<float2 *>(s_tmp);   // (offset inside the frame, angle in degrees); the blurred tile is dead after the resize
+    double *s_q = s_tmp;                                         // the blurred tile is dead after the resize: q, offset inside the frame, (float)gx, (float)-gy
+    int *s_off = reinterpret_cast<int *>(s_tmp + PRE_TW * PRE_TH);
+    float *s_fx = reinterpret_cast<float *>(s_off + PRE_TW * PRE_TH), *s_fy = s_fx + PRE_TW * PRE_TH;
+    static_assert((PRE_SR + 12) * PRE_SC * 8 >= PRE_TW * PRE_TH * 20, "the lists of defined pixels fit the row-pass tile");
     if (tid == 0) s_ndef = 0;
     __syncthreads();
     const int tx = tid & 63;
@@ -178,37 +190,37 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         if (PRE_TH % (PRE_NT / 64) != 0 && ty >= PRE_TH) break;
         const int x = dx0 + tx, y = dy0 + ty;
         bool def = false;
-        float deg = 0.f;
-        const size_t o = (size_t)f * g.s_stride + (size_t)y * g.sw + x;
+        double q = 0.0;
+        float fx = 0.f, fy = 0.f;
         if (x < g.sw && y < g.sh) {
-            if (x == g.sw - 1 || y == g.sh - 1) { ang[o] = NOTDEF_F; modgrad[o] = 0.0; }
-            else {
+            if (x < g.sw - 1 && y < g.sh - 1) {
                 const double *im = s_sc + ty * (PRE_TW + 1) + tx;
                 const double DA = im[PRE_TW + 2] - im[0];
                 const double BC = im[1] - im[PRE_TW + 1];
                 const double gx = DA + BC, gy = DA - BC;
-                const double norm = sqrt((gx * gx + gy * gy) / 4);
-                modgrad[o] = norm;
-                if (norm <= g.rho) ang[o] = NOTDEF_F;
-                else {
-                    deg = plf_fast_atan2((float)gx, (float)-gy);
-                    ang[o] = deg;
-                    def = true;
-                }
+                q = (gx * gx + gy * gy) / 4;
+                def = q > g.rho_q;
+                fx = (float)gx; fy = (float)-gy;
             }
+            if (!def) ang[(size_t)f * g.s_stride + (size_t)y * g.sw + x] = NOTDEF_F;
         }
         const unsigned long long m = __ballot(def);
         int base = 0;
         if (plf_lane() == 0 && m) base = atomicAdd(&s_ndef, __popcll(m));
         base = __shfl(base, 0, 64);
-        if (def) s_list[base + __popcll(m & ((1ull << plf_lane()) - 1ull))] = make_float2(__int_as_float(y * g.sw + x), deg);
+        if (def) {
+            const int e = base + __popcll(m & ((1ull << plf_lane()) - 1ull));
+            s_q[e] = q; s_off[e] = y * g.sw + x; s_fx[e] = fx; s_fy[e] = fy;
+        }
     }
     __syncthreads();
     const int ndef = s_ndef;
     for (int i = tid; i < ndef; i += PRE_NT) {
-        const float2 e = s_list[i];
-        const size_t o = (size_t)f * g.s_stride + (size_t)__float_as_int(e.x);
-        const double ad = (double)e.y * DEG2RAD_D;
+        const size_t o = (size_t)f * g.s_stride + (size_t)s_off[i];
+        modgrad[o] = sqrt(s_q[i]);
+        const float deg = plf_fast_atan2(s_fx[i], s_fy[i]);
+        ang[o] = deg;
+        const double ad = (double)deg * DEG2RAD_D;
         const double af = (double)(float)ad;
         double sf, cf;
         sincos(af, &sf, &cf);   // cs: cos / sin of the FLOAT-rounded angle, the increments region_grow adds
@@ -245,7 +257,7 @@ __global__ void __launch_bounds__(256) k_lsd_maxgrad(const float *__restrict__ a
     if (t == 0) maxgrad[f] = red[0];
 }
 
-__global__ void __launch_bounds__(256) k_lsd_seedkeys(const double *__restrict__ modgrad_all, const double *__restrict__ maxgrad,
+__global__ void __launch_bounds__(256) k_lsd_seedkeys(const float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double *__restrict__ maxgrad,
                                                       uint32_t *__restrict__ keys_all, LsdGeom g)
 {
     const int a = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y, NP = g.sw * g.sh;
@@ -253,8 +265,8 @@ __global__ void __launch_bounds__(256) k_lsd_seedkeys(const double *__restrict__
     const double mx = maxgrad[f];
     const double bin_coef = (mx > 0) ? 1023.0 / mx : 0.0;
     const int x = a % g.sw, y = a / g.sw;
-    int b = 0;   // last row / column: never seeds (angle NOTDEF), parked in the weakest bin
-    if (x < g.sw - 1 && y < g.sh - 1) {
+    int b = 0;   // pixels without a level-line angle (the last row / column among them) never seed and have no modgrad: parked in the weakest bin
+    if (x < g.sw - 1 && y < g.sh - 1 && ang_all[(size_t)f * g.s_stride + a] != NOTDEF_F) {
         b = (int)(modgrad_all[(size_t)f * g.s_stride + a] * bin_coef);
         if (b > 1023) b = 1023;
     }
