@@ -19,7 +19,7 @@ struct LbdCoefs { float gL[21]; float gG[63]; };  // (float) of the double LBD b
 // PRE_SC x PRE_SR blurred source pixels (checked on the host for the actual geometry) and 6 more rows of the row pass
 #define PRE_TW 64
 #ifndef PRE_TH
-#define PRE_TH 16
+#define PRE_TH 24   // 16 / 24 rows: 16.9 / 15.6 ms per 8192 frames (the row pass reads 6 extra rows per tile, the column pass works in bands of 8 source rows); 32 rows x 1024 threads: 21.5
 #endif
 #define PRE_SC 88
 #ifndef PRE_SR

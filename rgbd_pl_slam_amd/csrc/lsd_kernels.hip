@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     // LDS: the row-pass tile (22.5 KB; the column pass overwrites it IN PLACE with the blurred tile -- every thread first reads the 14 rows behind its
     // 8 outputs into registers, one barrier, then writes -- and the list of defined pixels reuses it at the end) + the scaled tile (8.8 KB): 31 KB per
     // workgroup, 4 resident tiles of 8 waves per CU (a separate 18 KB blurred tile made it 40 KB / 3 tiles)
-    __shared__ double s_tmp[(PRE_SR + 12) * PRE_SC];   // (+6 rows for the row pass, +6 that only keep the column pass's unconditional reads in bounds)
+    constexpr int PRE_TMP = (PRE_SR + 12) * PRE_SC * 8 >= PRE_TW * PRE_TH * 20 ? (PRE_SR + 12) * PRE_SC : (PRE_TW * PRE_TH * 20 + 7) / 8;
+    __shared__ double s_tmp[PRE_TMP];   // (+6 rows for the row pass, +6 that only keep the column pass's unconditional reads in bounds)
     __shared__ double s_sc[(PRE_TH + 1) * (PRE_TW + 1)];
     double *s_blur = s_tmp;   // blurred row r at s_tmp row r (after the column pass)
     const int f = blockIdx.z, tid = threadIdx.x;
@@ -180,13 +181,13 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     double *s_q = s_tmp;                                         // the blurred tile is dead after the resize: q, offset inside the frame, (float)gx, (float)-gy
     int *s_off = reinterpret_cast<int *>(s_tmp + PRE_TW * PRE_TH);
     float *s_fx = reinterpret_cast<float *>(s_off + PRE_TW * PRE_TH), *s_fy = s_fx + PRE_TW * PRE_TH;
-    static_assert((PRE_SR + 12) * PRE_SC * 8 >= PRE_TW * PRE_TH * 20, "the lists of defined pixels fit the row-pass tile");
     if (tid == 0) s_ndef = 0;
     __syncthreads();
     const int tx = tid & 63;
+    float *angf = ang + (size_t)f * g.s_stride;
 #pragma unroll
     for (int k = 0; k < (PRE_TH + PRE_NT / 64 - 1) / (PRE_NT / 64); k++) {
-        const int ty = (tid >> 6) + (PRE_NT / 64) * k;   // (wave-uniform)
+        const int ty = __builtin_amdgcn_readfirstlane(tid >> 6) + (PRE_NT / 64) * k;
         if (PRE_TH % (PRE_NT / 64) != 0 && ty >= PRE_TH) break;
         const int x = dx0 + tx, y = dy0 + ty;
         bool def = false;
@@ -202,12 +203,12 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
                 def = q > g.rho_q;
                 fx = (float)gx; fy = (float)-gy;
             }
-            if (!def) ang[(size_t)f * g.s_stride + (size_t)y * g.sw + x] = NOTDEF_F;
+            if (!def) angf[(unsigned)(y * g.sw + x)] = NOTDEF_F;
         }
         const unsigned long long m = __ballot(def);
         int base = 0;
         if (plf_lane() == 0 && m) base = atomicAdd(&s_ndef, __popcll(m));
-        base = __shfl(base, 0, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
         if (def) {
             const int e = base + __popcll(m & ((1ull << plf_lane()) - 1ull));
             s_q[e] = q; s_off[e] = y * g.sw + x; s_fx[e] = fx; s_fy[e] = fy;
@@ -215,20 +216,23 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     }
     __syncthreads();
     const int ndef = s_ndef;
+    double *mgf = modgrad + (size_t)f * g.s_stride;
+    double2 *csf = cs + (size_t)f * g.s_stride;
+    float2 *cs0f = cs0 + (size_t)f * g.s_stride;
     for (int i = tid; i < ndef; i += PRE_NT) {
-        const size_t o = (size_t)f * g.s_stride + (size_t)s_off[i];
-        modgrad[o] = sqrt(s_q[i]);
-        const float deg = plf_fast_atan2(s_fx[i], s_fy[i]);
-        ang[o] = deg;
+        const unsigned o = (unsigned)s_off[i];   // (32-bit offsets from the frame's scalar base pointers)
+        mgf[o] = sqrt(s_q[i]);
+        const float deg = plf_fast_atan2_1div(s_fx[i], s_fy[i]);
+        angf[o] = deg;
         const double ad = (double)deg * DEG2RAD_D;
         const double af = (double)(float)ad;
         double sf, cf;
         sincos(af, &sf, &cf);   // cs: cos / sin of the FLOAT-rounded angle, the increments region_grow adds
-        cs[o] = make_double2(cf, sf);
+        csf[o] = make_double2(cf, sf);
         // cs0: float(cos(ad)), float(sin(ad)) of the un-rounded angle.  ad = af + eps with |eps| <= 2^-25 |ad|: the second-order expansion around af is
         // within ~2 ulp (double) of cos / sin (ad), i.e. as close to the correctly rounded value as a second libm call is, at a twentieth of its cost
         const double eps = ad - af, h = 0.5 * eps * eps;
-        cs0[o] = make_float2((float)(cf - eps * sf - h * cf), (float)(sf + eps * cf - h * sf));
+        cs0f[o] = make_float2((float)(cf - eps * sf - h * cf), (float)(sf + eps * cf - h * sf));
     }
 }
 

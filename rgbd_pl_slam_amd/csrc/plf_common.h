@@ -100,6 +100,25 @@ __device__ __forceinline__ float plf_fast_atan2(float y, float x)
     if (y < 0) a = 360.f - a;
     return a;
 }
+// the same arithmetic with ONE division (the two branches above each carry their own ~12-instruction IEEE division): numerator = the smaller of |x|, |y|,
+// denominator = the larger + eps; for |x| == |y| both forms divide the same numbers
+__device__ __forceinline__ float plf_fast_atan2_1div(float y, float x)
+{
+    const float p1 = (float)(0.9997878412794807 * (180 / 3.14159265358979323846));
+    const float p3 = (float)(-0.3258083974640975 * (180 / 3.14159265358979323846));
+    const float p5 = (float)(0.1555786518463281 * (180 / 3.14159265358979323846));
+    const float p7 = (float)(-0.04432655554792128 * (180 / 3.14159265358979323846));
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool xge = ax >= ay;
+    const float c = __fdiv_rn(xge ? ay : ax, (xge ? ax : ay) + eps);
+    const float c2 = c * c;
+    const float t = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = xge ? t : 90.f - t;
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
 
 // sincosf as the reference's libm computes it (glibc >= 2.28 sysdeps/ieee754/flt-32/s_sincosf.c: quadrant
 // reduction and two degree-7/8 polynomials evaluated in double, result rounded to float).  The reference
