@@ -478,7 +478,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (h->prm.lbd_sobel_input == PLF_LBD_RAW)
         hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
     else
-        hipLaunchKernelGGL(k_blur5_sobel3, dim3((g.w + 63) / 64, (g.h + 15) / 16, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g, h->blur5);
+        hipLaunchKernelGGL(k_blur5_sobel3, dim3((g.w + BS_TW - 1) / BS_TW, (g.h + BS_TH - 1) / BS_TH, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g, h->blur5);
     if (!h->ev_front) PLF_HIP_TRY(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
     PLF_HIP_TRY(hipEventRecord(h->ev_front, s));
     h->ev_front_set = true;

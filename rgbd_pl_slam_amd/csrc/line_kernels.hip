@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(256) k_sobel3(const uint8_t *__restrict__ in, 
 }
 
 // BinaryDescriptor::computeGaussianPyramid (opencv_contrib 3.3): octave 0 = cv::GaussianBlur(image.clone(), Size(5, 5), 1), then the two
-// cv::Sobel calls read THAT image (plf_line_params.lbd_sobel_input = PLF_LBD_BLURRED).  Fused: a 256-thread block produces a 64 x 16 tile of
-// (dx, dy); the 5-tap row sums (22 x 66), the blurred bytes (18 x 66) and nothing else live in LDS -- the blurred image never reaches HBM.
+// cv::Sobel calls read THAT image (plf_line_params.lbd_sobel_input = PLF_LBD_BLURRED).  Fused: a 256-thread block produces a 64 x BS_TH tile of
+// (dx, dy); the 5-tap row sums (BS_TH + 6 rows x 66), the blurred bytes (BS_TH + 2 rows x 66) and nothing else live in LDS -- the blurred image never reaches HBM.
 // 8U GaussianBlur = 8-bit fixed-point separable filter: taps k5 (14 63 103 63 14), row pass exact int32, column pass sum / 65536 rounded as
 // OpenCV 3.3's SymmColumnVec_32s8u does (half-to-even) for x < (w & ~3) and as its scalar tail ((s + 32768) >> 16) for the last w % 4
 // columns -- the same rule as the 7 x 7 blur of the ORB path (orb_kernels.hip); REFLECT_101 at the image edge for the blur AND for the Sobel.
@@ -153,25 +153,20 @@ __global__ void __launch_bounds__(256) k_sobel3(const uint8_t *__restrict__ in, 
 // 7260 single-byte global loads per tile and ran at 1 TB/s), the 5-tap row sums are one v_dot4_u32_u8 + one multiply-add per pixel on byte windows
 // cut out with v_alignbyte, the column pass reads int4 row-sum vectors, the Sobel reads two dwords per row for 4 pixels.  The staged bytes are already
 // mirrored (REFLECT_101) at the image border, so the row pass has no border case.
-#define BS_TW 64
-#define BS_TH 16
+// (BS_TW, BS_TH: lsd_geom.h)
 #define BS_RAWW 80   // staged bytes per row: image x0 - 4 .. x0 + 75
 #define BS_RSW 68    // row sums per row:    image x0 - 1 .. x0 + 66 (66 used)
 #define BS_BLW 72    // blurred bytes per row: image x0 - 1 .. (68 written, 66 used)
-__global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, short2 *__restrict__ grad,
-                                                      LsdGeom g, int4 k5 /* k[0], k[1], k[2] */)
+// INNER: the tile's rows y0 - 3 .. y0 + BS_TH + 2 all lie inside the image (every tile but the first and last row of tiles): no row is reflected, no row test
+template <bool INNER>
+__device__ __forceinline__ void blur5_sobel3_tile(const uint8_t *__restrict__ img, ptrdiff_t pitch, short2 *__restrict__ gout, int W, int H, int x0, int y0, int t, int4 k5,
+                                                  uint8_t (*raw)[BS_RAWW], int (*rows)[BS_RSW], uint8_t (*blur)[BS_BLW])
 {
-    __shared__ __attribute__((aligned(16))) uint8_t raw[BS_TH + 6][BS_RAWW];   // image (x0 - 4 + i, y0 - 3 + r)
-    __shared__ __attribute__((aligned(16))) int rows[BS_TH + 6][BS_RSW];       // row sums at image (x0 - 1 + c, y0 - 3 + r)
-    __shared__ __attribute__((aligned(16))) uint8_t blur[BS_TH + 2][BS_BLW];   // blurred bytes at image (x0 - 1 + c, y0 - 1 + r)
-    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH, f = blockIdx.z, t = threadIdx.x;
-    const int W = g.w, H = g.h;
-    const uint8_t *img = in + (size_t)f * fstride;
     // ---- 0. raw bytes, mirrored in x
     for (int i = t; i < (BS_TH + 6) * (BS_RAWW / 4); i += 256) {
         const int r = i / (BS_RAWW / 4), i4 = i - r * (BS_RAWW / 4);
         const int Y = y0 - 3 + r, X4 = x0 - 4 + 4 * i4;
-        if (Y < 0 || Y >= H) continue;   // only reached through reflection, which lands inside the image
+        if (!INNER && (Y < 0 || Y >= H)) continue;   // only reached through reflection, which lands inside the image
         const uint8_t *S = img + (size_t)Y * pitch;
         uint32_t v;
         if (X4 >= 0 && X4 + 3 < W) v = *(const plf_u32u *)(S + X4);
@@ -189,7 +184,7 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
         for (int i = t; i < (BS_TH + 6) * (BS_RSW / 4); i += 256) {
             const int r = i / (BS_RSW / 4), g4 = i - r * (BS_RSW / 4);
             const int Y = y0 - 3 + r;
-            if (Y < 0 || Y >= H) continue;
+            if (!INNER && (Y < 0 || Y >= H)) continue;
             const uint32_t *rp = reinterpret_cast<const uint32_t *>(&raw[r][4 * g4]);
             const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
             int4 o;
@@ -207,8 +202,8 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
         for (int i = t; i < (BS_TH + 2) * (BS_RSW / 4); i += 256) {
             const int r = i / (BS_RSW / 4), g4 = i - r * (BS_RSW / 4);
             const int Y = y0 - 1 + r;
-            if (Y < 0 || Y >= H) continue;
-#define ROW_(yy) (*reinterpret_cast<const int4 *>(&rows[plf_reflect101((yy), H) - (y0 - 3)][4 * g4]))
+            if (!INNER && (Y < 0 || Y >= H)) continue;
+#define ROW_(yy) (*reinterpret_cast<const int4 *>(&rows[(INNER ? (yy) : plf_reflect101((yy), H)) - (y0 - 3)][4 * g4]))
             const int4 a = ROW_(Y - 2), b = ROW_(Y - 1), c = ROW_(Y), d = ROW_(Y + 1), e = ROW_(Y + 2);
 #undef ROW_
             const int sv[4] = {k5.x * (a.x + e.x) + k5.y * (b.x + d.x) + k5.z * c.x, k5.x * (a.y + e.y) + k5.y * (b.y + d.y) + k5.z * c.y,
@@ -225,13 +220,13 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
         }
     }
     __syncthreads();
-    // ---- 3. the two 3 x 3 Sobel derivatives of the blurred image, 4 pixels per thread (16 rows x 16 groups = one item each)
-    {
-        const int ry = t >> 4, cx = (t & 15) * 4;
+    // ---- 3. the two 3 x 3 Sobel derivatives of the blurred image, 4 pixels per item (BS_TH rows x 16 groups)
+    for (int it = t; it < BS_TH * 16; it += 256) {
+        const int ry = it >> 4, cx = (it & 15) * 4;
         const int x = x0 + cx, y = y0 + ry;
-        if (x >= W || y >= H) return;
-        const int ym = plf_reflect101(y - 1, H) - (y0 - 1), yc = ry + 1, yp = plf_reflect101(y + 1, H) - (y0 - 1);
-        short2 *out = grad + (size_t)f * g.full_stride + (size_t)y * W + x;
+        if (x >= W || y >= H) continue;
+        const int ym = INNER ? ry : plf_reflect101(y - 1, H) - (y0 - 1), yc = ry + 1, yp = INNER ? ry + 2 : plf_reflect101(y + 1, H) - (y0 - 1);
+        short2 *out = gout + (size_t)y * W + x;
         if (x >= 1 && x + 4 < W) {   // blurred columns x - 1 .. x + 4 exist: blur[][cx .. cx + 5]
             // Packed 16-bit lanes (round 4; the scalar form extracted 36 bytes and did ~100 instructions per 4 pixels, a third of the kernel): the bytes b0..b5 of
             // a row as pairs P01 P23 P45 (and Q12 Q34 for the rows' own sums), column sums C = top + 2 mid + bottom per pair, gx[j] = C[j+2] - C[j];
@@ -261,7 +256,7 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
             plf_short8 v;
             v.a = __builtin_bit_cast(short2, o4.x); v.b = __builtin_bit_cast(short2, o4.y); v.c = __builtin_bit_cast(short2, o4.z); v.d = __builtin_bit_cast(short2, o4.w);
             *(plf_short8 *)out = v;
-            return;
+            continue;
         }
         for (int j = 0; j < 4 && x + j < W; j++) {
             const int xx = x + j;
@@ -271,6 +266,19 @@ __global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict_
             out[j] = make_short2((short)gx, (short)gy);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_blur5_sobel3(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, short2 *__restrict__ grad,
+                                                      LsdGeom g, int4 k5 /* k[0], k[1], k[2] */)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t raw[BS_TH + 6][BS_RAWW];   // image (x0 - 4 + i, y0 - 3 + r)
+    __shared__ __attribute__((aligned(16))) int rows[BS_TH + 6][BS_RSW];       // row sums at image (x0 - 1 + c, y0 - 3 + r)
+    __shared__ __attribute__((aligned(16))) uint8_t blur[BS_TH + 2][BS_BLW];   // blurred bytes at image (x0 - 1 + c, y0 - 1 + r)
+    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH, f = blockIdx.z, t = threadIdx.x;
+    const uint8_t *img = in + (size_t)f * fstride;
+    short2 *gout = grad + (size_t)f * g.full_stride;
+    if (y0 >= 3 && y0 + BS_TH + 3 <= g.h) blur5_sobel3_tile<true>(img, pitch, gout, g.w, g.h, x0, y0, t, k5, raw, rows, blur);
+    else blur5_sobel3_tile<false>(img, pitch, gout, g.w, g.h, x0, y0, t, k5, raw, rows, blur);
 }
 
 __constant__ int c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3, 2, 4, 2, 5, 2, 6, 2, 7,

@@ -29,6 +29,12 @@ struct LbdCoefs { float gL[21]; float gG[63]; };  // (float) of the double LBD b
 #define PRE_NT 512   // 8 waves share the tile's LDS (4 tiles per CU = 8 waves per SIMD); 256 / 384 / 448 / 512 / 1024 threads: 16.3 / 14.7 / 15.1 / 13.5 / 18.9 ms per 4096 frames (round 2)
 #endif
 
+// k_blur5_sobel3: 256 threads produce a BS_TW x BS_TH tile of (dx, dy)
+#define BS_TW 64
+#ifndef BS_TH
+#define BS_TH 32
+#endif
+
 struct LsdGeom {
     int w, h;             // input image
     int sw, sh;           // 0.8x scaled image
