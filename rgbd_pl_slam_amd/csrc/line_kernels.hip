@@ -299,6 +299,16 @@ __device__ __forceinline__ float lbd_bcast(float lo, float hi, int j)   // entry
 {
     return __int_as_float(j < 64 ? __builtin_amdgcn_readlane(__float_as_int(lo), j) : __builtin_amdgcn_readlane(__float_as_int(hi), j - 64));
 }
+// (short)(int)roundf(v) clamped to [0, hi] as computeLBD does.  roundf rounds halves away from zero; for v >= 0 that is trunc(v) + (v - trunc(v) >= 0.5) -- the
+// difference is exact in float -- and every negative v ends at 0 after the clamp either way (trunc(v) <= 0, no increment).  Coordinates are far inside the
+// range of short (line_configure bounds the image size), so the wrap of the cast never acts.
+__device__ __forceinline__ short lbd_round_clamp(float v, short hi)
+{
+    const float tr = truncf(v);
+    int r = (short)((int)tr + ((v - tr >= 0.5f) ? 1 : 0));   // (the reference's cast, kept: one v_bfe_i32)
+    r = r < 0 ? 0 : r;
+    return (short)(r > (int)hi ? (int)hi : r);
+}
 __global__ void PLF_LBD_OCC __launch_bounds__(64) k_lbd(const short2 *__restrict__ grad_all, const plf_keyline *__restrict__ lines,
                                                         const int *__restrict__ n_out, uint8_t *__restrict__ desc, int capacity, LsdGeom g,
                                                         const LbdCoefs *__restrict__ cf)
@@ -328,10 +338,7 @@ __global__ void PLF_LBD_OCC __launch_bounds__(64) k_lbd(const short2 *__restrict
             short2 d[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                short tempCor = (short)(int)roundf(sCorX);
-                const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
-                tempCor = (short)(int)roundf(sCorY);
-                const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+                const short xCor = lbd_round_clamp(sCorX, imageWidth), yCor = lbd_round_clamp(sCorY, imageHeight);
                 d[q] = grad[(int)yCor * realWidth + (int)xCor];   // (steps past the end of the row read a clamped, valid address and are not accumulated)
                 sCorX += dL0;
                 sCorY += dL1;
@@ -341,8 +348,10 @@ __global__ void PLF_LBD_OCC __launch_bounds__(64) k_lbd(const short2 *__restrict
                 if (w0 + q < len) {
                     const float gDL = (float)d[q].x * dL0 + (float)d[q].y * dL1;
                     const float gDO = (float)d[q].x * dO0 + (float)d[q].y * dO1;
-                    if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
-                    if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
+                    // (if (g > 0) p += g; else n -= g;  as two unconditional additions: the sums start at +0 and only ever receive non-negative terms, so adding
+                    // +0 leaves them unchanged bit for bit, and max(-g, 0) is -g exactly when the reference subtracts a negative g)
+                    pgdL += fmaxf(gDL, 0.f); ngdL += fmaxf(-gDL, 0.f);
+                    pgdO += fmaxf(gDO, 0.f); ngdO += fmaxf(-gDO, 0.f);
                 }
             }
         }

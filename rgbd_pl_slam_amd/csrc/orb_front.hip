@@ -402,6 +402,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                     const int lo = rx0 - (ex0 + c4), hi = rx1 - (ex0 + c4);
                     poss &= (hi >= 4 ? 15u : (1u << max(hi, 0)) - 1u) & ~((1u << min(max(lo, 0), 4)) - 1u);
                 }
+#ifdef OF_COMPACT_BALLOT   // (the round 1-4 form: four ballots, one slot range per wave, raster order inside the wave)
                 const unsigned long long m0 = __ballot(poss & 1u), m1 = __ballot(poss & 2u), m2 = __ballot(poss & 4u), m3 = __ballot(poss & 8u);
                 const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
                 int base = 0;
@@ -413,6 +414,23 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 if (poss & 2u) LIST[base + n0 + __popcll(m1 & below)] = (uint16_t)(e0 + 1);
                 if (poss & 4u) LIST[base + n0 + n1 + __popcll(m2 & below)] = (uint16_t)(e0 + 2);
                 if (poss & 8u) LIST[base + n0 + n1 + n2 + __popcll(m3 & below)] = (uint16_t)(e0 + 3);
+#else
+                // The order of LIST is free (the score goes to S by position, the maxima to bit masks by position), so a group takes its 1-4 slots with one
+                // LDS atomic of its own and writes its survivors there -- a third of the phase's instructions were the four ballots, their prefix counts and
+                // four separately addressed stores.
+                if (poss) {
+                    // (inline asm: the compiler's atomic optimizer turns a divergent atomicAdd into a scalar loop over the active lanes -- ~9 instructions per lane)
+                    int base;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base)
+                                 : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)&s_nlist), "v"(__popc(poss)) : "memory");
+                    const uint32_t e0 = (uint32_t)(c4 | (ry << 8));
+                    uint16_t *L = LIST + base;
+                    if (poss & 1u) L[0] = (uint16_t)e0;
+                    if (poss & 2u) L[poss & 1u] = (uint16_t)(e0 + 1);
+                    if (poss & 4u) L[__popc(poss & 3u)] = (uint16_t)(e0 + 2);
+                    if (poss & 8u) L[__popc(poss & 7u)] = (uint16_t)(e0 + 3);
+                }
+#endif
             }
         }
     }

@@ -20,13 +20,20 @@ typedef uint32_t __attribute__((aligned(1))) plf_u32u;   // dword access at byte
 typedef unsigned long long __attribute__((aligned(1))) plf_u64u;
 struct __attribute__((aligned(4))) plf_int4u { int x, y, z, w; };
 
-__constant__ signed char c_pattern[1024];
-__constant__ int c_umax[16];
+__constant__ signed char c_pattern[1024];   // (as bytes: ONE 16-byte load per lane.  As floats -- four loads -- the key point wave is slower: the kernel is bound by the CU's vector-memory pipe)
+// IC_Angle: the columns u = -16..15 of patch row v that lie inside the disc, |u| <= umax[|v|], as one bit mask per |v| (bit u + 16)
+__constant__ uint32_t c_icmask[16];
 
 void plf_orb_upload_constants(const int *umax16)
 {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), plf_bit_pattern_31, 1024);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+    uint32_t msk[16];
+    for (int v = 0; v < 16; v++) {
+        msk[v] = 0;
+        for (int u = -16; u < 16; u++)
+            if ((u < 0 ? -u : u) <= umax16[v]) msk[v] |= 1u << (u + 16);
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_icmask), msk, sizeof(msk));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -74,24 +81,21 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
     int m10 = 0, m01 = 0;
     if (lane < PLF_PATCH) {
         const int v = lane - PLF_HALF_PATCH;
-        const int d = c_umax[v < 0 ? -v : v];
         // the row segment u = -16..15 as 8 dwords (the padded plane has 19 border pixels) and two byte dot products per
-        // dword: sum (u + 16) * I and sum I over |u| <= d, so m10 = sum u * I = first - 16 * second (exact integers)
+        // dword: sum (u + 16) * I and sum I over |u| <= umax[|v|], so m10 = sum u * I = first - 16 * second (exact integers)
         const uint8_t *row = center + (ptrdiff_t)v * L.ppitch - 16;
+        // per dword q: the row mask's nibble spread to a byte mask (n * 0x00204081 puts bit k of n at bit 8 k), the pixels outside the disc zeroed, then the
+        // two dot products against constants.  (Round 1-4 built weight words per lane from compile-time u and a run-time umax: ~130 of a key point's ~450
+        // vector instructions; a table of the words in memory cost four more 16-byte loads per lane and made the kernel SLOWER, 8.0 -> 9.5 ms.)
+        const uint32_t M = c_icmask[v < 0 ? -v : v];
         uint32_t sw = 0, si = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t px4 = *(const plf_u32u *)(row + 4 * q);
-            uint32_t wgt = 0, one = 0;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int u = 4 * q + e - 16;
-                const bool in = (u < 0 ? -u : u) <= d;
-                wgt |= (in ? (uint32_t)(u + 16) : 0u) << (8 * e);
-                one |= (in ? 1u : 0u) << (8 * e);
-            }
-            sw = __builtin_amdgcn_udot4(px4, wgt, sw, false);
-            si = __builtin_amdgcn_udot4(px4, one, si, false);
+            const uint32_t bm = ((((M >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            const uint32_t pm = px4 & bm;
+            sw = __builtin_amdgcn_udot4(pm, 0x03020100u + 0x04040404u * (uint32_t)q, sw, false);
+            si = __builtin_amdgcn_udot4(pm, 0x01010101u, si, false);
         }
         m10 = (int)sw - 16 * (int)si;
         m01 = v * (int)si;
@@ -116,9 +120,9 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
     }
     // lane j holds bits 4j..4j+3 -> nibble (j&1) of byte j>>1; assemble dwords in lanes 0,8,16,..
     uint32_t v = bits << (4 * (lane & 7));
-    v |= __shfl_xor(v, 1, 64);
-    v |= __shfl_xor(v, 2, 64);
-    v |= __shfl_xor(v, 4, 64);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // lanes i ^ 1 (quad_perm [1, 0, 3, 2])
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // lanes i ^ 2: the quad is complete
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror: a lane of the other quad of the group of 8
     if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + ((size_t)f * capacity + o) * 32)[lane >> 3] = v;
     if (lane == 0) {
         plf_keypoint kp;

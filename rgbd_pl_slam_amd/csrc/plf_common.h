@@ -24,11 +24,15 @@ static inline size_t plf_align_up(size_t v, size_t a) { return (v + a - 1) / a *
 // ---- wave-level helpers (64 lanes)
 __device__ __forceinline__ int plf_lane() { return threadIdx.x & 63; }
 
+// sum over the 64 lanes (all of them active), result wave-uniform: four DPP steps leave every lane of a row of 16 with its row's sum, four v_readlane add the
+// rows on the scalar unit.  (The butterfly over __shfl_xor was six ds_bpermute round trips with their address arithmetic and waits.)
 __device__ __forceinline__ int plf_wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2, 3, 0, 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // exclusive prefix sum across the 64 lanes of a wave
