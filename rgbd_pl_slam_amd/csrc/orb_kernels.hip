@@ -61,9 +61,11 @@ __global__ void __launch_bounds__(64) k_orient_brief(const uint8_t *__restrict__
     const int f = 8 * (int)blockIdx.y + ((int)blockIdx.x & 7), o = (int)blockIdx.x >> 3;
     if (f >= nframes) return;
     const int *cnt = selcnt + f * g.nlevels;
+    // (the per-level counts in ONE vector load, lane i = level i, walked with v_readlane: the scalar loop it replaces waited for eight dependent scalar loads)
+    const int cl = lane < g.nlevels ? cnt[lane] : 0;
     int offset = 0, total = 0, l = -1;
     for (int i = 0; i < g.nlevels; i++) {
-        const int c = cnt[i];
+        const int c = __builtin_amdgcn_readlane(cl, i);
         if (l < 0 && o < total + c) { l = i; offset = total; }
         total += c;
     }
