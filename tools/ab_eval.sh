@@ -1,4 +1,5 @@
 #!/bin/bash
+# (PLF_NFA_EVAL_BLOCKS and the ev64 / evw8 libraries belong to an experiment patch that was not kept -- profiles/r04_prepass_ab.txt has its record; the script documents how it was measured)
 # tools/ab_eval.sh: the starved k_nfa_eval launch of the overlapped step (profiles/r04_timeline.txt) under different launch shapes.  Run ON the GPU box.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 run() {  # name, env..., then bench
