@@ -193,6 +193,29 @@ def test_lines_tiny_images(w, h):
     ls.close()
 
 
+@pytest.mark.parametrize("h", [29, 30, 31, 59, 60, 61, 64, 65, 96, 97, 121])
+def test_lines_heights_around_the_tile_rows_of_the_pre_pass(h):
+    """k_lsd_pre works on 64 x 24 tiles of the 0.8x scaled image and k_blur5_sobel3 on 64 x 32 tiles of the input, with a copy of the body for interior tiles
+    (no row reflection): heights whose scaled size ends just before / on / just after a tile row (24, 48 scaled rows = 30, 60 input rows; 32, 64, 96 input rows),
+    both LBD inputs, both seed orders (the published order reads modgrad, which the pre-pass only writes where the level-line angle is defined)."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    rng = np.random.default_rng(100 + h)
+    w = 200
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (((xx // 9 + yy // 6) & 1) * 150 + ((xx + 2 * yy) % 40) + 20 + rng.integers(0, 10, (h, w))).astype(np.uint8)
+    for sobel_in in (0, 1):
+        for seed_order in (0, 1):
+            ext = LineSegment(nlines=40, max_width=w, max_height=h, lbd_sobel_input=sobel_in, seed_order=seed_order)
+            kl, desc, eq = ext.ExtractLineSegment(img)
+            segs = ext.segments(0)
+            ref_seg = orc.lsd_detect(img, seed_order=seed_order)["lines"]
+            ref = orc.line_extract(img, 40, lbd_sobel_input=sobel_in, seed_order=seed_order)
+            assert len(segs) == len(ref_seg) and np.array_equal(segs.view(np.uint32), ref_seg.view(np.uint32)), (h, sobel_in, seed_order)
+            assert len(kl) == len(ref["kl"]) and kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"]), (h, sobel_in, seed_order)
+            ext.close()
+
+
 def test_line_and_matcher_errors():
     """argument errors come back as PLF_E_BADARG (never a crash, never a silent wrong answer); an empty image is the
     reference's silent return (PLF_E_EMPTY, outputs untouched)"""
