@@ -206,14 +206,15 @@ __device__ __forceinline__ void blur5_sobel3_tile(const uint8_t *__restrict__ im
 #define ROW_(yy) (*reinterpret_cast<const int4 *>(&rows[(INNER ? (yy) : plf_reflect101((yy), H)) - (y0 - 3)][4 * g4]))
             const int4 a = ROW_(Y - 2), b = ROW_(Y - 1), c = ROW_(Y), d = ROW_(Y + 1), e = ROW_(Y + 2);
 #undef ROW_
-            const int sv[4] = {k5.x * (a.x + e.x) + k5.y * (b.x + d.x) + k5.z * c.x, k5.x * (a.y + e.y) + k5.y * (b.y + d.y) + k5.z * c.y,
-                               k5.x * (a.z + e.z) + k5.y * (b.z + d.z) + k5.z * c.z, k5.x * (a.w + e.w) + k5.y * (b.w + d.w) + k5.z * c.w};
+#define COL_(m) ((int)(__umul24(k5.x, a.m + e.m) + __umul24(k5.y, b.m + d.m) + __umul24(k5.z, c.m)))   // (row sums <= 255 * 257: 24-bit multiplies are exact)
+            const int sv[4] = {COL_(x), COL_(y), COL_(z), COL_(w)};
+#undef COL_
             uint32_t out = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int X = x0 - 1 + 4 * g4 + j, s_ = sv[j];
                 // half to even = (s + 0x7FFF + bit 16 of s) >> 16 (as in the 7x7 blur of the ORB path); the scalar tail rounds half up
-                const int v = (s_ + (X < wvec ? 0x7FFF + ((s_ >> 16) & 1) : 0x8000)) >> 16;
+                const int v = (s_ + 0x7FFF + (((s_ >> 16) & 1) | (X < wvec ? 0 : 1))) >> 16;
                 out |= (uint32_t)(v > 255 ? 255 : v) << (8 * j);
             }
             *reinterpret_cast<uint32_t *>(&blur[r][4 * g4]) = out;

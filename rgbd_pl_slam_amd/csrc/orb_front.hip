@@ -282,6 +282,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         const int pxs = tx == 0 ? 0 : xs4 + PLF_EDGE, pxe = tx == L.tcx - 1 ? L.ppitch : xe4 + PLF_EDGE;
         const int pys = ty == 0 ? 0 : ys + PLF_EDGE, pye = ty == L.tcy - 1 ? H + 2 * PLF_EDGE : ye + PLF_EDGE;
         uint8_t *plane = pyr + (size_t)f * g.pyr_stride + L.plane_off;
+        const int ppitch = L.ppitch;
         // groups of 4 level columns x4 = 4-aligned, from the one holding plane column pxs to the one holding pxe - 1
         const int xg0 = (pxs - PLF_EDGE) & ~3;
         // A thread owns one group of 4 columns and walks down the rows: what depends on the column only -- whether the group is a plain dword or
@@ -305,7 +306,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             for (int py = pys + trow; py < pye; py += NR) {
                 const int ly = py - PLF_EDGE;
                 const uint8_t *prow = P + (((unsigned)ly < (unsigned)H ? ly : plf_reflect101(ly, H)) - ey0) * PW;
-                uint8_t *d = dcol + (size_t)py * L.ppitch;
+                uint8_t *d = dcol + (size_t)py * ppitch;
                 if (full) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow + (x4 - ex0));
                 else {
 #pragma unroll
@@ -327,8 +328,13 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         const int k0 = taps.x, k1 = taps.y, k2 = taps.z, k3 = taps.w;
         const int OH = ye - ys, ngb = (EW >> 2) - 2, nseg = (OH + 7) >> 3, wvec = W & ~3;
         uint8_t *bp = blur + (size_t)f * g.blur_stride + L.blur_off;
+        const int bpitch = L.bpitch;   // (a local: read through the reference it is re-loaded from the kernel arguments behind every store)
         for (int it = tid; it < ngb * nseg; it += OF_NT) {
             const int seg = it / ngb, c4 = 4 + 4 * (it - seg * ngb), oy0 = seg * 8, x4 = ex0 + c4;
+            // rounding rule per column, settled once per item: 0 = the vector loop's half-to-even, 1 = the scalar tail's half-up (below: branch-free)
+            int tail[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tail[j] = x4 + j < wvec ? 0 : 1;
             int hs[14][4];
 #pragma unroll
             for (int r = 0; r < 14; r++) {
@@ -347,12 +353,15 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 uint32_t bw = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int sm = k0 * (hs[r - 6][j] + hs[r][j]) + k1 * (hs[r - 5][j] + hs[r - 1][j]) + k2 * (hs[r - 4][j] + hs[r - 2][j]) + k3 * hs[r - 3][j];
+                    // (24-bit multiplies: a row sum is at most 255 * 256, a pair of them 17 bits, a tap 6 -- v_mad_u32_u24 chains instead of v_mul_lo_u32 / v_mad_u64_u32)
+                    const int sm = (int)(__umul24(k0, hs[r - 6][j] + hs[r][j]) + __umul24(k1, hs[r - 5][j] + hs[r - 1][j]) + __umul24(k2, hs[r - 4][j] + hs[r - 2][j]) +
+                                         __umul24(k3, hs[r - 3][j]));
                     // SymmColumnVec_32s8u: sum / 65536 rounded half to even for x < (w & ~3); its scalar tail ((sum + 32768) >> 16) for the last w % 4 columns
-                    const int v = x4 + j < wvec ? (sm + 0x7FFF + ((sm >> 16) & 1)) >> 16 : (sm + 32768) >> 16;
+                    // (sm + 0x7FFF + bit 16 of sm) >> 16 in the vector columns, (sm + 0x8000) >> 16 in the tail: one expression, no EXEC region per pixel
+                    const int v = (sm + 0x7FFF + (((sm >> 16) & 1) | tail[j])) >> 16;
                     bw |= (uint32_t)min(v, 255) << (8 * j);
                 }
-                uint8_t *bo = bp + (size_t)(ys + oy) * L.bpitch + x4;
+                uint8_t *bo = bp + (size_t)(ys + oy) * bpitch + x4;
                 if (x4 >= xs4 && x4 + 3 < xe4) *reinterpret_cast<uint32_t *>(bo) = bw;
                 else
                     for (int j = 0; j < 4; j++)
