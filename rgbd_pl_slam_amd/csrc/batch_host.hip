@@ -183,7 +183,8 @@ static void worker_bind_numa(Worker *w)
     CPU_ZERO(&want);
     if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
     int n = 0;
-    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {   // "0-63,128-191"
+    char *save = nullptr;   // (strtok_r: every worker thread parses its own list at the same time -- strtok keeps its position in process-global state: ADVICE r04)
+    for (char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {   // "0-63,128-191"
         int a = -1, b = -1;
         if (sscanf(tok, "%d-%d", &a, &b) == 2) {} else if (sscanf(tok, "%d", &a) == 1) b = a; else continue;
         for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET(c, &cur)) { CPU_SET(c, &want); n++; }   // never beyond what the process may use
@@ -585,7 +586,11 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
             for (int f = 0; f < s.n; f++) s.h_nl[f] = nl[f];
             // the time-budget flags of the failed pass are meaningless as well: those of the redo (collected over its pieces by the line extractor)
             s.h_status[1] &= ~8;
-            if (plf_line_last_status(w->line, w->s_line) == PLF_W_TRUNCATED && plf_line_truncated(w->line, s.h_trunc, s.n) == PLF_OK) s.h_status[1] |= 8;
+            // (the flags are read whatever plf_line_last_status reports: it returns PLF_E_CAPACITY before it looks at the truncation bit, so a redo that clipped lines to
+            // capacity AND ran out of max_ms would otherwise be counted as complete: ADVICE r04)
+            if (w->owner->prm.line.max_ms > 0.f && plf_line_truncated(w->line, s.h_trunc, s.n) == PLF_OK) {
+                for (int f = 0; f < s.n; f++) if (s.h_trunc[f]) { s.h_status[1] |= 8; break; }
+            }
             if (match_lns || J.rgbd) {   // the Frame tail / matches of the failed pass are meaningless: redo them on the fresh lines
                 const size_t K = (size_t)s.n * w->line_cap;
                 W_TRY(hipMemcpyAsync(s.d_lines, s.h_lines, K * sizeof(plf_keyline), hipMemcpyHostToDevice, w->s_out));

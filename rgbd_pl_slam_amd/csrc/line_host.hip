@@ -191,7 +191,7 @@ static void line_free(plf_line *h)
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_nfa_fcnt, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
+                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -448,6 +448,9 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
             if (!strcmp(name, "spec_reccap") && (v < 1 || v > 8192)) return PLF_E_BADARG;
             if (!strcmp(name, "spec_spins") && v < 64) return PLF_E_BADARG;
             if (!strcmp(name, "wpg") && (v < 1 || v > 16)) return PLF_E_BADARG;
+            if (!strcmp(name, "spec_bands") && v != PLF_TUNE_AUTO && (v < 0 || v > 64)) return PLF_E_BADARG;   // (0 / 1: speculation off; the call clamps to what the frame allows)
+            if ((!strcmp(name, "nfa_small") && (v < 0 || v > 2)) || ((!strcmp(name, "nfa_table") || !strcmp(name, "nfa_list") || !strcmp(name, "nfa_two_pass")) && (v < 0 || v > 1)))
+                return PLF_E_BADARG;
             *e.p = v;
             return PLF_OK;
         }
@@ -541,18 +544,18 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // (the band count depends on the batch size -- 48 / 32 / 16 / ... -- and every change used to free and re-allocate hundreds of MB behind a stream
     // synchronisation, e.g. in a loop that mixes 1-frame and 12-frame calls.  The buffers are indexed by (frame * nbands + band) with the CURRENT band count as the
     // stride, so an allocation made for Fr frames x K bands serves every call with B <= Fr and B * nbands <= Fr * K.)
-    if (spec && (h->spec_frames < B || (size_t)B * spec_bands > h->spec_slots || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out))) {
+    if (spec && (h->spec_frames < B || (size_t)B * spec_bands > h->spec_slots || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out) || h->spec.rcap_rec != T.spec_reccap)) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->d_spec_rowcnt};
+                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr; h->d_spec_rowcnt = nullptr;
         size_t Fr = 8;   // frames the buffers are sized for: the batch rounded up to a power of two (~23 MB per VGA frame)
         while (Fr < (size_t)B) Fr <<= 1;
         const size_t K = (size_t)spec_bands;
-        h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.rcap_rec = 8192; h->spec.frames_cap = (int)Fr;
-        h->spec.rcap_rec = T.spec_reccap;   // (test hook: a small value forces the overflow fallback)
+        h->spec.nbands = spec_bands; h->spec.bm_words = bm_words; h->spec.tcap = (int)g.s_stride; h->spec.frames_cap = (int)Fr;
+        h->spec.rcap_rec = T.spec_reccap;   // (8192; test hook: a small value forces the overflow fallback -- a change re-allocates, see the condition above)
         bool ok = hipMalloc((void **)&h->spec.rxy, Fr * K * g.s_stride * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.tl, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc((void **)&h->spec.recs, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
@@ -578,6 +581,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                  hipMalloc((void **)&h->spec.round_state, Fr * 5 * sizeof(int)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.tl2b, Fr * K * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess;
         }
+#ifdef PLF_ROUND_LOG
+        if (ok && zmode && getenv("PLF_LSD_ROUND_LOG")) ok = hipMalloc((void **)&h->spec.round_log, Fr * K * 64 * sizeof(int)) == hipSuccess;
+#endif
         if (!ok) { (void)hipGetLastError(); h->spec_frames = -1; spec = false; zmode = false; }
         else { h->spec_frames = (int)Fr; h->spec_slots = Fr * K; h->spec_sglob_per_band = zmode; }
     }
@@ -621,6 +627,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
             // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;
             // rectangles assembled from the bands' logs; frames that did not reach the fixpoint within the rounds are committed serially (exact either way)
             const int rounds = T.spec_rounds;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
+#ifdef PLF_ROUND_LOG
+            if (h->spec.round_log) PLF_HIP_TRY(hipMemsetAsync(h->spec.round_log, 0, (size_t)h->spec_slots * 64 * sizeof(int), s));
+#endif
             const SpecBufs SBz = h->spec;
             hipLaunchKernelGGL(k_lsd_spec_grow, dim3(spec_bands, B), dim3(256), lds_grow, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, g, SBz);   // (waves 1-3 warm the L2)
             for (int r = 1; r <= rounds; r++) {
@@ -931,11 +940,25 @@ extern "C" int plf_line_debug_spec_stats(plf_line *h, int32_t *out8)
 // last odd round, round that found nothing left to change (0: none within the enqueued rounds), 1 if the frame was finished by the serial commit wave instead}
 extern "C" int plf_line_debug_spec_rounds(plf_line *h, int32_t *out, int32_t n_frames)
 {
-    if (!h || !out || n_frames < 1 || n_frames > h->prm.max_batch || !h->spec.round_state) return PLF_E_BADARG;
+    // (round_state holds frames_cap frames -- the last speculative allocation, not max_batch -- and is only meaningful for the frames of the last call: ADVICE r04)
+    if (!h || !out || n_frames < 1 || n_frames > h->last_frames || n_frames > h->spec.frames_cap || !h->spec.round_state) return PLF_E_BADARG;
     PLF_HIP_TRY(hipDeviceSynchronize());
     PLF_HIP_TRY(hipMemcpy(out, h->spec.round_state, (size_t)n_frames * 4 * sizeof(int), hipMemcpyDeviceToHost));
     return PLF_OK;
 }
+
+#ifdef PLF_ROUND_LOG
+// diagnostics (tools/round_log.py, -DPLF_ROUND_LOG builds): out[((f * nbands + band) * 16 + round - 1) * 4 ..] = {100 MHz ticks, seeds regrown, pixels regrown, records that stood};
+// returns the band count of the last call
+extern "C" int plf_line_debug_round_log(plf_line *h, int32_t *out, int32_t n_frames, int32_t *band_ticks_out)
+{
+    if (!h || !out || !h->spec.round_log || n_frames < 1 || (size_t)n_frames * h->spec.nbands > h->spec_slots) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    PLF_HIP_TRY(hipMemcpy(out, h->spec.round_log, (size_t)n_frames * h->spec.nbands * 64 * sizeof(int), hipMemcpyDeviceToHost));
+    if (band_ticks_out) PLF_HIP_TRY(hipMemcpy(band_ticks_out, h->spec.band_ticks, (size_t)n_frames * h->spec.nbands * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return h->spec.nbands;
+}
+#endif
 
 // diagnostics (tools/nfa_stats.py): rectangles that entered each rect_improve stage of the last staged batch (out16[0..5]; [5] = not meaningful after the last stage)
 extern "C" int plf_line_debug_nfa_counters(plf_line *h, int32_t *out16)

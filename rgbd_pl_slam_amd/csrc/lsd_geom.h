@@ -86,6 +86,7 @@ struct SpecBufs {
     int *round_state;   // [frame][4]: bands whose marks changed in the even / odd rounds, converged, fall back to the serial commit; behind the frames_cap frames: [frame] band workgroups through the current round
     int frames_cap;     // frames round_state was allocated for
     uint32_t *tl2b;     // [frame][band][2 * s_stride]: accepted pixels of a seed regrown by a validation
+    int *round_log;     // [frame][band][16 rounds][4] (diagnostics, -DPLF_ROUND_LOG builds with PLF_LSD_ROUND_LOG set; else null): ticks of the band's validation, seeds regrown, pixels regrown, records that stood
     int *band_ticks;    // [frame][band][2]: run time of the band wave in 100 MHz ticks, accepted pixels it logged (diagnostics: how well the band shares are balanced)
 };
 

@@ -2175,6 +2175,10 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
     bool ovf_n = false;
     const int p_end = y1 * W;
     const int nrec_band = cnt[0];
+#ifdef PLF_ROUND_LOG
+    const unsigned long long rl_t0 = wall_clock64();
+    int rl_seeds = 0, rl_px = 0;
+#endif
     int r_lo = 0, p_lo = y0 * W;
     while (p_lo < p_end && !ovf_n) {
         const int nh = min(SPEC_HCAP, nrec_band - r_lo);
@@ -2361,6 +2365,9 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                     recs_n[nrec_n] = r;
                 }
                 if (okr) nrect_n++;
+#ifdef PLF_ROUND_LOG
+                rl_seeds++; rl_px += tn;
+#endif
                 tn_n += tn; nrec_n++;
                 CBAR();
                 rescan = true;
@@ -2396,6 +2403,12 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
         SB.nrects[fb] = nrect_n;
     }
     if (__ballot(changed) && lane == 0) atomicAdd(&rs[round & 1], 1);
+#ifdef PLF_ROUND_LOG
+    if (SB.round_log && lane == 0 && round >= 1 && round <= 16) {
+        int *rl = SB.round_log + (fb * 16 + (round - 1)) * 4;
+        rl[0] = (int)(wall_clock64() - rl_t0); rl[1] = rl_seeds; rl[2] = rl_px; rl[3] = nrec_n - rl_seeds;
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(256) k_lsd_spec_validate(float *__restrict__ ang_all, const double *__restrict__ modgrad_all, const double2 *__restrict__ cs_all,

@@ -89,12 +89,12 @@ def main():
             ids = vga[b0:b0 + 8]
             stack = np.stack([group[i][0] for i in ids])
             r_spec = vga_line.extract_batch(stack)
-            os.environ["PLF_LSD_SPEC_BANDS"] = "0"
+            # (the schedule knobs are read once per handle: plf_line_tune, not the environment -- the environment toggles here were silent no-ops in round 4)
+            vga_line.tune("spec_bands", 0)
             r_ser = vga_line.extract_batch(stack)
-            del os.environ["PLF_LSD_SPEC_BANDS"]
-            os.environ["PLF_LSD_SPEC_BANDS"] = "4"
+            vga_line.tune("spec_bands", 4)
             r_4 = vga_line.extract_batch(stack)
-            del os.environ["PLF_LSD_SPEC_BANDS"]
+            vga_line.tune("spec_bands", -2147483647)
             r_orb = vga_orb.extract_batch(stack)
             batch_res.append((ids, r_spec, r_ser, r_4, r_orb))
         refs_o = [f.result() for f in futs_o]; refs_l = [f.result() for f in futs_l]

@@ -1,4 +1,5 @@
-"""single-frame LSD+LBD latency and the speculation timeline for a few band / halo settings (env hooks are read per call)
+"""single-frame LSD+LBD latency and the speculation timeline for a few band / halo settings (the env hooks are read when a handle is created: every
+configuration below makes its own handle AFTER setting them)
     python tools/spec_probe.py"""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
