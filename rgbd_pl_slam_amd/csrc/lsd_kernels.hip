@@ -21,6 +21,9 @@
 #include "lsd_geom.h"
 
 #define NOTDEF_F (-1024.0f)
+#ifndef PLF_SPEC_PF_REFINE
+#define PLF_SPEC_PF_REFINE 1   // (experiment: fetch-ahead in refine's regrowth of the band waves, STG == 0)
+#endif
 #define PI_D 3.1415926535897932384626433832795
 #define M_3_2_PI_D (3 * 3.14159265358979323846 / 2)
 #define M_2__PI_D (2 * 3.14159265358979323846)
@@ -399,6 +402,24 @@ __device__ __forceinline__ double readlane_d(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+
+// Wave-wide min / max by DPP (round 5): row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast:15 and row_bcast:31 across them -- lane 63 ends up with the
+// value over all 64 lanes and is broadcast with v_readlane.  __shfl_xor butterflies compile to ds_bpermute_b32 (~60 cycles each, six dependent levels: the four
+// double extents of region2rect cost a lone band wave ~800 cycles per call, the bounding box of a seed's record ~600); min and max are order-free, so the result
+// is the same bit for bit.  A lane without a source in a step keeps its own value (old = the value itself: op(v, v) = v).
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false); }
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_mov_d(double v)
+{
+    return __hiloint2double(dpp_mov_i<CTRL, ROWMASK>(__double2hiint(v)), dpp_mov_i<CTRL, ROWMASK>(__double2loint(v)));
+}
+#define PLF_DPP_REDUCE(v, OP, MOV)                                                                            \
+    v = OP(v, MOV<0x111, 0xf>(v)); v = OP(v, MOV<0x112, 0xf>(v)); v = OP(v, MOV<0x114, 0xf>(v)); v = OP(v, MOV<0x118, 0xf>(v)); \
+    v = OP(v, MOV<0x142, 0xa>(v)); v = OP(v, MOV<0x143, 0xc>(v));
+__device__ __forceinline__ int wave_min_i(int v) { PLF_DPP_REDUCE(v, min, dpp_mov_i) return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ int wave_max_i(int v) { PLF_DPP_REDUCE(v, max, dpp_mov_i) return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ double wave_min_d(double v) { PLF_DPP_REDUCE(v, fmin, dpp_mov_d) return readlane_d(v, 63); }
+__device__ __forceinline__ double wave_max_d(double v) { PLF_DPP_REDUCE(v, fmax, dpp_mov_d) return readlane_d(v, 63); }
+
 // Thresholds of the cheap alignment pre-test of region_grow (see there): t1 <= tan(prec - delta), t2 >= tan(prec + delta), delta = 0.05 degrees.
 // The pre-test only sorts candidates into "surely aligned", "surely not" and "border" (decided by the reference's own test), so ANY t1 below and
 // t2 above those tangents is sound: single-precision tanf with a 1e-4 relative safety factor (its error is ~1e-7; the band is ~2.5e-3 wide) keeps
@@ -419,7 +440,10 @@ __device__ __forceinline__ GrowTh grow_thresholds(double prec)
 }
 
 // 3x3 neighbourhood data of up to 7 queued region points: lane = slot * 9 + k9, neighbours in (yy, xx) order
-struct Grp { uint32_t w; double csx, csy; int a; uint32_t xy; };   // w: angle word (candidate iff < 0x80000000 and the lane is valid)
+struct Grp { uint32_t w; uint32_t fl; double csx, csy; int a; uint32_t xy; };   // w: angle word, fl: USED flag of the bitmap mode (candidate iff w < 0x80000000, fl == 0 and the lane is valid)
+// Round 5: in the bitmap mode (band waves, validation rounds) the flag stays a value of its own.  ang_load() merges it into the sign of the angle word, i.e. the
+// merged word depends on the GLOBAL load of the angle and the compiler placed `s_waitcnt vmcnt(1)` right behind the prefetch of the next group -- every group
+// of a lone band wave waited a full L2 round trip for a word it needs one group later.  With the flag apart nothing reads the prefetched registers before the hand-over.
 // The cos/sin increment is fetched together with the angle word (fetching it only for candidates, after the word has arrived, saves HBM traffic but puts a
 // second dependent round trip -- and an s_waitcnt that also stalls the group being processed -- into every step of the chain: 77.2 -> 71.4 ms per 4096
 // frames).
@@ -439,7 +463,8 @@ __device__ __forceinline__ Grp group_at(const RegCtx &C, uint32_t pxy, int kx, i
     // (no upper clamp: a region point is a defined pixel, x <= W-2 and y <= H-2, so its neighbours end at the last pixel of the frame)
     const int af = plf_lane() < nlanes ? max(G.a, 0) : 0;
     const double2 c = C.cs[af];
-    G.w = ang_load(C, af);
+    if (C.use_bm) { G.w = C.ang[af]; G.fl = (C.bm[af >> 5] >> (af & 31)) & 1u; }
+    else { G.w = ang_load(C, af); G.fl = 0u; }
     G.csx = c.x; G.csy = c.y;
     return G;
 }
@@ -512,7 +537,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
 #endif
         // (everything that reads what the current group's loads brought is computed HERE, in front of the prefetch, with a compiler barrier behind it: the wait for
         // those loads must not end up behind the loads of the next group -- vmcnt counts in order, so it would wait for them as well)
-        unsigned long long candm = __ballot(cur.w < 0x80000000u) & cur_valid & ~cur_stale;
+        unsigned long long candm = __ballot(cur.w < 0x80000000u && cur.fl == 0u) & cur_valid & ~cur_stale;
         const float ux = (float)cur.csx, uy = (float)cur.csy;
         asm volatile("" : : "v"(ux), "v"(uy), "v"(cur.w) : "memory");
         // ---- issue the loads of the next group: list entries that exist now
@@ -521,7 +546,7 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
         // trip costs nothing there: the kernel is bound by instruction issue and seven other chains fill the wait.  73.7 -> 69.2 ms per 8192 frames.
         nx_n = PF ? min(7, n - (i + cur_n)) : 0;
         if (nx_n < 0) nx_n = 0;
-        nx.w = 0xFFFFFFFFu; nx.csx = 0.0; nx.csy = 0.0; nx.a = -1; nx.xy = 0u;
+        nx.w = 0xFFFFFFFFu; nx.fl = 0u; nx.csx = 0.0; nx.csy = 0.0; nx.a = -1; nx.xy = 0u;
         nx_valid = 0ull; nx_stale = 0ull;
         if (nx_n > 0) nx = load_group(C, i + cur_n, nx_n, slot, kx, ky, nx_valid);
         // ---- process the current group
@@ -742,10 +767,14 @@ __device__ void region2rect(RegCtx &C, int n, double reg_angle, double prec, dou
         l_max = fmax(l_max, l); l_min = fmin(l_min, l);
         w_max = fmax(w_max, w); w_min = fmin(w_min, w);
     }
+    if (STG == 0) {   // lone band waves: the DPP reduction is ~450 cycles shorter than six dependent ds_bpermute levels
+        l_max = wave_max_d(l_max); l_min = wave_min_d(l_min); w_max = wave_max_d(w_max); w_min = wave_min_d(w_min);
+    } else {          // issue-bound large-batch kernel: the butterfly runs on the LDS pipe; the DPP form adds vector instructions (68.2 -> 70.1 ms per 8192 frames)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        l_max = fmax(l_max, shfl_d(l_max, lane ^ o)); l_min = fmin(l_min, shfl_d(l_min, lane ^ o));
-        w_max = fmax(w_max, shfl_d(w_max, lane ^ o)); w_min = fmin(w_min, shfl_d(w_min, lane ^ o));
+        for (int o = 32; o > 0; o >>= 1) {
+            l_max = fmax(l_max, shfl_d(l_max, lane ^ o)); l_min = fmin(l_min, shfl_d(l_min, lane ^ o));
+            w_max = fmax(w_max, shfl_d(w_max, lane ^ o)); w_min = fmin(w_min, shfl_d(w_min, lane ^ o));
+        }
     }
     rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy;
     rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
@@ -909,7 +938,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    n = region_grow<STG != 2>(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
+    n = region_grow<(STG != 2) && (STG != 0 || PLF_SPEC_PF_REFINE)>(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
     C.regrow_n = n;
     if (n < 2) return false;
     region2rect<STG>(C, n, reg_angle, prec, p, rec);
@@ -1228,12 +1257,15 @@ __device__ __forceinline__ void spec_append(const RegCtx &C, int n, uint32_t *__
 
 // the per-seed pipeline of the serial loop; the accepted pixels go to dst[t0 ..) (first growth, then the regrowth of refine)
 __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th0, int seed, float sdeg, float2 sc0, LsdRect &rec, uint32_t *__restrict__ dst,
-                                          int &tn, int cap, int &ovf, uint32_t mark, SpecBB &bb)
+                                          int &tn, int cap, int &ovf, uint32_t mark, SpecBB &bb, bool warm = false)
 {
     double reg_angle;
     C.regrow_n = -1;
     TIC(ts0);
-    int n = region_grow<1>(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
+#ifndef PLF_SPEC_PF
+#define PLF_SPEC_PF 0   // (round 5: no fetch-ahead in the band waves either -- fuller groups; the neighbourhood loads hit the L1: 2-3 % per call, tools/ab_few.sh)
+#endif
+    int n = region_grow<PLF_SPEC_PF>(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
     CBAR();
     TOCB(10, ts0);
     CNTB(16, 1); CNTB(17, n);
@@ -1241,6 +1273,9 @@ __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th
     spec_append(C, n, dst, tn, cap, ovf, mark, bb);
     TOCB(11, ts1);
     if (n < g.min_reg_size) return false;
+#ifdef PLF_WARM_NOREFINE
+    if (warm) return false;   // (experiment: the unrecorded warm-up regions stand as grown -- no rectangle, no refine; only the quality of the band's guess)
+#endif
     TIC(ts2);
     region2rect<0>(C, n, reg_angle, g.prec, g.p, rec);
     TOCB(12, ts2);
@@ -1557,12 +1592,12 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             LsdRect rec;
             const int t0 = tn;
-            if (lane == 0) __hip_atomic_store(&SB.cnt[fb * 4 + 3], seed + 1 + (phase << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // heartbeat (spec_wait_band)
+            if (lane == 0 && !SB.out) __hip_atomic_store(&SB.cnt[fb * 4 + 3], seed + 1 + (phase << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // heartbeat (spec_wait_band; nobody waits for a band wave when validation rounds follow)
             // every accepted pixel is logged as "still marked at the end of the seed" right away -- true unless refine released pixels (it regrew the region:
             // C.regrow_n >= 0, ~10 % of the large regions), in which case the entries are re-read and corrected; the bounding box comes out of the append
             // itself.  (Reading every log back to set the flag and find the box cost a global round trip per seed.)
             SpecBB bb = {W, H, -1, -1};
-            const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf, record ? 0x40000000u : 0u, bb);
+            const bool okr = spec_seed(C, g, th0, seed, sdeg, sc0, rec, tl, tn, SB.tcap, ovf, record ? 0x40000000u : 0u, bb, !record);
             TIC(trec);
             if (!record) { tn = 0; ovf = 0; }
             if (record && nrec >= SB.rcap_rec) ovf = 1;
@@ -1575,22 +1610,21 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
                         if (!((bm[q >> 5] >> (q & 31)) & 1u)) tl[i] = q;
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    bx0 = min(bx0, __shfl_xor(bx0, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64));
-                    bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
-                }
+                bx0 = wave_min_i(bx0); by0 = wave_min_i(by0); bx1 = wave_max_i(bx1); by1 = wave_max_i(by1);
                 if (lane == 0) {
-                    SpecRec r; r.seed = seed; r.t0 = t0; r.nt = tn - t0; r.has_rect = okr ? 1 : 0; r.rec = rec;
-                    r.bx0 = max(bx0 - 1, 0); r.by0 = max(by0 - 1, 0); r.bx1 = min(bx1 + 1, W - 1); r.by1 = min(by1 + 1, H - 1);
-                    recs[nrec] = r;
+                    // (the 32-byte header always, the 96-byte rectangle only when there is one: nothing reads `rec` of a record without -- nine records in ten)
+                    int4 *dst = reinterpret_cast<int4 *>(&recs[nrec]);
+                    dst[0] = make_int4(seed, t0, tn - t0, okr ? 1 : 0);
+                    dst[1] = make_int4(max(bx0 - 1, 0), max(by0 - 1, 0), min(bx1 + 1, W - 1), min(by1 + 1, H - 1));
+                    if (okr) recs[nrec].rec = rec;
                     atomicOr(&seedmap[seed >> 5], 1u << (seed & 31));
                 }
                 nrec++;
             }
             CBAR();
-            w = px < yb * W ? ang_load(C, px) : 0xFFFFFFFFu;   // flags from the bitmap: cheap, always current
-            ok = ok && lane > j && w < 0x80000000u;
+            // flags from the bitmap: cheap, always current (only the LDS word is read again: the angle word itself never changes in this mode, and re-loading it from
+            // global memory put an exposed round trip behind every seed)
+            ok = ok && lane > j && !((bm[px >> 5] >> (px & 31)) & 1u);
             mask = __ballot(ok);
             TOCB(18, trec);
         }
@@ -2354,15 +2388,12 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                     tl_n[tn_n + i] = q | (bm_get(T, (int)q) ? 0x40000000u : 0u);
                     if (S.get((int)q) != bm_get(T, (int)q)) dc_mark(Dc, (int)q, W, ctx);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    bx0 = min(bx0, __shfl_xor(bx0, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64));
-                    bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
-                }
+                bx0 = wave_min_i(bx0); by0 = wave_min_i(by0); bx1 = wave_max_i(bx1); by1 = wave_max_i(by1);
                 if (lane == 0) {
-                    SpecRec r; r.seed = gseed; r.t0 = tn_n; r.nt = tn; r.has_rect = okr ? 1 : 0; r.rec = rec;
-                    r.bx0 = max(bx0 - 1, 0); r.by0 = max(by0 - 1, 0); r.bx1 = min(bx1 + 1, W - 1); r.by1 = min(by1 + 1, H - 1);
-                    recs_n[nrec_n] = r;
+                    int4 *dst = reinterpret_cast<int4 *>(&recs_n[nrec_n]);
+                    dst[0] = make_int4(gseed, tn_n, tn, okr ? 1 : 0);
+                    dst[1] = make_int4(max(bx0 - 1, 0), max(by0 - 1, 0), min(bx1 + 1, W - 1), min(by1 + 1, H - 1));
+                    if (okr) recs_n[nrec_n].rec = rec;
                 }
                 if (okr) nrect_n++;
 #ifdef PLF_ROUND_LOG

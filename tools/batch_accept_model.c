@@ -19,6 +19,11 @@
 
 static long g_old_trips, g_new_trips, g_accepts, g_groups, g_batches, g_batch_hist[65], g_singles, g_border, g_regions, g_mismatch, g_retrim;
 static long g_lane_cands;
+static float g_pc_sx, g_pc_sy;
+static long g_pc_trips, g_pc_batches, g_pc_hist[65], g_pc_singles, g_pc_mismatch;
+#ifndef PC_ITERS
+#define PC_ITERS 1
+#endif
 static long g_sz_regions[8], g_sz_pixels[8], g_sz_groups[8];
 
 typedef struct { float t1, t2; } growth_t;
@@ -132,6 +137,67 @@ static void region_grow(lsd_t *L, int sx, int sy, regpt *reg, int *reg_size, dou
                 cand[u] = 0;
             }
             g_new_trips += trips;
+            /* ---------------- scheme 2: prefix consistency.  Guess A = lanes surely aligned with the sums at the start of the trip (first lane per pixel); every
+             * candidate lane is then classified against ITS OWN sums S_j = S + (float prefix sum of the guessed lanes before it); all lanes in front of the first lane
+             * whose class differs from the guess (or that is a border lane) are decided for good: the guessed lanes among them are accepted in one step. */
+            {
+                int cand2[63]; memcpy(cand2, lv, sizeof(cand2));
+                float px_ = sumdx, py_ = sumdy;
+                long trips2 = 0;
+                for (;;) {
+                    int any = 0;
+                    for (int j = 0; j < nl; j++) any |= cand2[j];
+                    if (!any) break;
+                    trips2++;
+                    float ux[63], uy[63];
+                    int A[63], A2[63], bord[63];
+                    for (int j = 0; j < nl; j++) if (cand2[j]) { ux[j] = (float)cos((double)(float)L->angles[la[j]]); uy[j] = (float)sin((double)(float)L->angles[la[j]]); }
+                    for (int j = 0; j < nl; j++) {
+                        A[j] = 0;
+                        if (!cand2[j]) continue;
+                        const float d = px_ * ux[j] + py_ * uy[j], a = fabsf(px_ * uy[j] - py_ * ux[j]);
+                        A[j] = a <= th.t1 * d;
+                        if (A[j]) for (int l = 0; l < j; l++) if (A[l] && la[l] == la[j]) A[j] = 0;
+                    }
+                    for (int it = 0; it < PC_ITERS; it++) {
+                        float sx2 = px_, sy2 = py_;
+                        for (int j = 0; j < nl; j++) {
+                            A2[j] = 0; bord[j] = 0;
+                            if (cand2[j]) {
+                                const float d = sx2 * ux[j] + sy2 * uy[j], a = fabsf(sx2 * uy[j] - sy2 * ux[j]);
+                                const int sa = a <= th.t1 * d, sr = a >= th.t2 * d;
+                                int dup = 0;
+                                for (int l = 0; l < j; l++) if (A[l] && la[l] == la[j]) dup = 1;
+                                A2[j] = sa && !dup; bord[j] = !sa && !sr && !dup;
+                            }
+                            if (A[j]) { sx2 += ux[j]; sy2 += uy[j]; }
+                        }
+                        if (it + 1 < PC_ITERS) memcpy(A, A2, sizeof(A));
+                    }
+                    int d = nl;
+                    for (int j = 0; j < nl; j++) if (cand2[j] && (A[j] != A2[j] || bord[j])) { d = j; break; }
+                    int nb = 0;
+                    for (int j = 0; j < d; j++) if (A2[j]) {
+                        nb++;
+                        px_ = (float)((double)px_ + cos((double)(float)L->angles[la[j]])); py_ = (float)((double)py_ + sin((double)(float)L->angles[la[j]]));
+                    }
+                    if (nb) { g_pc_batches++; g_pc_hist[nb]++; }
+                    for (int j = d; j < nl; j++) if (cand2[j]) for (int l = 0; l < d; l++) if (A2[l] && la[l] == la[j]) cand2[j] = 0;
+                    for (int j = 0; j < d; j++) cand2[j] = 0;
+                    if (d < nl && cand2[d] && !nb) {   /* nothing accepted in front of lane d: its sums are the trip's, so it is a border lane -> the reference's own test */
+                        const int acc = exact_aligned(L, la[d], (double)orc_fast_atan2(py_, px_) * DEG_TO_RADS, prec);
+                        g_pc_singles++;
+                        if (acc) {
+                            px_ = (float)((double)px_ + cos((double)(float)L->angles[la[d]])); py_ = (float)((double)py_ + sin((double)(float)L->angles[la[d]]));
+                            for (int j = d + 1; j < nl; j++) if (la[j] == la[d]) cand2[j] = 0;
+                        }
+                        cand2[d] = 0;
+                    }
+                }
+                g_pc_trips += trips2;
+                g_pc_sx = px_; g_pc_sy = py_;
+            }
+
             /* the batch loop must leave the same sums as the reference order below: checked after the group */
             const int n_before = n;
             long old = 1;
@@ -144,8 +210,7 @@ static void region_grow(lsd_t *L, int sx, int sy, regpt *reg, int *reg_size, dou
                     const float d = sumdx * ux + sumdy * uy, a = fabsf(sumdx * uy - sumdy * ux);
                     const int surely_not = a >= th.t2 * d, surely = a <= th.t1 * d;
                     const int al = exact_aligned(L, c, *reg_angle, prec);
-                    if (surely_not && al) g_mismatch++;
-                    if (surely && !al) g_mismatch++;
+                    if ((surely_not && al) || (surely && !al)) { g_mismatch++; fprintf(stderr, "mismatch: prec %.6f t1 %g t2 %g S (%g, %g) u (%g, %g) d %g a %g surely %d not %d al %d reg_angle %.6f pix angle %.6f n %d\n", prec, th.t1, th.t2, sumdx, sumdy, ux, uy, d, a, surely, surely_not, al, *reg_angle, L->angles[c], n); }
                     if (!surely_not) old++;
                     if (al) {
                         L->used[c] = USED;
@@ -161,6 +226,7 @@ static void region_grow(lsd_t *L, int sx, int sy, regpt *reg, int *reg_size, dou
             g_old_trips += old;
             g_accepts += n - n_before;
             if (sx_ != sumdx || sy_ != sumdy) g_mismatch++;
+            if (g_pc_sx != sumdx || g_pc_sy != sumdy) g_pc_mismatch++;
         }
         i += cur_n;
         if (nx_n == 0) {
@@ -195,6 +261,9 @@ int main(int argc, char **argv)
            (double)g_new_trips / g_old_trips);
     printf("  batches %ld singles %ld (border %ld) retrims %ld mismatches %ld; batch sizes:", g_batches, g_singles, g_border, g_retrim, g_mismatch);
     for (int k = 1; k < 20; k++) printf(" %d:%ld", k, g_batch_hist[k]);
+    printf("\n");
+    printf("  PREFIX-CONSISTENCY (iters %d): trips %ld (%.2f per group, ratio to old %.3f) batches %ld singles %ld mismatches %ld; batch sizes:", PC_ITERS, g_pc_trips, (double)g_pc_trips / g_groups, (double)g_pc_trips / g_old_trips, g_pc_batches, g_pc_singles, g_pc_mismatch);
+    for (int k = 1; k < 20; k++) printf(" %d:%ld", k, g_pc_hist[k]);
     printf("\n");
     printf("  region sizes 1 | 2-3 | 4-7 | 8-15 | 16-31 | 32-127 | 128+: regions");
     for (int b = 0; b < 7; b++) printf(" %ld", g_sz_regions[b]);

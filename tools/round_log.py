@@ -25,6 +25,11 @@ for c in range(N):
     g = bt[:, :, 0] / 100.0
     print("%s call %d, %d frame(s) x %d bands: band waves us max %.0f mean %.0f (slowest band of each frame: %s), logged px %d" %
           (fam, c, B, nb, g.max(), g.mean(), " ".join("%.0f" % x for x in g.max(axis=1)), int(bt[:, :, 1].sum())))
+    if os.environ.get("ROUND_LOG_BANDS"):
+        by = np.zeros(nb + 1, np.int32)
+        print("   frame 0 per band (us of the band wave, logged px | us of rounds 1..4):")
+        for b in range(nb):
+            print("     band %2d: %5.0f us %5d px | %s" % (b, g[0, b], bt[0, b, 1], " ".join("%4.0f(%d,%d)" % (rl[0, b, r, 0] / 100.0, rl[0, b, r, 1], rl[0, b, r, 2]) for r in range(5))))
     for r in range(16):
         t = rl[:, :, r, 0] / 100.0
         act = (rl[:, :, r, 0] > 0)
