@@ -59,7 +59,7 @@ def algorithmic_bytes(w, h, nfeat, nlines, lam_per_line=80):
 class Pipeline:
     """the device-resident step: both extractors + the four matchers for B frames in flight on one GPU"""
 
-    def __init__(self, w, h, nfeat, nlines, B, device, seed_base, serial=False, line_handles=1, front_wait=True, defer_match=True, distinct=1024):
+    def __init__(self, w, h, nfeat, nlines, B, device, seed_base, serial=False, line_handles=1, front_wait=True, defer_match=True, distinct=1024, family="polygons"):
         import numpy as np
         import torch
         from rgbd_pl_slam_amd import ORBextractor, LineSegment, Matcher, matchgen
@@ -73,7 +73,9 @@ class Pipeline:
         # distinct images tiled 128 times understate the tail of a diverse stream)
         ndist = min(B, max(1, distinct))
         self.ndist = ndist
-        self.h_distinct = synth_batch_parallel(seed_base, ndist, w, h)
+        # family "natural": synth.natural_frame (1/f texture + blurred scene + sensor noise) instead of the hard-edged polygon scenes
+        self.family = family
+        self.h_distinct = synth_batch_parallel(seed_base, ndist, w, h, family=family)
         self.d_img = torch.empty((B, h, w), dtype=torch.uint8, device="cuda")
         self.load_images(ndist)
         self.orb = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, max_batch=B, device=device)
@@ -226,6 +228,27 @@ class Pipeline:
         return {"min": int(c.min()), "median": int(np.median(c)), "max": int(c.max()), "mean": round(float(c.mean()), 1),
                 "what": "pixels left USED per frame by LSD region growing = length of the frame's serial chain; the one-wave-per-frame launch lasts as long as the longest"}
 
+    def rect_stats(self):
+        """rectangles per frame the last batch handed to the NFA validation"""
+        import numpy as np
+        c = self.lins[(self.k - 1) % len(self.lins)].rect_counts(self.B)
+        return {"min": int(c.min()), "median": int(np.median(c)), "max": int(c.max()), "mean": round(float(c.mean()), 1)}
+
+    def rounds_stats(self):
+        """validation rounds of the last few-frames batch (None for the other schedules)"""
+        import numpy as np
+        rs = self.lins[(self.k - 1) % len(self.lins)].spec_rounds(self.B) if self.B <= 16 else None
+        if rs is None:
+            return None
+        ok = rs[:, 3] == 0
+        r = rs[ok, 2]; r = r[r > 0]
+        return {"frames": int(len(rs)), "finished_by_serial_commit": int((~ok).sum()), "rounds_to_fixpoint_mean": round(float(r.mean()), 2) if len(r) else None,
+                "rounds_to_fixpoint_max": int(r.max()) if len(r) else None}
+
+    def lines_kept(self):
+        b = self.bufs[(self.k - 1) & 1]
+        return round(float(b["nl"].float().mean()), 1)
+
     def close(self):
         for o in [self.orb] + self.lins + self.mats:
             o.close()
@@ -259,15 +282,15 @@ def timed(pipe, steps, warmup, dist=None):
     return elapsed, reg_ms, reg_launches
 
 
-def single_frame_latency(device, w, h, nfeat, nlines, reps=20):
+def single_frame_latency(device, w, h, nfeat, nlines, reps=20, family="polygons"):
     """one frame at a time through the host-memory entry points (ORBextractor::operator(), LineSegment::ExtractLineSegment): what a live
     SLAM loop sees"""
     import numpy as np
     from rgbd_pl_slam_amd import ORBextractor, LineSegment
-    from rgbd_pl_slam_amd.synth import synth_frame
+    from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
     orb = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, device=device)
     lin = LineSegment(nlines=nlines, max_width=w, max_height=h, device=device)
-    imgs = [synth_frame(7000 + i, w, h) for i in range(4)]
+    imgs = [(natural_frame if family == "natural" else synth_frame)(7000 + i, w, h) for i in range(4)]
     to, tl = [], []
     for i in range(reps + 3):
         t0 = time.perf_counter(); orb(imgs[i % 4]); t1 = time.perf_counter(); lin.ExtractLineSegment(imgs[i % 4]); t2 = time.perf_counter()
@@ -275,7 +298,53 @@ def single_frame_latency(device, w, h, nfeat, nlines, reps=20):
             to.append(t1 - t0); tl.append(t2 - t1)
     orb.close(); lin.close()
     return {"orb_ms_median": round(1e3 * float(np.median(to)), 3), "lsd_lbd_ms_median": round(1e3 * float(np.median(tl)), 3), "frames": reps,
-            "what": "one %dx%d frame, host memory in and out, nothing else in flight" % (w, h)}
+            "what": "one %dx%d frame (%s), host memory in and out, nothing else in flight" % (w, h, family)}
+
+
+def reduce_elapsed_max(dist, seconds, device="cuda"):
+    """the job lasts as long as its slowest rank: MAX over the ranks of one float (the only reduction on the whole path; nccl = RCCL on the GPU box, gloo in the
+    CPU test tests/test_sharding.py)"""
+    if dist is None:
+        return float(seconds)
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def pcie_line(r, elapsed_max, world, n_frames, in_flight, steps, warmup, W, H, label, config):
+    """the JSON line of `bench.py --pcie` (rank 0): aggregate frames/s over all ranks from the slowest rank's time"""
+    frames = world * n_frames * max(1, steps)
+    r = dict(r); r.pop("elapsed_max", None)
+    return {
+        "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d, PCIe-inclusive" % (W, H),
+        "value": round(frames / elapsed_max, 2), "unit": "frames/s", "n_gpus": world, "steps": max(1, steps), "warmup": max(1, warmup),
+        "ms_per_step": round(1e3 * elapsed_max / max(1, steps), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64",
+        "data": "synthetic (pinned host frames, 256 distinct per GPU)",
+        "config": {"workload": label + "; host frames in, key points / descriptors / lines / local-map matches out in host memory (plf_batch_extract)",
+                   "baseline_config": config, "frames_per_call_per_gpu": n_frames, "frames_in_flight_per_gpu": in_flight,
+                   "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
+        "pcie": {"host_read_GBps_aggregate": round(frames * W * H / elapsed_max / 1e9, 2), "host_read_GBps_per_gpu": round(frames * W * H / elapsed_max / 1e9 / world, 2),
+                 "rank0": r}}
+
+
+def run_pcie(args, dist, rank, local_rank, world, B, W, H, NFEAT, NLINES, label, pcie_fn=None, local_map_fn=None):
+    """`bench.py --pcie`: every rank drives ITS GPU through the product's batch driver with host buffers of its own (the worker thread is bound to the GPU's NUMA
+    node, where the pinned buffers are then placed); K timed calls of 4 x in-flight frames each between barriers, MAX over the ranks.  pcie_fn / local_map_fn are
+    the test seams of tests/test_sharding.py (gloo, no GPU): the rank logic and the JSON assembly run unchanged."""
+    in_flight = min(B, 4096)
+    n_frames = 4 * in_flight
+    if local_map_fn is None:
+        def local_map_fn():
+            pm = Pipeline(W, H, NFEAT, NLINES, 8, local_rank, 10_000 * rank)   # (only for its local map: built from the features of a synthetic frame)
+            mp, ml = pm.mp, pm.ml
+            pm.close(); del pm
+            return mp, ml
+    mp, ml = local_map_fn()
+    r = (pcie_fn or pcie_inclusive)(local_rank, W, H, NFEAT, NLINES, n_frames, in_flight, mp, ml, reps=max(1, args.steps), warm=max(1, args.warmup), dist=dist)
+    if rank != 0:
+        return None
+    return pcie_line(r, r["elapsed_max"], world, n_frames, in_flight, args.steps, args.warmup, W, H, label, args.config)
 
 
 def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml, reps=2, warm=1, dist=None):
@@ -304,12 +373,7 @@ def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml, rep
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         total += dt
-    elapsed_max = total
-    if dist is not None:   # the job lasts as long as its slowest rank
-        import torch
-        t = torch.tensor([total], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_max = float(t[0])
+    elapsed_max = reduce_elapsed_max(dist, total)   # the job lasts as long as its slowest rank
     tm = bx.last_timing()
     aff = bx.worker_affinity(0)
     bx.close(); free_pinned(pin)
@@ -400,6 +464,8 @@ def main():
     ap.add_argument("--no-front-wait", action="store_true", help="diagnostic: let ORB start together with the line front stages")
     ap.add_argument("--no-defer-match", action="store_true", help="diagnostic: enqueue the matchers of step k in step k (default: behind the line front stages of "
                     "step k+1, so that they run in the shadow of the next region-growing kernel; +2.7 %%)")
+    ap.add_argument("--family", default="polygons", choices=["polygons", "natural"], help="diagnostic: image family of the main step (the headline is quoted on the "
+                    "polygon scenes of SURVEY 8d; the `natural` extras run the natural-image-like family in the same run)")
     ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
     ap.add_argument("--pcie", action="store_true", help="time the PCIe-INCLUSIVE leg instead (plf_batch_extract: pinned host frames in, features + local-map matches "
                     "out in host memory) on every rank; value = aggregate frames/s, plus the aggregate host read rate")
@@ -420,27 +486,9 @@ def main():
     W, H, NFEAT, NLINES, B0, label = CONFIGS[args.config]
     B = args.batch if args.batch > 0 else B0
     if args.pcie:
-        # every rank drives ITS GPU through the product's batch driver with host buffers of its own (the worker thread is bound to the GPU's NUMA node, where
-        # the pinned buffers are then placed); K timed calls of 4 x in-flight frames each between barriers, MAX over the ranks
-        in_flight = min(B, 4096)
-        n_frames = 4 * in_flight
-        pm = Pipeline(W, H, NFEAT, NLINES, 8, local_rank, 10_000 * rank)   # (only for its local map: built from the features of a synthetic frame)
-        mp, ml = pm.mp, pm.ml
-        pm.close(); del pm
-        r = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, n_frames, in_flight, mp, ml, reps=max(1, args.steps), warm=max(1, args.warmup), dist=dist)
+        line = run_pcie(args, dist, rank, local_rank, world, B, W, H, NFEAT, NLINES, label)
         if rank == 0:
-            el = r.pop("elapsed_max")
-            frames = world * n_frames * max(1, args.steps)
-            print(json.dumps({
-                "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d, PCIe-inclusive" % (W, H),
-                "value": round(frames / el, 2), "unit": "frames/s", "n_gpus": world, "steps": max(1, args.steps), "warmup": max(1, args.warmup),
-                "ms_per_step": round(1e3 * el / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64",
-                "data": "synthetic (pinned host frames, 256 distinct per GPU)",
-                "config": {"workload": label + "; host frames in, key points / descriptors / lines / local-map matches out in host memory (plf_batch_extract)",
-                           "baseline_config": args.config, "frames_per_call_per_gpu": n_frames, "frames_in_flight_per_gpu": in_flight,
-                           "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
-                "pcie": {"host_read_GBps_aggregate": round(frames * W * H / el / 1e9, 2), "host_read_GBps_per_gpu": round(frames * W * H / el / 1e9 / world, 2),
-                         "rank0": r}}))
+            print(json.dumps(line))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -449,7 +497,7 @@ def main():
     assert hi - lo == B
     def make_pipe(nb):
         return Pipeline(W, H, NFEAT, NLINES, nb, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait,
-                        defer_match=not args.no_defer_match, distinct=args.distinct)
+                        defer_match=not args.no_defer_match, distinct=args.distinct, family=args.family)
     try:
         pipe = make_pipe(B)
     except Exception as e:   # (8192 frames in flight hold ~150 GB of the 288 GB: a GPU that cannot give them runs the 4096-frame workload, and says so)
@@ -460,10 +508,7 @@ def main():
         B = 4096
         pipe = make_pipe(B)
     elapsed, reg_ms, reg_launches = timed(pipe, args.steps, args.warmup, dist)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = reduce_elapsed_max(dist, elapsed)
     frames = world * B * args.steps
     fps = frames / elapsed
 
@@ -516,7 +561,10 @@ def main():
                          "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches, "algorithmic_bytes_per_launch": b_region * B,
                          "valu_issue_frac": valu_frac, "valu_issue_source": valu_source},
         }
+        if world > 1:
+            out["extras"] = "skipped: tiled32 / fps_vs_in_flight / config3_as_specified / single_frame_latency / natural / pcie_inclusive / cpu_baseline are N = 1 figures"
         out["region_chain_length"] = pipe.chain_stats()
+        out["nfa_rectangles_per_frame"] = pipe.rect_stats()
         if world == 1 and args.config == 2 and not args.no_extras and not args.serial and pipe.ndist > 32:
             # the round-2 workload (32 distinct frames tiled to the batch), same pipeline object, same run: how much input diversity costs
             pipe.load_images(32)
@@ -550,6 +598,23 @@ def main():
             out["single_frame_latency"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES)
             out["pcie_inclusive"] = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, 16384, 4096, mp, ml)
             out["pcie_inclusive"].pop("elapsed_max", None)
+        if world == 1 and args.config == 2 and not args.no_extras and not args.serial:
+            # natural-image-like frames (synth.natural_frame) through the same step: large batch, 8 in flight, one frame
+            nat = {"what": "the default step on natural-image-like frames (1/f texture + lens-blurred scene + shot / read noise: synth.natural_frame) instead of "
+                           "the hard-edged polygon scenes; same workload, same run"}
+            pn = Pipeline(W, H, NFEAT, NLINES, B, local_rank, 40_000, distinct=args.distinct, family="natural")
+            en, rn, nn = timed(pn, args.steps, args.warmup)
+            nat["in_flight_%d" % B] = {"value": round(B * args.steps / en, 2), "unit": "frames/s", "ms_per_step": round(1e3 * en / args.steps, 3),
+                                       "region_kernel_ms": round(rn / max(nn, 1), 3), "region_chain_length": pn.chain_stats(), "nfa_rectangles_per_frame": pn.rect_stats(),
+                                       "lines_kept_mean": pn.lines_kept(), "vs_polygons": round((B * args.steps / en) / fps, 3)}
+            pn.close(); del pn
+            pn = Pipeline(W, H, NFEAT, NLINES, 8, local_rank, 41_000, distinct=8, family="natural")
+            en, rn, nn = timed(pn, 30, 5)
+            nat["in_flight_8"] = {"value": round(8 * 30 / en, 1), "unit": "frames/s", "ms_per_step": round(1e3 * en / 30, 3), "region_stage_ms": round(rn / max(nn, 1), 3),
+                                  "validation_rounds": pn.rounds_stats(), "nfa_rectangles_per_frame": pn.rect_stats(), "lines_kept_mean": pn.lines_kept()}
+            pn.close(); del pn
+            nat["single_frame"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES, family="natural")
+            out["natural"] = nat
         if world == 1 and args.cpu_seconds > 0:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(float(args.cpu_seconds), cores, W, H, NFEAT, NLINES)

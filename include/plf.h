@@ -188,6 +188,10 @@ int plf_line_debug_nfa_counters(plf_line *h, int32_t *out16);
  * that took the speculative schedule (its flags live in LDS).  Synchronises the device. */
 int plf_line_chain_lengths(plf_line *h, int32_t *out, int32_t n);
 
+/* Diagnostics (bench.py, natural-image extras): out[f] = rectangles frame f of the last batch handed to the NFA validation (regions of min_reg_size pixels or more
+ * that survived refine), n <= frames of that batch.  Synchronises the device. */
+int plf_line_rect_counts(plf_line *h, int32_t *out, int32_t n);
+
 /* Measurement hook (bench.py roofline): when enabled, every launch of the region-growing kernel -- the dominant
  * kernel of the whole front-end -- is bracketed by HIP events on the stream it is launched on.  The call
  * synchronises, then returns the accumulated kernel milliseconds and the number of launches since the last reset. */

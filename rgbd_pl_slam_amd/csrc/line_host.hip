@@ -12,13 +12,14 @@
 #include "lsd_geom.h"
 
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
-                          const int *, const float2 *);
+                          const int *, const float2 *, int *);
+__global__ void k_lsd_balance(const int *, int *, int, int);
 __global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
-__global__ void k_lsd_regions2(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int);
+__global__ void k_lsd_regions2(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int, const int *);
 __global__ void k_lsd_regions_lat(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
 // the same kernels with the time budget of plf_line_params.max_ms compiled in (separate instances: the default ones read no clock)
 __global__ void k_lsd_regions_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
-__global__ void k_lsd_regions2_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int);
+__global__ void k_lsd_regions2_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int, const int *);
 __global__ void k_lsd_regions_lat_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
 __global__ void k_lsd_spec_fused_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
 __global__ void k_lsd_spec_grow_budget(float *, const double *, const double2 *, const float2 *, LsdGeom, SpecBufs);
@@ -87,6 +88,7 @@ struct LineTune {
     int nfa_list;         // PLF_NFA_LIST         1: the rectangles k_nfa_small hands over take one wave each, all stages in one launch (k_nfa_fused_list: 3 NFA launches per
                           //                      batch instead of 17, but 17 ms instead of 9.5 per 8192 VGA frames); 0: the staged kernels
     int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
+    int balance;          // PLF_LSD_BALANCE      1: large batches -- the frames are dealt to the waves of k_lsd_regions2 by chain length (k_lsd_balance); 0: in batch order
 };
 static int tune_env_i(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static float tune_env_f(const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; }
@@ -112,6 +114,7 @@ static void line_tune_init(LineTune *t)
     t->nfa_small = tune_env_i("PLF_NFA_SMALL", 2);
     t->nfa_list = tune_env_i("PLF_NFA_LIST", 0);
     t->nfa_two_pass = tune_env_i("PLF_NFA_TWO_PASS", 1);
+    t->balance = tune_env_i("PLF_LSD_BALANCE", 1);
 }
 
 struct plf_line {
@@ -165,6 +168,7 @@ struct plf_line {
     int *d_counters;  // nrect[B], nseg[B], nout[B], status
     int *d_xofs, *d_yofs;
     float2 *d_xa, *d_yb;
+    int *d_balance;           // [2][max_batch + 16]: defined pixels per frame (k_lsd_pre), then the frame of every wave slot of k_lsd_regions2 (k_lsd_balance)
     int last_frames;
     hipStream_t last_stream;   // stream of the most recent call
     bool last_stream_set;
@@ -188,7 +192,7 @@ static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
                     h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
-                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_nfa_fcnt, h->d_vals, h->d_sort_scratch, h->d_lbd};
+                    h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_balance, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_nfa_fcnt, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
                   h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
@@ -382,6 +386,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_lines, B * (size_t)cap * sizeof(plf_keyline));
     ALLOC(h->d_ldesc, B * (size_t)cap * 32);
     ALLOC(h->d_lineeq, B * (size_t)cap * 3 * sizeof(double));
+    ALLOC(h->d_balance, 2 * (B + 16) * sizeof(int));
     ALLOC(h->d_counters, (5 * B + 16) * sizeof(int));   // nrect[B], nseg[B], nout[B], status[16] + truncated[B], chain lengths[B]
     ALLOC(h->d_lgam, 65536 * sizeof(double));
     ALLOC(h->d_nfa_tab, (size_t)NFA_TAB_P * (NFA_TAB_N * (NFA_TAB_N + 1) / 2) * sizeof(double));   // (lsd_geom.h)
@@ -441,7 +446,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
     const int v = (int)value;
     struct { const char *n; int *p; } ints[] = {{"lat_max", &t.lat_max}, {"spec_bands", &t.spec_bands}, {"spec_max", &t.spec_max}, {"spec_z", &t.spec_z},
         {"spec_rounds", &t.spec_rounds}, {"spec_halo", &t.spec_halo}, {"spec_fill", &t.spec_fill}, {"spec_clip", &t.spec_clip}, {"spec_nofuse", &t.spec_nofuse},
-        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_list", &t.nfa_list}, {"nfa_two_pass", &t.nfa_two_pass}};
+        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_list", &t.nfa_list}, {"nfa_two_pass", &t.nfa_two_pass}, {"balance", &t.balance}};
     for (auto &e : ints)
         if (!strcmp(name, e.n)) {
             if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
@@ -449,7 +454,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
             if (!strcmp(name, "spec_spins") && v < 64) return PLF_E_BADARG;
             if (!strcmp(name, "wpg") && (v < 1 || v > 16)) return PLF_E_BADARG;
             if (!strcmp(name, "spec_bands") && v != PLF_TUNE_AUTO && (v < 0 || v > 64)) return PLF_E_BADARG;   // (0 / 1: speculation off; the call clamps to what the frame allows)
-            if ((!strcmp(name, "nfa_small") && (v < 0 || v > 2)) || ((!strcmp(name, "nfa_table") || !strcmp(name, "nfa_list") || !strcmp(name, "nfa_two_pass")) && (v < 0 || v > 1)))
+            if ((!strcmp(name, "nfa_small") && (v < 0 || v > 2)) || ((!strcmp(name, "nfa_table") || !strcmp(name, "nfa_list") || !strcmp(name, "nfa_two_pass") || !strcmp(name, "balance")) && (v < 0 || v > 1)))
                 return PLF_E_BADARG;
             *e.p = v;
             return PLF_OK;
@@ -476,8 +481,19 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     int *nrect = h->d_counters, *nseg = h->d_counters + MB, *status = h->d_counters + 3 * MB, *nfail_unused = h->d_counters + 3 * MB + 16;
     (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
+    // large batches (the one-wave-per-frame kernel k_lsd_regions2): the frames are dealt to its waves by chain length = defined pixels, counted by k_lsd_pre
+    const bool balance = h->tune.balance && B > h->tune.spec_max && B > h->tune.lat_max && !h->tune.one_wave_groups && B <= 65536 && h->prm.seed_order == 0;
+    int *d_cost = balance ? h->d_balance : nullptr, *d_perm = balance ? h->d_balance + h->prm.max_batch + 16 : nullptr;
+    if (balance) PLF_HIP_TRY(hipMemsetAsync(d_cost, 0, (size_t)B * sizeof(int), s));
     hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + PRE_TW - 1) / PRE_TW, (g.sh + PRE_TH - 1) / PRE_TH, B), dim3(PRE_NT), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
-                       h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb);
+                       h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb, d_cost);
+    if (balance) {
+        // (here, in front of the Sobel kernel, not in front of k_lsd_regions2: the region kernel must follow its predecessor back to back -- in the 30 us of a small
+        // kernel the ORB tiles of the step, released by ev_front, took the CUs first and the region stage went from 68 to 110 ms inside bench.py)
+        const int wpg = h->tune.wpg;
+        PLF_HIP_TRY(hipMemsetAsync(d_perm, 0xFF, (size_t)((B + wpg - 1) / wpg) * wpg * sizeof(int), s));   // (-1: wave slots past the batch)
+        hipLaunchKernelGGL(k_lsd_balance, dim3((B + 255) / 256), dim3(256), 0, s, d_cost, d_perm, B, wpg);
+    }
     if (h->prm.lbd_sobel_input == PLF_LBD_RAW)
         hipLaunchKernelGGL(k_sobel3, dim3((((g.w + 3) / 4) * g.h + 255) / 256, 1, B), dim3(256), 0, s, d_gray, pitch, fstride, h->d_grad, g);
     else
@@ -654,7 +670,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         const int wpg = T.wpg;
         const size_t wave_lds = PLF_LSD_WAVE_LDS;
         hipLaunchKernelGGL(budget ? k_lsd_regions2_budget : k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
-                           h->d_rects, nrect, status, g, seeds, B);
+                           h->d_rects, nrect, status, g, seeds, B, balance ? d_perm : nullptr);
     }
     else
         hipLaunchKernelGGL(budget ? k_lsd_regions_budget : k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
@@ -980,6 +996,16 @@ extern "C" int plf_line_chain_lengths(plf_line *h, int32_t *out, int32_t n)
     hipLaunchKernelGGL(k_lsd_count_used, dim3(n), dim3(256), 0, h->stream, h->d_ang, d_out, h->g);
     PLF_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
     PLF_HIP_TRY(hipStreamSynchronize(h->stream));
+    return PLF_OK;
+}
+
+// diagnostics (bench.py): rectangles per frame of the last batch that went into the NFA validation
+extern "C" int plf_line_rect_counts(plf_line *h, int32_t *out, int32_t n)
+{
+    if (!h || !out || n < 1 || n > h->last_frames) return PLF_E_BADARG;
+    PLF_HIP_TRY(hipSetDevice(h->device));
+    PLF_HIP_TRY(hipDeviceSynchronize());
+    PLF_HIP_TRY(hipMemcpy(out, h->d_counters, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     return PLF_OK;
 }
 

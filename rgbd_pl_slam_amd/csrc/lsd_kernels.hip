@@ -21,6 +21,12 @@
 #include "lsd_geom.h"
 
 #define NOTDEF_F (-1024.0f)
+// issue priority of the THROUGHPUT kernels of the line stream (k_lsd_pre, the NFA kernels): the line stream is the critical path of the large-batch step and its
+// front / tail run beside ORB tiles (priority 2) and matcher waves (0)
+#ifndef PLF_LINE_PRIO
+#define PLF_LINE_PRIO 0
+#endif
+#define PLF_LINE_SETPRIO() do { if (PLF_LINE_PRIO) __builtin_amdgcn_s_setprio(PLF_LINE_PRIO); } while (0)
 #ifndef PLF_SPEC_PF_REFINE
 #define PLF_SPEC_PF_REFINE 1   // (experiment: fetch-ahead in refine's regrowth of the band waves, STG == 0)
 #endif
@@ -50,8 +56,9 @@ typedef uint32_t __attribute__((aligned(1))) plf_u32u_pre;
 __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ in, ptrdiff_t pitch, ptrdiff_t fstride, float *__restrict__ ang,
                                                  double *__restrict__ modgrad, double2 *__restrict__ cs, float2 *__restrict__ cs0, LsdGeom g,
                                                  LsdTaps t, const int *__restrict__ xofs, const float2 *__restrict__ xa,
-                                                 const int *__restrict__ yofs, const float2 *__restrict__ yb)
+                                                 const int *__restrict__ yofs, const float2 *__restrict__ yb, int *__restrict__ defcount)
 {
+    PLF_LINE_SETPRIO();
     // LDS: the row-pass tile (22.5 KB; the column pass overwrites it IN PLACE with the blurred tile -- every thread first reads the 14 rows behind its
     // 8 outputs into registers, one barrier, then writes -- and the list of defined pixels reuses it at the end) + the scaled tile (8.8 KB): 31 KB per
     // workgroup, 4 resident tiles of 8 waves per CU (a separate 18 KB blurred tile made it 40 KB / 3 tiles)
@@ -219,6 +226,9 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     }
     __syncthreads();
     const int ndef = s_ndef;
+    // pixels with a level-line angle = the length of the frame's region-growing chain to within the few pixels refine releases (every one of them ends up USED):
+    // the cost by which k_lsd_balance deals the frames of a large batch to the waves of k_lsd_regions2
+    if (defcount && tid == 0 && ndef) atomicAdd(&defcount[f], ndef);
     double *mgf = modgrad + (size_t)f * g.s_stride;
     double2 *csf = cs + (size_t)f * g.s_stride;
     float2 *cs0f = cs0 + (size_t)f * g.s_stride;
@@ -976,14 +986,19 @@ template <int LDSOFF, int FPW, bool BUDGET>
 __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                              const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                              uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                             int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int nframes)
+                                             int *__restrict__ status, const LsdGeom &g, const uint32_t *__restrict__ seeds_all, int nframes,
+                                             const int *__restrict__ perm = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_base[];
     // LDSOFF < 0 (k_lsd_regions2): blockDim.x / 64 frames per workgroup, one wave each, the LDS offset of a wave is a run-time scalar
     const int wv = LDSOFF < 0 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (LDSOFF ? 1 : 0);
     const int fpw = LDSOFF < 0 ? (int)(blockDim.x >> 6) : FPW;
-    const int f = FPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * fpw + wv, lane = FPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    if (FPW != 1 && f >= nframes) return;
+    int f = FPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * fpw + wv;
+    const int lane = FPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    // (large batches: which frame this wave slot works on is dealt by k_lsd_balance -- frames of similar chain length share a workgroup, the workgroups of a CU get
+    // equal sums; slots past the batch hold -1)
+    if (LDSOFF < 0 && perm) f = f < nframes + fpw ? __builtin_amdgcn_readfirstlane(perm[f]) : -1;
+    if (FPW != 1 && (f < 0 || f >= nframes)) return;
     LDS_PTR(char) smem = (LDS_PTR(char))smem_base + (LDSOFF < 0 ? wv * PLF_LSD_WAVE_LDS : LDSOFF);
     const uint32_t *seeds = seeds_all ? seeds_all + (size_t)f * g.s_stride : nullptr;   // sorted keys (seed_order 1) or raster
     const int W = g.sw, H = g.sh, NP = W * H;
@@ -1150,6 +1165,43 @@ __global__ void __launch_bounds__(64) k_lsd_regions_budget(float *__restrict__ a
     regions_body<0, 1, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
 }
 
+// Which frame goes to which wave of k_lsd_regions2 (round 5).  All waves of the launch are resident at once -- 8 per SIMD: waves v and v + 4 of each of the CU's four
+// workgroups (tools/wave_placement.hip reads HW_ID of this launch shape) -- and the launch lasts until the slowest SIMD has worked off its 8 chains.  In batch order
+// the sums of the chain lengths of a workgroup differ by 5 % (polygon scenes) to 30 % (natural-image-like frames) from the mean.  Here the frames are sorted by cost
+// (defined pixels, counted by k_lsd_pre: exactly the chain length but for the pixels refine releases), cut into fpw tiles of G = B / fpw ranks, and workgroup w
+// takes rank w of the even tiles and rank G - 1 - w of the odd ones (serpentine: every workgroup gets about the same sum), tile k and tile fpw - 1 - k on the
+// two waves that share a SIMD -- so every SIMD gets about the same sum WHEREVER the dispatcher puts the workgroup (other kernels run beside this one).
+// Measured, 8192 VGA frames (tools/balance_probe.py re-orders the batch on the host, tools/balance_dbg.py compares permutations): region kernel 68.2 -> 61.2 ms
+// on polygon scenes, 218 -> 198 ms on natural-image-like frames.  Workgroups of ADJACENT ranks dealt to the CUs in serpentine order -- equal sums per CU, like
+// chains in a workgroup -- gain nothing as a permutation (215 ms) although the same order laid out in memory by the host runs in 181 ms, and lose 60 % beside the
+// ORB kernels of the step, where workgroup w no longer lands on CU w mod 256.
+// Rank by counting, one thread per frame over workgroups of 256 threads and 1 KB of LDS: rank(i) = frames with a larger cost (ties: batch order) -- B^2 comparisons,
+// ~30 us for 8192 frames -- because the kernel runs beside the ORB tiles and the matchers of the step: a one-block bitonic sort (1024 threads, 64 KB of LDS) waited
+// ~40 ms for a CU with that much room (region stage 68 -> 108 ms inside bench.py although it took 0.1 ms alone).  perm[] is pre-set to -1 by the host (slots past
+// the batch).  Only which wave does which frame.
+__global__ void __launch_bounds__(256) k_lsd_balance(const int *__restrict__ cost, int *__restrict__ perm, int B, int fpw)
+{
+    __shared__ int sc[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ci = i < B ? cost[i] : -1;
+    int rank = 0;
+    for (int base = 0; base < B; base += 256) {
+        __syncthreads();
+        sc[threadIdx.x] = base + (int)threadIdx.x < B ? cost[base + threadIdx.x] : -1;
+        __syncthreads();
+        const int n = min(256, B - base);
+        for (int j = 0; j < n; j++) { const int cj = sc[j]; rank += (cj > ci || (cj == ci && base + j < i)) ? 1 : 0; }
+    }
+    if (i >= B) return;
+    const int G = (B + fpw - 1) / fpw;                       // workgroups; tile k = ranks [k G, (k + 1) G)
+    const int k = rank / G, pos = rank - k * G;
+    const int w = (k & 1) ? G - 1 - pos : pos;
+    // waves v and v + fpw / 2 share a SIMD (fpw = 8: v and v + 4): tiles k and fpw - 1 - k
+    const int half = fpw >> 1;
+    const int v = (fpw & 1) ? k : (k < half ? k : half + (fpw - 1 - k));
+    perm[w * fpw + v] = i;
+}
+
 // VGPR cap of the large-batch region kernel = waves per SIMD it is built for (tools/variant_build.sh overrides it).  8: 64 VGPRs, 19 of them spilled (80 bytes of
 // scratch per lane) -- the kernel is slower per wave, and eight chains per SIMD instead of four more than make up for it (end of round 3: 8192 frames in
 // flight 35.3 k frames/s against 33.1 k with 4096 at 96 VGPRs; at 4096 in flight the two builds are equal, the co-runners get the registers)
@@ -1168,16 +1220,18 @@ __global__ void __launch_bounds__(64) k_lsd_regions_budget(float *__restrict__ a
 __global__ void PLF_REGIONS_OCC __launch_bounds__(1024) k_lsd_regions2(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                       const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                       uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                                      int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
+                                                      int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes,
+                                                      const int *__restrict__ perm)
 {
-    regions_body<-1, 0, false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
+    regions_body<-1, 0, false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes, perm);
 }
 __global__ void __launch_bounds__(1024) k_lsd_regions2_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
                                                       const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
                                                       uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                                      int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes)
+                                                      int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all, int nframes,
+                                                      const int *__restrict__ perm)
 {
-    regions_body<-1, 0, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes);
+    regions_body<-1, 0, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, nframes, perm);
 }
 
 // Latency mode (a handful of frames in flight, e.g. the live SLAM loop): the chain of one frame is all there is to run, so its memory round
@@ -2975,11 +3029,13 @@ __device__ __forceinline__ void nfa_count_wave_body(const float *__restrict__ an
 __global__ void __launch_bounds__(64) k_nfa_count_w(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
                                                     const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
 {
+    PLF_LINE_SETPRIO();
     nfa_count_wave_body<6>(ang_all, entries, counters, cidx, mult, counts, g);
 }
 __global__ void __launch_bounds__(64) k_nfa_count1_w(const float *__restrict__ ang_all, const NfaEntry *__restrict__ entries,
                                                      const int *__restrict__ counters, int cidx, int mult, NfaCounts *__restrict__ counts, LsdGeom g)
 {
+    PLF_LINE_SETPRIO();
     nfa_count_wave_body<1>(ang_all, entries, counters, cidx, mult, counts, g);
 }
 
@@ -3019,6 +3075,7 @@ __global__ void __launch_bounds__(EV_T) k_nfa_eval(int stage, const double *__re
                                                    const NfaEntry *__restrict__ entries, const int *__restrict__ counters,
                                                    double *__restrict__ vals, LsdGeom g)
 {
+    PLF_LINE_SETPRIO();
     __shared__ uint16_t order[EV_CHUNK];
     __shared__ int hist[32];
     const bool multi = (stage == 0 || stage == 4);
@@ -3078,6 +3135,7 @@ __global__ void __launch_bounds__(64) k_nfa_math(int stage, const double *__rest
                                                  NfaEntry *__restrict__ ent_out, int *__restrict__ counters, float4 *__restrict__ seg_all,
                                                  uint8_t *__restrict__ keep_all, LsdGeom g)
 {
+    PLF_LINE_SETPRIO();
     const int n = counters[stage];
     const double LOG_EPS = 0.0, delta = 0.5, delta_2 = delta / 2.0;
     for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
@@ -3236,6 +3294,7 @@ __global__ void PLF_NFA_SMALL_OCC __launch_bounds__(64) k_nfa_small(const float 
                                                   NfaEntry *__restrict__ entries, NfaState *__restrict__ states, int *__restrict__ counters,
                                                   int *__restrict__ status, LsdGeom g, int nframes, NfaState *__restrict__ surv, int *__restrict__ fcnt, int scap)
 {
+    PLF_LINE_SETPRIO();
     // grid (8 * slots, ceil(B / 8)): workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), so XCD x works through frame 8 * blockIdx.y + x and the
     // angle words of a frame are pulled into ONE L2 (k_orient_brief's order)
     const int f = 8 * (int)blockIdx.y + ((int)blockIdx.x & 7), slot = (int)blockIdx.x >> 3, nslots = (int)gridDim.x >> 3;
@@ -3276,6 +3335,7 @@ __global__ void PLF_NFA_SMALL_OCC __launch_bounds__(64) k_nfa_small2(const float
                                                    NfaState *__restrict__ states, int *__restrict__ counters, int *__restrict__ status, LsdGeom g, int nframes,
                                                    const NfaState *__restrict__ surv, const int *__restrict__ fcnt, int scap)
 {
+    PLF_LINE_SETPRIO();
     const int f = 8 * (int)blockIdx.y + ((int)blockIdx.x & 7), slot = (int)blockIdx.x >> 3, nslots = (int)gridDim.x >> 3;
     if (f >= nframes) return;
     __shared__ int s_par[4][5 * 12];

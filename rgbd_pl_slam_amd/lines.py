@@ -116,6 +116,19 @@ class LineSegment:
         L.check(L.lib().plf_line_chain_lengths(self._h, L.vp(out), n), "plf_line_chain_lengths")
         return out
 
+    def rect_counts(self, n):
+        """rectangles the first n frames of the last batch handed to the NFA validation (plf_line_rect_counts)"""
+        out = np.zeros(n, np.int32)
+        L.check(L.lib().plf_line_rect_counts(self._h, L.vp(out), n), "plf_line_rect_counts")
+        return out
+
+    def spec_rounds(self, n):
+        """per frame of the last few-frames batch: (bands changed in the last even round, in the last odd round, round of the fixpoint, finished by the serial commit wave)"""
+        out = np.zeros(4 * n, np.int32)
+        if L.lib().plf_line_debug_spec_rounds(self._h, L.vp(out), n) != 0:
+            return None
+        return out.reshape(n, 4)
+
     def nfa_counters(self):
         """rectangles of the last batch that entered each rect_improve stage (plf_line_debug_nfa_counters)"""
         out = np.zeros(16, np.int32)

@@ -65,7 +65,16 @@ def synth_batch(seed0, n, w=640, h=480):
     return np.stack([synth_frame(seed0 + i, w, h) for i in range(n)])
 
 
-def synth_batch_parallel(seed0, n, w=640, h=480, workers=0):
+def natural_batch(seed0, n, w=640, h=480):
+    return np.stack([natural_frame(seed0 + i, w, h) for i in range(n)])
+
+
+def natural_batch_parallel(seed0, n, w=640, h=480, workers=0):
+    """natural_batch on worker processes (see synth_batch_parallel)"""
+    return synth_batch_parallel(seed0, n, w, h, workers, family="natural")
+
+
+def synth_batch_parallel(seed0, n, w=640, h=480, workers=0, family="polygons"):
     """synth_batch on worker PROCESSES (a VGA frame costs ~70 ms of numpy: a thousand distinct frames for bench.py would take a minute on one core).
     The workers are plain `python -m rgbd_pl_slam_amd.synth` subprocesses writing .npy files -- no fork after the parent initialised HIP, and no
     multiprocessing re-import of the caller's main script (a tool without a __main__ guard would run again in every worker).  Falls back to the serial
@@ -74,8 +83,9 @@ def synth_batch_parallel(seed0, n, w=640, h=480, workers=0):
     if workers <= 0:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         workers = max(1, min(48, cores // 2, n // 8))
+    serial = natural_batch if family == "natural" else synth_batch
     if workers <= 1 or n < 16:
-        return synth_batch(seed0, n, w, h)
+        return serial(seed0, n, w, h)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         with tempfile.TemporaryDirectory(prefix="plf_synth_") as tmp:
@@ -84,7 +94,7 @@ def synth_batch_parallel(seed0, n, w=640, h=480, workers=0):
                 lo, hi = k * n // workers, (k + 1) * n // workers
                 if hi > lo:
                     out = os.path.join(tmp, "part%03d.npy" % k)
-                    procs.append((out, subprocess.Popen([sys.executable, "-m", "rgbd_pl_slam_amd.synth", str(seed0 + lo), str(hi - lo), str(w), str(h), out],
+                    procs.append((out, subprocess.Popen([sys.executable, "-m", "rgbd_pl_slam_amd.synth", str(seed0 + lo), str(hi - lo), str(w), str(h), out, family],
                                                         cwd=root, env=dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", "")))))
             parts = []
             for out, pr in procs:
@@ -93,7 +103,7 @@ def synth_batch_parallel(seed0, n, w=640, h=480, workers=0):
                 parts.append(np.load(out))
         return np.concatenate(parts)
     except Exception:          # (no subprocesses available: sandboxed hosts)
-        return synth_batch(seed0, n, w, h)
+        return serial(seed0, n, w, h)
 
 
 def texture_frame(seed, kind=None, size=None):
@@ -169,7 +179,8 @@ def natural_frame(seed, w=640, h=480):
     return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
 
 
-if __name__ == "__main__":      # worker of synth_batch_parallel: seed0 n w h out.npy
+if __name__ == "__main__":      # worker of synth_batch_parallel: seed0 n w h out.npy [family]
     import sys
     _s0, _n, _w, _h = (int(x) for x in sys.argv[1:5])
-    np.save(sys.argv[5], synth_batch(_s0, _n, _w, _h))
+    _fam = sys.argv[6] if len(sys.argv) > 6 else "polygons"
+    np.save(sys.argv[5], natural_batch(_s0, _n, _w, _h) if _fam == "natural" else synth_batch(_s0, _n, _w, _h))

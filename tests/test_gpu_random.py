@@ -138,8 +138,9 @@ def test_hamming_properties_full_size():
     assert bool((dab[i, j] <= dab[i, k] + dbb[k, j]).all())
 
 
-@pytest.mark.parametrize("w,h,B,R,nfeat,nlines", [(640, 480, 8192, 64, 1000, 100), (1280, 960, 2048, 16, 4000, 400)])
-def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines):
+@pytest.mark.parametrize("w,h,B,R,nfeat,nlines,family", [(640, 480, 8192, 64, 1000, 100, "mixed"), (1280, 960, 2048, 16, 4000, 400, "mixed"),
+                                                         (640, 480, 8192, 32, 1000, 100, "natural")])
+def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines, family):
     """The shapes the headline is quoted on: 8192 VGA frames in flight (the default of bench.py: eight region-growing chains per SIMD, the 64-register build of
     k_lsd_regions2) and 2048 frames of 1280x960 with 4000 ORB + 400 lines (BASELINE.md's configs[3] shape at bench scale), R independently seeded frames tiled to
     the batch.  Every replica of a frame must reproduce the bytes of its original, and the originals must equal the oracle: key lines, LBD rows, line equations,
@@ -148,9 +149,13 @@ def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines):
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from rgbd_pl_slam_amd import ORBextractor, LineSegment, PlfError
-    from rgbd_pl_slam_amd.synth import synth_frame, texture_frame
+    from rgbd_pl_slam_amd.synth import synth_frame, texture_frame, natural_frame
     from rgbd_pl_slam_amd._lib import KP_DTYPE
-    base = np.stack([synth_frame(900 + r, w=w, h=h) if r % 3 else texture_frame(7000 + r, size=(w, h))[0] for r in range(R)])
+    # ("natural": the natural-image-like family of bench.py's `natural` extras -- twice the region-growing chain, ten times the regions: VERDICT r04 item 2)
+    if family == "natural":
+        base = np.stack([natural_frame(1900 + r, w=w, h=h) for r in range(R)])
+    else:
+        base = np.stack([synth_frame(900 + r, w=w, h=h) if r % 3 else texture_frame(7000 + r, size=(w, h))[0] for r in range(R)])
     with ThreadPoolExecutor(16) as pool:
         ref_orb = list(pool.map(lambda im: orc.orb_extract(im, nfeatures=nfeat), base))
         ref_line = list(pool.map(lambda im: orc.line_extract(im, nlines), base))

@@ -79,3 +79,59 @@ def test_batch_driver_refuses_to_run_without_a_gpu():
     with pytest.raises(L.PlfError) as e:
         BatchExtractor()
     assert e.value.status == L.PLF_E_HIP                            # no CPU path behind the driver either
+
+
+def _pcie_worker(rank, world, port, q):
+    """`bench.py --gpus 2 --pcie` without a GPU: the rank logic (barrier, MAX over the ranks, JSON assembly on rank 0) runs unchanged on gloo; only the GPU leg
+    (plf_batch_extract on pinned host frames) and the local map are stubs"""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def stub_pcie(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml, reps=2, warm=1, dist=None):
+        total = (1.0 + 1.0 * device) * reps                      # rank 1 is twice as slow: the job lasts as long as rank 1
+        dist.barrier()
+        return {"value": round(n_frames / (total / reps), 1), "unit": "frames/s", "frames": n_frames, "frames_in_flight": in_flight,
+                "elapsed_max": bench.reduce_elapsed_max(dist, total, device="cpu"), "worker_numa_node": -1, "worker_cpus_bound": 0}
+
+    args = argparse.Namespace(steps=3, warmup=1, config=2)
+    W, H, NFEAT, NLINES, B0, label = bench.CONFIGS[2]
+    line = bench.run_pcie(args, dist, rank, rank, world, B0, W, H, NFEAT, NLINES, label, pcie_fn=stub_pcie, local_map_fn=lambda: (None, None))
+    q.put((rank, line))
+    dist.destroy_process_group()
+
+
+def test_world2_pcie_branch_json_and_elapsed_max():
+    """the --pcie branch had never executed with world > 1"""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_pcie_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    assert res[1] is None                                   # only rank 0 prints
+    line = res[0]
+    json.dumps(line)                                        # serialisable as it stands
+    in_flight = 4096; n_frames = 4 * in_flight
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    # slowest rank: 2.0 s per call x 3 calls = 6.0 s for 2 ranks x 3 calls x n_frames frames
+    assert line["ms_per_step"] == 2000.0 and line["value"] == round(2 * 3 * n_frames / 6.0, 2)
+    assert line["config"]["frames_per_call_per_gpu"] == n_frames and line["config"]["frames_in_flight_per_gpu"] == in_flight
+    assert "elapsed_max" not in line["pcie"]["rank0"] and line["pcie"]["host_read_GBps_per_gpu"] * 2 == pytest.approx(line["pcie"]["host_read_GBps_aggregate"], abs=0.02)
+
+
+def test_pcie_line_and_reduction_single_rank():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.reduce_elapsed_max(None, 1.25) == 1.25
+    W, H, NFEAT, NLINES, B0, label = bench.CONFIGS[2]
+    line = bench.pcie_line({"value": 1.0, "elapsed_max": 4.0}, 4.0, 1, 16384, 4096, 2, 1, W, H, label, 2)
+    assert line["value"] == round(16384 * 2 / 4.0, 2) and line["n_gpus"] == 1 and "elapsed_max" not in line["pcie"]["rank0"]
