@@ -2203,7 +2203,6 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
-    if (threadIdx.x >= 64) return;
     const int W = g.sw, H = g.sh;
     const size_t fb = (size_t)f * SB.nbands + band;
     int *rs = SB.round_state + f * 4;
@@ -2223,18 +2222,22 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
     const uint32_t *pre = SB.pre + fb * SB.bm_words;
     uint32_t *halo = SB.halo + fb * SB.bm_words;
     // T = what the bands before this one mark now, S = what this band's log assumed they mark; nothing to do where they agree
+    // (round 5: ALL FOUR waves of the workgroup load the two bitmaps -- 2 x 24 KB at VGA, 192 dependent-latency loads per lane of one wave: the 28 us every band
+    // paid in every round it ran, the whole cost of a round in which nothing is regrown; the other three waves leave behind the barrier)
     bool differ = false;
-    for (int i0 = lane; i0 < SB.bm_words; i0 += 256) {
+    for (int i0 = lane; i0 < SB.bm_words; i0 += 1024) {
         uint32_t a[4], e[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u; a[u] = i < SB.bm_words ? pre[i] : 0u; e[u] = i < SB.bm_words ? halo[i] : 0u; }
+        for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u; a[u] = i < SB.bm_words ? pre[i] : 0u; e[u] = i < SB.bm_words ? halo[i] : 0u; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = i0 + 64 * u;
+            const int i = i0 + 256 * u;
             if (i < SB.bm_words) { T[i] = a[u]; if (SG) __hip_atomic_store(&S.g[i], e[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.l[i] = e[u]; differ |= a[u] != e[u]; }
         }
     }
-    if (!__ballot(differ)) return;
+    if (SG) __threadfence();
+    if (!__syncthreads_or(differ ? 1 : 0)) return;
+    if (threadIdx.x >= 64) return;
     for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
     CBAR();
     for (int wi = lane; wi < SB.bm_words; wi += 64) {

@@ -392,7 +392,7 @@ static int match_lastframe_impl(plf_matcher *h, const plf_frame_view *frames, in
     // the span table one row per last-frame point, the lists the LDS.  Frames that overflow the pool, and everything else, use k_match_lastframe.
     const int item_cap = (last->n + 1) & ~1;
     const size_t lds_fast = (size_t)kp_cap * 8 + 3 * (size_t)item_cap * sizeof(uint16_t);
-    const bool fast = !RL.on && n_frames > 1 && maxn <= 65535 && last->n <= 65534 && last->n <= h->max_mp && last->n > 0 && lds_fast <= 150 * 1024;
+    const bool fast = !RL.on && n_frames >= 1 && maxn <= 65535 && last->n <= 65534 && last->n <= h->max_mp && last->n > 0 && lds_fast <= 150 * 1024;
     if (fast) {
         PLF_HIP_TRY(hipMemsetAsync(h->d_overflow, 0, 2 * (size_t)h->max_batch * sizeof(int), s));
         hipLaunchKernelGGL(k_lf_candidates, dim3((last->n + 255) / 256, n_frames), dim3(256), 0, s, h->d_frames, L, d_poses, th, mono, match_of_kp, kp_stride,
@@ -789,7 +789,7 @@ extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view 
     M.m = ml->m; M.x1 = ml->x1; M.y1 = ml->y1; M.x2 = ml->x2; M.y2 = ml->y2; M.level = ml->level; M.view_cos = ml->view_cos;
     M.in_view = ml->in_view; M.desc = ml->desc;
     const int cap = (maxn + 63) & ~63;
-    hipLaunchKernelGGL(k_match_project_lines, dim3(n_frames), dim3(256), (size_t)cap * 8, s, h->d_lframes, M, th, nnratio, match_of_line,
+    hipLaunchKernelGGL(k_match_project_lines, dim3(n_frames), dim3(256), (size_t)cap * 56, s, h->d_lframes, M, th, nnratio, match_of_line,
                        line_stride, nmatches, h->d_done, cap);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;

@@ -64,15 +64,32 @@ __global__ void __launch_bounds__(256) k_build_grid(const FrameDev *__restrict__
     plf_block_excl_scan(cnt, GRID_CELLS + 1, scan_tmp);
     for (int c = t; c <= GRID_CELLS; c += T) cs[c] = cnt[c];
     __syncthreads();
-    // stable placement: rank of key point i among the earlier key points of the same cell
-    for (int i = t; i < F.n; i += T) {
-        const int c = cell_of[i];
-        if (c < 0) continue;
-        int r = 0;
-        for (int j = 0; j < i; j++) r += (cell_of[j] == c);
-        ci[cnt[c] + r] = i;
-        const plf_keypoint kp = F.keys[i];
-        const_cast<float4 *>(F.cell_kp)[cnt[c] + r] = make_float4(kp.x, kp.y, __int_as_float(kp.octave), __int_as_float(i));
+    // stable placement (insertion order inside a cell = key-point order).  Round 5: ONE wave walks the key points in chunks of 64 -- the rank of a key point among
+    // the earlier ones of its cell = the cell's cursor (cnt[], advanced chunk by chunk) + the lanes below it in the chunk that hold the same cell (64 v_readlane
+    // compares).  Until then every key point counted ALL earlier key points of the frame with the same cell, a loop of dependent global loads: O(n^2) -- 0.12 ms
+    // per call for the 1000 key points of one VGA frame, 0.53 ms for 2000, twice per frame (map-point and last-frame search): as long as the ORB extraction itself.
+    if (t < 64) {
+        for (int base = 0; base < F.n; base += 64) {
+            const int i = base + t;
+            const int c = i < F.n ? cell_of[i] : -1;
+            int r = 0, total = 0;
+#pragma unroll 8
+            for (int l = 0; l < 64; l++) {
+                const int cl = __builtin_amdgcn_readlane(c, l);
+                const bool same = cl == c;
+                r += (same && l < t) ? 1 : 0; total += same ? 1 : 0;
+            }
+            int pos = 0;
+            if (c >= 0) {
+                pos = cnt[c] + r;
+                ci[pos] = i;
+                const plf_keypoint kp = F.keys[i];
+                const_cast<float4 *>(F.cell_kp)[pos] = make_float4(kp.x, kp.y, __int_as_float(kp.octave), __int_as_float(i));
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (c >= 0 && r == total - 1) cnt[c] = pos + 1;   // the last lane of every cell group moves the cell's cursor (one writer per cell)
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -1321,12 +1338,33 @@ __device__ __forceinline__ bool line_in_area(const plf_keyline &kl, float x1, fl
     return true;
 }
 
+// the same test on the four fields of a key line staged in LDS (x = pt_x, y = pt_y, z = angle, w = octave bits): identical arithmetic
+__device__ __forceinline__ bool line_in_area4(const float4 kl, float x1, float y1, float x2, float y2, float r, int minLevel, int maxLevel)
+{
+    const double dx = 0.5 * (double)(x1 + x2) - (double)kl.x, dy = 0.5 * (double)(y1 + y2) - (double)kl.y;
+    const double distance = dx * dx + dy * dy;
+    if (distance > (double)(r * r)) return false;
+    const float slope = (y1 - y2) / (x1 - x2) - kl.z;
+    if ((double)slope > (double)r * 0.01) return false;
+    const int octave = __float_as_int(kl.w);
+    if ((minLevel > 0) || (maxLevel > 0)) {
+        if (octave < minLevel) return false;
+        if (maxLevel >= 0 && octave > maxLevel) return false;
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
                                                              int *__restrict__ match_all, int line_stride, int *__restrict__ nmatches,
                                                              uint8_t *__restrict__ done_all, int line_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *claim = (int *)smem, *owner = claim + line_cap;
+    // Round 5: the four fields of every key line that the window test reads and its 32 descriptor bytes are staged in LDS once (line_cap is a multiple of 64: 56 bytes
+    // per line).  Every thread walks ALL lines of the frame three times per round for each of its map lines -- from global memory that was 0.30 ms for one frame
+    // of 100 lines against 500 map lines, on the critical path of a single frame: the line matchers can only start when LSD + LBD are done.
+    float4 *lg = reinterpret_cast<float4 *>(owner + line_cap);
+    uint4 *ld = reinterpret_cast<uint4 *>(lg + line_cap);
     __shared__ int s_left, s_acc;
     const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x;
     LineFrameDev F = frames[f];
@@ -1334,7 +1372,13 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
     int *match = match_all + (size_t)f * line_stride;
     uint8_t *done = done_all + (size_t)f * ML.m;
     const bool bFactor = th != 1.0f;
-    for (int k = t; k < F.n; k += T) claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
+    for (int k = t; k < F.n; k += T) {
+        claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
+        const plf_keyline kl = F.lines[k];
+        lg[k] = make_float4(kl.pt_x, kl.pt_y, kl.angle, __int_as_float(kl.octave));
+        const uint4 *dsrc = reinterpret_cast<const uint4 *>(F.desc + 32 * (size_t)k);
+        ld[2 * k] = dsrc[0]; ld[2 * k + 1] = dsrc[1];
+    }
     if (t == 0) s_acc = 0;
     for (int m = t; m < ML.m; m += T) done[m] = ML.in_view[m] ? 0 : 1;
     __syncthreads();
@@ -1348,8 +1392,9 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
             float r = radius_by_viewing_cos(ML.view_cos[m]);
             if (bFactor) r *= th;
             const float rad = r * F.scale_factors[lvl];
+            const float mx1 = ML.x1[m], my1 = ML.y1[m], mx2 = ML.x2[m], my2 = ML.y2[m];
             for (int i = 0; i < F.n; i++)
-                if (claim[i] == -1 && line_in_area(F.lines[i], ML.x1[m], ML.y1[m], ML.x2[m], ML.y2[m], rad, lvl - 1, lvl)) atomicMin(&owner[i], m);
+                if (claim[i] == -1 && line_in_area4(lg[i], mx1, my1, mx2, my2, rad, lvl - 1, lvl)) atomicMin(&owner[i], m);
         }
         __syncthreads();
         for (int m = t; m < ML.m; m += T) {
@@ -1358,19 +1403,23 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
             float r = radius_by_viewing_cos(ML.view_cos[m]);
             if (bFactor) r *= th;
             const float rad = r * F.scale_factors[lvl];
+            const float mx1 = ML.x1[m], my1 = ML.y1[m], mx2 = ML.x2[m], my2 = ML.y2[m];
             bool safe = true;
             for (int i = 0; i < F.n; i++)
-                if (claim[i] == -1 && owner[i] != m && line_in_area(F.lines[i], ML.x1[m], ML.y1[m], ML.x2[m], ML.y2[m], rad, lvl - 1, lvl)) safe = false;
+                if (claim[i] == -1 && owner[i] != m && line_in_area4(lg[i], mx1, my1, mx2, my2, rad, lvl - 1, lvl)) safe = false;
             if (!safe) { atomicAdd(&s_left, 1); continue; }
             int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-            const uint8_t *d = ML.desc + 32 * (size_t)m;
+            const uint4 d0 = reinterpret_cast<const uint4 *>(ML.desc + 32 * (size_t)m)[0], d1 = reinterpret_cast<const uint4 *>(ML.desc + 32 * (size_t)m)[1];
             for (int i = 0; i < F.n; i++) {
                 if (claim[i] != -1) continue;
-                const plf_keyline kl = F.lines[i];
-                if (!line_in_area(kl, ML.x1[m], ML.y1[m], ML.x2[m], ML.y2[m], rad, lvl - 1, lvl)) continue;
-                const int dist = hamming_g(d, F.desc + 32 * (size_t)i);
-                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kl.octave; bestIdx = i; }
-                else if (dist < bestDist2) { bestLevel2 = kl.octave; bestDist2 = dist; }
+                const float4 kl = lg[i];
+                if (!line_in_area4(kl, mx1, my1, mx2, my2, rad, lvl - 1, lvl)) continue;
+                const uint4 b0 = ld[2 * i], b1 = ld[2 * i + 1];
+                const int dist = __popc(d0.x ^ b0.x) + __popc(d0.y ^ b0.y) + __popc(d0.z ^ b0.z) + __popc(d0.w ^ b0.w) + __popc(d1.x ^ b1.x) + __popc(d1.y ^ b1.y) +
+                                 __popc(d1.z ^ b1.z) + __popc(d1.w ^ b1.w);
+                const int oct = __float_as_int(kl.w);
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct; bestIdx = i; }
+                else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; }
             }
             done[m] = 1;
             if (bestDist <= TH_HIGH) {
