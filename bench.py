@@ -301,6 +301,28 @@ def single_frame_latency(device, w, h, nfeat, nlines, reps=20, family="polygons"
             "what": "one %dx%d frame (%s), host memory in and out, nothing else in flight" % (w, h, family)}
 
 
+def tracking_call_latency(device, cfg, family="polygons", reps=30):
+    """What ONE TrackRGBD call sees of this path (Examples/RGB-D/rgbd_tum.cc:96-116 times the call per frame): both extractors of one frame on two streams, then
+    the four tracking matchers, synchronised after every frame -- nothing else in flight, features and matches device-resident."""
+    import numpy as np
+    import torch
+    W, H, NFEAT, NLINES, _, label = CONFIGS[cfg]
+    p = Pipeline(W, H, NFEAT, NLINES, 1, device, 4321, defer_match=False, distinct=1, family=family)
+    for _ in range(4):
+        p.step()
+    torch.cuda.synchronize()
+    ts, tm = [], []
+    for _ in range(reps):
+        t = time.perf_counter(); p.step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    for _ in range(reps):
+        t = time.perf_counter(); p.match_step(); torch.cuda.synchronize(); tm.append(time.perf_counter() - t)
+    m0 = p.matches_frame0()
+    p.close()
+    return {"extract_and_match_ms_median": round(1e3 * float(np.median(ts)), 3), "matchers_alone_ms_median": round(1e3 * float(np.median(tm)), 3), "frames": reps,
+            "keypoints": m0["keypoints"], "lines": m0["lines"], "what": "one %dx%d frame (%s), %d ORB + %d lines, both extractors then the four matchers, synchronised per frame" %
+                                                                        (W, H, family, NFEAT, NLINES)}
+
+
 def reduce_elapsed_max(dist, seconds, device="cuda"):
     """the job lasts as long as its slowest rank: MAX over the ranks of one float (the only reduction on the whole path; nccl = RCCL on the GPU box, gloo in the
     CPU test tests/test_sharding.py)"""
@@ -519,9 +541,7 @@ def main():
         # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
         traffic, traffic_source = None, None
         try:
-            src = os.path.join("profiles", "r04_pmc_traffic.json")
-            if not os.path.exists(os.path.join(ROOT, src)):
-                src = os.path.join("profiles", "r03_pmc_traffic.json")
+            src = next((c for c in (os.path.join("profiles", "r%02d_pmc_traffic.json" % r) for r in (5, 4, 3)) if os.path.exists(os.path.join(ROOT, c))), None)
             with open(os.path.join(ROOT, src)) as fh:
                 pmc = json.load(fh)
             if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):
@@ -535,14 +555,15 @@ def main():
         # tools/classify_isa.py) over 1024 SIMDs x clock x the step time measured here
         valu_frac, valu_source = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_valu_classes.json")) as fh:
+            vsrc = next(c for c in (os.path.join("profiles", "r%02d_valu_classes.json" % r) for r in (5, 4)) if os.path.exists(os.path.join(ROOT, c)))
+            with open(os.path.join(ROOT, vsrc)) as fh:
                 vc = json.load(fh)
             if args.config == 2:
                 cyc = vc["valu_issue_simd_cycles_per_step"] * B / vc["frames_per_step"]
                 step_s = elapsed / args.steps
                 valu_frac = round(cyc / (vc["simds"] * vc["clock_hz"] * step_s), 3)
-                valu_source = ("profiles/r04_valu_classes.json: %.3g VALU wave-instructions per %d-frame step (SQ_INSTS_VALU), mean %.2f issue cycles each by class "
-                               "(tools/classify_isa.py; intervals from profiles/r03_valu_issue.json)" % (vc["valu_wave_instructions_per_step"], vc["frames_per_step"],
+                valu_source = ("%s: %.3g VALU wave-instructions per %d-frame step (SQ_INSTS_VALU), mean %.2f issue cycles each by class "
+                               "(tools/classify_isa.py; intervals from profiles/r03_valu_issue.json)" % (vsrc, vc["valu_wave_instructions_per_step"], vc["frames_per_step"],
                                                                                                         vc["mean_cycles_per_valu"]))
         except Exception:
             valu_frac = None
@@ -596,6 +617,10 @@ def main():
                                            "region_stage_ms": round(r3 / max(n3, 1), 3)}
             p3.close(); del p3
             out["single_frame_latency"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES)
+            # the reference's own operating regime: one frame per TrackRGBD call, extraction AND the tracking matchers (round 5: the matchers of a single frame had
+            # never been timed -- the last-frame search alone took 2.7 ms per 1000 key points)
+            out["tracking_call_latency"] = {"config2": tracking_call_latency(local_rank, 2), "config3_one_frame": tracking_call_latency(local_rank, 3),
+                                            "config2_natural": tracking_call_latency(local_rank, 2, family="natural")}
             out["pcie_inclusive"] = pcie_inclusive(local_rank, W, H, NFEAT, NLINES, 16384, 4096, mp, ml)
             out["pcie_inclusive"].pop("elapsed_max", None)
         if world == 1 and args.config == 2 and not args.no_extras and not args.serial:

@@ -271,3 +271,25 @@ def test_natural_image_family_single_few_and_many():
                 _eq_orb(ro[f][0], ro[f][1], refs_o[i])
                 assert rl[f][0].tobytes() == refs_l[i]["kl"].tobytes() and np.array_equal(rl[f][1], refs_l[i]["desc"]), (w, B, f)
         ext.close(); ls.close()
+
+
+def test_large_batch_balance_is_only_a_schedule():
+    """Round 5: the frames of a large batch are dealt to the waves of k_lsd_regions2 by chain length (k_lsd_balance).  Which wave grows which frame must not change a
+    byte: 700 mixed frames (natural-image-like, textures, polygon scenes -- chain lengths from 10^4 to 2 * 10^5) with the balance on and off, and frame by frame
+    against the oracle on a sample."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame, texture_frame, natural_frame
+    B = 700
+    base = [natural_frame(4000 + r) if r % 3 == 0 else texture_frame(4100 + r, size=(640, 480))[0] if r % 3 == 1 else synth_frame(4200 + r) for r in range(28)]
+    imgs = np.stack([base[i % 28] for i in range(B)])
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
+    on = ls.extract_batch(imgs)
+    ls.tune("balance", 0)
+    off = ls.extract_batch(imgs)
+    for f in range(B):
+        assert on[f][0].tobytes() == off[f][0].tobytes() and np.array_equal(on[f][1], off[f][1]) and on[f][2].tobytes() == off[f][2].tobytes(), "frame %d" % f
+    for f in (0, 1, 2, 27, 400, 699):
+        ref = orc.line_extract(base[f % 28], 100)
+        assert np.array_equal(on[f][1], ref["desc"]) and on[f][0].tobytes() == ref["kl"].tobytes(), "frame %d" % f
+    ls.close()
