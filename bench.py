@@ -56,6 +56,9 @@ def algorithmic_bytes(w, h, nfeat, nlines, lam_per_line=80):
     return b_orb, b_line, 6 * ps
 
 
+_STREAM_CACHE = {}
+
+
 class Pipeline:
     """the device-resident step: both extractors + the four matchers for B frames in flight on one GPU"""
 
@@ -96,11 +99,17 @@ class Pipeline:
         # HIP streams: LSD/LBD on a high-priority stream per line handle (region growing is a serial chain per frame and the long pole), ORB on sA,
         # the matchers on sM.  The two extractors are independent, as the two threads of the PL-SLAM Frame constructor are.
         pa, pb, pm = [int(x) for x in os.environ.get("PLF_BENCH_PRIO", "0,-1,0").split(",")]
-        self.sA = torch.cuda.Stream(priority=pa)
-        self.sBs = [torch.cuda.Stream(priority=pb) for _ in self.lins]
+        # (one set of streams per process, shared by every Pipeline: torch hands out its pooled streams round-robin and HIP maps them onto a few hardware queues,
+        # so the ORB and matcher streams of a LATER pipeline could land on one queue -- the natural-image extras, the tenth pipeline of a run, ran 10 % slower and
+        # with region-kernel launches alternating between 210 and 330 ms, which a fresh process never showed: profiles/r05_regions_trace.txt)
+        key = (device, pa, pb, pm, len(self.lins))
+        if key not in _STREAM_CACHE:
+            _STREAM_CACHE[key] = (torch.cuda.Stream(priority=pa), [torch.cuda.Stream(priority=pb) for _ in self.lins], torch.cuda.Stream(priority=pm))
+        self.sA, sBs_, sM_ = _STREAM_CACHE[key]
+        self.sBs = list(sBs_)
         if serial:
             self.sBs = [self.sA for _ in self.lins]
-        self.sM = self.sA if serial else torch.cuda.Stream(priority=pm)
+        self.sM = self.sA if serial else sM_
         # local map / last frame built from the features of frame 0 (so that real matches exist); replicas per GPU
         b0 = self.bufs[0]
         torch.cuda.synchronize()
@@ -307,12 +316,15 @@ def tracking_call_latency(device, cfg, family="polygons", reps=30):
     import numpy as np
     import torch
     W, H, NFEAT, NLINES, _, label = CONFIGS[cfg]
+    from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
     p = Pipeline(W, H, NFEAT, NLINES, 1, device, 4321, defer_match=False, distinct=1, family=family)
-    for _ in range(4):
-        p.step()
+    frames = torch.from_numpy(np.stack([(natural_frame if family == "natural" else synth_frame)(7000 + i, W, H) for i in range(6)])).cuda()   # (the frames of single_frame_latency)
+    for i in range(6):
+        p.d_img[0].copy_(frames[i]); p.step()
     torch.cuda.synchronize()
     ts, tm = [], []
-    for _ in range(reps):
+    for i in range(reps):
+        p.d_img[0].copy_(frames[i % 6]); torch.cuda.synchronize()
         t = time.perf_counter(); p.step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     for _ in range(reps):
         t = time.perf_counter(); p.match_step(); torch.cuda.synchronize(); tm.append(time.perf_counter() - t)
