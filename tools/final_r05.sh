@@ -20,6 +20,9 @@ bash tools/variant_build.sh rl lsd_kernels.hip=-DPLF_ROUND_LOG line_host.hip=-DP
 timeout 1200 python tools/soak_large.py 9000 3000 > $O/r05_soak.txt 2>&1
 timeout 900 python tools/soak.py 200 32 40000 >> $O/r05_soak.txt 2>&1
 timeout 600 python tools/soak_match.py 120 9000 >> $O/r05_soak.txt 2>&1
+bash tools/r05_regions_trace.sh > $O/r05_regions_trace.txt 2>&1
+( bash tools/lsd_timing.sh && python tools/lsd_timing2.py polygons 0 && python tools/lsd_timing2.py natural 0 ) 2>&1 | grep -v amdgpu.ids > $O/r05_timing.txt
+timeout 1500 python tools/baseline_table.py r05 > $O/r05_baseline_table.log 2>&1
 timeout 1500 python bench.py > $O/r05_bench_default.json 2> $O/r05_bench_default.err
 python - <<'PY'
 import json
