@@ -204,6 +204,20 @@ static void region_grow(lsd_t *L, int sx, int sy, regpt *reg, int *reg_size, dou
         }
     }
     *reg_size = n;
+#ifdef ORC_LSD_STATS   /* tools/singleton_stats.c */
+    {
+        extern long orc_stat[16];
+        orc_stat[0]++; orc_stat[3] += n;
+        if (n <= 3) { orc_stat[4]++; orc_stat[5] += n; }
+        if (n == 1) {
+            orc_stat[1]++;
+            int compat = 0;
+            for (int yy = sy - 1; yy <= sy + 1; ++yy) for (int xx = sx - 1; xx <= sx + 1; ++xx)
+                if ((xx != sx || yy != sy) && is_aligned(L, xx, yy, L->angles[addr], prec)) compat++;
+            if (!compat) orc_stat[2]++;
+        }
+    }
+#endif
 }
 
 static double get_theta(const regpt *reg, int reg_size, double x, double y, double reg_angle, double prec)

@@ -159,6 +159,7 @@ struct plf_line {
     unsigned long long *d_sort_scratch;   // [frame][sort_cap] when sort_cap > sort_lds
     double2 *d_cs;
     float2 *d_cs0;
+    uint8_t *d_sgl;           // [max_batch][s_stride] neighbour bytes of k_lsd_pre (LsdGeom::sgl)
     float *d_ang;
     uint32_t *d_rxy;
     LsdRect *d_rects;
@@ -191,7 +192,7 @@ struct plf_line {
 static void line_free(plf_line *h)
 {
     void *ptrs[] = {h->d_in, h->d_keep, h->d_ldesc, h->d_modgrad, h->d_maxgrad, h->d_keys[0], h->d_keys[1], h->d_seg_off, h->d_sort_tmp, h->d_lineeq, h->d_cs,
-                    h->d_ang, h->d_rxy, h->d_cs0, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
+                    h->d_ang, h->d_rxy, h->d_cs0, h->d_sgl, h->d_rects, h->d_seg, h->d_segs_out, h->d_grad, h->d_kl_tmp, h->d_lines, h->d_counters,
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_balance, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_nfa_fcnt, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
@@ -298,6 +299,7 @@ static int line_configure(plf_line *h, int w, int hh)
     while (g.sort_cap < g.rect_cap) g.sort_cap <<= 1;
     g.sort_lds = g.sort_cap < 4096 ? g.sort_cap : 4096;
     g.nfa_pool = h->alloc_nfa_pool;
+    g.sgl = h->d_sgl;
     // kernels of a previous call (any stream: the caller's streams do not synchronise with the null stream) may still read the tables
     if (h->cur_w >= 0) PLF_HIP_TRY(hipDeviceSynchronize());
     PLF_HIP_TRY(hipMemcpy(h->d_xofs, xofs.data(), sizeof(int) * g.sw, hipMemcpyHostToDevice));
@@ -377,6 +379,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_cs, B * S * sizeof(double2));
     ALLOC(h->d_ang, B * S * sizeof(float));
     ALLOC(h->d_cs0, B * S * sizeof(float2));
+    ALLOC(h->d_sgl, B * S);
     ALLOC(h->d_rxy, B * S * sizeof(uint32_t));
     ALLOC(h->d_rects, B * R * sizeof(LsdRect));
     ALLOC(h->d_seg, B * R * sizeof(float4));

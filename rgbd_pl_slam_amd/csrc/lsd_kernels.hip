@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     // fastAtan2 and sincos below run on full waves of defined pixels only.  modgrad is written for those pixels alone: nothing reads it elsewhere
     // (region2rect weighs region points, k_lsd_maxgrad / k_lsd_seedkeys test the angle first).
     __shared__ int s_ndef;
+    __shared__ float s_angt[PRE_TW * PRE_TH];                    // the tile's level-line angles (NOTDEF_F where there is none): the neighbour bytes below
     double *s_q = s_tmp;                                         // the blurred tile is dead after the resize: q, offset inside the frame, (float)gx, (float)-gy
     int *s_off = reinterpret_cast<int *>(s_tmp + PRE_TW * PRE_TH);
     float *s_fx = reinterpret_cast<float *>(s_off + PRE_TW * PRE_TH), *s_fy = s_fx + PRE_TW * PRE_TH;
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         bool def = false;
         double q = 0.0;
         float fx = 0.f, fy = 0.f;
+        s_angt[ty * PRE_TW + tx] = NOTDEF_F;
         if (x < g.sw && y < g.sh) {
             if (x < g.sw - 1 && y < g.sh - 1) {
                 const double *im = s_sc + ty * (PRE_TW + 1) + tx;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         base = __builtin_amdgcn_readfirstlane(base);
         if (def) {
             const int e = base + __popcll(m & ((1ull << plf_lane()) - 1ull));
-            s_q[e] = q; s_off[e] = y * g.sw + x; s_fx[e] = fx; s_fy[e] = fy;
+            s_q[e] = q; s_off[e] = ty * PRE_TW + tx; s_fx[e] = fx; s_fy[e] = fy;   // (the position inside the tile: the frame offset follows from it)
         }
     }
     __syncthreads();
@@ -233,10 +235,12 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     double2 *csf = cs + (size_t)f * g.s_stride;
     float2 *cs0f = cs0 + (size_t)f * g.s_stride;
     for (int i = tid; i < ndef; i += PRE_NT) {
-        const unsigned o = (unsigned)s_off[i];   // (32-bit offsets from the frame's scalar base pointers)
+        const int loc = s_off[i];
+        const unsigned o = (unsigned)((dy0 + loc / PRE_TW) * g.sw + dx0 + loc % PRE_TW);   // (32-bit offsets from the frame's scalar base pointers)
         mgf[o] = sqrt(s_q[i]);
         const float deg = plf_fast_atan2_1div(s_fx[i], s_fy[i]);
         angf[o] = deg;
+        s_angt[loc] = deg;
         const double ad = (double)deg * DEG2RAD_D;
         const double af = (double)(float)ad;
         double sf, cf;
@@ -246,6 +250,34 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         // within ~2 ulp (double) of cos / sin (ad), i.e. as close to the correctly rounded value as a second libm call is, at a twentieth of its cost
         const double eps = ad - af, h = 0.5 * eps * eps;
         cs0f[o] = make_float2((float)(cf - eps * sf - h * cf), (float)(sf + eps * cf - h * sf));
+    }
+    // Neighbour bytes (LsdGeom::sgl; see singles_run in the region-growing section): for every pixel with an angle, which of its 8 neighbours MAY pass the first
+    // alignment test of a region seeded here -- angle within the tolerance + 0.001 degrees of this pixel's (circular difference in single precision: a superset of
+    // the reference's double test), or outside this tile and inside the image (unknown).  Byte 0 = the seed can only ever grow itself.
+    if (g.sgl) {
+        __syncthreads();
+        uint8_t *sglf = g.sgl + (size_t)f * g.s_stride;
+        const float tol = (float)(g.prec * (180.0 / PI_D)) + 1.0e-3f;
+        for (int i = tid; i < ndef; i += PRE_NT) {
+            const int loc = s_off[i], ty = loc / PRE_TW, tx = loc % PRE_TW;
+            const int x = dx0 + tx, y = dy0 + ty;
+            const float a = s_angt[loc];
+            uint32_t m8 = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int ddx = (k < 3 ? k : k == 3 ? 0 : k == 4 ? 2 : k - 5) - 1, ddy = k < 3 ? -1 : k < 5 ? 0 : 1;
+                const int nx = tx + ddx, ny = ty + ddy;
+                bool may;
+                if (nx >= 0 && nx < PRE_TW && ny >= 0 && ny < PRE_TH) {
+                    const float b = s_angt[ny * PRE_TW + nx];
+                    float d = fabsf(a - b);
+                    d = fminf(d, 360.f - d);
+                    may = b >= 0.f && d < tol;
+                } else may = x + ddx >= 0 && y + ddy >= 0 && x + ddx < g.sw && y + ddy < g.sh;
+                m8 |= may ? (1u << k) : 0u;
+            }
+            sglf[(unsigned)(y * g.sw + x)] = (uint8_t)m8;
+        }
     }
 }
 
@@ -324,6 +356,7 @@ struct RegCtx {
     const double *modgrad;
     const double2 *cs;
     const float2 *cs0;
+    const uint8_t *sgl;        // per pixel with an angle: which neighbours may pass the first test of a region seeded here (k_lsd_pre; 0 = the seed can only grow itself)
     int cbase;                 // first pixel of the 64-pixel seed chunk being scanned (regions_body; chunk_taken)
     LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
@@ -975,6 +1008,31 @@ __device__ __forceinline__ unsigned long long chunk_taken(RegCtx &C, int n, int 
     return __ballot(v != 0u);
 }
 
+// Seeds that can only grow a ONE-pixel region (round 5).  On natural-image-like frames 44 % of the regions region growing starts are a single pixel (21 % on the
+// polygon scenes; tools/singleton_stats.py): the seed's 8 neighbours are undefined, taken, or not aligned with the seed's own level-line angle -- and the first
+// step of region_grow tests exactly that, every neighbour against reg_angle = the seed's angle (the sums only move after the first accept).  Such a seed costs the
+// whole per-seed path plus one group (~250 instructions) to mark one pixel.  k_lsd_pre therefore leaves one byte per pixel with a level-line angle (LsdGeom::sgl):
+// bit k set iff neighbour k (raster order, the centre skipped) MAY pass that first test -- it has an angle within the tolerance + 0.001 degrees (single precision:
+// a superset of the reference's double-precision test |theta - a| <= prec, wrap at 3/2 pi = the circular difference; the float differences are good to 5e-5
+// degrees), or it lies outside the tile k_lsd_pre was looking at (unknown: 11 % of the pixels have such neighbours).  A seed whose byte is 0 is a STATIC SINGLE:
+// whatever has been marked or released by the time its turn comes, no neighbour can be accepted, its region is the seed alone -- 72 % of the single-pixel regions
+// of natural-image-like frames, 46 % on the polygon scenes.  At its turn it sets its flag and nothing else (n = 1 < min_reg_size: no rectangle, no chunk_taken);
+// a run of singles in front of the next ordinary seed is marked in one step -- the same flags in the same order as the serial loop.  A single that an earlier
+// region takes (a region's mean angle may accept what none of its pixels would) leaves the seed mask the usual way.
+// (Measured and dropped: looking at the neighbours' USED flags as well when a chunk is loaded -- eight more loads and ~90 instructions per chunk of 64 seeds
+// with mostly 1-3 candidate lanes -- finds the other singles too and costs the polygon scenes more than it saves: k_lsd_regions2 64.5 -> 66.7 ms per 8192
+// frames, natural 209 -> 191.5 ms; tools/experiments/README.md.)
+// the leading run of singles of the seed mask: the seeds in front of the first one that needs the pipeline
+__device__ __forceinline__ unsigned long long singles_run(unsigned long long mask, unsigned long long smask)
+{
+    const unsigned long long ns = mask & ~smask;
+    const unsigned long long below = ns ? ((ns & (0ull - ns)) - 1ull) : ~0ull;
+    return mask & smask & below;
+}
+#ifndef PLF_LSD_SINGLES
+#define PLF_LSD_SINGLES 1   // (0: every seed takes the pipeline -- the A/B switch, tools/ab.sh)
+#endif
+
 // LDS of one wave of the large-batch region kernel: the first 1280 words of the region list (rcap <= 1279 + the mailbox word) and 1 KB for the parked seed chunk
 // (PLF_LSD_WAVE_LIST / PLF_LSD_WAVE_LDS: lsd_geom.h, shared with the host)
 #ifndef PLF_REGIONS_PRIO
@@ -1008,6 +1066,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
+    C.sgl = g.sgl + (size_t)f * g.s_stride;
     C.rxy_l = (LDS_PTR(uint32_t))smem;
     C.rcap = LDSOFF < 0 ? min(g.rcap, PLF_LSD_WAVE_LIST / 4 - 1) : g.rcap;   // (the large-batch kernel keeps a shorter head of the list in LDS)
     C.gcap = (int)g.s_stride;
@@ -1041,19 +1100,42 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     int bx = 0, by = 0;
     for (int base = 0; base < NP; base += 64, bx += 64) {
         if (bx >= W) { bx -= W; by++; }
-        unsigned long long mask;
+        unsigned long long mask, smask = 0ull;
         {
             int px = base + lane;
             if (seeds) px = px < NP ? (int)(seeds[px] & 0xFFFFFu) : NP;
             float2 c0 = make_float2(0.f, 0.f);
             if (px < NP) c0 = C.cs0[px];
+            // (the neighbour byte is fetched WITH the angle word, for every lane: under `w < 0x80000000` it was a second, dependent round trip per chunk -- the
+            // kernel is a chain of round trips as much as of instructions: 207 -> 215 ms per 8192 natural frames instead of a gain)
+            const uint32_t sb = (PLF_LSD_SINGLES && px < NP) ? (uint32_t)C.sgl[px] : 0xFFu;
             const uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
-            park[lane] = park_t{(uint32_t)px, w, __float_as_uint(c0.x), __float_as_uint(c0.y)};
             mask = __ballot(w < 0x80000000u);
+            if (PLF_LSD_SINGLES) smask = __ballot(w < 0x80000000u && sb == 0u);
+            park[lane] = park_t{(uint32_t)px, w, __float_as_uint(c0.x), __float_as_uint(c0.y)};
         }
         CBAR();
         C.cbase = seeds ? -0x40000000 : base;
         while (mask) {
+#ifndef PLF_NO_UNI_MASK
+            // Round 5: the seed mask is pinned to scalar registers.  It is wave-uniform by construction (ballots), but the compiler kept it in a VGPR pair and ran this
+            // loop as a divergent one -- v_ffbl, 64-bit vector shifts and EXEC save / restore around every seed: k_lsd_regions2 198 -> 181 ms per 8192
+            // natural-image-like frames (38 k seeds per frame), VGPR spills 21 -> 9 (tools/r05_ab_quick.sh; -DPLF_NO_UNI_MASK restores the old code).
+            mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mask >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)mask);
+#endif
+            if (PLF_LSD_SINGLES) {
+                // the static singles in front of the next ordinary seed: their flags, nothing else (n = 1).  Every lane of the run reads its own parked entry into
+                // registers of its own.  (A variant that took one single per trip, flagged in its parked pixel index and stored from the registers of the broadcast
+                // read `park[j]`, made the compiler put `s_waitcnt vmcnt(0)` in front of that read -- the pending flag stores of the previous seed -- for EVERY seed:
+                // 207 -> 213 ms per 8192 natural frames instead of a gain.)
+                const unsigned long long run = smask ? singles_run(mask, smask) : 0ull;   // (most chunks of a hard-edged scene hold no single: one scalar test per seed)
+                if (run) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(run)) { const park_t me = park[lane]; used_set(C, (int)me.x, me.y); }
+                    CNT(23, __popcll(run));
+                    mask &= ~run; smask &= ~run;
+                    if (!mask) break;
+                }
+            }
             if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
             const park_t sv = park[j];
@@ -1102,12 +1184,23 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
         // (the seed sums are fetched with the angle words, not after them: one round trip per chunk of 64 seeds instead of two dependent ones)
         float2 c0 = make_float2(0.f, 0.f);
         if (px < NP) c0 = C.cs0[px];
+        const uint32_t sb = (PLF_LSD_SINGLES && px < NP) ? (uint32_t)C.sgl[px] : 0xFFu;   // (with the angle word, not behind it)
         uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
         const float deg = __uint_as_float(w);
         C.cbase = seeds ? -0x40000000 : base;   // (list order: the chunk is not contiguous, flags are re-read after every region)
-        unsigned long long mask = __ballot(ok);
+        unsigned long long mask = __ballot(ok), smask = 0ull;
+        if (PLF_LSD_SINGLES && mask) smask = __ballot(ok && sb == 0u);
         while (mask) {
+            if (PLF_LSD_SINGLES) {
+                const unsigned long long run = singles_run(mask, smask);
+                if (run) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(run)) used_set(C, px, w);
+                    ok = ok && !((run >> lane) & 1ull);
+                    mask &= ~run;
+                    if (!mask) break;
+                }
+            }
             if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
             const int seed = __builtin_amdgcn_readlane(px, j);
@@ -1356,6 +1449,7 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
+    C.sgl = g.sgl + (size_t)f * g.s_stride;
     C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
     C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
     C.cbase = -0x40000000;
@@ -1632,15 +1726,47 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     if (record) { CBAR(); for (int i = lane; i < SB.bm_words; i += 64) halo[i] = bm[i]; }
     for (int base = ya * W; base < yb * W; base += 64) {
         const int px = base + lane;
+        // (round 5: the seed sums and the neighbour byte are fetched WITH the angle word, for every lane of the chunk -- under `ok` they were a second, dependent
+        // round trip per chunk of a lone wave)
+        float2 c0 = make_float2(0.f, 0.f);
+        uint32_t sb = 0xFFu;
+        if (px < yb * W) { c0 = C.cs0[px]; if (PLF_LSD_SINGLES) sb = (uint32_t)C.sgl[px]; }
         uint32_t w = px < yb * W ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
-        float2 c0 = make_float2(0.f, 0.f);
-        if (ok) c0 = C.cs0[px];
-        unsigned long long mask = __ballot(ok);
+        unsigned long long mask = __ballot(ok), smask = 0ull;
+        if (PLF_LSD_SINGLES && mask) smask = __ballot(ok && sb == 0u);
         while (mask) {
             if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
             const int seed = base + j;
+            if (PLF_LSD_SINGLES && ((smask >> j) & 1ull)) {
+                // a seed that can only grow a one-pixel region (static single, see singles_run): its flag, and in the recorded phase the record region_grow + spec_append would
+                // have left -- one log entry, still marked; bounding box = the pixel; no rectangle
+                if (!record) {
+                    const unsigned long long run = singles_run(mask, smask);
+                    if (__builtin_amdgcn_inverse_ballot_w64(run)) used_set(C, px, w);
+                    ok = ok && !((run >> lane) & 1ull);
+                    mask &= ~run;
+                    continue;
+                }
+                if (lane == j) used_set(C, px, w);
+                if (tn + 1 > SB.tcap || nrec >= SB.rcap_rec) ovf = 1;
+                if (!ovf) {
+                    if (lane == 0) {
+                        const int qy = seed / W, qx = seed - qy * W;
+                        tl[tn] = (uint32_t)seed | 0x40000000u;
+                        int4 *dst = reinterpret_cast<int4 *>(&recs[nrec]);
+                        dst[0] = make_int4(seed, tn, 1, 0);
+                        dst[1] = make_int4(max(qx - 1, 0), max(qy - 1, 0), min(qx + 1, W - 1), min(qy + 1, H - 1));
+                        atomicOr(&seedmap[seed >> 5], 1u << (seed & 31));
+                    }
+                    nrec++; tn++;
+                }
+                CBAR();
+                ok = ok && lane > j;
+                mask &= ~((2ull << j) - 1ull);
+                continue;
+            }
             const float sdeg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(__uint_as_float(w)), j));
             const float2 sc0 = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.x), j)),
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
@@ -2577,6 +2703,7 @@ extern "C" void plf_lsd_timing_dump()
     printf("[lsd timing, band wave %d of frame 0 accumulated, cycles] region_grow %lld  log append %lld  region2rect %lld  refine %lld | warm-up phase %lld  own phase %lld\n", PLF_TIMING_BAND, t[10], t[11], t[12], t[13], t[14], t[15]);
     printf("[lsd timing] region_grow of frame 0: accept loops %lld cycles, exposed load wait %lld cycles | band wave: %lld, %lld\n", t[19], t[20], t[21], t[22]);
     printf("[lsd timing, band wave %d] seeds %lld  pixels grown %lld  per-seed record + rescan %lld cycles\n", PLF_TIMING_BAND, t[16], t[17], t[18]);
+    printf("[lsd timing, frame 0 of the large-batch kernel] static singles marked without the pipeline %lld\n", t[23]);
 }
 #endif
 

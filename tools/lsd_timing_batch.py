@@ -4,10 +4,10 @@ import rgbd_pl_slam_amd._lib as L
 L.LIB_PATH = os.environ.get("PLF_TIMING_LIB", "/tmp/plft/libplf_hip.so")
 import numpy as np, torch
 from rgbd_pl_slam_amd import LineSegment
-from rgbd_pl_slam_amd.synth import synth_batch
+from rgbd_pl_slam_amd.synth import synth_batch, natural_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 w, h, nl = 640, 480, 100
-imgs = synth_batch(0, 16)
+imgs = (natural_batch if (len(sys.argv) > 2 and sys.argv[2] == "natural") else synth_batch)(0, 16)
 imgs = np.concatenate([imgs] * ((B + 15) // 16))[:B]
 d = torch.from_numpy(imgs).cuda()
 ls = LineSegment(nlines=nl, max_width=w, max_height=h, max_batch=B)
