@@ -204,18 +204,17 @@ static void region_grow(lsd_t *L, int sx, int sy, regpt *reg, int *reg_size, dou
         }
     }
     *reg_size = n;
-#ifdef ORC_LSD_STATS   /* tools/singleton_stats.c */
+#ifdef ORC_LSD_STATS   /* tools/singleton_stats.c, tests/test_oracle_props.py: the argument behind the GPU's "static singles" (lsd_kernels.hip, singles_run) */
     {
         extern long orc_stat[16];
         orc_stat[0]++; orc_stat[3] += n;
         if (n <= 3) { orc_stat[4]++; orc_stat[5] += n; }
-        if (n == 1) {
-            orc_stat[1]++;
-            int compat = 0;
-            for (int yy = sy - 1; yy <= sy + 1; ++yy) for (int xx = sx - 1; xx <= sx + 1; ++xx)
-                if ((xx != sx || yy != sy) && is_aligned(L, xx, yy, L->angles[addr], prec)) compat++;
-            if (!compat) orc_stat[2]++;
-        }
+        /* neighbours whose angle passes the FIRST test of a region seeded here (theta = the seed's own angle), whatever their flags */
+        int compat = 0;
+        for (int yy = sy - 1; yy <= sy + 1; ++yy) for (int xx = sx - 1; xx <= sx + 1; ++xx)
+            if ((xx != sx || yy != sy) && is_aligned(L, xx, yy, L->angles[addr], prec)) compat++;
+        if (n == 1) { orc_stat[1]++; if (!compat) orc_stat[2]++; }
+        if (!compat && n != 1) orc_stat[6]++;   /* must never happen: a seed without such a neighbour grows itself alone */
     }
 #endif
 }

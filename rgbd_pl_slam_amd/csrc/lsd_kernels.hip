@@ -1301,7 +1301,9 @@ __global__ void __launch_bounds__(256) k_lsd_balance(const int *__restrict__ cos
 #ifndef PLF_REGIONS_WPE
 #define PLF_REGIONS_WPE 8
 #endif
-#if PLF_REGIONS_WPE > 0
+#if PLF_REGIONS_WPE > 0 && defined(PLF_REGIONS_NSGPR)   // (experiment: an explicit scalar-register budget)
+#define PLF_REGIONS_OCC __attribute__((amdgpu_waves_per_eu(PLF_REGIONS_WPE, PLF_REGIONS_WPE), amdgpu_num_sgpr(PLF_REGIONS_NSGPR)))
+#elif PLF_REGIONS_WPE > 0
 #define PLF_REGIONS_OCC __attribute__((amdgpu_waves_per_eu(PLF_REGIONS_WPE, PLF_REGIONS_WPE)))
 #else
 #define PLF_REGIONS_OCC

@@ -40,3 +40,32 @@ def test_orb_extract_basic_invariants():
     assert r["ncells"] == [280, 192, 130, 88, 54, 35, 24, 12]
     # empty / flat image: no keypoints
     assert len(orc.orb_extract(np.full((480, 640), 77, np.uint8))["kps"]) == 0
+
+
+def test_lsd_seed_without_aligned_neighbour_grows_alone(tmp_path):
+    """The argument behind the GPU's static singles (lsd_kernels.hip, singles_run): a seed none of whose 8 neighbours has a level-line angle within
+    the tolerance of its own grows a ONE-pixel region, whatever is marked around it -- counted inside the oracle's own region loop
+    (oracle/lsd_oracle.c under ORC_LSD_STATS, built here the way tools/singleton_stats.c says)."""
+    import os
+    import subprocess
+    from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libsingle.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fopenmp", "-ffp-contract=off", "-w", "-DORC_LSD_STATS", "-I", os.path.join(root, "oracle"),
+                           os.path.join(root, "tools", "singleton_stats.c"), os.path.join(root, "oracle", "orb_oracle.c"), os.path.join(root, "oracle", "lbd_oracle.c"),
+                           os.path.join(root, "oracle", "timing.c"), "-o", so, "-lm"])
+    L = C.CDLL(so)
+    L.orc_stats.restype = C.POINTER(C.c_long)
+    st = L.orc_stats()
+    rng = np.random.default_rng(3)
+    imgs = [synth_frame(11, 320, 240), natural_frame(12, 320, 240), rng.integers(0, 256, (120, 160)).astype(np.uint8)]
+    for g in imgs:
+        for i in range(16):
+            st[i] = 0
+        g = np.ascontiguousarray(g, np.uint8)
+        h, w = g.shape
+        lines = np.zeros((1 << 14, 4), np.float32)
+        L.orc_lsd_detect(g.ctypes.data_as(C.c_void_p), C.c_int(w), C.c_int(h), C.c_ssize_t(w), C.c_int(0), lines.ctypes.data_as(C.c_void_p), C.c_int(1 << 14), None)
+        assert st[0] > 0 and st[2] > 0        # regions were grown, some of them foreseen singles
+        assert st[2] <= st[1] <= st[0]
+        assert st[6] == 0                      # no foreseen single ever grew beyond itself
