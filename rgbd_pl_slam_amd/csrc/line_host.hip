@@ -159,7 +159,7 @@ struct plf_line {
     unsigned long long *d_sort_scratch;   // [frame][sort_cap] when sort_cap > sort_lds
     double2 *d_cs;
     float2 *d_cs0;
-    uint8_t *d_sgl;           // [max_batch][s_stride] neighbour bytes of k_lsd_pre (LsdGeom::sgl)
+    uint32_t *d_sgl;          // [max_batch][s_stride / 32] bitmap of the static singles, written by k_lsd_pre (LsdGeom::sgl)
     float *d_ang;
     uint32_t *d_rxy;
     LsdRect *d_rects;
@@ -379,7 +379,7 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_cs, B * S * sizeof(double2));
     ALLOC(h->d_ang, B * S * sizeof(float));
     ALLOC(h->d_cs0, B * S * sizeof(float2));
-    ALLOC(h->d_sgl, B * S);
+    ALLOC(h->d_sgl, B * S / 8);
     ALLOC(h->d_rxy, B * S * sizeof(uint32_t));
     ALLOC(h->d_rects, B * R * sizeof(LsdRect));
     ALLOC(h->d_seg, B * R * sizeof(float4));
@@ -488,6 +488,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     const bool balance = h->tune.balance && B > h->tune.spec_max && B > h->tune.lat_max && !h->tune.one_wave_groups && B <= 65536 && h->prm.seed_order == 0;
     int *d_cost = balance ? h->d_balance : nullptr, *d_perm = balance ? h->d_balance + h->prm.max_batch + 16 : nullptr;
     if (balance) PLF_HIP_TRY(hipMemsetAsync(d_cost, 0, (size_t)B * sizeof(int), s));
+    // (bitmap of the static singles: k_lsd_pre writes whole words when the scaled rows are multiples of 32 pixels, and ORs into a cleared map otherwise)
+    if (g.sw & 31) PLF_HIP_TRY(hipMemsetAsync(h->d_sgl, 0, (size_t)B * (g.s_stride / 8), s));
     hipLaunchKernelGGL(k_lsd_pre, dim3((g.sw + PRE_TW - 1) / PRE_TW, (g.sh + PRE_TH - 1) / PRE_TH, B), dim3(PRE_NT), 0, s, d_gray, pitch, fstride, h->d_ang, h->d_modgrad,
                        h->d_cs, h->d_cs0, g, h->taps, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb, d_cost);
     if (balance) {

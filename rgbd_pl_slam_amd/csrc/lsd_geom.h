@@ -51,8 +51,8 @@ struct LsdGeom {
     int sort_lds;         // sort keys k_lsd_finalize keeps in LDS (frames with more segments sort in a global scratch row)
     int nfa_pool;         // rectangles of the whole batch the NFA stage buffers hold (entries are compacted over the batch)
     unsigned budget_ticks; // plf_line_params.max_ms in ticks of the 100 MHz wall clock (k_*_budget kernels only)
-    uint8_t *sgl;         // [frame][s_stride] neighbour bytes of k_lsd_pre (a device buffer of the handle, carried here because every kernel of the line pipeline gets the geometry):
-                          // per pixel with an angle, the neighbours that may pass the first alignment test of a region seeded there; 0 = a seed that can only grow itself
+    uint32_t *sgl;        // [frame][s_stride / 32] bitmap of the static singles (k_lsd_pre; a device buffer of the handle, carried here because every kernel of the line
+                          // pipeline gets the geometry): pixels with an angle none of whose neighbours can pass the first alignment test of a region seeded there
 };
 
 // banded speculative region growing: one record per effective seed of a band wave, and the buffers of both phases

@@ -188,11 +188,13 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
     // fastAtan2 and sincos below run on full waves of defined pixels only.  modgrad is written for those pixels alone: nothing reads it elsewhere
     // (region2rect weighs region points, k_lsd_maxgrad / k_lsd_seedkeys test the angle first).
     __shared__ int s_ndef;
-    __shared__ float s_angt[PRE_TW * PRE_TH];                    // the tile's level-line angles (NOTDEF_F where there is none): the neighbour bytes below
+    __shared__ float s_angt[PRE_TW * PRE_TH];                    // the tile's level-line angles (NOTDEF_F where there is none): the static singles below
+    __shared__ unsigned long long s_rowbits[PRE_TH];             // static singles of the tile, one word per tile row
     double *s_q = s_tmp;                                         // the blurred tile is dead after the resize: q, offset inside the frame, (float)gx, (float)-gy
     int *s_off = reinterpret_cast<int *>(s_tmp + PRE_TW * PRE_TH);
     float *s_fx = reinterpret_cast<float *>(s_off + PRE_TW * PRE_TH), *s_fy = s_fx + PRE_TW * PRE_TH;
     if (tid == 0) s_ndef = 0;
+    if (tid < PRE_TH) s_rowbits[tid] = 0ull;
     __syncthreads();
     const int tx = tid & 63;
     float *angf = ang + (size_t)f * g.s_stride;
@@ -251,34 +253,52 @@ __global__ void __launch_bounds__(PRE_NT) k_lsd_pre(const uint8_t *__restrict__ 
         const double eps = ad - af, h = 0.5 * eps * eps;
         cs0f[o] = make_float2((float)(cf - eps * sf - h * cf), (float)(sf + eps * cf - h * sf));
     }
-    // Neighbour bytes (LsdGeom::sgl; see singles_run in the region-growing section): for every pixel with an angle, which of its 8 neighbours MAY pass the first
-    // alignment test of a region seeded here -- angle within the tolerance + 0.001 degrees of this pixel's (circular difference in single precision: a superset of
-    // the reference's double test), or outside this tile and inside the image (unknown).  Byte 0 = the seed can only ever grow itself.
+    // Static singles (LsdGeom::sgl; see singles_run in the region-growing section): one BIT per pixel, set iff the pixel has an angle and none of its 8
+    // neighbours can pass the first alignment test of a region seeded there -- no neighbour's angle is within the tolerance + 0.001 degrees of the pixel's
+    // (circular difference in single precision: a superset of the reference's double test).  Pixels on the rim of this tile (neighbours outside: unknown, 11 % of
+    // the pixels) never get the bit.  Interior pixels read their neighbours from the tile of angles without bounds tests; the bits of a tile row are collected
+    // in one 64-bit LDS word and written as (up to) two dwords -- a byte per pixel, stored from the compacted lanes, cost the kernel 1.5 ms per 8192 natural
+    // frames in partial-line writes alone.
+#ifndef PLF_PRE_NOSGL
     if (g.sgl) {
         __syncthreads();
-        uint8_t *sglf = g.sgl + (size_t)f * g.s_stride;
         const float tol = (float)(g.prec * (180.0 / PI_D)) + 1.0e-3f;
         for (int i = tid; i < ndef; i += PRE_NT) {
             const int loc = s_off[i], ty = loc / PRE_TW, tx = loc % PRE_TW;
-            const int x = dx0 + tx, y = dy0 + ty;
-            const float a = s_angt[loc];
-            uint32_t m8 = 0u;
+            if (tx > 0 && tx < PRE_TW - 1 && ty > 0 && ty < PRE_TH - 1) {
+                const float a = s_angt[loc];
+                const float *nb = s_angt + loc;
+                float best = 1.0e9f;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int ddx = (k < 3 ? k : k == 3 ? 0 : k == 4 ? 2 : k - 5) - 1, ddy = k < 3 ? -1 : k < 5 ? 0 : 1;
-                const int nx = tx + ddx, ny = ty + ddy;
-                bool may;
-                if (nx >= 0 && nx < PRE_TW && ny >= 0 && ny < PRE_TH) {
-                    const float b = s_angt[ny * PRE_TW + nx];
-                    float d = fabsf(a - b);
-                    d = fminf(d, 360.f - d);
-                    may = b >= 0.f && d < tol;
-                } else may = x + ddx >= 0 && y + ddy >= 0 && x + ddx < g.sw && y + ddy < g.sh;
-                m8 |= may ? (1u << k) : 0u;
+                for (int k = 0; k < 8; k++) {
+                    const int off = (k < 3 ? k - 1 - PRE_TW : k == 3 ? -1 : k == 4 ? 1 : k - 6 + PRE_TW);
+                    const float b = nb[off];
+                    const float d = fabsf(a - b), e = 360.f - d;
+                    const float m = d < e ? d : e;
+                    best = (b >= 0.f && m < best) ? m : best;
+                }
+                if (!(best < tol)) atomicOr(&s_rowbits[ty], 1ull << tx);
             }
-            sglf[(unsigned)(y * g.sw + x)] = (uint8_t)m8;
+        }
+        __syncthreads();
+        if (tid < min(PRE_TH, g.sh - dy0)) {
+            // (row tid of the tile = 64 bits at pixel index (dy0 + tid) * sw + dx0 of the frame's bitmap)
+            const unsigned long long bits = s_rowbits[tid];
+            uint32_t *bmf = g.sgl + (size_t)f * (g.s_stride >> 5);
+            const unsigned idx = (unsigned)((dy0 + tid) * g.sw + dx0);
+            if ((g.sw & 31) == 0) {   // the words lie inside the row and belong to this tile alone: plain stores, zero words included (nothing clears the map)
+                bmf[idx >> 5] = (uint32_t)bits;
+                if (dx0 + 32 < g.sw) bmf[(idx >> 5) + 1] = (uint32_t)(bits >> 32);
+            } else if (bits) {        // any width: the host cleared the map, the row's bits are OR-ed into up to three words
+                const unsigned o = idx & 31u;
+                atomicOr(&bmf[idx >> 5], (uint32_t)(bits << o));
+                const unsigned long long hi = o ? bits >> (32 - o) : bits >> 32;
+                if ((uint32_t)hi) atomicOr(&bmf[(idx >> 5) + 1], (uint32_t)hi);
+                if (o && (uint32_t)(hi >> 32)) atomicOr(&bmf[(idx >> 5) + 2], (uint32_t)(hi >> 32));
+            }
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,7 +376,7 @@ struct RegCtx {
     const double *modgrad;
     const double2 *cs;
     const float2 *cs0;
-    const uint8_t *sgl;        // per pixel with an angle: which neighbours may pass the first test of a region seeded here (k_lsd_pre; 0 = the seed can only grow itself)
+    const uint32_t *sgl;       // bitmap of the frame's static singles (k_lsd_pre): pixels with an angle none of whose neighbours can pass the first test of a region seeded there
     int cbase;                 // first pixel of the 64-pixel seed chunk being scanned (regions_body; chunk_taken)
     LDS_PTR(uint32_t) rxy_l;   // LDS part of the region list (x | y << 16)
     uint32_t *rxy_g;           // global overflow of the region list (entries >= rcap)
@@ -1012,9 +1032,9 @@ __device__ __forceinline__ unsigned long long chunk_taken(RegCtx &C, int n, int 
 // polygon scenes; tools/singleton_stats.py): the seed's 8 neighbours are undefined, taken, or not aligned with the seed's own level-line angle -- and the first
 // step of region_grow tests exactly that, every neighbour against reg_angle = the seed's angle (the sums only move after the first accept).  Such a seed costs the
 // whole per-seed path plus one group (~250 instructions) to mark one pixel.  k_lsd_pre therefore leaves one byte per pixel with a level-line angle (LsdGeom::sgl):
-// bit k set iff neighbour k (raster order, the centre skipped) MAY pass that first test -- it has an angle within the tolerance + 0.001 degrees (single precision:
-// a superset of the reference's double-precision test |theta - a| <= prec, wrap at 3/2 pi = the circular difference; the float differences are good to 5e-5
-// degrees), or it lies outside the tile k_lsd_pre was looking at (unknown: 11 % of the pixels have such neighbours).  A seed whose byte is 0 is a STATIC SINGLE:
+// 1 if some neighbour MAY pass that first test -- it has an angle within the tolerance + 0.001 degrees (single precision: a superset of the reference's
+// double-precision test |theta - a| <= prec, wrap at 3/2 pi = the circular difference; the float differences are good to 5e-5 degrees) -- or if the pixel lies
+// on the rim of the tile k_lsd_pre was looking at (neighbours unknown: 11 % of the pixels).  A seed whose byte is 0 is a STATIC SINGLE:
 // whatever has been marked or released by the time its turn comes, no neighbour can be accepted, its region is the seed alone -- 72 % of the single-pixel regions
 // of natural-image-like frames, 46 % on the polygon scenes.  At its turn it sets its flag and nothing else (n = 1 < min_reg_size: no rectangle, no chunk_taken);
 // a run of singles in front of the next ordinary seed is marked in one step -- the same flags in the same order as the serial loop.  A single that an earlier
@@ -1066,7 +1086,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
-    C.sgl = g.sgl + (size_t)f * g.s_stride;
+    C.sgl = g.sgl + (size_t)f * (g.s_stride >> 5);
     C.rxy_l = (LDS_PTR(uint32_t))smem;
     C.rcap = LDSOFF < 0 ? min(g.rcap, PLF_LSD_WAVE_LIST / 4 - 1) : g.rcap;   // (the large-batch kernel keeps a shorter head of the list in LDS)
     C.gcap = (int)g.s_stride;
@@ -1106,12 +1126,17 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             if (seeds) px = px < NP ? (int)(seeds[px] & 0xFFFFFu) : NP;
             float2 c0 = make_float2(0.f, 0.f);
             if (px < NP) c0 = C.cs0[px];
-            // (the neighbour byte is fetched WITH the angle word, for every lane: under `w < 0x80000000` it was a second, dependent round trip per chunk -- the
-            // kernel is a chain of round trips as much as of instructions: 207 -> 215 ms per 8192 natural frames instead of a gain)
-            const uint32_t sb = (PLF_LSD_SINGLES && px < NP) ? (uint32_t)C.sgl[px] : 0xFFu;
+            // (the singles' bits are fetched WITH the angle word, not behind it: a byte per pixel loaded under `w < 0x80000000` was a second, dependent round trip
+            // per chunk -- the kernel is a chain of round trips as much as of instructions: 207 -> 215 ms per 8192 natural frames instead of a gain.  Raster
+            // order: the chunk's 64 bits are two words at a wave-uniform address.)
+            // (every lane loads the word that holds its own bit -- the same two words for the whole chunk in raster order -- and the bits are taken out only
+            // after the angle words have arrived: pinning the words to scalar registers right behind their load made the compiler wait for them BEFORE it
+            // issued the angle-word load, the dependent round trip again)
+            uint32_t sgw = 0u;
+            if (PLF_LSD_SINGLES && px < NP) sgw = C.sgl[px >> 5];
             const uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
             mask = __ballot(w < 0x80000000u);
-            if (PLF_LSD_SINGLES) smask = __ballot(w < 0x80000000u && sb == 0u);
+            if (PLF_LSD_SINGLES) smask = __ballot(w < 0x80000000u && ((sgw >> (px & 31)) & 1u));
             park[lane] = park_t{(uint32_t)px, w, __float_as_uint(c0.x), __float_as_uint(c0.y)};
         }
         CBAR();
@@ -1184,13 +1209,13 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
         // (the seed sums are fetched with the angle words, not after them: one round trip per chunk of 64 seeds instead of two dependent ones)
         float2 c0 = make_float2(0.f, 0.f);
         if (px < NP) c0 = C.cs0[px];
-        const uint32_t sb = (PLF_LSD_SINGLES && px < NP) ? (uint32_t)C.sgl[px] : 0xFFu;   // (with the angle word, not behind it)
+        const bool sgb = PLF_LSD_SINGLES && px < NP && ((C.sgl[px >> 5] >> (px & 31)) & 1u);   // (static single; fetched with the angle word, not behind it)
         uint32_t w = px < NP ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
         const float deg = __uint_as_float(w);
         C.cbase = seeds ? -0x40000000 : base;   // (list order: the chunk is not contiguous, flags are re-read after every region)
         unsigned long long mask = __ballot(ok), smask = 0ull;
-        if (PLF_LSD_SINGLES && mask) smask = __ballot(ok && sb == 0u);
+        if (PLF_LSD_SINGLES && mask) smask = __ballot(ok && sgb);
         while (mask) {
             if (PLF_LSD_SINGLES) {
                 const unsigned long long run = singles_run(mask, smask);
@@ -1388,6 +1413,8 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat_budget(float *__restric
 // ------------------------------------------------------------------------------------------------
 // (SpecRec / SpecBufs: lsd_geom.h, shared with line_host.hip)
 
+__device__ __forceinline__ unsigned long long spec_bits64(const uint32_t *__restrict__ map, int p, int words);
+
 // append the current region list [0, n) as pixel indices
 // (mark: OR-ed into every entry -- the band waves log "still marked at the end of the seed" optimistically, see spec_grow_body; bb: per-lane partial bounding box
 // x0, y0, x1, y1 of the appended pixels, or nullptr)
@@ -1451,7 +1478,7 @@ __device__ __forceinline__ void spec_ctx(RegCtx &C, const LsdGeom &g, int f, flo
     C.modgrad = modgrad_all + (size_t)f * g.s_stride;
     C.cs = cs_all + (size_t)f * g.s_stride;
     C.cs0 = cs0_all + (size_t)f * g.s_stride;
-    C.sgl = g.sgl + (size_t)f * g.s_stride;
+    C.sgl = g.sgl + (size_t)f * (g.s_stride >> 5);
     C.rxy_l = list; C.rcap = g.rcap; C.gcap = (int)g.s_stride; C.rxy_g = rxy_g;
     C.use_bm = 1; C.bm = bm; C.regrow_n = -1;
     C.cbase = -0x40000000;
@@ -1728,15 +1755,14 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     if (record) { CBAR(); for (int i = lane; i < SB.bm_words; i += 64) halo[i] = bm[i]; }
     for (int base = ya * W; base < yb * W; base += 64) {
         const int px = base + lane;
-        // (round 5: the seed sums and the neighbour byte are fetched WITH the angle word, for every lane of the chunk -- under `ok` they were a second, dependent
-        // round trip per chunk of a lone wave)
+        // (round 5: the seed sums and the singles' bits are fetched WITH the angle word, for every lane of the chunk -- under `ok` the sums were a second,
+        // dependent round trip per chunk of a lone wave)
         float2 c0 = make_float2(0.f, 0.f);
-        uint32_t sb = 0xFFu;
-        if (px < yb * W) { c0 = C.cs0[px]; if (PLF_LSD_SINGLES) sb = (uint32_t)C.sgl[px]; }
+        if (px < yb * W) c0 = C.cs0[px];
+        const unsigned long long sbits = PLF_LSD_SINGLES ? spec_bits64(C.sgl, base, SB.bm_words) : 0ull;
         uint32_t w = px < yb * W ? ang_load(C, px) : 0xFFFFFFFFu;
         bool ok = w < 0x80000000u;
-        unsigned long long mask = __ballot(ok), smask = 0ull;
-        if (PLF_LSD_SINGLES && mask) smask = __ballot(ok && sb == 0u);
+        unsigned long long mask = __ballot(ok), smask = mask & sbits;
         while (mask) {
             if (BUDGET && wall_clock64() > C.t_dead) { truncated = true; break; }
             const int j = __ffsll((long long)mask) - 1;
