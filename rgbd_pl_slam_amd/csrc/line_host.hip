@@ -598,7 +598,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                  hipMalloc((void **)&h->spec.tl_alt, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.recs_alt, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.cnt_alt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
-                 hipMalloc((void **)&h->spec.nrects, Fr * K * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.nrects, Fr * K * 3 * sizeof(int)) == hipSuccess &&   // (+ [frame][band][2] behind the counts: the rows a band's records reach, spec_reach)
                  hipMalloc((void **)&h->spec.round_state, Fr * 5 * sizeof(int)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.tl2b, Fr * K * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess;
         }

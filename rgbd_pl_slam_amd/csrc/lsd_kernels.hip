@@ -1414,6 +1414,9 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat_budget(float *__restric
 // (SpecRec / SpecBufs: lsd_geom.h, shared with line_host.hip)
 
 __device__ __forceinline__ unsigned long long spec_bits64(const uint32_t *__restrict__ map, int p, int words);
+// rows [reach[0], reach[1]] a band's log can depend on (SpecBufs::nrects, second part)
+__device__ __forceinline__ int *spec_reach(const SpecBufs &SB, size_t fb) { return SB.nrects + (size_t)SB.frames_cap * SB.nbands + fb * 2; }
+
 
 // append the current region list [0, n) as pixel indices
 // (mark: OR-ed into every entry -- the band waves log "still marked at the end of the seed" optimistically, see spec_grow_body; bb: per-lane partial bounding box
@@ -1632,6 +1635,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     const GrowTh th0 = grow_thresholds(g.prec);
     const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
     int nrec = 0, tn = 0, ovf = 0, nrect_band = 0;
+    int reach0 = y0, reach1 = max(y1 - 1, y0);   // rows the log depends on: the band's own rows, widened by every record's dilated box
     if (band > 0 && (SB.halo_rows > 0 || SB.fill_rows > 0)) {
         // The warm-up starts from "every defined pixel ABOVE the warm-up rows is taken" (in the serial run they all are when this band's turn comes, bar the
         // few that refine released) instead of an empty map: on an empty map the regions of the top warm-up rows grew upwards without bound -- work that
@@ -1788,6 +1792,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
                         dst[1] = make_int4(max(qx - 1, 0), max(qy - 1, 0), min(qx + 1, W - 1), min(qy + 1, H - 1));
                         atomicOr(&seedmap[seed >> 5], 1u << (seed & 31));
                     }
+                    reach0 = min(reach0, max(seed / W - 1, 0)); reach1 = max(reach1, min(seed / W + 1, H - 1));
                     nrec++; tn++;
                 }
                 CBAR();
@@ -1827,6 +1832,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
                     if (okr) recs[nrec].rec = rec;
                     atomicOr(&seedmap[seed >> 5], 1u << (seed & 31));
                 }
+                reach0 = min(reach0, max(by0 - 1, 0)); reach1 = max(reach1, min(by1 + 1, H - 1));
                 nrec++;
             }
             CBAR();
@@ -1845,7 +1851,7 @@ __device__ __forceinline__ void spec_grow_body(int band, int f, float *__restric
     if (SB.out) {   // validation rounds follow: what the band's own records mark (its flags minus the state its warm-up rows left) and its rectangle count
         uint32_t *outb = SB.out + fb * SB.bm_words;
         for (int i = lane; i < SB.bm_words; i += 64) outb[i] = bm[i] & ~halo[i];   // (halo[] = the band's initial state, written when its own seeds started: zeros for band 0)
-        if (lane == 0) SB.nrects[fb] = nrect_band;
+        if (lane == 0) { SB.nrects[fb] = nrect_band; int *rc = spec_reach(SB, fb); rc[0] = reach0; rc[1] = reach1; }
     }
     // A band wave that ran out of its time budget leaves an INCOMPLETE log: the seeds it did not reach are in neither S nor T, so the commit wave -- a later launch
     // with a clock of its own in the two-launch schedule -- would never see them as candidates and could finish "in time" with regions missing.  Such a
@@ -1878,6 +1884,22 @@ __device__ __forceinline__ void dc_mark(LDS_PTR(uint32_t) Dc, int a, int W, int 
 }
 
 // the band's speculative flags S: in LDS next to T, or (frames whose two bitmaps exceed the LDS) in global memory
+// Does a flag that differs between the truth T and the band's speculative state S at a pixel of the 3x3 dilation of a record's accepted set invalidate the record?
+// Round 5, the refined rule (model: oracle/lsd_oracle.c, orc_lsd_band_rounds_refined; exact on every frame tried): only if
+//   * the pixel is one the record ACCEPTED (centre) and it is truly taken -- an earlier band owns it --, or
+//   * the speculation saw the pixel TAKEN and it is truly free: the record skipped a pixel it might have accepted.
+// A neighbour the speculation saw FREE and did not accept was rejected for its angle every time it was tested; truly taken, it is skipped instead: the same
+// outcome.  (An accepted pixel is free in S when its record is checked: the record found it free, and the marks of the records before it are already in S.)
+// The shipped rule until then -- any difference invalidates -- redid 5-10 % more accepts (tools/refined_rule_model.py).
+#ifndef PLF_SPEC_REFINED_RULE
+#define PLF_SPEC_REFINED_RULE 1
+#endif
+__device__ __forceinline__ bool spec_flag_matters(bool t, bool sv, bool centre)
+{
+    if (!PLF_SPEC_REFINED_RULE) return t != sv;
+    return centre ? (t || sv) : (sv && !t);
+}
+
 template <bool SG> struct SpecS {
     LDS_PTR(uint32_t) l;
     uint32_t *g;
@@ -2204,7 +2226,7 @@ __device__ __forceinline__ void spec_commit_body(int f, float *__restrict__ ang_
                                 for (int dx = -1; dx <= 1; dx++) {
                                     const int xx = qx + dx;
                                     if (xx < 0 || xx >= W) continue;
-                                    hit |= bm_get(T, yy * W + xx) != S.get(yy * W + xx);
+                                    hit |= spec_flag_matters(bm_get(T, yy * W + xx), S.get(yy * W + xx), dx == 0 && dy == 0);
                                 }
                             }
                         }
@@ -2378,7 +2400,15 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
     // T = what the bands before this one mark now, S = what this band's log assumed they mark; nothing to do where they agree
     // (round 5: ALL FOUR waves of the workgroup load the two bitmaps -- 2 x 24 KB at VGA, 192 dependent-latency loads per lane of one wave: the 28 us every band
     // paid in every round it ran, the whole cost of a round in which nothing is regrown; the other three waves leave behind the barrier)
+    // Round 5: the words in which they differ are bracketed on the way; if all of them lie in rows this band's log cannot depend on -- outside its own rows and
+    // the dilated boxes of its records (spec_reach) -- the serial processing of its seeds from the new state leaves the same log, every flag it reads being
+    // unchanged: E_b := pre[b], nothing else.  (The late rounds of a call are mostly that: one band regrows a region, every band below it walked all of its
+    // records -- 30-80 us each -- to find nothing to do.)
+    __shared__ int s_dirty[2];
+    if (threadIdx.x == 0) { s_dirty[0] = 0x7fffffff; s_dirty[1] = -1; }
+    __syncthreads();
     bool differ = false;
+    int wlo = 0x7fffffff, whi = -1;
     for (int i0 = lane; i0 < SB.bm_words; i0 += 1024) {
         uint32_t a[4], e[4];
 #pragma unroll
@@ -2386,11 +2416,26 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + 256 * u;
-            if (i < SB.bm_words) { T[i] = a[u]; if (SG) __hip_atomic_store(&S.g[i], e[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.l[i] = e[u]; differ |= a[u] != e[u]; }
+            if (i < SB.bm_words) {
+                T[i] = a[u]; if (SG) __hip_atomic_store(&S.g[i], e[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.l[i] = e[u];
+                if (a[u] != e[u]) { differ = true; wlo = min(wlo, i); whi = max(whi, i); }
+            }
         }
     }
+    if (differ) { atomicMin(&s_dirty[0], wlo); atomicMax(&s_dirty[1], whi); }
     if (SG) __threadfence();
     if (!__syncthreads_or(differ ? 1 : 0)) return;
+#ifndef PLF_SPEC_NO_REACH_SKIP
+    {
+        const int dlo = s_dirty[0], dhi = s_dirty[1];
+        const int dy0 = (dlo * 32) / W, dy1 = min(H - 1, (dhi * 32 + 31) / W);
+        const int *rc = spec_reach(SB, fb);
+        if (dy1 < rc[0] || dy0 > rc[1]) {
+            for (int i = dlo + (int)threadIdx.x; i <= dhi; i += 256) { const uint32_t a = pre[i]; if (a != halo[i]) halo[i] = a; }
+            return;
+        }
+    }
+#endif
     if (threadIdx.x >= 64) return;
     for (int i = lane; i < cwords; i += 64) Dc[i] = 0u;
     CBAR();
@@ -2417,6 +2462,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
     const uint32_t *defmap = SB.defmap + (size_t)f * SB.bm_words;
     const int y0 = SB.band_y[f * (SB.nbands + 1) + band], y1 = SB.band_y[f * (SB.nbands + 1) + band + 1];
     int nrec_n = 0, tn_n = 0, nrect_n = 0;
+    int reach0 = y0, reach1 = max(y1 - 1, y0), lr0 = H, lr1 = -1;   // rows the new log depends on (spec_reach); lr*: per-lane, over the records copied in runs
     bool ovf_n = false;
     const int p_end = y1 * W;
     const int nrec_band = cnt[0];
@@ -2528,6 +2574,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                         int4 v0 = src[0];
                         v0.y += tn_n - t_begin;                 // t0 in the new log
                         dst[0] = v0;
+                        lr0 = min(lr0, (int)(Hb0[i] >> 16)); lr1 = max(lr1, (int)(Hb1[i] >> 16));
 #pragma unroll
                         for (int q = 1; q < (int)(sizeof(SpecRec) / 16); q++) dst[q] = src[q];
                     }
@@ -2558,7 +2605,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                             for (int dx = -1; dx <= 1; dx++) {
                                 const int xx = qx + dx;
                                 if (xx < 0 || xx >= W) continue;
-                                hit |= bm_get(T, yy * W + xx) != S.get(yy * W + xx);
+                                hit |= spec_flag_matters(bm_get(T, yy * W + xx), S.get(yy * W + xx), dx == 0 && dy == 0);
                             }
                         }
                     }
@@ -2573,6 +2620,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                         if (e & 0x40000000u) { bm_set(T, (int)(e & 0x3FFFFFFFu)); S.set((int)(e & 0x3FFFFFFFu)); }
                     }
                     if (lane == 0) { SpecRec r = recs[r_lo + rsu]; r.t0 = tn_n; recs_n[nrec_n] = r; }
+                    reach0 = min(reach0, (int)(Hb0[rsu] >> 16)); reach1 = max(reach1, (int)(Hb1[rsu] >> 16));
                     if (Hnt[rsu] & 0x80000000u) nrect_n++;
                     tn_n += nt; nrec_n++;
                     CBAR();
@@ -2606,6 +2654,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                     dst[1] = make_int4(max(bx0 - 1, 0), max(by0 - 1, 0), min(bx1 + 1, W - 1), min(by1 + 1, H - 1));
                     if (okr) recs_n[nrec_n].rec = rec;
                 }
+                reach0 = min(reach0, max(by0 - 1, 0)); reach1 = max(reach1, min(by1 + 1, H - 1));
                 if (okr) nrect_n++;
 #ifdef PLF_ROUND_LOG
                 rl_seeds++; rl_px += tn;
@@ -2639,10 +2688,12 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
         __threadfence();
         for (int i = lane; i < nrec_n; i += 64) { const int sdp = recs_n[i].seed; atomicOr(&seedmap[sdp >> 5], 1u << (sdp & 31)); }
     }
+    reach0 = min(reach0, wave_min_i(lr0)); reach1 = max(reach1, wave_max_i(lr1));
     if (lane == 0) {
         cnt_n[0] = nrec_n; cnt_n[1] = tn_n; cnt_n[2] = 0; cnt_n[3] = 0;
         SB.side[fb] = sd ^ 1;
         SB.nrects[fb] = nrect_n;
+        int *rc = spec_reach(SB, fb); rc[0] = reach0; rc[1] = reach1;
     }
     if (__ballot(changed) && lane == 0) atomicAdd(&rs[round & 1], 1);
 #ifdef PLF_ROUND_LOG

@@ -62,3 +62,30 @@ def test_banded_speculative_region_growing_model_is_exact():
                 ok2 = L.orc_lsd_band_speculation(img.ctypes.data_as(C.c_void_p), 640, 480, C.c_ssize_t(640), nb, st2)
                 L.orc_lsd_band_speculation_halo(0)
                 assert ok2 == 1 and st2[6] == 1 and st2[2] < 0.8 * redo_plain
+
+
+def test_validation_rounds_model_is_exact_with_both_validity_rules():
+    """CPU model of the parallel validation rounds (k_lsd_spec_prefix / k_lsd_spec_validate; oracle/lsd_oracle.c: orc_lsd_band_rounds, the GPU's warm-up =
+    mode 3 with 4 rows): the fixpoint equals the serial seed loop bit for bit with the rule 'any differing flag in the 3x3 dilation of the accepted set
+    invalidates a record' and with the refined rule the kernels ship (lsd_kernels.hip, spec_flag_matters), which redoes less."""
+    import ctypes as C
+    from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
+    L = orc.lib()
+    rng = np.random.default_rng(9)
+    imgs = [synth_frame(21, 320, 240), natural_frame(22, 320, 240), (rng.integers(0, 256, (240, 320)) // 32 * 32).astype(np.uint8)]
+    L.orc_lsd_band_rounds_mode(3); L.orc_lsd_band_speculation_halo(4)
+    try:
+        for img in imgs:
+            img = np.ascontiguousarray(img, np.uint8)
+            redo = []
+            for refined in (0, 1):
+                L.orc_lsd_band_rounds_refined(refined)
+                for nb in (6, 24):
+                    st = (C.c_long * 8)()
+                    ok = L.orc_lsd_band_rounds(img.ctypes.data_as(C.c_void_p), 320, 240, C.c_ssize_t(320), nb, st)
+                    assert ok == 1 and st[6] == 1, (refined, nb, list(st))
+                    if nb == 24:
+                        redo.append(st[3])
+            assert redo[1] <= redo[0]
+    finally:
+        L.orc_lsd_band_rounds_refined(0); L.orc_lsd_band_rounds_mode(0); L.orc_lsd_band_speculation_halo(0)
