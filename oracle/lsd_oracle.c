@@ -812,6 +812,8 @@ static void band_log_push(band_log *B, int seed, int has_rect, const rect_t *rec
 }
 
 static int g_rounds_mode = 0, g_rounds_refined = 0;
+static long g_rounds_needless = 0;
+long orc_lsd_band_rounds_needless(void) { const long v = g_rounds_needless; g_rounds_needless = 0; return v; }
 static double g_fill_tol = 1.0;
 void orc_lsd_band_rounds_fill_tol(double t) { g_fill_tol = t; }
 void orc_lsd_band_rounds_refined(int m) { g_rounds_refined = m; }
@@ -1016,7 +1018,13 @@ int orc_lsd_band_rounds(const uint8_t *gray, int w, int h, ptrdiff_t pitch, int 
                         int nt; rect_t rec;
                         L.used = T;
                         stats[7]++;
+                        const long redo_before = redo;
                         const int ok = run_seed(&L, adx, reg, prec, p, min_reg_size, touched, &nt, &rec, &redo);
+                        if (r && r->nt == nt) {   /* (diagnostics: accepts redone for a record that came out exactly as it was -- what a perfect validity test would save) */
+                            int same_rec = 1;
+                            for (int i = 0; i < nt && same_rec; i++) same_rec = (B[b].tl[r->t0 + i] & 0x3FFFFFFF) == touched[i];
+                            if (same_rec) g_rounds_needless += redo - redo_before;
+                        }
                         band_log_push(&N, adx, ok, &rec, touched, nt, T);
                         if (ok) N.rects[N.nrect++] = rec;
                         for (int i = 0; i < nt; i++) D[touched[i]] = S[touched[i]] != T[touched[i]];

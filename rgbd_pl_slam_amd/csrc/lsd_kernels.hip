@@ -564,7 +564,7 @@ __device__ __forceinline__ Grp load_group(const RegCtx &C, int first, int cnt, i
 // cone test, or it was a border lane, and border lanes pass `|S x u| < t2 * S . u` as well), so |S| only grows; and the pixels a region takes out of the seed
 // chunk are no longer tracked per accept (seven scalar instructions each) but read off the list once, when a small region ends (regions_body).
 template <int PF>
-__device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out)
+__device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, double prec, GrowTh th, double &reg_angle_out, int min_n)
 {
     const int lane = plf_lane();
     double reg_angle = (double)deg0 * DEG2RAD_D;
@@ -697,7 +697,9 @@ __device__ int region_grow(RegCtx &C, int sx, int sy, float deg0, float2 cs0, do
             nx_stale = 0ull;
         }
     }
-    if (n_theta != n) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
+    // (round 5: the final angle only for a region somebody looks at -- min_n = the caller's minimum region size.  Two regions in three stay below it, and the
+    // fastAtan2 with its two IEEE divisions was ~50 instructions of every one of them)
+    if (n_theta != n && n >= min_n) reg_angle = (double)plf_fast_atan2(sumdy, sumdx) * DEG2RAD_D;
     reg_angle_out = reg_angle;
     return n;
 }
@@ -1001,7 +1003,7 @@ __device__ bool refine(RegCtx &C, int &n, double reg_angle, double prec, double 
     CBAR();   // one wave owns the frame: LDS accesses of a wave are performed in order
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    n = region_grow<(STG != 2) && (STG != 0 || PLF_SPEC_PF_REFINE)>(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle);
+    n = region_grow<(STG != 2) && (STG != 0 || PLF_SPEC_PF_REFINE)>(C, (int)(q0 & 0xFFFF), (int)(q0 >> 16), deg_c, C.cs0[a0], tau, grow_thresholds(tau), reg_angle, 2);
     C.regrow_n = n;
     if (n < 2) return false;
     region2rect<STG>(C, n, reg_angle, prec, p, rec);
@@ -1173,7 +1175,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
             int sx, sy;
             if (walk) { sx = bx + j; sy = by; if (sx >= W) { sx -= W; sy++; } }
             else { sx = seed % W; sy = seed / W; }
-            int n = region_grow<(LDSOFF >= 0)>(C, sx, sy, sdeg, sc0, prec, th0, reg_angle);
+            int n = region_grow<(LDSOFF >= 0)>(C, sx, sy, sdeg, sc0, prec, th0, reg_angle, g.min_reg_size);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
             const bool big = n >= g.min_reg_size;
             if (big) {
@@ -1234,7 +1236,7 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0.y), j)));
             double reg_angle;
             TIC(t0);
-            int n = region_grow<(LDSOFF >= 0)>(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle);
+            int n = region_grow<(LDSOFF >= 0)>(C, seed % W, seed / W, sdeg, sc0, prec, th0, reg_angle, g.min_reg_size);
             TOC(0, t0); CNT(4, 1); CNT(5, n);
             const bool big = n >= g.min_reg_size;
             if (big) {
@@ -1444,7 +1446,7 @@ __device__ __forceinline__ bool spec_seed(RegCtx &C, const LsdGeom &g, GrowTh th
 #ifndef PLF_SPEC_PF
 #define PLF_SPEC_PF 0   // (round 5: no fetch-ahead in the band waves either -- fuller groups; the neighbourhood loads hit the L1: 2-3 % per call, tools/ab_few.sh)
 #endif
-    int n = region_grow<PLF_SPEC_PF>(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle);
+    int n = region_grow<PLF_SPEC_PF>(C, seed % C.W, seed / C.W, sdeg, sc0, g.prec, th0, reg_angle, g.min_reg_size);
     CBAR();
     TOCB(10, ts0);
     CNTB(16, 1); CNTB(17, n);
