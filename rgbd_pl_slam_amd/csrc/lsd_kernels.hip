@@ -1033,10 +1033,10 @@ __device__ __forceinline__ unsigned long long chunk_taken(RegCtx &C, int n, int 
 // Seeds that can only grow a ONE-pixel region (round 5).  On natural-image-like frames 44 % of the regions region growing starts are a single pixel (21 % on the
 // polygon scenes; tools/singleton_stats.py): the seed's 8 neighbours are undefined, taken, or not aligned with the seed's own level-line angle -- and the first
 // step of region_grow tests exactly that, every neighbour against reg_angle = the seed's angle (the sums only move after the first accept).  Such a seed costs the
-// whole per-seed path plus one group (~250 instructions) to mark one pixel.  k_lsd_pre therefore leaves one byte per pixel with a level-line angle (LsdGeom::sgl):
-// 1 if some neighbour MAY pass that first test -- it has an angle within the tolerance + 0.001 degrees (single precision: a superset of the reference's
-// double-precision test |theta - a| <= prec, wrap at 3/2 pi = the circular difference; the float differences are good to 5e-5 degrees) -- or if the pixel lies
-// on the rim of the tile k_lsd_pre was looking at (neighbours unknown: 11 % of the pixels).  A seed whose byte is 0 is a STATIC SINGLE:
+// whole per-seed path plus one group (~250 instructions) to mark one pixel.  k_lsd_pre therefore leaves one BIT per pixel (LsdGeom::sgl), set iff the pixel has
+// an angle and NO neighbour may pass that first test -- none has an angle within the tolerance + 0.001 degrees (single precision: a superset of the reference's
+// double-precision test |theta - a| <= prec, wrap at 3/2 pi = the circular difference; the float differences are good to 5e-5 degrees); pixels on the rim of
+// the tile k_lsd_pre was looking at never get it (neighbours unknown: 11 % of the pixels).  A seed whose bit is set is a STATIC SINGLE:
 // whatever has been marked or released by the time its turn comes, no neighbour can be accepted, its region is the seed alone -- 72 % of the single-pixel regions
 // of natural-image-like frames, 46 % on the polygon scenes.  At its turn it sets its flag and nothing else (n = 1 < min_reg_size: no rectangle, no chunk_taken);
 // a run of singles in front of the next ordinary seed is marked in one step -- the same flags in the same order as the serial loop.  A single that an earlier
