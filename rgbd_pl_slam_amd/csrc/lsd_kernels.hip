@@ -904,7 +904,14 @@ __device__ bool reduce_region_radius(RegCtx &C, int &n, double reg_angle, double
                 const unsigned long long im = __ballot(in);
                 if (in) {
                     const int k = fcount + __popcll(im & ~((2ull << lane) - 1ull));   // kept points with a higher index come first
-                    rxy_put(C, (int)__hip_atomic_load(&tmp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), q);
+                    // (round 5: a SWAP, as in the reference's loop -- the removed point goes to the slot the kept one leaves.  Until then the hole was simply
+                    // overwritten: the prefix [0, n) was right, but the list as a whole was no longer a permutation of what the regrowth had accepted, and the
+                    // few-frames schedule logs exactly that list AFTER refine() as "every pixel the seed ever accepted": a pixel accepted by the regrowth and
+                    // released here was missing from the record, i.e. its neighbourhood was not covered by the validity test of the validation rounds.)
+                    const int hole = (int)__hip_atomic_load(&tmp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t hq = rxy_get(C, hole);
+                    rxy_put(C, hole, q);
+                    rxy_put(C, i, hq);
                 }
                 fcount += __popcll(im);
             }
