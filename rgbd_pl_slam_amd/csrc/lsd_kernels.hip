@@ -1894,15 +1894,19 @@ __device__ __forceinline__ void dc_mark(LDS_PTR(uint32_t) Dc, int a, int W, int 
 
 // the band's speculative flags S: in LDS next to T, or (frames whose two bitmaps exceed the LDS) in global memory
 // Does a flag that differs between the truth T and the band's speculative state S at a pixel of the 3x3 dilation of a record's accepted set invalidate the record?
-// Shipped rule: ANY difference does.
-// Round 5 tried a refined rule (PLF_SPEC_REFINED_RULE=1; model: oracle/lsd_oracle.c, orc_lsd_band_rounds_refined): only a difference at an ACCEPTED pixel that is
-// truly taken, or at a pixel the speculation saw TAKEN that is truly free -- a neighbour the speculation saw free and did not accept was rejected for its angle
-// and is skipped now: the same outcome.  The CPU model is exact with it on every frame tried (171 runs), the kernels were exact on the 192 GPU tests and redid
-// 5-10 % fewer accepts (one frame 4.04 -> 3.94 ms) -- and a 12,288-frame soak found ONE frame (texture_frame(61546), 48 bands, band 38, round 2) where a record
-// of 256 accepted pixels stood under it and regrows to 255: the lists part in the regrowth of refine().  The argument has a hole that is not understood yet
-// (profiles/r05_soak_long.txt, tools/repro_lines.py, tools/experiments/README.md).  Exactness is the first gate: the rule is OFF.
+// Round 5, the refined rule (model: oracle/lsd_oracle.c, orc_lsd_band_rounds_refined; tests/test_models.py): only if
+//   * the pixel is one the record ACCEPTED (centre) and it is truly taken -- an earlier band owns it --, or
+//   * the speculation saw the pixel TAKEN and it is truly free: the record skipped a pixel it might have accepted.
+// A neighbour the speculation saw FREE and did not accept was rejected for its angle every time it was tested; truly taken, it is skipped instead: the same
+// outcome.  (An accepted pixel is free in S when its record is checked: the record found it free, and the marks of the records before it are already in S.)
+// The rule "any difference invalidates" redid 5-10 % more accepts (tools/refined_rule_model.py; one frame 4.04 -> 3.94 ms).
+// The rule needs the record to list EVERY pixel the seed accepted -- an accepted pixel that is missing counts as a mere neighbour.  A 12,288-frame soak found
+// the one place where that failed (profiles/r05_soak_long_refined_rule.txt: texture_frame(61546), 48 bands; tools/repro_lines.py): reduce_region_radius
+// overwrote list entries instead of swapping them, so a pixel accepted by refine()'s regrowth and released again dropped out of the list that is logged
+// afterwards.  Fixed there (the list stays a permutation); with it the rule is exact on that frame and on 17,600 more
+// (profiles/r05_soak_refined_rule_fixed.txt).  -DPLF_SPEC_REFINED_RULE=0 restores the old rule.
 #ifndef PLF_SPEC_REFINED_RULE
-#define PLF_SPEC_REFINED_RULE 0
+#define PLF_SPEC_REFINED_RULE 1
 #endif
 __device__ __forceinline__ bool spec_flag_matters(bool t, bool sv, bool centre)
 {

@@ -67,8 +67,8 @@ def test_banded_speculative_region_growing_model_is_exact():
 def test_validation_rounds_model_is_exact_with_both_validity_rules():
     """CPU model of the parallel validation rounds (k_lsd_spec_prefix / k_lsd_spec_validate; oracle/lsd_oracle.c: orc_lsd_band_rounds, the GPU's warm-up =
     mode 3 with 4 rows): the fixpoint equals the serial seed loop bit for bit with the rule 'any differing flag in the 3x3 dilation of the accepted set
-    invalidates a record' (what the kernels ship) and with the refined rule of lsd_kernels.hip's spec_flag_matters, which redoes less -- and which the kernels
-    do NOT ship: a GPU soak found a frame on which it is not exact there (texture_frame(61546) at 48 bands) although this model is."""
+    invalidates a record' and with the refined rule the kernels ship (lsd_kernels.hip, spec_flag_matters), which redoes less.  (The rule needs every accepted
+    pixel in the record: a GPU soak found the one list that missed some, reduce_region_radius -- fixed there.)"""
     import ctypes as C
     from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
     L = orc.lib()
