@@ -293,3 +293,23 @@ def test_large_batch_balance_is_only_a_schedule():
         ref = orc.line_extract(base[f % 28], 100)
         assert np.array_equal(on[f][1], ref["desc"]) and on[f][0].tobytes() == ref["kl"].tobytes(), "frame %d" % f
     ls.close()
+
+
+def test_soak_regression_refine_released_pixels_stay_in_the_record():
+    """The frame on which a 12,288-frame soak found the refined validity rule of the validation rounds inexact (round 5): reduce_region_radius dropped pixels that
+    refine()'s regrowth had accepted and released from the list the few-frames schedule logs as the seed's accepted set, and a record that should have been
+    regrown stood (48 bands, band 38).  One frame at a time, several band counts, and the frame tiled to a few-frames batch."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import texture_frame
+    img, _ = texture_frame(61546)
+    assert img.shape == (480, 640)
+    ref = orc.line_extract(img, 100, 0)
+    for bands in (-2147483647, 24, 40, 48, 56):
+        ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=8)
+        ls.tune("spec_bands", bands)
+        kl, desc, eq = ls.ExtractLineSegment(img)
+        assert len(kl) == len(ref["kl"]) and kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"]), bands
+        for kl, desc, eq in ls.extract_batch(np.stack([img] * 3)):
+            assert len(kl) == len(ref["kl"]) and kl.tobytes() == ref["kl"].tobytes() and np.array_equal(desc, ref["desc"]), bands
+        ls.close()
