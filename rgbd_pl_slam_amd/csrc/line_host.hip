@@ -196,7 +196,7 @@ static void line_free(plf_line *h)
                     h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_balance, h->d_lgam, h->d_nfa_tab, h->d_ent[0], h->d_ent[1], h->d_st[0], h->d_st[1], h->d_cnt, h->d_nfa_counters, h->d_nfa_fcnt, h->d_vals, h->d_sort_scratch, h->d_lbd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     void *sp[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
+                  h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.reach, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
     for (void *p : sp) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 2 * 512; i++) if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -568,7 +568,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (spec && (h->spec_frames < B || (size_t)B * spec_bands > h->spec_slots || h->spec.bm_words != bm_words || (size_t)h->spec.tcap != g.s_stride || (zmode && !h->spec.out) || h->spec.rcap_rec != T.spec_reccap)) {
         // (re)allocate for lat_max frames of the current geometry
         void *old[] = {h->spec.rxy, h->spec.tl, h->spec.recs, h->spec.cnt, h->spec.seedmap, h->spec.defmap, h->spec.tl2, h->spec.band_y, h->spec.done, h->spec.sglob, h->spec.halo, h->d_spec_stats,
-                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
+                       h->spec.out, h->spec.pre, h->spec.tl_alt, h->spec.recs_alt, h->spec.cnt_alt, h->spec.side, h->spec.nrects, h->spec.reach, h->spec.round_state, h->spec.tl2b, h->spec.band_ticks, h->spec.round_log, h->d_spec_rowcnt};
         PLF_HIP_TRY(hipStreamSynchronize(s));
         for (void *q : old) if (q) (void)hipFree(q);
         memset(&h->spec, 0, sizeof(h->spec)); h->d_spec_stats = nullptr; h->d_spec_rowcnt = nullptr;
@@ -598,7 +598,8 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
                  hipMalloc((void **)&h->spec.tl_alt, Fr * K * (size_t)h->spec.tcap * sizeof(uint32_t)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.recs_alt, Fr * K * (size_t)h->spec.rcap_rec * sizeof(SpecRec)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.cnt_alt, Fr * K * 4 * sizeof(int)) == hipSuccess &&
-                 hipMalloc((void **)&h->spec.nrects, Fr * K * 3 * sizeof(int)) == hipSuccess &&   // (+ [frame][band][2] behind the counts: the rows a band's records reach, spec_reach)
+                 hipMalloc((void **)&h->spec.nrects, Fr * K * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&h->spec.reach, Fr * K * 2 * sizeof(int)) == hipSuccess &&   // (the rows a band's records reach, spec_reach: indexed by slot, whatever the call's band count)
                  hipMalloc((void **)&h->spec.round_state, Fr * 5 * sizeof(int)) == hipSuccess &&
                  hipMalloc((void **)&h->spec.tl2b, Fr * K * 2 * g.s_stride * sizeof(uint32_t)) == hipSuccess;
         }

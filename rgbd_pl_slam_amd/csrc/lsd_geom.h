@@ -84,8 +84,10 @@ struct SpecBufs {
     SpecRec *recs_alt;
     int *cnt_alt;
     int *side;          // [frame][band]: side that holds the band's current log (0: tl / recs / cnt)
-    int *nrects;        // [frame][band]: rectangles in the band's current log; behind the frames_cap * nbands counts: [frame][band][2] = first / last row the band's log
-                        // can depend on (its own rows and the dilated boxes of its records): a validation round whose changes lie outside leaves the log as it is
+    int *nrects;        // [frame][band]: rectangles in the band's current log
+    int *reach;         // [frame][band][2] = first / last row the band's log can depend on (its own rows and the dilated boxes of its records): a validation round
+                        // whose changes lie outside leaves the log as it is.  A buffer of its own (2 ints per slot of the allocation): its base must not depend on the
+                        // band count of the CALL, which may exceed the allocation's
     int *round_state;   // [frame][4]: bands whose marks changed in the even / odd rounds, converged, fall back to the serial commit; behind the frames_cap frames: [frame] band workgroups through the current round
     int frames_cap;     // frames round_state was allocated for
     uint32_t *tl2b;     // [frame][band][2 * s_stride]: accepted pixels of a seed regrown by a validation

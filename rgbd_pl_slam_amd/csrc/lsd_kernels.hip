@@ -1423,8 +1423,8 @@ __global__ void __launch_bounds__(256) k_lsd_regions_lat_budget(float *__restric
 // (SpecRec / SpecBufs: lsd_geom.h, shared with line_host.hip)
 
 __device__ __forceinline__ unsigned long long spec_bits64(const uint32_t *__restrict__ map, int p, int words);
-// rows [reach[0], reach[1]] a band's log can depend on (SpecBufs::nrects, second part)
-__device__ __forceinline__ int *spec_reach(const SpecBufs &SB, size_t fb) { return SB.nrects + (size_t)SB.frames_cap * SB.nbands + fb * 2; }
+// rows [reach[0], reach[1]] a band's log can depend on (SpecBufs::reach; fb = frame * nbands + band < slots of the allocation)
+__device__ __forceinline__ int *spec_reach(const SpecBufs &SB, size_t fb) { return SB.reach + fb * 2; }
 
 
 // append the current region list [0, n) as pixel indices

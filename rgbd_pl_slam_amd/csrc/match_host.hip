@@ -54,6 +54,7 @@ struct LineTriDev { const uint8_t *has_ml1, *has_ml2, *stereo1, *stereo2; int on
 __global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *, int *, int *, int, int, int, const LineFrameDev *, double, LineTriDev);
 __global__ void k_lines_fuse_pick(const int *, const int *, const uint8_t *, int, int *, int *);
 __global__ void k_match_project_lines(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
+__global__ void k_match_project_lines_g(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
 __global__ void k_hamming_matrix(const uint8_t *, int, const uint8_t *, int, int *);
 
 struct plf_matcher {
@@ -173,6 +174,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     (void)hipFuncSetAttribute((const void *)k_match_lastframe, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lf_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_project_lines_g, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();  // the attribute call is advisory; never leave a sticky error behind for other HIP users
     *out = h;
     return PLF_OK;
@@ -789,8 +791,17 @@ extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view 
     M.m = ml->m; M.x1 = ml->x1; M.y1 = ml->y1; M.x2 = ml->x2; M.y2 = ml->y2; M.level = ml->level; M.view_cos = ml->view_cos;
     M.in_view = ml->in_view; M.desc = ml->desc;
     const int cap = (maxn + 63) & ~63;
-    hipLaunchKernelGGL(k_match_project_lines, dim3(n_frames), dim3(256), (size_t)cap * 56, s, h->d_lframes, M, th, nnratio, match_of_line,
-                       line_stride, nmatches, h->d_done, cap);
+    // the frame's lines staged in LDS while they fit (56 bytes per line: up to 2688 lines in 150 KB), else read from global memory (8 bytes of LDS per line: the
+    // 18000 lines plf_matcher_create accepts take 144 KB) -- ADVICE r05
+    // (PLF_MATCH_LINES_STAGE_MAX: test hook -- 0 forces the global-memory variant on small frames)
+    const char *stage_env = getenv("PLF_MATCH_LINES_STAGE_MAX");
+    const int stage_lines = stage_env ? atoi(stage_env) : 150 * 1024 / 56;
+    if (cap <= stage_lines)
+        hipLaunchKernelGGL(k_match_project_lines, dim3(n_frames), dim3(256), (size_t)cap * 56, s, h->d_lframes, M, th, nnratio, match_of_line,
+                           line_stride, nmatches, h->d_done, cap);
+    else
+        hipLaunchKernelGGL(k_match_project_lines_g, dim3(n_frames), dim3(256), (size_t)cap * 8, s, h->d_lframes, M, th, nnratio, match_of_line,
+                           line_stride, nmatches, h->d_done, cap);
     PLF_HIP_TRY(hipGetLastError());
     return PLF_OK;
 }

@@ -1354,7 +1354,10 @@ __device__ __forceinline__ bool line_in_area4(const float4 kl, float x1, float y
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
+// STAGED: the frame's lines live in LDS (56 bytes per line; host: while line_cap * 56 fits the 150 KB the kernel may ask for, i.e. up to 2688 lines); otherwise
+// they are read from global memory as before round 5 (8 bytes of LDS per line: plf_matcher_create accepts max_lines up to 18000 -- ADVICE r05)
+template <bool STAGED>
+__device__ __forceinline__ void match_project_lines_body(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
                                                              int *__restrict__ match_all, int line_stride, int *__restrict__ nmatches,
                                                              uint8_t *__restrict__ done_all, int line_cap)
 {
@@ -1374,11 +1377,20 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
     const bool bFactor = th != 1.0f;
     for (int k = t; k < F.n; k += T) {
         claim[k] = match[k] < -2 ? -1 : match[k];   // (-3 marks of an earlier check_orientation = 2 call read as free; -2 stays "occupied")
-        const plf_keyline kl = F.lines[k];
-        lg[k] = make_float4(kl.pt_x, kl.pt_y, kl.angle, __int_as_float(kl.octave));
-        const uint4 *dsrc = reinterpret_cast<const uint4 *>(F.desc + 32 * (size_t)k);
-        ld[2 * k] = dsrc[0]; ld[2 * k + 1] = dsrc[1];
+        if (STAGED) {
+            const plf_keyline kl = F.lines[k];
+            lg[k] = make_float4(kl.pt_x, kl.pt_y, kl.angle, __int_as_float(kl.octave));
+            const uint4 *dsrc = reinterpret_cast<const uint4 *>(F.desc + 32 * (size_t)k);
+            ld[2 * k] = dsrc[0]; ld[2 * k + 1] = dsrc[1];
+        }
     }
+    // the four window-test fields / the two descriptor halves of key line i
+    auto line4 = [&](int i) -> float4 {
+        if (STAGED) return lg[i];
+        const plf_keyline &kl = F.lines[i];
+        return make_float4(kl.pt_x, kl.pt_y, kl.angle, __int_as_float(kl.octave));
+    };
+    auto desc_half = [&](int i, int hlf) -> uint4 { return STAGED ? ld[2 * i + hlf] : reinterpret_cast<const uint4 *>(F.desc + 32 * (size_t)i)[hlf]; };
     if (t == 0) s_acc = 0;
     for (int m = t; m < ML.m; m += T) done[m] = ML.in_view[m] ? 0 : 1;
     __syncthreads();
@@ -1394,7 +1406,7 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
             const float rad = r * F.scale_factors[lvl];
             const float mx1 = ML.x1[m], my1 = ML.y1[m], mx2 = ML.x2[m], my2 = ML.y2[m];
             for (int i = 0; i < F.n; i++)
-                if (claim[i] == -1 && line_in_area4(lg[i], mx1, my1, mx2, my2, rad, lvl - 1, lvl)) atomicMin(&owner[i], m);
+                if (claim[i] == -1 && line_in_area4(line4(i), mx1, my1, mx2, my2, rad, lvl - 1, lvl)) atomicMin(&owner[i], m);
         }
         __syncthreads();
         for (int m = t; m < ML.m; m += T) {
@@ -1406,15 +1418,15 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
             const float mx1 = ML.x1[m], my1 = ML.y1[m], mx2 = ML.x2[m], my2 = ML.y2[m];
             bool safe = true;
             for (int i = 0; i < F.n; i++)
-                if (claim[i] == -1 && owner[i] != m && line_in_area4(lg[i], mx1, my1, mx2, my2, rad, lvl - 1, lvl)) safe = false;
+                if (claim[i] == -1 && owner[i] != m && line_in_area4(line4(i), mx1, my1, mx2, my2, rad, lvl - 1, lvl)) safe = false;
             if (!safe) { atomicAdd(&s_left, 1); continue; }
             int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
             const uint4 d0 = reinterpret_cast<const uint4 *>(ML.desc + 32 * (size_t)m)[0], d1 = reinterpret_cast<const uint4 *>(ML.desc + 32 * (size_t)m)[1];
             for (int i = 0; i < F.n; i++) {
                 if (claim[i] != -1) continue;
-                const float4 kl = lg[i];
+                const float4 kl = line4(i);
                 if (!line_in_area4(kl, mx1, my1, mx2, my2, rad, lvl - 1, lvl)) continue;
-                const uint4 b0 = ld[2 * i], b1 = ld[2 * i + 1];
+                const uint4 b0 = desc_half(i, 0), b1 = desc_half(i, 1);
                 const int dist = __popc(d0.x ^ b0.x) + __popc(d0.y ^ b0.y) + __popc(d0.z ^ b0.z) + __popc(d0.w ^ b0.w) + __popc(d1.x ^ b1.x) + __popc(d1.y ^ b1.y) +
                                  __popc(d1.z ^ b1.z) + __popc(d1.w ^ b1.w);
                 const int oct = __float_as_int(kl.w);
@@ -1434,6 +1446,19 @@ __global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev 
     }
     for (int k = t; k < F.n; k += T) match[k] = claim[k];
     if (t == 0) nmatches[f] = s_acc;
+}
+
+__global__ void __launch_bounds__(256) k_match_project_lines(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
+                                                             int *__restrict__ match_all, int line_stride, int *__restrict__ nmatches,
+                                                             uint8_t *__restrict__ done_all, int line_cap)
+{
+    match_project_lines_body<true>(frames, ML, th, nnratio, match_all, line_stride, nmatches, done_all, line_cap);
+}
+__global__ void __launch_bounds__(256) k_match_project_lines_g(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
+                                                               int *__restrict__ match_all, int line_stride, int *__restrict__ nmatches,
+                                                               uint8_t *__restrict__ done_all, int line_cap)
+{
+    match_project_lines_body<false>(frames, ML, th, nnratio, match_all, line_stride, nmatches, done_all, line_cap);
 }
 
 __global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t *__restrict__ a, int na, const uint8_t *__restrict__ b, int nb,

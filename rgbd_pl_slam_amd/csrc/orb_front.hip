@@ -321,16 +321,61 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
 #endif
     // ---- 3. GaussianBlur 7x7.  A thread owns one group of 4 columns for a segment of 8 output rows and walks down the 14 tile rows behind
     // them: row sums by two byte dot products per pixel (taps 18 34 49 55 fit a byte; v_alignbyte lines the 4-byte windows up), the 7 live
-    // rows of sums stay in registers (fully unrolled: no window shifting), exact int32 column sums, rounded as OpenCV 3.3's column filter does
+    // rows of sums stay in registers (fully unrolled: no window shifting), exact column sums, rounded as OpenCV 3.3's column filter does.
+    // Round 6: the column sums run in fp32.  On gfx950 v_add_f32 / v_fma_f32 issue at twice the rate of the integer multiply-adds, shifts, min and bit-field
+    // forms (profiles/r03_valu_issue.json: 2.2 against 4.2 cycles per SIMD), and the arithmetic is EXACT: a row sum is an integer <= 255 * 257, the taps are
+    // scaled by 2^-16 (a power of two), so every partial sum is an integer multiple of 2^-16 that needs at most 24 bits while the final sum stays below 2^24 * 2^-16
+    // = 256 -- and a sum of 256 or more is clamped to 255 whatever its last bits are (fp32 rounding cannot carry a value across 256 = 2^8 downwards).  The vector
+    // rule of SymmColumnVec_32s8u, sum / 65536 rounded half to even, is what (t + 2^23) - 2^23 computes in the default rounding mode; v_cvt_pk_u8_f32 converts
+    // the integer-valued float, saturates and places the byte.  The w % 4 tail columns of the image (half-up rule) keep the integer path.
     {
         const uint32_t K0123 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
         const uint32_t K210 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
         const int k0 = taps.x, k1 = taps.y, k2 = taps.z, k3 = taps.w;
+        const float kf0 = (float)k0 * (1.f / 65536.f), kf1 = (float)k1 * (1.f / 65536.f), kf2 = (float)k2 * (1.f / 65536.f), kf3 = (float)k3 * (1.f / 65536.f);
+        float magic = 8388608.f;          // 2^23; held in a VGPR: as a 32-bit literal it would halve the issue rate of the two additions that use it
+        asm volatile("" : "+v"(magic));
         const int OH = ye - ys, ngb = (EW >> 2) - 2, nseg = (OH + 7) >> 3, wvec = W & ~3;
         uint8_t *bp = blur + (size_t)f * g.blur_stride + L.blur_off;
         const int bpitch = L.bpitch;   // (a local: read through the reference it is re-loaded from the kernel arguments behind every store)
         for (int it = tid; it < ngb * nseg; it += OF_NT) {
             const int seg = it / ngb, c4 = 4 + 4 * (it - seg * ngb), oy0 = seg * 8, x4 = ex0 + c4;
+#ifndef OF_BLUR_INT
+            if (x4 + 3 < wvec) {
+                float hf[14][4];
+#pragma unroll
+                for (int r = 0; r < 14; r++) {
+                    const int ey = min(oy0 + r, EH - 1);   // (rows past the tile only feed outputs that are not stored)
+                    const uint32_t *p = reinterpret_cast<const uint32_t *>(P + ey * PW + c4 - 4);
+                    const uint32_t A = p[0], B = p[1], C = p[2];   // level x - 4 .. x + 7 of the group's first pixel x
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t lo4 = j == 3 ? B : __builtin_amdgcn_alignbyte(B, A, j + 1);   // bytes x + j - 3 .. x + j
+                        const uint32_t hi4 = j == 3 ? C : __builtin_amdgcn_alignbyte(C, B, j + 1);   // bytes x + j + 1 .. x + j + 4 (the last has tap 0)
+                        hf[r][j] = (float)__builtin_amdgcn_udot4(hi4, K210, __builtin_amdgcn_udot4(lo4, K0123, 0u, false), false);
+                    }
+                    if (r < 6) continue;
+                    const int oy = oy0 + r - 6;
+                    if (oy >= OH) continue;
+                    uint32_t bw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float t = kf0 * (hf[r - 6][j] + hf[r][j]);
+                        t = __builtin_fmaf(kf1, hf[r - 5][j] + hf[r - 1][j], t);
+                        t = __builtin_fmaf(kf2, hf[r - 4][j] + hf[r - 2][j], t);
+                        t = __builtin_fmaf(kf3, hf[r - 3][j], t);
+                        t = (t + magic) - magic;   // sum / 65536, half to even (t < 2^9)
+                        bw = __builtin_amdgcn_cvt_pk_u8_f32(t, j, bw);   // (saturates at 255)
+                    }
+                    uint8_t *bo = bp + (size_t)(ys + oy) * bpitch + x4;
+                    if (x4 >= xs4 && x4 + 3 < xe4) *reinterpret_cast<uint32_t *>(bo) = bw;
+                    else
+                        for (int j = 0; j < 4; j++)
+                            if (x4 + j >= xs4 && x4 + j < xe4) bo[j] = (uint8_t)(bw >> (8 * j));
+                }
+                continue;
+            }
+#endif
             // rounding rule per column, settled once per item: 0 = the vector loop's half-to-even, 1 = the scalar tail's half-up (below: branch-free)
             int tail[4];
 #pragma unroll
@@ -466,8 +511,61 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
 #if defined(OF_STOP) && OF_STOP <= 5
     return;
 #endif
-    // ---- 5. 3x3 non-maximum suppression inside each cell's computed region (neighbours outside it count as 0), per survivor; the maxima are
-    // recorded as one bit per (cell, row, column) for the two thresholds
+    // ---- 5. 3x3 non-maximum suppression inside each cell's computed region (neighbours outside it count as 0); the maxima are recorded as one bit per
+    // (cell, row, column) for the two thresholds.
+    // Round 6: only the survivors that ARE corners (score >= minThFAST: a third of them on the polygon scenes) need the eight neighbours, and a wave pays for that
+    // path whenever one of its lanes does.  Each wave therefore walks its chunks of LIST, queues the corners it finds (ballot + prefix count, a 128-entry queue of its
+    // own in the dead table area) and runs the neighbourhood test on 64 queued corners at a time: densely packed lanes, and branch-free -- the eight scores are
+    // read unconditionally (the bytes around the score tile are valid LDS) and masked with the four "inside the cell" flags.  Before: 8 EXEC regions per survivor
+    // wave, 50 M of the kernel's 306 M vector instructions per 1024-frame launch (profiles/r06_orb_phase_insts.txt).
+#ifndef OF_NMS_OLD
+    {
+        const int wv = tid >> 6, lane = tid & 63;
+        uint16_t *Q = reinterpret_cast<uint16_t *>(XT) + wv * 128;
+        const int iniTh = g.iniTh;
+        auto nms_one = [&](int q) {
+            const int c = q & 255, ry = q >> 8;
+            const uint8_t *sp = S + ry * SP + c - cS0;
+            const int sc = sp[0];
+            const int x = ex0 + c, y = ry0 + ry;
+            const bool ccol = x >= xm, crow = y >= ym;
+            const int xl = ccol ? xm : rx0, xr = ccol ? rx1 : xm, yt = crow ? ym : ry0, yb_ = crow ? ry1 : ym;   // the cell's computed region
+            const uint32_t ml = x != xl ? ~0u : 0u, mr = x + 1 != xr ? ~0u : 0u, mu = y != yt ? ~0u : 0u, md = y + 1 != yb_ ? ~0u : 0u;
+            const uint32_t a = sp[-1] & ml, b = sp[1] & mr;
+            const uint32_t u0 = sp[-SP - 1] & ml, u1 = sp[-SP], u2 = sp[-SP + 1] & mr;
+            const uint32_t d0 = sp[SP - 1] & ml, d1 = sp[SP], d2 = sp[SP + 1] & mr;
+            const uint32_t up = max(max(u0, u1), u2) & mu, dn = max(max(d0, d1), d2) & md;
+            const uint32_t nb = max(max(a, b), max(up, dn));
+            if ((uint32_t)sc > nb) {
+                const int ci = (ccol ? 1 : 0) + (crow ? 2 : 0);
+                const unsigned long long bit = 1ull << (x - xl);
+                atomicOr(&s_mask[ci][y - yt][1], bit);
+                if (sc >= iniTh) atomicOr(&s_mask[ci][y - yt][0], bit);
+            }
+        };
+        int qn = 0;   // (wave-uniform)
+        for (int k0 = wv * 64; k0 < nl; k0 += OF_NT) {
+            const int k = k0 + lane;
+            int q = 0;
+            bool corner = false;
+            if (k < nl) {
+                q = LIST[k];
+                corner = (int)S[(q >> 8) * SP + (q & 255) - cS0] >= tmin;
+            }
+            const unsigned long long m = __ballot(corner);
+            if (m == 0ull) continue;
+            if (corner) Q[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)q;
+            qn += __popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (qn >= 64) {
+                qn -= 64;
+                nms_one(Q[qn + lane]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        if (lane < qn) nms_one(Q[lane]);
+    }
+#else
     for (int k = tid; k < nl; k += OF_NT) {
         const int q = LIST[k], c = q & 255, ry = q >> 8;
         const uint8_t *sp = S + ry * SP + c - cS0;
@@ -489,6 +587,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             if (sc >= g.iniTh) atomicOr(&s_mask[ci][y - yt][0], bit);
         }
     }
+#endif
     __syncthreads();
     // ---- 6. per cell (one wave each): iniThFAST, or minThFAST when that leaves the cell empty; raster-ordered emission
     {

@@ -279,7 +279,9 @@ static int orb_configure(plf_orb *h, int w, int hh)
         g.lds_eh = maxEH;
         auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
         const size_t sz_p = (size_t)g.lds_pw * (maxEH + 1) + 16;
-        const size_t sz_s = (size_t)g.lds_sp * maxRH + 16, sz_t = (size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16;
+        const size_t sz_s = (size_t)g.lds_sp * maxRH + 16;
+        // resize tables; the non-maximum suppression re-uses the area for its per-wave corner queues (128 uint16 each: k_orb_level phase 5)
+        const size_t sz_t = std::max((size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16, (size_t)(PLF_ORB_LEVEL_THREADS / 64) * 256 + 16);
         const size_t sz_list = (size_t)maxRW * maxRH * 2 + 16;   // FAST survivor list (aliases the staged source)
         size_t sz_a = 0;
         for (g.lds_parts = 1; g.lds_parts <= 4; g.lds_parts++) {

@@ -516,6 +516,26 @@ def test_alternating_batch_sizes_share_the_speculation_buffers():
     ls.close()
 
 
+def test_one_handle_mixed_band_counts_and_batch_sizes():
+    """the rows a band's records reach (spec_reach) lived behind the band counts at an offset of frames_cap * nbands with the band count of the CALL,
+    which may exceed the band count of the allocation (the buffers are re-used whenever frames x bands fits): 16 frames x 8 bands allocate 128 slots, 2 frames x 64
+    bands re-use them and indexed up to 16 * 64 + 2 * 2 * 64 ints of a 384-int buffer.  One handle, band counts and batch sizes mixed so that the later calls have
+    MORE bands than the allocation, every frame against the oracle (the reach rows now have a buffer of their own, indexed by slot)."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame
+    imgs = [synth_frame(8500 + i) for i in range(16)]
+    refs = [orc.line_extract(im, 100) for im in imgs]
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=16)
+    for (bands, B) in ((8, 16), (64, 2), (32, 4), (48, 1), (16, 8), (64, 1), (8, 16), (24, 5)):
+        ls.tune("spec_bands", bands)
+        idx = [(3 * bands + i) % 16 for i in range(B)]
+        res = ls.extract_batch(np.stack([imgs[i] for i in idx]))
+        for f, i in enumerate(idx):
+            assert res[f][0].tobytes() == refs[i]["kl"].tobytes() and np.array_equal(res[f][1], refs[i]["desc"]), (bands, B, f)
+    ls.close()
+
+
 def test_one_handle_alternating_image_sizes_rebuilds_the_nfa_table():
     """The table of NFA values (k_nfa_table) depends on the scaled image size (LOG_NT enters nfa_d's exit test): a handle that sees a different size must refill it.
     One handle, sizes 640x480 -> 320x240 -> 800x600 -> 640x480, single frames and a batch of 70 (the staged NFA kernels' hand-over), against the oracle."""

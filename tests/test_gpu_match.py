@@ -302,6 +302,41 @@ def test_line_matcher_scenes(sc):
     m.close()
 
 
+@pytest.mark.parametrize("force", [True, False], ids=["forced_on_a_small_frame", "more_lines_than_fit_the_lds"])
+def test_line_projection_search_global_memory_variant(monkeypatch, force):
+    """k_match_project_lines stages 56 bytes per line in LDS, which fits up to 2688 lines while plf_matcher_create accepts max_lines up to 18000:
+    frames above that run the variant that reads the lines from global memory (8 bytes of LDS per line).  Same bits as the oracle, on a small frame with the
+    variant forced (PLF_MATCH_LINES_STAGE_MAX=0) and on a frame of > 2688 lines (the lines of 13 synthetic frames together)."""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    from rgbd_pl_slam_amd.synth import synth_frame
+    if force:
+        monkeypatch.setenv("PLF_MATCH_LINES_STAGE_MAX", "0")
+        a = orc.line_extract(synth_frame(0), 100)
+        kl, desc, M = a["kl"], a["desc"], 500
+    else:
+        parts = [orc.line_extract(synth_frame(60 + i), 400) for i in range(13)]   # (~250 lines each)
+        kl = np.concatenate([p_["kl"] for p_ in parts]); desc = np.concatenate([p_["desc"] for p_ in parts])
+        assert len(kl) > 2688
+        M = 1500
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    ml = matchgen.make_map_lines(kl, desc, M, 11)
+    init = np.full(len(kl), -1, np.int32); init[::9] = -2
+    ref_match, ref_n = orc.search_lines_by_projection(kl, desc, scale, ml, 3.0, 0.8, init)
+    assert ref_n > 10
+    m = Matcher(max_lines=4096, max_mappoints=4096)
+    dkl = torch.from_numpy(np.frombuffer(np.ascontiguousarray(kl).tobytes(), np.uint8).copy()).cuda()
+    dld = _dev(desc); dsc = _dev(scale)
+    view = Matcher.lineframe_view(len(kl), dkl, dld, dsc)
+    dml = {k: _dev(v) for k, v in ml.items()}
+    match = _dev(init); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    m.SearchLinesByProjection([view], dml, 3.0, 0.8, match, len(kl), nm)
+    torch.cuda.synchronize()
+    assert int(nm[0]) == ref_n and np.array_equal(match.cpu().numpy(), ref_match)
+    m.close()
+
+
 LINE_KF_SCENES = [
     # lines in keyframe 1 / 2, how many of keyframe 1's lines reappear in keyframe 2, bit flips, share with a MapLine (kf1, kf2), share with stereo, bOnlyStereo, MAD factor
     dict(s1=30, s2=31, n=120, keep=90, flips=12, ml1=0.3, ml2=0.3, st=0.7, only=0, f=0.1),

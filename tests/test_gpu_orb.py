@@ -82,6 +82,25 @@ def test_orb_flat_and_noise_images():
     ext.close()
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (642, 481), (333, 250)])
+def test_orb_blur_saturation_and_tail_columns(w, h):
+    """The 7x7 blur's taps sum to 257 per axis (OpenCV 3.3's 8-bit fixed point, not renormalised): plateaus of 254 / 255 give column sums of 256 * 65536 and more, which
+    SymmColumnVec_32s8u saturates to 255 -- the fp32 column pass of k_orb_level (round 6) relies on v_cvt_pk_u8_f32 saturating there -- and exact halves (x.5 * 65536)
+    round to even in the vector columns and up in the w % 4 tail columns.  Bright plateaus, a 254 / 255 checkerboard, ramps that hit the ties, odd sizes."""
+    _need_gpu()
+    rng = np.random.default_rng(w)
+    img = np.full((h, w), 255, np.uint8)
+    img[: h // 3] = 254
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[h // 3: h // 2] = np.where(((yy[h // 3: h // 2] // 9) + (xx[h // 3: h // 2] // 9)) % 2 == 0, 255, 253).astype(np.uint8)
+    img[h // 2: 2 * h // 3] = (255 - (xx[h // 2: 2 * h // 3] % 64)).astype(np.uint8)
+    img[2 * h // 3:] = rng.choice(np.array([0, 128, 254, 255], np.uint8), size=(h - 2 * h // 3, w))
+    for _ in range(30):   # dark rectangles: corners on the plateaus
+        x0, y0 = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+        img[y0:y0 + int(rng.integers(8, 40)), x0:x0 + int(rng.integers(8, 40))] = int(rng.integers(0, 256))
+    _compare(img, 1000)
+
+
 def test_orb_batch_equals_single():
     _need_gpu()
     from rgbd_pl_slam_amd import ORBextractor
