@@ -21,6 +21,16 @@
 
 typedef uint32_t __attribute__((aligned(1))) plf_u32u;
 
+// plf_reflect101 for indices at most one image size outside [0, n): two selects instead of the general loop (which the compiler keeps as a data-dependent loop
+// in every place it is inlined: the tile phases carried five of them); anything further out -- halo wider than a tiny level -- still takes the loop
+__device__ __forceinline__ int of_reflect101(int p, int n)
+{
+    int q = p < 0 ? -p : p;
+    q = q >= n ? 2 * (n - 1) - q : q;
+    if (__builtin_expect((unsigned)q >= (unsigned)n, 0)) return plf_reflect101(p, n);
+    return q;
+}
+
 // cornerScore<16> of cv::FAST (largest threshold for which the pixel is still a corner) minus 1, clamped at 0; d[k] = I_p - I_ring[k]
 // (scalar form: the definition; the kernel runs the packed form orb_fast_score_pk below)
 __device__ __forceinline__ int orb_fast_score(const int d[16], int t)
@@ -161,21 +171,61 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     if (l == 0) {
         const uint8_t *img = in + (size_t)f * in_fstride;
         // (a thread owns a column group and walks down the rows, as in the plane write below: the column test and the mirrored columns are settled once)
+#ifndef OF_COPY_OLD
+        // Round 6: the threads are dealt to (column group, row slot) by the tile's own group count -- 240 of 256 lanes busy on a VGA tile instead of the 20 of every
+        // 32 that the fixed 32-groups-per-row layout used -- and the rows inside the image step a pointer; only rows mirrored at the image border take the
+        // REFLECT_101 path (10.6 vector lane-instructions per pixel for this COPY before, profiles/r06_orb_phase_insts.txt)
+        {
+            const int ng0 = EW >> 2, nslots = OF_NT / ng0;
+            const uint32_t rcp0 = 0xFFFFFFFFu / (uint32_t)ng0 + 1u;
+            const int slot = ng0 > 1 ? (int)__umulhi((uint32_t)tid, rcp0) : tid, cg = tid - slot * ng0;
+            if (slot < nslots) {
+                const int c4 = cg * 4, x = ex0 + c4;
+                const bool whole = x >= 0 && x + 3 < W;
+                int mx[4] = {x, x + 1, x + 2, x + 3};
+                if (!whole) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mx[j] = of_reflect101(x + j, W);
+                }
+                const int in0 = max(0, -ey0), in1 = min(EH, H - ey0);   // tile rows [in0, in1) lie inside the image
+                int ey = slot;
+                if (ey < in0) ey += (in0 - ey + nslots - 1) / nslots * nslots;
+                const uint8_t *row = img + (size_t)(ey0 + ey) * in_pitch;
+                uint8_t *dst = P + ey * PW + c4;
+                const size_t rstep = (size_t)nslots * in_pitch;
+                if (whole) {
+                    row += x;
+                    for (; ey < in1; ey += nslots, row += rstep, dst += nslots * PW) *reinterpret_cast<uint32_t *>(dst) = *(const plf_u32u *)row;
+                } else {
+                    for (; ey < in1; ey += nslots, row += rstep, dst += nslots * PW)
+                        *reinterpret_cast<uint32_t *>(dst) = (uint32_t)row[mx[0]] | ((uint32_t)row[mx[1]] << 8) | ((uint32_t)row[mx[2]] << 16) | ((uint32_t)row[mx[3]] << 24);
+                }
+                if (in0 > 0 || in1 < EH) {
+                    for (int e2 = slot; e2 < EH; e2 += nslots) {
+                        if (e2 >= in0 && e2 < in1) continue;
+                        const uint8_t *r2 = img + (size_t)of_reflect101(ey0 + e2, H) * in_pitch;
+                        *reinterpret_cast<uint32_t *>(P + e2 * PW + c4) = (uint32_t)r2[mx[0]] | ((uint32_t)r2[mx[1]] << 8) | ((uint32_t)r2[mx[2]] << 16) | ((uint32_t)r2[mx[3]] << 24);
+                    }
+                }
+            }
+        }
+#else
         for (int c4 = tc4; c4 < EW; c4 += 128) {
             const int x = ex0 + c4;
             const bool whole = x >= 0 && x + 3 < W;
             int mx[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) mx[j] = plf_reflect101(x + j, W);
+            for (int j = 0; j < 4; j++) mx[j] = of_reflect101(x + j, W);
             for (int ey = trow; ey < EH; ey += NR) {
                 const int y = ey0 + ey;
-                const uint8_t *row = img + (size_t)((unsigned)y < (unsigned)H ? y : plf_reflect101(y, H)) * in_pitch;
+                const uint8_t *row = img + (size_t)((unsigned)y < (unsigned)H ? y : of_reflect101(y, H)) * in_pitch;
                 uint32_t v;
                 if (whole) v = *(const plf_u32u *)(row + x);
                 else v = (uint32_t)row[mx[0]] | ((uint32_t)row[mx[1]] << 8) | ((uint32_t)row[mx[2]] << 16) | ((uint32_t)row[mx[3]] << 24);
                 *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = v;
             }
         }
+#endif
     } else {
         const OrbLevel &SL = g.lv[l - 1];
         const int SPW = g.lds_spw;
@@ -192,7 +242,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 uint32_t cf[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int X = plf_reflect101(ex0 + 4 * i + j, W);
+                    const int X = of_reflect101(ex0 + 4 * i + j, W);
                     const int sx = xofs[L.tabx_off + X];
                     const short2 a = xa[L.tabx_off + X];
                     off[j] = sx - sx_lo; nxt[j] = min(sx + 1, SL.w - 1) - sx_lo;
@@ -209,7 +259,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                     XT[4 * i + j] = t;
                 }
             } else {
-                const int Y = plf_reflect101(ey0 + (i - ngrp), H);
+                const int Y = of_reflect101(ey0 + (i - ngrp), H);
                 const int sy = yofs[L.taby_off + Y];
                 const short2 b = yb[L.taby_off + Y];
                 OrbRowTab t;
@@ -232,6 +282,76 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             for (int c4 = tc4; c4 < SWt + 8; c4 += 128)   // (+8: the 12-byte windows below may read past the last needed byte; the padded plane has them)
                 *reinterpret_cast<uint32_t *>(SRC + r * SPW + c4) = *(const plf_u32u *)(src + (size_t)(ps_lo + r) * SL.ppitch + sx_lo + c4);
         __syncthreads();                 // (first part: the tables above as well)
+#ifndef OF_RESIZE_OLD
+        // Round 6: a thread owns one column group for a BAND of consecutive tile rows and walks down them.  What depends on the column group only -- its four table
+        // entries, the window offset -- is loaded once, and consecutive output rows share a source row (scale 1.2: the lower source row of output row y is the upper one
+        // of row y + 1 five times out of six): its horizontal pass (one v_perm + one v_dot2 per output, already >> 4) stays in registers.  The arithmetic is
+        // unchanged; (c * x) >> 16 of the vertical pass is one v_mul_hi_u32 with the coefficient held as c << 16 (c <= 2048, x < 2^15: no overflow).
+        // Before: every (row, group) item reloaded the tables and ran both horizontal passes -- 100 vector instructions per 4 outputs, 64 M of the kernel's 306 M per
+        // 1024-frame launch (profiles/r06_orb_phase_insts.txt).
+        {
+            const int nrows = e1 - e0, tpg = OF_NT / ngrp, bh = (nrows + tpg - 1) / tpg;
+            const int band = ngrp > 1 ? (int)__umulhi((uint32_t)tid, rcp_g) : tid, cg = tid - band * ngrp;
+            const int rA = e0 + band * bh, rB = min(rA + bh, e1);
+            if (band < tpg && rA < rB) {
+                const int c4 = cg * 4;
+                OrbColTab t[4];
+                *reinterpret_cast<uint4 *>(&t[0]) = *reinterpret_cast<const uint4 *>(&XT[c4]);
+                *reinterpret_cast<uint4 *>(&t[2]) = *reinterpret_cast<const uint4 *>(&XT[c4 + 2]);
+                const int gm = GM[cg];
+                uint8_t *pout = P + rA * PW + c4;
+                const int srow0 = sy_lo - ps_lo;
+                if (gm >= 0) {
+                    const int base = gm & ~3, sh = gm & 3;
+                    const uint8_t *sb = SRC + base;
+                    int prev = -0x7fffffff;
+                    uint32_t hp[4] = {0u, 0u, 0u, 0u};
+                    auto hpass = [&](int srow, uint32_t hx[4]) {
+                        const uint8_t *r = sb + srow * SPW;
+                        const uint32_t a0 = *reinterpret_cast<const uint32_t *>(r), a1 = *reinterpret_cast<const uint32_t *>(r + 4), a2 = *reinterpret_cast<const uint32_t *>(r + 8);
+                        const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, sh), ahi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            hx[j] = (uint32_t)(__builtin_amdgcn_sdot2(__builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm(ahi, alo, t[j].sel)), __builtin_bit_cast(plf_s2v, t[j].coef), 0, false) >> 4);
+                    };
+                    for (int ey = rA; ey < rB; ey++, pout += PW) {
+                        const OrbRowTab ty_ = YT[ey];
+                        const int s0 = ty_.off + srow0, s1 = ty_.nxt + srow0;
+                        uint32_t h0[4], h1[4];
+                        if (s0 != prev) hpass(s0, h0);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) h0[j] = hp[j];
+                        }
+                        hpass(s1, h1);
+                        const uint32_t cs0 = (uint32_t)(uint16_t)ty_.c0 << 16, cs1 = (uint32_t)(uint16_t)ty_.c1 << 16;
+                        uint32_t out = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            out |= ((__umulhi(cs0, h0[j]) + __umulhi(cs1, h1[j]) + 2u) >> 2) << (8 * j);   // (<= 255: the coefficients of a pair sum to 2048)
+                            hp[j] = h1[j];
+                        }
+                        prev = s1;
+                        *reinterpret_cast<uint32_t *>(pout) = out;
+                    }
+                } else {
+                    for (int ey = rA; ey < rB; ey++, pout += PW) {
+                        const OrbRowTab ty_ = YT[ey];
+                        const uint8_t *r0 = SRC + (ty_.off + srow0) * SPW, *r1 = SRC + (ty_.nxt + srow0) * SPW;
+                        uint32_t out = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int o0 = (int)(t[j].sel & 0xFFFF), o1 = (int)(t[j].sel >> 16), c0 = (short)(t[j].coef & 0xFFFF), c1 = (short)(t[j].coef >> 16);
+                            const int sa = r0[o0] * c0 + r0[o1] * c1;
+                            const int sb_ = r1[o0] * c0 + r1[o1] * c1;
+                            out |= (uint32_t)(((((ty_.c0 * (sa >> 4)) >> 16) + ((ty_.c1 * (sb_ >> 4)) >> 16) + 2) >> 2) & 0xFF) << (8 * j);
+                        }
+                        *reinterpret_cast<uint32_t *>(pout) = out;
+                    }
+                }
+            }
+        }
+#else
         for (int i = tid + e0 * ngrp; i < ngrp * e1; i += OF_NT) {
             const int ey = ngrp > 1 ? (int)__umulhi((uint32_t)i, rcp_g) : i, c4 = (i - ey * ngrp) * 4;
             const OrbRowTab ty_ = YT[ey];
@@ -269,6 +389,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = out;
             }
         }
+#endif
         }
     }
     __syncthreads();
@@ -293,19 +414,70 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         // (measured alternatives for the stores themselves: 16-byte stores at byte alignment 29.8 -> 41.9 ms per 4096 frames; a plane layout that
         // makes these dword stores aligned -- pitch rounded to 64, one pad byte in front of every row -- changes nothing: 29.8 ms; writing the mirrored
         // border columns as byte-swapped dwords instead of single bytes: 30.4 ms)
+#ifndef OF_PLANE_MAP_OLD
+        // (round 6: threads dealt to (column group, row slot) by the tile's own group count, as in the level-0 copy above)
+        const int ngp = (pxe - PLF_EDGE - xg0 + 3) >> 2, NRp = OF_NT / ngp;
+        const uint32_t rcpp = 0xFFFFFFFFu / (uint32_t)ngp + 1u;
+        const int pslot = ngp > 1 ? (int)__umulhi((uint32_t)tid, rcpp) : tid;
+        for (int x4 = xg0 + 4 * (tid - pslot * ngp); pslot < NRp && x4 + PLF_EDGE < pxe; x4 += 4 * ngp) {
+#define OF_PROW pslot
+#define OF_PNR NRp
+#else
         for (int x4 = xg0 + tc4; x4 + PLF_EDGE < pxe; x4 += 128) {
+#define OF_PROW trow
+#define OF_PNR NR
+#endif
             const bool full = x4 >= 0 && x4 + 3 < W && x4 + PLF_EDGE >= pxs && x4 + 3 + PLF_EDGE < pxe;
-            int sc[4];
-            bool ok[4];
+            int sc[4] = {x4 - ex0, x4 + 1 - ex0, x4 + 2 - ex0, x4 + 3 - ex0};
+            bool ok[4] = {true, true, true, true};
+            if (!full) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                ok[j] = x4 + j + PLF_EDGE >= pxs && x4 + j + PLF_EDGE < pxe;
-                sc[j] = plf_reflect101(x4 + j, W) - ex0;
+                for (int j = 0; j < 4; j++) {
+                    ok[j] = x4 + j + PLF_EDGE >= pxs && x4 + j + PLF_EDGE < pxe;
+                    sc[j] = of_reflect101(x4 + j, W) - ex0;
+                }
             }
             uint8_t *dcol = plane + PLF_EDGE + x4;
-            for (int py = pys + trow; py < pye; py += NR) {
+#ifndef OF_PLANE_OLD
+            // Round 6: the rows inside the level (all rows of a tile that is not in the first / last tile row) need no mirror test: one LDS read, one store and two
+            // pointer steps per row; only the border rows above / below the level go through the REFLECT_101 index (a data-dependent loop in machine code, which
+            // the row loop used to carry for every row: 43 vector instructions per stored dword, profiles/r06_orb_phase_insts.txt)
+            const int pin0 = max(pys, PLF_EDGE), pin1 = min(pye, H + PLF_EDGE);   // plane rows [pin0, pin1) hold level rows [pin0 - 19, pin1 - 19)
+            {
+                int py = pys + OF_PROW;
+                if (py < pin0) py += (pin0 - py + OF_PNR - 1) / OF_PNR * OF_PNR;   // first row of this thread inside the level
+                const uint8_t *prow = P + (py - PLF_EDGE - ey0) * PW;
+                uint8_t *d = dcol + (size_t)py * ppitch;
+                const size_t dstep = (size_t)OF_PNR * ppitch;
+                if (full) {
+                    prow += x4 - ex0;
+                    for (; py < pin1; py += OF_PNR, prow += OF_PNR * PW, d += dstep) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow);
+                } else {
+                    for (; py < pin1; py += OF_PNR, prow += OF_PNR * PW, d += dstep) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (ok[j]) d[j] = prow[sc[j]];
+                    }
+                }
+            }
+            if (pys < pin0 || pye > pin1) {   // (first / last tile row only)
+                for (int py = pys + OF_PROW; py < pye; py += OF_PNR) {
+                    if (py >= pin0 && py < pin1) continue;
+                    const int ly = py - PLF_EDGE;
+                    const uint8_t *prow = P + (of_reflect101(ly, H) - ey0) * PW;
+                    uint8_t *d = dcol + (size_t)py * ppitch;
+                    if (full) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow + (x4 - ex0));
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (ok[j]) d[j] = prow[sc[j]];
+                    }
+                }
+            }
+#else
+            for (int py = pys + OF_PROW; py < pye; py += OF_PNR) {
                 const int ly = py - PLF_EDGE;
-                const uint8_t *prow = P + (((unsigned)ly < (unsigned)H ? ly : plf_reflect101(ly, H)) - ey0) * PW;
+                const uint8_t *prow = P + (((unsigned)ly < (unsigned)H ? ly : of_reflect101(ly, H)) - ey0) * PW;
                 uint8_t *d = dcol + (size_t)py * ppitch;
                 if (full) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow + (x4 - ex0));
                 else {
@@ -314,7 +486,10 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                         if (ok[j]) d[j] = prow[sc[j]];
                 }
             }
+#endif
         }
+#undef OF_PROW
+#undef OF_PNR
     }
 #if defined(OF_STOP) && OF_STOP <= 2
     return;
@@ -417,112 +592,103 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
 #if defined(OF_STOP) && OF_STOP <= 3
     return;
 #endif
-    // ---- 4. FAST score of the cells' computed regions (score tile S: rows ry0.., columns = tile columns)
+    // ---- 4-6. FAST-9/16 of the cells: pre-test, score, 3x3 non-maximum suppression, emission -- the reference's TWO calls per cell (so@0x763d4, so@0x76753) as two
+    // passes over the tile (round 6).  Pass A runs everything at iniThFAST for all cells: the pre-test passes 18 % of the pixels instead of 28 % at minThFAST (44 instead
+    // of 80 % on natural-image-like frames, tools/experiments/README.md), and every later stage -- the exact score of the survivors (the largest phase), the neighbourhood
+    // test -- scales with that.  A cell with a maximum at iniThFAST is emitted at once, as the reference's first call does.  Pass B, only for the cells that stayed
+    // empty (12 % on the polygon scenes) and only if the tile has any: the same three stages at minThFAST restricted to those cells.  Results are the same bits: a score
+    // is exact whatever threshold admitted the pixel (orb_fast_score_pk), a maximum >= iniThFAST beats every neighbour below iniThFAST whether that neighbour carries
+    // its exact score or 0, and non-maximum suppression never looks across a cell border.
+    //   pre-test: a thread owns one group of 4 columns for a band of rows and walks down them; a bright 9-arc needs two ADJACENT compass points of the ring with
+    //     d > t, a dark one two with d < -t; two pixels per instruction in packed int16 lanes; the four flags come off the sign bits (bits 0, 16: first pixel pair; 1,
+    //     17: second), survivors take their LIST slots with one LDS atomic per group (LIST's order is free);
+    //   score: cornerScore<16> of every survivor, densely packed over the lanes (S by position);
+    //   suppression: each wave walks its chunks of LIST, queues the survivors whose score reaches the pass's threshold (128-entry queue of its own in the dead table
+    //     area) and tests 64 queued corners at a time, branch-free (the eight scores are read unconditionally -- the bytes around the score tile are valid LDS -- and
+    //     masked with the four "inside the cell" flags); maxima are recorded as one bit per (cell, row, column);
+    //   emission: one wave per cell, lane = row; prefix count by a DPP scan, raster order.
     const int RH = ry1 - ry0;
     const int SP = g.lds_sp, cS0 = (rx0 - ex0) & ~3;   // score tile: pitch and first tile column (the computed regions only)
+    __shared__ int s_need;
     for (int i = tid; i < ((SP * RH + 3) >> 2); i += OF_NT) reinterpret_cast<uint32_t *>(S)[i] = 0u;
+    if (tid == 0) s_need = 0;
     __syncthreads();   // (every thread is done with the staged source: LIST aliases it)
-    const int tmin = g.minTh;
+    const int tmin = g.minTh, tini = g.iniTh;
+    const int wv = tid >> 6, lane = tid & 63;
+    const uint32_t lds_nlist = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)&s_nlist;
+    // pre-test geometry of this thread: column group, band of rows, the pixels of the group inside the computed regions split by cell column
+    const int cA = (rx0 - ex0) & ~3, cB = (rx1 - 1 - ex0) & ~3, ngr = ((cB - cA) >> 2) + 1;
+    const uint32_t rcp_r = 0xFFFFFFFFu / (uint32_t)ngr + 1u;
+    const int ptpg = OF_NT / ngr, pbh = (RH + ptpg - 1) / ptpg;
+    const int pband = ngr > 1 ? (int)__umulhi((uint32_t)tid, rcp_r) : tid, pc4 = cA + (tid - pband * ngr) * 4;
+    const int prA = pband * pbh, prB = pband < ptpg ? min(prA + pbh, RH) : prA;
+    uint32_t cmL, cmR;   // flag positions (0, 16, 1, 17 = pixel 0, 1, 2, 3) of the group's pixels in the left / right cell column
     {
-        const int cA = (rx0 - ex0) & ~3, cB = (rx1 - 1 - ex0) & ~3, ngr = ((cB - cA) >> 2) + 1, nit = ngr * RH;
-        const uint32_t rcp_r = 0xFFFFFFFFu / (uint32_t)ngr + 1u;
-        for (int i0 = 0; i0 < nit; i0 += OF_NT) {   // (uniform trip count: the ballots below need every lane)
-            {
-                const int i = i0 + tid;
-                const int ry = ngr > 1 ? (int)__umulhi((uint32_t)i, rcp_r) : i, c4 = cA + (i - ry * ngr) * 4;   // (ngr == 1: the reciprocal does not fit 32 bits)
-                uint32_t poss = 0;
-                if (i < nit) {
-                    const uint8_t *prow = P + (ry0 + ry - ey0) * PW + c4;
-                    const uint32_t Lw = *reinterpret_cast<const uint32_t *>(prow - 4), C = *reinterpret_cast<const uint32_t *>(prow),
-                                   Rw = *reinterpret_cast<const uint32_t *>(prow + 4), N = *reinterpret_cast<const uint32_t *>(prow + 3 * PW),
-                                   Sd = *reinterpret_cast<const uint32_t *>(prow - 3 * PW);
-                    // two pixels per instruction in packed int16 lanes: d = ring - centre for the compass points 0 (row + 3), 4 (x + 3), 8 (row - 3),
-                    // 12 (x - 3); a bright 9-arc needs two ADJACENT compass points with d > t, a dark one two with d < -t
-                    const plf_s2v tt = {(short)tmin, (short)tmin};
+        const int lo = rx0 - (ex0 + pc4), hi = rx1 - (ex0 + pc4), mid = xm - (ex0 + pc4);   // first pixel of the right cell column, relative to the group
+        const uint32_t in4 = (hi >= 4 ? 15u : (1u << max(hi, 0)) - 1u) & ~((1u << min(max(lo, 0), 4)) - 1u);
+        const uint32_t l4 = in4 & ((1u << min(max(mid, 0), 4)) - 1u), r4 = in4 & ~l4;
+        cmL = (l4 & 1u) | ((l4 & 2u) << 15) | ((l4 & 4u) >> 1) | ((l4 & 8u) << 14);
+        cmR = (r4 & 1u) | ((r4 & 2u) << 15) | ((r4 & 4u) >> 1) | ((r4 & 8u) << 14);
+    }
+    auto pretest = [&](int t, uint32_t cells_on) {
+        const plf_s2v tt = {(short)t, (short)t};
+        const int ymr = min(max(ym - ry0, 0), RH);   // first row of the lower cell row, relative to the region
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const uint32_t cm = ((cells_on >> (2 * half)) & 1u ? cmL : 0u) | ((cells_on >> (2 * half + 1)) & 1u ? cmR : 0u);
+            const int r0 = half ? max(prA, ymr) : prA, r1 = half ? prB : min(prB, ymr);
+            if (cm == 0u || r0 >= r1) continue;
+            const uint8_t *prow = P + (ry0 + r0 - ey0) * PW + pc4;
+            for (int ry = r0; ry < r1; ry++, prow += PW) {
+                const uint32_t Lw = *reinterpret_cast<const uint32_t *>(prow - 4), C = *reinterpret_cast<const uint32_t *>(prow),
+                               Rw = *reinterpret_cast<const uint32_t *>(prow + 4), N = *reinterpret_cast<const uint32_t *>(prow + 3 * PW),
+                               Sd = *reinterpret_cast<const uint32_t *>(prow - 3 * PW);
+                uint32_t sg[2];
 #pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        const plf_s2v v = OF_PAIR(Lw, C, Rw, 4 + j);
-                        const plf_s2v dn = OF_PAIR1(N, j) - v, de = OF_PAIR(Lw, C, Rw, 7 + j) - v, ds = OF_PAIR1(Sd, j) - v, dw = OF_PAIR(Lw, C, Rw, 1 + j) - v;
-                        // max over the four ADJACENT pairs of min(pair) = min(max(dn, ds), max(de, dw)): min distributes over max, and every point of {n, s} is
-                        // adjacent to every point of {e, w} on the 4-cycle -- the same VALUE with 3 instead of 7 packed operations (dk: dually)
-                        const plf_s2v br = of_min(of_max(dn, ds), of_max(de, dw));
-                        const plf_s2v dk = of_max(of_min(dn, ds), of_min(de, dw));
-                        const plf_s2v m = of_max(br, -dk) - tt;   // > 0: possible corner
-                        if (m.x > 0) poss |= 1u << j;
-                        if (m.y > 0) poss |= 2u << j;
-                    }
-                    // pixels of the group outside the computed regions
-                    const int lo = rx0 - (ex0 + c4), hi = rx1 - (ex0 + c4);
-                    poss &= (hi >= 4 ? 15u : (1u << max(hi, 0)) - 1u) & ~((1u << min(max(lo, 0), 4)) - 1u);
+                for (int j = 0; j < 4; j += 2) {
+                    // d = ring - centre for the compass points 0 (row + 3), 4 (x + 3), 8 (row - 3), 12 (x - 3)
+                    const plf_s2v v = OF_PAIR(Lw, C, Rw, 4 + j);
+                    const plf_s2v dn = OF_PAIR1(N, j) - v, de = OF_PAIR(Lw, C, Rw, 7 + j) - v, ds = OF_PAIR1(Sd, j) - v, dw = OF_PAIR(Lw, C, Rw, 1 + j) - v;
+                    // max over the four ADJACENT pairs of min(pair) = min(max(dn, ds), max(de, dw)): min distributes over max, and every point of {n, s} is
+                    // adjacent to every point of {e, w} on the 4-cycle (dk: dually)
+                    const plf_s2v br = of_min(of_max(dn, ds), of_max(de, dw));
+                    const plf_s2v dk = of_max(of_min(dn, ds), of_min(de, dw));
+                    sg[j >> 1] = __builtin_bit_cast(uint32_t, of_min(tt - br, tt + dk));   // sign bit set <=> br > t or dk < -t: possible corner
                 }
-#ifdef OF_COMPACT_BALLOT   // (the round 1-4 form: four ballots, one slot range per wave, raster order inside the wave)
-                const unsigned long long m0 = __ballot(poss & 1u), m1 = __ballot(poss & 2u), m2 = __ballot(poss & 4u), m3 = __ballot(poss & 8u);
-                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-                int base = 0;
-                if (plf_lane() == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(&s_nlist, n0 + n1 + n2 + n3);
-                base = __shfl(base, 0, 64);
-                const unsigned long long below = (1ull << plf_lane()) - 1ull;
-                const uint16_t e0 = (uint16_t)(c4 | (ry << 8));
-                if (poss & 1u) LIST[base + __popcll(m0 & below)] = e0;
-                if (poss & 2u) LIST[base + n0 + __popcll(m1 & below)] = (uint16_t)(e0 + 1);
-                if (poss & 4u) LIST[base + n0 + n1 + __popcll(m2 & below)] = (uint16_t)(e0 + 2);
-                if (poss & 8u) LIST[base + n0 + n1 + n2 + __popcll(m3 & below)] = (uint16_t)(e0 + 3);
-#else
-                // The order of LIST is free (the score goes to S by position, the maxima to bit masks by position), so a group takes its 1-4 slots with one
-                // LDS atomic of its own and writes its survivors there -- a third of the phase's instructions were the four ballots, their prefix counts and
-                // four separately addressed stores.
+                const uint32_t poss = (((sg[0] >> 15) & 0x10001u) | ((sg[1] >> 14) & 0x20002u)) & cm;
                 if (poss) {
                     // (inline asm: the compiler's atomic optimizer turns a divergent atomicAdd into a scalar loop over the active lanes -- ~9 instructions per lane)
                     int base;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base)
-                                 : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)&s_nlist), "v"(__popc(poss)) : "memory");
-                    const uint32_t e0 = (uint32_t)(c4 | (ry << 8));
-                    uint16_t *L = LIST + base;
-                    if (poss & 1u) L[0] = (uint16_t)e0;
-                    if (poss & 2u) L[poss & 1u] = (uint16_t)(e0 + 1);
-                    if (poss & 4u) L[__popc(poss & 3u)] = (uint16_t)(e0 + 2);
-                    if (poss & 8u) L[__popc(poss & 7u)] = (uint16_t)(e0 + 3);
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(lds_nlist), "v"(__popc(poss)) : "memory");
+                    const uint32_t e0 = (uint32_t)(pc4 | (ry << 8));
+                    uint16_t *Lp = LIST + base;
+                    if (poss & 1u) Lp[0] = (uint16_t)e0;
+                    if (poss & 2u) Lp[poss & 1u] = (uint16_t)(e0 + 2);
+                    if (poss & 0x10000u) Lp[__popc(poss & 3u)] = (uint16_t)(e0 + 1);
+                    if (poss & 0x20000u) Lp[__popc(poss & 0x10003u)] = (uint16_t)(e0 + 3);
                 }
-#endif
             }
         }
-    }
-    __syncthreads();
-#if defined(OF_STOP) && OF_STOP <= 4
-    return;
-#endif
-    const int nl = s_nlist;
-    for (int k = tid; k < nl; k += OF_NT) {
-        const int q = LIST[k], c = q & 255, ry = q >> 8;
-        const uint8_t *p = P + (ry0 + ry - ey0) * PW + c;
-        const int v = p[0];
-        // ring pixel k and k + 8 packed as (low, high) int16, subtracted from (v, v) by one v_pk_sub_i16
-        const plf_s2v vv = {(short)v, (short)v};
+    };
+    auto score = [&](int nl) {
+        for (int k = tid; k < nl; k += OF_NT) {
+            const int q = LIST[k], c = q & 255, ry = q >> 8;
+            const uint8_t *p = P + (ry0 + ry - ey0) * PW + c;
+            const int v = p[0];
+            // ring pixel k and k + 8 packed as (low, high) int16, subtracted from (v, v) by one v_pk_sub_i16
+            const plf_s2v vv = {(short)v, (short)v};
 #define OF_RP_(a, b) (vv - __builtin_bit_cast(plf_s2v, (uint32_t)(a) | ((uint32_t)(b) << 16)))
-        plf_s2v Pk[8];
-        Pk[0] = OF_RP_(p[3 * PW], p[-3 * PW]);          Pk[1] = OF_RP_(p[3 * PW + 1], p[-3 * PW - 1]);
-        Pk[2] = OF_RP_(p[2 * PW + 2], p[-2 * PW - 2]);  Pk[3] = OF_RP_(p[PW + 3], p[-PW - 3]);
-        Pk[4] = OF_RP_(p[3], p[-3]);                    Pk[5] = OF_RP_(p[-PW + 3], p[PW - 3]);
-        Pk[6] = OF_RP_(p[-2 * PW + 2], p[2 * PW - 2]);  Pk[7] = OF_RP_(p[-3 * PW + 1], p[3 * PW - 1]);
+            plf_s2v Pk[8];
+            Pk[0] = OF_RP_(p[3 * PW], p[-3 * PW]);          Pk[1] = OF_RP_(p[3 * PW + 1], p[-3 * PW - 1]);
+            Pk[2] = OF_RP_(p[2 * PW + 2], p[-2 * PW - 2]);  Pk[3] = OF_RP_(p[PW + 3], p[-PW - 3]);
+            Pk[4] = OF_RP_(p[3], p[-3]);                    Pk[5] = OF_RP_(p[-PW + 3], p[PW - 3]);
+            Pk[6] = OF_RP_(p[-2 * PW + 2], p[2 * PW - 2]);  Pk[7] = OF_RP_(p[-3 * PW + 1], p[3 * PW - 1]);
 #undef OF_RP_
-        S[ry * SP + c - cS0] = (uint8_t)orb_fast_score_pk(Pk, tmin);
-    }
-    __syncthreads();
-#if defined(OF_STOP) && OF_STOP <= 5
-    return;
-#endif
-    // ---- 5. 3x3 non-maximum suppression inside each cell's computed region (neighbours outside it count as 0); the maxima are recorded as one bit per
-    // (cell, row, column) for the two thresholds.
-    // Round 6: only the survivors that ARE corners (score >= minThFAST: a third of them on the polygon scenes) need the eight neighbours, and a wave pays for that
-    // path whenever one of its lanes does.  Each wave therefore walks its chunks of LIST, queues the corners it finds (ballot + prefix count, a 128-entry queue of its
-    // own in the dead table area) and runs the neighbourhood test on 64 queued corners at a time: densely packed lanes, and branch-free -- the eight scores are
-    // read unconditionally (the bytes around the score tile are valid LDS) and masked with the four "inside the cell" flags.  Before: 8 EXEC regions per survivor
-    // wave, 50 M of the kernel's 306 M vector instructions per 1024-frame launch (profiles/r06_orb_phase_insts.txt).
-#ifndef OF_NMS_OLD
-    {
-        const int wv = tid >> 6, lane = tid & 63;
-        uint16_t *Q = reinterpret_cast<uint16_t *>(XT) + wv * 128;
-        const int iniTh = g.iniTh;
+            S[ry * SP + c - cS0] = (uint8_t)orb_fast_score_pk(Pk, tmin);
+        }
+    };
+    uint16_t *Q = reinterpret_cast<uint16_t *>(XT) + wv * 128;
+    auto nms = [&](int nl, int tc, int which) {   // maxima with a score >= tc -> s_mask[cell][row][which]
         auto nms_one = [&](int q) {
             const int c = q & 255, ry = q >> 8;
             const uint8_t *sp = S + ry * SP + c - cS0;
@@ -536,12 +702,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             const uint32_t d0 = sp[SP - 1] & ml, d1 = sp[SP], d2 = sp[SP + 1] & mr;
             const uint32_t up = max(max(u0, u1), u2) & mu, dn = max(max(d0, d1), d2) & md;
             const uint32_t nb = max(max(a, b), max(up, dn));
-            if ((uint32_t)sc > nb) {
-                const int ci = (ccol ? 1 : 0) + (crow ? 2 : 0);
-                const unsigned long long bit = 1ull << (x - xl);
-                atomicOr(&s_mask[ci][y - yt][1], bit);
-                if (sc >= iniTh) atomicOr(&s_mask[ci][y - yt][0], bit);
-            }
+            if ((uint32_t)sc > nb) atomicOr(&s_mask[(ccol ? 1 : 0) + (crow ? 2 : 0)][y - yt][which], 1ull << (x - xl));
         };
         int qn = 0;   // (wave-uniform)
         for (int k0 = wv * 64; k0 < nl; k0 += OF_NT) {
@@ -550,7 +711,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             bool corner = false;
             if (k < nl) {
                 q = LIST[k];
-                corner = (int)S[(q >> 8) * SP + (q & 255) - cS0] >= tmin;
+                corner = (int)S[(q >> 8) * SP + (q & 255) - cS0] >= tc;
             }
             const unsigned long long m = __ballot(corner);
             if (m == 0ull) continue;
@@ -564,55 +725,34 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             }
         }
         if (lane < qn) nms_one(Q[lane]);
-    }
-#else
-    for (int k = tid; k < nl; k += OF_NT) {
-        const int q = LIST[k], c = q & 255, ry = q >> 8;
-        const uint8_t *sp = S + ry * SP + c - cS0;
-        const int sc = sp[0];
-        if (sc < tmin) continue;
-        const int x = ex0 + c, y = ry0 + ry;
-        const int ccol = x >= xm, crow = y >= ym;
-        const int xl = ccol ? xm : rx0, xr = ccol ? rx1 : xm, yt = crow ? ym : ry0, yb_ = crow ? ry1 : ym;   // the cell's computed region
-        const bool okl = x > xl, okr = x + 1 < xr, oku = y > yt, okd = y + 1 < yb_;
-        int nb = 0;
-        if (okl) nb = max(nb, (int)sp[-1]);
-        if (okr) nb = max(nb, (int)sp[1]);
-        if (oku) { nb = max(nb, (int)sp[-SP]); if (okl) nb = max(nb, (int)sp[-SP - 1]); if (okr) nb = max(nb, (int)sp[-SP + 1]); }
-        if (okd) { nb = max(nb, (int)sp[SP]); if (okl) nb = max(nb, (int)sp[SP - 1]); if (okr) nb = max(nb, (int)sp[SP + 1]); }
-        if (sc > nb) {
-            const int ci = ccol + 2 * crow;
-            const unsigned long long bit = 1ull << (x - xl);
-            atomicOr(&s_mask[ci][y - yt][1], bit);
-            if (sc >= g.iniTh) atomicOr(&s_mask[ci][y - yt][0], bit);
-        }
-    }
-#endif
-    __syncthreads();
-    // ---- 6. per cell (one wave each): iniThFAST, or minThFAST when that leaves the cell empty; raster-ordered emission
-    {
-        const int wv = tid >> 6, lane = tid & 63;
-        const int cx = cx0 + (wv & 1), cy = cy0 + (wv >> 1);
-        if (cx >= cx1 || cy >= cy1) return;
-        const int cell = L.cell_base + cy * L.ncx + cx;
-        const int4 rc = cells[cell];                 // x0, y0, w, h of the sub-image (level interior coordinates)
-        const int ch = rc.w - 6;                     // rows of the computed region
-        const uint8_t *sp = S + (rc.y + 3 - ry0) * SP + (rc.x + 3 - ex0 - cS0);
-        const unsigned long long my20 = lane < ch ? s_mask[wv][lane][0] : 0ull, my7 = lane < ch ? s_mask[wv][lane][1] : 0ull;   // lane r = row r
-        const int n20 = plf_wave_sum(__popcll(my20));
-        const unsigned long long mine = n20 > 0 ? my20 : my7;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // this wave's cell
+    const int ecx = cx0 + (wv & 1), ecy = cy0 + (wv >> 1);
+    const bool ecell = wv < 4 && ecx < cx1 && ecy < cy1;
+    const int cell = L.cell_base + ecy * L.ncx + ecx;
+    int4 rc = make_int4(0, 0, 6, 6);
+    if (ecell) rc = cells[cell];                     // x0, y0, w, h of the sub-image (level interior coordinates)
+    auto emit = [&](unsigned long long mine) {       // raster-ordered emission of the cell's maxima (lane r holds row r's bits)
         const int cnt = __popcll(mine);
-        const int total = plf_wave_sum(cnt);
-        const int excl = plf_wave_excl_scan(cnt);
+        int incl = cnt;   // inclusive prefix sum over the wave: four row shifts, two row broadcasts
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);   // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);   // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+        const int total = __builtin_amdgcn_readlane(incl, 63), excl = incl - cnt;
         int base = 0;
         if (lane == 0 && total > 0) base = atomicAdd(&poolcnt[f * g.nlevels + l], total);
-        base = __shfl(base, 0, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
         if (lane == 0) cellinfo[(size_t)f * g.cells_total + cell] = make_int2(base, total);
         if (total == 0) return;
         if (base + total > (int)L.pool_cap) {  // cannot happen (pool sized for the densest possible NMS output)
             if (lane == 0) atomicOr(status, 1);
             return;
         }
+        const uint8_t *sp = S + (rc.y + 3 - ry0) * SP + (rc.x + 3 - ex0 - cS0);
         uint2 *out = pool + (size_t)f * g.pool_stride + L.pool_off + base + excl;
         unsigned long long mm = mine;
         const int gy = rc.y + 3 + lane;
@@ -625,5 +765,41 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             // coordinates relative to (minBorderX, minBorderY) as DistributeOctTree expects
             out[k++] = make_uint2((uint32_t)(x - PLF_MINB) | ((uint32_t)(gy - PLF_MINB) << 16), (uint32_t)resp);
         }
+    };
+    const int ch = rc.w - 6;                         // rows of the cell's computed region
+    // ---- pass A: iniThFAST, all cells
+    pretest(tini, 0xFu);
+    __syncthreads();
+#if defined(OF_STOP) && OF_STOP <= 4
+    return;
+#endif
+    int nl = s_nlist;
+    score(nl);
+    __syncthreads();
+#if defined(OF_STOP) && OF_STOP <= 5
+    return;
+#endif
+    nms(nl, tini, 0);
+    __syncthreads();
+#if defined(OF_STOP) && OF_STOP <= 6
+    return;
+#endif
+    if (ecell) {
+        const unsigned long long my20 = lane < ch ? s_mask[wv][lane][0] : 0ull;
+        if (__ballot(my20 != 0ull) != 0ull) emit(my20);
+        else if (lane == 0) atomicOr(&s_need, 1 << wv);
     }
+    if (tid == 0) s_nlist = 0;   // (every thread read the count before the barrier above)
+    __syncthreads();
+    const uint32_t need = (uint32_t)s_need;
+    if (need == 0u) return;
+    // ---- pass B: minThFAST, the cells the first pass left empty
+    pretest(tmin, need);
+    __syncthreads();
+    nl = s_nlist;
+    score(nl);
+    __syncthreads();
+    nms(nl, tmin, 1);
+    __syncthreads();
+    if (ecell && ((need >> wv) & 1u)) emit(lane < ch ? s_mask[wv][lane][1] : 0ull);
 }
