@@ -135,7 +135,8 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     __builtin_amdgcn_s_setprio(PLF_ORB_PRIO);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_nlist;
-    __shared__ unsigned long long s_mask[4][64][2];   // per cell of the tile, per row of its computed region: NMS maxima >= iniTh / >= minTh
+    __shared__ unsigned long long s_mask[4][64];   // per cell of the tile, per row of its computed region: the NMS maxima of the pass that emits the cell (a cell that
+                                                     // needs the second pass has none from the first)
     const OrbLevel &L = g.lv[l];
     const int tid = threadIdx.x, f = blockIdx.y;
     const int trow = tid >> 5, tc4 = (tid & 31) * 4;
@@ -166,12 +167,11 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     OrbRowTab *YT = reinterpret_cast<OrbRowTab *>(XT + PW);
     short *GM = reinterpret_cast<short *>(YT + g.lds_eh);   // per column group: first source byte of its window (negative: -1 - first, window wider than 8)
     if (tid == 0) s_nlist = 0;
-    for (int i = tid; i < 4 * 64 * 2; i += OF_NT) (&s_mask[0][0][0])[i] = 0ull;
+    for (int i = tid; i < 4 * 64; i += OF_NT) (&s_mask[0][0])[i] = 0ull;
     // ---- 1. the level pixels of the tile
     if (l == 0) {
         const uint8_t *img = in + (size_t)f * in_fstride;
         // (a thread owns a column group and walks down the rows, as in the plane write below: the column test and the mirrored columns are settled once)
-#ifndef OF_COPY_OLD
         // Round 6: the threads are dealt to (column group, row slot) by the tile's own group count -- 240 of 256 lanes busy on a VGA tile instead of the 20 of every
         // 32 that the fixed 32-groups-per-row layout used -- and the rows inside the image step a pointer; only rows mirrored at the image border take the
         // REFLECT_101 path (10.6 vector lane-instructions per pixel for this COPY before, profiles/r06_orb_phase_insts.txt)
@@ -209,23 +209,6 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 }
             }
         }
-#else
-        for (int c4 = tc4; c4 < EW; c4 += 128) {
-            const int x = ex0 + c4;
-            const bool whole = x >= 0 && x + 3 < W;
-            int mx[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) mx[j] = of_reflect101(x + j, W);
-            for (int ey = trow; ey < EH; ey += NR) {
-                const int y = ey0 + ey;
-                const uint8_t *row = img + (size_t)((unsigned)y < (unsigned)H ? y : of_reflect101(y, H)) * in_pitch;
-                uint32_t v;
-                if (whole) v = *(const plf_u32u *)(row + x);
-                else v = (uint32_t)row[mx[0]] | ((uint32_t)row[mx[1]] << 8) | ((uint32_t)row[mx[2]] << 16) | ((uint32_t)row[mx[3]] << 24);
-                *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = v;
-            }
-        }
-#endif
     } else {
         const OrbLevel &SL = g.lv[l - 1];
         const int SPW = g.lds_spw;
@@ -282,7 +265,6 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             for (int c4 = tc4; c4 < SWt + 8; c4 += 128)   // (+8: the 12-byte windows below may read past the last needed byte; the padded plane has them)
                 *reinterpret_cast<uint32_t *>(SRC + r * SPW + c4) = *(const plf_u32u *)(src + (size_t)(ps_lo + r) * SL.ppitch + sx_lo + c4);
         __syncthreads();                 // (first part: the tables above as well)
-#ifndef OF_RESIZE_OLD
         // Round 6: a thread owns one column group for a BAND of consecutive tile rows and walks down them.  What depends on the column group only -- its four table
         // entries, the window offset -- is loaded once, and consecutive output rows share a source row (scale 1.2: the lower source row of output row y is the upper one
         // of row y + 1 five times out of six): its horizontal pass (one v_perm + one v_dot2 per output, already >> 4) stays in registers.  The arithmetic is
@@ -351,45 +333,6 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 }
             }
         }
-#else
-        for (int i = tid + e0 * ngrp; i < ngrp * e1; i += OF_NT) {
-            const int ey = ngrp > 1 ? (int)__umulhi((uint32_t)i, rcp_g) : i, c4 = (i - ey * ngrp) * 4;
-            const OrbRowTab ty_ = YT[ey];
-            const uint8_t *r0 = SRC + (ty_.off + sy_lo - ps_lo) * SPW, *r1 = SRC + (ty_.nxt + sy_lo - ps_lo) * SPW;
-            {
-                OrbColTab t[4];
-                *reinterpret_cast<uint4 *>(&t[0]) = *reinterpret_cast<const uint4 *>(&XT[c4]);
-                *reinterpret_cast<uint4 *>(&t[2]) = *reinterpret_cast<const uint4 *>(&XT[c4 + 2]);
-                const int gm = GM[c4 >> 2];
-                uint32_t out = 0;
-                if (gm >= 0) {
-                    const int base = gm & ~3, sh = gm & 3;
-                    const uint32_t a0 = *reinterpret_cast<const uint32_t *>(r0 + base), a1 = *reinterpret_cast<const uint32_t *>(r0 + base + 4),
-                                   a2 = *reinterpret_cast<const uint32_t *>(r0 + base + 8);
-                    const uint32_t b0 = *reinterpret_cast<const uint32_t *>(r1 + base), b1 = *reinterpret_cast<const uint32_t *>(r1 + base + 4),
-                                   b2 = *reinterpret_cast<const uint32_t *>(r1 + base + 8);
-                    const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, sh), ahi = __builtin_amdgcn_alignbyte(a2, a1, sh);
-                    const uint32_t blo = __builtin_amdgcn_alignbyte(b1, b0, sh), bhi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const plf_s2v cf = __builtin_bit_cast(plf_s2v, t[j].coef);
-                        const int s0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm(ahi, alo, t[j].sel)), cf, 0, false);
-                        const int s1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(plf_s2v, __builtin_amdgcn_perm(bhi, blo, t[j].sel)), cf, 0, false);
-                        out |= (uint32_t)(((((ty_.c0 * (s0 >> 4)) >> 16) + ((ty_.c1 * (s1 >> 4)) >> 16) + 2) >> 2) & 0xFF) << (8 * j);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int o0 = (int)(t[j].sel & 0xFFFF), o1 = (int)(t[j].sel >> 16), c0 = (short)(t[j].coef & 0xFFFF), c1 = (short)(t[j].coef >> 16);
-                        const int s0 = r0[o0] * c0 + r0[o1] * c1;
-                        const int s1 = r1[o0] * c0 + r1[o1] * c1;
-                        out |= (uint32_t)(((((ty_.c0 * (s0 >> 4)) >> 16) + ((ty_.c1 * (s1 >> 4)) >> 16) + 2) >> 2) & 0xFF) << (8 * j);
-                    }
-                }
-                *reinterpret_cast<uint32_t *>(P + ey * PW + c4) = out;
-            }
-        }
-#endif
         }
     }
     __syncthreads();
@@ -414,19 +357,11 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         // (measured alternatives for the stores themselves: 16-byte stores at byte alignment 29.8 -> 41.9 ms per 4096 frames; a plane layout that
         // makes these dword stores aligned -- pitch rounded to 64, one pad byte in front of every row -- changes nothing: 29.8 ms; writing the mirrored
         // border columns as byte-swapped dwords instead of single bytes: 30.4 ms)
-#ifndef OF_PLANE_MAP_OLD
         // (round 6: threads dealt to (column group, row slot) by the tile's own group count, as in the level-0 copy above)
         const int ngp = (pxe - PLF_EDGE - xg0 + 3) >> 2, NRp = OF_NT / ngp;
         const uint32_t rcpp = 0xFFFFFFFFu / (uint32_t)ngp + 1u;
         const int pslot = ngp > 1 ? (int)__umulhi((uint32_t)tid, rcpp) : tid;
         for (int x4 = xg0 + 4 * (tid - pslot * ngp); pslot < NRp && x4 + PLF_EDGE < pxe; x4 += 4 * ngp) {
-#define OF_PROW pslot
-#define OF_PNR NRp
-#else
-        for (int x4 = xg0 + tc4; x4 + PLF_EDGE < pxe; x4 += 128) {
-#define OF_PROW trow
-#define OF_PNR NR
-#endif
             const bool full = x4 >= 0 && x4 + 3 < W && x4 + PLF_EDGE >= pxs && x4 + 3 + PLF_EDGE < pxe;
             int sc[4] = {x4 - ex0, x4 + 1 - ex0, x4 + 2 - ex0, x4 + 3 - ex0};
             bool ok[4] = {true, true, true, true};
@@ -438,22 +373,21 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 }
             }
             uint8_t *dcol = plane + PLF_EDGE + x4;
-#ifndef OF_PLANE_OLD
             // Round 6: the rows inside the level (all rows of a tile that is not in the first / last tile row) need no mirror test: one LDS read, one store and two
             // pointer steps per row; only the border rows above / below the level go through the REFLECT_101 index (a data-dependent loop in machine code, which
             // the row loop used to carry for every row: 43 vector instructions per stored dword, profiles/r06_orb_phase_insts.txt)
             const int pin0 = max(pys, PLF_EDGE), pin1 = min(pye, H + PLF_EDGE);   // plane rows [pin0, pin1) hold level rows [pin0 - 19, pin1 - 19)
             {
-                int py = pys + OF_PROW;
-                if (py < pin0) py += (pin0 - py + OF_PNR - 1) / OF_PNR * OF_PNR;   // first row of this thread inside the level
+                int py = pys + pslot;
+                if (py < pin0) py += (pin0 - py + NRp - 1) / NRp * NRp;   // first row of this thread inside the level
                 const uint8_t *prow = P + (py - PLF_EDGE - ey0) * PW;
                 uint8_t *d = dcol + (size_t)py * ppitch;
-                const size_t dstep = (size_t)OF_PNR * ppitch;
+                const size_t dstep = (size_t)NRp * ppitch;
                 if (full) {
                     prow += x4 - ex0;
-                    for (; py < pin1; py += OF_PNR, prow += OF_PNR * PW, d += dstep) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow);
+                    for (; py < pin1; py += NRp, prow += NRp * PW, d += dstep) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow);
                 } else {
-                    for (; py < pin1; py += OF_PNR, prow += OF_PNR * PW, d += dstep) {
+                    for (; py < pin1; py += NRp, prow += NRp * PW, d += dstep) {
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             if (ok[j]) d[j] = prow[sc[j]];
@@ -461,7 +395,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                 }
             }
             if (pys < pin0 || pye > pin1) {   // (first / last tile row only)
-                for (int py = pys + OF_PROW; py < pye; py += OF_PNR) {
+                for (int py = pys + pslot; py < pye; py += NRp) {
                     if (py >= pin0 && py < pin1) continue;
                     const int ly = py - PLF_EDGE;
                     const uint8_t *prow = P + (of_reflect101(ly, H) - ey0) * PW;
@@ -474,22 +408,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                     }
                 }
             }
-#else
-            for (int py = pys + OF_PROW; py < pye; py += OF_PNR) {
-                const int ly = py - PLF_EDGE;
-                const uint8_t *prow = P + (((unsigned)ly < (unsigned)H ? ly : of_reflect101(ly, H)) - ey0) * PW;
-                uint8_t *d = dcol + (size_t)py * ppitch;
-                if (full) *(plf_u32u *)d = *reinterpret_cast<const uint32_t *>(prow + (x4 - ex0));
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (ok[j]) d[j] = prow[sc[j]];
-                }
-            }
-#endif
         }
-#undef OF_PROW
-#undef OF_PNR
     }
 #if defined(OF_STOP) && OF_STOP <= 2
     return;
@@ -688,7 +607,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         }
     };
     uint16_t *Q = reinterpret_cast<uint16_t *>(XT) + wv * 128;
-    auto nms = [&](int nl, int tc, int which) {   // maxima with a score >= tc -> s_mask[cell][row][which]
+    auto nms = [&](int nl, int tc) {   // maxima with a score >= tc -> s_mask[cell][row]
         auto nms_one = [&](int q) {
             const int c = q & 255, ry = q >> 8;
             const uint8_t *sp = S + ry * SP + c - cS0;
@@ -702,7 +621,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
             const uint32_t d0 = sp[SP - 1] & ml, d1 = sp[SP], d2 = sp[SP + 1] & mr;
             const uint32_t up = max(max(u0, u1), u2) & mu, dn = max(max(d0, d1), d2) & md;
             const uint32_t nb = max(max(a, b), max(up, dn));
-            if ((uint32_t)sc > nb) atomicOr(&s_mask[(ccol ? 1 : 0) + (crow ? 2 : 0)][y - yt][which], 1ull << (x - xl));
+            if ((uint32_t)sc > nb) atomicOr(&s_mask[(ccol ? 1 : 0) + (crow ? 2 : 0)][y - yt], 1ull << (x - xl));
         };
         int qn = 0;   // (wave-uniform)
         for (int k0 = wv * 64; k0 < nl; k0 += OF_NT) {
@@ -779,13 +698,13 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
 #if defined(OF_STOP) && OF_STOP <= 5
     return;
 #endif
-    nms(nl, tini, 0);
+    nms(nl, tini);
     __syncthreads();
 #if defined(OF_STOP) && OF_STOP <= 6
     return;
 #endif
     if (ecell) {
-        const unsigned long long my20 = lane < ch ? s_mask[wv][lane][0] : 0ull;
+        const unsigned long long my20 = lane < ch ? s_mask[wv][lane] : 0ull;
         if (__ballot(my20 != 0ull) != 0ull) emit(my20);
         else if (lane == 0) atomicOr(&s_need, 1 << wv);
     }
@@ -799,7 +718,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
     nl = s_nlist;
     score(nl);
     __syncthreads();
-    nms(nl, tmin, 1);
+    nms(nl, tmin);
     __syncthreads();
-    if (ecell && ((need >> wv) & 1u)) emit(lane < ch ? s_mask[wv][lane][1] : 0ull);
+    if (ecell && ((need >> wv) & 1u)) emit(lane < ch ? s_mask[wv][lane] : 0ull);
 }

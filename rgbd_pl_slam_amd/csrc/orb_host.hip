@@ -286,8 +286,8 @@ static int orb_configure(plf_orb *h, int w, int hh)
         size_t sz_a = 0;
         for (g.lds_parts = 1; g.lds_parts <= 4; g.lds_parts++) {
             sz_a = std::max((size_t)g.lds_spw * (maxSHp[g.lds_parts] + 1) + 16, sz_list);
-            // five tiles per CU: 160 KB / 5 minus the 4112 static bytes; stop splitting when the survivor list is what is left
-            if (up16(sz_p) + up16(sz_a) + up16(sz_s) + up16(sz_t) <= 160 * 1024 / 5 - 4112 - 64 || sz_a == sz_list || g.lds_parts == 4) break;
+            // five tiles per CU: 160 KB / 5 minus the 2064 static bytes (the NMS masks, round 6: one set for both passes); stop splitting when the survivor list is what is left
+            if (up16(sz_p) + up16(sz_a) + up16(sz_s) + up16(sz_t) <= 160 * 1024 / 5 - 2064 - 64 || sz_a == sz_list || g.lds_parts == 4) break;
         }
         g.lds_off_a = (int)up16(sz_p);
         g.lds_off_s = g.lds_off_a + (int)up16(sz_a);
@@ -296,7 +296,7 @@ static int orb_configure(plf_orb *h, int w, int hh)
         g.lds_total = g.lds_off_tab + (int)up16(sz_t);
         if (g.lds_total > 150 * 1024) return PLF_E_BADARG;
         if (getenv("PLF_ORB_DEBUG_LDS"))
-            fprintf(stderr, "[plf] k_orb_level LDS: P %zu, SRC/LIST %zu (%d parts), S %zu, tables %zu -> %d dynamic + 4112 static (pw %d, spw %d, sp %d, eh %d, maxRW %d, maxRH %d)\n",
+            fprintf(stderr, "[plf] k_orb_level LDS: P %zu, SRC/LIST %zu (%d parts), S %zu, tables %zu -> %d dynamic + 2064 static (pw %d, spw %d, sp %d, eh %d, maxRW %d, maxRH %d)\n",
                     sz_p, sz_a, g.lds_parts, sz_s, sz_t, g.lds_total, g.lds_pw, g.lds_spw, g.lds_sp, g.lds_eh, maxRW, maxRH);
     }
     // keep the per-frame strides of the allocation (max size) so that buffer sizes stay valid
