@@ -43,6 +43,11 @@ typedef enum {
                             host buffers in or out do that themselves) */
     , PLF_W_TRUNCATED = 1 /* not an error (plf_line_last_status only): at least one frame of the batch spent its plf_line_params.max_ms and was finished
                             with the line segments found so far; extraction calls themselves return PLF_OK for such a batch */
+    , PLF_W_SLOW = 2      /* not an error, outputs complete and exact: plf_line_extract / plf_line_extract_batch with host outputs took more than `slow_factor`
+                            (10) times the median per-frame time of this handle's recent calls at this image size, and more than `slow_floor_ms` (20 ms) per frame.
+                            Images that are pathological for LSD (quantised textures: thousands of tiny regions) cost the GPU's serial region chain seconds per
+                            frame; a caller with a frame deadline can answer the warning by creating the handle with plf_line_params.max_ms.  plf_line_tune
+                            "slow_factor" = 0 switches the warning off.  Also reported by plf_line_last_status until the next call. */
 } plf_status;
 
 enum { PLF_MEM_HOST = 0, PLF_MEM_DEVICE = 1 };
@@ -142,7 +147,7 @@ void plf_line_destroy(plf_line *h);
 /* Schedule knobs of a line-extractor handle (frames-in-flight thresholds of its schedules, band counts ...).  They are read from the environment ONCE, when the handle
  * is created (PLF_LSD_*, PLF_NFA_FUSED: experiments), and never again; this call changes one of them afterwards -- a tuning and test hook, not needed in production:
  * "spec_max" (frames in flight up to which the banded speculative schedule is used, 640), "spec_bands", "spec_z", "spec_rounds", "spec_halo", "spec_clip", "spec_fill",
- * "spec_fill_tol", "spec_stagger", "spec_nofuse", "spec_spins", "spec_reccap", "lat_max", "wpg", "one_wave_groups", "nfa_fused" (frames in flight up to which one wave per
+ * "spec_fill_tol", "spec_stagger", "spec_nofuse", "spec_spins", "spec_reccap", "lat_max", "wpg", "one_wave_groups", "slow_factor", "slow_floor_ms" (PLF_W_SLOW), "nfa_fused" (frames in flight up to which one wave per
  * rectangle runs all NFA stages, 64).  Every schedule gives the same bits.  PLF_E_BADARG for an unknown name or a value out of range. */
 int plf_line_tune(plf_line *h, const char *name, double value);
 

@@ -25,7 +25,9 @@ struct Error : std::runtime_error {
     int status;
     Error(int st, const char *what) : std::runtime_error(std::string(what) + ": " + plf_status_string(st)), status(st) {}
 };
-inline void check(int st, const char *what) { if (st != PLF_OK) throw Error(st, what); }
+// errors (< 0) throw; warnings (> 0: the outputs are complete -- PLF_W_SLOW) are kept for the caller to look at
+inline int &last_warning() { static thread_local int w = 0; return w; }
+inline void check(int st, const char *what) { last_warning() = st > 0 ? st : 0; if (st < 0) throw Error(st, what); }
 
 // ------------------------------------------------------------------ ORBextractor
 class ORBextractor {

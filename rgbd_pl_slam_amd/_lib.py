@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLF_LIB_PATH") or os.path.join(_HERE, "libplf_hip.so")   # (PLF_LIB_PATH: A/B measurements of scratch builds)
 
 PLF_OK, PLF_E_EMPTY, PLF_E_BADARG, PLF_E_CAPACITY, PLF_E_HIP, PLF_E_NOMEM, PLF_E_RECTS = 0, -1, -2, -3, -4, -5, -6
-PLF_W_TRUNCATED = 1
+PLF_W_TRUNCATED, PLF_W_SLOW = 1, 2
+last_warning = 0   # the last positive (warning) status a call returned through check(): PLF_W_SLOW
 MEM_HOST, MEM_DEVICE = 0, 1
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -123,7 +124,10 @@ def lib():
 
 
 def check(status, what):
-    if status != PLF_OK:
+    """errors (< 0) raise; warnings (> 0: outputs complete) are kept in `last_warning`"""
+    global last_warning
+    last_warning = status if status > 0 else 0
+    if status < 0:
         raise PlfError(status, what)
 
 

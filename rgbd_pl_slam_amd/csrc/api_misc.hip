@@ -14,6 +14,8 @@ extern "C" const char *plf_status_string(int status)
         case PLF_E_HIP: return "HIP runtime error";
         case PLF_E_NOMEM: return "out of memory";
         case PLF_E_RECTS: return "more LSD rectangles than the line handle holds";
+        case PLF_W_TRUNCATED: return "warning: a frame ran out of its time budget (max_ms)";
+        case PLF_W_SLOW: return "warning: the call took far longer than the handle's recent calls (outputs complete)";
         default: return "unknown";
     }
 }

@@ -581,7 +581,7 @@ static int chunk_retire(Worker *w, Slot &s, const Job &J, int *soft)
             std::vector<int32_t> nl(s.n);
             int rc = plf_line_extract_batch(w->line, d_gray, PLF_MEM_DEVICE, s.n, J.w, J.h, J.w, (ptrdiff_t)J.w * J.h, s.h_lines, s.h_ldesc, s.h_eq, nl.data(),
                                             PLF_MEM_HOST, w->line_cap, w->s_line);
-            if (rc != PLF_OK && rc != PLF_E_CAPACITY) return rc;
+            if (rc < 0 && rc != PLF_E_CAPACITY) return rc;   // (> 0: warnings -- PLF_W_SLOW: the redo of a pathological chunk IS slow; outputs complete)
             if (rc == PLF_E_CAPACITY) *soft = PLF_E_CAPACITY;
             for (int f = 0; f < s.n; f++) s.h_nl[f] = nl[f];
             // the time-budget flags of the failed pass are meaningless as well: those of the redo (collected over its pieces by the line extractor)

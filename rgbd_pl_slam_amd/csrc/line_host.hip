@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <chrono>
 #include <hipcub/hipcub.hpp>
 #include "plf_common.h"
 #include "lsd_geom.h"
@@ -89,6 +90,8 @@ struct LineTune {
                           //                      batch instead of 17, but 17 ms instead of 9.5 per 8192 VGA frames); 0: the staged kernels
     int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
     int balance;          // PLF_LSD_BALANCE      1: large batches -- the frames are dealt to the waves of k_lsd_regions2 by chain length (k_lsd_balance); 0: in batch order
+    float slow_factor;    // PLF_LSD_SLOW_FACTOR  PLF_W_SLOW: a host-output call that takes more than this many times the median per-frame time of the recent calls (10; 0: off)
+    float slow_floor_ms;  // PLF_LSD_SLOW_FLOOR_MS  ... and more than this per frame (20 ms)
 };
 static int tune_env_i(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static float tune_env_f(const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; }
@@ -106,6 +109,8 @@ static void line_tune_init(LineTune *t)
     t->spec_stagger = tune_env_f("PLF_LSD_SPEC_STAGGER", 0.2f);
     t->spec_nofuse = getenv("PLF_LSD_SPEC_NOFUSE") ? 1 : 0;
     t->spec_spins = std::max(64, tune_env_i("PLF_LSD_SPEC_SPINS", 1 << 21));
+    t->slow_factor = tune_env_f("PLF_LSD_SLOW_FACTOR", 10.f);
+    t->slow_floor_ms = tune_env_f("PLF_LSD_SLOW_FLOOR_MS", 20.f);
     { const int v = tune_env_i("PLF_LSD_SPEC_RECCAP", 8192); t->spec_reccap = (v >= 1 && v <= 8192) ? v : 8192; }
     t->wpg = std::max(1, std::min(16, tune_env_i("PLF_LSD_WPG", 8)));
     t->one_wave_groups = getenv("PLF_LSD_ONE_WAVE_GROUPS") ? 1 : 0;
@@ -187,6 +192,10 @@ struct plf_line {
     int32_t *retry_flags;      // [max_batch]
     int retry_status, retry_depth;
     bool retry_valid;
+    // PLF_W_SLOW: per-frame wall time (ms) of the last host-output calls at the current image size (ring), and whether the last call was flagged
+    float slow_hist[32];
+    int slow_n, slow_w, slow_h;
+    bool slow_last;
 };
 
 static void line_free(plf_line *h)
@@ -464,6 +473,8 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
         }
     if (!strcmp(name, "spec_fill_tol")) { t.spec_fill_tol = (float)value; return PLF_OK; }
     if (!strcmp(name, "spec_stagger")) { t.spec_stagger = (float)value; return PLF_OK; }
+    if (!strcmp(name, "slow_factor")) { if (value < 0) return PLF_E_BADARG; t.slow_factor = (float)value; return PLF_OK; }
+    if (!strcmp(name, "slow_floor_ms")) { if (value < 0) return PLF_E_BADARG; t.slow_floor_ms = (float)value; return PLF_OK; }
     return PLF_E_BADARG;
 }
 
@@ -755,7 +766,8 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
     PLF_HIP_TRY(hipSetDevice(h->device));
     int rc = line_configure(h, width, height);
     if (rc != PLF_OK) return rc;
-    if (h->retry_depth == 0) { h->retry_valid = false; h->retry_status = 0; }
+    if (h->retry_depth == 0) { h->retry_valid = false; h->retry_status = 0; h->slow_last = false; }
+    const auto t_call0 = std::chrono::steady_clock::now();
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // handle-owned scratch is ordered by the stream of the previous call: a call on another stream waits for it first (include/plf.h, "Streams")
     plf_order_begin(h->order, s);
@@ -865,6 +877,21 @@ extern "C" int plf_line_extract_batch(plf_line *h, const uint8_t *gray, int32_t 
         } else memset(h->retry_flags, 0, sizeof(int32_t) * n_frames);
     }
     if (status & 2) ret = PLF_E_CAPACITY;
+    // PLF_W_SLOW (include/plf.h): this call against the handle's own history at this image size.  Host-output calls only (they end with a synchronisation, so the
+    // wall time is the work's); pieces of a batch redone in halves and calls that ran out of max_ms do not enter the history.
+    if (host_out && h->retry_depth == 0 && !(status & 8)) {
+        const float ms = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count() / n_frames);
+        if (h->slow_w != width || h->slow_h != height) { h->slow_n = 0; h->slow_w = width; h->slow_h = height; }
+        const int have = std::min(h->slow_n, 32);
+        if (have >= 8 && h->tune.slow_factor > 0.f) {
+            float tmp[32];
+            memcpy(tmp, h->slow_hist, sizeof(float) * have);
+            std::nth_element(tmp, tmp + have / 2, tmp + have);
+            if (ms > h->tune.slow_factor * tmp[have / 2] && ms > h->tune.slow_floor_ms) { h->slow_last = true; if (ret == PLF_OK) ret = PLF_W_SLOW; }
+        }
+        h->slow_hist[h->slow_n % 32] = ms;
+        h->slow_n = h->slow_n < (1 << 30) ? h->slow_n + 1 : 32;   // (calls so far at this size: the ring's write index, and min(n, 32) its fill)
+    }
     return ret;
 }
 
@@ -881,7 +908,7 @@ extern "C" int plf_line_last_status(plf_line *h, void *stream)
     PLF_HIP_TRY(hipMemcpyAsync(&status, h->d_counters + 3 * (size_t)h->prm.max_batch, sizeof(int), hipMemcpyDeviceToHost, s));
     PLF_HIP_TRY(hipStreamSynchronize(s));
     if (h->retry_valid) status = (status & ~1) | h->retry_status;   // a batch redone in halves: the bits of all its pieces
-    return (status & 4) ? PLF_E_HIP : (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : (status & 8) ? PLF_W_TRUNCATED : PLF_OK;
+    return (status & 4) ? PLF_E_HIP : (status & 1) ? PLF_E_RECTS : (status & 2) ? PLF_E_CAPACITY : (status & 8) ? PLF_W_TRUNCATED : h->slow_last ? PLF_W_SLOW : PLF_OK;
 }
 
 // which frames of the last batch ran out of their time budget (plf_line_params.max_ms): flags[f] = 1 / 0

@@ -536,6 +536,39 @@ def test_one_handle_mixed_band_counts_and_batch_sizes():
     ls.close()
 
 
+def test_slow_frame_warning_outputs_complete():
+    """PLF_W_SLOW: a host-output call that takes far longer per frame than the handle's recent calls returns the warning -- the outputs are
+    complete and exact -- and plf_line_last_status repeats it until the next call.  History of cheap frames (flat images: nothing to grow), then a frame of blocky
+    noise (thousands of tiny regions); the thresholds are lowered through plf_line_tune so that the test does not need a frame that takes seconds.  With
+    slow_factor = 0 the same frame passes silently; a different image size starts a new history."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    import rgbd_pl_slam_amd._lib as L
+    ls = LineSegment(nlines=100, max_width=640, max_height=480)
+    ls.tune("slow_factor", 2.0); ls.tune("slow_floor_ms", 0.0)
+    flat = np.full((480, 640), 90, np.uint8)
+    for _ in range(10):
+        ls.ExtractLineSegment(flat)
+        assert L.last_warning == 0
+    rng = np.random.default_rng(3)
+    noisy = (rng.integers(0, 256, (480, 640)) // 64 * 64).astype(np.uint8)
+    ref = orc.line_extract(noisy, 100)
+    kl, ld, eq = ls.ExtractLineSegment(noisy)
+    assert L.last_warning == L.PLF_W_SLOW
+    assert ls.last_status() == L.PLF_W_SLOW
+    assert kl.tobytes() == ref["kl"].tobytes() and np.array_equal(ld, ref["desc"])   # complete and exact
+    ls.ExtractLineSegment(flat)
+    assert L.last_warning == 0 and ls.last_status() == 0
+    ls.tune("slow_factor", 0.0)
+    ls.ExtractLineSegment(noisy)
+    assert L.last_warning == 0
+    ls.tune("slow_factor", 2.0)
+    small = np.ascontiguousarray(noisy[:240, :320])
+    ls.ExtractLineSegment(small)   # first call at another size: no history, no warning
+    assert L.last_warning == 0
+    ls.close()
+
+
 def test_one_handle_alternating_image_sizes_rebuilds_the_nfa_table():
     """The table of NFA values (k_nfa_table) depends on the scaled image size (LOG_NT enters nfa_d's exit test): a handle that sees a different size must refill it.
     One handle, sizes 640x480 -> 320x240 -> 800x600 -> 640x480, single frames and a batch of 70 (the staged NFA kernels' hand-over), against the oracle."""
