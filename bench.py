@@ -410,11 +410,13 @@ def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml, rep
     elapsed_max = reduce_elapsed_max(dist, total)   # the job lasts as long as its slowest rank
     tm = bx.last_timing()
     aff = bx.worker_affinity(0)
+    per_worker = [{k: round(v, 4) for k, v in bx.worker_timing(i).items()} for i in range(bx.n_devices)]
     bx.close(); free_pinned(pin)
     mb = n_frames * w * h / 1e6
     return {"value": round(n_frames / best, 1), "unit": "frames/s", "frames": n_frames, "frames_in_flight": in_flight,
             "h2d_MBps": round(mb / best, 1), "worker_seconds": {k: round(v, 4) for k, v in tm.items()},
             "worker_numa_node": aff[0], "worker_cpus_bound": aff[1], "elapsed_max": elapsed_max,
+            "per_worker_seconds": per_worker,   # (staging = host memory bandwidth: on 8 GPUs 8 x 13 GB/s of H2D are 105 GB/s of host reads -- the number to watch)
             "what": "plf_batch_extract: %d host frames (pinned, %d distinct) -> key points, descriptors, lines and local-map matches in host memory, 1 GPU" % (n_frames, nd)}
 
 
@@ -484,6 +486,107 @@ def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
             "per_core": round(n / dt / threads, 3), "single_thread": single}
 
 
+def run_headline(args, dist, rank, local_rank, world, B, W, H, NFEAT, NLINES, label, make_pipe, timed_fn=None, reduce_device="cuda"):
+    """The headline step on this rank and, on rank 0, the JSON line without the N = 1 extras.  The job is world * B frames per step; this rank's block of it comes
+    from the product's partition (plf_batch_shard, contiguous blocks) and is always B frames: weak scaling.  make_pipe(nb) builds the device-resident pipeline
+    (tests/test_sharding.py passes a stub and runs the rank logic -- partition, barrier, MAX over the ranks, assembly -- with world 8 on gloo).
+    Returns (out or None, pipe, fps, elapsed, B)."""
+    import torch
+    from rgbd_pl_slam_amd.batch import shard
+    timed_fn = timed_fn or timed
+    lo, hi = shard(world * B, world, rank)
+    assert hi - lo == B and lo == rank * B
+    try:
+        pipe = make_pipe(B)
+    except Exception as e:   # (8192 frames in flight hold ~150 GB of the 288 GB: a GPU that cannot give them runs the 4096-frame workload, and says so)
+        if args.batch > 0 or B <= 4096 or world > 1:
+            raise
+        sys.stderr.write("bench.py: %d frames in flight could not be set up (%r); falling back to 4096\n" % (B, e))
+        torch.cuda.empty_cache()
+        B = 4096
+        pipe = make_pipe(B)
+    elapsed, reg_ms, reg_launches = timed_fn(pipe, args.steps, args.warmup, dist)
+    elapsed = reduce_elapsed_max(dist, elapsed, device=reduce_device)
+    frames = world * B * args.steps
+    fps = frames / elapsed
+    if rank != 0:
+        return None, pipe, fps, elapsed, B
+    b_orb, b_line, b_region = algorithmic_bytes(W, H, NFEAT, NLINES)
+    reg_avg_s = (reg_ms / max(reg_launches, 1)) * 1e-3
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected with rocprofv3 --pmc in
+    # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
+    traffic, traffic_source = None, None
+    try:
+        src = next((c for c in (os.path.join("profiles", "r%02d_pmc_traffic.json" % r) for r in (5, 4, 3)) if os.path.exists(os.path.join(ROOT, c))), None)
+        with open(os.path.join(ROOT, src)) as fh:
+            pmc = json.load(fh)
+        if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):
+            traffic = int(pmc["region_kernel"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
+            traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command at %d frames per launch, scaled to %d)" % (src, pmc["frames_per_launch"], B)
+    except Exception:
+        traffic = None
+    achieved = (b_region * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
+    # share of the step during which an average SIMD's vector issue port is taken: counted VALU instructions per kernel (rocprofv3 --pmc SQ_INSTS_VALU of this
+    # command, committed) x the issue interval of their class (2.2 / 4.2 / 8 / 16 cycles per SIMD, measured by tools/valu_issue.hip; mix per kernel from its ISA:
+    # tools/classify_isa.py) over 1024 SIMDs x clock x the step time measured here
+    valu_frac, valu_source = None, None
+    try:
+        vsrc = next(c for c in (os.path.join("profiles", "r%02d_valu_classes.json" % r) for r in (5, 4)) if os.path.exists(os.path.join(ROOT, c)))
+        with open(os.path.join(ROOT, vsrc)) as fh:
+            vc = json.load(fh)
+        if args.config == 2:
+            cyc = vc["valu_issue_simd_cycles_per_step"] * B / vc["frames_per_step"]
+            step_s = elapsed / args.steps
+            valu_frac = round(cyc / (vc["simds"] * vc["clock_hz"] * step_s), 3)
+            valu_source = ("%s: %.3g VALU wave-instructions per %d-frame step (SQ_INSTS_VALU), mean %.2f issue cycles each by class "
+                           "(tools/classify_isa.py; intervals from profiles/r03_valu_issue.json)" % (vsrc, vc["valu_wave_instructions_per_step"], vc["frames_per_step"],
+                                                                                                    vc["mean_cycles_per_valu"]))
+    except Exception:
+        valu_frac = None
+    out = {
+        "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d" % (W, H),
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/f64", "data": "synthetic (%d independently seeded %dx%d frames per GPU tiled to the batch, resident in HBM; per-frame poses change every step)" % (pipe.ndist, W, H),
+        "config": {"workload": label + "; matching per frame: SearchByProjection vs a %d-point local map + vs the last frame, line projection search vs %d map "
+                                       "lines + brute-force Hamming kNN (k = 2) of the LBD descriptors vs the last frame's lines" % (M_POINTS, M_LINES),
+                   "baseline_config": args.config, "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
+        "matches_frame0": pipe.matches_frame0(),
+        "pipeline_algorithmic_GBps": round(fps * (b_orb + b_line) / 1e9, 2),
+        "roofline": {"bound": "hbm", "kernel": "LSD region growing (k_lsd_regions2 / k_lsd_spec_* for few frames in flight)", "achieved": round(achieved, 3),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                     "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches, "algorithmic_bytes_per_launch": b_region * B,
+                     "valu_issue_frac": valu_frac, "valu_issue_source": valu_source},
+    }
+    out["frames_of_this_rank"] = [lo, hi]
+    # the whole path against the HBM roofline (SURVEY 8d: algorithmic bytes per frame x frames/s / 8 TB/s), and the ten heaviest kernels one by one: algorithmic bytes
+    # per launch (SURVEY 8d term), solo and overlapped duration (rocprofv3 --kernel-trace --stats of this command with --serial / as it is), counter traffic
+    # (--pmc FETCH_SIZE + WRITE_SIZE) -- collected by tools/per_kernel_roofline.py in separate passes of this command and committed
+    out["roofline"]["pipeline_frac"] = round(fps * (b_orb + b_line) / 1e9 / HBM_PEAK_GBS, 5)
+    try:
+        ksrc = next(c for c in (os.path.join("profiles", "r%02d_per_kernel.json" % r) for r in (6,)) if os.path.exists(os.path.join(ROOT, c)))
+        with open(os.path.join(ROOT, ksrc)) as fh:
+            pk = json.load(fh)
+        if args.config == 2 and (pk.get("width"), pk.get("height")) == (W, H):
+            out["roofline"]["per_kernel"] = pk["kernels"]
+            out["roofline"]["per_kernel_source"] = "%s (%d frames per launch)" % (ksrc, pk["frames_per_launch"])
+    except Exception:
+        pass
+    # vector-issue occupancy from COUNTERS (VERDICT r05 item 4): sum over the step's kernels of SQ_ACTIVE_INST_VALU (units of 4 cycles, one SIMD each) x 4 over
+    # 1024 SIMDs x the cycles of the step measured here; beside the modelled valu_issue_frac
+    try:
+        isrc = next(c for c in (os.path.join("profiles", "r%02d_issue_counters.json" % r) for r in (6,)) if os.path.exists(os.path.join(ROOT, c)))
+        with open(os.path.join(ROOT, isrc)) as fh:
+            ic = json.load(fh)
+        if args.config == 2:
+            quads = ic["active_inst_valu_per_step"] * B / ic["frames_per_step"]
+            out["roofline"]["valu_busy_frac"] = round(quads * 4.0 / (ic["simds"] * ic["clock_hz"] * (elapsed / args.steps)), 3)
+            out["roofline"]["valu_busy_source"] = "%s: sum of SQ_ACTIVE_INST_VALU over the kernels of one %d-frame step" % (isrc, ic["frames_per_step"])
+    except Exception:
+        pass
+    return out, pipe, fps, elapsed, B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -526,74 +629,12 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    # the job = world * B frames per step; this rank's block of it (contiguous, plf_batch_shard) -- always B frames: weak scaling
-    lo, hi = shard(world * B, world, rank)
-    assert hi - lo == B
     def make_pipe(nb):
         return Pipeline(W, H, NFEAT, NLINES, nb, local_rank, 10_000 * rank, serial=args.serial, line_handles=args.line_handles, front_wait=not args.no_front_wait,
                         defer_match=not args.no_defer_match, distinct=args.distinct, family=args.family)
-    try:
-        pipe = make_pipe(B)
-    except Exception as e:   # (8192 frames in flight hold ~150 GB of the 288 GB: a GPU that cannot give them runs the 4096-frame workload, and says so)
-        if args.batch > 0 or B <= 4096 or world > 1:
-            raise
-        sys.stderr.write("bench.py: %d frames in flight could not be set up (%r); falling back to 4096\n" % (B, e))
-        torch.cuda.empty_cache()
-        B = 4096
-        pipe = make_pipe(B)
-    elapsed, reg_ms, reg_launches = timed(pipe, args.steps, args.warmup, dist)
-    elapsed = reduce_elapsed_max(dist, elapsed)
-    frames = world * B * args.steps
-    fps = frames / elapsed
+    out, pipe, fps, elapsed, B = run_headline(args, dist, rank, local_rank, world, B, W, H, NFEAT, NLINES, label, make_pipe)
 
     if rank == 0:
-        b_orb, b_line, b_region = algorithmic_bytes(W, H, NFEAT, NLINES)
-        reg_avg_s = (reg_ms / max(reg_launches, 1)) * 1e-3
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected with rocprofv3 --pmc in
-        # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
-        traffic, traffic_source = None, None
-        try:
-            src = next((c for c in (os.path.join("profiles", "r%02d_pmc_traffic.json" % r) for r in (5, 4, 3)) if os.path.exists(os.path.join(ROOT, c))), None)
-            with open(os.path.join(ROOT, src)) as fh:
-                pmc = json.load(fh)
-            if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):
-                traffic = int(pmc["region_kernel"]["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
-                traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command at %d frames per launch, scaled to %d)" % (src, pmc["frames_per_launch"], B)
-        except Exception:
-            traffic = None
-        achieved = (b_region * B) / reg_avg_s / 1e9 if reg_avg_s > 0 else 0.0
-        # share of the step during which an average SIMD's vector issue port is taken: counted VALU instructions per kernel (rocprofv3 --pmc SQ_INSTS_VALU of this
-        # command, committed) x the issue interval of their class (2.2 / 4.2 / 8 / 16 cycles per SIMD, measured by tools/valu_issue.hip; mix per kernel from its ISA:
-        # tools/classify_isa.py) over 1024 SIMDs x clock x the step time measured here
-        valu_frac, valu_source = None, None
-        try:
-            vsrc = next(c for c in (os.path.join("profiles", "r%02d_valu_classes.json" % r) for r in (5, 4)) if os.path.exists(os.path.join(ROOT, c)))
-            with open(os.path.join(ROOT, vsrc)) as fh:
-                vc = json.load(fh)
-            if args.config == 2:
-                cyc = vc["valu_issue_simd_cycles_per_step"] * B / vc["frames_per_step"]
-                step_s = elapsed / args.steps
-                valu_frac = round(cyc / (vc["simds"] * vc["clock_hz"] * step_s), 3)
-                valu_source = ("%s: %.3g VALU wave-instructions per %d-frame step (SQ_INSTS_VALU), mean %.2f issue cycles each by class "
-                               "(tools/classify_isa.py; intervals from profiles/r03_valu_issue.json)" % (vsrc, vc["valu_wave_instructions_per_step"], vc["frames_per_step"],
-                                                                                                        vc["mean_cycles_per_valu"]))
-        except Exception:
-            valu_frac = None
-        out = {
-            "metric": "RGB-D frames/sec (ORB+LSD extract + BF-Hamming match) at %dx%d" % (W, H),
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/f64", "data": "synthetic (%d independently seeded %dx%d frames per GPU tiled to the batch, resident in HBM; per-frame poses change every step)" % (pipe.ndist, W, H),
-            "config": {"workload": label + "; matching per frame: SearchByProjection vs a %d-point local map + vs the last frame, line projection search vs %d map "
-                                           "lines + brute-force Hamming kNN (k = 2) of the LBD descriptors vs the last frame's lines" % (M_POINTS, M_LINES),
-                       "baseline_config": args.config, "frames_in_flight_per_gpu": B, "parallelism": "frames sharded over %d GPU(s) by contiguous blocks, no collective" % world},
-            "matches_frame0": pipe.matches_frame0(),
-            "pipeline_algorithmic_GBps": round(fps * (b_orb + b_line) / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": "LSD region growing (k_lsd_regions2 / k_lsd_spec_* for few frames in flight)", "achieved": round(achieved, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                         "avg_launch_ms": round(reg_avg_s * 1e3, 3), "launches": reg_launches, "algorithmic_bytes_per_launch": b_region * B,
-                         "valu_issue_frac": valu_frac, "valu_issue_source": valu_source},
-        }
         if world > 1:
             out["extras"] = "skipped: tiled32 / fps_vs_in_flight / config3_as_specified / single_frame_latency / natural / pcie_inclusive / cpu_baseline are N = 1 figures"
         out["region_chain_length"] = pipe.chain_stats()

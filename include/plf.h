@@ -626,6 +626,9 @@ int64_t plf_batch_truncated_frames(const plf_batch *b);
 /* Seconds the workers of the last plf_batch_extract spent (max over workers): [0] total, [1] staging copies into pinned
  * memory, [2] waiting for the GPU, [3] unpacking outputs. */
 int plf_batch_last_timing(const plf_batch *b, double *out4);
+/* The same four figures of ONE worker (= GPU devices[worker]) for the last plf_batch_extract: on an 8-GPU host the first thing to look at when the frames/s do not
+ * scale -- staging (host memory bandwidth: every worker copies its frames into its own pinned slots) against gpu_wait. */
+int plf_batch_worker_timing(const plf_batch *b, int32_t worker, double *out4);
 /* Where worker `worker` (= GPU devices[worker]) runs: the NUMA node of its GPU (-1: unknown / single node) and the number of CPUs its thread was bound to before it
  * allocated its pinned staging slots (0: not bound -- no sysfs view, or PLF_BATCH_NO_AFFINITY=1).  Eight GPUs on a two-socket host: every worker reads its
  * images through its own socket's memory controllers. */

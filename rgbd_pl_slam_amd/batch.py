@@ -213,3 +213,9 @@ class BatchExtractor:
         t = (C.c_double * 4)()
         L.check(L.lib().plf_batch_last_timing(self._h, t), "plf_batch_last_timing")
         return dict(total=t[0], staging=t[1], gpu_wait=t[2], unpack=t[3])
+
+    def worker_timing(self, worker):
+        """seconds worker `worker` (= GPU devices[worker]) spent in the last extract: total, staging copies, waiting for its GPU, unpacking outputs"""
+        t = (C.c_double * 4)()
+        L.check(L.lib().plf_batch_worker_timing(self._h, int(worker), t), "plf_batch_worker_timing")
+        return dict(total=t[0], staging=t[1], gpu_wait=t[2], unpack=t[3])

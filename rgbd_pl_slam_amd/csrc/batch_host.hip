@@ -871,6 +871,14 @@ extern "C" int plf_batch_worker_affinity(const plf_batch *b, int32_t worker, int
     return PLF_OK;
 }
 
+extern "C" int plf_batch_worker_timing(const plf_batch *b, int32_t worker, double *out4)
+{
+    if (!b || !out4 || worker < 0 || worker >= (int32_t)b->workers.size()) return PLF_E_BADARG;
+    const Worker *w = b->workers[worker];
+    out4[0] = w->t_total; out4[1] = w->t_stage; out4[2] = w->t_wait; out4[3] = w->t_unpack;
+    return PLF_OK;
+}
+
 extern "C" int plf_batch_last_timing(const plf_batch *b, double *out4)
 {
     if (!b || !out4) return PLF_E_BADARG;

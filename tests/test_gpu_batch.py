@@ -285,6 +285,42 @@ def test_two_workers_on_one_gpu_37_vga_frames_with_local_map():
     bx.close()
 
 
+def test_eight_workers_config4_exactly_as_specified():
+    """BASELINE configs[3] exactly as written: batch 64 of 1280x960 frames, 4000 ORB + 400 lines, sharded over EIGHT workers -- eight NUMA-bound
+    threads, eight sets of pinned slots, eight stream sets -- with 8 frames in flight each; without an 8-GPU node all eight drive device 0.  Every worker must get
+    plf_batch_shard(64, 8, r) = 8 frames; a sample of frames from every worker against the oracle, the rest against the frames that repeat them."""
+    _need_gpu()
+    from rgbd_pl_slam_amd.batch import BatchExtractor, shard
+    from rgbd_pl_slam_amd.synth import synth_frame
+    distinct = [synth_frame(2300 + i, 1280, 960) for i in range(16)]
+    order = [(5 * i) % 16 for i in range(64)]                 # every worker's block holds 8 different images
+    imgs = np.stack([distinct[k] for k in order])
+    bx = BatchExtractor(nfeatures=4000, nlines=400, width=1280, height=960, frames_in_flight=8, devices=[0] * 8)
+    assert bx.n_devices == 8 and [shard(64, 8, r) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    res = bx.extract(imgs)
+    refs = {}
+    for f in list(range(0, 64, 9)) + [7, 8, 63]:              # frames 0, 9, 18, ...: one or two per worker, both ends of a block
+        k = order[f]
+        if k not in refs:
+            refs[k] = (orc.orb_extract(distinct[k], nfeatures=4000), orc.line_extract(distinct[k], 400))
+        _same_orb(res[f], refs[k][0], "frame %d" % f)
+        _same_lines(res[f], refs[k][1], "frame %d" % f)
+    first = {}
+    for f in range(64):                                        # every frame equals the first frame that carried the same image (different workers, different slots)
+        k = order[f]
+        if k in first:
+            g = res[first[k]]
+            assert res[f]["kps"].tobytes() == g["kps"].tobytes() and np.array_equal(res[f]["desc"], g["desc"]), f
+            assert res[f]["lines"].tobytes() == g["lines"].tobytes() and np.array_equal(res[f]["ldesc"], g["ldesc"]), f
+        else:
+            first[k] = f
+    tms = [bx.worker_timing(w) for w in range(8)]
+    assert all(t["total"] > 0 and t["gpu_wait"] >= 0 for t in tms)
+    tot = bx.last_timing()
+    assert tot["total"] == max(t["total"] for t in tms)
+    bx.close()
+
+
 def test_four_workers_on_one_gpu_config4_shape():
     """BASELINE configs[3] shape (1280x960, 4000 ORB + 400 lines) on FOUR workers (devices = [0, 0, 0, 0]): 16 frames = 4 per worker, 2 in flight, so every
     worker pipelines two chunks through both slots while three others compete for the GPU"""

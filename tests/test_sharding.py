@@ -135,3 +135,64 @@ def test_pcie_line_and_reduction_single_rank():
     W, H, NFEAT, NLINES, B0, label = bench.CONFIGS[2]
     line = bench.pcie_line({"value": 1.0, "elapsed_max": 4.0}, 4.0, 1, 16384, 4096, 2, 1, W, H, label, 2)
     assert line["value"] == round(16384 * 2 / 4.0, 2) and line["n_gpus"] == 1 and "elapsed_max" not in line["pcie"]["rank0"]
+
+
+class _StubPipe:
+    """what bench.run_headline touches of bench.Pipeline -- the rank logic (partition, barrier, MAX over the ranks, JSON assembly) runs unchanged without a GPU"""
+    def __init__(self, nb):
+        self.nb = nb; self.ndist = nb
+    def matches_frame0(self):
+        return {"points_map": 0}
+    def close(self):
+        pass
+
+
+def _headline_worker(rank, world, port, q):
+    """`bench.py --gpus 8 --config 4` (BASELINE configs[3]: 64 frames of 1280x960 over 8 GPUs) on gloo: every rank must get shard(64, 8, r) = 8 frames, the job lasts as
+    long as the slowest rank, rank 0 assembles the line"""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    made = []
+
+    def make_pipe(nb):
+        made.append(nb)
+        return _StubPipe(nb)
+
+    def stub_timed(pipe, steps, warmup, d):
+        d.barrier()
+        return 0.5 + 0.25 * rank, 10.0 * steps, steps      # rank 7 is the slowest: 2.25 s for the 5 steps
+
+    args = argparse.Namespace(steps=5, warmup=1, config=4, batch=0)
+    W, H, NFEAT, NLINES, B0, label = bench.CONFIGS[4]
+    out, pipe, fps, elapsed, B = bench.run_headline(args, dist, rank, rank, world, B0, W, H, NFEAT, NLINES, label, make_pipe, timed_fn=stub_timed, reduce_device="cpu")
+    q.put((rank, out, made, B, elapsed, tuple(shard(world * B0, world, rank))))
+    dist.destroy_process_group()
+
+
+def test_world8_config4_headline_sharding_and_line():
+    """configs[3] exactly as written -- batch 64 over 8 GPUs, 8 frames each -- through bench.py's own rank logic (world 8 on gloo)"""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_headline_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=300) for _ in range(8))}
+    for p in ps:
+        p.join(timeout=60)
+    for r in range(8):
+        rank, out, made, B, elapsed, blk = res[r]
+        assert made == [8] and B == 8 and blk == (8 * r, 8 * r + 8)          # 64 frames, 8 contiguous per rank
+        assert elapsed == 0.5 + 0.25 * 7                                      # MAX over the ranks
+        assert (out is None) == (r != 0)                                      # only rank 0 assembles the line
+    line = res[0][1]
+    json.dumps(line)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["steps"] == 5 and line["frames_of_this_rank"] == [0, 8]
+    assert line["value"] == round(8 * 8 * 5 / 2.25, 2) and line["ms_per_step"] == 450.0
+    assert line["config"]["baseline_config"] == 4 and line["config"]["frames_in_flight_per_gpu"] == 8 and "1280x960" in line["metric"]
+    assert line["roofline"]["avg_launch_ms"] == 10.0 and 0 < line["roofline"]["pipeline_frac"] < 1
