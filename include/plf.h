@@ -147,7 +147,7 @@ void plf_line_destroy(plf_line *h);
 /* Schedule knobs of a line-extractor handle (frames-in-flight thresholds of its schedules, band counts ...).  They are read from the environment ONCE, when the handle
  * is created (PLF_LSD_*, PLF_NFA_FUSED: experiments), and never again; this call changes one of them afterwards -- a tuning and test hook, not needed in production:
  * "spec_max" (frames in flight up to which the banded speculative schedule is used, 640), "spec_bands", "spec_z", "spec_rounds", "spec_halo", "spec_clip", "spec_fill",
- * "spec_fill_tol", "spec_stagger", "spec_nofuse", "spec_spins", "spec_reccap", "lat_max", "wpg", "one_wave_groups", "slow_factor", "slow_floor_ms" (PLF_W_SLOW), "nfa_fused" (frames in flight up to which one wave per
+ * "spec_fill_tol", "spec_stagger", "spec_nofuse", "spec_spins", "spec_reccap", "lat_max", "wpg", "slow_factor", "slow_floor_ms" (PLF_W_SLOW), "nfa_fused" (frames in flight up to which one wave per
  * rectangle runs all NFA stages, 64).  Every schedule gives the same bits.  PLF_E_BADARG for an unknown name or a value out of range. */
 int plf_line_tune(plf_line *h, const char *name, double value);
 

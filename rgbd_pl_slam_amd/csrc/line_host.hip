@@ -15,11 +15,9 @@
 __global__ void k_lsd_pre(const uint8_t *, ptrdiff_t, ptrdiff_t, float *, double *, double2 *, float2 *, LsdGeom, LsdTaps, const int *, const float2 *,
                           const int *, const float2 *, int *);
 __global__ void k_lsd_balance(const int *, int *, int, int);
-__global__ void k_lsd_regions(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
 __global__ void k_lsd_regions2(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int, const int *);
 __global__ void k_lsd_regions_lat(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
 // the same kernels with the time budget of plf_line_params.max_ms compiled in (separate instances: the default ones read no clock)
-__global__ void k_lsd_regions_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *);
 __global__ void k_lsd_regions2_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int, const int *);
 __global__ void k_lsd_regions_lat_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, const uint32_t *, int *);
 __global__ void k_lsd_spec_fused_budget(float *, const double *, const double2 *, const float2 *, uint32_t *, LsdRect *, int *, int *, LsdGeom, SpecBufs, int *, int);
@@ -40,7 +38,6 @@ __global__ void k_nfa_count_w(const float *, const NfaEntry *, const int *, int,
 __global__ void k_nfa_count1_w(const float *, const NfaEntry *, const int *, int, int, NfaCounts *, LsdGeom);
 __global__ void k_nfa_eval(int, const double *, const double *, const NfaCounts *, const NfaEntry *, const int *, double *, LsdGeom);
 __global__ void k_nfa_table(double *, const double *, double);
-__global__ void k_nfa_fused_list(const float *, const double *, const NfaState *, const int *, uint8_t *, float4 *, LsdGeom);
 __global__ void k_nfa_small(const float *, const double *, const LsdRect *, const int *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int, NfaState *, int *, int);
 __global__ void k_nfa_small2(const float *, const double *, const LsdRect *, uint8_t *, float4 *, NfaEntry *, NfaState *, int *, int *, LsdGeom, int, const NfaState *, const int *, int);
 __global__ void k_nfa_math(int, const double *, const NfaEntry *, const NfaState *, NfaState *, NfaEntry *, int *, float4 *, uint8_t *, LsdGeom);
@@ -81,13 +78,10 @@ struct LineTune {
     int spec_spins;       // PLF_LSD_SPEC_SPINS   polls without a heartbeat before the commit wave gives up (test hook)
     int spec_reccap;      // PLF_LSD_SPEC_RECCAP  records per band log (test hook: forces the overflow path)
     int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (8)
-    int one_wave_groups;  // PLF_LSD_ONE_WAVE_GROUPS  one frame per workgroup for large batches too
     int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
     int nfa_small;        // PLF_NFA_SMALL        2: rect_improve of the rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle; 1: only for more
                           //                      than nfa_fused frames in flight (one frame: 4.41 ms with it, 4.63 ms with k_nfa_fused); 0: off
     int nfa_two_pass;     // PLF_NFA_TWO_PASS     1: above nfa_fused frames in flight k_nfa_small only runs stage 0 and queues the undecided rectangles for k_nfa_small2 (stages 1-4)
-    int nfa_list;         // PLF_NFA_LIST         1: the rectangles k_nfa_small hands over take one wave each, all stages in one launch (k_nfa_fused_list: 3 NFA launches per
-                          //                      batch instead of 17, but 17 ms instead of 9.5 per 8192 VGA frames); 0: the staged kernels
     int nfa_table;        // PLF_NFA_TABLE        1: NFA values of rectangles of fewer than 512 pixels come from the per-image-size table (k_nfa_table)
     int balance;          // PLF_LSD_BALANCE      1: large batches -- the frames are dealt to the waves of k_lsd_regions2 by chain length (k_lsd_balance); 0: in batch order
     float slow_factor;    // PLF_LSD_SLOW_FACTOR  PLF_W_SLOW: a host-output call that takes more than this many times the median per-frame time of the recent calls (10; 0: off)
@@ -113,11 +107,9 @@ static void line_tune_init(LineTune *t)
     t->slow_floor_ms = tune_env_f("PLF_LSD_SLOW_FLOOR_MS", 20.f);
     { const int v = tune_env_i("PLF_LSD_SPEC_RECCAP", 8192); t->spec_reccap = (v >= 1 && v <= 8192) ? v : 8192; }
     t->wpg = std::max(1, std::min(16, tune_env_i("PLF_LSD_WPG", 8)));
-    t->one_wave_groups = getenv("PLF_LSD_ONE_WAVE_GROUPS") ? 1 : 0;
     t->nfa_fused = tune_env_i("PLF_NFA_FUSED", 64);
     t->nfa_table = tune_env_i("PLF_NFA_TABLE", 1);
     t->nfa_small = tune_env_i("PLF_NFA_SMALL", 2);
-    t->nfa_list = tune_env_i("PLF_NFA_LIST", 0);
     t->nfa_two_pass = tune_env_i("PLF_NFA_TWO_PASS", 1);
     t->balance = tune_env_i("PLF_LSD_BALANCE", 1);
 }
@@ -425,7 +417,6 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     ALLOC(h->d_yofs, sizeof(int) * (size_t)g.sh); ALLOC(h->d_yb, sizeof(float2) * (size_t)g.sh);
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { line_free(h); free(h); return PLF_E_HIP; }
-    (void)hipFuncSetAttribute((const void *)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_grow, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -433,7 +424,6 @@ extern "C" int plf_line_create(const plf_line_params *p, plf_line **out)
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_validate, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit_rest, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_lsd_regions_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_regions_lat_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_grow_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lsd_spec_commit_budget, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -458,7 +448,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
     const int v = (int)value;
     struct { const char *n; int *p; } ints[] = {{"lat_max", &t.lat_max}, {"spec_bands", &t.spec_bands}, {"spec_max", &t.spec_max}, {"spec_z", &t.spec_z},
         {"spec_rounds", &t.spec_rounds}, {"spec_halo", &t.spec_halo}, {"spec_fill", &t.spec_fill}, {"spec_clip", &t.spec_clip}, {"spec_nofuse", &t.spec_nofuse},
-        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"one_wave_groups", &t.one_wave_groups}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_list", &t.nfa_list}, {"nfa_two_pass", &t.nfa_two_pass}, {"balance", &t.balance}};
+        {"spec_spins", &t.spec_spins}, {"spec_reccap", &t.spec_reccap}, {"wpg", &t.wpg}, {"nfa_fused", &t.nfa_fused}, {"nfa_table", &t.nfa_table}, {"nfa_small", &t.nfa_small}, {"nfa_two_pass", &t.nfa_two_pass}, {"balance", &t.balance}};
     for (auto &e : ints)
         if (!strcmp(name, e.n)) {
             if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
@@ -466,7 +456,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
             if (!strcmp(name, "spec_spins") && v < 64) return PLF_E_BADARG;
             if (!strcmp(name, "wpg") && (v < 1 || v > 16)) return PLF_E_BADARG;
             if (!strcmp(name, "spec_bands") && v != PLF_TUNE_AUTO && (v < 0 || v > 64)) return PLF_E_BADARG;   // (0 / 1: speculation off; the call clamps to what the frame allows)
-            if ((!strcmp(name, "nfa_small") && (v < 0 || v > 2)) || ((!strcmp(name, "nfa_table") || !strcmp(name, "nfa_list") || !strcmp(name, "nfa_two_pass") || !strcmp(name, "balance")) && (v < 0 || v > 1)))
+            if ((!strcmp(name, "nfa_small") && (v < 0 || v > 2)) || ((!strcmp(name, "nfa_table") || !strcmp(name, "nfa_two_pass") || !strcmp(name, "balance")) && (v < 0 || v > 1)))
                 return PLF_E_BADARG;
             *e.p = v;
             return PLF_OK;
@@ -496,7 +486,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     (void)nfail_unused;
     PLF_HIP_TRY(hipMemsetAsync(status, 0, (16 + MB) * sizeof(int), s));
     // large batches (the one-wave-per-frame kernel k_lsd_regions2): the frames are dealt to its waves by chain length = defined pixels, counted by k_lsd_pre
-    const bool balance = h->tune.balance && B > h->tune.spec_max && B > h->tune.lat_max && !h->tune.one_wave_groups && B <= 65536 && h->prm.seed_order == 0;
+    const bool balance = h->tune.balance && B > h->tune.spec_max && B > h->tune.lat_max && B <= 65536 && h->prm.seed_order == 0;
     int *d_cost = balance ? h->d_balance : nullptr, *d_perm = balance ? h->d_balance + h->prm.max_batch + 16 : nullptr;
     if (balance) PLF_HIP_TRY(hipMemsetAsync(d_cost, 0, (size_t)B * sizeof(int), s));
     // (bitmap of the static singles: k_lsd_pre writes whole words when the scaled rows are multiples of 32 pixels, and ORs into a cleared map otherwise)
@@ -683,15 +673,12 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     } else if (B <= lat_max)
         hipLaunchKernelGGL(budget ? k_lsd_regions_lat_budget : k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
-    else if (!T.one_wave_groups) {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
+    else {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
         const int wpg = T.wpg;
         const size_t wave_lds = PLF_LSD_WAVE_LDS;
         hipLaunchKernelGGL(budget ? k_lsd_regions2_budget : k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B, balance ? d_perm : nullptr);
     }
-    else
-        hipLaunchKernelGGL(budget ? k_lsd_regions_budget : k_lsd_regions, dim3(B), dim3(64), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
-                           h->d_rects, nrect, status, g, seeds);
     if (prof) { (void)hipEventRecord(h->prof_ev[2 * h->prof_n + 1], s); h->prof_n++; }
     // rect_improve.  Few frames in flight: one wave per rectangle runs all five stages (k_nfa_fused: a rectangle only waits for itself); otherwise the staged
     // kernels: first evaluation + 5 search stages, each = (wave-parallel pixel count, lane-parallel NFA math) over work lists compacted over the batch
@@ -721,10 +708,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         else
             hipLaunchKernelGGL(k_nfa_init, dim3(g.rect_cap < 4096 ? (g.rect_cap + 255) / 256 : 16, B), dim3(256), 0, s, h->d_rects, nrect, h->d_keep, h->d_ent[0], h->d_st[0],
                                h->d_nfa_counters, status, g);
-        if (small_first && T.nfa_list) {
-            // the queued rectangles (a few per frame): one wave each, all stages (2 waves per SIMD by registers: 2048 persistent waves)
-            hipLaunchKernelGGL(k_nfa_fused_list, dim3(2048), dim3(64), 0, s, h->d_ang, h->d_lgam, h->d_st[0], h->d_nfa_counters, h->d_keep, h->d_seg, g);
-        } else {
+        {
             hipLaunchKernelGGL(k_nfa_clamp, dim3(1), dim3(1), 0, s, h->d_nfa_counters, status, g);
 #ifndef PLF_NFA_COUNT_WAVES
 #define PLF_NFA_COUNT_WAVES (256 * 64)   // persistent waves of k_nfa_count: 16 per SIMD offered (occupancy by VGPRs: 8); the kernel is HBM-latency bound

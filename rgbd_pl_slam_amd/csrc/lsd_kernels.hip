@@ -1277,21 +1277,6 @@ __device__ __forceinline__ void regions_body(float *__restrict__ ang_all, const 
     if (BUDGET && truncated && lane == 0) { atomicOr(status, 8); status[16 + f] = 1; }
 }
 
-__global__ void __launch_bounds__(64) k_lsd_regions(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
-                                                    const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
-                                                    uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                                    int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
-{
-    regions_body<0, 1, false>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
-}
-__global__ void __launch_bounds__(64) k_lsd_regions_budget(float *__restrict__ ang_all, const double *__restrict__ modgrad_all,
-                                                           const double2 *__restrict__ cs_all, const float2 *__restrict__ cs0_all,
-                                                           uint32_t *__restrict__ rxy_all, LsdRect *__restrict__ rects_all, int *__restrict__ nrect,
-                                                           int *__restrict__ status, LsdGeom g, const uint32_t *__restrict__ seeds_all)
-{
-    regions_body<0, 1, true>(ang_all, modgrad_all, cs_all, cs0_all, rxy_all, rects_all, nrect, status, g, seeds_all, 0);
-}
-
 // Which frame goes to which wave of k_lsd_regions2 (round 5).  All waves of the launch are resident at once -- 8 per SIMD: waves v and v + 4 of each of the CU's four
 // workgroups (tools/wave_placement.hip reads HW_ID of this launch shape) -- and the launch lasts until the slowest SIMD has worked off its 8 chains.  In batch order
 // the sums of the chain lengths of a workgroup differ by 5 % (polygon scenes) to 30 % (natural-image-like frames) from the mean.  Here the frames are sorted by cost
@@ -3811,18 +3796,5 @@ __global__ void __launch_bounds__(64) k_nfa_fused(const float *__restrict__ ang_
         st.rec = rects_all[(size_t)f * g.rect_cap + ri]; st.log_nfa = -1; st.frame = f; st.rect = ri;
         if (lane == 0) keep_all[(size_t)f * g.rect_cap + ri] = 0;
         nfa_fused_rect(ang, lgam, nfatab, tab, st, keep_all, seg_all, g);
-    }
-}
-
-// the same for the rectangles k_nfa_small handed over (the stage-0 work list; the few per frame that have 512 pixels or more): persistent waves over the list
-__global__ void __launch_bounds__(64) k_nfa_fused_list(const float *__restrict__ ang_all, const double *__restrict__ lgam, const NfaState *__restrict__ states,
-                                                       const int *__restrict__ counters, uint8_t *__restrict__ keep_all, float4 *__restrict__ seg_all, LsdGeom g)
-{
-    __shared__ double tab_s[6 * NFA_COOP_BLK];
-    LDS_PTR(double) tab = (LDS_PTR(double))tab_s;
-    const int n = min(counters[0], g.nfa_pool);   // (a fuller list: k_nfa_small has set the status bit)
-    for (int q = blockIdx.x; q < n; q += gridDim.x) {
-        NfaState st = states[q];
-        nfa_fused_rect(ang_all + (size_t)st.frame * g.s_stride, lgam, nullptr, tab, st, keep_all, seg_all, g);
     }
 }

@@ -536,6 +536,28 @@ def test_one_handle_mixed_band_counts_and_batch_sizes():
     ls.close()
 
 
+@pytest.mark.parametrize("knobs,B", [({"nfa_small": 0}, 3), ({"nfa_table": 0}, 2), ({"nfa_small": 1}, 5), ({"nfa_two_pass": 0, "nfa_fused": 4}, 9), ({"nfa_small": 1, "nfa_fused": 2}, 6)],
+                         ids=["fused_with_table", "fused_no_table", "small_only_above_fused", "small_single_pass_plus_staged", "small_above_fused_two_pass"])
+def test_lines_nfa_schedules(knobs, B):
+    """Every NFA (rect_improve) schedule reachable through plf_line_tune gives the same bits (kernel index): k_nfa_fused (one wave per rectangle,
+    with and without the value table), k_nfa_small in one pass followed by the staged kernels, k_nfa_small + k_nfa_small2 on a small batch.  The defaults are covered
+    by every other test."""
+    _need_gpu()
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
+    imgs = [synth_frame(8700 + i) if i % 2 == 0 else natural_frame(8700 + i) for i in range(B)]
+    refs = [orc.line_extract(im, 100) for im in imgs]
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
+    for k, v in knobs.items():
+        ls.tune(k, v)
+    res = ls.extract_batch(np.stack(imgs))
+    for f in range(B):
+        assert res[f][0].tobytes() == refs[f]["kl"].tobytes() and np.array_equal(res[f][1], refs[f]["desc"]), (knobs, f)
+    kl, ld, eq = ls.ExtractLineSegment(imgs[0])
+    assert kl.tobytes() == refs[0]["kl"].tobytes() and np.array_equal(ld, refs[0]["desc"])
+    ls.close()
+
+
 def test_slow_frame_warning_outputs_complete():
     """PLF_W_SLOW: a host-output call that takes far longer per frame than the handle's recent calls returns the warning -- the outputs are
     complete and exact -- and plf_line_last_status repeats it until the next call.  History of cheap frames (flat images: nothing to grow), then a frame of blocky
