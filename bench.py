@@ -517,7 +517,7 @@ def run_headline(args, dist, rank, local_rank, world, B, W, H, NFEAT, NLINES, la
     # separate passes on this very command (tools/pmc_traffic.py) and committed; scaled here to this run's batch
     traffic, traffic_source = None, None
     try:
-        src = next((c for c in (os.path.join("profiles", "r%02d_pmc_traffic.json" % r) for r in (5, 4, 3)) if os.path.exists(os.path.join(ROOT, c))), None)
+        src = next((c for c in (os.path.join("profiles", "r%02d_pmc_traffic.json" % r) for r in (6, 5, 4, 3)) if os.path.exists(os.path.join(ROOT, c))), None)
         with open(os.path.join(ROOT, src)) as fh:
             pmc = json.load(fh)
         if (pmc.get("width"), pmc.get("height")) in ((W, H), (None, None)):
@@ -531,7 +531,7 @@ def run_headline(args, dist, rank, local_rank, world, B, W, H, NFEAT, NLINES, la
     # tools/classify_isa.py) over 1024 SIMDs x clock x the step time measured here
     valu_frac, valu_source = None, None
     try:
-        vsrc = next(c for c in (os.path.join("profiles", "r%02d_valu_classes.json" % r) for r in (5, 4)) if os.path.exists(os.path.join(ROOT, c)))
+        vsrc = next(c for c in (os.path.join("profiles", "r%02d_valu_classes.json" % r) for r in (6, 5, 4)) if os.path.exists(os.path.join(ROOT, c)))
         with open(os.path.join(ROOT, vsrc)) as fh:
             vc = json.load(fh)
         if args.config == 2:
