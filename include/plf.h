@@ -146,7 +146,7 @@ int plf_line_create(const plf_line_params *params, plf_line **out);
 void plf_line_destroy(plf_line *h);
 /* Schedule knobs of a line-extractor handle (frames-in-flight thresholds of its schedules, band counts ...).  They are read from the environment ONCE, when the handle
  * is created (PLF_LSD_*, PLF_NFA_FUSED: experiments), and never again; this call changes one of them afterwards -- a tuning and test hook, not needed in production:
- * "spec_max" (frames in flight up to which the banded speculative schedule is used, 640), "spec_bands", "spec_z", "spec_rounds", "spec_halo", "spec_clip", "spec_fill",
+ * "spec_max" (frames in flight up to which the banded speculative schedule is used, 256), "spec_bands", "spec_z", "spec_rounds", "spec_halo", "spec_clip", "spec_fill",
  * "spec_fill_tol", "spec_stagger", "spec_nofuse", "spec_spins", "spec_reccap", "lat_max", "wpg", "slow_factor", "slow_floor_ms" (PLF_W_SLOW), "nfa_fused" (frames in flight up to which one wave per
  * rectangle runs all NFA stages, 64).  Every schedule gives the same bits.  PLF_E_BADARG for an unknown name or a value out of range. */
 int plf_line_tune(plf_line *h, const char *name, double value);
@@ -174,7 +174,7 @@ int plf_line_last_status(plf_line *h, void *stream);
 /* flags[f] = 1 if frame f of the last batch ran out of plf_line_params.max_ms (waits for the stream of that call) */
 int plf_line_truncated(plf_line *h, int32_t *flags, int32_t n);
 
-/* Diagnostics of the banded speculative region growing used for <= 640 frames in flight, frame 0 of the last batch:
+/* Diagnostics of the banded speculative region growing used for <= 256 frames in flight, frame 0 of the last batch:
  * out8 = {regions committed from the speculation, regions grown by the commit wave, chunks committed in one step, records checked pixel by pixel,
  * kilo-cycles spent regrowing, validating, in total, in per-band setup}.  PLF_E_BADARG if the path has not run on this handle. */
 int plf_line_debug_spec_stats(plf_line *h, int32_t *out8);

@@ -66,8 +66,8 @@ __global__ void k_lsd_spec_assemble(LsdRect *, int *, int *, LsdGeom, SpecBufs, 
 struct LineTune {
     int lat_max;          // PLF_LSD_LAT_MAX      frames in flight up to which the latency kernel (one frame per workgroup + L2 warm-up waves) is used when speculation is off
     int spec_bands;       // PLF_LSD_SPEC_BANDS   row bands of the speculative schedule (AUTO: 48 / 32 / 16 / 8 / 4 / 2 by frames in flight)
-    int spec_max;         // PLF_LSD_SPEC_MAX     frames in flight up to which the speculative schedule is used (640; 0 = never)
-    int spec_z;           // PLF_LSD_SPEC_Z       ... up to which the validation rounds replace the serial commit wave (16)
+    int spec_max;         // PLF_LSD_SPEC_MAX     frames in flight up to which the speculative schedule is used (256; 0 = never)
+    int spec_z;           // PLF_LSD_SPEC_Z       ... up to which the validation rounds replace the serial commit wave (256: round 6, mid-range batches)
     int spec_rounds;      // PLF_LSD_SPEC_ROUNDS  validation rounds enqueued (12)
     int spec_halo;        // PLF_LSD_SPEC_HALO    warm-up rows above a band (AUTO: 4 with validation rounds, 16 otherwise)
     int spec_fill;        // PLF_LSD_SPEC_FILL    rows of the no-growth guess instead of warm-up growth (0 = off)
@@ -77,7 +77,7 @@ struct LineTune {
     int spec_nofuse;      // PLF_LSD_SPEC_NOFUSE  never the one-launch schedule
     int spec_spins;       // PLF_LSD_SPEC_SPINS   polls without a heartbeat before the commit wave gives up (test hook)
     int spec_reccap;      // PLF_LSD_SPEC_RECCAP  records per band log (test hook: forces the overflow path)
-    int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (8)
+    int wpg;              // PLF_LSD_WPG          frames (= waves) per workgroup of the large-batch region kernel (AUTO: 2 up to 768 frames in flight, 4 up to 1536, else 8)
     int nfa_fused;        // PLF_NFA_FUSED        frames in flight up to which one wave per rectangle runs all NFA stages (64)
     int nfa_small;        // PLF_NFA_SMALL        2: rect_improve of the rectangles the table covers in one launch (k_nfa_small), 16 lanes per rectangle; 1: only for more
                           //                      than nfa_fused frames in flight (one frame: 4.41 ms with it, 4.63 ms with k_nfa_fused); 0: off
@@ -93,8 +93,8 @@ static void line_tune_init(LineTune *t)
 {
     t->lat_max = tune_env_i("PLF_LSD_LAT_MAX", 8);
     t->spec_bands = tune_env_i("PLF_LSD_SPEC_BANDS", PLF_TUNE_AUTO);
-    t->spec_max = tune_env_i("PLF_LSD_SPEC_MAX", 640);
-    t->spec_z = tune_env_i("PLF_LSD_SPEC_Z", 16);
+    t->spec_max = tune_env_i("PLF_LSD_SPEC_MAX", 256);
+    t->spec_z = tune_env_i("PLF_LSD_SPEC_Z", 256);
     t->spec_rounds = std::max(1, std::min(64, tune_env_i("PLF_LSD_SPEC_ROUNDS", 12)));
     t->spec_halo = tune_env_i("PLF_LSD_SPEC_HALO", PLF_TUNE_AUTO);
     t->spec_fill = tune_env_i("PLF_LSD_SPEC_FILL", 0);
@@ -106,7 +106,7 @@ static void line_tune_init(LineTune *t)
     t->slow_factor = tune_env_f("PLF_LSD_SLOW_FACTOR", 10.f);
     t->slow_floor_ms = tune_env_f("PLF_LSD_SLOW_FLOOR_MS", 20.f);
     { const int v = tune_env_i("PLF_LSD_SPEC_RECCAP", 8192); t->spec_reccap = (v >= 1 && v <= 8192) ? v : 8192; }
-    t->wpg = std::max(1, std::min(16, tune_env_i("PLF_LSD_WPG", 8)));
+    t->wpg = getenv("PLF_LSD_WPG") ? std::max(1, std::min(16, tune_env_i("PLF_LSD_WPG", 8))) : PLF_TUNE_AUTO;
     t->nfa_fused = tune_env_i("PLF_NFA_FUSED", 64);
     t->nfa_table = tune_env_i("PLF_NFA_TABLE", 1);
     t->nfa_small = tune_env_i("PLF_NFA_SMALL", 2);
@@ -454,7 +454,7 @@ extern "C" int plf_line_tune(plf_line *h, const char *name, double value)
             if (!strcmp(name, "spec_rounds") && (v < 1 || v > 64)) return PLF_E_BADARG;
             if (!strcmp(name, "spec_reccap") && (v < 1 || v > 8192)) return PLF_E_BADARG;
             if (!strcmp(name, "spec_spins") && v < 64) return PLF_E_BADARG;
-            if (!strcmp(name, "wpg") && (v < 1 || v > 16)) return PLF_E_BADARG;
+            if (!strcmp(name, "wpg") && v != PLF_TUNE_AUTO && (v < 1 || v > 16)) return PLF_E_BADARG;
             if (!strcmp(name, "spec_bands") && v != PLF_TUNE_AUTO && (v < 0 || v > 64)) return PLF_E_BADARG;   // (0 / 1: speculation off; the call clamps to what the frame allows)
             if ((!strcmp(name, "nfa_small") && (v < 0 || v > 2)) || ((!strcmp(name, "nfa_table") || !strcmp(name, "nfa_two_pass") || !strcmp(name, "balance")) && (v < 0 || v > 1)))
                 return PLF_E_BADARG;
@@ -477,6 +477,11 @@ extern "C" void plf_line_destroy(plf_line *h)
     free(h);
 }
 
+// Frames (= waves) per workgroup of k_lsd_regions2.  With 8 per workgroup a batch of 512 frames is 64 workgroups: a quarter of the CUs run eight chains each while
+// the rest idle.  Round 6 (tools/midrange_sweep.sh, the step of bench.py --batch N): 512 frames in flight 11.0 k -> 12.9 k frames/s with 2 per workgroup, 1024:
+// 21.6 k -> 22.4 k with 4; from 2048 on the launch fills the chip either way and 8 keeps the LDS of a CU for the co-running tiles.
+static int line_wpg(const LineTune &T, int B) { return T.wpg != PLF_TUNE_AUTO ? T.wpg : (B <= 768 ? 2 : B <= 1536 ? 4 : 8); }
+
 static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pitch, ptrdiff_t fstride, plf_keyline *d_lines, uint8_t *d_ldesc,
                         double *d_eq, int *d_nout, int capacity, hipStream_t s)
 {
@@ -496,7 +501,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     if (balance) {
         // (here, in front of the Sobel kernel, not in front of k_lsd_regions2: the region kernel must follow its predecessor back to back -- in the 30 us of a small
         // kernel the ORB tiles of the step, released by ev_front, took the CUs first and the region stage went from 68 to 110 ms inside bench.py)
-        const int wpg = h->tune.wpg;
+        const int wpg = line_wpg(h->tune, B);
         PLF_HIP_TRY(hipMemsetAsync(d_perm, 0xFF, (size_t)((B + wpg - 1) / wpg) * wpg * sizeof(int), s));   // (-1: wave slots past the batch)
         hipLaunchKernelGGL(k_lsd_balance, dim3((B + 255) / 256), dim3(256), 0, s, d_cost, d_perm, B, wpg);
     }
@@ -533,7 +538,10 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // measured on one MI355X (VGA, frames/s with 16 / 8 / 4 / 2 bands): 8 frames 448 / 378 / 291 / 197; 32: 1277 / 1252 / 1079 / 679; 128: 3392 / 4321 /
     // 4007 / 1511; 256: 3866 / 5713 / 6800 / 5381; 512: - / 7237 / 8352 / 8856 (serial kernel: 7220); at 1024 the batch itself hides the latency
     // of the one-wave-per-frame kernel (9.8k with 2 bands vs 11.9k)
-    const int spec_bands_req = T.spec_bands != PLF_TUNE_AUTO ? T.spec_bands : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 16 : B <= 160 ? 8 : B <= 384 ? 4 : 2);   // round 3 (validation rounds, fast commit): 48 / 32 bands up to 8 / 16 frames   // (24 vs 16 bands at 1-8 frames: 13.2 vs 13.8 ms single frame, 510 vs 500 frames/s at 8)
+    // Round 6 (tools/midrange_sweep2.sh): with the validation rounds up to 256 frames in flight (spec_z) the best band count keeps frames x bands around 768-2048 --
+    // a little above the 512 band workgroups the chip holds at the validation's LDS size: 32 frames 3.2 k -> 4.0 k frames/s (24 bands), 64: 5.2 k -> 6.1 k (12), 128: 8.5 k
+    // -> 9.4 k (8), 256: 9.4 k -> 10.1 k (8); above 256 the one-wave-per-frame kernel with 2 frames per workgroup wins (line_wpg).
+    const int spec_bands_req = T.spec_bands != PLF_TUNE_AUTO ? T.spec_bands : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 24 : B <= 64 ? 12 : B <= 256 ? 8 : B <= 384 ? 4 : 2);
     const int spec_max = T.spec_max;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
@@ -674,7 +682,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         hipLaunchKernelGGL(budget ? k_lsd_regions_lat_budget : k_lsd_regions_lat, dim3(B), dim3(256), h->regions_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, status);
     else {   // 8 frames per workgroup (one wave each), 5120 + 1024 bytes of LDS per wave: see k_lsd_regions2 / regions_body
-        const int wpg = T.wpg;
+        const int wpg = line_wpg(T, B);
         const size_t wave_lds = PLF_LSD_WAVE_LDS;
         hipLaunchKernelGGL(budget ? k_lsd_regions2_budget : k_lsd_regions2, dim3((B + wpg - 1) / wpg), dim3(64 * wpg), wpg * wave_lds, s, h->d_ang, h->d_modgrad, h->d_cs, h->d_cs0, h->d_rxy,
                            h->d_rects, nrect, status, g, seeds, B, balance ? d_perm : nullptr);

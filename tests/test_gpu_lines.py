@@ -22,7 +22,7 @@ def _need_gpu():
 #   "rounds"     validation rounds (every band validates itself, all at once) until the fixpoint -- the default up to 16 frames;
 #   "one_round"  a single round, which rarely reaches the fixpoint: the serial commit wave then finishes the frame from the half-validated logs;
 #   "commit"     no rounds: the one-launch schedule with the serial commit wave (what more than 16 frames in flight take).
-SCHEDULES = pytest.mark.parametrize("schedule", ["rounds", "one_round", "commit", "fill"])
+SCHEDULES = pytest.mark.parametrize("schedule", ["rounds", "one_round", "commit", "two_launch", "fill"])
 
 
 def _set_schedule(monkeypatch, schedule):
@@ -30,6 +30,9 @@ def _set_schedule(monkeypatch, schedule):
         monkeypatch.setenv("PLF_LSD_SPEC_ROUNDS", "1")
     elif schedule == "commit":
         monkeypatch.setenv("PLF_LSD_SPEC_Z", "0")
+    elif schedule == "two_launch":   # band waves and serial commit wave as two launches (k_lsd_spec_grow + k_lsd_spec_commit): what batches beyond the fused
+        monkeypatch.setenv("PLF_LSD_SPEC_Z", "0")          # launch's residency limit take when the validation rounds are off (round 6: they are on up to 256 frames in flight)
+        monkeypatch.setenv("PLF_LSD_SPEC_NOFUSE", "1")
     elif schedule == "fill":       # validation rounds on the no-growth guess of the state above a band (PLF_LSD_SPEC_FILL, off by default)
         monkeypatch.setenv("PLF_LSD_SPEC_FILL", "8")
 

@@ -138,6 +138,37 @@ def test_hamming_properties_full_size():
     assert bool((dab[i, j] <= dab[i, k] + dbb[k, j]).all())
 
 
+@pytest.mark.parametrize("B", [24, 60, 100, 250, 300, 700, 1100])
+def test_mid_range_batches_line_schedules(B):
+    """Round 6 changed which schedule a mid-range batch of the line extractor takes: validation rounds up to 256 frames in flight (24 / 12 / 8 bands per frame for up
+    to 32 / 64 / 256 frames), above that the one-wave-per-frame kernel with 2 (up to 768 frames) or 4 (up to 1536) frames per workgroup.  One batch size inside every
+    range, 12 distinct frames of three families tiled to the batch (B is not a multiple of 12, of the frames per workgroup or of 64): the originals against the oracle,
+    every replica against its original."""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import LineSegment
+    from rgbd_pl_slam_amd.synth import synth_frame, texture_frame, natural_frame
+    R = 12
+    base = np.stack([synth_frame(3100 + r) if r % 3 == 0 else natural_frame(3100 + r) if r % 3 == 1 else texture_frame(7300 + r, size=(640, 480))[0] for r in range(R)])
+    refs = [orc.line_extract(im, 100) for im in base]
+    ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
+    d = torch.from_numpy(np.concatenate([base] * (B // R + 1))[:B]).cuda()
+    lines = torch.zeros((B, 100, 17), dtype=torch.float32, device="cuda"); ldesc = torch.zeros((B, 100, 32), dtype=torch.uint8, device="cuda")
+    leq = torch.zeros((B, 100, 3), dtype=torch.float64, device="cuda"); nl = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for rep in range(2):   # (second call: buffers re-used)
+        ls.extract_batch_device(d, 640, 480, lines, ldesc, leq, nl, 100, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ls.last_status() == 0
+        nlh = nl.cpu().numpy()
+        for f in range(R):
+            l = int(nlh[f]); rl = refs[f]
+            assert (nlh[f::R] == l).all()
+            assert bool((ldesc[f::R, :l] == ldesc[f, :l]).all()) and bool((lines[f::R, :l].view(torch.int32) == lines[f, :l].view(torch.int32)).all()), (B, f)
+            assert bool((leq[f::R, :l].view(torch.int64) == leq[f, :l].view(torch.int64)).all())
+            assert l == len(rl["kl"]) and np.array_equal(ldesc[f, :l].cpu().numpy(), rl["desc"]) and lines[f, :l].cpu().numpy().tobytes() == rl["kl"].tobytes(), (B, f)
+    ls.close()
+
+
 @pytest.mark.parametrize("w,h,B,R,nfeat,nlines,family", [(640, 480, 8192, 64, 1000, 100, "mixed"), (1280, 960, 2048, 16, 4000, 400, "mixed"),
                                                          (640, 480, 8192, 32, 1000, 100, "natural")])
 def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines, family):
