@@ -282,12 +282,18 @@ static int orb_configure(plf_orb *h, int w, int hh)
         const size_t sz_s = (size_t)g.lds_sp * maxRH + 16;
         // resize tables; the non-maximum suppression re-uses the area for its per-wave corner queues (128 uint16 each: k_orb_level phase 5)
         const size_t sz_t = std::max((size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16, (size_t)(PLF_ORB_LEVEL_THREADS / 64) * 256 + 16);
-        const size_t sz_list = (size_t)maxRW * maxRH * 2 + 16;   // FAST survivor list (aliases the staged source)
+#ifndef PLF_ORB_TILES_TARGET
+#define PLF_ORB_TILES_TARGET 5   // resident tiles per CU the staging passes are chosen for
+#endif
+#ifndef PLF_ORB_EXPERIMENT_LIST_DIV
+#define PLF_ORB_EXPERIMENT_LIST_DIV 1   // (occupancy experiments ONLY, tools/variant_build.sh: a list that cannot hold every pixel of the tile is unsafe on dense textures)
+#endif
+        const size_t sz_list = (size_t)maxRW * maxRH * 2 / PLF_ORB_EXPERIMENT_LIST_DIV + 16;   // FAST survivor list (aliases the staged source)
         size_t sz_a = 0;
         for (g.lds_parts = 1; g.lds_parts <= 4; g.lds_parts++) {
             sz_a = std::max((size_t)g.lds_spw * (maxSHp[g.lds_parts] + 1) + 16, sz_list);
             // five tiles per CU: 160 KB / 5 minus the 2064 static bytes (the NMS masks, round 6: one set for both passes); stop splitting when the survivor list is what is left
-            if (up16(sz_p) + up16(sz_a) + up16(sz_s) + up16(sz_t) <= 160 * 1024 / 5 - 2064 - 64 || sz_a == sz_list || g.lds_parts == 4) break;
+            if (up16(sz_p) + up16(sz_a) + up16(sz_s) + up16(sz_t) <= 160 * 1024 / PLF_ORB_TILES_TARGET - 2064 - 64 || sz_a == sz_list || g.lds_parts == 4) break;
         }
         g.lds_off_a = (int)up16(sz_p);
         g.lds_off_s = g.lds_off_a + (int)up16(sz_a);

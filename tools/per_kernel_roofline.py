@@ -34,7 +34,12 @@ TERMS = {   # kernel -> (SURVEY 8d term, bytes per frame)
 }
 def stats(path, steps):
     out = {}
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    # (the pipeline object runs one step of its own when it is built: the steps of a run = the launches of k_lsd_regions2, one per step, whatever --steps / --warmup said)
+    for r in rows:
+        if r["Name"].startswith("k_lsd_regions2("):
+            steps = int(r["Calls"])
+    for r in rows:
         n = r["Name"].split("(")[0]
         if n.startswith("k_"):
             out[n] = {"calls_per_step": float(r["Calls"]) / steps, "avg_ms": float(r["AverageNs"]) / 1e6, "per_step_ms": float(r["TotalDurationNs"]) / 1e6 / steps}
