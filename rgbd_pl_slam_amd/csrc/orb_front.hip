@@ -549,13 +549,18 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         cmL = (l4 & 1u) | ((l4 & 2u) << 15) | ((l4 & 4u) >> 1) | ((l4 & 8u) << 14);
         cmR = (r4 & 1u) | ((r4 & 2u) << 15) | ((r4 & 4u) >> 1) | ((r4 & 8u) << 14);
     }
-    auto pretest = [&](int t, uint32_t cells_on) {
+    // LIST holds half the pixels of the largest computed region (g.lds_list_cap entries, the host's arithmetic): enough for any HALF of a tile's rows.  A group whose
+    // slots would end past the capacity writes nothing -- the count still grows, and a pass that finds more survivors than the list holds redoes the tile in two row
+    // halves (fast_pass below; dense noise only).  The list is what decided the LDS of a tile: with all pixels (10 KB at VGA) 5 tiles fit a CU, with half of them 6 --
+    // ORB extractor 6.69 -> 6.36 ms per 1024 frames (tools/orb_ab_libs.sh r6occ6).
+    const int list_cap = g.lds_list_cap;
+    auto pretest = [&](int t, uint32_t cells_on, int rlo, int rhi) {   // rows [rlo, rhi) of the region
         const plf_s2v tt = {(short)t, (short)t};
         const int ymr = min(max(ym - ry0, 0), RH);   // first row of the lower cell row, relative to the region
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             const uint32_t cm = ((cells_on >> (2 * half)) & 1u ? cmL : 0u) | ((cells_on >> (2 * half + 1)) & 1u ? cmR : 0u);
-            const int r0 = half ? max(prA, ymr) : prA, r1 = half ? prB : min(prB, ymr);
+            const int r0 = max(half ? max(prA, ymr) : prA, rlo), r1 = min(half ? prB : min(prB, ymr), rhi);
             if (cm == 0u || r0 >= r1) continue;
             const uint8_t *prow = P + (ry0 + r0 - ey0) * PW + pc4;
             for (int ry = r0; ry < r1; ry++, prow += PW) {
@@ -581,6 +586,7 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(lds_nlist), "v"(__popc(poss)) : "memory");
                     const uint32_t e0 = (uint32_t)(pc4 | (ry << 8));
                     uint16_t *Lp = LIST + base;
+                    if (base + 4 > list_cap) continue;   // (no room for a whole group: nothing is written, the pass is redone in halves)
                     if (poss & 1u) Lp[0] = (uint16_t)e0;
                     if (poss & 2u) Lp[poss & 1u] = (uint16_t)(e0 + 2);
                     if (poss & 0x10000u) Lp[__popc(poss & 3u)] = (uint16_t)(e0 + 1);
@@ -686,39 +692,51 @@ __global__ void OF_OCC __launch_bounds__(OF_NT) k_orb_level(const uint8_t *__res
         }
     };
     const int ch = rc.w - 6;                         // rows of the cell's computed region
+    // one pass = pre-test, score, suppression at threshold t for the cells `on`.  More survivors than LIST holds (dense noise): the rows in two halves -- each fits by
+    // construction -- scored one after the other; the suppression needs every score, so it runs on the second half's list and then on the first half's, found again.
+    auto fast_pass = [&](int t, uint32_t on, int stop) -> bool {
+        pretest(t, on, 0, RH);
+        __syncthreads();
+        int nl = s_nlist;
+        if (stop == 4) return true;
+        if (nl + 4 <= list_cap) {   // (a group is refused when fewer than 4 slots are left: nl + 4 <= cap means none was)
+            score(nl);
+            __syncthreads();
+            if (stop == 5) return true;
+            nms(nl, t);
+            __syncthreads();
+            return stop == 6;
+        }
+        const int hr = (RH + 1) >> 1;
+        for (int step = 0; step < 3; step++) {   // rows [0, hr): score; rows [hr, RH): score + suppression; rows [0, hr) again: suppression
+            __syncthreads();   // (every thread has read the count)
+            if (tid == 0) s_nlist = 0;
+            __syncthreads();
+            pretest(t, on, step == 1 ? hr : 0, step == 1 ? RH : hr);
+            __syncthreads();
+            nl = s_nlist;
+            if (step < 2) { score(nl); __syncthreads(); }
+            if (step > 0) { nms(nl, t); __syncthreads(); }
+        }
+        return stop == 5 || stop == 6;
+    };
+#ifdef OF_STOP
+    constexpr int of_stop = OF_STOP;
+#else
+    constexpr int of_stop = 0;
+#endif
     // ---- pass A: iniThFAST, all cells
-    pretest(tini, 0xFu);
-    __syncthreads();
-#if defined(OF_STOP) && OF_STOP <= 4
-    return;
-#endif
-    int nl = s_nlist;
-    score(nl);
-    __syncthreads();
-#if defined(OF_STOP) && OF_STOP <= 5
-    return;
-#endif
-    nms(nl, tini);
-    __syncthreads();
-#if defined(OF_STOP) && OF_STOP <= 6
-    return;
-#endif
+    if (fast_pass(tini, 0xFu, of_stop)) return;
     if (ecell) {
         const unsigned long long my20 = lane < ch ? s_mask[wv][lane] : 0ull;
         if (__ballot(my20 != 0ull) != 0ull) emit(my20);
         else if (lane == 0) atomicOr(&s_need, 1 << wv);
     }
-    if (tid == 0) s_nlist = 0;   // (every thread read the count before the barrier above)
+    if (tid == 0) s_nlist = 0;   // (every thread read the count before the last barrier)
     __syncthreads();
     const uint32_t need = (uint32_t)s_need;
     if (need == 0u) return;
     // ---- pass B: minThFAST, the cells the first pass left empty
-    pretest(tmin, need);
-    __syncthreads();
-    nl = s_nlist;
-    score(nl);
-    __syncthreads();
-    nms(nl, tmin);
-    __syncthreads();
+    fast_pass(tmin, need, 0);
     if (ecell && ((need >> wv) & 1u)) emit(lane < ch ? s_mask[wv][lane] : 0ull);
 }

@@ -45,6 +45,7 @@ struct OrbGeom {
     uint32_t sel_stride;   // entries per frame
     // LDS layout of k_orb_level (bytes; maxima over the levels): pixel tile pitch, source tile pitch, score tile pitch, byte offsets
     int lds_pw, lds_spw, lds_sp, lds_eh, lds_off_a, lds_off_s, lds_off_list, lds_off_tab, lds_total;
+    int lds_list_cap;    // entries of the FAST survivor list: half the pixels of the largest computed region of a tile (k_orb_level redoes denser passes in two row halves)
     int lds_parts;       // the source rows of a tile are staged in this many passes (rows of the tile split evenly): bounds the staging buffer
     OrbLevel lv[PLF_MAX_LEVELS];
 };

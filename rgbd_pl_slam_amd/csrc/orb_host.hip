@@ -283,12 +283,12 @@ static int orb_configure(plf_orb *h, int w, int hh)
         // resize tables; the non-maximum suppression re-uses the area for its per-wave corner queues (128 uint16 each: k_orb_level phase 5)
         const size_t sz_t = std::max((size_t)(g.lds_pw + maxEH) * 8 + (size_t)(g.lds_pw / 4 + 1) * 2 + 16, (size_t)(PLF_ORB_LEVEL_THREADS / 64) * 256 + 16);
 #ifndef PLF_ORB_TILES_TARGET
-#define PLF_ORB_TILES_TARGET 5   // resident tiles per CU the staging passes are chosen for
+#define PLF_ORB_TILES_TARGET 6   // resident tiles per CU the staging passes are chosen for (round 6: 5 -> 6 with the halved survivor list)
 #endif
-#ifndef PLF_ORB_EXPERIMENT_LIST_DIV
-#define PLF_ORB_EXPERIMENT_LIST_DIV 1   // (occupancy experiments ONLY, tools/variant_build.sh: a list that cannot hold every pixel of the tile is unsafe on dense textures)
-#endif
-        const size_t sz_list = (size_t)maxRW * maxRH * 2 / PLF_ORB_EXPERIMENT_LIST_DIV + 16;   // FAST survivor list (aliases the staged source)
+        // FAST survivor list (aliases the staged source): half the pixels of the largest computed region, rounded up to whole rows + one group -- any half of a tile's
+        // rows fits; a pass with more survivors is redone in two row halves (k_orb_level: fast_pass)
+        g.lds_list_cap = maxRW * ((maxRH + 1) / 2) + 4;
+        const size_t sz_list = (size_t)g.lds_list_cap * 2 + 16;
         size_t sz_a = 0;
         for (g.lds_parts = 1; g.lds_parts <= 4; g.lds_parts++) {
             sz_a = std::max((size_t)g.lds_spw * (maxSHp[g.lds_parts] + 1) + 16, sz_list);
