@@ -1,5 +1,6 @@
 // lsd_geom.h -- geometry / constants of the line pipeline shared by host code and kernels.
 #pragma once
+#include <cstddef>
 #include <stdint.h>
 
 struct LsdRect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
@@ -57,6 +58,10 @@ struct LsdGeom {
 
 // banded speculative region growing: one record per effective seed of a band wave, and the buffers of both phases
 struct SpecRec { int seed, t0, nt, has_rect; int bx0, by0, bx1, by1; LsdRect rec; };   // b*: bounding box of the accepted pixels, dilated by one
+// (the band waves and the validation rounds write and read a record's header as two int4 words -- seed, t0, nt, has_rect | bx0, by0, bx1, by1 -- in front of rec)
+static_assert(offsetof(SpecRec, seed) == 0 && offsetof(SpecRec, t0) == 4 && offsetof(SpecRec, nt) == 8 && offsetof(SpecRec, has_rect) == 12, "SpecRec header word 0");
+static_assert(offsetof(SpecRec, bx0) == 16 && offsetof(SpecRec, by0) == 20 && offsetof(SpecRec, bx1) == 24 && offsetof(SpecRec, by1) == 28, "SpecRec header word 1");
+static_assert(offsetof(SpecRec, rec) >= 32 && sizeof(SpecRec) % 16 == 0 && alignof(SpecRec) <= 16, "SpecRec: the header is 32 bytes, records stay 16-byte aligned in their arrays");
 struct SpecBufs {
     uint32_t *rxy;      // [frame][band][s_stride] list overflow of the band waves
     uint32_t *tl;       // [frame][band][tcap] accepted pixels (bit 30: still marked at the end of the seed)
