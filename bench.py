@@ -291,6 +291,11 @@ def timed(pipe, steps, warmup, dist=None):
     return elapsed, reg_ms, reg_launches
 
 
+def _frame_fn(family):
+    from rgbd_pl_slam_amd.synth import synth_frame, natural_frame, photo_frame
+    return {"natural": natural_frame, "photo": photo_frame}.get(family, synth_frame)
+
+
 def single_frame_latency(device, w, h, nfeat, nlines, reps=20, family="polygons"):
     """one frame at a time through the host-memory entry points (ORBextractor::operator(), LineSegment::ExtractLineSegment): what a live
     SLAM loop sees"""
@@ -299,7 +304,7 @@ def single_frame_latency(device, w, h, nfeat, nlines, reps=20, family="polygons"
     from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
     orb = ORBextractor(nfeatures=nfeat, max_width=w, max_height=h, device=device)
     lin = LineSegment(nlines=nlines, max_width=w, max_height=h, device=device)
-    imgs = [(natural_frame if family == "natural" else synth_frame)(7000 + i, w, h) for i in range(4)]
+    imgs = [_frame_fn(family)(7000 + i, w, h) for i in range(4)]
     to, tl = [], []
     for i in range(reps + 3):
         t0 = time.perf_counter(); orb(imgs[i % 4]); t1 = time.perf_counter(); lin.ExtractLineSegment(imgs[i % 4]); t2 = time.perf_counter()
@@ -318,7 +323,7 @@ def tracking_call_latency(device, cfg, family="polygons", reps=30):
     W, H, NFEAT, NLINES, _, label = CONFIGS[cfg]
     from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
     p = Pipeline(W, H, NFEAT, NLINES, 1, device, 4321, defer_match=False, distinct=1, family=family)
-    frames = torch.from_numpy(np.stack([(natural_frame if family == "natural" else synth_frame)(7000 + i, W, H) for i in range(6)])).cuda()   # (the frames of single_frame_latency)
+    frames = torch.from_numpy(np.stack([_frame_fn(family)(7000 + i, W, H) for i in range(6)])).cuda()   # (the frames of single_frame_latency)
     for i in range(6):
         p.d_img[0].copy_(frames[i]); p.step()
     torch.cuda.synchronize()
@@ -601,7 +606,7 @@ def main():
     ap.add_argument("--no-front-wait", action="store_true", help="diagnostic: let ORB start together with the line front stages")
     ap.add_argument("--no-defer-match", action="store_true", help="diagnostic: enqueue the matchers of step k in step k (default: behind the line front stages of "
                     "step k+1, so that they run in the shadow of the next region-growing kernel; +2.7 %%)")
-    ap.add_argument("--family", default="polygons", choices=["polygons", "natural"], help="diagnostic: image family of the main step (the headline is quoted on the "
+    ap.add_argument("--family", default="polygons", choices=["polygons", "natural", "photo"], help="diagnostic: image family of the main step (the headline is quoted on the "
                     "polygon scenes of SURVEY 8d; the `natural` extras run the natural-image-like family in the same run)")
     ap.add_argument("--serial", action="store_true", help="diagnostic: everything on one stream (solo kernel durations under rocprofv3)")
     ap.add_argument("--pcie", action="store_true", help="time the PCIe-INCLUSIVE leg instead (plf_batch_extract: pinned host frames in, features + local-map matches "
@@ -693,6 +698,24 @@ def main():
             pn.close(); del pn
             nat["single_frame"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES, family="natural")
             out["natural"] = nat
+            # REAL photographs (tests/golden/real: seven CC0 / public-domain photographs; synth.photo_frame cuts VGA windows out of them at their native scale and
+            # extends them by reflection): no TUM frame exists here or on the GPU box, these are the real-camera input the image offers
+            rp = {"what": "the default step on windows of real photographs (tests/golden/real, CC0 / public domain: camera man, astronaut, coffee cup, cat, bricks, "
+                          "grass, gravel) instead of synthetic frames; same workload, same run"}
+            pn = Pipeline(W, H, NFEAT, NLINES, B, local_rank, 50_000, distinct=args.distinct, family="photo")
+            en, rn, nn = timed(pn, args.steps, args.warmup)
+            rp["in_flight_%d" % B] = {"value": round(B * args.steps / en, 2), "unit": "frames/s", "ms_per_step": round(1e3 * en / args.steps, 3),
+                                      "region_kernel_ms": round(rn / max(nn, 1), 3), "region_chain_length": pn.chain_stats(), "nfa_rectangles_per_frame": pn.rect_stats(),
+                                      "lines_kept_mean": pn.lines_kept(), "vs_polygons": round((B * args.steps / en) / fps, 3)}
+            pn.close(); del pn
+            pn = Pipeline(W, H, NFEAT, NLINES, 8, local_rank, 51_000, distinct=8, family="photo")
+            en, rn, nn = timed(pn, 30, 5)
+            rp["in_flight_8"] = {"value": round(8 * 30 / en, 1), "unit": "frames/s", "ms_per_step": round(1e3 * en / 30, 3), "region_stage_ms": round(rn / max(nn, 1), 3),
+                                 "lines_kept_mean": pn.lines_kept()}
+            pn.close(); del pn
+            rp["single_frame"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES, family="photo")
+            rp["tracking_call"] = tracking_call_latency(local_rank, 2, family="photo")
+            out["real_photos"] = rp
         if world == 1 and args.cpu_seconds > 0:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(float(args.cpu_seconds), cores, W, H, NFEAT, NLINES)

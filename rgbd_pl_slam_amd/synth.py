@@ -83,7 +83,9 @@ def synth_batch_parallel(seed0, n, w=640, h=480, workers=0, family="polygons"):
     if workers <= 0:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         workers = max(1, min(48, cores // 2, n // 8))
-    serial = natural_batch if family == "natural" else synth_batch
+    serial = natural_batch if family == "natural" else photo_batch if family == "photo" else synth_batch
+    if family == "photo":      # (a crop + a reflection: no worker processes needed)
+        return serial(seed0, n, w, h)
     if workers <= 1 or n < 16:
         return serial(seed0, n, w, h)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -179,8 +181,58 @@ def natural_frame(seed, w=640, h=480):
     return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
 
 
+_PHOTOS = None
+
+
+def photo_dir():
+    """tests/golden/real: the CC0 / public-domain photographs of tests/golden/make_real_photos.py (MANIFEST.json holds provenance and licences)"""
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real")
+
+
+def photos():
+    """the photographs as 8-bit gray images (colour ones through OpenCV's 8-bit RGB2GRAY arithmetic), in MANIFEST order; decoded by the in-tree PNG reader"""
+    global _PHOTOS
+    if _PHOTOS is None:
+        import json, os
+        from .png import read_png
+        d = photo_dir()
+        names = sorted(json.load(open(os.path.join(d, "MANIFEST.json"))))
+        out = []
+        for nme in names:
+            im = read_png(os.path.join(d, nme))
+            if im.ndim == 3:
+                c = im[:, :, :3].astype(np.uint32)
+                im = ((c[:, :, 0] * 4899 + c[:, :, 1] * 9617 + c[:, :, 2] * 1868 + 8192) >> 14).astype(np.uint8)
+            out.append(np.ascontiguousarray(im))
+        _PHOTOS = out
+    return _PHOTOS
+
+
+def photo_frame(seed, w=640, h=480):
+    """A frame cut out of a REAL photograph (family "photo"; VERDICT r05: every configuration had only seen synthetic stand-ins): photograph seed % 7, mirrored or
+    not, a random window of it at its native scale -- no resampling -- extended to w x h by reflection where the photograph is smaller (512 x 512, 600 x 400 and
+    451 x 300 pixels: reflection keeps the statistics of the texture and adds no edge).  Frames of neighbouring seeds from one photograph overlap the way the frames
+    of a video do."""
+    rng = np.random.default_rng(77000 + seed)
+    ph = photos()
+    g = ph[seed % len(ph)]
+    if rng.random() < 0.5:
+        g = g[:, ::-1]
+    H, W = g.shape
+    ch, cw = min(h, H), min(w, W)
+    y0 = int(rng.integers(0, H - ch + 1)); x0 = int(rng.integers(0, W - cw + 1))
+    c = g[y0:y0 + ch, x0:x0 + cw]
+    pt = int(rng.integers(0, h - ch + 1)); pl = int(rng.integers(0, w - cw + 1))
+    return np.ascontiguousarray(np.pad(c, ((pt, h - ch - pt), (pl, w - cw - pl)), mode="reflect"))
+
+
+def photo_batch(seed0, n, w=640, h=480):
+    return np.stack([photo_frame(seed0 + i, w, h) for i in range(n)])
+
+
 if __name__ == "__main__":      # worker of synth_batch_parallel: seed0 n w h out.npy [family]
     import sys
     _s0, _n, _w, _h = (int(x) for x in sys.argv[1:5])
     _fam = sys.argv[6] if len(sys.argv) > 6 else "polygons"
-    np.save(sys.argv[5], natural_batch(_s0, _n, _w, _h) if _fam == "natural" else synth_batch(_s0, _n, _w, _h))
+    np.save(sys.argv[5], natural_batch(_s0, _n, _w, _h) if _fam == "natural" else photo_batch(_s0, _n, _w, _h) if _fam == "photo" else synth_batch(_s0, _n, _w, _h))

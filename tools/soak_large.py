@@ -1,5 +1,5 @@
 """Large batches through the one-wave-per-frame region kernel (k_lsd_regions2: eight chains per SIMD, 768-entry list head in LDS): N mixed frames (texture
-families + polygon scenes + natural-image-like frames) in ONE call, every frame against the oracle byte for byte.
+families + polygon scenes + natural-image-like frames + windows of the real photographs of tests/golden/real) in ONE call, every frame against the oracle byte for byte.
     python tools/soak_large.py [first_seed=0] [N=3000]"""
 import sys, os
 from concurrent.futures import ThreadPoolExecutor
@@ -8,12 +8,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import orc
 from rgbd_pl_slam_amd import LineSegment
-from rgbd_pl_slam_amd.synth import texture_frame, synth_frame, natural_frame
+from rgbd_pl_slam_amd.synth import texture_frame, synth_frame, natural_frame, photo_frame
 
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 pool = ThreadPoolExecutor(min(64, os.cpu_count() or 8))
-imgs = list(pool.map(lambda s: natural_frame(seed0 + s) if s % 4 == 3 else texture_frame(seed0 + s, size=(640, 480))[0] if s % 3 else synth_frame(seed0 + s), range(N)))
+imgs = list(pool.map(lambda s: photo_frame(seed0 + s) if s % 5 == 4 else natural_frame(seed0 + s) if s % 4 == 3 else texture_frame(seed0 + s, size=(640, 480))[0] if s % 3 else synth_frame(seed0 + s), range(N)))
 refs = list(pool.map(lambda im: orc.line_extract(im, 100), imgs))
 ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=N)
 bad = 0
