@@ -68,7 +68,8 @@ struct LineTune {
     int spec_bands;       // PLF_LSD_SPEC_BANDS   row bands of the speculative schedule (AUTO: 48 / 32 / 16 / 8 / 4 / 2 by frames in flight)
     int spec_max;         // PLF_LSD_SPEC_MAX     frames in flight up to which the speculative schedule is used (256; 0 = never)
     int spec_z;           // PLF_LSD_SPEC_Z       ... up to which the validation rounds replace the serial commit wave (256: round 6, mid-range batches)
-    int spec_rounds;      // PLF_LSD_SPEC_ROUNDS  validation rounds enqueued (12)
+    int spec_rounds;      // PLF_LSD_SPEC_ROUNDS  validation rounds enqueued (20; 12 until the real photographs of round 6: gravel, a coffee cup and one natural-image-like frame
+                          //                      needed 13-14 and fell back to the serial commit of the rest, +1.5 ms; an idle round costs ~4 us)
     int spec_halo;        // PLF_LSD_SPEC_HALO    warm-up rows above a band (AUTO: 4 with validation rounds, 16 otherwise)
     int spec_fill;        // PLF_LSD_SPEC_FILL    rows of the no-growth guess instead of warm-up growth (0 = off)
     float spec_fill_tol;  // PLF_LSD_SPEC_FILL_TOL
@@ -95,7 +96,7 @@ static void line_tune_init(LineTune *t)
     t->spec_bands = tune_env_i("PLF_LSD_SPEC_BANDS", PLF_TUNE_AUTO);
     t->spec_max = tune_env_i("PLF_LSD_SPEC_MAX", 256);
     t->spec_z = tune_env_i("PLF_LSD_SPEC_Z", 256);
-    t->spec_rounds = std::max(1, std::min(64, tune_env_i("PLF_LSD_SPEC_ROUNDS", 12)));
+    t->spec_rounds = std::max(1, std::min(64, tune_env_i("PLF_LSD_SPEC_ROUNDS", 20)));
     t->spec_halo = tune_env_i("PLF_LSD_SPEC_HALO", PLF_TUNE_AUTO);
     t->spec_fill = tune_env_i("PLF_LSD_SPEC_FILL", 0);
     t->spec_fill_tol = tune_env_f("PLF_LSD_SPEC_FILL_TOL", 11.25f);
@@ -657,7 +658,7 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (zmode) {
             // band waves (equal shares), then rounds in which every band validates itself against what the bands before it mark, all bands at once;
             // rectangles assembled from the bands' logs; frames that did not reach the fixpoint within the rounds are committed serially (exact either way)
-            const int rounds = T.spec_rounds;   // (3-8 rounds reach the fixpoint on the synthetic frames; a launch of a frame that has converged returns at once: ~15 us per idle round)
+            const int rounds = T.spec_rounds;   // (3-10 rounds reach the fixpoint on the synthetic frames, up to 14 on real photographs; a launch of a frame that has converged returns at once: ~4 us per idle round)
 #ifdef PLF_ROUND_LOG
             if (h->spec.round_log) PLF_HIP_TRY(hipMemsetAsync(h->spec.round_log, 0, (size_t)h->spec_slots * 64 * sizeof(int), s));
 #endif
