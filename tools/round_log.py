@@ -1,4 +1,4 @@
-"""Per-round anatomy of the validation rounds (few frames in flight): python tools/round_log.py <polygons|natural> [B=1] [calls=4]
+"""Per-round anatomy of the validation rounds (few frames in flight): python tools/round_log.py <polygons|natural|photo> [B=1] [calls=4]   (photo: PHOTO=k picks the photograph, 6 = gravel)
 Needs a -DPLF_ROUND_LOG library:  bash tools/variant_build.sh rl lsd_kernels.hip=-DPLF_ROUND_LOG line_host.hip=-DPLF_ROUND_LOG
                                   PLF_LIB_PATH=tools/scratch/libplf_rl.so PLF_LSD_ROUND_LOG=1 python tools/round_log.py natural 1"""
 import sys, os, ctypes as C
@@ -6,11 +6,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import rgbd_pl_slam_amd._lib as L
 from rgbd_pl_slam_amd import LineSegment
-from rgbd_pl_slam_amd.synth import synth_frame, natural_frame
+from rgbd_pl_slam_amd.synth import synth_frame, natural_frame, photo_frame
 fam = sys.argv[1] if len(sys.argv) > 1 else "polygons"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-gen = natural_frame if fam == "natural" else synth_frame
+gen = natural_frame if fam == "natural" else (lambda s: photo_frame(51000 + int(os.environ.get("PHOTO", "6")) + 7 * (s % 2))) if fam == "photo" else synth_frame
 ls = LineSegment(nlines=100, max_width=640, max_height=480, max_batch=B)
 lib = L.lib()
 lib.plf_line_debug_round_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
