@@ -542,7 +542,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
     // Round 6 (tools/midrange_sweep2.sh): with the validation rounds up to 256 frames in flight (spec_z) the best band count keeps frames x bands around 768-2048 --
     // a little above the 512 band workgroups the chip holds at the validation's LDS size: 32 frames 3.2 k -> 4.0 k frames/s (24 bands), 64: 5.2 k -> 6.1 k (12), 128: 8.5 k
     // -> 9.4 k (8), 256: 9.4 k -> 10.1 k (8); above 256 the one-wave-per-frame kernel with 2 frames per workgroup wins (line_wpg).
-    const int spec_bands_req = T.spec_bands != PLF_TUNE_AUTO ? T.spec_bands : (B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 24 : B <= 64 ? 12 : B <= 256 ? 8 : B <= 384 ? 4 : 2);
+    // One frame in flight: 64 bands (tools/experiments/r06/bands_one_frame.py: LSD+LBD call, mean over 24 polygon scenes / 16 natural-image-like frames / 14 windows of real
+    // photographs, 48 -> 64 bands: 3.94 -> 3.89, 7.47 -> 7.20, 10.98 -> 10.35 ms; from two frames on the two are equal within the noise).
+    const int spec_bands_req = T.spec_bands != PLF_TUNE_AUTO ? T.spec_bands : (B <= 1 ? 64 : B <= 8 ? 48 : B <= 16 ? 32 : B <= 32 ? 24 : B <= 64 ? 12 : B <= 256 ? 8 : B <= 384 ? 4 : 2);
     const int spec_max = T.spec_max;
     const int bm_words = (g.sw * g.sh + 31) / 32, list_words = (g.rcap + 1 + 15) & ~15;
     const int coarse_words = (((((g.sw + 7) >> 3) + 31) & ~31) >> 5) * ((g.sh + 7) >> 3);   // tile rows padded to whole words (spec_commit_body)
