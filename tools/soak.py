@@ -21,6 +21,13 @@ SEED0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 
 
 def make_image(seed):
+    if seed % 5 == 4:      # a window of one of the real photographs of tests/golden/real: VGA, or a random size (reflection where the photograph is smaller)
+        from rgbd_pl_slam_amd.synth import photo_frame
+        rng = np.random.default_rng(55 + seed)
+        if rng.random() < 0.5:
+            return photo_frame(seed), "photo"
+        w = int(rng.integers(240, 900)); h = int(rng.integers(max(200, w // 2 + 40), min(700, w) + 1))
+        return photo_frame(seed, w, h), "photo"
     return texture_frame(seed)
 
 
