@@ -227,6 +227,18 @@ def photo_frame(seed, w=640, h=480):
     return np.ascontiguousarray(np.pad(c, ((pt, h - ch - pt), (pl, w - cw - pl)), mode="reflect"))
 
 
+def photo_pan_rgb(name, n, w=640, h=480, step=6):
+    """n colour frames (file order R, G, B) of a camera PANNING over one of the colour photographs (astronaut.png, coffee.png, chelsea.png): the w x h window moves
+    `step` pixels per frame along the diagonal of the photograph extended by reflection -- consecutive frames overlap like those of a video"""
+    import os
+    from .png import read_png
+    im = read_png(os.path.join(photo_dir(), name))[:, :, :3]
+    H, W = im.shape[:2]
+    need_h, need_w = h + step * n, w + step * n
+    big = np.pad(im, ((0, max(0, need_h - H)), (0, max(0, need_w - W)), (0, 0)), mode="reflect")
+    return np.stack([np.ascontiguousarray(big[step * i:step * i + h, step * i:step * i + w]) for i in range(n)])
+
+
 def photo_batch(seed0, n, w=640, h=480):
     return np.stack([photo_frame(seed0 + i, w, h) for i in range(n)])
 
