@@ -563,20 +563,20 @@ def test_lines_nfa_schedules(knobs, B):
 
 def test_slow_frame_warning_outputs_complete():
     """PLF_W_SLOW: a host-output call that takes far longer per frame than the handle's recent calls returns the warning -- the outputs are
-    complete and exact -- and plf_line_last_status repeats it until the next call.  History of cheap frames (flat images: nothing to grow), then a frame of blocky
-    noise (thousands of tiny regions); the thresholds are lowered through plf_line_tune so that the test does not need a frame that takes seconds.  With
+    complete and exact -- and plf_line_last_status repeats it until the next call.  History of cheap frames (flat images: nothing to grow), then a window of the
+    gravel photograph (regions that cross many bands: 13 validation rounds); the thresholds are lowered through plf_line_tune so that the test does not need a frame that takes seconds.  With
     slow_factor = 0 the same frame passes silently; a different image size starts a new history."""
     _need_gpu()
     from rgbd_pl_slam_amd import LineSegment
     import rgbd_pl_slam_amd._lib as L
     ls = LineSegment(nlines=100, max_width=640, max_height=480)
-    ls.tune("slow_factor", 4.0); ls.tune("slow_floor_ms", 0.0)   # (4x: far above the jitter of a 1 ms call on a busy host, far below the ~20x of the noisy frame)
+    ls.tune("slow_factor", 4.0); ls.tune("slow_floor_ms", 0.0)   # (4x: far above the jitter of a 1.6 ms call on a busy host, far below the ~15x of the hard frame)
     flat = np.full((480, 640), 90, np.uint8)
     for _ in range(10):
         ls.ExtractLineSegment(flat)
         assert L.last_warning == 0
-    rng = np.random.default_rng(3)
-    noisy = (rng.integers(0, 256, (480, 640)) // 64 * 64).astype(np.uint8)
+    from rgbd_pl_slam_amd.synth import photo_frame
+    noisy = photo_frame(51006)      # a window of the gravel photograph: ~25 ms with one frame in flight, 15x a flat frame (profiles/r06_photo_latency.txt)
     ref = orc.line_extract(noisy, 100)
     kl, ld, eq = ls.ExtractLineSegment(noisy)
     assert L.last_warning == L.PLF_W_SLOW
