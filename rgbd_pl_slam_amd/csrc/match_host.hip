@@ -55,6 +55,7 @@ __global__ void k_lines_lastframe(const int *, const int *, int, const uint8_t *
 __global__ void k_lines_fuse_pick(const int *, const int *, const uint8_t *, int, int *, int *);
 __global__ void k_match_project_lines(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
 __global__ void k_match_project_lines_g(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
+__global__ void k_match_project_lines_w(const LineFrameDev *, MapLineDev, float, float, int *, int, int *, uint8_t *, int);
 __global__ void k_hamming_matrix(const uint8_t *, int, const uint8_t *, int, int *);
 
 struct plf_matcher {
@@ -175,6 +176,7 @@ extern "C" int plf_matcher_create(int32_t device, int32_t max_keypoints, int32_t
     (void)hipFuncSetAttribute((const void *)k_lf_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void *)k_match_project_lines_g, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_match_project_lines_w, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipGetLastError();  // the attribute call is advisory; never leave a sticky error behind for other HIP users
     *out = h;
     return PLF_OK;
@@ -796,7 +798,13 @@ extern "C" int plf_match_project_lines(plf_matcher *h, const plf_lineframe_view 
     // (PLF_MATCH_LINES_STAGE_MAX: test hook -- 0 forces the global-memory variant on small frames)
     const char *stage_env = getenv("PLF_MATCH_LINES_STAGE_MAX");
     const int stage_lines = stage_env ? atoi(stage_env) : 150 * 1024 / 56;
-    if (cap <= stage_lines)
+    // few frames in flight: one wave per map line, the key lines across the lanes (k_match_project_lines_w; PLF_MATCH_LINES_WAVE_MAX: test hook, 0 = never)
+    const char *wave_env = getenv("PLF_MATCH_LINES_WAVE_MAX");
+    const int wave_frames = wave_env ? atoi(wave_env) : 64;
+    if (cap <= stage_lines && n_frames <= wave_frames && cap <= 65536)
+        hipLaunchKernelGGL(k_match_project_lines_w, dim3(n_frames), dim3(1024), (size_t)cap * 56, s, h->d_lframes, M, th, nnratio, match_of_line,
+                           line_stride, nmatches, h->d_done, cap);
+    else if (cap <= stage_lines)
         hipLaunchKernelGGL(k_match_project_lines, dim3(n_frames), dim3(256), (size_t)cap * 56, s, h->d_lframes, M, th, nnratio, match_of_line,
                            line_stride, nmatches, h->d_done, cap);
     else

@@ -1461,6 +1461,109 @@ __global__ void __launch_bounds__(256) k_match_project_lines_g(const LineFrameDe
     match_project_lines_body<false>(frames, ML, th, nnratio, match_all, line_stride, nmatches, done_all, line_cap);
 }
 
+// Few frames in flight (the reference's own regime: one frame per TrackRGBD call): the same greedy assignment with one WAVE per map line and the frame's key lines
+// across its lanes -- the window test of 64 lines at once, the best / second-best candidate by two wave-wide minima of (distance << 16 | line): the reference's
+// loop `if (dist < best) {second = best; best = dist} else if (dist < second) second = dist` in ascending line order keeps exactly the lexicographic minimum and the
+// lexicographic minimum of the rest.  The thread-per-map-line kernel above walks all lines three times per round on every thread: 0.19-0.25 ms for 100 lines against
+// 500 map lines, all of it on the critical path of a single frame (the line matchers start when LSD + LBD are done); 16 waves per frame here.
+// Rounds, phases and barriers are those of match_project_lines_body: a map line is matched in the round in which it owns every free line of its window.
+__device__ __forceinline__ int wave_min_key(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__global__ void __launch_bounds__(1024) k_match_project_lines_w(const LineFrameDev *__restrict__ frames, MapLineDev ML, float th, float nnratio,
+                                                                int *__restrict__ match_all, int line_stride, int *__restrict__ nmatches,
+                                                                uint8_t *__restrict__ done_all, int line_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *claim = (int *)smem, *owner = claim + line_cap;
+    float4 *lg = reinterpret_cast<float4 *>(owner + line_cap);
+    uint4 *ld = reinterpret_cast<uint4 *>(lg + line_cap);
+    __shared__ int s_left, s_acc;
+    const int f = blockIdx.x, t = threadIdx.x, T = blockDim.x, lane = t & 63, wv = t >> 6, NW = T >> 6;
+    LineFrameDev F = frames[f];
+    if (F.n_dev) F.n = min(F.n, *F.n_dev);
+    int *match = match_all + (size_t)f * line_stride;
+    uint8_t *done = done_all + (size_t)f * ML.m;
+    const bool bFactor = th != 1.0f;
+    for (int k = t; k < F.n; k += T) {
+        claim[k] = match[k] < -2 ? -1 : match[k];
+        const plf_keyline kl = F.lines[k];
+        lg[k] = make_float4(kl.pt_x, kl.pt_y, kl.angle, __int_as_float(kl.octave));
+        const uint4 *dsrc = reinterpret_cast<const uint4 *>(F.desc + 32 * (size_t)k);
+        ld[2 * k] = dsrc[0]; ld[2 * k + 1] = dsrc[1];
+    }
+    if (t == 0) s_acc = 0;
+    for (int m = t; m < ML.m; m += T) done[m] = ML.in_view[m] ? 0 : 1;
+    __syncthreads();
+    const int nchunk = (F.n + 63) >> 6;
+    for (int round = 0; round <= ML.m; round++) {
+        for (int k = t; k < F.n; k += T) owner[k] = 0x7fffffff;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+        for (int m = wv; m < ML.m; m += NW) {
+            if (done[m]) continue;
+            const int lvl = ML.level[m];
+            float r = radius_by_viewing_cos(ML.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            const float mx1 = ML.x1[m], my1 = ML.y1[m], mx2 = ML.x2[m], my2 = ML.y2[m];
+            for (int c = 0; c < nchunk; c++) {
+                const int i = c * 64 + lane;
+                if (i < F.n && claim[i] == -1 && line_in_area4(lg[i], mx1, my1, mx2, my2, rad, lvl - 1, lvl)) atomicMin(&owner[i], m);
+            }
+        }
+        __syncthreads();
+        for (int m = wv; m < ML.m; m += NW) {
+            if (done[m]) continue;
+            const int lvl = ML.level[m];
+            float r = radius_by_viewing_cos(ML.view_cos[m]);
+            if (bFactor) r *= th;
+            const float rad = r * F.scale_factors[lvl];
+            const float mx1 = ML.x1[m], my1 = ML.y1[m], mx2 = ML.x2[m], my2 = ML.y2[m];
+            const uint4 d0 = reinterpret_cast<const uint4 *>(ML.desc + 32 * (size_t)m)[0], d1 = reinterpret_cast<const uint4 *>(ML.desc + 32 * (size_t)m)[1];
+            bool unsafe = false;
+            int k1 = 0x7fffffff, k2 = 0x7fffffff;      // this lane's two smallest keys (distance << 16 | line); its lines come in ascending order
+            for (int c = 0; c < nchunk; c++) {
+                const int i = c * 64 + lane;
+                const bool cand = i < F.n && claim[i] == -1 && line_in_area4(lg[i], mx1, my1, mx2, my2, rad, lvl - 1, lvl);
+                if (cand) {
+                    if (owner[i] != m) unsafe = true;
+                    const uint4 b0 = ld[2 * i], b1 = ld[2 * i + 1];
+                    const int dist = __popc(d0.x ^ b0.x) + __popc(d0.y ^ b0.y) + __popc(d0.z ^ b0.z) + __popc(d0.w ^ b0.w) + __popc(d1.x ^ b1.x) + __popc(d1.y ^ b1.y) +
+                                     __popc(d1.z ^ b1.z) + __popc(d1.w ^ b1.w);
+                    if (dist < 256) {                  // (a distance of 256 never enters the reference's `dist < 256` chain)
+                        const int key = (dist << 16) | i;
+                        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                    }
+                }
+            }
+            if (__ballot(unsafe)) { if (lane == 0) atomicAdd(&s_left, 1); continue; }
+            const int kb = wave_min_key(k1);
+            const int ks = wave_min_key(k1 == kb ? k2 : k1);
+            if (lane == 0) {
+                done[m] = 1;
+                if (kb != 0x7fffffff) {
+                    const int bestDist = kb >> 16, bestIdx = kb & 0xFFFF;
+                    const int bestLevel = __float_as_int(lg[bestIdx].w);
+                    const int bestDist2 = ks != 0x7fffffff ? ks >> 16 : 256, bestLevel2 = ks != 0x7fffffff ? __float_as_int(lg[ks & 0xFFFF].w) : -1;
+                    if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) {
+                        claim[bestIdx] = m;
+                        atomicAdd(&s_acc, 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    for (int k = t; k < F.n; k += T) match[k] = claim[k];
+    if (t == 0) nmatches[f] = s_acc;
+}
+
 __global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t *__restrict__ a, int na, const uint8_t *__restrict__ b, int nb,
                                                         int *__restrict__ dist)
 {

@@ -337,6 +337,52 @@ def test_line_projection_search_global_memory_variant(monkeypatch, force):
     m.close()
 
 
+@pytest.mark.parametrize("wave_max", ["64", "0"], ids=["wave_per_map_line", "thread_per_map_line"])
+def test_line_projection_search_wave_and_thread_kernels(monkeypatch, wave_max):
+    """Round 6: up to 64 frames per call the line projection search runs one wave per map line with the key lines across the lanes (k_match_project_lines_w); larger
+    batches keep the thread-per-map-line kernel.  Both on the same scenes (PLF_MATCH_LINES_WAVE_MAX is read per call): crowded windows (1500 map lines for ~250
+    lines: several rounds), descriptors duplicated so that best and second-best tie at distance 0 and at equal distances (the reference's first-come order), pre-set
+    matches, th = 1 and th != 1 -- and a call of 70 frames (always the thread kernel) next to one of 64."""
+    _need_gpu()
+    import torch
+    from rgbd_pl_slam_amd import Matcher
+    from rgbd_pl_slam_amd.synth import synth_frame, photo_frame
+    monkeypatch.setenv("PLF_MATCH_LINES_WAVE_MAX", wave_max)
+    scale = orc.orb_tables(1000, 1.2, 8)["scale"]
+    m = Matcher(max_lines=1024, max_mappoints=4096, max_batch=70)
+    rng = np.random.default_rng(8)
+    views, refs, keep = [], [], []
+    for k, (img, nl, M, th, nn) in enumerate([(synth_frame(70), 400, 1500, 3.0, 0.8), (photo_frame(9), 300, 1200, 1.0, 0.9), (synth_frame(71), 100, 500, 3.0, 0.8),
+                                             (photo_frame(11), 64, 300, 2.0, 0.7), (synth_frame(72), 65, 700, 3.0, 1.0)]):
+        a = orc.line_extract(img, nl)
+        kl, desc = a["kl"].copy(), a["desc"].copy()
+        n = len(kl)
+        assert n >= 40
+        # ties: every third line gets the descriptor of its predecessor (equal distances to every map line; when they share the octave the ratio test sees them)
+        desc[2::3] = desc[1::3][:len(desc[2::3])]
+        ml = matchgen.make_map_lines(kl, desc, M, 20 + k)
+        init = np.full(n, -1, np.int32); init[::7] = -2; init[3::11] = 5
+        ref_match, ref_n = orc.search_lines_by_projection(kl, desc, scale, ml, th, nn, init)
+        dkl = torch.from_numpy(np.frombuffer(np.ascontiguousarray(kl).tobytes(), np.uint8).copy()).cuda()
+        dld = _dev(desc); dsc = _dev(scale)
+        view = Matcher.lineframe_view(n, dkl, dld, dsc)
+        dml = {kk: _dev(v) for kk, v in ml.items()}
+        match = _dev(init); nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        m.SearchLinesByProjection([view], dml, th, nn, match, n, nm)
+        torch.cuda.synchronize()
+        assert int(nm[0]) == ref_n and np.array_equal(match.cpu().numpy(), ref_match), k
+        if k == 2:
+            keep = (view, dml, init, ref_match, ref_n, n, (dkl, dld, dsc))
+    assert keep[4] > 10
+    view, dml, init, ref_match, ref_n, n, _alive = keep
+    for B in (64, 70):      # 64: the wave kernel (unless forced off); 70: always the thread kernel
+        match = _dev(np.tile(init, (B, 1))); nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+        m.SearchLinesByProjection([view] * B, dml, 3.0, 0.8, match, n, nm)
+        torch.cuda.synchronize()
+        assert (nm.cpu().numpy() == ref_n).all() and (match.cpu().numpy() == ref_match[None]).all(), B
+    m.close()
+
+
 LINE_KF_SCENES = [
     # lines in keyframe 1 / 2, how many of keyframe 1's lines reappear in keyframe 2, bit flips, share with a MapLine (kf1, kf2), share with stereo, bOnlyStereo, MAD factor
     dict(s1=30, s2=31, n=120, keep=90, flips=12, ml1=0.3, ml2=0.3, st=0.7, only=0, f=0.1),
