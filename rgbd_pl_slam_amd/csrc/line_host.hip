@@ -634,8 +634,9 @@ static int line_enqueue(plf_line *h, const uint8_t *d_gray, int B, ptrdiff_t pit
         if (h->spec.fill_rows > 0) h->spec.halo_rows = 0;
         // rows below the band the warm-up regions may reach (< 0: unbounded).  Clipping shortens the band waves (2.79 -> 2.51 ms, one VGA frame) and lengthens the
         // validation rounds (2.08 -> 2.77 ms): it loses for one frame (6.0 vs 6.5 ms) and wins once a round lasts as long as the slowest band of several frames
-        // anyway (8 frames in flight: 977 -> 1014 frames/s)
-        h->spec.halo_clip = T.spec_clip != PLF_TUNE_AUTO ? T.spec_clip : (B >= 4 ? 16 : -1);
+        // anyway (8 frames in flight: 977 -> 1014 frames/s).  Round 6, with 64 bands for one frame and the refined validity rule: 16 rows for one frame too (polygons
+        // 3.89 -> 3.87 ms, natural-image-like 7.21 -> 7.03, real photographs 10.3 -> 9.9: tools/experiments/r06/halo_rows.py)
+        h->spec.halo_clip = T.spec_clip != PLF_TUNE_AUTO ? T.spec_clip : 16;
         // one launch while all its workgroups fit the chip at the commit wave's LDS size (2 per CU): the commit wave follows the bands as they
         // finish, and the bands are staggered for that; otherwise two launches with equal bands
         // ... and only while EVERY workgroup of the launch can be resident at the same time: the commit workgroups wait for band workgroups of the
