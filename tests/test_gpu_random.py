@@ -170,7 +170,7 @@ def test_mid_range_batches_line_schedules(B):
 
 
 @pytest.mark.parametrize("w,h,B,R,nfeat,nlines,family", [(640, 480, 8192, 64, 1000, 100, "mixed"), (1280, 960, 2048, 16, 4000, 400, "mixed"),
-                                                         (640, 480, 8192, 32, 1000, 100, "natural")])
+                                                         (640, 480, 8192, 32, 1000, 100, "natural"), (640, 480, 8192, 32, 1000, 100, "photo")])
 def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines, family):
     """The shapes the headline is quoted on: 8192 VGA frames in flight (the default of bench.py: eight region-growing chains per SIMD, the 64-register build of
     k_lsd_regions2) and 2048 frames of 1280x960 with 4000 ORB + 400 lines (BASELINE.md's configs[3] shape at bench scale), R independently seeded frames tiled to
@@ -185,6 +185,9 @@ def test_bench_size_batch_is_exact_and_deterministic(w, h, B, R, nfeat, nlines, 
     # ("natural": the natural-image-like family of bench.py's `natural` extras -- twice the region-growing chain, ten times the regions: VERDICT r04 item 2)
     if family == "natural":
         base = np.stack([natural_frame(1900 + r, w=w, h=h) for r in range(R)])
+    elif family == "photo":      # (windows of the real photographs of tests/golden/real: bench.py's `real_photos` block -- four or five windows of each photograph)
+        from rgbd_pl_slam_amd.synth import photo_frame
+        base = np.stack([photo_frame(50000 + r, w, h) for r in range(R)])
     else:
         base = np.stack([synth_frame(900 + r, w=w, h=h) if r % 3 else texture_frame(7000 + r, size=(w, h))[0] for r in range(R)])
     with ThreadPoolExecutor(16) as pool:
