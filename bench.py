@@ -425,7 +425,7 @@ def pcie_inclusive(device, w, h, nfeat, nlines, n_frames, in_flight, mp, ml, rep
             "what": "plf_batch_extract: %d host frames (pinned, %d distinct) -> key points, descriptors, lines and local-map matches in host memory, 1 GPU" % (n_frames, nd)}
 
 
-def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
+def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines, family="polygons", single_only=False):
     """The CPU oracle (a port of the reference algorithm, kind="port") timed on this host, built HERE with the reference's flags
     (-O3 -march=native, /root/reference CMakeLists.txt:14): (a) one frame at a time on one thread, as Examples/RGB-D/rgbd_tum.cc:98-116 times
     it -- median / p95 and the per-stage split; (a2) ORB and LSD on two threads (PL-SLAM family); (b) one frame per thread on all cores."""
@@ -443,7 +443,7 @@ def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
         L = orc.lib(); flags = "-O2 (the -O3 -march=native build failed on this host)"
     L.orc_frontend_throughput.restype = C.c_double
     L.orc_frontend_latency.restype = C.c_long
-    frames = np.stack([synth_frame(5000 + i, w, h) for i in range(16)])
+    frames = np.stack([_frame_fn(family)(5000 + i, w, h) for i in range(16)])
     r0 = orc.orb_extract(frames[0], nfeatures=nfeat)
     l0 = orc.line_extract(frames[0], nlines)
     mp = {k: np.ascontiguousarray(v) for k, v in matchgen.make_local_map(r0["kps"], r0["desc"], M_POINTS, 1, w=w, h=h).items()}
@@ -471,6 +471,9 @@ def cpu_baseline(seconds_target, threads, w, h, nfeat, nlines):
               "ms_mean": round(1e3 * float(per1.mean()), 2), "frames_per_s": round(1.0 / float(np.median(per1)), 2), "frames": n1, "warmup": 3,
               "stage_ms_per_frame": {nm: round(1e3 * float(st1[i]) / n1, 3) for i, nm in enumerate(names)},
               "orb_lsd_on_two_threads_ms_median": round(1e3 * float(np.median(per2)), 2), "two_thread_frames": n2}
+    if single_only:      # (the real_photos block: the port on the same kind of frames, one at a time)
+        single["kind"] = "port"; single["flags"] = flags; single["what"] = "the CPU port on 16 %dx%d frames of the family '%s', one at a time on one thread" % (w, h, family)
+        return single
 
     def run(n, t):
         chk = C.c_long(0)
@@ -715,6 +718,8 @@ def main():
             pn.close(); del pn
             rp["single_frame"] = single_frame_latency(local_rank, W, H, NFEAT, NLINES, family="photo")
             rp["tracking_call"] = tracking_call_latency(local_rank, 2, family="photo")
+            if args.cpu_seconds > 0:
+                rp["cpu_port_single_thread"] = cpu_baseline(min(8.0, float(args.cpu_seconds)), 1, W, H, NFEAT, NLINES, family="photo", single_only=True)
             out["real_photos"] = rp
         if world == 1 and args.cpu_seconds > 0:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
