@@ -2467,7 +2467,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
     const int nrec_band = cnt[0];
 #ifdef PLF_ROUND_LOG
     const unsigned long long rl_t0 = wall_clock64();
-    int rl_seeds = 0, rl_px = 0;
+    int rl_seeds = 0, rl_px = 0, rl_same = 0, rl_same_px = 0, rl_old_t0 = -1, rl_old_nt = 0, rl_b_only = 0, rl_b_small = 0;   // (same: regrown records that came out with the accepted list they had)
 #endif
     int r_lo = 0, p_lo = y0 * W;
     while (p_lo < p_end && !ovf_n) {
@@ -2584,6 +2584,9 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                 CBAR();
             }
             int gseed = -1;
+#ifdef PLF_ROUND_LOG
+            rl_old_t0 = -1;
+#endif
             if (pc >= 0) {
                 pos = pc + 1;
                 if (bm_get(T, pc)) continue;
@@ -2611,6 +2614,13 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                     if (__ballot(hit)) valid = false;
                 }
                 cur = rsu + 1; pos = seed + 1;
+#ifdef PLF_ROUND_LOG
+                if (!valid && true_eff) {   // why: an accepted pixel truly taken (a), or only pixels the speculation saw taken that are truly free (b)
+                    bool any_a = false;
+                    for (int i = lane; i < nt; i += 64) any_a |= bm_get(T, (int)(tl[t0 + i] & 0x3FFFFFFFu));
+                    if (!__ballot(any_a)) { rl_b_only++; if (nt < g.min_reg_size) rl_b_small++; }
+                }
+#endif
                 if (valid) {
                     if (tn_n + nt > SB.tcap || nrec_n + 1 > SB.rcap_rec) { ovf_n = true; break; }
                     for (int i = lane; i < nt; i += 64) {
@@ -2628,6 +2638,9 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                 for (int i = lane; i < nt; i += 64) { const uint32_t e = tl[t0 + i]; if (e & 0x40000000u) { const int q = (int)(e & 0x3FFFFFFFu); S.set(q); if (!bm_get(T, q)) dc_mark(Dc, q, W, ctx); } }
                 CBAR();
                 if (true_eff) gseed = seed;
+#ifdef PLF_ROUND_LOG
+                rl_old_t0 = t0; rl_old_nt = nt;
+#endif
                 rescan = true;
             }
             if (gseed >= 0) {   // grow on T; the result is a record of the new log
@@ -2657,6 +2670,11 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
                 if (okr) nrect_n++;
 #ifdef PLF_ROUND_LOG
                 rl_seeds++; rl_px += tn;
+                if (rl_old_t0 >= 0 && tn == rl_old_nt) {
+                    bool diff = false;
+                    for (int i = lane; i < tn; i += 64) diff |= tl2[i] != (tl[rl_old_t0 + i] & 0x3FFFFFFFu);
+                    if (!__ballot(diff)) { rl_same++; rl_same_px += tn; }
+                }
 #endif
                 tn_n += tn; nrec_n++;
                 CBAR();
@@ -2698,7 +2716,7 @@ __device__ __forceinline__ void spec_validate_body(int band, int f, float *__res
 #ifdef PLF_ROUND_LOG
     if (SB.round_log && lane == 0 && round >= 1 && round <= 16) {
         int *rl = SB.round_log + (fb * 16 + (round - 1)) * 4;
-        rl[0] = (int)(wall_clock64() - rl_t0); rl[1] = rl_seeds; rl[2] = rl_px; rl[3] = nrec_n - rl_seeds;
+        rl[0] = (int)(wall_clock64() - rl_t0); rl[1] = rl_seeds | (rl_same << 16); rl[2] = min(rl_px, 0xFFFF) | (min(rl_same_px, 0xFFFF) << 16); rl[3] = min(nrec_n - rl_seeds, 0xFFFF) | (min(rl_b_only, 255) << 16) | (min(rl_b_small, 255) << 24);
     }
 #endif
 }

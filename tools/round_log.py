@@ -21,7 +21,10 @@ for c in range(N):
     nb = lib.plf_line_debug_round_log(ls._h, L.vp(buf), B, L.vp(bt))
     if nb <= 0:
         print("no round log (library without -DPLF_ROUND_LOG or PLF_LSD_ROUND_LOG unset):", nb); break
-    rl = buf[:B * nb * 64].reshape(B, nb, 16, 4); bt = bt[:B * nb * 2].reshape(B, nb, 2)
+    rl = buf[:B * nb * 64].reshape(B, nb, 16, 4).copy(); bt = bt[:B * nb * 2].reshape(B, nb, 2)
+    same = (rl[:, :, :, 1] >> 16) & 0xFFFF; same_px = (rl[:, :, :, 2] >> 16) & 0xFFFF      # regrown records that came out with the accepted list they had
+    b_only = (rl[:, :, :, 3] >> 16) & 0xFF; b_small = (rl[:, :, :, 3] >> 24) & 0xFF  # invalid records none of whose accepted pixels is truly taken (only "seen taken, truly free" neighbours); of those, regions below the minimum size
+    rl[:, :, :, 1] &= 0xFFFF; rl[:, :, :, 2] &= 0xFFFF; rl[:, :, :, 3] &= 0xFFFF
     g = bt[:, :, 0] / 100.0
     print("%s call %d, %d frame(s) x %d bands: band waves us max %.0f mean %.0f (slowest band of each frame: %s), logged px %d" %
           (fam, c, B, nb, g.max(), g.mean(), " ".join("%.0f" % x for x in g.max(axis=1)), int(bt[:, :, 1].sum())))
@@ -35,9 +38,9 @@ for c in range(N):
         act = (rl[:, :, r, 0] > 0)
         if not act.any(): continue
         redo = rl[:, :, r, 1] > 0
-        print("   round %2d: bands that ran %3d, that regrew %3d | us max %.0f, mean of active %.0f | seeds regrown %d (max per band %d), pixels regrown %d (max per band %d), records standing %d" %
+        print("   round %2d: bands that ran %3d, that regrew %3d | us max %.0f, mean of active %.0f | seeds regrown %d (max per band %d), pixels regrown %d (max per band %d), records standing %d | regrown to the SAME list: %d seeds, %d pixels | invalid without a taken accepted pixel: %d (small regions: %d)" %
               (r + 1, int(act.sum()), int(redo.sum()), t.max(), t[act].mean(), int(rl[:, :, r, 1].sum()), int(rl[:, :, r, 1].max()), int(rl[:, :, r, 2].sum()),
-               int(rl[:, :, r, 2].max()), int(rl[:, :, r, 3].sum())))
+               int(rl[:, :, r, 2].max()), int(rl[:, :, r, 3].sum()), int(same[:, :, r].sum()), int(same_px[:, :, r].sum()), int(b_only[:, :, r].sum()), int(b_small[:, :, r].sum())))
     # what the round barriers cost: Jacobi rounds as launched (every round lasts as long as its slowest band of ANY frame) against the same passes under
     # dataflow synchronisation (band b starts round r when the bands b' < b of ITS frame are through round r - 1: that is all pre[b] depends on)
     t = rl[:, :, :, 0] / 100.0
