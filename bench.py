@@ -14,7 +14,8 @@ Workloads (--config, numbering = BASELINE.json configs[] counted from 1):
   4            configs[3]: 1280x960, 4000 ORB + 400 lines, batch 64 sharded over 8 GPUs = 8 frames in flight per GPU
 Frames are independent, so ranks shard the job with no collective (rgbd_pl_slam_amd.batch.shard = plf_batch_shard; weak scaling:
 every rank processes its own frames_in_flight).  Prints ONE JSON line on rank 0; at N = 1 the default config also carries the
-secondary figures (config 3 as specified, single-frame latency, PCIe-inclusive rate through the product's batch driver, CPU baseline).
+secondary figures (config 3 as specified, single-frame and tracking-call latency, frames/s against frames in flight, the same step on natural-image-like frames
+(`natural`) and on windows of REAL photographs (`real_photos`: tests/golden/real), PCIe-inclusive rate through the product's batch driver, CPU baseline).
 """
 import argparse
 import json
